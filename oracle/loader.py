@@ -1,0 +1,176 @@
+"""oracle/loader.py -- ctypes access to the CHECKERS (test infrastructure only).
+
+Loads
+  * oracle/_ref/libjpegdec_ref_scalar.so  -- the real reference, scalar integer path (parity oracle)
+  * oracle/_ref/libjpegdec_ref_sse2.so    -- the real reference, SSE2 build (CPU timing baseline)
+  * oracle/liboracle.so                   -- our C restatement (oracle/jpegdec_oracle.c)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Nothing here reads /root/reference at run time (the .so files are prebuilt by oracle/Makefile).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# pixel types / options: values are the reference's public constants (src/JPEGDEC.h:68-75,102-111)
+RGB565_LE, RGB565_BE, RGB8888, GRAY8 = 0, 1, 2, 3
+SCALE_HALF, SCALE_QUARTER, SCALE_EIGHTH = 2, 4, 8
+EXIF_THUMBNAIL, LUMA_ONLY, USES_DMA = 32, 64, 128
+
+BYTES_PER_PIXEL = {RGB565_LE: 2, RGB565_BE: 2, RGB8888: 4, GRAY8: 1}
+
+
+def digest(buf) -> str:
+    """Short content hash used for golden vectors (sha256, first 16 hex digits)."""
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(np.frombuffer(memoryview(buf), dtype=np.uint8))).hexdigest()[:16]
+
+
+def mcu_dims(subsample: int):
+    """MCU width/height in pixels for the reference's ucSubSample byte (jpeg.inl:5008-5046)."""
+    return {0x00: (8, 8), 0x11: (8, 8), 0x12: (8, 16), 0x21: (16, 8), 0x22: (16, 16)}[subsample]
+
+
+def scale_shift(options: int) -> int:
+    if options & SCALE_HALF:
+        return 1
+    if options & SCALE_QUARTER:
+        return 2
+    if options & SCALE_EIGHTH:
+        return 3
+    return 0
+
+
+class RefDecoder:
+    """The real reference (bitbank2/JPEGDEC) behind oracle/ref_shim.cpp."""
+
+    def __init__(self, simd: bool = False):
+        name = "libjpegdec_ref_sse2.so" if simd else "libjpegdec_ref_scalar.so"
+        path = os.path.join(HERE, "_ref", name)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (run `make -C oracle ref` where /root/reference exists)")
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.ref_is_simd.restype = C.c_int
+        L.ref_get_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+        L.ref_get_info.restype = C.c_int
+        L.ref_decode_cb.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_int), C.c_int, C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ref_decode_cb.restype = C.c_int
+        L.ref_decode_fb.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.ref_decode_fb.restype = C.c_int
+        L.ref_bench.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+        L.ref_bench.restype = C.c_double
+        assert bool(L.ref_is_simd()) == simd
+
+    def info(self, data: bytes):
+        arr = (C.c_int * 10)()
+        rc = self.lib.ref_get_info(data, len(data), arr)
+        keys = ["width", "height", "subsample", "bpp", "jpegtype", "orientation", "hasthumb",
+                "thumbw", "thumbh", "lasterror"]
+        d = dict(zip(keys, list(arr)))
+        d["ok"] = rc
+        return d
+
+    def decode_cb(self, data: bytes, pixel_type=RGB8888, options=0, max_mcus=0, xoff=0, yoff=0,
+                  crop=None, used_only=False, stop_after=0, want_log=False, canvas_shape=None):
+        """Callback-mode decode assembled into an MCU-padded canvas.
+
+        Returns dict(rc, canvas (rows x pitch_bytes uint8), n_calls, dma_reuse, last_error, log)."""
+        inf = self.info(data)
+        if not inf["ok"]:
+            return dict(rc=-1, canvas=None, n_calls=0, dma_reuse=0, last_error=inf["lasterror"], log=None)
+        mw, mh = mcu_dims(inf["subsample"])
+        sh = scale_shift(options) if inf["jpegtype"] == 0 else 3
+        pt = GRAY8 if (options & LUMA_ONLY and pixel_type < GRAY8) else pixel_type
+        bpp = BYTES_PER_PIXEL[pt]
+        if inf["subsample"] == 0 and pt == RGB8888:
+            bpp = 4  # reference reports 32 bpp but writes 16-bit pixels
+        cx = (inf["width"] + mw - 1) // mw
+        cy = (inf["height"] + mh - 1) // mh
+        if canvas_shape is None:
+            rows = cy * (mh >> sh) + yoff
+            cols = cx * (mw >> sh) + xoff
+            # strips may overhang the padded width when iMCUCount does not divide cx: add slack
+            cols += 2048
+        else:
+            rows, cols = canvas_shape
+        canvas = np.zeros((rows, cols * bpp), dtype=np.uint8)
+        maxlog = 1 << 16
+        log = (C.c_int * (6 * maxlog))() if want_log else None
+        n_calls = C.c_int(0)
+        dma = C.c_int(0)
+        err = C.c_int(0)
+        croparr = (C.c_int * 4)(*crop) if crop is not None else None
+        rc = self.lib.ref_decode_cb(data, len(data), pixel_type, options, max_mcus, xoff, yoff,
+                                    croparr, canvas.ctypes.data_as(C.c_void_p), cols * bpp, rows,
+                                    1 if used_only else 0, log, maxlog if want_log else 0, stop_after,
+                                    C.byref(n_calls), C.byref(dma), C.byref(err))
+        out_log = None
+        if want_log:
+            n = min(n_calls.value, maxlog)
+            out_log = np.frombuffer(log, dtype=np.int32)[: 6 * n].reshape(n, 6).copy()
+        return dict(rc=rc, canvas=canvas, n_calls=n_calls.value, dma_reuse=dma.value,
+                    last_error=err.value, log=out_log, info=inf, bpp=bpp, scale_shift=sh)
+
+    def decode_frame(self, data: bytes, pixel_type=RGB8888, options=0):
+        """Full frame (H>>s x W>>s pixels, tightly packed) assembled from the draw callbacks."""
+        r = self.decode_cb(data, pixel_type, options, used_only=False)
+        if r["rc"] != 1:
+            return r["rc"], None
+        inf, sh, bpp = r["info"], r["scale_shift"], r["bpp"]
+        adj = (1 << sh) - 1
+        w = (inf["width"] + adj) >> sh
+        h = (inf["height"] + adj) >> sh
+        return 1, np.ascontiguousarray(r["canvas"][:h, : w * bpp])
+
+    def decode_fb(self, data: bytes, pixel_type=RGB8888, options=0):
+        """Framebuffer-mode decode; returns (rc, buffer rows_padded x (W*bpp))."""
+        inf = self.info(data)
+        if not inf["ok"]:
+            return -1, None
+        mw, mh = mcu_dims(inf["subsample"])
+        sh = scale_shift(options)
+        pt = GRAY8 if (options & LUMA_ONLY and pixel_type < GRAY8) else pixel_type
+        bpp = BYTES_PER_PIXEL[pt]
+        cy = (inf["height"] + mh - 1) // mh
+        rows = cy * mh + mh  # generous: reference overruns rows
+        fb = np.zeros((rows + 8, inf["width"] * bpp + 64), dtype=np.uint8).reshape(-1)
+        err = C.c_int(0)
+        rc = self.lib.ref_decode_fb(data, len(data), pixel_type, options,
+                                    fb.ctypes.data_as(C.c_void_p), C.byref(err))
+        return rc, fb
+
+    def bench(self, datas, pixel_type=RGB8888, options=0, reps=1, threads=1):
+        n = len(datas)
+        arr = (C.c_char_p * n)(*datas)
+        lens = (C.c_int * n)(*[len(d) for d in datas])
+        px = C.c_longlong(0)
+        fl = C.c_int(0)
+        secs = self.lib.ref_bench(arr, lens, n, pixel_type, options, reps, threads,
+                                  C.byref(px), C.byref(fl))
+        return dict(seconds=secs, pixels=px.value, failures=fl.value)
+
+
+def ref_available(simd=False) -> bool:
+    name = "libjpegdec_ref_sse2.so" if simd else "libjpegdec_ref_scalar.so"
+    return os.path.exists(os.path.join(HERE, "_ref", name))
+
+
+def load_c_array_header(path: str) -> bytes:
+    """Parse a `const uint8_t x[] = {0xff,0xd8,...};` C header into bytes (used only in the build
+    container, where the reference's own test_images/*.h exist; never on the GPU box)."""
+    txt = open(path, "r", errors="replace").read()
+    body = txt[txt.index("{") + 1: txt.rindex("}")]
+    body = re.sub(r"//[^\n]*", "", body)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    vals = re.findall(r"0[xX][0-9a-fA-F]+|\d+", body)
+    return bytes(int(v, 0) & 0xFF for v in vals)
