@@ -174,3 +174,121 @@ def load_c_array_header(path: str) -> bytes:
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     vals = re.findall(r"0[xX][0-9a-fA-F]+|\d+", body)
     return bytes(int(v, 0) & 0xFF for v in vals)
+
+
+class OracleDecoder:
+    """Our C restatement (oracle/jpegdec_oracle.c) -- the portable checker."""
+
+    def __init__(self):
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (run `make -C oracle liboracle.so`)")
+        self.lib = C.CDLL(path)
+        L = self.lib
+
+        class Info(C.Structure):
+            _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int), ("subsample", C.c_int),
+                        ("mode", C.c_int), ("restart_interval", C.c_int), ("quant_id", C.c_int * 4),
+                        ("dc_id", C.c_int * 4), ("ac_id", C.c_int * 4), ("scan_offset", C.c_int),
+                        ("error", C.c_int)]
+
+        self.Info = Info
+        L.orc_get_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(Info)]
+        L.orc_filter.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.orc_huff_tables.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_quant_tables.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.orc_entropy.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+        L.orc_block_pixels.argtypes = [C.c_void_p, C.c_uint16, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_block_pixels.restype = None
+        L.orc_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int)]
+        L.orc_draw_plan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_int]
+        L.orc_range_limit.restype = C.c_uint8
+        L.orc_range565.restype = C.c_uint16
+        L.orc_gray565.restype = C.c_uint16
+
+    def info(self, data: bytes):
+        inf = self.Info()
+        rc = self.lib.orc_get_info(data, len(data), C.byref(inf))
+        d = {k: getattr(inf, k) for k in ("width", "height", "ncomp", "subsample", "mode",
+                                           "restart_interval", "scan_offset", "error")}
+        d["quant_id"] = list(inf.quant_id)
+        d["dc_id"] = list(inf.dc_id)
+        d["ac_id"] = list(inf.ac_id)
+        d["ok"] = rc
+        return d
+
+    def filter(self, scan: bytes) -> bytes:
+        out = np.zeros(len(scan) + 16, dtype=np.uint8)
+        n = self.lib.orc_filter(scan, len(scan), out.ctypes.data_as(C.c_void_p))
+        return out[:n].tobytes()
+
+    def huff_tables(self, data: bytes):
+        dc = np.zeros(2 * 1024, dtype=np.uint8)
+        ac = np.zeros(2 * 2048, dtype=np.uint16)
+        rc = self.lib.orc_huff_tables(data, len(data), dc.ctypes.data_as(C.c_void_p),
+                                      ac.ctypes.data_as(C.c_void_p))
+        return rc, dc, ac
+
+    def quant_tables(self, data: bytes):
+        q = np.zeros((4, 64), dtype=np.int16)
+        rc = self.lib.orc_quant_tables(data, len(data), q.ctypes.data_as(C.c_void_p))
+        return rc, q
+
+    def canvas_geometry(self, data: bytes, pixel_type=RGB8888, options=0):
+        inf = self.info(data)
+        mw, mh = mcu_dims(inf["subsample"])
+        sh = scale_shift(options)
+        pt = GRAY8 if (options & LUMA_ONLY and pixel_type < GRAY8) else pixel_type
+        bpp = BYTES_PER_PIXEL[pt]
+        if inf["subsample"] == 0 and pt == RGB8888:
+            bpp = 2  # reference writes 16-bit pixels for gray JPEG + RGB8888 (SURVEY C.5)
+        cx = (inf["width"] + mw - 1) // mw
+        cy = (inf["height"] + mh - 1) // mh
+        return inf, cx, cy, mw >> sh, mh >> sh, bpp, sh
+
+    def entropy(self, data: bytes, options=0):
+        inf, cx, cy, mw, mh, bpp, sh = self.canvas_geometry(data, RGB8888, 0)
+        bpm = {0x00: 1, 0x11: 3, 0x22: 6, 0x12: 4, 0x21: 4}[inf["subsample"]]
+        if inf["ncomp"] == 1:
+            bpm = 1
+        nb = cx * cy * bpm
+        coefs = np.zeros((nb, 64), dtype=np.int16)
+        flags = np.zeros(nb, dtype=np.uint16)
+        state = np.zeros((cx * cy, 2), dtype=np.uint32)
+        dcp = np.zeros((cx * cy, 3), dtype=np.int32)
+        n = self.lib.orc_entropy(data, len(data), options, nb, coefs.ctypes.data_as(C.c_void_p),
+                                 flags.ctypes.data_as(C.c_void_p), state.ctypes.data_as(C.c_void_p),
+                                 dcp.ctypes.data_as(C.c_void_p))
+        return n, coefs, flags, state, dcp
+
+    def decode_canvas(self, data: bytes, pixel_type=RGB8888, options=0):
+        """MCU-padded canvas (cy*mh rows x cx*mw*bpp bytes)."""
+        inf, cx, cy, mw, mh, bpp, sh = self.canvas_geometry(data, pixel_type, options)
+        canvas = np.zeros((cy * mh, cx * mw * bpp), dtype=np.uint8)
+        err = C.c_int(0)
+        rc = self.lib.orc_decode(data, len(data), pixel_type, options, canvas.ctypes.data_as(C.c_void_p),
+                                 canvas.shape[1], canvas.shape[0], C.byref(err))
+        return rc, canvas, err.value
+
+    def decode_frame(self, data: bytes, pixel_type=RGB8888, options=0):
+        inf, cx, cy, mw, mh, bpp, sh = self.canvas_geometry(data, pixel_type, options)
+        rc, canvas, err = self.decode_canvas(data, pixel_type, options)
+        if rc != 1:
+            return rc, None
+        adj = (1 << sh) - 1
+        w = (inf["width"] + adj) >> sh
+        h = (inf["height"] + adj) >> sh
+        return 1, np.ascontiguousarray(canvas[:h, : w * bpp])
+
+    def draw_plan(self, data: bytes, pixel_type=RGB8888, options=0, max_mcus=0, uses_dma=False):
+        rects = np.zeros((1 << 16, 6), dtype=np.int32)
+        n = self.lib.orc_draw_plan(data, len(data), pixel_type, options, max_mcus, 1 if uses_dma else 0,
+                                   rects.ctypes.data_as(C.c_void_p), rects.shape[0])
+        return rects[: max(n, 0)].copy()
+
+
+def oracle_available() -> bool:
+    return os.path.exists(os.path.join(HERE, "liboracle.so"))
