@@ -1,0 +1,32 @@
+# Top-level build.  `make` builds everything that can be built where it runs:
+#   jpegdec_amd/libjpegdec_amd.so   the product: host front end + HIP runtime + gfx950 kernels (hipcc)
+#   oracle/liboracle.so             the checker (CPU restatement)            -- test infrastructure
+#   oracle/_ref/*.so                the real reference, if /root/reference is present -- test infrastructure
+#   tests/hostsim/libjda_hostsim.so wave emulator for CPU-only unit tests    -- test infrastructure
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX   ?= g++
+ARCH  ?= gfx950
+CSRC  = jpegdec_amd/csrc
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fwrapv -Wall -Wno-unused-function -Iinclude
+LIB = jpegdec_amd/libjpegdec_amd.so
+LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
+LIB_DEPS = $(LIB_SRCS) $(CSRC)/jda_internal.h $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h include/jpegdec_amd.h include/JPEGDEC.h
+
+all: lib oracle hostsim
+
+lib: $(LIB)
+$(LIB): $(LIB_DEPS)
+	$(HIPCC) $(HIPFLAGS) -o $@ $(LIB_SRCS)
+
+oracle:
+	$(MAKE) -C oracle all
+
+hostsim: tests/hostsim/libjda_hostsim.so
+tests/hostsim/libjda_hostsim.so: tests/hostsim/hostsim.cpp $(CSRC)/jda_frontend.cpp $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h $(CSRC)/jda_internal.h
+	$(CXX) -O2 -std=c++17 -fPIC -shared -fwrapv -Wall -Wno-unused-function -Wno-unknown-pragmas -Iinclude -o $@ tests/hostsim/hostsim.cpp $(CSRC)/jda_frontend.cpp
+
+clean:
+	rm -f $(LIB) tests/hostsim/libjda_hostsim.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle hostsim clean

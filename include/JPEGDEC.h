@@ -1,0 +1,119 @@
+// include/JPEGDEC.h -- the reference's public surface (bitbank2/JPEGDEC src/JPEGDEC.h), kept as the
+// API contract for the decode path, implemented on the MI355X-native C-ABI of jpegdec_amd.h.
+//
+// Names, argument meaning, constants and the return / error convention are the reference's
+// (src/JPEGDEC.h:68-75 options, :102-111 pixel types, :119-126 errors, :143-156 JPEGDRAW and the
+// draw callback, :249-287 class JPEGDEC); the state behind them is not: the reference keeps an
+// 18 KB JPEGIMAGE inside the object and streams the file 2 KiB at a time, this class keeps a
+// small handle and hands the whole image to the GPU.
+//
+// open*/decode return 1 = success, 0 = failure; getLastError() gives the code.
+#ifndef JPEGDEC_AMD_JPEGDEC_H
+#define JPEGDEC_AMD_JPEGDEC_H
+
+#include <stdint.h>
+
+// ---- decoder options (reference src/JPEGDEC.h:68-75)
+#define JPEG_AUTO_ROTATE 1        /* defined but never read by the reference either */
+#define JPEG_SCALE_HALF 2
+#define JPEG_SCALE_QUARTER 4
+#define JPEG_SCALE_EIGHTH 8
+#define JPEG_LE_PIXELS 16         /* defined but never read by the reference either */
+#define JPEG_EXIF_THUMBNAIL 32
+#define JPEG_LUMA_ONLY 64
+#define JPEG_USES_DMA 128
+
+#define MAX_BUFFERED_PIXELS 2048  /* size of the strip a draw callback receives, in uint16 units */
+
+enum { JPEG_MODE_BASELINE = 0, JPEG_MODE_PROGRESSIVE, JPEG_MODE_INVALID };
+
+enum {
+    RGB565_LITTLE_ENDIAN = 0,
+    RGB565_BIG_ENDIAN,
+    RGB8888,
+    EIGHT_BIT_GRAYSCALE,
+    FOUR_BIT_DITHERED,
+    TWO_BIT_DITHERED,
+    ONE_BIT_DITHERED,
+    INVALID_PIXEL_TYPE
+};
+
+enum {
+    JPEG_SUCCESS = 0,
+    JPEG_INVALID_PARAMETER,
+    JPEG_DECODE_ERROR,
+    JPEG_UNSUPPORTED_FEATURE,
+    JPEG_INVALID_FILE,
+    JPEG_ERROR_MEMORY,
+    JPEG_ERROR_NO_DEVICE,        /* extension: no usable MI355X / HIP runtime (there is no CPU fallback) */
+    JPEG_ERROR_HIP               /* extension: a HIP call failed */
+};
+
+typedef struct jpeg_file_tag {
+    int32_t iPos;
+    int32_t iSize;
+    uint8_t *pData;
+    void *fHandle;
+} JPEGFILE;
+
+typedef struct jpeg_draw_tag {
+    int x, y;                 // upper left corner of this block of pixels
+    int iWidth, iHeight;      // size of this block
+    int iWidthUsed;           // columns that lie inside the image
+    int iBpp;                 // 8, 16 or 32
+    uint16_t *pPixels;        // strip of iWidth x (MCU height) pixels, pitch = iWidth pixels
+    void *pUser;
+} JPEGDRAW;
+
+typedef int32_t(JPEG_READ_CALLBACK)(JPEGFILE *pFile, uint8_t *pBuf, int32_t iLen);
+typedef int32_t(JPEG_SEEK_CALLBACK)(JPEGFILE *pFile, int32_t iPosition);
+typedef int(JPEG_DRAW_CALLBACK)(JPEGDRAW *pDraw);
+typedef void *(JPEG_OPEN_CALLBACK)(const char *szFilename, int32_t *pFileSize);
+typedef void(JPEG_CLOSE_CALLBACK)(void *pHandle);
+
+#ifdef __cplusplus
+
+struct jpegdec_amd_state;   // private
+
+class JPEGDEC {
+  public:
+    JPEGDEC();
+    ~JPEGDEC();
+    JPEGDEC(const JPEGDEC &) = delete;
+    JPEGDEC &operator=(const JPEGDEC &) = delete;
+
+    int openRAM(uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw);
+    int openFLASH(const uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw);
+    int open(const char *szFilename, JPEG_OPEN_CALLBACK *pfnOpen, JPEG_CLOSE_CALLBACK *pfnClose,
+             JPEG_READ_CALLBACK *pfnRead, JPEG_SEEK_CALLBACK *pfnSeek, JPEG_DRAW_CALLBACK *pfnDraw);
+    int open(const char *szFilename, JPEG_DRAW_CALLBACK *pfnDraw);
+    int open(void *fHandle, int iDataSize, JPEG_CLOSE_CALLBACK *pfnClose, JPEG_READ_CALLBACK *pfnRead,
+             JPEG_SEEK_CALLBACK *pfnSeek, JPEG_DRAW_CALLBACK *pfnDraw);
+    void setFramebuffer(void *pFramebuffer);
+    void setCropArea(int x, int y, int w, int h);
+    void getCropArea(int *x, int *y, int *w, int *h);
+    void close();
+    int decode(int x, int y, int iOptions);
+    int decodeDither(uint8_t *pDither, int iOptions);
+    int decodeDither(int x, int y, uint8_t *pDither, int iOptions);
+    int getOrientation();
+    int getWidth();
+    int getHeight();
+    int getBpp();
+    void setUserPointer(void *p);
+    int getSubSample();
+    int getJPEGType();
+    int hasThumb();
+    int getThumbWidth();
+    int getThumbHeight();
+    int getLastError();
+    void setPixelType(int iType);
+    int getPixelType();
+    void setMaxOutputSize(int iMaxMCUs);
+
+  private:
+    jpegdec_amd_state *_jpeg;
+};
+
+#endif // __cplusplus
+#endif

@@ -1,0 +1,188 @@
+/* include/jpegdec_amd.h -- C-ABI of the MI355X-native baseline-JPEG decode path.
+ *
+ * This is the drop-in boundary for ONE hot path of bitbank2/JPEGDEC: the per-MCU loop of
+ * DecodeJPEG (reference src/jpeg.inl:5109-5353: JPEGDecodeMCU -> JPEGIDCT -> JPEGPutMCU*).
+ * Plain C types only: no C++, no exceptions, no torch types cross this boundary.  The reference
+ * API (openRAM/openFLASH/decode()/JPEG_DRAW_CALLBACK, include/JPEGDEC.h here) is implemented on
+ * top of these entry points; INTEGRATION.md shows the binding a maintainer of the reference
+ * would add at jpeg.inl:5109.
+ *
+ * Stages and the reference code each entry point replaces (paths relative to the reference):
+ *   jda_parse        host   JPEGParseInfo + JPEGGetSOS + JPEGGetHuffTables   src/jpeg.inl:1572-1785, 1378-1425, 837-873
+ *   jda_prepare      host   JPEGMakeHuffTables, JPEGFilter over the whole scan, JPEGFixQuantD and the serial
+ *                           entropy pre-scan (JPEGDecodeMCU in skip mode)    src/jpeg.inl:1066-1275, 1431-1540, 1789-1811, 2090-2274
+ *   jda_upload       H2D    (no reference equivalent: the reference streams 2 KiB at a time, :1544-1566)
+ *   jda_batch_decode GPU    the MCU loops of DecodeJPEG for every image of a batch   src/jpeg.inl:5109-5353
+ *                           = JPEGDecodeMCU :2090-2274, JPEGIDCT :2278-2798 (+ DC-only bypass :5146-5154),
+ *                             JPEGPutMCU8BitGray/Gray/11/22 :2799-4544, JPEGPixel* :3101-3278
+ *
+ * Conventions: functions returning int return JDA_SUCCESS (0) or one of the JDA_* error codes,
+ * whose values equal the reference's enum (src/JPEGDEC.h:119-126) so getLastError() can pass
+ * them through.  Every GPU entry point fails with JDA_ERROR_NO_DEVICE when no HIP device is
+ * usable -- there is no CPU fallback in this library.
+ */
+#ifndef JPEGDEC_AMD_H
+#define JPEGDEC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JDA_ABI_VERSION 1
+
+/* error codes: 0..5 are the reference's (src/JPEGDEC.h:119-126) */
+enum {
+    JDA_SUCCESS = 0,
+    JDA_INVALID_PARAMETER = 1,
+    JDA_DECODE_ERROR = 2,
+    JDA_UNSUPPORTED_FEATURE = 3,
+    JDA_INVALID_FILE = 4,
+    JDA_ERROR_MEMORY = 5,
+    JDA_ERROR_NO_DEVICE = 6,   /* no usable HIP device / runtime error (detail: jda_last_hip_error) */
+    JDA_ERROR_HIP = 7
+};
+
+/* pixel types: the reference's enum (src/JPEGDEC.h:102-111) */
+enum {
+    JDA_RGB565_LITTLE_ENDIAN = 0,
+    JDA_RGB565_BIG_ENDIAN = 1,
+    JDA_RGB8888 = 2,            /* memory order R,G,B,A as the reference's scalar path (jpeg.inl:3162-3175) */
+    JDA_EIGHT_BIT_GRAYSCALE = 3
+};
+
+/* decode options: the reference's bits (src/JPEGDEC.h:68-75) */
+enum {
+    JDA_SCALE_HALF = 2,
+    JDA_SCALE_QUARTER = 4,
+    JDA_SCALE_EIGHTH = 8,
+    JDA_LUMA_ONLY = 64
+};
+
+/* ------------------------------------------------------------------ host front end */
+
+typedef struct jda_image_info {
+    int32_t width, height;        /* SOF0 (jpeg.inl:1684-1685) */
+    int32_t ncomp;                /* 1 or 3 */
+    int32_t subsample;            /* reference ucSubSample: 0x00 gray, 0x11, 0x12, 0x21, 0x22 (jpeg.inl:1698-1713) */
+    int32_t bpp;                  /* bits per sample * ncomp (jpeg.inl:1687) */
+    int32_t jpeg_type;            /* 0 baseline, 1 progressive (src/JPEGDEC.h:94-99) */
+    int32_t restart_interval;     /* DRI (jpeg.inl:1715-1718) */
+    int32_t orientation;          /* EXIF tag 274 if present else 0 */
+    int32_t mcu_w, mcu_h;         /* MCU size in source pixels */
+    int32_t mcus_x, mcus_y;       /* MCU grid (jpeg.inl:5013-5037) */
+    int32_t scan_offset;          /* byte offset of the entropy-coded data */
+} jda_image_info;
+
+/* Header parse only.  Accept/reject rules follow JPEGParseInfo (jpeg.inl:1572-1785). */
+int jda_parse(const uint8_t *jpeg, int32_t len, jda_image_info *info);
+
+/* An image made ready for the GPU (host memory): expanded Huffman LUTs, prescaled quant tables,
+ * the filtered scan and the per-MCU index produced by the serial pre-scan. */
+typedef struct jda_image jda_image;
+
+/* Parse + table build + filter + pre-scan.  `options` are the JDA_SCALE_* / JDA_LUMA_ONLY bits the
+ * image will be decoded with (they do not change the index; they are validated here).
+ * Returns NULL on failure with *err set.  The JPEG buffer is not referenced after return. */
+jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
+void jda_image_free(jda_image *img);
+
+const jda_image_info *jda_image_get_info(const jda_image *img);
+/* views into the prepared image (owned by img): the filtered scan, the per-MCU index
+ * (n_mcus+1 entries: (byte position << 7) | bit offset, in the reference bit reader's
+ * coordinates (pBuf, ulBitOff) at each MCU start), and the DC predictors at each MCU start
+ * (n_mcus * ncomp int16).  *n_mcus_ok < mcus_x*mcus_y means the pre-scan hit an invalid code
+ * there (the reference returns JPEG_DECODE_ERROR at that MCU, jpeg.inl:2137, 2237, 5354-5356). */
+const uint8_t *jda_image_scan(const jda_image *img, uint32_t *len);
+const uint32_t *jda_image_mcu_index(const jda_image *img, uint32_t *n_mcus_ok);
+const int16_t *jda_image_mcu_dc(const jda_image *img);
+/* the table blob uploaded to the GPU: DC LUTs 2x1024 B, AC LUTs 2x2048 uint16, quant 4x64 int16 */
+const uint8_t *jda_image_tables(const jda_image *img, uint32_t *bytes);
+/* number of places where the reference's un-refilled magnitude read drops low bits
+ * (SURVEY.md fact 6); informational */
+uint32_t jda_image_truncation_events(const jda_image *img);
+
+/* Geometry of the decoded surface for (pixel_type, options): bytes per pixel, and the
+ * MCU-padded canvas size in output pixels (what the reference's draw callbacks tile). */
+int jda_output_geometry(const jda_image_info *info, int32_t pixel_type, int32_t options,
+                        int32_t *bytes_per_pixel, int32_t *out_w, int32_t *out_h,
+                        int32_t *canvas_w, int32_t *canvas_h);
+
+/* Draw-callback plan (jpeg.inl:5062-5084, 5300-5336): rects[6*i..] = x, y, iWidth, iHeight,
+ * iWidthUsed, iBpp of every JPEGDRAW the reference issues.  Returns the count (or -1). */
+int jda_draw_plan(const jda_image_info *info, int32_t pixel_type, int32_t options, int32_t max_mcus,
+                  int32_t uses_dma, int32_t *rects, int32_t max_rects);
+
+/* ------------------------------------------------------------------ device runtime */
+
+typedef struct jda_ctx jda_ctx;        /* one per process per GPU: device, stream, events */
+typedef struct jda_dev_image jda_dev_image; /* an image's inputs resident in HBM */
+typedef struct jda_batch jda_batch;    /* a launch plan over many resident images */
+
+int jda_device_count(void);
+jda_ctx *jda_create(int32_t device, int32_t *err);
+void jda_destroy(jda_ctx *ctx);
+const char *jda_last_hip_error(const jda_ctx *ctx);
+void *jda_stream(jda_ctx *ctx);        /* the hipStream_t every launch of this ctx goes to */
+
+/* device memory helpers (so callers need no HIP binding of their own) */
+void *jda_malloc(jda_ctx *ctx, size_t bytes);
+void jda_free(jda_ctx *ctx, void *dptr);
+int jda_memset(jda_ctx *ctx, void *dptr, int value, size_t bytes);
+int jda_copy_to_host(jda_ctx *ctx, void *host, const void *dptr, size_t bytes);   /* synchronous */
+int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes); /* synchronous */
+
+/* H2D: tables + index + filtered scan of one prepared image into one HBM allocation. */
+jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err);
+void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg);
+size_t jda_dev_image_bytes(const jda_dev_image *dimg);
+
+/* where one image of a batch is written */
+typedef struct jda_output {
+    void *pixels;            /* DEVICE pointer, 16-byte aligned */
+    int32_t pitch_bytes;     /* multiple of 16 */
+    int32_t width_px;        /* clip: pixels written per row (<= canvas_w) */
+    int32_t rows;            /* clip: rows written (<= canvas_h) */
+} jda_output;
+
+/* Build the launch plan for n resident images decoded with one (pixel_type, options) each. */
+jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *images,
+                            const jda_output *outputs, const int32_t *pixel_types,
+                            const int32_t *options, int32_t *err);
+void jda_batch_destroy(jda_ctx *ctx, jda_batch *batch);
+
+/* Enqueue the decode kernels for the whole batch on the ctx stream (asynchronous). */
+int jda_batch_decode(jda_ctx *ctx, jda_batch *batch);
+/* launch statistics of the plan */
+typedef struct jda_batch_stats {
+    int64_t source_pixels;      /* sum of width*height */
+    int64_t output_bytes;       /* bytes the kernels write */
+    int64_t scan_bytes;         /* filtered entropy-coded bytes read */
+    int64_t index_bytes;        /* per-MCU index + DC predictor bytes read */
+    int64_t table_bytes;
+    int32_t n_launches;         /* kernel launches per jda_batch_decode */
+    int32_t n_workgroups;
+} jda_batch_stats;
+int jda_batch_get_stats(const jda_batch *batch, jda_batch_stats *stats);
+
+int jda_sync(jda_ctx *ctx);
+
+/* HIP-event timing on the ctx stream: start/stop record events on that stream; elapsed blocks
+ * until stop has happened and returns milliseconds (<0 on error). */
+int jda_timer_start(jda_ctx *ctx);
+int jda_timer_stop(jda_ctx *ctx);
+double jda_timer_elapsed_ms(jda_ctx *ctx);
+
+/* One-call convenience used by the JPEGDEC class: prepare + upload + decode + copy back into a
+ * HOST canvas of canvas_w x canvas_h pixels (pitch_bytes per row). */
+int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
+                       int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows);
+
+const char *jda_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGDEC_AMD_H */

@@ -1,0 +1,28 @@
+"""jpegdec_amd -- MI355X-native baseline-JPEG decode path behind bitbank2/JPEGDEC's API.
+
+The product is the C-ABI shared library ``jpegdec_amd/libjpegdec_amd.so`` (host front end in
+C++, hand-written gfx950 HIP kernels; see include/jpegdec_amd.h).  This Python package is only a
+thin ctypes binding used by the tests and by bench.py -- there is no Python or CPU decode path:
+every decode call fails loudly when the HIP library or a GPU is missing.
+"""
+from .binding import (  # noqa: F401
+    GRAY8,
+    LUMA_ONLY,
+    RGB565_BE,
+    RGB565_LE,
+    RGB8888,
+    SCALE_EIGHTH,
+    SCALE_HALF,
+    SCALE_QUARTER,
+    Batch,
+    Context,
+    DeviceImage,
+    JdaError,
+    PreparedImage,
+    decode_to_host,
+    draw_plan,
+    library_path,
+    load_library,
+    output_geometry,
+    parse,
+)

@@ -1,0 +1,289 @@
+"""ctypes binding of include/jpegdec_amd.h (the C-ABI).  Plumbing only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+# constants = include/jpegdec_amd.h (= the reference's src/JPEGDEC.h values)
+RGB565_LE, RGB565_BE, RGB8888, GRAY8 = 0, 1, 2, 3
+SCALE_HALF, SCALE_QUARTER, SCALE_EIGHTH, LUMA_ONLY = 2, 4, 8, 64
+
+ERROR_NAMES = {0: "JDA_SUCCESS", 1: "JDA_INVALID_PARAMETER", 2: "JDA_DECODE_ERROR",
+               3: "JDA_UNSUPPORTED_FEATURE", 4: "JDA_INVALID_FILE", 5: "JDA_ERROR_MEMORY",
+               6: "JDA_ERROR_NO_DEVICE", 7: "JDA_ERROR_HIP"}
+
+
+class JdaError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__("%s (%d) %s" % (ERROR_NAMES.get(code, "?"), code, what))
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "ncomp", "subsample", "bpp", "jpeg_type", "restart_interval",
+        "orientation", "mcu_w", "mcu_h", "mcus_x", "mcus_y", "scan_offset")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Output(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("pitch_bytes", C.c_int32), ("width_px", C.c_int32),
+                ("rows", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("source_pixels", C.c_int64), ("output_bytes", C.c_int64), ("scan_bytes", C.c_int64),
+                ("index_bytes", C.c_int64), ("table_bytes", C.c_int64), ("n_launches", C.c_int32),
+                ("n_workgroups", C.c_int32)]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjpegdec_amd.so")
+
+
+_lib = None
+
+# every symbol include/jpegdec_amd.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_PROTOTYPES = [
+    ("jda_parse", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(ImageInfo)]),
+    ("jda_prepare", _P, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_image_free", None, [_P]),
+    ("jda_image_get_info", C.POINTER(ImageInfo), [_P]),
+    ("jda_image_scan", _P, [_P, C.POINTER(C.c_uint32)]),
+    ("jda_image_mcu_index", _P, [_P, C.POINTER(C.c_uint32)]),
+    ("jda_image_mcu_dc", _P, [_P]),
+    ("jda_image_tables", _P, [_P, C.POINTER(C.c_uint32)]),
+    ("jda_image_truncation_events", C.c_uint32, [_P]),
+    ("jda_output_geometry", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 5),
+    ("jda_draw_plan", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
+    ("jda_device_count", C.c_int, []),
+    ("jda_create", _P, [C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_destroy", None, [_P]),
+    ("jda_last_hip_error", C.c_char_p, [_P]),
+    ("jda_stream", _P, [_P]),
+    ("jda_malloc", _P, [_P, C.c_size_t]),
+    ("jda_free", None, [_P, _P]),
+    ("jda_memset", C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    ("jda_copy_to_host", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("jda_copy_to_device", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("jda_upload", _P, [_P, _P, C.POINTER(C.c_int32)]),
+    ("jda_dev_image_free", None, [_P, _P]),
+    ("jda_dev_image_bytes", C.c_size_t, [_P]),
+    ("jda_batch_create", _P, [_P, C.c_int32, C.POINTER(_P), C.POINTER(Output), C.POINTER(C.c_int32),
+                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("jda_batch_destroy", None, [_P, _P]),
+    ("jda_batch_decode", C.c_int, [_P, _P]),
+    ("jda_batch_get_stats", C.c_int, [_P, C.POINTER(BatchStats)]),
+    ("jda_sync", C.c_int, [_P]),
+    ("jda_timer_start", C.c_int, [_P]),
+    ("jda_timer_stop", C.c_int, [_P]),
+    ("jda_timer_elapsed_ms", C.c_double, [_P]),
+    ("jda_decode_to_host", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32]),
+    ("jda_version", C.c_char_p, []),
+]
+
+
+def load_library():
+    """Load libjpegdec_amd.so (built by `make lib` / __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s is missing: build it with `make lib` (hipcc --offload-arch=gfx950); "
+                                "jpegdec_amd has no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, res, args in _PROTOTYPES:
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def parse(jpeg: bytes) -> dict:
+    info = ImageInfo()
+    rc = load_library().jda_parse(jpeg, len(jpeg), C.byref(info))
+    d = info.as_dict()
+    d["status"] = rc
+    return d
+
+
+def output_geometry(info: ImageInfo, pixel_type=RGB8888, options=0):
+    vals = [C.c_int32(0) for _ in range(5)]
+    rc = load_library().jda_output_geometry(C.byref(info), pixel_type, options, *[C.byref(v) for v in vals])
+    if rc != 0:
+        raise JdaError(rc, "jda_output_geometry")
+    return dict(zip(("bpp", "out_w", "out_h", "canvas_w", "canvas_h"), [v.value for v in vals]))
+
+
+def draw_plan(info: ImageInfo, pixel_type=RGB8888, options=0, max_mcus=0, uses_dma=False):
+    rects = np.zeros((1 << 16, 6), dtype=np.int32)
+    n = load_library().jda_draw_plan(C.byref(info), pixel_type, options, max_mcus, 1 if uses_dma else 0,
+                                     rects.ctypes.data_as(_P), rects.shape[0])
+    return rects[: max(n, 0)].copy()
+
+
+class PreparedImage:
+    """Host-side result of parse + LUT build + scan filter + serial pre-scan (jda_prepare)."""
+
+    def __init__(self, jpeg: bytes):
+        self.lib = load_library()
+        err = C.c_int32(0)
+        self.handle = self.lib.jda_prepare(jpeg, len(jpeg), C.byref(err))
+        if not self.handle:
+            raise JdaError(err.value, "jda_prepare")
+        self.info = self.lib.jda_image_get_info(self.handle).contents
+
+    def close(self):
+        if self.handle:
+            self.lib.jda_image_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_mcus(self):
+        return self.info.mcus_x * self.info.mcus_y
+
+    def scan(self) -> np.ndarray:
+        n = C.c_uint32(0)
+        p = self.lib.jda_image_scan(self.handle, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+
+    def mcu_index(self):
+        n = C.c_uint32(0)
+        p = self.lib.jda_image_mcu_index(self.handle, C.byref(n))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(self.n_mcus + 1,)).copy()
+        return arr, n.value
+
+    def mcu_dc(self) -> np.ndarray:
+        p = self.lib.jda_image_mcu_dc(self.handle)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(self.n_mcus, self.info.ncomp)).copy()
+
+    def tables(self) -> np.ndarray:
+        n = C.c_uint32(0)
+        p = self.lib.jda_image_tables(self.handle, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+
+    def truncation_events(self) -> int:
+        return self.lib.jda_image_truncation_events(self.handle)
+
+    def geometry(self, pixel_type=RGB8888, options=0):
+        return output_geometry(self.info, pixel_type, options)
+
+
+class Context:
+    """One per process per GPU: HIP device + stream + timing events (jda_create)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        err = C.c_int32(0)
+        self.handle = self.lib.jda_create(device, C.byref(err))
+        if not self.handle:
+            raise JdaError(err.value, "jda_create(device=%d): no usable HIP device -- there is no CPU fallback" % device)
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            self.lib.jda_destroy(self.handle)
+            self.handle = None
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            raise JdaError(rc, what + ": " + (self.lib.jda_last_hip_error(self.handle) or b"").decode())
+
+    def malloc(self, nbytes: int) -> int:
+        p = self.lib.jda_malloc(self.handle, nbytes)
+        if not p:
+            raise JdaError(5, "jda_malloc(%d)" % nbytes)
+        return p
+
+    def free(self, ptr):
+        self.lib.jda_free(self.handle, ptr)
+
+    def memset(self, ptr, value, nbytes):
+        self.check(self.lib.jda_memset(self.handle, ptr, value, nbytes), "jda_memset")
+
+    def to_host(self, ptr, nbytes) -> np.ndarray:
+        out = np.empty(nbytes, dtype=np.uint8)
+        self.check(self.lib.jda_copy_to_host(self.handle, out.ctypes.data_as(_P), ptr, nbytes), "jda_copy_to_host")
+        return out
+
+    def sync(self):
+        self.check(self.lib.jda_sync(self.handle), "jda_sync")
+
+    def timer_start(self):
+        self.check(self.lib.jda_timer_start(self.handle), "jda_timer_start")
+
+    def timer_stop(self):
+        self.check(self.lib.jda_timer_stop(self.handle), "jda_timer_stop")
+
+    def timer_elapsed_ms(self) -> float:
+        return self.lib.jda_timer_elapsed_ms(self.handle)
+
+
+class DeviceImage:
+    """Inputs of one image resident in HBM (jda_upload)."""
+
+    def __init__(self, ctx: Context, prepared: PreparedImage):
+        self.ctx = ctx
+        err = C.c_int32(0)
+        self.handle = ctx.lib.jda_upload(ctx.handle, prepared.handle, C.byref(err))
+        if not self.handle:
+            raise JdaError(err.value, "jda_upload")
+        self.info = ImageInfo.from_buffer_copy(prepared.info)
+        self.nbytes = ctx.lib.jda_dev_image_bytes(self.handle)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.jda_dev_image_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+class Batch:
+    """Launch plan over resident images (jda_batch_create / jda_batch_decode)."""
+
+    def __init__(self, ctx: Context, images, outputs, pixel_types, options):
+        """outputs: list of (device_ptr, pitch_bytes, width_px, rows)."""
+        n = len(images)
+        self.ctx = ctx
+        himgs = (_P * n)(*[im.handle for im in images])
+        outs = (Output * n)(*[Output(*o) for o in outputs])
+        pts = (C.c_int32 * n)(*pixel_types)
+        opts = (C.c_int32 * n)(*options)
+        err = C.c_int32(0)
+        self.handle = ctx.lib.jda_batch_create(ctx.handle, n, himgs, outs, pts, opts, C.byref(err))
+        if not self.handle:
+            raise JdaError(err.value, "jda_batch_create: " + (ctx.lib.jda_last_hip_error(ctx.handle) or b"").decode())
+        st = BatchStats()
+        ctx.lib.jda_batch_get_stats(self.handle, C.byref(st))
+        self.stats = {k: getattr(st, k) for k, _ in BatchStats._fields_}
+
+    def decode(self):
+        self.ctx.check(self.ctx.lib.jda_batch_decode(self.ctx.handle, self.handle), "jda_batch_decode")
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.jda_batch_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+def decode_to_host(ctx: Context, jpeg: bytes, pixel_type=RGB8888, options=0):
+    """Decode one image through the GPU path into an MCU-padded host canvas (rows x pitch bytes)."""
+    info = ImageInfo()
+    rc = ctx.lib.jda_parse(jpeg, len(jpeg), C.byref(info))
+    if rc != 0:
+        raise JdaError(rc, "jda_parse")
+    g = output_geometry(info, pixel_type, options)
+    canvas = np.zeros((g["canvas_h"], g["canvas_w"] * g["bpp"]), dtype=np.uint8)
+    rc = ctx.lib.jda_decode_to_host(ctx.handle, jpeg, len(jpeg), pixel_type, options,
+                                    canvas.ctypes.data_as(_P), canvas.shape[1], canvas.shape[0])
+    return rc, canvas, g

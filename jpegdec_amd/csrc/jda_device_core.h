@@ -1,0 +1,488 @@
+// jda_device_core.h -- the per-lane decode logic of the HIP kernels.
+//
+// Everything here is written once and compiled twice: by hipcc into the gfx950 kernels of
+// jda_kernels.hip, and by g++ into tests/hostsim (a lane-by-lane CPU emulation of one wavefront
+// used ONLY by the unit tests to check the kernel logic where no GPU exists).  The product path
+// never runs this on the CPU.
+//
+// One wavefront decodes one "strip": up to 64 consecutive MCUs of one MCU row.
+//   phase A (lane = MCU, lane-private): for each block of the MCU
+//        Huffman/RLE expand into a lane-private 8x8 int16 block in LDS   <- JPEGDecodeMCU  jpeg.inl:2090-2274
+//        dequant + fixed-point IDCT + range limit -> 64 bytes in LDS     <- JPEGIDCT       jpeg.inl:2278-2798
+//                                                                           DC-only bypass jpeg.inl:5146-5154
+//   phase B (lanes tile the strip's output rows so that stores are coalesced)
+//        YCbCr -> RGB565/RGB8888/gray, chroma upsample, 1/2-1/4-1/8     <- JPEGPutMCU*    jpeg.inl:2799-4544
+//                                                                           JPEGPixel*     jpeg.inl:3101-3278
+// The bit reader reproduces the reference's 64-bit window and refill rule exactly, so that the
+// low-bit truncation of SURVEY.md fact 6 is reproduced by construction.
+#ifndef JDA_DEVICE_CORE_H
+#define JDA_DEVICE_CORE_H
+
+#include <stdint.h>
+
+#include "jda_internal.h"
+
+#if defined(__HIPCC__)
+#define JDA_HD __host__ __device__ __forceinline__
+#else
+#define JDA_HD static inline __attribute__((always_inline))
+#endif
+
+// ---- per-wave LDS layout -------------------------------------------------------------------
+#define JDA_COEF_STRIDE 136      // bytes per lane: 64 int16 + 8 pad (34 dwords: conflict-free b64 access)
+#define JDA_WAVE_LANES 64
+
+template <int MODE> struct jda_mode_traits;
+template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8 }; };
+template <> struct jda_mode_traits<JDA_MODE_444>  { enum { NLUMA = 1, NBLK = 3, MCU_W = 8, MCU_H = 8 }; };
+template <> struct jda_mode_traits<JDA_MODE_420>  { enum { NLUMA = 4, NBLK = 6, MCU_W = 16, MCU_H = 16 }; };
+
+template <int MODE> struct jda_lds_layout {
+    enum {
+        PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * 64 + 8,   // bytes per lane (pad 2 dwords)
+        COEF_OFF = 0,
+        PLANE_OFF = JDA_WAVE_LANES * JDA_COEF_STRIDE,
+        WAVE_BYTES = PLANE_OFF + JDA_WAVE_LANES * PLANE_STRIDE
+    };
+};
+
+// ---- small helpers ---------------------------------------------------------------------------
+JDA_HD uint32_t jda_alignbyte(uint32_t hi, uint32_t lo, uint32_t byte_shift)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, byte_shift);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (byte_shift & 3)));
+#endif
+}
+
+// sign-extended 10-bit field starting at bit `lo` (the reference's "& 0x3ff" table index)
+JDA_HD int32_t jda_sext10_at(int32_t v, int lo) { return (int32_t)((uint32_t)v << (22 - lo)) >> 22; }
+JDA_HD int32_t jda_clamp255(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// ucRangeTable[(v >> 5) & 0x3ff]  (jpeg.inl:159-222, 2786-2793)
+JDA_HD uint32_t jda_range_limit5(int32_t v) { return (uint32_t)jda_clamp255(jda_sext10_at(v, 5) + 128); }
+
+// 64-bit big-endian window at an arbitrary byte position (MOTOLONG, src/JPEGDEC.h:316-318),
+// assembled from three aligned dword loads.
+JDA_HD uint64_t jda_load_be64(const uint8_t *base, uint32_t pos)
+{
+    const uint32_t *p = (const uint32_t *)(base + (pos & ~3u));
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t sh = pos & 3u;
+    const uint32_t a = jda_alignbyte(w1, w0, sh);
+    const uint32_t b = jda_alignbyte(w2, w1, sh);
+    return ((uint64_t)__builtin_bswap32(a) << 32) | __builtin_bswap32(b);
+}
+
+struct jda_bitreader {
+    const uint8_t *base;
+    uint32_t pos;    // bb.pBuf - start of filtered scan
+    uint32_t off;    // bb.ulBitOff
+    uint64_t bits;   // bb.ulBits
+};
+
+JDA_HD void jda_refill(jda_bitreader &br)
+{
+    if (br.off > 47) {                                   // jpeg.inl:2110-2114 (REGISTER_WIDTH-17)
+        br.pos += br.off >> 3;
+        br.off &= 7;
+        br.bits = jda_load_be64(br.base, br.pos);
+    }
+}
+
+// EXTEND of the next s bits of the (un-refilled) window (jpeg.inl:2249-2252, 2155-2158)
+JDA_HD int32_t jda_take_extend(uint64_t bits, uint32_t off, uint32_t s)
+{
+    const uint32_t top = (uint32_t)((bits << off) >> 32);      // zeros enter when off + s > 64
+    const uint32_t v = top >> (32 - s);
+    return (top & 0x80000000u) ? (int32_t)v : (int32_t)v - (int32_t)((1u << s) - 1u);
+}
+
+// ---- Huffman / RLE expand of one 8x8 block (jpeg.inl:2090-2274) ------------------------------
+// LIMIT: 64 = store every coefficient, 5 = 1/4 and 1/8 scale (zigzag 1..4 only), 1 = skip block.
+// coef: lane-private int16[64] (natural order).  Returns the reference's u16MCUFlags.
+template <int LIMIT>
+JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const uint8_t *dc_lut, const uint16_t *ac_lut,
+                                 const uint8_t *zigzag, int16_t *coef, int32_t &pred)
+{
+    uint32_t flags = 0;
+    jda_refill(br);
+    if (LIMIT == 64) {
+        uint64_t *z = (uint64_t *)coef;                 // memset(pMCU, 0, 128)  :2121
+#pragma unroll
+        for (int i = 0; i < 16; i++) z[i] = 0;
+    } else if (LIMIT == 5) {
+        coef[1] = 0; coef[8] = 0; coef[9] = 0;          // :2118
+    }
+    // DC  (:2129-2165)
+    uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
+    code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
+    uint32_t e = dc_lut[code];
+    br.off += e >> 4;
+    const uint32_t s = e & 0xfu;
+    if (s) {
+        const int32_t folded = (int8_t)dc_lut[code + 512];
+        if (folded) pred += folded;
+        else {
+            jda_refill(br);
+            pred += jda_take_extend(br.bits, br.off, s);
+            br.off += s;
+        }
+    }
+    if (LIMIT > 1) coef[0] = (int16_t)pred;
+    // AC  (:2223-2265)
+    int k = 1;
+    while (k < 64) {
+        jda_refill(br);
+        code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
+        code = code >= 0xfc00u ? (code & 0x7ffu) : (code >> 6);
+        e = ac_lut[code];
+        br.off += e >> 8;
+        e &= 0xffu;
+        if (e == 0) break;                              // EOB (no refill follows)
+        k += (int)(e >> 4);
+        const uint32_t ms = e & 0xfu;
+        if (LIMIT > 1 && k < LIMIT && ms) {
+            const uint32_t n = zigzag[k];
+            flags |= (1u << (n & 7u)) | (n << 8);
+            coef[n] = (int16_t)jda_take_extend(br.bits, br.off, ms);
+        }
+        br.off += ms;
+        k++;
+        jda_refill(br);
+    }
+    return flags;
+}
+
+// ---- dequant + IDCT + range limit (jpeg.inl:2553-2797) ---------------------------------------
+// One 1-D pass of the reference's row stage on eight int32 inputs, block-level variant chosen by
+// the occupancy flags (jpeg.inl:2686-2743).  Returns the eight range-limited bytes packed LE.
+struct jda_row8 { uint32_t lo, hi; };
+
+JDA_HD jda_row8 jda_idct_row(const int32_t s[8], uint32_t flags)
+{
+    int32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    if ((flags & 0xf0u) == 0) {
+        if ((flags & 0xfcu) == 0) {                                  // :2688-2697
+            t0 = t1 = t2 = t3 = s[0];
+            t7 = s[1];
+            t6 = (t7 * 217) >> 8;
+            t5 = (t7 * 145) >> 8;
+            t4 = -((t7 * 51) >> 8);
+        } else {                                                     // :2698-2718
+            const int32_t a = s[0], c = s[2];
+            const int32_t m = (c * 106) >> 8;
+            t0 = a + c; t3 = a - c; t1 = a + m; t2 = a - m;
+            const int32_t z13 = s[3], z11 = s[1];
+            t7 = z11 + z13;
+            const int32_t t11 = ((z11 - z13) * 362) >> 8;
+            const int32_t z5 = ((z11 - z13) * 473) >> 8;
+            const int32_t t10 = ((z11 * 277) >> 8) - z5;
+            const int32_t t12 = ((z13 * 669) >> 8) + z5;
+            t6 = t12 - t7; t5 = t11 - t6; t4 = t10 + t5;
+        }
+    } else {                                                         // :2720-2743
+        const int32_t t10 = s[0] + s[4], t11 = s[0] - s[4];
+        const int32_t t13 = s[2] + s[6];
+        const int32_t t12 = (((s[2] - s[6]) * 362) >> 8) - t13;
+        t0 = t10 + t13; t3 = t10 - t13; t1 = t11 + t12; t2 = t11 - t12;
+        const int32_t z13 = s[5] + s[3], z10 = s[5] - s[3];
+        const int32_t z11 = s[1] + s[7], z12 = s[1] - s[7];
+        t7 = z11 + z13;
+        const int32_t u11 = ((z11 - z13) * 362) >> 8;
+        const int32_t z5 = ((z10 + z12) * 473) >> 8;
+        const int32_t u10 = ((z12 * 277) >> 8) - z5;
+        const int32_t u12 = ((z10 * -669) >> 8) + z5;
+        t6 = u12 - t7; t5 = u11 - t6; t4 = u10 + t5;
+    }
+    jda_row8 r;                                                      // :2786-2793
+    r.lo = jda_range_limit5(t0 + t7) | (jda_range_limit5(t1 + t6) << 8) |
+           (jda_range_limit5(t2 + t5) << 16) | (jda_range_limit5(t3 - t4) << 24);
+    r.hi = jda_range_limit5(t3 + t4) | (jda_range_limit5(t2 - t5) << 8) |
+           (jda_range_limit5(t1 - t6) << 16) | (jda_range_limit5(t0 - t7) << 24);
+    return r;
+}
+
+// Column stage for one column (jpeg.inl:2561-2676): c[r] = raw coefficient of row r, q[r] its
+// prescaled quantiser; results truncated to int16 as the reference stores them back.
+JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], bool rows47_empty, int32_t out[8])
+{
+    int32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    if (rows47_empty) {                                              // :2561-2601
+        const int32_t a = c[0] * q[0];
+        const int32_t b = c[2] * q[2];
+        const int32_t m = (b * 106) >> 8;
+        t0 = a + b; t3 = a - b; t1 = a + m; t2 = a - m;
+        t4 = c[1] * q[1];
+        if (c[3] != 0) {
+            const int32_t d = c[3] * q[3];
+            t7 = t4 + d;
+            const int32_t t11 = ((t4 - d) * 362) >> 8;
+            const int32_t z5 = ((t4 - d) * 473) >> 8;
+            const int32_t t12 = ((d * 669) >> 8) + z5;               // (-tmp5 * -669) >> 8
+            t6 = t12 - t7;
+            t5 = t11 - t6;
+            const int32_t t10 = ((t4 * 277) >> 8) - z5;
+            t4 = t10 + t5;
+        } else {
+            t7 = t4;
+            t5 = (145 * t4) >> 8;
+            t6 = (217 * t4) >> 8;
+            t4 = (-51 * t4) >> 8;
+        }
+    } else {                                                         // :2602-2676
+        // the reference's zero tests on rows 4..7 only skip work; the arithmetic is identical
+        const int32_t e0 = c[0] * q[0], e4 = c[4] * q[4];
+        const int32_t t10 = e0 + e4, t11 = e0 - e4;
+        const int32_t e2 = c[2] * q[2], e6 = c[6] * q[6];
+        const int32_t t13 = e2 + e6;
+        const int32_t t12 = (((e2 - e6) * 362) >> 8) - t13;
+        t0 = t10 + t13; t3 = t10 - t13; t1 = t11 + t12; t2 = t11 - t12;
+        const int32_t o3 = c[3] * q[3], o5 = c[5] * q[5];
+        const int32_t z13 = o5 + o3, z10 = o5 - o3;
+        const int32_t o1 = c[1] * q[1], o7 = c[7] * q[7];
+        const int32_t z11 = o1 + o7, z12 = o1 - o7;
+        t7 = z11 + z13;
+        const int32_t u11 = ((z11 - z13) * 362) >> 8;
+        const int32_t z5 = ((z10 + z12) * 473) >> 8;
+        const int32_t u12 = ((z10 * -669) >> 8) + z5;
+        t6 = u12 - t7;
+        t5 = u11 - t6;
+        const int32_t u10 = ((z12 * 277) >> 8) - z5;
+        t4 = u10 + t5;
+    }
+    out[0] = (int16_t)(t0 + t7); out[1] = (int16_t)(t1 + t6);
+    out[2] = (int16_t)(t2 + t5); out[3] = (int16_t)(t3 - t4);
+    out[4] = (int16_t)(t3 + t4); out[5] = (int16_t)(t2 - t5);
+    out[6] = (int16_t)(t1 - t6); out[7] = (int16_t)(t0 - t7);
+}
+
+// Full 8x8 block: coef (lane-private, natural order) -> 64 bytes written as 16 dwords to `out`.
+JDA_HD void jda_idct_block(const int16_t *coef, const int16_t *quant, uint32_t flags, uint32_t *out)
+{
+    int32_t ws[64];
+    const bool rows47_empty = (flags & 0x2000u) == 0;
+#pragma unroll
+    for (int col = 0; col < 8; col++) {
+        int32_t c[8], q[8], r[8];
+#pragma unroll
+        for (int row = 0; row < 8; row++) { c[row] = coef[row * 8 + col]; q[row] = quant[row * 8 + col]; }
+        jda_idct_col(c, q, rows47_empty, r);
+#pragma unroll
+        for (int row = 0; row < 8; row++) ws[row * 8 + col] = r[row];
+    }
+#pragma unroll
+    for (int row = 0; row < 8; row++) {
+        const jda_row8 p = jda_idct_row(&ws[row * 8], flags);
+        out[row * 2] = p.lo;
+        out[row * 2 + 1] = p.hi;
+    }
+}
+
+// 1/4 scale: 2x2 block from coefficients 0,1,8,9 (jpeg.inl:2305-2326) -> 4 bytes
+JDA_HD uint32_t jda_idct_2x2(const int16_t *coef, const int16_t *quant)
+{
+    const int32_t a = coef[0] * quant[0], b = coef[8] * quant[8];
+    const int32_t c = coef[1] * quant[1], d = coef[9] * quant[9];
+    const int32_t t0 = a + b, t2 = a - b, t1 = c + d, t3 = c - d;
+    return jda_range_limit5(t0 + t1) | (jda_range_limit5(t0 - t1) << 8) |
+           (jda_range_limit5(t2 + t3) << 16) | (jda_range_limit5(t2 - t3) << 24);
+}
+
+// ---- colour conversion (jpeg.inl:3101-3278) -------------------------------------------------
+struct jda_ycc { int32_t y; int32_t cb; int32_t cr; };   // y pre-scaled by 2^12 (or sum<<10)
+
+JDA_HD uint32_t jda_pixel_rgba(jda_ycc p)
+{
+    const int32_t cb = p.cb - 128, cr = p.cr - 128;
+    const int32_t r = jda_clamp255((5742 * cr + p.y) >> 12);
+    const int32_t g = jda_clamp255((-1409 * cb - 2925 * cr + p.y) >> 12);
+    const int32_t b = jda_clamp255((7258 * cb + p.y) >> 12);
+    return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xff000000u;
+}
+
+JDA_HD uint32_t jda_pixel_565(jda_ycc p, bool big_endian)
+{
+    const int32_t cb = p.cb - 128, cr = p.cr - 128;
+    // usRangeTableR/G/B[(x >> 12) & 0x3ff]: 10-bit wrap, then clamp
+    const int32_t r = jda_clamp255(jda_sext10_at(5742 * cr + p.y, 12));
+    const int32_t g = jda_clamp255(jda_sext10_at(-1409 * cb - 2925 * cr + p.y, 12));
+    const int32_t b = jda_clamp255(jda_sext10_at(7258 * cb + p.y, 12));
+    uint32_t v = (uint32_t)((r >> 3) << 11) | (uint32_t)((g >> 2) << 5) | (uint32_t)(b >> 3);
+    if (big_endian) v = ((v & 0xffu) << 8) | (v >> 8);
+    return v;
+}
+
+JDA_HD uint32_t jda_gray_565(uint32_t y, bool big_endian)
+{
+    uint32_t v = ((y >> 3) << 11) | ((y >> 2) << 5) | (y >> 3);     // usGrayTo565
+    if (big_endian) v = ((v & 0xffu) << 8) | (v >> 8);
+    return v;
+}
+
+// Sample fetch for output pixel (px,py) of one MCU's output tile, per subsampling mode and scale
+// shift.  planes: the MCU's blocks, 64 bytes each, block order Y.. Cb Cr.  `luma` = only the
+// luma value is wanted (GRAY8 output / gray JPEG): returned in .y UNscaled (0..255).
+template <int MODE>
+JDA_HD jda_ycc jda_fetch(const uint8_t *planes, uint32_t px, uint32_t py, int shift, bool luma)
+{
+    typedef jda_mode_traits<MODE> T;
+    jda_ycc o;
+    o.cb = 128; o.cr = 128;
+    const uint8_t *Y = planes;
+    uint32_t cidx = 0;                                  // index into the 8x8 chroma blocks
+    if (MODE == JDA_MODE_420) {
+        // which luma block, and the position inside it
+        const uint32_t bsz = 8u >> shift;               // block edge in output pixels: 8,4,2,1
+        const uint32_t q = (py / bsz) * 2 + (px / bsz);
+        Y = planes + 64 * q;
+        const uint32_t bx = px & (bsz - 1), by = py & (bsz - 1);
+        if (shift == 0) { o.y = Y[by * 8 + bx]; cidx = (py >> 1) * 8 + (px >> 1); }         // :4333-4543
+        else if (shift == 1) {                                                              // :3577-3626
+            const uint8_t *s = Y + by * 16 + bx * 2;
+            o.y = s[0] + s[1] + s[8] + s[9];
+            cidx = py * 8 + px;
+        } else if (shift == 2) { o.y = Y[by * 2 + bx]; cidx = q; }                          // :3664-3748
+        else { o.y = Y[0]; cidx = 0; }                                                      // :3627-3663
+        if (!luma) {
+            o.cb = planes[64 * 4 + cidx];
+            o.cr = planes[64 * 5 + cidx];
+            o.y = (shift == 1) ? (o.y << 10) : (o.y << 12);
+        } else if (shift == 1) o.y = (o.y + 2) >> 2;                                        // :2979-2999
+    } else {
+        if (shift == 0) { cidx = py * 8 + px; o.y = Y[cidx]; }
+        else if (shift == 1) {
+            cidx = py * 16 + px * 2;
+            o.y = Y[cidx] + Y[cidx + 1] + Y[cidx + 8] + Y[cidx + 9];
+        } else if (shift == 2) { cidx = py * 2 + px; o.y = Y[cidx]; }
+        else { cidx = 0; o.y = Y[0]; }
+        if (MODE == JDA_MODE_444 && !luma) {
+            const uint8_t *Cb = planes + 64, *Cr = planes + 128;
+            if (shift == 1) {                                                               // :3297-3322
+                o.cb = (Cb[cidx] + Cb[cidx + 1] + Cb[cidx + 8] + Cb[cidx + 9] + 2) >> 2;
+                o.cr = (Cr[cidx] + Cr[cidx + 1] + Cr[cidx + 8] + Cr[cidx + 9] + 2) >> 2;
+                o.y <<= 10;
+            } else { o.cb = Cb[cidx]; o.cr = Cr[cidx]; o.y <<= 12; }
+        } else if (shift == 1) o.y = (o.y + 2) >> 2;                                        // :2812-2827, 3043-3069
+        (void)T::NBLK;
+    }
+    return o;
+}
+
+// value of one output pixel in its final format
+template <int MODE>
+JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py, int shift, int pixel_type)
+{
+    if (pixel_type == JDA_EIGHT_BIT_GRAYSCALE) return (uint32_t)jda_fetch<MODE>(planes, px, py, shift, true).y;
+    if (MODE == JDA_MODE_GRAY)                     // gray JPEG -> RGB565 (JPEGPutMCUGray, :3037-3099)
+        return jda_gray_565((uint32_t)jda_fetch<MODE>(planes, px, py, shift, true).y, pixel_type != JDA_RGB565_LITTLE_ENDIAN);
+    const jda_ycc p = jda_fetch<MODE>(planes, px, py, shift, false);
+    if (pixel_type == JDA_RGB8888) return jda_pixel_rgba(p);
+    return jda_pixel_565(p, pixel_type == JDA_RGB565_BIG_ENDIAN);
+}
+
+// ---- phase A: one lane decodes one MCU into its LDS planes ----------------------------------
+template <int MODE>
+JDA_HD void jda_phase_a(const jda_dev_desc &D, const jda_strip &S, uint32_t lane,
+                        const uint8_t *tables, uint8_t *wave_lds)
+{
+    typedef jda_mode_traits<MODE> T;
+    typedef jda_lds_layout<MODE> L;
+    if (lane >= S.count) return;
+    const uint32_t mcu = S.mcu_y * D.mcus_x + S.mcu_x0 + lane;
+    if (mcu >= D.n_mcus_ok) return;
+    int16_t *coef = (int16_t *)(wave_lds + L::COEF_OFF + lane * JDA_COEF_STRIDE);
+    uint8_t *planes = wave_lds + L::PLANE_OFF + lane * L::PLANE_STRIDE;
+    const uint8_t *zigzag = tables + JDA_TB_ZIGZAG;
+
+    jda_bitreader br;
+    br.base = D.scan;
+    const uint32_t ix = D.mcu_index[mcu];
+    br.pos = ix >> JDA_INDEX_OFF_BITS;
+    br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
+    br.bits = jda_load_be64(br.base, br.pos);
+    int32_t pred[3];
+    pred[0] = D.mcu_dc[mcu * D.ncomp];
+    pred[1] = pred[2] = 0;
+    if (MODE != JDA_MODE_GRAY) { pred[1] = D.mcu_dc[mcu * 3 + 1]; pred[2] = D.mcu_dc[mcu * 3 + 2]; }
+
+    const int shift = D.scale_shift;
+    const int nblk = (MODE != JDA_MODE_GRAY && D.gray_from_color) ? T::NLUMA : T::NBLK;   // :5225-5233
+    for (int b = 0; b < nblk; b++) {
+        const int c = b < T::NLUMA ? 0 : b - T::NLUMA + 1;
+        const uint8_t *dcl = tables + JDA_TB_DC + D.dc_id[c] * 1024;
+        const uint16_t *acl = (const uint16_t *)(tables + JDA_TB_AC) + D.ac_id[c] * 2048;
+        const int16_t *quant = (const int16_t *)(tables + JDA_TB_QUANT) + D.q_id[c] * 64;
+        uint32_t *out = (uint32_t *)(planes + 64 * b);
+        int32_t &p = pred[c];
+        if (shift >= 2) {
+            const uint32_t flags = jda_decode_block<5>(br, dcl, acl, zigzag, coef, p);
+            if (flags == 0 || shift == 3) {                                   // :5146-5154 (iMaxFill = 1)
+                const uint32_t v = jda_range_limit5(p * (int32_t)quant[0]);
+                out[0] = v * 0x01010101u;
+            } else out[0] = jda_idct_2x2(coef, quant);
+        } else {
+            const uint32_t flags = jda_decode_block<64>(br, dcl, acl, zigzag, coef, p);
+            if (flags == 0) {                                                 // DC-only bypass
+                const uint32_t v = jda_range_limit5(p * (int32_t)quant[0]) * 0x01010101u;
+#pragma unroll
+                for (int i = 0; i < 16; i++) out[i] = v;
+            } else jda_idct_block(coef, quant, flags, out);
+        }
+    }
+}
+
+// ---- phase B: the wave's lanes tile the strip's output, 4 pixels per lane per step ----------
+template <int MODE>
+JDA_HD void jda_phase_b(const jda_dev_desc &D, const jda_strip &S, uint32_t lane, const uint8_t *wave_lds)
+{
+    typedef jda_mode_traits<MODE> T;
+    typedef jda_lds_layout<MODE> L;
+    const int shift = D.scale_shift;
+    const uint32_t mw = (uint32_t)T::MCU_W >> shift, mh = (uint32_t)T::MCU_H >> shift;   // MCU tile in output px
+    const int pt = D.pixel_type;
+    const uint32_t bpp = pt == JDA_RGB8888 ? 4u : (pt == JDA_EIGHT_BIT_GRAYSCALE ? 1u : 2u);
+    // MCUs actually decoded in this strip
+    uint32_t count = S.count;
+    const uint32_t first = S.mcu_y * D.mcus_x + S.mcu_x0;
+    if (first >= D.n_mcus_ok) return;
+    if (first + count > D.n_mcus_ok) count = D.n_mcus_ok - first;
+    const uint32_t tile_w = count * mw;                           // output pixels per row of the strip
+    const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
+    const uint32_t groups_per_row = (tile_w + 3) >> 2;
+    const uint32_t total = groups_per_row * mh;
+    for (uint32_t g = lane; g < total; g += JDA_WAVE_LANES) {
+        const uint32_t row = g / groups_per_row;
+        const uint32_t tx = (g - row * groups_per_row) * 4;       // x inside the strip tile
+        const uint32_t Y = y_base + row;
+        if (Y >= D.out_rows) continue;
+        const uint32_t X = x_base + tx;
+        if (X >= D.out_w) continue;
+        uint32_t v[4];
+        uint32_t n = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t x = tx + j;
+            v[j] = 0;
+            if (x < tile_w && X + j < D.out_w) {
+                const uint32_t m = x / mw;
+                const uint8_t *planes = wave_lds + L::PLANE_OFF + m * L::PLANE_STRIDE;
+                v[j] = jda_output_pixel<MODE>(planes, x - m * mw, row, shift, pt);
+                n = j + 1;
+            }
+        }
+        uint8_t *dst = D.out + (size_t)Y * D.out_pitch + (size_t)X * bpp;
+        if (bpp == 4) {
+            if (n == 4) { uint32_t *d = (uint32_t *)dst; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+            else for (uint32_t j = 0; j < n; j++) ((uint32_t *)dst)[j] = v[j];
+        } else if (bpp == 2) {
+            if (n == 4) { uint32_t *d = (uint32_t *)dst; d[0] = v[0] | (v[1] << 16); d[1] = v[2] | (v[3] << 16); }
+            else for (uint32_t j = 0; j < n; j++) ((uint16_t *)dst)[j] = (uint16_t)v[j];
+        } else {
+            if (n == 4) *(uint32_t *)dst = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            else for (uint32_t j = 0; j < n; j++) dst[j] = (uint8_t)v[j];
+        }
+    }
+}
+
+#endif // JDA_DEVICE_CORE_H

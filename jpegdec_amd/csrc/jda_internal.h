@@ -1,0 +1,52 @@
+// jda_internal.h -- structures shared by the host front end, the device runtime and the kernels.
+#ifndef JDA_INTERNAL_H
+#define JDA_INTERNAL_H
+
+#include <stdint.h>
+
+#include "../../include/jpegdec_amd.h"
+
+// ---- table blob uploaded per image (16-byte aligned, one contiguous copy into LDS) ----
+// layout mirrors what the reference keeps in JPEGIMAGE (src/JPEGDEC.h:235-238) so that the
+// kernels index the LUTs exactly like JPEGDecodeMCU does (jpeg.inl:2129-2136, 2231-2236).
+#define JDA_TB_DC        0        // 2 x 1024 bytes   (ucHuffDC)
+#define JDA_TB_AC        2048     // 2 x 2048 uint16  (usHuffAC)
+#define JDA_TB_QUANT     10240    // 4 x 64 int16     (sQuantTable after JPEGFixQuantD)
+#define JDA_TB_ZIGZAG    10752    // 64 bytes         (cZigZag2: zigzag position -> natural index)
+#define JDA_TABLE_BYTES  10816
+
+#define JDA_SCAN_PAD     32       // zero bytes after the filtered scan (window loads overrun)
+#define JDA_INDEX_OFF_BITS 7      // index entry = (byte position << 7) | bit offset (0..64)
+
+// kinds of MCU the kernels are specialised for
+enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2 };
+
+// ---- device-side descriptors ----
+struct jda_dev_desc {             // one per image of a batch, 96 bytes
+    const uint8_t *scan;          // filtered entropy-coded bytes (4-byte aligned, padded)
+    const uint32_t *mcu_index;    // n_mcus+1 entries
+    const int16_t *mcu_dc;        // n_mcus * ncomp
+    const uint8_t *tables;        // JDA_TABLE_BYTES
+    uint8_t *out;                 // output surface
+    uint32_t out_pitch;           // bytes
+    uint32_t out_w, out_rows;     // clip in output pixels / rows
+    uint32_t mcus_x, mcus_y;
+    uint32_t n_mcus_ok;           // MCUs the pre-scan validated (others are not decoded)
+    uint32_t scan_len;
+    uint8_t mode;                 // JDA_MODE_*
+    uint8_t ncomp;
+    uint8_t pixel_type;           // JDA_RGB565_* / RGB8888 / EIGHT_BIT_GRAYSCALE (after LUMA_ONLY folding)
+    uint8_t scale_shift;          // 0..3
+    uint8_t dc_id[3], ac_id[3], q_id[3];
+    uint8_t gray_from_color;      // colour JPEG decoded to GRAY8: chroma blocks are not decoded
+    uint8_t pad_[2];
+};
+
+struct jda_strip {                // one wavefront's work: <= 64 consecutive MCUs of one MCU row
+    uint32_t image;               // index into the descriptor array
+    uint32_t mcu_y;
+    uint32_t mcu_x0;
+    uint32_t count;               // 0 = padding entry
+};
+
+#endif

@@ -1,0 +1,74 @@
+// jda_plan.h -- host-side construction of the device descriptors and the strip work list.
+// Shared by the HIP runtime (jda_runtime.cpp) and the unit-test wave emulator (tests/hostsim).
+#ifndef JDA_PLAN_H
+#define JDA_PLAN_H
+
+#include <string.h>
+
+#include <vector>
+
+#include "jda_internal.h"
+
+extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
+
+#define JDA_WAVES_PER_WG 4
+
+inline int jda_mode_of(const jda_image_info &I)
+{
+    if (I.subsample == 0x22) return JDA_MODE_420;
+    if (I.subsample == 0x11) return JDA_MODE_444;
+    return JDA_MODE_GRAY;
+}
+
+// Fill everything of the descriptor except the device pointers.  Returns JDA_* status.
+inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, int options,
+                         const jda_output &out)
+{
+    const jda_image_info &I = *jda_image_get_info(img);
+    memset(&D, 0, sizeof(D));
+    if (pixel_type < 0 || pixel_type > JDA_EIGHT_BIT_GRAYSCALE) return JDA_INVALID_PARAMETER;   // src/JPEGDEC.cpp:47-53
+    if ((options & JDA_LUMA_ONLY) && pixel_type < JDA_EIGHT_BIT_GRAYSCALE) pixel_type = JDA_EIGHT_BIT_GRAYSCALE; // jpeg.inl:4991-4993
+    int bpp, ow, oh, cw, ch;
+    int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
+    if (rc != JDA_SUCCESS) return rc;
+    D.mode = (uint8_t)jda_mode_of(I);
+    D.ncomp = (uint8_t)I.ncomp;
+    // gray JPEG with an RGB8888 request is drawn as RGB565 by the reference
+    D.pixel_type = (uint8_t)((D.mode == JDA_MODE_GRAY && pixel_type == JDA_RGB8888) ? JDA_RGB565_BIG_ENDIAN : pixel_type);
+    D.scale_shift = (uint8_t)((options & JDA_SCALE_HALF) ? 1 : (options & JDA_SCALE_QUARTER) ? 2 : (options & JDA_SCALE_EIGHTH) ? 3 : 0);
+    D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pixel_type == JDA_EIGHT_BIT_GRAYSCALE);
+    jda_image_component_ids(img, D.dc_id, D.ac_id, D.q_id);
+    D.mcus_x = (uint32_t)I.mcus_x;
+    D.mcus_y = (uint32_t)I.mcus_y;
+    uint32_t nok = 0, slen = 0;
+    jda_image_mcu_index(img, &nok);
+    jda_image_scan(img, &slen);
+    D.n_mcus_ok = nok;
+    D.scan_len = slen;
+    D.out = (uint8_t *)out.pixels;
+    D.out_pitch = (uint32_t)out.pitch_bytes;
+    D.out_w = (uint32_t)(out.width_px < cw ? out.width_px : cw);
+    D.out_rows = (uint32_t)(out.rows < ch ? out.rows : ch);
+    if (out.pitch_bytes < (int)D.out_w * bpp) return JDA_INVALID_PARAMETER;
+    return JDA_SUCCESS;
+}
+
+// Strips of one image: each MCU row is cut into runs of <= 64 MCUs; the list is padded with
+// empty strips to a multiple of the waves per workgroup so a workgroup never spans two images.
+inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y)
+{
+    for (uint32_t y = 0; y < mcus_y; y++)
+        for (uint32_t x = 0; x < mcus_x; x += 64) {
+            jda_strip s;
+            s.image = image; s.mcu_y = y; s.mcu_x0 = x;
+            s.count = mcus_x - x < 64 ? mcus_x - x : 64;
+            v.push_back(s);
+        }
+    while (v.size() % JDA_WAVES_PER_WG) {
+        jda_strip s;
+        s.image = image; s.mcu_y = 0; s.mcu_x0 = 0; s.count = 0;
+        v.push_back(s);
+    }
+}
+
+#endif

@@ -1,0 +1,372 @@
+// jda_runtime.cpp -- device runtime behind the C-ABI: context (device, stream, events), resident
+// images, batch launch plans.  The reference has no such layer (it is a single-threaded
+// streaming decoder); this is the seam that replaces the body of the MCU loops of
+// DecodeJPEG (reference src/jpeg.inl:5109-5353) with one kernel launch per batch.
+//
+// There is NO CPU fallback here: every entry point reports JDA_ERROR_NO_DEVICE / JDA_ERROR_HIP
+// when the HIP device or a HIP call is not available.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "jda_internal.h"
+#include "jda_plan.h"
+
+extern "C" hipError_t jda_launch_decode(int mode, const jda_dev_desc *descs, const jda_strip *strips,
+                                        uint32_t n_strips, hipStream_t stream);
+
+struct jda_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev_start, ev_stop;
+    char last_error[256];
+};
+
+struct jda_dev_image {
+    uint8_t *base;            // one allocation: tables | index | dc | scan
+    size_t bytes;
+    size_t off_tables, off_index, off_dc, off_scan;
+    jda_image_info info;
+    jda_dev_desc proto;       // descriptor without output / format fields
+    uint32_t scan_len, n_mcus_ok;
+    uint8_t dc_id[3], ac_id[3], q_id[3];
+    // host copy of what jda_fill_desc needs
+    const jda_image *host;    // NOT owned; only dereferenced inside jda_upload
+};
+
+struct jda_batch {
+    int32_t n_images;
+    jda_dev_desc *d_descs;
+    jda_strip *d_strips[3];   // per mode
+    uint32_t n_strips[3];
+    jda_batch_stats stats;
+};
+
+static int set_err(jda_ctx *ctx, hipError_t e, const char *what)
+{
+    if (ctx) snprintf(ctx->last_error, sizeof(ctx->last_error), "%s: %s", what, hipGetErrorString(e));
+    return JDA_ERROR_HIP;
+}
+
+#define JDA_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err((ctx), e_, #call); } while (0)
+
+static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+extern "C" {
+
+int jda_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+jda_ctx *jda_create(int32_t device, int32_t *err)
+{
+    int32_t dummy;
+    if (!err) err = &dummy;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
+    jda_ctx *ctx = new (std::nothrow) jda_ctx;
+    if (!ctx) { *err = JDA_ERROR_MEMORY; return NULL; }
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        delete ctx;
+        *err = JDA_ERROR_NO_DEVICE;
+        return NULL;
+    }
+    *err = JDA_SUCCESS;
+    return ctx;
+}
+
+void jda_destroy(jda_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipEventDestroy(ctx->ev_start);
+    hipEventDestroy(ctx->ev_stop);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *jda_last_hip_error(const jda_ctx *ctx) { return ctx ? ctx->last_error : "no context"; }
+void *jda_stream(jda_ctx *ctx) { return ctx ? (void *)ctx->stream : NULL; }
+
+void *jda_malloc(jda_ctx *ctx, size_t bytes)
+{
+    if (!ctx) return NULL;
+    void *p = NULL;
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) { set_err(ctx, e, "hipMalloc"); return NULL; }
+    return p;
+}
+
+void jda_free(jda_ctx *ctx, void *dptr)
+{
+    if (ctx && dptr) { hipSetDevice(ctx->device); hipFree(dptr); }
+}
+
+int jda_memset(jda_ctx *ctx, void *dptr, int value, size_t bytes)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    JDA_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    JDA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDA_SUCCESS;
+}
+
+int jda_copy_to_host(jda_ctx *ctx, void *host, const void *dptr, size_t bytes)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    JDA_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JDA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDA_SUCCESS;
+}
+
+int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    JDA_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    JDA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDA_SUCCESS;
+}
+
+jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
+{
+    int32_t dummy;
+    if (!err) err = &dummy;
+    if (!ctx || !img) { *err = ctx ? JDA_INVALID_PARAMETER : JDA_ERROR_NO_DEVICE; return NULL; }
+    const jda_image_info &I = *jda_image_get_info(img);
+    uint32_t scan_len = 0, nok = 0, tbytes = 0;
+    const uint8_t *scan = jda_image_scan(img, &scan_len);
+    const uint32_t *index = jda_image_mcu_index(img, &nok);
+    const int16_t *dc = jda_image_mcu_dc(img);
+    const uint8_t *tables = jda_image_tables(img, &tbytes);
+    const size_t n_mcus = (size_t)I.mcus_x * I.mcus_y;
+
+    jda_dev_image *d = new (std::nothrow) jda_dev_image;
+    if (!d) { *err = JDA_ERROR_MEMORY; return NULL; }
+    memset(d, 0, sizeof(*d));
+    d->info = I;
+    d->host = img;
+    d->scan_len = scan_len;
+    d->n_mcus_ok = nok;
+    jda_image_component_ids(img, d->dc_id, d->ac_id, d->q_id);
+    d->off_tables = 0;
+    d->off_index = align16(tbytes);
+    d->off_dc = d->off_index + align16((n_mcus + 1) * sizeof(uint32_t));
+    d->off_scan = d->off_dc + align16(n_mcus * I.ncomp * sizeof(int16_t));
+    d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc((void **)&d->base, d->bytes);
+    if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); delete d; *err = JDA_ERROR_MEMORY; return NULL; }
+    // stage through one pinned-size host buffer so it is a single H2D copy
+    std::vector<uint8_t> stage(d->bytes, 0);
+    memcpy(stage.data() + d->off_tables, tables, tbytes);
+    memcpy(stage.data() + d->off_index, index, (n_mcus + 1) * sizeof(uint32_t));
+    memcpy(stage.data() + d->off_dc, dc, n_mcus * I.ncomp * sizeof(int16_t));
+    memcpy(stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
+    e = hipMemcpyAsync(d->base, stage.data(), d->bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { set_err(ctx, e, "hipMemcpy(image)"); hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
+    *err = JDA_SUCCESS;
+    return d;
+}
+
+void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg)
+{
+    if (!dimg) return;
+    if (ctx) hipSetDevice(ctx->device);
+    if (dimg->base) hipFree(dimg->base);
+    delete dimg;
+}
+
+size_t jda_dev_image_bytes(const jda_dev_image *dimg) { return dimg ? dimg->bytes : 0; }
+
+jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *images,
+                            const jda_output *outputs, const int32_t *pixel_types,
+                            const int32_t *options, int32_t *err)
+{
+    int32_t dummy;
+    if (!err) err = &dummy;
+    if (!ctx) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
+    if (n <= 0 || !images || !outputs) { *err = JDA_INVALID_PARAMETER; return NULL; }
+    std::vector<jda_dev_desc> descs((size_t)n);
+    std::vector<jda_strip> strips[3];
+    jda_batch_stats st;
+    memset(&st, 0, sizeof(st));
+    for (int i = 0; i < n; i++) {
+        const jda_dev_image *im = images[i];
+        if (!im) { *err = JDA_INVALID_PARAMETER; return NULL; }
+        const jda_image_info &I = im->info;
+        const int pt_req = pixel_types ? pixel_types[i] : JDA_RGB8888;
+        const int opt = options ? options[i] : 0;
+        jda_dev_desc &D = descs[(size_t)i];
+        memset(&D, 0, sizeof(D));
+        if (pt_req < 0 || pt_req > JDA_EIGHT_BIT_GRAYSCALE) { *err = JDA_INVALID_PARAMETER; return NULL; }
+        int pt = pt_req;
+        if ((opt & JDA_LUMA_ONLY) && pt < JDA_EIGHT_BIT_GRAYSCALE) pt = JDA_EIGHT_BIT_GRAYSCALE;   // jpeg.inl:4991-4993
+        int bpp, ow, oh, cw, ch;
+        if (jda_output_geometry(&I, pt, opt, &bpp, &ow, &oh, &cw, &ch) != JDA_SUCCESS) { *err = JDA_INVALID_PARAMETER; return NULL; }
+        const jda_output &O = outputs[i];
+        D.mode = (uint8_t)jda_mode_of(I);
+        D.ncomp = (uint8_t)I.ncomp;
+        D.pixel_type = (uint8_t)((D.mode == JDA_MODE_GRAY && pt == JDA_RGB8888) ? JDA_RGB565_BIG_ENDIAN : pt);
+        D.scale_shift = (uint8_t)((opt & JDA_SCALE_HALF) ? 1 : (opt & JDA_SCALE_QUARTER) ? 2 : (opt & JDA_SCALE_EIGHTH) ? 3 : 0);
+        D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE);
+        memcpy(D.dc_id, im->dc_id, 3); memcpy(D.ac_id, im->ac_id, 3); memcpy(D.q_id, im->q_id, 3);
+        D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
+        D.n_mcus_ok = im->n_mcus_ok; D.scan_len = im->scan_len;
+        D.tables = im->base + im->off_tables;
+        D.mcu_index = (const uint32_t *)(im->base + im->off_index);
+        D.mcu_dc = (const int16_t *)(im->base + im->off_dc);
+        D.scan = im->base + im->off_scan;
+        D.out = (uint8_t *)O.pixels;
+        D.out_pitch = (uint32_t)O.pitch_bytes;
+        D.out_w = (uint32_t)(O.width_px < cw ? O.width_px : cw);
+        D.out_rows = (uint32_t)(O.rows < ch ? O.rows : ch);
+        if (!O.pixels || ((uintptr_t)O.pixels & 15) || (O.pitch_bytes & 15) || O.pitch_bytes < (int)D.out_w * bpp) {
+            *err = JDA_INVALID_PARAMETER; return NULL;
+        }
+        jda_append_strips(strips[D.mode], (uint32_t)i, D.mcus_x, D.mcus_y);
+        st.source_pixels += (int64_t)I.width * I.height;
+        st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
+        st.scan_bytes += im->scan_len;
+        st.index_bytes += (int64_t)I.mcus_x * I.mcus_y * (4 + 2 * I.ncomp);
+        st.table_bytes += JDA_TABLE_BYTES;
+    }
+    jda_batch *b = new (std::nothrow) jda_batch;
+    if (!b) { *err = JDA_ERROR_MEMORY; return NULL; }
+    memset(b, 0, sizeof(*b));
+    b->n_images = n;
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc((void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
+    if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
+    for (int m = 0; m < 3 && e == hipSuccess; m++) {
+        b->n_strips[m] = (uint32_t)strips[m].size();
+        if (!b->n_strips[m]) continue;
+        e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
+        if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
+        st.n_launches++;
+        st.n_workgroups += (int32_t)(strips[m].size() / JDA_WAVES_PER_WG);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        set_err(ctx, e, "jda_batch_create");
+        jda_batch_destroy(ctx, b);
+        *err = JDA_ERROR_HIP;
+        return NULL;
+    }
+    b->stats = st;
+    *err = JDA_SUCCESS;
+    return b;
+}
+
+void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
+{
+    if (!b) return;
+    if (ctx) hipSetDevice(ctx->device);
+    if (b->d_descs) hipFree(b->d_descs);
+    for (int m = 0; m < 3; m++) if (b->d_strips[m]) hipFree(b->d_strips[m]);
+    delete b;
+}
+
+int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (!b) return JDA_INVALID_PARAMETER;
+    for (int m = 0; m < 3; m++) {
+        if (!b->n_strips[m]) continue;
+        JDA_HIP(ctx, jda_launch_decode(m, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
+    }
+    return JDA_SUCCESS;
+}
+
+int jda_batch_get_stats(const jda_batch *b, jda_batch_stats *stats)
+{
+    if (!b || !stats) return JDA_INVALID_PARAMETER;
+    *stats = b->stats;
+    return JDA_SUCCESS;
+}
+
+int jda_sync(jda_ctx *ctx)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    JDA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDA_SUCCESS;
+}
+
+int jda_timer_start(jda_ctx *ctx)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    JDA_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    return JDA_SUCCESS;
+}
+
+int jda_timer_stop(jda_ctx *ctx)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    JDA_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    return JDA_SUCCESS;
+}
+
+double jda_timer_elapsed_ms(jda_ctx *ctx)
+{
+    if (!ctx) return -1.0;
+    if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
+                       int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    int32_t err = JDA_SUCCESS;
+    jda_image *img = jda_prepare(jpeg, len, &err);
+    if (!img) return err;
+    const jda_image_info &I = *jda_image_get_info(img);
+    int bpp, ow, oh, cw, ch;
+    int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
+    if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
+    uint32_t nok = 0;
+    jda_image_mcu_index(img, &nok);
+    const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
+    const int dpitch = (int)align16((size_t)cw * bpp);
+    const int drows = rows < ch ? rows : ch;
+    jda_dev_image *dimg = jda_upload(ctx, img, &err);
+    jda_image_free(img);
+    if (!dimg) return err;
+    void *dout = jda_malloc(ctx, (size_t)dpitch * ch);
+    if (!dout) { jda_dev_image_free(ctx, dimg); return JDA_ERROR_MEMORY; }
+    jda_output O;
+    O.pixels = dout; O.pitch_bytes = dpitch; O.width_px = cw; O.rows = drows;
+    jda_batch *b = jda_batch_create(ctx, 1, &dimg, &O, &pixel_type, &options, &err);
+    rc = err;
+    if (b) {
+        if (!complete) hipMemsetAsync(dout, 0, (size_t)dpitch * ch, ctx->stream);
+        rc = jda_batch_decode(ctx, b);
+        if (rc == JDA_SUCCESS) {
+            const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
+            hipError_t e = hipMemcpy2DAsync(host_pixels, (size_t)pitch_bytes, dout, (size_t)dpitch, row_bytes, (size_t)drows, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = set_err(ctx, e, "copy back");
+        }
+        jda_batch_destroy(ctx, b);
+    }
+    jda_free(ctx, dout);
+    jda_dev_image_free(ctx, dimg);
+    if (rc == JDA_SUCCESS && !complete) rc = JDA_DECODE_ERROR;   // jpeg.inl:5354-5356
+    return rc;
+}
+
+} // extern "C"

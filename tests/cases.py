@@ -1,0 +1,41 @@
+"""Shared test inputs: small deterministic synthetic JPEGs covering the shapes the path supports."""
+import functools
+import os
+
+from jpegdec_amd.synth import synth_jpeg
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> kwargs for synth_jpeg
+SYNTH_CASES = {
+    "c420_333x217": dict(width=333, height=217, subsampling="4:2:0", seed=11),
+    "c444_333x217": dict(width=333, height=217, subsampling="4:4:4", seed=12),
+    "gray_333x217": dict(width=333, height=217, subsampling="gray", seed=13),
+    "c420_640x368_rstrow": dict(width=640, height=368, subsampling="4:2:0", seed=14, restart_rows=1),
+    "c420_256x256_q98": dict(width=256, height=256, subsampling="4:2:0", seed=15, quality=98),
+    "c444_256x256_q100_opt": dict(width=256, height=256, subsampling="4:4:4", seed=16, quality=100, optimize=True),
+    "gray_64x64_rst3": dict(width=64, height=64, subsampling="gray", seed=17, restart_blocks=3),
+    "c420_1100x48": dict(width=1100, height=48, subsampling="4:2:0", seed=18),       # > 64 MCUs per row: 2 strips
+    "gray_1100x24": dict(width=1100, height=24, subsampling="gray", seed=19),        # 138 MCUs per row: 3 strips
+    "c420_16x16": dict(width=16, height=16, subsampling="4:2:0", seed=20),           # single MCU
+    "c444_8x8_q30": dict(width=8, height=8, subsampling="4:4:4", seed=21, quality=30),
+    "c420_1280x720": dict(width=1280, height=720, subsampling="4:2:0", seed=1234),   # BASELINE config 2 shape
+    "c420_250x250_q10": dict(width=250, height=250, subsampling="4:2:0", seed=22, quality=10),  # many DC-only blocks
+}
+
+PIXEL_TYPES = (0, 1, 2, 3)                 # RGB565_LE, RGB565_BE, RGB8888, GRAY8
+OPTIONS = (0, 2, 4, 8, 64, 64 | 2)         # full, 1/2, 1/4, 1/8, luma-only, luma-only 1/2
+
+
+@functools.lru_cache(maxsize=None)
+def jpeg_for(name: str) -> bytes:
+    path = os.path.join(GOLDEN_DIR, name + ".jpg")
+    if os.path.exists(path):               # committed fixture wins (keeps tests independent of Pillow's version)
+        return open(path, "rb").read()
+    return synth_jpeg(**SYNTH_CASES[name])
+
+
+def all_modes(name):
+    for pt in PIXEL_TYPES:
+        for opt in OPTIONS:
+            yield pt, opt

@@ -1,0 +1,58 @@
+// tests/hostsim/hostsim.cpp -- TEST INFRASTRUCTURE: a lane-by-lane CPU emulation of one wavefront.
+//
+// Compiles the very same per-lane decode logic the HIP kernels use (jpegdec_amd/csrc/
+// jda_device_core.h) with g++ and runs every strip the way the kernel does: all 64 lanes through
+// phase A, then all 64 lanes through phase B, over a byte array standing in for the wave's LDS.
+// It exists so the kernel logic can be checked against the oracle on machines without a GPU
+// (`pytest -m "not gpu"`).  It is not part of libjpegdec_amd.so and nothing in the product calls it.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../jpegdec_amd/csrc/jda_device_core.h"
+#include "../../jpegdec_amd/csrc/jda_plan.h"
+
+template <int MODE>
+static void run_strips(const jda_dev_desc &D, const std::vector<jda_strip> &strips, const uint8_t *tables)
+{
+    typedef jda_lds_layout<MODE> L;
+    std::vector<uint64_t> lds_store((L::WAVE_BYTES + 7) / 8);
+    uint8_t *wave_lds = (uint8_t *)lds_store.data();
+    for (size_t i = 0; i < strips.size(); i++) {
+        const jda_strip &S = strips[i];
+        if (S.count == 0) continue;
+        memset(wave_lds, 0xA5, L::WAVE_BYTES);   // poison: LDS is not zero-initialised on the GPU either
+        for (uint32_t lane = 0; lane < 64; lane++) jda_phase_a<MODE>(D, S, lane, tables, wave_lds);
+        for (uint32_t lane = 0; lane < 64; lane++) jda_phase_b<MODE>(D, S, lane, wave_lds);
+    }
+}
+
+extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int options,
+                              uint8_t *out, int pitch_bytes, int width_px, int rows)
+{
+    int32_t err = 0;
+    jda_image *img = jda_prepare(jpeg, len, &err);
+    if (!img) return err ? err : -1;
+    jda_dev_desc D;
+    jda_output o;
+    o.pixels = out; o.pitch_bytes = pitch_bytes; o.width_px = width_px; o.rows = rows;
+    int rc = jda_fill_desc(D, img, pixel_type, options, o);
+    if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
+    uint32_t n;
+    D.scan = jda_image_scan(img, &n);
+    D.mcu_index = jda_image_mcu_index(img, &n);
+    D.mcu_dc = jda_image_mcu_dc(img);
+    D.tables = jda_image_tables(img, &n);
+    std::vector<jda_strip> strips;
+    jda_append_strips(strips, 0, D.mcus_x, D.mcus_y);
+    switch (D.mode) {
+    case JDA_MODE_GRAY: run_strips<JDA_MODE_GRAY>(D, strips, D.tables); break;
+    case JDA_MODE_444: run_strips<JDA_MODE_444>(D, strips, D.tables); break;
+    default: run_strips<JDA_MODE_420>(D, strips, D.tables); break;
+    }
+    const jda_image_info *I = jda_image_get_info(img);
+    rc = (D.n_mcus_ok == (uint32_t)(I->mcus_x * I->mcus_y)) ? JDA_SUCCESS : JDA_DECODE_ERROR;
+    jda_image_free(img);
+    return rc;
+}

@@ -1,0 +1,91 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, must be bit-exact to the oracle.
+
+Checker = oracle/liboracle.so (our restatement, itself pinned to the real reference by
+tests/test_oracle_*.py) and, where it travelled along, oracle/_ref (the real reference's scalar
+build).  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+import jpegdec_amd as J
+from tests.cases import SYNTH_CASES, all_modes, jpeg_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(SYNTH_CASES))
+def test_decode_bit_exact_all_modes(name, gpu_ctx, oracle):
+    jpeg = jpeg_for(name)
+    for pt, opt in all_modes(name):
+        rc, got, g = J.decode_to_host(gpu_ctx, jpeg, pt, opt)
+        assert rc == 0, (name, pt, opt, rc)
+        orc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+        assert orc == 1, (name, pt, opt, err)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), "%s pt=%d opt=%d: %d differing bytes" % (
+            name, pt, opt, int(np.count_nonzero(got != want)))
+
+
+def test_matches_real_reference_when_present(gpu_ctx, ref_scalar):
+    """Same comparison against the unmodified reference (scalar integer build) if oracle/_ref travelled."""
+    for name in ("c420_333x217", "c444_256x256_q100_opt", "gray_64x64_rst3", "c420_1280x720"):
+        jpeg = jpeg_for(name)
+        for pt, opt in ((J.RGB8888, 0), (J.RGB565_LE, 0), (J.RGB565_BE, J.SCALE_HALF), (J.GRAY8, J.SCALE_QUARTER),
+                        (J.RGB8888, J.SCALE_EIGHTH)):
+            if name.startswith("gray") and pt == J.RGB8888:
+                continue
+            rc, got, g = J.decode_to_host(gpu_ctx, jpeg, pt, opt)
+            assert rc == 0
+            r = ref_scalar.decode_cb(jpeg, pt, opt)
+            assert r["rc"] == 1
+            want = r["canvas"][: g["out_h"], : g["canvas_w"] * g["bpp"]]
+            assert np.array_equal(got[: g["out_h"]], want), (name, pt, opt)
+
+
+def test_batch_of_mixed_images_resident(gpu_ctx, oracle):
+    """One launch plan over several resident images of different shapes and output formats."""
+    names = ["c420_333x217", "c444_333x217", "gray_333x217", "c420_1100x48", "c420_640x368_rstrow"]
+    pts = [J.RGB8888, J.RGB565_LE, J.GRAY8, J.RGB8888, J.RGB565_BE]
+    opts = [0, J.SCALE_HALF, 0, J.SCALE_QUARTER, 0]
+    prepared = [J.PreparedImage(jpeg_for(n)) for n in names]
+    dev = [J.DeviceImage(gpu_ctx, p) for p in prepared]
+    outs, ptrs, geos = [], [], []
+    for p, pt, opt in zip(prepared, pts, opts):
+        g = p.geometry(pt, opt)
+        pitch = (g["canvas_w"] * g["bpp"] + 15) & ~15
+        ptr = gpu_ctx.malloc(pitch * g["canvas_h"])
+        gpu_ctx.memset(ptr, 0, pitch * g["canvas_h"])
+        outs.append((ptr, pitch, g["canvas_w"], g["canvas_h"]))
+        ptrs.append(ptr)
+        geos.append((g, pitch))
+    batch = J.Batch(gpu_ctx, dev, outs, pts, opts)
+    batch.decode()
+    batch.decode()          # idempotent: decoding twice into the same surface changes nothing
+    gpu_ctx.sync()
+    for n, pt, opt, ptr, (g, pitch) in zip(names, pts, opts, ptrs, geos):
+        got = gpu_ctx.to_host(ptr, pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[:, : g["canvas_w"] * g["bpp"]]
+        rc, want, _ = oracle.decode_canvas(jpeg_for(n), pt, opt)
+        assert rc == 1 and np.array_equal(got, want), n
+    batch.close()
+    for d in dev:
+        d.close()
+    for ptr in ptrs:
+        gpu_ctx.free(ptr)
+
+
+def test_clip_to_image_size(gpu_ctx, oracle):
+    """width_px / rows clip: writing only W x H pixels leaves the rest of the surface untouched."""
+    jpeg = jpeg_for("c420_333x217")
+    p = J.PreparedImage(jpeg)
+    d = J.DeviceImage(gpu_ctx, p)
+    g = p.geometry(J.RGB8888, 0)
+    pitch = (g["canvas_w"] * 4 + 15) & ~15
+    ptr = gpu_ctx.malloc(pitch * g["canvas_h"])
+    gpu_ctx.memset(ptr, 0x5A, pitch * g["canvas_h"])
+    b = J.Batch(gpu_ctx, [d], [(ptr, pitch, g["out_w"], g["out_h"])], [J.RGB8888], [0])
+    b.decode()
+    gpu_ctx.sync()
+    got = gpu_ctx.to_host(ptr, pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)
+    rc, want, _ = oracle.decode_canvas(jpeg, J.RGB8888, 0)
+    assert np.array_equal(got[: g["out_h"], : g["out_w"] * 4], want[: g["out_h"], : g["out_w"] * 4])
+    assert (got[g["out_h"]:, :] == 0x5A).all() and (got[:, g["out_w"] * 4:] == 0x5A).all()
+    b.close(); d.close(); gpu_ctx.free(ptr)
