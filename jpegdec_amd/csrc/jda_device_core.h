@@ -47,6 +47,10 @@ template <int MODE> struct jda_lds_layout {
 };
 
 // ---- small helpers ---------------------------------------------------------------------------
+// type-punned wide accesses to the int16 / uint8 LDS arrays must not be reordered by TBAA
+typedef uint64_t __attribute__((may_alias)) jda_u64_alias;
+typedef uint32_t __attribute__((may_alias)) jda_u32_alias;
+
 JDA_HD uint32_t jda_alignbyte(uint32_t hi, uint32_t lo, uint32_t byte_shift)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -55,6 +59,16 @@ JDA_HD uint32_t jda_alignbyte(uint32_t hi, uint32_t lo, uint32_t byte_shift)
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (byte_shift & 3)));
 #endif
 }
+
+// Hides a value from instruction selection.  Needed because hipcc (ROCm 7.2) fuses
+//   clamp255(a >> 12) | clamp255(b >> 12) << 8   into gfx950's v_ashr_pk_u8_i32 and then treats
+// the result as a zero-extended 16-bit value, but the instruction leaves garbage in bits 31:16
+// (observed on MI355X: low bits of the blue channel corrupted).  Breaking the pattern costs nothing.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JDA_OPAQUE(x) asm("" : "+v"(x))
+#else
+#define JDA_OPAQUE(x) ((void)0)
+#endif
 
 // sign-extended 10-bit field starting at bit `lo` (the reference's "& 0x3ff" table index)
 JDA_HD int32_t jda_sext10_at(int32_t v, int lo) { return (int32_t)((uint32_t)v << (22 - lo)) >> 22; }
@@ -66,7 +80,7 @@ JDA_HD uint32_t jda_range_limit5(int32_t v) { return (uint32_t)jda_clamp255(jda_
 // assembled from three aligned dword loads.
 JDA_HD uint64_t jda_load_be64(const uint8_t *base, uint32_t pos)
 {
-    const uint32_t *p = (const uint32_t *)(base + (pos & ~3u));
+    const jda_u32_alias *p = (const jda_u32_alias *)(base + (pos & ~3u));
     const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
     const uint32_t sh = pos & 3u;
     const uint32_t a = jda_alignbyte(w1, w0, sh);
@@ -108,7 +122,7 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const uint8_t *dc_lut, const
     uint32_t flags = 0;
     jda_refill(br);
     if (LIMIT == 64) {
-        uint64_t *z = (uint64_t *)coef;                 // memset(pMCU, 0, 128)  :2121
+        jda_u64_alias *z = (jda_u64_alias *)coef;       // memset(pMCU, 0, 128)  :2121
 #pragma unroll
         for (int i = 0; i < 16; i++) z[i] = 0;
     } else if (LIMIT == 5) {
@@ -258,7 +272,7 @@ JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], bool rows47_emp
 }
 
 // Full 8x8 block: coef (lane-private, natural order) -> 64 bytes written as 16 dwords to `out`.
-JDA_HD void jda_idct_block(const int16_t *coef, const int16_t *quant, uint32_t flags, uint32_t *out)
+JDA_HD void jda_idct_block(const int16_t *coef, const int16_t *quant, uint32_t flags, jda_u32_alias *out)
 {
     int32_t ws[64];
     const bool rows47_empty = (flags & 0x2000u) == 0;
@@ -296,8 +310,9 @@ JDA_HD uint32_t jda_pixel_rgba(jda_ycc p)
 {
     const int32_t cb = p.cb - 128, cr = p.cr - 128;
     const int32_t r = jda_clamp255((5742 * cr + p.y) >> 12);
-    const int32_t g = jda_clamp255((-1409 * cb - 2925 * cr + p.y) >> 12);
+    int32_t g = jda_clamp255((-1409 * cb - 2925 * cr + p.y) >> 12);
     const int32_t b = jda_clamp255((7258 * cb + p.y) >> 12);
+    JDA_OPAQUE(g);
     return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xff000000u;
 }
 
@@ -413,7 +428,7 @@ JDA_HD void jda_phase_a(const jda_dev_desc &D, const jda_strip &S, uint32_t lane
         const uint8_t *dcl = tables + JDA_TB_DC + D.dc_id[c] * 1024;
         const uint16_t *acl = (const uint16_t *)(tables + JDA_TB_AC) + D.ac_id[c] * 2048;
         const int16_t *quant = (const int16_t *)(tables + JDA_TB_QUANT) + D.q_id[c] * 64;
-        uint32_t *out = (uint32_t *)(planes + 64 * b);
+        jda_u32_alias *out = (jda_u32_alias *)(planes + 64 * b);
         int32_t &p = pred[c];
         if (shift >= 2) {
             const uint32_t flags = jda_decode_block<5>(br, dcl, acl, zigzag, coef, p);
@@ -473,13 +488,13 @@ JDA_HD void jda_phase_b(const jda_dev_desc &D, const jda_strip &S, uint32_t lane
         }
         uint8_t *dst = D.out + (size_t)Y * D.out_pitch + (size_t)X * bpp;
         if (bpp == 4) {
-            if (n == 4) { uint32_t *d = (uint32_t *)dst; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
-            else for (uint32_t j = 0; j < n; j++) ((uint32_t *)dst)[j] = v[j];
+            if (n == 4) { jda_u32_alias *d = (jda_u32_alias *)dst; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+            else for (uint32_t j = 0; j < n; j++) ((jda_u32_alias *)dst)[j] = v[j];
         } else if (bpp == 2) {
-            if (n == 4) { uint32_t *d = (uint32_t *)dst; d[0] = v[0] | (v[1] << 16); d[1] = v[2] | (v[3] << 16); }
+            if (n == 4) { jda_u32_alias *d = (jda_u32_alias *)dst; d[0] = v[0] | (v[1] << 16); d[1] = v[2] | (v[3] << 16); }
             else for (uint32_t j = 0; j < n; j++) ((uint16_t *)dst)[j] = (uint16_t)v[j];
         } else {
-            if (n == 4) *(uint32_t *)dst = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            if (n == 4) *(jda_u32_alias *)dst = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
             else for (uint32_t j = 0; j < n; j++) dst[j] = (uint8_t)v[j];
         }
     }
