@@ -12,7 +12,7 @@ LIB = jpegdec_amd/libjpegdec_amd.so
 LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
 LIB_DEPS = $(LIB_SRCS) $(CSRC)/jda_internal.h $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h include/jpegdec_amd.h include/JPEGDEC.h
 
-all: lib oracle hostsim
+all: lib oracle hostsim classshim
 
 lib: $(LIB)
 $(LIB): $(LIB_DEPS)
@@ -25,8 +25,13 @@ hostsim: tests/hostsim/libjda_hostsim.so
 tests/hostsim/libjda_hostsim.so: tests/hostsim/hostsim.cpp $(CSRC)/jda_frontend.cpp $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h $(CSRC)/jda_internal.h
 	$(CXX) -O2 -std=c++17 -fPIC -shared -fwrapv -Wall -Wno-unused-function -Wno-unknown-pragmas -Iinclude -o $@ tests/hostsim/hostsim.cpp $(CSRC)/jda_frontend.cpp
 
+# the reference-API driver (oracle/ref_shim.cpp) built against the product's JPEGDEC class -- test infrastructure
+classshim: tests/libjpegdec_class_shim.so
+tests/libjpegdec_class_shim.so: oracle/ref_shim.cpp include/JPEGDEC.h $(LIB)
+	$(CXX) -O2 -std=c++17 -fPIC -shared -w -DSHIM_PRODUCT -Iinclude -o $@ oracle/ref_shim.cpp -Ljpegdec_amd -ljpegdec_amd -lpthread -Wl,-rpath,'$$ORIGIN/../jpegdec_amd'
+
 clean:
 	rm -f $(LIB) tests/hostsim/libjda_hostsim.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim clean
+.PHONY: all lib oracle hostsim classshim clean

@@ -28,7 +28,11 @@ def digest(buf) -> str:
     """Short content hash used for golden vectors (sha256, first 16 hex digits)."""
     import hashlib
 
-    return hashlib.sha256(np.ascontiguousarray(np.frombuffer(memoryview(buf), dtype=np.uint8))).hexdigest()[:16]
+    if isinstance(buf, np.ndarray):
+        data = np.ascontiguousarray(buf).view(np.uint8)
+    else:
+        data = np.frombuffer(memoryview(buf), dtype=np.uint8)
+    return hashlib.sha256(data).hexdigest()[:16]
 
 
 def mcu_dims(subsample: int):
@@ -49,9 +53,11 @@ def scale_shift(options: int) -> int:
 class RefDecoder:
     """The real reference (bitbank2/JPEGDEC) behind oracle/ref_shim.cpp."""
 
-    def __init__(self, simd: bool = False):
-        name = "libjpegdec_ref_sse2.so" if simd else "libjpegdec_ref_scalar.so"
-        path = os.path.join(HERE, "_ref", name)
+    def __init__(self, simd: bool = False, path: str = None):
+        """path: load another build of the same shim (tests use this for the product's class)."""
+        if path is None:
+            name = "libjpegdec_ref_sse2.so" if simd else "libjpegdec_ref_scalar.so"
+            path = os.path.join(HERE, "_ref", name)
         if not os.path.exists(path):
             raise FileNotFoundError(path + " (run `make -C oracle ref` where /root/reference exists)")
         self.lib = C.CDLL(path)

@@ -15,7 +15,13 @@
 #include <time.h>
 #include <pthread.h>
 
+#ifdef SHIM_PRODUCT
+// Third build of the same shim: against the PRODUCT's drop-in class (include/JPEGDEC.h, linked
+// with libjpegdec_amd.so) so the very same driver code exercises reference and product.
+#include "JPEGDEC.h"
+#else
 #include "JPEGDEC.cpp"   // reference src/JPEGDEC.cpp (which #includes jpeg.inl), via -I
+#endif
 
 namespace {
 
@@ -86,7 +92,9 @@ int ref_is_simd(void)
 #endif
 }
 
+#ifndef SHIM_PRODUCT
 int ref_sizeof_state(void) { return (int)sizeof(JPEGIMAGE); }
+#endif
 
 // info[0..9] = width,height,subsample,bpp,jpegtype,orientation,hasthumb,thumbw,thumbh,lasterror
 int ref_get_info(const uint8_t *data, int len, int *info)

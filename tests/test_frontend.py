@@ -1,0 +1,111 @@
+"""Host front end of the product (jpegdec_amd/csrc/jda_frontend.cpp, via the C-ABI; no GPU calls):
+parse, Huffman LUTs, scan filter, quant prescale, serial pre-scan index, draw plan -- each against
+the oracle's independent restatement of the same reference stage."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import jpegdec_amd as J
+from jpegdec_amd.binding import ImageInfo, load_library
+from oracle.loader import USES_DMA
+from tests.cases import SYNTH_CASES, jpeg_for
+
+
+@pytest.mark.parametrize("name", sorted(SYNTH_CASES))
+def test_prepare_matches_oracle_stage_by_stage(name, oracle, product_lib):
+    jpeg = jpeg_for(name)
+    p = J.PreparedImage(jpeg)
+    oi = oracle.info(jpeg)
+    assert (p.info.width, p.info.height, p.info.ncomp, p.info.subsample, p.info.restart_interval, p.info.scan_offset) == (
+        oi["width"], oi["height"], oi["ncomp"], oi["subsample"], oi["restart_interval"], oi["scan_offset"])
+    # filtered scan == JPEGFilter over the whole scan
+    assert p.scan().tobytes() == oracle.filter(jpeg[oi["scan_offset"]:])
+    # table blob: DC LUTs | AC LUTs | prescaled quant | zigzag
+    t = p.tables()
+    rc, dc, ac = oracle.huff_tables(jpeg)
+    assert rc == 1
+    assert np.array_equal(t[:2048], dc)
+    assert np.array_equal(t[2048:10240].view(np.uint16), ac)
+    rc, q = oracle.quant_tables(jpeg)
+    assert np.array_equal(t[10240:10752].view(np.int16).reshape(4, 64), q)
+    assert list(t[10752:10816]) == [oracle.lib.orc_zigzag_to_natural(k) for k in range(64)]
+    # pre-scan index == the oracle's bit-reader phase and DC predictors at every MCU start
+    n, coefs, flags, state, dcp = oracle.entropy(jpeg, 0)
+    idx, nok = p.mcu_index()
+    assert nok == p.n_mcus and n == len(flags)
+    assert np.array_equal(idx[:-1] >> 7, state[:, 0]) and np.array_equal(idx[:-1] & 127, state[:, 1])
+    assert np.array_equal(p.mcu_dc().astype(np.int32), dcp[:, : p.info.ncomp])
+    p.close()
+
+
+def test_truncation_events_are_counted(product_lib):
+    """high-quality streams hit the un-refilled magnitude read; smooth ones do not."""
+    assert J.PreparedImage(jpeg_for("c444_256x256_q100_opt")).truncation_events() > 0
+
+
+def test_reject_rules(product_lib):
+    good = jpeg_for("c420_16x16")
+    assert J.parse(good[:100])["status"] == 4                      # JPEG_INVALID_FILE: < 256 bytes (jpeg.inl:1598)
+    assert J.parse(b"\x00" * 400)["status"] == 4                   # no SOI (jpeg.inl:1604)
+    sof = good.index(b"\xff\xc0")
+    bad = bytearray(good); bad[sof + 1] = 0xC1
+    assert J.parse(bytes(bad))["status"] == 3                      # SOF1 -> JPEG_UNSUPPORTED_FEATURE (jpeg.inl:1649)
+    bad = bytearray(good); bad[sof + 1] = 0xC2
+    with pytest.raises(J.JdaError) as e:
+        J.PreparedImage(bytes(bad))                                # progressive: off this path
+    assert e.value.code == 3
+    bad = bytearray(good); bad[sof + 11] = 0x41                    # Y sampling 4x1: reference divides by zero
+    with pytest.raises(J.JdaError):
+        J.PreparedImage(bytes(bad))
+    with pytest.raises(J.JdaError):
+        J.PreparedImage(good[: good.index(b"\xff\xda")])           # no SOS -> JPEG_DECODE_ERROR
+
+
+def test_truncated_scan_reports_partial_index(product_lib):
+    jpeg = jpeg_for("c420_333x217")
+    cut = jpeg[: len(jpeg) // 2] + b"\xff\xd9" + b"\x00" * 300
+    p = J.PreparedImage(cut)
+    idx, nok = p.mcu_index()
+    assert 0 < nok <= p.n_mcus
+
+
+def test_fuzz_does_not_crash(product_lib):
+    """The reference's own fuzz loop (MacOS/JPEGDEC_Test/main.cpp:262-281): invert each of the
+    first bytes of the file; the front end must fail cleanly or produce an index, never crash."""
+    jpeg = bytearray(jpeg_for("c420_333x217"))
+    for i in range(0, min(len(jpeg), 700)):
+        b = bytearray(jpeg); b[i] ^= 0xFF
+        try:
+            J.PreparedImage(bytes(b)).close()
+        except J.JdaError:
+            pass
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        b = bytearray(jpeg)
+        for _ in range(2):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        try:
+            J.PreparedImage(bytes(b)).close()
+        except J.JdaError:
+            pass
+
+
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "gray_333x217", "c420_1100x48", "c420_16x16"])
+def test_draw_plan_matches_oracle(name, oracle, product_lib):
+    jpeg = jpeg_for(name)
+    info = ImageInfo()
+    assert load_library().jda_parse(jpeg, len(jpeg), C.byref(info)) == 0
+    for pt in (0, 2, 3):
+        for opt in (0, 2, 4, 8, USES_DMA):
+            for mm in (0, 3):
+                got = J.draw_plan(info, pt, opt & ~USES_DMA, mm, bool(opt & USES_DMA))
+                want = oracle.draw_plan(jpeg, pt, opt & ~USES_DMA, mm, bool(opt & USES_DMA))
+                assert np.array_equal(got, want), (pt, opt, mm)
+
+
+def test_output_geometry(product_lib):
+    p = J.PreparedImage(jpeg_for("c420_333x217"))
+    assert p.geometry(J.RGB8888, 0) == dict(bpp=4, out_w=333, out_h=217, canvas_w=336, canvas_h=224)
+    assert p.geometry(J.RGB565_LE, J.SCALE_HALF) == dict(bpp=2, out_w=167, out_h=109, canvas_w=168, canvas_h=112)
+    assert p.geometry(J.RGB8888, J.LUMA_ONLY | J.SCALE_EIGHTH) == dict(bpp=1, out_w=42, out_h=28, canvas_w=42, canvas_h=28)

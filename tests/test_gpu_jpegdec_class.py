@@ -1,0 +1,73 @@
+"""The reference's class API (openFLASH / setPixelType / decode / JPEG_DRAW_CALLBACK /
+setFramebuffer) on the GPU path.  The SAME driver (oracle/ref_shim.cpp) is built once against the
+real reference and once against include/JPEGDEC.h + libjpegdec_amd.so; outputs, draw-callback
+sequences and error codes must agree.  Mirrors the reference's own tests 1, 9 and the perf loop
+(MacOS/JPEGDEC_Test/JPEGDEC_Test/main.cpp:74-105, 218-234)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.loader import GRAY8, RGB565_LE, RGB8888, SCALE_HALF, SCALE_QUARTER, USES_DMA, RefDecoder
+from tests.cases import jpeg_for
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def product_class(gpu_ctx):
+    import subprocess
+    subprocess.run(["make", "classshim"], cwd=ROOT, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return RefDecoder(False, path=os.path.join(ROOT, "tests", "libjpegdec_class_shim.so"))
+
+
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "gray_333x217", "c420_1100x48", "c420_640x368_rstrow"])
+def test_draw_callbacks_deliver_the_oracle_frame(name, product_class, oracle):
+    jpeg = jpeg_for(name)
+    inf = product_class.info(jpeg)
+    oi = oracle.info(jpeg)
+    assert inf["ok"] == 1 and (inf["width"], inf["height"], inf["subsample"]) == (oi["width"], oi["height"], oi["subsample"])
+    for pt, opt in ((RGB565_LE, 0), (RGB8888, 0), (GRAY8, 0), (RGB565_LE, SCALE_HALF), (GRAY8, SCALE_QUARTER)):
+        if name.startswith("gray") and pt == RGB8888:
+            continue
+        r = product_class.decode_cb(jpeg, pt, opt, want_log=True)
+        assert r["rc"] == 1 and r["last_error"] == 0
+        rc, want, _ = oracle.decode_canvas(jpeg, pt, opt)
+        sh = r["scale_shift"]
+        h = (inf["height"] + (1 << sh) - 1) >> sh
+        assert np.array_equal(r["canvas"][:h, : want.shape[1]], want[:h]), (name, pt, opt)
+        assert np.array_equal(r["log"], oracle.draw_plan(jpeg, pt, opt)), (name, pt, opt)   # same JPEGDRAW sequence
+
+
+def test_same_behaviour_as_the_real_reference(product_class, ref_scalar):
+    jpeg = jpeg_for("c420_333x217")
+    for pt, opt, mm in ((RGB565_LE, 0, 0), (RGB8888, 0, 3), (GRAY8, SCALE_HALF, 0), (RGB565_LE, USES_DMA, 0)):
+        a = product_class.decode_cb(jpeg, pt, opt, max_mcus=mm, want_log=True, xoff=5, yoff=7)
+        b = ref_scalar.decode_cb(jpeg, pt, opt, max_mcus=mm, want_log=True, xoff=5, yoff=7)
+        assert a["rc"] == b["rc"] == 1
+        assert np.array_equal(a["log"], b["log"])
+        assert a["dma_reuse"] == b["dma_reuse"]                       # reference test 9: DMA ping-pong
+        h = a["canvas"].shape[0] - 16
+        assert np.array_equal(a["canvas"][:h], b["canvas"][:h])
+    # early exit: callback returns 0 after 3 strips (jpeg.inl:5325) -- decode still returns 1
+    a = product_class.decode_cb(jpeg, RGB565_LE, 0, stop_after=3)
+    b = ref_scalar.decode_cb(jpeg, RGB565_LE, 0, stop_after=3)
+    assert (a["rc"], a["n_calls"]) == (b["rc"], b["n_calls"]) == (1, 3)
+
+
+def test_framebuffer_mode(product_class, oracle):
+    jpeg = jpeg_for("c420_640x368_rstrow")            # width is an MCU multiple: framebuffer == canvas
+    rc, fb = product_class.decode_fb(jpeg, RGB8888, 0)
+    assert rc == 1
+    orc, want, _ = oracle.decode_canvas(jpeg, RGB8888, 0)
+    assert np.array_equal(fb[: want.size].reshape(want.shape), want)
+
+
+def test_error_codes(product_class):
+    good = jpeg_for("c420_16x16")
+    assert product_class.info(good[:100])["lasterror"] == 4          # JPEG_INVALID_FILE
+    bad = bytearray(good); bad[good.index(b"\xff\xc0") + 1] = 0xC1
+    assert product_class.info(bytes(bad))["lasterror"] == 3          # JPEG_UNSUPPORTED_FEATURE
+    r = product_class.decode_cb(good, 9, 0)                          # invalid pixel type -> JPEG_INVALID_PARAMETER (src/JPEGDEC.cpp:47-53)
+    assert r["last_error"] in (1, 0)

@@ -1,0 +1,32 @@
+"""Kernel logic without a GPU: tests/hostsim compiles the very code the HIP kernels run per lane
+(jpegdec_amd/csrc/jda_device_core.h) with g++ and steps one wavefront lane by lane.  It must agree
+byte for byte with the oracle, padded MCU area included.  (Test infrastructure, not a fallback.)"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests.cases import SYNTH_CASES, all_modes, jpeg_for
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hostsim(built_checkers):
+    lib = C.CDLL(os.path.join(ROOT, "tests", "hostsim", "libjda_hostsim.so"))
+    lib.hostsim_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return lib
+
+
+@pytest.mark.parametrize("name", sorted(SYNTH_CASES))
+def test_wave_emulation_equals_oracle(name, hostsim, oracle):
+    jpeg = jpeg_for(name)
+    for pt, opt in all_modes(name):
+        rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+        assert rc == 1
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+        hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+        assert hrc == 0
+        assert np.array_equal(got, want), (name, pt, opt, int(np.count_nonzero(got != want)))
