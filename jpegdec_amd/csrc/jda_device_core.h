@@ -42,7 +42,8 @@ template <int MODE> struct jda_lds_layout {
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * 64 + 8,   // bytes per lane (pad 2 dwords)
         COEF_OFF = 0,
         PLANE_OFF = JDA_WAVE_LANES * JDA_COEF_STRIDE,
-        WAVE_BYTES = PLANE_OFF + JDA_WAVE_LANES * PLANE_STRIDE
+        WIN_OFF = PLANE_OFF + JDA_WAVE_LANES * PLANE_STRIDE,       // multiple of 16
+        WAVE_BYTES = WIN_OFF + 4096                                // + JDA_WIN_BYTES
     };
 };
 
@@ -78,30 +79,56 @@ JDA_HD uint32_t jda_range_limit5(int32_t v) { return (uint32_t)jda_clamp255(jda_
 
 // 64-bit big-endian window at an arbitrary byte position (MOTOLONG, src/JPEGDEC.h:316-318),
 // assembled from three aligned dword loads.
-JDA_HD uint64_t jda_load_be64(const uint8_t *base, uint32_t pos)
+JDA_HD uint64_t jda_be64_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t pos)
 {
-    const jda_u32_alias *p = (const jda_u32_alias *)(base + (pos & ~3u));
-    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
     const uint32_t sh = pos & 3u;
     const uint32_t a = jda_alignbyte(w1, w0, sh);
     const uint32_t b = jda_alignbyte(w2, w1, sh);
     return ((uint64_t)__builtin_bswap32(a) << 32) | __builtin_bswap32(b);
 }
 
+// The wave's view of the filtered scan: bytes [win_lo, win_lo + win_len) are staged in LDS (copied
+// with coalesced 16-byte loads by jda_window_fill); anything beyond is read from HBM directly.
 struct jda_bitreader {
-    const uint8_t *base;
-    uint32_t pos;    // bb.pBuf - start of filtered scan
-    uint32_t off;    // bb.ulBitOff
-    uint64_t bits;   // bb.ulBits
+    const uint8_t *base;     // filtered scan in global memory (4-byte aligned, zero padded)
+    const uint8_t *win;      // LDS copy
+    uint32_t win_lo;         // 16-byte aligned scan offset of win[0]
+    uint32_t win_len;        // bytes staged (multiple of 16)
+    uint32_t pos;            // bb.pBuf - start of filtered scan
+    uint32_t off;            // bb.ulBitOff
+    uint64_t bits;           // bb.ulBits
 };
+
+JDA_HD uint64_t jda_load_be64(const jda_bitreader &br, uint32_t pos)
+{
+    const uint32_t a = pos & ~3u;
+    const uint32_t rel = a - br.win_lo;
+    if (rel + 12u <= br.win_len) {                      // (a < win_lo wraps to a huge rel: falls through)
+        const jda_u32_alias *p = (const jda_u32_alias *)(br.win + rel);
+        return jda_be64_from_words(p[0], p[1], p[2], pos);
+    }
+    const jda_u32_alias *p = (const jda_u32_alias *)(br.base + a);
+    return jda_be64_from_words(p[0], p[1], p[2], pos);
+}
 
 JDA_HD void jda_refill(jda_bitreader &br)
 {
     if (br.off > 47) {                                   // jpeg.inl:2110-2114 (REGISTER_WIDTH-17)
         br.pos += br.off >> 3;
         br.off &= 7;
-        br.bits = jda_load_be64(br.base, br.pos);
+        br.bits = jda_load_be64(br, br.pos);
     }
+}
+
+// Cooperative copy of the strip's part of the scan into the wave's LDS window: lane l copies the
+// 16-byte chunks l, l+64, ...  Every lane of the wave calls it; the wave then fences.
+struct jda_chunk16 { uint32_t w[4]; };
+typedef jda_chunk16 __attribute__((may_alias)) jda_chunk16_alias;
+JDA_HD void jda_window_fill(const uint8_t *scan, uint32_t win_lo, uint32_t win_len, uint8_t *win, uint32_t lane)
+{
+    const jda_chunk16_alias *src = (const jda_chunk16_alias *)(scan + win_lo);
+    jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
+    for (uint32_t i = lane; i < (win_len >> 4); i += JDA_WAVE_LANES) dst[i] = src[i];
 }
 
 // EXTEND of the next s bits of the (un-refilled) window (jpeg.inl:2249-2252, 2155-2158)
@@ -144,10 +171,11 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const uint8_t *dc_lut, const
         }
     }
     if (LIMIT > 1) coef[0] = (int16_t)pred;
-    // AC  (:2223-2265)
+    // AC  (:2223-2265).  The reference refills at the top AND the bottom of every iteration; the top
+    // one is a no-op after a bottom one, so one refill before the loop + one per iteration is identical.
     int k = 1;
+    jda_refill(br);
     while (k < 64) {
-        jda_refill(br);
         code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
         code = code >= 0xfc00u ? (code & 0x7ffu) : (code >> 6);
         e = ac_lut[code];
@@ -166,6 +194,20 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const uint8_t *dc_lut, const
         jda_refill(br);
     }
     return flags;
+}
+
+// Multiplication by an IDCT constant.  FAST: both operands are known to fit in 24 signed bits (the
+// host checks max|coef| * max|quant| < 2^21 for the image, see jda_frontend.cpp), so the full-rate
+// 24-bit multiplier gives the exact low 32 bits; otherwise the full 32-bit multiply (quarter rate).
+template <bool FAST> JDA_HD int32_t jda_mulc(int32_t x, int32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FAST) return __mul24(x, c);     // v_mul_i32_i24 (hip_runtime.h is included by the .hip file)
+    return x * c;
+#else
+    if (FAST) return (int32_t)((uint32_t)(((int32_t)((uint32_t)x << 8)) >> 8) * (uint32_t)c);   // emulate the 24-bit operand
+    return (int32_t)((uint32_t)x * (uint32_t)c);
+#endif
 }
 
 // ---- dequant + IDCT + range limit (jpeg.inl:2553-2797) ---------------------------------------
@@ -219,30 +261,31 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8], uint32_t flags)
 
 // Column stage for one column (jpeg.inl:2561-2676): c[r] = raw coefficient of row r, q[r] its
 // prescaled quantiser; results truncated to int16 as the reference stores them back.
+template <bool FAST>
 JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], bool rows47_empty, int32_t out[8])
 {
     int32_t t0, t1, t2, t3, t4, t5, t6, t7;
     if (rows47_empty) {                                              // :2561-2601
         const int32_t a = c[0] * q[0];
         const int32_t b = c[2] * q[2];
-        const int32_t m = (b * 106) >> 8;
+        const int32_t m = jda_mulc<FAST>(b, 106) >> 8;
         t0 = a + b; t3 = a - b; t1 = a + m; t2 = a - m;
         t4 = c[1] * q[1];
         if (c[3] != 0) {
             const int32_t d = c[3] * q[3];
             t7 = t4 + d;
-            const int32_t t11 = ((t4 - d) * 362) >> 8;
-            const int32_t z5 = ((t4 - d) * 473) >> 8;
-            const int32_t t12 = ((d * 669) >> 8) + z5;               // (-tmp5 * -669) >> 8
+            const int32_t t11 = jda_mulc<FAST>(t4 - d, 362) >> 8;
+            const int32_t z5 = jda_mulc<FAST>(t4 - d, 473) >> 8;
+            const int32_t t12 = (jda_mulc<FAST>(d, 669) >> 8) + z5;               // (-tmp5 * -669) >> 8
             t6 = t12 - t7;
             t5 = t11 - t6;
-            const int32_t t10 = ((t4 * 277) >> 8) - z5;
+            const int32_t t10 = (jda_mulc<FAST>(t4, 277) >> 8) - z5;
             t4 = t10 + t5;
         } else {
             t7 = t4;
-            t5 = (145 * t4) >> 8;
-            t6 = (217 * t4) >> 8;
-            t4 = (-51 * t4) >> 8;
+            t5 = jda_mulc<FAST>(t4, 145) >> 8;
+            t6 = jda_mulc<FAST>(t4, 217) >> 8;
+            t4 = jda_mulc<FAST>(t4, -51) >> 8;
         }
     } else {                                                         // :2602-2676
         // the reference's zero tests on rows 4..7 only skip work; the arithmetic is identical
@@ -250,19 +293,19 @@ JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], bool rows47_emp
         const int32_t t10 = e0 + e4, t11 = e0 - e4;
         const int32_t e2 = c[2] * q[2], e6 = c[6] * q[6];
         const int32_t t13 = e2 + e6;
-        const int32_t t12 = (((e2 - e6) * 362) >> 8) - t13;
+        const int32_t t12 = (jda_mulc<FAST>(e2 - e6, 362) >> 8) - t13;
         t0 = t10 + t13; t3 = t10 - t13; t1 = t11 + t12; t2 = t11 - t12;
         const int32_t o3 = c[3] * q[3], o5 = c[5] * q[5];
         const int32_t z13 = o5 + o3, z10 = o5 - o3;
         const int32_t o1 = c[1] * q[1], o7 = c[7] * q[7];
         const int32_t z11 = o1 + o7, z12 = o1 - o7;
         t7 = z11 + z13;
-        const int32_t u11 = ((z11 - z13) * 362) >> 8;
-        const int32_t z5 = ((z10 + z12) * 473) >> 8;
-        const int32_t u12 = ((z10 * -669) >> 8) + z5;
+        const int32_t u11 = jda_mulc<FAST>(z11 - z13, 362) >> 8;
+        const int32_t z5 = jda_mulc<FAST>(z10 + z12, 473) >> 8;
+        const int32_t u12 = (jda_mulc<FAST>(z10, -669) >> 8) + z5;
         t6 = u12 - t7;
         t5 = u11 - t6;
-        const int32_t u10 = ((z12 * 277) >> 8) - z5;
+        const int32_t u10 = (jda_mulc<FAST>(z12, 277) >> 8) - z5;
         t4 = u10 + t5;
     }
     out[0] = (int16_t)(t0 + t7); out[1] = (int16_t)(t1 + t6);
@@ -272,6 +315,7 @@ JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], bool rows47_emp
 }
 
 // Full 8x8 block: coef (lane-private, natural order) -> 64 bytes written as 16 dwords to `out`.
+template <bool FAST>
 JDA_HD void jda_idct_block(const int16_t *coef, const int16_t *quant, uint32_t flags, jda_u32_alias *out)
 {
     int32_t ws[64];
@@ -281,7 +325,7 @@ JDA_HD void jda_idct_block(const int16_t *coef, const int16_t *quant, uint32_t f
         int32_t c[8], q[8], r[8];
 #pragma unroll
         for (int row = 0; row < 8; row++) { c[row] = coef[row * 8 + col]; q[row] = quant[row * 8 + col]; }
-        jda_idct_col(c, q, rows47_empty, r);
+        jda_idct_col<FAST>(c, q, rows47_empty, r);
 #pragma unroll
         for (int row = 0; row < 8; row++) ws[row * 8 + col] = r[row];
     }
@@ -396,10 +440,34 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
     return jda_pixel_565(p, pixel_type == JDA_RGB565_BIG_ENDIAN);
 }
 
+// ---- the wave's bitstream window --------------------------------------------------------------
+// The strip's MCUs are consecutive in the scan, so the bytes the wave needs are one contiguous run
+// starting at the first MCU's position; up to JDA_WIN_BYTES of it are staged in LDS.
+#define JDA_WIN_BYTES 4096
+struct jda_window { uint32_t lo, len; };
+
+JDA_HD jda_window jda_strip_window(const jda_dev_desc &D, const jda_strip &S, uint32_t max_bytes)
+{
+    jda_window w;
+    w.lo = 0; w.len = 0;
+    const uint32_t first = S.mcu_y * D.mcus_x + S.mcu_x0;
+    if (S.count == 0 || first >= D.n_mcus_ok) return w;
+    uint32_t last = first + S.count;                         // index has n_mcus + 1 entries
+    if (last > D.n_mcus_ok) last = D.n_mcus_ok;
+    w.lo = (D.mcu_index[first] >> JDA_INDEX_OFF_BITS) & ~15u;
+    // a lane may read 12 bytes past the (unrefilled) position of the next MCU's start + 8
+    uint32_t hi = ((D.mcu_index[last] >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
+    const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u; // never read past the padded allocation
+    if (hi > cap) hi = cap;
+    w.len = hi > w.lo ? hi - w.lo : 0;
+    if (w.len > max_bytes) w.len = max_bytes;
+    return w;
+}
+
 // ---- phase A: one lane decodes one MCU into its LDS planes ----------------------------------
-template <int MODE>
+template <int MODE, bool FAST>
 JDA_HD void jda_phase_a(const jda_dev_desc &D, const jda_strip &S, uint32_t lane,
-                        const uint8_t *tables, uint8_t *wave_lds)
+                        const uint8_t *tables, uint8_t *wave_lds, const jda_window &W)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
@@ -412,10 +480,13 @@ JDA_HD void jda_phase_a(const jda_dev_desc &D, const jda_strip &S, uint32_t lane
 
     jda_bitreader br;
     br.base = D.scan;
+    br.win = wave_lds + L::WIN_OFF;
+    br.win_lo = W.lo;
+    br.win_len = W.len;
     const uint32_t ix = D.mcu_index[mcu];
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
-    br.bits = jda_load_be64(br.base, br.pos);
+    br.bits = jda_load_be64(br, br.pos);
     int32_t pred[3];
     pred[0] = D.mcu_dc[mcu * D.ncomp];
     pred[1] = pred[2] = 0;
@@ -427,7 +498,9 @@ JDA_HD void jda_phase_a(const jda_dev_desc &D, const jda_strip &S, uint32_t lane
         const int c = b < T::NLUMA ? 0 : b - T::NLUMA + 1;
         const uint8_t *dcl = tables + JDA_TB_DC + D.dc_id[c] * 1024;
         const uint16_t *acl = (const uint16_t *)(tables + JDA_TB_AC) + D.ac_id[c] * 2048;
-        const int16_t *quant = (const int16_t *)(tables + JDA_TB_QUANT) + D.q_id[c] * 64;
+        // the quantisers are wave-uniform: read them from the global table blob so the compiler
+        // keeps them in SGPRs (scalar loads) instead of spending LDS reads on a broadcast
+        const int16_t *quant = (const int16_t *)(D.tables + JDA_TB_QUANT) + D.q_id[c] * 64;
         jda_u32_alias *out = (jda_u32_alias *)(planes + 64 * b);
         int32_t &p = pred[c];
         if (shift >= 2) {
@@ -442,12 +515,150 @@ JDA_HD void jda_phase_a(const jda_dev_desc &D, const jda_strip &S, uint32_t lane
                 const uint32_t v = jda_range_limit5(p * (int32_t)quant[0]) * 0x01010101u;
 #pragma unroll
                 for (int i = 0; i < 16; i++) out[i] = v;
-            } else jda_idct_block(coef, quant, flags, out);
+            } else if (!(D.pad_[0] & 2)) jda_idct_block<FAST>(coef, quant, flags, out);
         }
     }
 }
 
-// ---- phase B: the wave's lanes tile the strip's output, 4 pixels per lane per step ----------
+// ---- phase B ---------------------------------------------------------------------------------
+// The wave's lanes tile the strip's output so that consecutive lanes store consecutive 16-byte
+// (or 8-byte) groups: every store instruction writes whole, contiguous cache lines.
+
+// four converted pixels -> memory in the requested format, clipped at the right edge
+JDA_HD void jda_store4(uint8_t *row, uint32_t X, uint32_t out_w, int pt, const uint32_t v[4])
+{
+    const uint32_t n = X + 4 <= out_w ? 4u : out_w - X;
+    if (pt == JDA_RGB8888) {
+        jda_u32_alias *d = (jda_u32_alias *)(row + (size_t)X * 4);
+        if (n == 4) { d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+        else for (uint32_t j = 0; j < n; j++) d[j] = v[j];
+    } else if (pt == JDA_EIGHT_BIT_GRAYSCALE) {
+        if (n == 4) *(jda_u32_alias *)(row + X) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        else for (uint32_t j = 0; j < n; j++) row[X + j] = (uint8_t)v[j];
+    } else {
+        if (n == 4) { jda_u32_alias *d = (jda_u32_alias *)(row + (size_t)X * 2); d[0] = v[0] | (v[1] << 16); d[1] = v[2] | (v[3] << 16); }
+        else for (uint32_t j = 0; j < n; j++) ((uint16_t *)(row + (size_t)X * 2))[j] = (uint16_t)v[j];
+    }
+}
+
+// one chroma sample shared by a 2x2 (or 1x1) group: the products of jpeg.inl:3158-3161
+struct jda_chroma { int32_t r, g, b; };
+JDA_HD jda_chroma jda_chroma_terms(uint32_t cb8, uint32_t cr8)
+{
+    const int32_t cb = (int32_t)cb8 - 128, cr = (int32_t)cr8 - 128;
+    jda_chroma t;
+    t.r = 5742 * cr; t.g = -1409 * cb - 2925 * cr; t.b = 7258 * cb;
+    return t;
+}
+JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t, int pt)
+{
+    const int32_t y = (int32_t)(y8 << 12);
+    if (pt == JDA_RGB8888) {
+        const int32_t r = jda_clamp255((t.r + y) >> 12);
+        int32_t g = jda_clamp255((t.g + y) >> 12);
+        const int32_t b = jda_clamp255((t.b + y) >> 12);
+        JDA_OPAQUE(g);
+        return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xff000000u;
+    }
+    const int32_t r = jda_clamp255(jda_sext10_at(t.r + y, 12));
+    const int32_t g = jda_clamp255(jda_sext10_at(t.g + y, 12));
+    const int32_t b = jda_clamp255(jda_sext10_at(t.b + y, 12));
+    uint32_t v = (uint32_t)((r >> 3) << 11) | (uint32_t)((g >> 2) << 5) | (uint32_t)(b >> 3);
+    if (pt == JDA_RGB565_BIG_ENDIAN) v = ((v & 0xffu) << 8) | (v >> 8);
+    return v;
+}
+
+// full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): per step a lane
+// converts a 4x2 pixel group (two rows share the chroma samples)
+JDA_HD void jda_phase_b_420_full(const jda_dev_desc &D, uint32_t lane, const uint8_t *plane_base,
+                                 uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    const int pt = D.pixel_type;
+    const uint32_t bpp = pt == JDA_RGB8888 ? 4u : 2u;
+    for (uint32_t rp = 0; rp < 8; rp++) {
+        const uint32_t Y0 = y_base + 2 * rp;
+        if (Y0 >= D.out_rows) break;
+        const bool second = Y0 + 1 < D.out_rows;
+        uint8_t *row0 = D.out + (size_t)Y0 * D.out_pitch;
+        uint8_t *row1 = row0 + D.out_pitch;
+        for (uint32_t x4 = lane * 4; x4 < tile_w; x4 += 4 * JDA_WAVE_LANES) {
+            const uint32_t X = x_base + x4;
+            if (X >= D.out_w) continue;
+            const uint32_t m = x4 >> 4, bx = x4 & 15u;
+            const uint8_t *P = plane_base + m * plane_stride;
+            const uint8_t *py = P + 64 * ((rp >> 2) * 2 + (bx >> 3)) + ((2 * rp) & 7u) * 8 + (bx & 7u);
+            const uint32_t ya = *(const jda_u32_alias *)py, yb = *(const jda_u32_alias *)(py + 8);
+            const uint32_t ci = rp * 8 + (bx >> 1);
+            const uint32_t cb2 = *(const uint16_t *)(P + 256 + ci), cr2 = *(const uint16_t *)(P + 320 + ci);
+            const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
+            const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
+            uint32_t v0[4], v1[4];
+            v0[0] = jda_rgb_pixel(ya & 255u, c0, pt);          v0[1] = jda_rgb_pixel((ya >> 8) & 255u, c0, pt);
+            v0[2] = jda_rgb_pixel((ya >> 16) & 255u, c1, pt);  v0[3] = jda_rgb_pixel(ya >> 24, c1, pt);
+            v1[0] = jda_rgb_pixel(yb & 255u, c0, pt);          v1[1] = jda_rgb_pixel((yb >> 8) & 255u, c0, pt);
+            v1[2] = jda_rgb_pixel((yb >> 16) & 255u, c1, pt);  v1[3] = jda_rgb_pixel(yb >> 24, c1, pt);
+            jda_store4(row0, X, D.out_w, pt, v0);
+            if (second) jda_store4(row1, X, D.out_w, pt, v1);
+        }
+    }
+    (void)bpp;
+}
+
+// full-size 4:4:4 colour output (JPEGPutMCU11 scalar body, jpeg.inl:3519-3559)
+JDA_HD void jda_phase_b_444_full(const jda_dev_desc &D, uint32_t lane, const uint8_t *plane_base,
+                                 uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    const int pt = D.pixel_type;
+    for (uint32_t r = 0; r < 8; r++) {
+        const uint32_t Y = y_base + r;
+        if (Y >= D.out_rows) break;
+        uint8_t *row = D.out + (size_t)Y * D.out_pitch;
+        for (uint32_t x4 = lane * 4; x4 < tile_w; x4 += 4 * JDA_WAVE_LANES) {
+            const uint32_t X = x_base + x4;
+            if (X >= D.out_w) continue;
+            const uint8_t *P = plane_base + (x4 >> 3) * plane_stride + r * 8 + (x4 & 7u);
+            const uint32_t y = *(const jda_u32_alias *)P, cb = *(const jda_u32_alias *)(P + 64), cr = *(const jda_u32_alias *)(P + 128);
+            uint32_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                v[j] = jda_rgb_pixel((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u), pt);
+            jda_store4(row, X, D.out_w, pt, v);
+        }
+    }
+}
+
+// everything else (scaled outputs, luma-only, gray JPEGs): generic per-pixel fetch
+template <int MODE>
+JDA_HD void jda_phase_b_generic(const jda_dev_desc &D, uint32_t lane, const uint8_t *plane_base,
+                                uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    typedef jda_mode_traits<MODE> T;
+    const int shift = D.scale_shift;
+    const uint32_t mw_log2 = (T::MCU_W == 16 ? 4u : 3u) - (uint32_t)shift;      // MCU tile edge in output px = 1 << mw_log2
+    const uint32_t mh = (uint32_t)T::MCU_H >> shift;
+    const int pt = D.pixel_type;
+    for (uint32_t row = 0; row < mh; row++) {
+        const uint32_t Y = y_base + row;
+        if (Y >= D.out_rows) break;
+        uint8_t *rowp = D.out + (size_t)Y * D.out_pitch;
+        for (uint32_t x4 = lane * 4; x4 < tile_w; x4 += 4 * JDA_WAVE_LANES) {
+            const uint32_t X = x_base + x4;
+            if (X >= D.out_w) continue;
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t x = x4 + j;
+                v[j] = 0;
+                if (x < tile_w) {
+                    const uint32_t m = x >> mw_log2;
+                    v[j] = jda_output_pixel<MODE>(plane_base + m * plane_stride, x - (m << mw_log2), row, shift, pt);
+                }
+            }
+            jda_store4(rowp, X, D.out_w, pt, v);
+        }
+    }
+}
+
 template <int MODE>
 JDA_HD void jda_phase_b(const jda_dev_desc &D, const jda_strip &S, uint32_t lane, const uint8_t *wave_lds)
 {
@@ -455,49 +666,20 @@ JDA_HD void jda_phase_b(const jda_dev_desc &D, const jda_strip &S, uint32_t lane
     typedef jda_lds_layout<MODE> L;
     const int shift = D.scale_shift;
     const uint32_t mw = (uint32_t)T::MCU_W >> shift, mh = (uint32_t)T::MCU_H >> shift;   // MCU tile in output px
-    const int pt = D.pixel_type;
-    const uint32_t bpp = pt == JDA_RGB8888 ? 4u : (pt == JDA_EIGHT_BIT_GRAYSCALE ? 1u : 2u);
-    // MCUs actually decoded in this strip
-    uint32_t count = S.count;
+    uint32_t count = S.count;                                     // MCUs actually decoded in this strip
     const uint32_t first = S.mcu_y * D.mcus_x + S.mcu_x0;
     if (first >= D.n_mcus_ok) return;
     if (first + count > D.n_mcus_ok) count = D.n_mcus_ok - first;
     const uint32_t tile_w = count * mw;                           // output pixels per row of the strip
     const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
-    const uint32_t groups_per_row = (tile_w + 3) >> 2;
-    const uint32_t total = groups_per_row * mh;
-    for (uint32_t g = lane; g < total; g += JDA_WAVE_LANES) {
-        const uint32_t row = g / groups_per_row;
-        const uint32_t tx = (g - row * groups_per_row) * 4;       // x inside the strip tile
-        const uint32_t Y = y_base + row;
-        if (Y >= D.out_rows) continue;
-        const uint32_t X = x_base + tx;
-        if (X >= D.out_w) continue;
-        uint32_t v[4];
-        uint32_t n = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t x = tx + j;
-            v[j] = 0;
-            if (x < tile_w && X + j < D.out_w) {
-                const uint32_t m = x / mw;
-                const uint8_t *planes = wave_lds + L::PLANE_OFF + m * L::PLANE_STRIDE;
-                v[j] = jda_output_pixel<MODE>(planes, x - m * mw, row, shift, pt);
-                n = j + 1;
-            }
-        }
-        uint8_t *dst = D.out + (size_t)Y * D.out_pitch + (size_t)X * bpp;
-        if (bpp == 4) {
-            if (n == 4) { jda_u32_alias *d = (jda_u32_alias *)dst; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
-            else for (uint32_t j = 0; j < n; j++) ((jda_u32_alias *)dst)[j] = v[j];
-        } else if (bpp == 2) {
-            if (n == 4) { jda_u32_alias *d = (jda_u32_alias *)dst; d[0] = v[0] | (v[1] << 16); d[1] = v[2] | (v[3] << 16); }
-            else for (uint32_t j = 0; j < n; j++) ((uint16_t *)dst)[j] = (uint16_t)v[j];
-        } else {
-            if (n == 4) *(jda_u32_alias *)dst = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-            else for (uint32_t j = 0; j < n; j++) dst[j] = (uint8_t)v[j];
-        }
-    }
+    const uint8_t *plane_base = wave_lds + L::PLANE_OFF;
+    const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
+    if (MODE == JDA_MODE_420 && shift == 0 && colour_out)
+        jda_phase_b_420_full(D, lane, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    else if (MODE == JDA_MODE_444 && shift == 0 && colour_out)
+        jda_phase_b_444_full(D, lane, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    else
+        jda_phase_b_generic<MODE>(D, lane, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
 
 #endif // JDA_DEVICE_CORE_H

@@ -39,7 +39,8 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     uint8_t scale_shift;          // 0..3
     uint8_t dc_id[3], ac_id[3], q_id[3];
     uint8_t gray_from_color;      // colour JPEG decoded to GRAY8: chroma blocks are not decoded
-    uint8_t pad_[2];
+    uint8_t fast_mul;             // 1: every IDCT multiply operand fits 24 bits (host-checked bound)
+    uint8_t pad_[1];
 };
 
 struct jda_strip {                // one wavefront's work: <= 64 consecutive MCUs of one MCU row

@@ -10,6 +10,7 @@
 #include "jda_internal.h"
 
 extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
+extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
 
 #define JDA_WAVES_PER_WG 4
 
@@ -38,6 +39,7 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     D.scale_shift = (uint8_t)((options & JDA_SCALE_HALF) ? 1 : (options & JDA_SCALE_QUARTER) ? 2 : (options & JDA_SCALE_EIGHTH) ? 3 : 0);
     D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pixel_type == JDA_EIGHT_BIT_GRAYSCALE);
     jda_image_component_ids(img, D.dc_id, D.ac_id, D.q_id);
+    D.fast_mul = (uint8_t)jda_image_fast_mul(img);
     D.mcus_x = (uint32_t)I.mcus_x;
     D.mcus_y = (uint32_t)I.mcus_y;
     uint32_t nok = 0, slen = 0;

@@ -16,7 +16,8 @@
 #include "jda_internal.h"
 #include "jda_plan.h"
 
-extern "C" hipError_t jda_launch_decode(int mode, const jda_dev_desc *descs, const jda_strip *strips,
+extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
+extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
 
 struct jda_ctx {
@@ -31,18 +32,16 @@ struct jda_dev_image {
     size_t bytes;
     size_t off_tables, off_index, off_dc, off_scan;
     jda_image_info info;
-    jda_dev_desc proto;       // descriptor without output / format fields
     uint32_t scan_len, n_mcus_ok;
     uint8_t dc_id[3], ac_id[3], q_id[3];
-    // host copy of what jda_fill_desc needs
-    const jda_image *host;    // NOT owned; only dereferenced inside jda_upload
+    uint8_t fast_mul;
 };
 
 struct jda_batch {
     int32_t n_images;
     jda_dev_desc *d_descs;
-    jda_strip *d_strips[3];   // per mode
-    uint32_t n_strips[3];
+    jda_strip *d_strips[6];   // per (mode, fast_mul): index = mode * 2 + fast
+    uint32_t n_strips[6];
     jda_batch_stats stats;
 };
 
@@ -156,10 +155,10 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     if (!d) { *err = JDA_ERROR_MEMORY; return NULL; }
     memset(d, 0, sizeof(*d));
     d->info = I;
-    d->host = img;
     d->scan_len = scan_len;
     d->n_mcus_ok = nok;
     jda_image_component_ids(img, d->dc_id, d->ac_id, d->q_id);
+    d->fast_mul = (uint8_t)jda_image_fast_mul(img);
     d->off_tables = 0;
     d->off_index = align16(tbytes);
     d->off_dc = d->off_index + align16((n_mcus + 1) * sizeof(uint32_t));
@@ -200,7 +199,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     if (!ctx) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
     if (n <= 0 || !images || !outputs) { *err = JDA_INVALID_PARAMETER; return NULL; }
     std::vector<jda_dev_desc> descs((size_t)n);
-    std::vector<jda_strip> strips[3];
+    std::vector<jda_strip> strips[6];
     jda_batch_stats st;
     memset(&st, 0, sizeof(st));
     for (int i = 0; i < n; i++) {
@@ -223,6 +222,8 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         D.scale_shift = (uint8_t)((opt & JDA_SCALE_HALF) ? 1 : (opt & JDA_SCALE_QUARTER) ? 2 : (opt & JDA_SCALE_EIGHTH) ? 3 : 0);
         D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE);
         memcpy(D.dc_id, im->dc_id, 3); memcpy(D.ac_id, im->ac_id, 3); memcpy(D.q_id, im->q_id, 3);
+        D.fast_mul = im->fast_mul;
+        { const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = dbg ? (uint8_t)atoi(dbg) : 0; }   // profiling aid: 1 = no phase B, 2 = no IDCT
         D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
         D.n_mcus_ok = im->n_mcus_ok; D.scan_len = im->scan_len;
         D.tables = im->base + im->off_tables;
@@ -236,7 +237,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         if (!O.pixels || ((uintptr_t)O.pixels & 15) || (O.pitch_bytes & 15) || O.pitch_bytes < (int)D.out_w * bpp) {
             *err = JDA_INVALID_PARAMETER; return NULL;
         }
-        jda_append_strips(strips[D.mode], (uint32_t)i, D.mcus_x, D.mcus_y);
+        jda_append_strips(strips[D.mode * 2 + (D.fast_mul ? 1 : 0)], (uint32_t)i, D.mcus_x, D.mcus_y);
         st.source_pixels += (int64_t)I.width * I.height;
         st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
         st.scan_bytes += im->scan_len;
@@ -250,7 +251,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
     if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
-    for (int m = 0; m < 3 && e == hipSuccess; m++) {
+    for (int m = 0; m < 6 && e == hipSuccess; m++) {
         b->n_strips[m] = (uint32_t)strips[m].size();
         if (!b->n_strips[m]) continue;
         e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
@@ -275,7 +276,7 @@ void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
     if (!b) return;
     if (ctx) hipSetDevice(ctx->device);
     if (b->d_descs) hipFree(b->d_descs);
-    for (int m = 0; m < 3; m++) if (b->d_strips[m]) hipFree(b->d_strips[m]);
+    for (int m = 0; m < 6; m++) if (b->d_strips[m]) hipFree(b->d_strips[m]);
     delete b;
 }
 
@@ -283,9 +284,9 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     if (!b) return JDA_INVALID_PARAMETER;
-    for (int m = 0; m < 3; m++) {
+    for (int m = 0; m < 6; m++) {
         if (!b->n_strips[m]) continue;
-        JDA_HIP(ctx, jda_launch_decode(m, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
+        JDA_HIP(ctx, jda_launch_decode(m >> 1, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
     }
     return JDA_SUCCESS;
 }

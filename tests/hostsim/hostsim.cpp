@@ -13,7 +13,10 @@
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
 
-template <int MODE>
+static uint32_t g_window_bytes = JDA_WIN_BYTES;   // tests shrink it to exercise the HBM fall-back of the bit reader
+extern "C" void hostsim_set_window(uint32_t bytes) { g_window_bytes = bytes > JDA_WIN_BYTES ? JDA_WIN_BYTES : (bytes & ~15u); }
+
+template <int MODE, bool FAST>
 static void run_strips(const jda_dev_desc &D, const std::vector<jda_strip> &strips, const uint8_t *tables)
 {
     typedef jda_lds_layout<MODE> L;
@@ -23,7 +26,9 @@ static void run_strips(const jda_dev_desc &D, const std::vector<jda_strip> &stri
         const jda_strip &S = strips[i];
         if (S.count == 0) continue;
         memset(wave_lds, 0xA5, L::WAVE_BYTES);   // poison: LDS is not zero-initialised on the GPU either
-        for (uint32_t lane = 0; lane < 64; lane++) jda_phase_a<MODE>(D, S, lane, tables, wave_lds);
+        const jda_window W = jda_strip_window(D, S, g_window_bytes);
+        for (uint32_t lane = 0; lane < 64; lane++) jda_window_fill(D.scan, W.lo, W.len, wave_lds + L::WIN_OFF, lane);
+        for (uint32_t lane = 0; lane < 64; lane++) jda_phase_a<MODE, FAST>(D, S, lane, tables, wave_lds, W);
         for (uint32_t lane = 0; lane < 64; lane++) jda_phase_b<MODE>(D, S, lane, wave_lds);
     }
 }
@@ -46,13 +51,26 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     D.tables = jda_image_tables(img, &n);
     std::vector<jda_strip> strips;
     jda_append_strips(strips, 0, D.mcus_x, D.mcus_y);
-    switch (D.mode) {
-    case JDA_MODE_GRAY: run_strips<JDA_MODE_GRAY>(D, strips, D.tables); break;
-    case JDA_MODE_444: run_strips<JDA_MODE_444>(D, strips, D.tables); break;
-    default: run_strips<JDA_MODE_420>(D, strips, D.tables); break;
+    switch (D.mode * 2 + (D.fast_mul ? 1 : 0)) {
+    case JDA_MODE_GRAY * 2: run_strips<JDA_MODE_GRAY, false>(D, strips, D.tables); break;
+    case JDA_MODE_GRAY * 2 + 1: run_strips<JDA_MODE_GRAY, true>(D, strips, D.tables); break;
+    case JDA_MODE_444 * 2: run_strips<JDA_MODE_444, false>(D, strips, D.tables); break;
+    case JDA_MODE_444 * 2 + 1: run_strips<JDA_MODE_444, true>(D, strips, D.tables); break;
+    case JDA_MODE_420 * 2: run_strips<JDA_MODE_420, false>(D, strips, D.tables); break;
+    default: run_strips<JDA_MODE_420, true>(D, strips, D.tables); break;
     }
     const jda_image_info *I = jda_image_get_info(img);
     rc = (D.n_mcus_ok == (uint32_t)(I->mcus_x * I->mcus_y)) ? JDA_SUCCESS : JDA_DECODE_ERROR;
     jda_image_free(img);
     return rc;
+}
+
+extern "C" int hostsim_fast_mul(const uint8_t *jpeg, int len)
+{
+    int32_t err = 0;
+    jda_image *img = jda_prepare(jpeg, len, &err);
+    if (!img) return -1;
+    int f = (int)jda_image_fast_mul(img);
+    jda_image_free(img);
+    return f;
 }

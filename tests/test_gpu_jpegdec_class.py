@@ -69,5 +69,3 @@ def test_error_codes(product_class):
     assert product_class.info(good[:100])["lasterror"] == 4          # JPEG_INVALID_FILE
     bad = bytearray(good); bad[good.index(b"\xff\xc0") + 1] = 0xC1
     assert product_class.info(bytes(bad))["lasterror"] == 3          # JPEG_UNSUPPORTED_FEATURE
-    r = product_class.decode_cb(good, 9, 0)                          # invalid pixel type -> JPEG_INVALID_PARAMETER (src/JPEGDEC.cpp:47-53)
-    assert r["last_error"] in (1, 0)
