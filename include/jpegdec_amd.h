@@ -74,13 +74,14 @@ typedef struct jda_image_info {
     int32_t mcu_w, mcu_h;         /* MCU size in source pixels */
     int32_t mcus_x, mcus_y;       /* MCU grid (jpeg.inl:5013-5037) */
     int32_t scan_offset;          /* byte offset of the entropy-coded data */
+    int32_t blocks_per_mcu;       /* 1 gray, 3 for 4:4:4, 6 for 4:2:0 (Y.. Cb Cr in scan order) */
 } jda_image_info;
 
 /* Header parse only.  Accept/reject rules follow JPEGParseInfo (jpeg.inl:1572-1785). */
 int jda_parse(const uint8_t *jpeg, int32_t len, jda_image_info *info);
 
 /* An image made ready for the GPU (host memory): expanded Huffman LUTs, prescaled quant tables,
- * the filtered scan and the per-MCU index produced by the serial pre-scan. */
+ * the filtered scan and the per-block index produced by the serial pre-scan. */
 typedef struct jda_image jda_image;
 
 /* Parse + table build + filter + pre-scan.  `options` are the JDA_SCALE_* / JDA_LUMA_ONLY bits the
@@ -90,14 +91,15 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
 void jda_image_free(jda_image *img);
 
 const jda_image_info *jda_image_get_info(const jda_image *img);
-/* views into the prepared image (owned by img): the filtered scan, the per-MCU index
- * (n_mcus+1 entries: (byte position << 7) | bit offset, in the reference bit reader's
- * coordinates (pBuf, ulBitOff) at each MCU start), and the DC predictors at each MCU start
- * (n_mcus * ncomp int16).  *n_mcus_ok < mcus_x*mcus_y means the pre-scan hit an invalid code
- * there (the reference returns JPEG_DECODE_ERROR at that MCU, jpeg.inl:2137, 2237, 5354-5356). */
+/* views into the prepared image (owned by img): the filtered scan; the per-BLOCK index
+ * (n_blocks+1 entries, n_blocks = mcus_x*mcus_y*blocks_per_mcu, scan order): (byte position << 7) |
+ * bit offset = the reference bit reader's state (bb.pBuf, bb.ulBitOff) on entry to JPEGDecodeMCU
+ * for that block; and the DC predictor of the block's component on entry (n_blocks int16).
+ * *n_mcus_ok < mcus_x*mcus_y means the pre-scan hit an invalid code in that MCU (the reference
+ * returns JPEG_DECODE_ERROR there, jpeg.inl:2137, 2237, 5354-5356). */
 const uint8_t *jda_image_scan(const jda_image *img, uint32_t *len);
-const uint32_t *jda_image_mcu_index(const jda_image *img, uint32_t *n_mcus_ok);
-const int16_t *jda_image_mcu_dc(const jda_image *img);
+const uint32_t *jda_image_block_index(const jda_image *img, uint32_t *n_mcus_ok);
+const int16_t *jda_image_block_dc(const jda_image *img);
 /* the table blob uploaded to the GPU: DC LUTs 2x1024 B, AC LUTs 2x2048 uint16, quant 4x64 int16 */
 const uint8_t *jda_image_tables(const jda_image *img, uint32_t *bytes);
 /* number of places where the reference's un-refilled magnitude read drops low bits
@@ -160,7 +162,7 @@ typedef struct jda_batch_stats {
     int64_t source_pixels;      /* sum of width*height */
     int64_t output_bytes;       /* bytes the kernels write */
     int64_t scan_bytes;         /* filtered entropy-coded bytes read */
-    int64_t index_bytes;        /* per-MCU index + DC predictor bytes read */
+    int64_t index_bytes;        /* per-block index + DC predictor bytes read */
     int64_t table_bytes;
     int32_t n_launches;         /* kernel launches per jda_batch_decode */
     int32_t n_workgroups;

@@ -22,7 +22,7 @@ class JdaError(RuntimeError):
 class ImageInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "ncomp", "subsample", "bpp", "jpeg_type", "restart_interval",
-        "orientation", "mcu_w", "mcu_h", "mcus_x", "mcus_y", "scan_offset")]
+        "orientation", "mcu_w", "mcu_h", "mcus_x", "mcus_y", "scan_offset", "blocks_per_mcu")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -53,8 +53,8 @@ _PROTOTYPES = [
     ("jda_image_free", None, [_P]),
     ("jda_image_get_info", C.POINTER(ImageInfo), [_P]),
     ("jda_image_scan", _P, [_P, C.POINTER(C.c_uint32)]),
-    ("jda_image_mcu_index", _P, [_P, C.POINTER(C.c_uint32)]),
-    ("jda_image_mcu_dc", _P, [_P]),
+    ("jda_image_block_index", _P, [_P, C.POINTER(C.c_uint32)]),
+    ("jda_image_block_dc", _P, [_P]),
     ("jda_image_tables", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_truncation_events", C.c_uint32, [_P]),
     ("jda_output_geometry", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 5),
@@ -158,15 +158,20 @@ class PreparedImage:
         p = self.lib.jda_image_scan(self.handle, C.byref(n))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
 
-    def mcu_index(self):
+    @property
+    def n_blocks(self):
+        return self.n_mcus * self.info.blocks_per_mcu
+
+    def block_index(self):
+        """(index[n_blocks+1] uint32 = pos<<7|off per block, n_mcus_ok)"""
         n = C.c_uint32(0)
-        p = self.lib.jda_image_mcu_index(self.handle, C.byref(n))
-        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(self.n_mcus + 1,)).copy()
+        p = self.lib.jda_image_block_index(self.handle, C.byref(n))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(self.n_blocks + 1,)).copy()
         return arr, n.value
 
-    def mcu_dc(self) -> np.ndarray:
-        p = self.lib.jda_image_mcu_dc(self.handle)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(self.n_mcus, self.info.ncomp)).copy()
+    def block_dc(self) -> np.ndarray:
+        p = self.lib.jda_image_block_dc(self.handle)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(self.n_blocks,)).copy()
 
     def tables(self) -> np.ndarray:
         n = C.c_uint32(0)

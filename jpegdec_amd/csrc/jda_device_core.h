@@ -28,22 +28,41 @@
 #define JDA_HD static inline __attribute__((always_inline))
 #endif
 
-// ---- per-wave LDS layout -------------------------------------------------------------------
-#define JDA_COEF_STRIDE 136      // bytes per lane: 64 int16 + 8 pad (34 dwords: conflict-free b64 access)
-#define JDA_WAVE_LANES 64
+// ---- workgroup tile and LDS layout ------------------------------------------------------------
+// One 192-thread workgroup (3 wavefronts) decodes one "tile": 192 consecutive 8x8 blocks of one MCU
+// row = 32 MCUs of 4:2:0, 64 MCUs of 4:4:4 or 192 MCUs of a gray image.
+#define JDA_WG_THREADS 192
+#define JDA_TILE_BLOCKS 192
+#define JDA_COEF_STRIDE 136      // bytes per block in LDS: 64 int16 + 8 pad (row reads stay 8-byte aligned)
+#define JDA_WIN_BYTES 2048       // LDS window over the tile's slice of the filtered scan
+#define JDA_COLLIST_ENTRIES 1536 // 192 blocks x 8 columns, uint16 each
 
 template <int MODE> struct jda_mode_traits;
-template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8 }; };
-template <> struct jda_mode_traits<JDA_MODE_444>  { enum { NLUMA = 1, NBLK = 3, MCU_W = 8, MCU_H = 8 }; };
-template <> struct jda_mode_traits<JDA_MODE_420>  { enum { NLUMA = 4, NBLK = 6, MCU_W = 16, MCU_H = 16 }; };
+template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
+template <> struct jda_mode_traits<JDA_MODE_444>  { enum { NLUMA = 1, NBLK = 3, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
+template <> struct jda_mode_traits<JDA_MODE_420>  { enum { NLUMA = 4, NBLK = 6, MCU_W = 16, MCU_H = 16, MCU_W_LOG2 = 4 }; };
+
+// LDS copy of the table blob: DC LUTs, the SHORT halves of the AC LUTs (codes that do not start
+// with six 1 bits; the long halves are rare and stay in global memory), quantisers, zigzag.
+#define JDA_LT_DC      0         // 2 x 1024
+#define JDA_LT_AC      2048      // 2 x 1024 uint16
+#define JDA_LT_QUANT   6144      // 4 x 64 int16
+#define JDA_LT_ZIGZAG  6656      // 64
+#define JDA_LT_BYTES   6720
 
 template <int MODE> struct jda_lds_layout {
     enum {
-        PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * 64 + 8,   // bytes per lane (pad 2 dwords)
-        COEF_OFF = 0,
-        PLANE_OFF = JDA_WAVE_LANES * JDA_COEF_STRIDE,
-        WIN_OFF = PLANE_OFF + JDA_WAVE_LANES * PLANE_STRIDE,       // multiple of 16
-        WAVE_BYTES = WIN_OFF + 4096                                // + JDA_WIN_BYTES
+        MCUS = JDA_TILE_BLOCKS / jda_mode_traits<MODE>::NBLK,        // MCUs per tile
+        PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * 64 + 8,        // bytes per MCU (8 pad: conflict-free colour reads)
+        TAB_OFF = 0,
+        COEF_OFF = JDA_LT_BYTES,
+        PLANE_OFF = COEF_OFF + JDA_TILE_BLOCKS * JDA_COEF_STRIDE,
+        INFO_OFF = PLANE_OFF + MCUS * PLANE_STRIDE,                 // uint32 flags per block
+        ROWLIST_OFF = INFO_OFF + JDA_TILE_BLOCKS * 4,               // 4 classes x 192 block ids (uint8)
+        CNT_OFF = ROWLIST_OFF + 4 * JDA_TILE_BLOCKS,                // 8 uint32 counters
+        COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
+        WIN_OFF = COLLIST_OFF + JDA_COLLIST_ENTRIES * 2,
+        TOTAL_BYTES = WIN_OFF + JDA_WIN_BYTES
     };
 };
 
@@ -87,7 +106,7 @@ JDA_HD uint64_t jda_be64_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint3
     return ((uint64_t)__builtin_bswap32(a) << 32) | __builtin_bswap32(b);
 }
 
-// The wave's view of the filtered scan: bytes [win_lo, win_lo + win_len) are staged in LDS (copied
+// The workgroup's view of the filtered scan: bytes [win_lo, win_lo + win_len) are staged in LDS (copied
 // with coalesced 16-byte loads by jda_window_fill); anything beyond is read from HBM directly.
 struct jda_bitreader {
     const uint8_t *base;     // filtered scan in global memory (4-byte aligned, zero padded)
@@ -120,15 +139,15 @@ JDA_HD void jda_refill(jda_bitreader &br)
     }
 }
 
-// Cooperative copy of the strip's part of the scan into the wave's LDS window: lane l copies the
-// 16-byte chunks l, l+64, ...  Every lane of the wave calls it; the wave then fences.
+// Cooperative copy of the tile's part of the scan into the LDS window: thread t copies the 16-byte
+// chunks t, t+192, ...  Every thread of the workgroup calls it; a barrier follows.
 struct jda_chunk16 { uint32_t w[4]; };
 typedef jda_chunk16 __attribute__((may_alias)) jda_chunk16_alias;
 JDA_HD void jda_window_fill(const uint8_t *scan, uint32_t win_lo, uint32_t win_len, uint8_t *win, uint32_t lane)
 {
     const jda_chunk16_alias *src = (const jda_chunk16_alias *)(scan + win_lo);
     jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
-    for (uint32_t i = lane; i < (win_len >> 4); i += JDA_WAVE_LANES) dst[i] = src[i];
+    for (uint32_t i = lane; i < (win_len >> 4); i += JDA_WG_THREADS) dst[i] = src[i];
 }
 
 // EXTEND of the next s bits of the (un-refilled) window (jpeg.inl:2249-2252, 2155-2158)
@@ -139,12 +158,38 @@ JDA_HD int32_t jda_take_extend(uint64_t bits, uint32_t off, uint32_t s)
     return (top & 0x80000000u) ? (int32_t)v : (int32_t)v - (int32_t)((1u << s) - 1u);
 }
 
+// LDS atomic add (list append); on the host emulator threads run one after another
+JDA_HD uint32_t jda_lds_add(uint32_t *p, uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    const uint32_t old = *p;
+    *p = old + v;
+    return old;
+#endif
+}
+
+JDA_HD uint32_t jda_popcount8(uint32_t v)
+{
+    return (uint32_t)__builtin_popcount(v & 0xffu);
+}
+
 // ---- Huffman / RLE expand of one 8x8 block (jpeg.inl:2090-2274) ------------------------------
-// LIMIT: 64 = store every coefficient, 5 = 1/4 and 1/8 scale (zigzag 1..4 only), 1 = skip block.
-// coef: lane-private int16[64] (natural order).  Returns the reference's u16MCUFlags.
+// LIMIT: 64 = store every coefficient; 5 = 1/4 scale (zigzag 1..4 only, jpeg.inl:2117-2119);
+//        1 = 1/8 scale: only the DC term is wanted.
+// Because every block has its own index entry, decoding may stop as soon as the wanted
+// coefficients are known (the reference has to walk to EOB to find the next block).
+// coef: the block's int16[64] in LDS (natural order).  Returns the reference's u16MCUFlags.
+struct jda_tables {
+    const uint8_t *dc;        // LDS: 1024-byte DC LUT of this block's component
+    const uint16_t *ac_short; // LDS: 1024 entries
+    const uint16_t *ac_long;  // global: 1024 entries (codes starting 111111)
+    const uint8_t *zigzag;    // LDS
+};
+
 template <int LIMIT>
-JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const uint8_t *dc_lut, const uint16_t *ac_lut,
-                                 const uint8_t *zigzag, int16_t *coef, int32_t &pred)
+JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred)
 {
     uint32_t flags = 0;
     jda_refill(br);
@@ -158,11 +203,11 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const uint8_t *dc_lut, const
     // DC  (:2129-2165)
     uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
     code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
-    uint32_t e = dc_lut[code];
+    uint32_t e = T.dc[code];
     br.off += e >> 4;
     const uint32_t s = e & 0xfu;
     if (s) {
-        const int32_t folded = (int8_t)dc_lut[code + 512];
+        const int32_t folded = (int8_t)T.dc[code + 512];
         if (folded) pred += folded;
         else {
             jda_refill(br);
@@ -170,22 +215,23 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const uint8_t *dc_lut, const
             br.off += s;
         }
     }
-    if (LIMIT > 1) coef[0] = (int16_t)pred;
+    if (LIMIT == 1) return 0;
+    coef[0] = (int16_t)pred;
     // AC  (:2223-2265).  The reference refills at the top AND the bottom of every iteration; the top
     // one is a no-op after a bottom one, so one refill before the loop + one per iteration is identical.
     int k = 1;
     jda_refill(br);
-    while (k < 64) {
+    while (k < LIMIT) {
         code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
-        code = code >= 0xfc00u ? (code & 0x7ffu) : (code >> 6);
-        e = ac_lut[code];
+        if (code >= 0xfc00u) e = T.ac_long[code & 0x3ffu];           // usHuffAC[1024 + ...]  :2232-2233
+        else e = T.ac_short[code >> 6];
         br.off += e >> 8;
         e &= 0xffu;
         if (e == 0) break;                              // EOB (no refill follows)
         k += (int)(e >> 4);
         const uint32_t ms = e & 0xfu;
-        if (LIMIT > 1 && k < LIMIT && ms) {
-            const uint32_t n = zigzag[k];
+        if (k < LIMIT && ms) {
+            const uint32_t n = T.zigzag[k];
             flags |= (1u << (n & 7u)) | (n << 8);
             coef[n] = (int16_t)jda_take_extend(br.bits, br.off, ms);
         }
@@ -215,28 +261,28 @@ template <bool FAST> JDA_HD int32_t jda_mulc(int32_t x, int32_t c)
 // the occupancy flags (jpeg.inl:2686-2743).  Returns the eight range-limited bytes packed LE.
 struct jda_row8 { uint32_t lo, hi; };
 
-JDA_HD jda_row8 jda_idct_row(const int32_t s[8], uint32_t flags)
+// RC: 0 = only columns 0-1 occupied, 1 = columns 0-3, 2 = any (the block-level tests of :2686-2688)
+template <int RC>
+JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
 {
     int32_t t0, t1, t2, t3, t4, t5, t6, t7;
-    if ((flags & 0xf0u) == 0) {
-        if ((flags & 0xfcu) == 0) {                                  // :2688-2697
-            t0 = t1 = t2 = t3 = s[0];
-            t7 = s[1];
-            t6 = (t7 * 217) >> 8;
-            t5 = (t7 * 145) >> 8;
-            t4 = -((t7 * 51) >> 8);
-        } else {                                                     // :2698-2718
-            const int32_t a = s[0], c = s[2];
-            const int32_t m = (c * 106) >> 8;
-            t0 = a + c; t3 = a - c; t1 = a + m; t2 = a - m;
-            const int32_t z13 = s[3], z11 = s[1];
-            t7 = z11 + z13;
-            const int32_t t11 = ((z11 - z13) * 362) >> 8;
-            const int32_t z5 = ((z11 - z13) * 473) >> 8;
-            const int32_t t10 = ((z11 * 277) >> 8) - z5;
-            const int32_t t12 = ((z13 * 669) >> 8) + z5;
-            t6 = t12 - t7; t5 = t11 - t6; t4 = t10 + t5;
-        }
+    if (RC == 0) {                                                   // :2688-2697
+        t0 = t1 = t2 = t3 = s[0];
+        t7 = s[1];
+        t6 = (t7 * 217) >> 8;
+        t5 = (t7 * 145) >> 8;
+        t4 = -((t7 * 51) >> 8);
+    } else if (RC == 1) {                                            // :2698-2718
+        const int32_t a = s[0], c = s[2];
+        const int32_t m = (c * 106) >> 8;
+        t0 = a + c; t3 = a - c; t1 = a + m; t2 = a - m;
+        const int32_t z13 = s[3], z11 = s[1];
+        t7 = z11 + z13;
+        const int32_t t11 = ((z11 - z13) * 362) >> 8;
+        const int32_t z5 = ((z11 - z13) * 473) >> 8;
+        const int32_t t10 = ((z11 * 277) >> 8) - z5;
+        const int32_t t12 = ((z13 * 669) >> 8) + z5;
+        t6 = t12 - t7; t5 = t11 - t6; t4 = t10 + t5;
     } else {                                                         // :2720-2743
         const int32_t t10 = s[0] + s[4], t11 = s[0] - s[4];
         const int32_t t13 = s[2] + s[6];
@@ -261,11 +307,11 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8], uint32_t flags)
 
 // Column stage for one column (jpeg.inl:2561-2676): c[r] = raw coefficient of row r, q[r] its
 // prescaled quantiser; results truncated to int16 as the reference stores them back.
-template <bool FAST>
-JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], bool rows47_empty, int32_t out[8])
+template <bool FAST, bool HALF>
+JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], int32_t out[8])
 {
     int32_t t0, t1, t2, t3, t4, t5, t6, t7;
-    if (rows47_empty) {                                              // :2561-2601
+    if (HALF) {                                              // :2561-2601
         const int32_t a = c[0] * q[0];
         const int32_t b = c[2] * q[2];
         const int32_t m = jda_mulc<FAST>(b, 106) >> 8;
@@ -312,29 +358,6 @@ JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], bool rows47_emp
     out[2] = (int16_t)(t2 + t5); out[3] = (int16_t)(t3 - t4);
     out[4] = (int16_t)(t3 + t4); out[5] = (int16_t)(t2 - t5);
     out[6] = (int16_t)(t1 - t6); out[7] = (int16_t)(t0 - t7);
-}
-
-// Full 8x8 block: coef (lane-private, natural order) -> 64 bytes written as 16 dwords to `out`.
-template <bool FAST>
-JDA_HD void jda_idct_block(const int16_t *coef, const int16_t *quant, uint32_t flags, jda_u32_alias *out)
-{
-    int32_t ws[64];
-    const bool rows47_empty = (flags & 0x2000u) == 0;
-#pragma unroll
-    for (int col = 0; col < 8; col++) {
-        int32_t c[8], q[8], r[8];
-#pragma unroll
-        for (int row = 0; row < 8; row++) { c[row] = coef[row * 8 + col]; q[row] = quant[row * 8 + col]; }
-        jda_idct_col<FAST>(c, q, rows47_empty, r);
-#pragma unroll
-        for (int row = 0; row < 8; row++) ws[row * 8 + col] = r[row];
-    }
-#pragma unroll
-    for (int row = 0; row < 8; row++) {
-        const jda_row8 p = jda_idct_row(&ws[row * 8], flags);
-        out[row * 2] = p.lo;
-        out[row * 2 + 1] = p.hi;
-    }
 }
 
 // 1/4 scale: 2x2 block from coefficients 0,1,8,9 (jpeg.inl:2305-2326) -> 4 bytes
@@ -440,90 +463,231 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
     return jda_pixel_565(p, pixel_type == JDA_RGB565_BIG_ENDIAN);
 }
 
-// ---- the wave's bitstream window --------------------------------------------------------------
-// The strip's MCUs are consecutive in the scan, so the bytes the wave needs are one contiguous run
-// starting at the first MCU's position; up to JDA_WIN_BYTES of it are staged in LDS.
-#define JDA_WIN_BYTES 4096
-struct jda_window { uint32_t lo, len; };
 
-JDA_HD jda_window jda_strip_window(const jda_dev_desc &D, const jda_strip &S, uint32_t max_bytes)
+// ================================================================================================
+// Tile phases.  Every thread of the 192-thread workgroup runs each phase; a workgroup barrier
+// separates consecutive phases (the host emulator runs all threads of a phase, then the next).
+//
+//   P0  tables -> LDS, the tile's slice of the scan -> LDS window, zero the list counters
+//   P1  thread = block: Huffman/RLE expand into the block's int16[64] in LDS (JPEGDecodeMCU,
+//       jpeg.inl:2090-2274); classify the block and append its non-empty columns / its row class to
+//       work lists.  Scaled 1/4 and 1/8 outputs are finished here (2x2 IDCT or DC fill).
+//   P2  thread = (block, non-empty column): dequant + column stage of the IDCT (jpeg.inl:2553-2679).
+//       Empty columns cost nothing -- the reference's own shortcut (:2555-2560), made data-parallel
+//       by compacting the work items with LDS atomics.
+//   P3  thread = (block, row): row stage + range limit (jpeg.inl:2680-2797), blocks grouped by the
+//       reference's row variant so that a pass never mixes variants.  8 samples -> the MCU's plane.
+//   P4  threads tile the output rows: colour conversion and coalesced stores (JPEGPutMCU*).
+// ================================================================================================
+
+struct jda_tile_ctx {                 // wave-uniform facts about the tile, computed once per thread
+    uint32_t first_mcu;               // linear MCU index of the tile's first MCU
+    uint32_t count;                   // MCUs of the tile that are decoded (<= MCUS, clipped by n_mcus_ok)
+    uint32_t first_block;             // linear block index of the tile's first block
+    uint32_t win_lo, win_len;         // bytes of the scan staged in LDS
+};
+
+template <int MODE>
+JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
 {
-    jda_window w;
-    w.lo = 0; w.len = 0;
-    const uint32_t first = S.mcu_y * D.mcus_x + S.mcu_x0;
-    if (S.count == 0 || first >= D.n_mcus_ok) return w;
-    uint32_t last = first + S.count;                         // index has n_mcus + 1 entries
-    if (last > D.n_mcus_ok) last = D.n_mcus_ok;
-    w.lo = (D.mcu_index[first] >> JDA_INDEX_OFF_BITS) & ~15u;
-    // a lane may read 12 bytes past the (unrefilled) position of the next MCU's start + 8
-    uint32_t hi = ((D.mcu_index[last] >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
-    const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u; // never read past the padded allocation
-    if (hi > cap) hi = cap;
-    w.len = hi > w.lo ? hi - w.lo : 0;
-    if (w.len > max_bytes) w.len = max_bytes;
-    return w;
+    typedef jda_mode_traits<MODE> T;
+    jda_tile_ctx C;
+    C.first_mcu = S.mcu_y * D.mcus_x + S.mcu_x0;
+    C.count = S.count;
+    if (C.first_mcu >= D.n_mcus_ok) C.count = 0;
+    else if (C.first_mcu + C.count > D.n_mcus_ok) C.count = D.n_mcus_ok - C.first_mcu;
+    C.first_block = C.first_mcu * T::NBLK;
+    C.win_lo = 0; C.win_len = 0;
+    if (C.count) {
+        // the tile's blocks are consecutive in the scan: stage one contiguous run of bytes
+        C.win_lo = (D.blk_index[C.first_block] >> JDA_INDEX_OFF_BITS) & ~15u;
+        // a thread may read 12 bytes past (start of the block after the tile) + 8
+        uint32_t hi = ((D.blk_index[C.first_block + C.count * T::NBLK] >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
+        const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;      // never past the padded allocation
+        if (hi > cap) hi = cap;
+        C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
+        if (C.win_len > JDA_WIN_BYTES) C.win_len = JDA_WIN_BYTES;
+    }
+    return C;
 }
 
-// ---- phase A: one lane decodes one MCU into its LDS planes ----------------------------------
-template <int MODE, bool FAST>
-JDA_HD void jda_phase_a(const jda_dev_desc &D, const jda_strip &S, uint32_t lane,
-                        const uint8_t *tables, uint8_t *wave_lds, const jda_window &W)
+// ---- P0 ---------------------------------------------------------------------------------------
+template <int MODE>
+JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t t, uint8_t *lds, uint32_t win_cap)
+{
+    typedef jda_lds_layout<MODE> L;
+    const jda_chunk16_alias *blob = (const jda_chunk16_alias *)D.tables;
+    jda_chunk16_alias *tab = (jda_chunk16_alias *)(lds + L::TAB_OFF);
+    // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;
+    // quant + zigzag: blob[10240, 10816) -> LT_QUANT
+    for (uint32_t i = t; i < JDA_LT_BYTES / 16; i += JDA_WG_THREADS) {
+        uint32_t src;
+        if (i < 128) src = i;                                   // DC
+        else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
+        else if (i < 384) src = (JDA_TB_AC >> 4) + 256 + (i - 256); // AC table 1, short half
+        else src = (JDA_TB_QUANT >> 4) + (i - 384);
+        tab[i] = blob[src];
+    }
+    if (t < 8) ((uint32_t *)(lds + L::CNT_OFF))[t] = 0;
+    const uint32_t len = C.win_len < win_cap ? C.win_len : win_cap;
+    jda_window_fill(D.scan, C.win_lo, len, lds + L::WIN_OFF, t);
+}
+
+// ---- P1 ---------------------------------------------------------------------------------------
+template <int MODE>
+JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t t, uint8_t *lds, uint32_t win_cap)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
-    if (lane >= S.count) return;
-    const uint32_t mcu = S.mcu_y * D.mcus_x + S.mcu_x0 + lane;
-    if (mcu >= D.n_mcus_ok) return;
-    int16_t *coef = (int16_t *)(wave_lds + L::COEF_OFF + lane * JDA_COEF_STRIDE);
-    uint8_t *planes = wave_lds + L::PLANE_OFF + lane * L::PLANE_STRIDE;
-    const uint8_t *zigzag = tables + JDA_TB_ZIGZAG;
+    const uint32_t m = t / T::NBLK, b = t - m * T::NBLK;         // MCU within tile, block within MCU
+    if (m >= C.count) return;
+    if (MODE != JDA_MODE_GRAY && D.gray_from_color && b >= (uint32_t)T::NLUMA) return;   // :5225-5233 chroma never decoded
+    const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
+    const uint8_t *tab = lds + L::TAB_OFF;
+    jda_tables TB;
+    TB.dc = tab + JDA_LT_DC + D.dc_id[c] * 1024;
+    TB.ac_short = (const uint16_t *)(tab + JDA_LT_AC) + D.ac_id[c] * 1024;
+    TB.ac_long = (const uint16_t *)(D.tables + JDA_TB_AC) + D.ac_id[c] * 2048 + 1024;
+    TB.zigzag = tab + JDA_LT_ZIGZAG;
+    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + D.q_id[c] * 64;
+    int16_t *coef = (int16_t *)(lds + L::COEF_OFF + t * JDA_COEF_STRIDE);
+    uint8_t *plane = lds + L::PLANE_OFF + m * L::PLANE_STRIDE + b * 64;
 
     jda_bitreader br;
     br.base = D.scan;
-    br.win = wave_lds + L::WIN_OFF;
-    br.win_lo = W.lo;
-    br.win_len = W.len;
-    const uint32_t ix = D.mcu_index[mcu];
+    br.win = lds + L::WIN_OFF;
+    br.win_lo = C.win_lo;
+    br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
+    const uint32_t gb = C.first_block + t;
+    const uint32_t ix = D.blk_index[gb];
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
     br.bits = jda_load_be64(br, br.pos);
-    int32_t pred[3];
-    pred[0] = D.mcu_dc[mcu * D.ncomp];
-    pred[1] = pred[2] = 0;
-    if (MODE != JDA_MODE_GRAY) { pred[1] = D.mcu_dc[mcu * 3 + 1]; pred[2] = D.mcu_dc[mcu * 3 + 2]; }
+    int32_t pred = D.blk_dc[gb];
 
     const int shift = D.scale_shift;
-    const int nblk = (MODE != JDA_MODE_GRAY && D.gray_from_color) ? T::NLUMA : T::NBLK;   // :5225-5233
-    for (int b = 0; b < nblk; b++) {
-        const int c = b < T::NLUMA ? 0 : b - T::NLUMA + 1;
-        const uint8_t *dcl = tables + JDA_TB_DC + D.dc_id[c] * 1024;
-        const uint16_t *acl = (const uint16_t *)(tables + JDA_TB_AC) + D.ac_id[c] * 2048;
-        // the quantisers are wave-uniform: read them from the global table blob so the compiler
-        // keeps them in SGPRs (scalar loads) instead of spending LDS reads on a broadcast
-        const int16_t *quant = (const int16_t *)(D.tables + JDA_TB_QUANT) + D.q_id[c] * 64;
-        jda_u32_alias *out = (jda_u32_alias *)(planes + 64 * b);
-        int32_t &p = pred[c];
-        if (shift >= 2) {
-            const uint32_t flags = jda_decode_block<5>(br, dcl, acl, zigzag, coef, p);
-            if (flags == 0 || shift == 3) {                                   // :5146-5154 (iMaxFill = 1)
-                const uint32_t v = jda_range_limit5(p * (int32_t)quant[0]);
-                out[0] = v * 0x01010101u;
-            } else out[0] = jda_idct_2x2(coef, quant);
-        } else {
-            const uint32_t flags = jda_decode_block<64>(br, dcl, acl, zigzag, coef, p);
-            if (flags == 0) {                                                 // DC-only bypass
-                const uint32_t v = jda_range_limit5(p * (int32_t)quant[0]) * 0x01010101u;
+    if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
+        jda_decode_block<1>(br, TB, coef, pred);
+        *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
+        return;
+    }
+    if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
+        const uint32_t flags = jda_decode_block<5>(br, TB, coef, pred);
+        *(jda_u32_alias *)plane = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
+                                             : jda_idct_2x2(coef, quant);
+        return;
+    }
+    const uint32_t flags = jda_decode_block<64>(br, TB, coef, pred);
+    ((uint32_t *)(lds + L::INFO_OFF))[t] = flags;
+    uint32_t *cnt = (uint32_t *)(lds + L::CNT_OFF);
+    uint8_t *rowlist = lds + L::ROWLIST_OFF;
+    if (flags == 0) {                                            // DC-only block (:5146-5154): row class 3
+        rowlist[3 * JDA_TILE_BLOCKS + jda_lds_add(&cnt[5], 1)] = (uint8_t)t;
+        return;
+    }
+    // columns that hold data (column 0 always, :2555); rows 4-7 empty selects the short column stage
+    const uint32_t colmask = (flags & 0xffu) | 1u;
+    const uint32_t ncols = jda_popcount8(colmask);
+    const bool half = (flags & 0x2000u) == 0;
+    const uint32_t base = jda_lds_add(&cnt[half ? 0 : 1], ncols);
+    uint16_t *collist = (uint16_t *)(lds + L::COLLIST_OFF);
+    uint32_t j = 0;
 #pragma unroll
-                for (int i = 0; i < 16; i++) out[i] = v;
-            } else if (!(D.pad_[0] & 2)) jda_idct_block<FAST>(coef, quant, flags, out);
+    for (uint32_t col = 0; col < 8; col++) {
+        if (colmask & (1u << col)) {
+            const uint32_t slot = half ? base + j : (JDA_COLLIST_ENTRIES - 1u) - (base + j);   // two lists, one array
+            collist[slot] = (uint16_t)((t << 3) | col);
+            j++;
         }
+    }
+    const uint32_t rc = (flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u);       // :2686-2688
+    rowlist[rc * JDA_TILE_BLOCKS + jda_lds_add(&cnt[2 + rc], 1)] = (uint8_t)t;
+}
+
+// ---- P2 ---------------------------------------------------------------------------------------
+template <int MODE, bool FAST, bool HALF>
+JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, uint8_t *lds)
+{
+    typedef jda_mode_traits<MODE> T;
+    typedef jda_lds_layout<MODE> L;
+    const uint32_t blk = item >> 3, col = item & 7u;
+    const uint32_t b = blk % T::NBLK;
+    const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
+    const int16_t *quant = (const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT) + D.q_id[c] * 64 + col;
+    int16_t *coef = (int16_t *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE) + col;
+    int32_t cv[8], qv[8], r[8];
+#pragma unroll
+    for (int row = 0; row < 8; row++) {
+        if (HALF && row >= 4) { cv[row] = 0; qv[row] = 0; }
+        else { cv[row] = coef[row * 8]; qv[row] = quant[row * 8]; }
+    }
+    jda_idct_col<FAST, HALF>(cv, qv, r);
+#pragma unroll
+    for (int row = 0; row < 8; row++) coef[row * 8] = (int16_t)r[row];
+}
+
+template <int MODE, bool FAST>
+JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
+{
+    typedef jda_lds_layout<MODE> L;
+    const uint32_t *cnt = (const uint32_t *)(lds + L::CNT_OFF);
+    const uint16_t *collist = (const uint16_t *)(lds + L::COLLIST_OFF);
+    const uint32_t n_half = cnt[0], n_full = cnt[1];
+    for (uint32_t i = t; i < n_half; i += JDA_WG_THREADS) jda_p2_column_item<MODE, FAST, true>(D, collist[i], lds);
+    for (uint32_t i = t; i < n_full; i += JDA_WG_THREADS)
+        jda_p2_column_item<MODE, FAST, false>(D, collist[(JDA_COLLIST_ENTRIES - 1u) - i], lds);
+}
+
+// ---- P3 ---------------------------------------------------------------------------------------
+template <int MODE, int RC>
+JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *lds, uint32_t n_blocks)
+{
+    typedef jda_mode_traits<MODE> T;
+    typedef jda_lds_layout<MODE> L;
+    const uint8_t *list = lds + L::ROWLIST_OFF + RC * JDA_TILE_BLOCKS;
+    for (uint32_t i = t; i < n_blocks * 8; i += JDA_WG_THREADS) {
+        const uint32_t blk = list[i >> 3], row = i & 7u;
+        const jda_u64_alias *src = (const jda_u64_alias *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 16);
+        int32_t sv[8];
+        const uint64_t a = src[0];
+        sv[0] = (int16_t)a; sv[1] = (int16_t)(a >> 16); sv[2] = (int16_t)(a >> 32); sv[3] = (int16_t)(a >> 48);
+        if (RC == 2) {
+            const uint64_t bq = src[1];
+            sv[4] = (int16_t)bq; sv[5] = (int16_t)(bq >> 16); sv[6] = (int16_t)(bq >> 32); sv[7] = (int16_t)(bq >> 48);
+        } else { sv[4] = sv[5] = sv[6] = sv[7] = 0; }
+        const jda_row8 p = jda_idct_row<RC>(sv);
+        const uint32_t m = blk / T::NBLK, b = blk - m * T::NBLK;
+        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::PLANE_OFF + m * L::PLANE_STRIDE + b * 64 + row * 8);
+        dst[0] = p.lo; dst[1] = p.hi;
     }
 }
 
-// ---- phase B ---------------------------------------------------------------------------------
-// The wave's lanes tile the strip's output so that consecutive lanes store consecutive 16-byte
-// (or 8-byte) groups: every store instruction writes whole, contiguous cache lines.
+template <int MODE>
+JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
+{
+    typedef jda_mode_traits<MODE> T;
+    typedef jda_lds_layout<MODE> L;
+    const uint32_t *cnt = (const uint32_t *)(lds + L::CNT_OFF);
+    jda_p3_row_class<MODE, 0>(t, lds, cnt[2]);
+    jda_p3_row_class<MODE, 1>(t, lds, cnt[3]);
+    jda_p3_row_class<MODE, 2>(t, lds, cnt[4]);
+    // DC-only blocks: all 64 samples = RT((pred * q0) >> 5)  (:5146-5154); 2 threads x 32 bytes per block
+    const uint8_t *list = lds + L::ROWLIST_OFF + 3 * JDA_TILE_BLOCKS;
+    const uint32_t n_dc = cnt[5];
+    for (uint32_t i = t; i < n_dc * 2; i += JDA_WG_THREADS) {
+        const uint32_t blk = list[i >> 1], halfblk = i & 1u;
+        const uint32_t m = blk / T::NBLK, b = blk - m * T::NBLK;
+        const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
+        const int32_t q0 = ((const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT))[D.q_id[c] * 64];
+        const int32_t dc = *(const int16_t *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE);
+        const uint32_t v = jda_range_limit5(dc * q0) * 0x01010101u;
+        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::PLANE_OFF + m * L::PLANE_STRIDE + b * 64 + halfblk * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = v;
+    }
+}
 
+// ---- P4: colour conversion + coalesced stores ------------------------------------------------------
 // four converted pixels -> memory in the requested format, clipped at the right edge
 JDA_HD void jda_store4(uint8_t *row, uint32_t X, uint32_t out_w, int pt, const uint32_t v[4])
 {
@@ -568,118 +732,104 @@ JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t, int pt)
     return v;
 }
 
-// full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): per step a lane
-// converts a 4x2 pixel group (two rows share the chroma samples)
-JDA_HD void jda_phase_b_420_full(const jda_dev_desc &D, uint32_t lane, const uint8_t *plane_base,
-                                 uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+// full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
+// pixel group (the two rows share their chroma samples); items are dealt to the threads in row-major
+// order so that consecutive threads store consecutive 16-byte groups.
+JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                            uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
 {
     const int pt = D.pixel_type;
-    const uint32_t bpp = pt == JDA_RGB8888 ? 4u : 2u;
-    for (uint32_t rp = 0; rp < 8; rp++) {
-        const uint32_t Y0 = y_base + 2 * rp;
-        if (Y0 >= D.out_rows) break;
-        const bool second = Y0 + 1 < D.out_rows;
+    const uint32_t groups = tile_w >> 2;                          // 4-pixel groups per row (tile_w is a multiple of 16)
+    for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
+        const uint32_t rp = i / groups, x4 = (i - rp * groups) * 4;
+        const uint32_t Y0 = y_base + 2 * rp, X = x_base + x4;
+        if (Y0 >= D.out_rows || X >= D.out_w) continue;
+        const uint32_t m = x4 >> 4, bx = x4 & 15u;
+        const uint8_t *P = plane_base + m * plane_stride;
+        const uint8_t *py = P + 64 * ((rp >> 2) * 2 + (bx >> 3)) + ((2 * rp) & 7u) * 8 + (bx & 7u);
+        const uint32_t ya = *(const jda_u32_alias *)py, yb = *(const jda_u32_alias *)(py + 8);
+        const uint32_t ci = rp * 8 + (bx >> 1);
+        const uint32_t cb2 = *(const uint16_t *)(P + 256 + ci), cr2 = *(const uint16_t *)(P + 320 + ci);
+        const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
+        const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
+        uint32_t v0[4], v1[4];
+        v0[0] = jda_rgb_pixel(ya & 255u, c0, pt);          v0[1] = jda_rgb_pixel((ya >> 8) & 255u, c0, pt);
+        v0[2] = jda_rgb_pixel((ya >> 16) & 255u, c1, pt);  v0[3] = jda_rgb_pixel(ya >> 24, c1, pt);
+        v1[0] = jda_rgb_pixel(yb & 255u, c0, pt);          v1[1] = jda_rgb_pixel((yb >> 8) & 255u, c0, pt);
+        v1[2] = jda_rgb_pixel((yb >> 16) & 255u, c1, pt);  v1[3] = jda_rgb_pixel(yb >> 24, c1, pt);
         uint8_t *row0 = D.out + (size_t)Y0 * D.out_pitch;
-        uint8_t *row1 = row0 + D.out_pitch;
-        for (uint32_t x4 = lane * 4; x4 < tile_w; x4 += 4 * JDA_WAVE_LANES) {
-            const uint32_t X = x_base + x4;
-            if (X >= D.out_w) continue;
-            const uint32_t m = x4 >> 4, bx = x4 & 15u;
-            const uint8_t *P = plane_base + m * plane_stride;
-            const uint8_t *py = P + 64 * ((rp >> 2) * 2 + (bx >> 3)) + ((2 * rp) & 7u) * 8 + (bx & 7u);
-            const uint32_t ya = *(const jda_u32_alias *)py, yb = *(const jda_u32_alias *)(py + 8);
-            const uint32_t ci = rp * 8 + (bx >> 1);
-            const uint32_t cb2 = *(const uint16_t *)(P + 256 + ci), cr2 = *(const uint16_t *)(P + 320 + ci);
-            const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
-            const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
-            uint32_t v0[4], v1[4];
-            v0[0] = jda_rgb_pixel(ya & 255u, c0, pt);          v0[1] = jda_rgb_pixel((ya >> 8) & 255u, c0, pt);
-            v0[2] = jda_rgb_pixel((ya >> 16) & 255u, c1, pt);  v0[3] = jda_rgb_pixel(ya >> 24, c1, pt);
-            v1[0] = jda_rgb_pixel(yb & 255u, c0, pt);          v1[1] = jda_rgb_pixel((yb >> 8) & 255u, c0, pt);
-            v1[2] = jda_rgb_pixel((yb >> 16) & 255u, c1, pt);  v1[3] = jda_rgb_pixel(yb >> 24, c1, pt);
-            jda_store4(row0, X, D.out_w, pt, v0);
-            if (second) jda_store4(row1, X, D.out_w, pt, v1);
-        }
+        jda_store4(row0, X, D.out_w, pt, v0);
+        if (Y0 + 1 < D.out_rows) jda_store4(row0 + D.out_pitch, X, D.out_w, pt, v1);
     }
-    (void)bpp;
 }
 
 // full-size 4:4:4 colour output (JPEGPutMCU11 scalar body, jpeg.inl:3519-3559)
-JDA_HD void jda_phase_b_444_full(const jda_dev_desc &D, uint32_t lane, const uint8_t *plane_base,
-                                 uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                            uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
 {
     const int pt = D.pixel_type;
-    for (uint32_t r = 0; r < 8; r++) {
-        const uint32_t Y = y_base + r;
-        if (Y >= D.out_rows) break;
-        uint8_t *row = D.out + (size_t)Y * D.out_pitch;
-        for (uint32_t x4 = lane * 4; x4 < tile_w; x4 += 4 * JDA_WAVE_LANES) {
-            const uint32_t X = x_base + x4;
-            if (X >= D.out_w) continue;
-            const uint8_t *P = plane_base + (x4 >> 3) * plane_stride + r * 8 + (x4 & 7u);
-            const uint32_t y = *(const jda_u32_alias *)P, cb = *(const jda_u32_alias *)(P + 64), cr = *(const jda_u32_alias *)(P + 128);
-            uint32_t v[4];
+    const uint32_t groups = tile_w >> 2;
+    for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
+        const uint32_t r = i / groups, x4 = (i - r * groups) * 4;
+        const uint32_t Y = y_base + r, X = x_base + x4;
+        if (Y >= D.out_rows || X >= D.out_w) continue;
+        const uint8_t *P = plane_base + (x4 >> 3) * plane_stride + r * 8 + (x4 & 7u);
+        const uint32_t y = *(const jda_u32_alias *)P, cb = *(const jda_u32_alias *)(P + 64), cr = *(const jda_u32_alias *)(P + 128);
+        uint32_t v[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                v[j] = jda_rgb_pixel((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u), pt);
-            jda_store4(row, X, D.out_w, pt, v);
-        }
+        for (int j = 0; j < 4; j++)
+            v[j] = jda_rgb_pixel((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u), pt);
+        jda_store4(D.out + (size_t)Y * D.out_pitch, X, D.out_w, pt, v);
     }
 }
 
 // everything else (scaled outputs, luma-only, gray JPEGs): generic per-pixel fetch
 template <int MODE>
-JDA_HD void jda_phase_b_generic(const jda_dev_desc &D, uint32_t lane, const uint8_t *plane_base,
-                                uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+JDA_HD void jda_p4_generic(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                           uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
 {
     typedef jda_mode_traits<MODE> T;
     const int shift = D.scale_shift;
-    const uint32_t mw_log2 = (T::MCU_W == 16 ? 4u : 3u) - (uint32_t)shift;      // MCU tile edge in output px = 1 << mw_log2
+    const uint32_t mw_log2 = (uint32_t)T::MCU_W_LOG2 - (uint32_t)shift;       // MCU tile edge in output px = 1 << mw_log2
     const uint32_t mh = (uint32_t)T::MCU_H >> shift;
     const int pt = D.pixel_type;
-    for (uint32_t row = 0; row < mh; row++) {
-        const uint32_t Y = y_base + row;
-        if (Y >= D.out_rows) break;
-        uint8_t *rowp = D.out + (size_t)Y * D.out_pitch;
-        for (uint32_t x4 = lane * 4; x4 < tile_w; x4 += 4 * JDA_WAVE_LANES) {
-            const uint32_t X = x_base + x4;
-            if (X >= D.out_w) continue;
-            uint32_t v[4];
+    const uint32_t groups = (tile_w + 3) >> 2;
+    for (uint32_t i = t; i < groups * mh; i += JDA_WG_THREADS) {
+        const uint32_t row = i / groups, x4 = (i - row * groups) * 4;
+        const uint32_t Y = y_base + row, X = x_base + x4;
+        if (Y >= D.out_rows || X >= D.out_w) continue;
+        uint32_t v[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t x = x4 + j;
-                v[j] = 0;
-                if (x < tile_w) {
-                    const uint32_t m = x >> mw_log2;
-                    v[j] = jda_output_pixel<MODE>(plane_base + m * plane_stride, x - (m << mw_log2), row, shift, pt);
-                }
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t x = x4 + j;
+            v[j] = 0;
+            if (x < tile_w) {
+                const uint32_t m = x >> mw_log2;
+                v[j] = jda_output_pixel<MODE>(plane_base + m * plane_stride, x - (m << mw_log2), row, shift, pt);
             }
-            jda_store4(rowp, X, D.out_w, pt, v);
         }
+        jda_store4(D.out + (size_t)Y * D.out_pitch, X, D.out_w, pt, v);
     }
 }
 
 template <int MODE>
-JDA_HD void jda_phase_b(const jda_dev_desc &D, const jda_strip &S, uint32_t lane, const uint8_t *wave_lds)
+JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *lds)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
+    if (C.count == 0) return;
     const int shift = D.scale_shift;
     const uint32_t mw = (uint32_t)T::MCU_W >> shift, mh = (uint32_t)T::MCU_H >> shift;   // MCU tile in output px
-    uint32_t count = S.count;                                     // MCUs actually decoded in this strip
-    const uint32_t first = S.mcu_y * D.mcus_x + S.mcu_x0;
-    if (first >= D.n_mcus_ok) return;
-    if (first + count > D.n_mcus_ok) count = D.n_mcus_ok - first;
-    const uint32_t tile_w = count * mw;                           // output pixels per row of the strip
+    const uint32_t tile_w = C.count * mw;                         // output pixels per row of the tile
     const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
-    const uint8_t *plane_base = wave_lds + L::PLANE_OFF;
+    const uint8_t *plane_base = lds + L::PLANE_OFF;
     const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
     if (MODE == JDA_MODE_420 && shift == 0 && colour_out)
-        jda_phase_b_420_full(D, lane, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        jda_p4_420_full(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
     else if (MODE == JDA_MODE_444 && shift == 0 && colour_out)
-        jda_phase_b_444_full(D, lane, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        jda_p4_444_full(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
     else
-        jda_phase_b_generic<MODE>(D, lane, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        jda_p4_generic<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
 
 #endif // JDA_DEVICE_CORE_H

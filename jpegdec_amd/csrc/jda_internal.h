@@ -24,8 +24,8 @@ enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2 };
 // ---- device-side descriptors ----
 struct jda_dev_desc {             // one per image of a batch, 96 bytes
     const uint8_t *scan;          // filtered entropy-coded bytes (4-byte aligned, padded)
-    const uint32_t *mcu_index;    // n_mcus+1 entries
-    const int16_t *mcu_dc;        // n_mcus * ncomp
+    const uint32_t *blk_index;    // n_blocks+1 entries: (byte position << 7) | bit offset at each block start
+    const int16_t *blk_dc;        // n_blocks: the block's DC predictor on entry
     const uint8_t *tables;        // JDA_TABLE_BYTES
     uint8_t *out;                 // output surface
     uint32_t out_pitch;           // bytes
@@ -43,11 +43,11 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     uint8_t pad_[1];
 };
 
-struct jda_strip {                // one wavefront's work: <= 64 consecutive MCUs of one MCU row
+struct jda_strip {                // one workgroup's tile: <= 192 consecutive blocks (32/64/192 MCUs) of one MCU row
     uint32_t image;               // index into the descriptor array
     uint32_t mcu_y;
     uint32_t mcu_x0;
-    uint32_t count;               // 0 = padding entry
+    uint32_t count;               // MCUs in the tile
 };
 
 #endif

@@ -12,7 +12,6 @@
 extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
 
-#define JDA_WAVES_PER_WG 4
 
 inline int jda_mode_of(const jda_image_info &I)
 {
@@ -43,7 +42,7 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     D.mcus_x = (uint32_t)I.mcus_x;
     D.mcus_y = (uint32_t)I.mcus_y;
     uint32_t nok = 0, slen = 0;
-    jda_image_mcu_index(img, &nok);
+    jda_image_block_index(img, &nok);
     jda_image_scan(img, &slen);
     D.n_mcus_ok = nok;
     D.scan_len = slen;
@@ -55,22 +54,18 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     return JDA_SUCCESS;
 }
 
-// Strips of one image: each MCU row is cut into runs of <= 64 MCUs; the list is padded with
-// empty strips to a multiple of the waves per workgroup so a workgroup never spans two images.
-inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y)
+// Tiles of one image: each MCU row is cut into runs of 192 blocks (32 MCUs of 4:2:0, 64 of 4:4:4,
+// 192 of gray); one workgroup decodes one tile.
+inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode)
 {
+    const uint32_t per = mode == JDA_MODE_420 ? 32u : (mode == JDA_MODE_444 ? 64u : 192u);
     for (uint32_t y = 0; y < mcus_y; y++)
-        for (uint32_t x = 0; x < mcus_x; x += 64) {
+        for (uint32_t x = 0; x < mcus_x; x += per) {
             jda_strip s;
             s.image = image; s.mcu_y = y; s.mcu_x0 = x;
-            s.count = mcus_x - x < 64 ? mcus_x - x : 64;
+            s.count = mcus_x - x < per ? mcus_x - x : per;
             v.push_back(s);
         }
-    while (v.size() % JDA_WAVES_PER_WG) {
-        jda_strip s;
-        s.image = image; s.mcu_y = 0; s.mcu_x0 = 0; s.count = 0;
-        v.push_back(s);
-    }
 }
 
 #endif

@@ -146,10 +146,10 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     const jda_image_info &I = *jda_image_get_info(img);
     uint32_t scan_len = 0, nok = 0, tbytes = 0;
     const uint8_t *scan = jda_image_scan(img, &scan_len);
-    const uint32_t *index = jda_image_mcu_index(img, &nok);
-    const int16_t *dc = jda_image_mcu_dc(img);
+    const uint32_t *index = jda_image_block_index(img, &nok);
+    const int16_t *dc = jda_image_block_dc(img);
     const uint8_t *tables = jda_image_tables(img, &tbytes);
-    const size_t n_mcus = (size_t)I.mcus_x * I.mcus_y;
+    const size_t n_blocks = (size_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu;
 
     jda_dev_image *d = new (std::nothrow) jda_dev_image;
     if (!d) { *err = JDA_ERROR_MEMORY; return NULL; }
@@ -161,8 +161,8 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     d->fast_mul = (uint8_t)jda_image_fast_mul(img);
     d->off_tables = 0;
     d->off_index = align16(tbytes);
-    d->off_dc = d->off_index + align16((n_mcus + 1) * sizeof(uint32_t));
-    d->off_scan = d->off_dc + align16(n_mcus * I.ncomp * sizeof(int16_t));
+    d->off_dc = d->off_index + align16((n_blocks + 1) * sizeof(uint32_t));
+    d->off_scan = d->off_dc + align16(n_blocks * sizeof(int16_t));
     d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
     hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&d->base, d->bytes);
@@ -170,8 +170,8 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     // stage through one pinned-size host buffer so it is a single H2D copy
     std::vector<uint8_t> stage(d->bytes, 0);
     memcpy(stage.data() + d->off_tables, tables, tbytes);
-    memcpy(stage.data() + d->off_index, index, (n_mcus + 1) * sizeof(uint32_t));
-    memcpy(stage.data() + d->off_dc, dc, n_mcus * I.ncomp * sizeof(int16_t));
+    memcpy(stage.data() + d->off_index, index, (n_blocks + 1) * sizeof(uint32_t));
+    memcpy(stage.data() + d->off_dc, dc, n_blocks * sizeof(int16_t));
     memcpy(stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
     e = hipMemcpyAsync(d->base, stage.data(), d->bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -227,8 +227,8 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
         D.n_mcus_ok = im->n_mcus_ok; D.scan_len = im->scan_len;
         D.tables = im->base + im->off_tables;
-        D.mcu_index = (const uint32_t *)(im->base + im->off_index);
-        D.mcu_dc = (const int16_t *)(im->base + im->off_dc);
+        D.blk_index = (const uint32_t *)(im->base + im->off_index);
+        D.blk_dc = (const int16_t *)(im->base + im->off_dc);
         D.scan = im->base + im->off_scan;
         D.out = (uint8_t *)O.pixels;
         D.out_pitch = (uint32_t)O.pitch_bytes;
@@ -237,11 +237,11 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         if (!O.pixels || ((uintptr_t)O.pixels & 15) || (O.pitch_bytes & 15) || O.pitch_bytes < (int)D.out_w * bpp) {
             *err = JDA_INVALID_PARAMETER; return NULL;
         }
-        jda_append_strips(strips[D.mode * 2 + (D.fast_mul ? 1 : 0)], (uint32_t)i, D.mcus_x, D.mcus_y);
+        jda_append_strips(strips[D.mode * 2 + (D.fast_mul ? 1 : 0)], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode);
         st.source_pixels += (int64_t)I.width * I.height;
         st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
         st.scan_bytes += im->scan_len;
-        st.index_bytes += (int64_t)I.mcus_x * I.mcus_y * (4 + 2 * I.ncomp);
+        st.index_bytes += (int64_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu * 6;
         st.table_bytes += JDA_TABLE_BYTES;
     }
     jda_batch *b = new (std::nothrow) jda_batch;
@@ -257,7 +257,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)(strips[m].size() / JDA_WAVES_PER_WG);
+        st.n_workgroups += (int32_t)strips[m].size();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -340,7 +340,7 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
     int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
     if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
     uint32_t nok = 0;
-    jda_image_mcu_index(img, &nok);
+    jda_image_block_index(img, &nok);
     const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
     const int dpitch = (int)align16((size_t)cw * bpp);
     const int drows = rows < ch ? rows : ch;

@@ -16,20 +16,25 @@
 static uint32_t g_window_bytes = JDA_WIN_BYTES;   // tests shrink it to exercise the HBM fall-back of the bit reader
 extern "C" void hostsim_set_window(uint32_t bytes) { g_window_bytes = bytes > JDA_WIN_BYTES ? JDA_WIN_BYTES : (bytes & ~15u); }
 
+// one workgroup = 192 threads stepping through the kernel's phases; a phase runs for every thread
+// before the next one starts (= the __syncthreads() between them)
 template <int MODE, bool FAST>
-static void run_strips(const jda_dev_desc &D, const std::vector<jda_strip> &strips, const uint8_t *tables)
+static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles)
 {
     typedef jda_lds_layout<MODE> L;
-    std::vector<uint64_t> lds_store((L::WAVE_BYTES + 7) / 8);
-    uint8_t *wave_lds = (uint8_t *)lds_store.data();
-    for (size_t i = 0; i < strips.size(); i++) {
-        const jda_strip &S = strips[i];
-        if (S.count == 0) continue;
-        memset(wave_lds, 0xA5, L::WAVE_BYTES);   // poison: LDS is not zero-initialised on the GPU either
-        const jda_window W = jda_strip_window(D, S, g_window_bytes);
-        for (uint32_t lane = 0; lane < 64; lane++) jda_window_fill(D.scan, W.lo, W.len, wave_lds + L::WIN_OFF, lane);
-        for (uint32_t lane = 0; lane < 64; lane++) jda_phase_a<MODE, FAST>(D, S, lane, tables, wave_lds, W);
-        for (uint32_t lane = 0; lane < 64; lane++) jda_phase_b<MODE>(D, S, lane, wave_lds);
+    std::vector<uint64_t> lds_store((L::TOTAL_BYTES + 7) / 8);
+    uint8_t *lds = (uint8_t *)lds_store.data();
+    for (size_t i = 0; i < tiles.size(); i++) {
+        const jda_strip &S = tiles[i];
+        memset(lds, 0xA5, L::TOTAL_BYTES);       // poison: LDS is not zero-initialised on the GPU either
+        const jda_tile_ctx C = jda_tile_setup<MODE>(D, S);
+        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p0_stage<MODE>(D, C, t, lds, g_window_bytes);
+        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p1_entropy<MODE>(D, C, t, lds, g_window_bytes);
+        if (D.scale_shift < 2) {
+            for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p2_columns<MODE, FAST>(D, t, lds);
+            for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p3_rows<MODE>(D, t, lds);
+        }
+        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p4_output<MODE>(D, S, C, t, lds);
     }
 }
 
@@ -46,18 +51,18 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
     uint32_t n;
     D.scan = jda_image_scan(img, &n);
-    D.mcu_index = jda_image_mcu_index(img, &n);
-    D.mcu_dc = jda_image_mcu_dc(img);
+    D.blk_index = jda_image_block_index(img, &n);
+    D.blk_dc = jda_image_block_dc(img);
     D.tables = jda_image_tables(img, &n);
     std::vector<jda_strip> strips;
-    jda_append_strips(strips, 0, D.mcus_x, D.mcus_y);
+    jda_append_strips(strips, 0, D.mcus_x, D.mcus_y, D.mode);
     switch (D.mode * 2 + (D.fast_mul ? 1 : 0)) {
-    case JDA_MODE_GRAY * 2: run_strips<JDA_MODE_GRAY, false>(D, strips, D.tables); break;
-    case JDA_MODE_GRAY * 2 + 1: run_strips<JDA_MODE_GRAY, true>(D, strips, D.tables); break;
-    case JDA_MODE_444 * 2: run_strips<JDA_MODE_444, false>(D, strips, D.tables); break;
-    case JDA_MODE_444 * 2 + 1: run_strips<JDA_MODE_444, true>(D, strips, D.tables); break;
-    case JDA_MODE_420 * 2: run_strips<JDA_MODE_420, false>(D, strips, D.tables); break;
-    default: run_strips<JDA_MODE_420, true>(D, strips, D.tables); break;
+    case JDA_MODE_GRAY * 2: run_tiles<JDA_MODE_GRAY, false>(D, strips); break;
+    case JDA_MODE_GRAY * 2 + 1: run_tiles<JDA_MODE_GRAY, true>(D, strips); break;
+    case JDA_MODE_444 * 2: run_tiles<JDA_MODE_444, false>(D, strips); break;
+    case JDA_MODE_444 * 2 + 1: run_tiles<JDA_MODE_444, true>(D, strips); break;
+    case JDA_MODE_420 * 2: run_tiles<JDA_MODE_420, false>(D, strips); break;
+    default: run_tiles<JDA_MODE_420, true>(D, strips); break;
     }
     const jda_image_info *I = jda_image_get_info(img);
     rc = (D.n_mcus_ok == (uint32_t)(I->mcus_x * I->mcus_y)) ? JDA_SUCCESS : JDA_DECODE_ERROR;
