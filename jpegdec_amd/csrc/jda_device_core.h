@@ -687,6 +687,10 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
     }
 }
 
+// i / d without an integer division per work item: q = (i * ceil(2^22 / d)) >> 22, exact while
+// i * d < 2^22 (here i < 16 * d and d <= 384, so i * d < 2.4M) and i * ceil(2^22 / d) < 2^32
+JDA_HD uint32_t jda_recip22(uint32_t d) { return ((1u << 22) + d - 1u) / d; }
+
 // ---- P4: colour conversion + coalesced stores ------------------------------------------------------
 // four converted pixels -> memory in the requested format, clipped at the right edge
 JDA_HD void jda_store4(uint8_t *row, uint32_t X, uint32_t out_w, int pt, const uint32_t v[4])
@@ -705,28 +709,30 @@ JDA_HD void jda_store4(uint8_t *row, uint32_t X, uint32_t out_w, int pt, const u
     }
 }
 
-// one chroma sample shared by a 2x2 (or 1x1) group: the products of jpeg.inl:3158-3161
+// one chroma sample shared by a 2x2 (or 1x1) group: the products of jpeg.inl:3158-3161, already
+// shifted: ((k*c) + (Y << 12)) >> 12 == Y + ((k*c) >> 12) exactly, because Y << 12 is a multiple of 4096
 struct jda_chroma { int32_t r, g, b; };
 JDA_HD jda_chroma jda_chroma_terms(uint32_t cb8, uint32_t cr8)
 {
     const int32_t cb = (int32_t)cb8 - 128, cr = (int32_t)cr8 - 128;
     jda_chroma t;
-    t.r = 5742 * cr; t.g = -1409 * cb - 2925 * cr; t.b = 7258 * cb;
+    t.r = (5742 * cr) >> 12; t.g = (-1409 * cb - 2925 * cr) >> 12; t.b = (7258 * cb) >> 12;
     return t;
 }
 JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t, int pt)
 {
-    const int32_t y = (int32_t)(y8 << 12);
+    const int32_t y = (int32_t)y8;
     if (pt == JDA_RGB8888) {
-        const int32_t r = jda_clamp255((t.r + y) >> 12);
-        int32_t g = jda_clamp255((t.g + y) >> 12);
-        const int32_t b = jda_clamp255((t.b + y) >> 12);
+        const int32_t r = jda_clamp255(t.r + y);
+        int32_t g = jda_clamp255(t.g + y);
+        const int32_t b = jda_clamp255(t.b + y);
         JDA_OPAQUE(g);
         return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xff000000u;
     }
-    const int32_t r = jda_clamp255(jda_sext10_at(t.r + y, 12));
-    const int32_t g = jda_clamp255(jda_sext10_at(t.g + y, 12));
-    const int32_t b = jda_clamp255(jda_sext10_at(t.b + y, 12));
+    // RGB565 goes through the 10-bit wrapping tables
+    const int32_t r = jda_clamp255(jda_sext10_at(t.r + y, 0));
+    const int32_t g = jda_clamp255(jda_sext10_at(t.g + y, 0));
+    const int32_t b = jda_clamp255(jda_sext10_at(t.b + y, 0));
     uint32_t v = (uint32_t)((r >> 3) << 11) | (uint32_t)((g >> 2) << 5) | (uint32_t)(b >> 3);
     if (pt == JDA_RGB565_BIG_ENDIAN) v = ((v & 0xffu) << 8) | (v >> 8);
     return v;
@@ -740,8 +746,9 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
 {
     const int pt = D.pixel_type;
     const uint32_t groups = tile_w >> 2;                          // 4-pixel groups per row (tile_w is a multiple of 16)
+    const uint32_t inv = jda_recip22(groups);
     for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
-        const uint32_t rp = i / groups, x4 = (i - rp * groups) * 4;
+        const uint32_t rp = (i * inv) >> 22, x4 = (i - rp * groups) * 4;
         const uint32_t Y0 = y_base + 2 * rp, X = x_base + x4;
         if (Y0 >= D.out_rows || X >= D.out_w) continue;
         const uint32_t m = x4 >> 4, bx = x4 & 15u;
@@ -769,8 +776,9 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
 {
     const int pt = D.pixel_type;
     const uint32_t groups = tile_w >> 2;
+    const uint32_t inv = jda_recip22(groups);
     for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
-        const uint32_t r = i / groups, x4 = (i - r * groups) * 4;
+        const uint32_t r = (i * inv) >> 22, x4 = (i - r * groups) * 4;
         const uint32_t Y = y_base + r, X = x_base + x4;
         if (Y >= D.out_rows || X >= D.out_w) continue;
         const uint8_t *P = plane_base + (x4 >> 3) * plane_stride + r * 8 + (x4 & 7u);
@@ -794,8 +802,9 @@ JDA_HD void jda_p4_generic(const jda_dev_desc &D, uint32_t t, const uint8_t *pla
     const uint32_t mh = (uint32_t)T::MCU_H >> shift;
     const int pt = D.pixel_type;
     const uint32_t groups = (tile_w + 3) >> 2;
+    const uint32_t inv = jda_recip22(groups);
     for (uint32_t i = t; i < groups * mh; i += JDA_WG_THREADS) {
-        const uint32_t row = i / groups, x4 = (i - row * groups) * 4;
+        const uint32_t row = (i * inv) >> 22, x4 = (i - row * groups) * 4;
         const uint32_t Y = y_base + row, X = x_base + x4;
         if (Y >= D.out_rows || X >= D.out_w) continue;
         uint32_t v[4];

@@ -55,9 +55,12 @@ int orc_quant_tables(const uint8_t *data, int len, int16_t *q);
  * order writes 64 int16 coefficients (natural order) and the reference's u16MCUFlags.
  * Also optionally records the bit-reader phase at each MCU start: mcu_state[2*i+0]=byte position
  * in the filtered stream, [2*i+1]=bit offset (0..64), and mcu_dcpred[3*i..] the three predictors.
+ * blk_state / blk_dcpred (optional) record the same per BLOCK: the reader phase on entry to
+ * JPEGDecodeMCU and that block's DC predictor before it.
  * returns number of blocks decoded (<0: error). */
 int orc_entropy(const uint8_t *data, int len, int options, int max_blocks,
-                int16_t *coefs, uint16_t *flags, uint32_t *mcu_state, int32_t *mcu_dcpred);
+                int16_t *coefs, uint16_t *flags, uint32_t *mcu_state, int32_t *mcu_dcpred,
+                uint32_t *blk_state, int32_t *blk_dcpred);
 
 /* one block: dequant + IDCT + range limit (jpeg.inl:2278-2326, 2553-2797 and the DC-only
  * bypass :5146-5154).  pred = running DC predictor (int), coef[0] must hold (int16)pred.

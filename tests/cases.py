@@ -15,8 +15,10 @@ SYNTH_CASES = {
     "c420_256x256_q98": dict(width=256, height=256, subsampling="4:2:0", seed=15, quality=98),
     "c444_256x256_q100_opt": dict(width=256, height=256, subsampling="4:4:4", seed=16, quality=100, optimize=True),
     "gray_64x64_rst3": dict(width=64, height=64, subsampling="gray", seed=17, restart_blocks=3),
-    "c420_1100x48": dict(width=1100, height=48, subsampling="4:2:0", seed=18),       # > 64 MCUs per row: 2 strips
-    "gray_1100x24": dict(width=1100, height=24, subsampling="gray", seed=19),        # 138 MCUs per row: 3 strips
+    "c420_1100x48": dict(width=1100, height=48, subsampling="4:2:0", seed=18),       # > 32 MCUs per row: 3 tiles
+    "gray_1100x24": dict(width=1100, height=24, subsampling="gray", seed=19),        # 138 MCUs per row: one partial tile
+    "gray_1600x16": dict(width=1600, height=16, subsampling="gray", seed=23),        # a full 192-MCU gray tile + remainder
+    "c444_600x16": dict(width=600, height=16, subsampling="4:4:4", seed=24),         # a full 64-MCU 4:4:4 tile + remainder
     "c420_16x16": dict(width=16, height=16, subsampling="4:2:0", seed=20),           # single MCU
     "c444_8x8_q30": dict(width=8, height=8, subsampling="4:4:4", seed=21, quality=30),
     "c420_1280x720": dict(width=1280, height=720, subsampling="4:2:0", seed=1234),   # BASELINE config 2 shape

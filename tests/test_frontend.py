@@ -30,12 +30,14 @@ def test_prepare_matches_oracle_stage_by_stage(name, oracle, product_lib):
     rc, q = oracle.quant_tables(jpeg)
     assert np.array_equal(t[10240:10752].view(np.int16).reshape(4, 64), q)
     assert list(t[10752:10816]) == [oracle.lib.orc_zigzag_to_natural(k) for k in range(64)]
-    # pre-scan index == the oracle's bit-reader phase and DC predictors at every MCU start
+    # pre-scan index == the oracle's bit-reader phase and DC predictor on entry to every block
     n, coefs, flags, state, dcp = oracle.entropy(jpeg, 0)
-    idx, nok = p.mcu_index()
-    assert nok == p.n_mcus and n == len(flags)
-    assert np.array_equal(idx[:-1] >> 7, state[:, 0]) and np.array_equal(idx[:-1] & 127, state[:, 1])
-    assert np.array_equal(p.mcu_dc().astype(np.int32), dcp[:, : p.info.ncomp])
+    idx, nok = p.block_index()
+    assert nok == p.n_mcus and n == len(flags) == p.n_blocks
+    assert np.array_equal(idx[:-1] >> 7, oracle.blk_state[:, 0]) and np.array_equal(idx[:-1] & 127, oracle.blk_state[:, 1])
+    assert np.array_equal(p.block_dc().astype(np.int32), oracle.blk_pred)
+    bpm = p.info.blocks_per_mcu                      # MCU starts are the first block of each MCU
+    assert np.array_equal(idx[:-1:bpm] >> 7, state[:, 0]) and np.array_equal(idx[:-1:bpm] & 127, state[:, 1])
     p.close()
 
 
@@ -66,7 +68,7 @@ def test_truncated_scan_reports_partial_index(product_lib):
     jpeg = jpeg_for("c420_333x217")
     cut = jpeg[: len(jpeg) // 2] + b"\xff\xd9" + b"\x00" * 300
     p = J.PreparedImage(cut)
-    idx, nok = p.mcu_index()
+    idx, nok = p.block_index()
     assert 0 < nok <= p.n_mcus
 
 
