@@ -53,16 +53,18 @@ template <> struct jda_mode_traits<JDA_MODE_420>  { enum { NLUMA = 4, NBLK = 6, 
 template <int MODE> struct jda_lds_layout {
     enum {
         MCUS = JDA_TILE_BLOCKS / jda_mode_traits<MODE>::NBLK,        // MCUs per tile
-        PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * 64 + 8,        // bytes per MCU (8 pad: conflict-free colour reads)
         TAB_OFF = 0,
+        // one 136-byte slot per block: int16[64] coefficients, later (first 64 bytes) its 8x8 samples --
+        // the row stage stores its bytes over the block it has just read, as the reference does (:2682)
         COEF_OFF = JDA_LT_BYTES,
-        PLANE_OFF = COEF_OFF + JDA_TILE_BLOCKS * JDA_COEF_STRIDE,
-        INFO_OFF = PLANE_OFF + MCUS * PLANE_STRIDE,                 // uint32 flags per block
-        ROWLIST_OFF = INFO_OFF + JDA_TILE_BLOCKS * 4,               // 4 classes x 192 block ids (uint8)
+        ROWLIST_OFF = COEF_OFF + JDA_TILE_BLOCKS * JDA_COEF_STRIDE,  // 4 classes x 192 block ids (uint8)
         CNT_OFF = ROWLIST_OFF + 4 * JDA_TILE_BLOCKS,                // 8 uint32 counters
         COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
         WIN_OFF = COLLIST_OFF + JDA_COLLIST_ENTRIES * 2,
-        TOTAL_BYTES = WIN_OFF + JDA_WIN_BYTES
+        TOTAL_BYTES = WIN_OFF + JDA_WIN_BYTES,                      // 39,264 B: four workgroups per CU
+        PLANE_OFF = COEF_OFF,
+        BLOCK_STRIDE = JDA_COEF_STRIDE,                             // bytes between consecutive blocks' samples
+        PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE // bytes between consecutive MCUs' samples
     };
 };
 
@@ -109,7 +111,7 @@ JDA_HD uint64_t jda_be64_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint3
 // The workgroup's view of the filtered scan: bytes [win_lo, win_lo + win_len) are staged in LDS (copied
 // with coalesced 16-byte loads by jda_window_fill); anything beyond is read from HBM directly.
 struct jda_bitreader {
-    const uint8_t *base;     // filtered scan in global memory (4-byte aligned, zero padded)
+    const uint8_t JDA_GLOBAL *base;     // filtered scan in global memory (4-byte aligned, zero padded)
     const uint8_t *win;      // LDS copy
     uint32_t win_lo;         // 16-byte aligned scan offset of win[0]
     uint32_t win_len;        // bytes staged (multiple of 16)
@@ -126,7 +128,7 @@ JDA_HD uint64_t jda_load_be64(const jda_bitreader &br, uint32_t pos)
         const jda_u32_alias *p = (const jda_u32_alias *)(br.win + rel);
         return jda_be64_from_words(p[0], p[1], p[2], pos);
     }
-    const jda_u32_alias *p = (const jda_u32_alias *)(br.base + a);
+    const jda_u32_alias JDA_GLOBAL *p = (const jda_u32_alias JDA_GLOBAL *)(br.base + a);
     return jda_be64_from_words(p[0], p[1], p[2], pos);
 }
 
@@ -143,9 +145,9 @@ JDA_HD void jda_refill(jda_bitreader &br)
 // chunks t, t+192, ...  Every thread of the workgroup calls it; a barrier follows.
 struct jda_chunk16 { uint32_t w[4]; };
 typedef jda_chunk16 __attribute__((may_alias)) jda_chunk16_alias;
-JDA_HD void jda_window_fill(const uint8_t *scan, uint32_t win_lo, uint32_t win_len, uint8_t *win, uint32_t lane)
+JDA_HD void jda_window_fill(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint8_t *win, uint32_t lane)
 {
-    const jda_chunk16_alias *src = (const jda_chunk16_alias *)(scan + win_lo);
+    const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
     jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
     for (uint32_t i = lane; i < (win_len >> 4); i += JDA_WG_THREADS) dst[i] = src[i];
 }
@@ -184,7 +186,7 @@ JDA_HD uint32_t jda_popcount8(uint32_t v)
 struct jda_tables {
     const uint8_t *dc;        // LDS: 1024-byte DC LUT of this block's component
     const uint16_t *ac_short; // LDS: 1024 entries
-    const uint16_t *ac_long;  // global: 1024 entries (codes starting 111111)
+    const uint16_t JDA_GLOBAL *ac_long;  // global: 1024 entries (codes starting 111111)
     const uint8_t *zigzag;    // LDS
 };
 
@@ -417,7 +419,7 @@ JDA_HD jda_ycc jda_fetch(const uint8_t *planes, uint32_t px, uint32_t py, int sh
         // which luma block, and the position inside it
         const uint32_t bsz = 8u >> shift;               // block edge in output pixels: 8,4,2,1
         const uint32_t q = (py / bsz) * 2 + (px / bsz);
-        Y = planes + 64 * q;
+        Y = planes + JDA_COEF_STRIDE * q;
         const uint32_t bx = px & (bsz - 1), by = py & (bsz - 1);
         if (shift == 0) { o.y = Y[by * 8 + bx]; cidx = (py >> 1) * 8 + (px >> 1); }         // :4333-4543
         else if (shift == 1) {                                                              // :3577-3626
@@ -427,8 +429,8 @@ JDA_HD jda_ycc jda_fetch(const uint8_t *planes, uint32_t px, uint32_t py, int sh
         } else if (shift == 2) { o.y = Y[by * 2 + bx]; cidx = q; }                          // :3664-3748
         else { o.y = Y[0]; cidx = 0; }                                                      // :3627-3663
         if (!luma) {
-            o.cb = planes[64 * 4 + cidx];
-            o.cr = planes[64 * 5 + cidx];
+            o.cb = planes[JDA_COEF_STRIDE * 4 + cidx];
+            o.cr = planes[JDA_COEF_STRIDE * 5 + cidx];
             o.y = (shift == 1) ? (o.y << 10) : (o.y << 12);
         } else if (shift == 1) o.y = (o.y + 2) >> 2;                                        // :2979-2999
     } else {
@@ -439,7 +441,7 @@ JDA_HD jda_ycc jda_fetch(const uint8_t *planes, uint32_t px, uint32_t py, int sh
         } else if (shift == 2) { cidx = py * 2 + px; o.y = Y[cidx]; }
         else { cidx = 0; o.y = Y[0]; }
         if (MODE == JDA_MODE_444 && !luma) {
-            const uint8_t *Cb = planes + 64, *Cr = planes + 128;
+            const uint8_t *Cb = planes + JDA_COEF_STRIDE, *Cr = planes + 2 * JDA_COEF_STRIDE;
             if (shift == 1) {                                                               // :3297-3322
                 o.cb = (Cb[cidx] + Cb[cidx + 1] + Cb[cidx + 8] + Cb[cidx + 9] + 2) >> 2;
                 o.cr = (Cr[cidx] + Cr[cidx + 1] + Cr[cidx + 8] + Cr[cidx + 9] + 2) >> 2;
@@ -480,6 +482,14 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 //   P4  threads tile the output rows: colour conversion and coalesced stores (JPEGPutMCU*).
 // ================================================================================================
 
+// component table ids: the descriptor bytes are workgroup-uniform (scalar loads); pick by the
+// lane's component with selects instead of a per-lane indexed global load
+JDA_HD uint32_t jda_pick3(const uint8_t ids[3], uint32_t c)
+{
+    const uint32_t a = ids[0], b = ids[1], d = ids[2];
+    return c == 0 ? a : (c == 1 ? b : d);
+}
+
 struct jda_tile_ctx {                 // wave-uniform facts about the tile, computed once per thread
     uint32_t first_mcu;               // linear MCU index of the tile's first MCU
     uint32_t count;                   // MCUs of the tile that are decoded (<= MCUS, clipped by n_mcus_ok)
@@ -500,9 +510,9 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
     C.win_lo = 0; C.win_len = 0;
     if (C.count) {
         // the tile's blocks are consecutive in the scan: stage one contiguous run of bytes
-        C.win_lo = (D.blk_index[C.first_block] >> JDA_INDEX_OFF_BITS) & ~15u;
+        C.win_lo = (JDA_G(const uint32_t, D.blk_index)[C.first_block] >> JDA_INDEX_OFF_BITS) & ~15u;
         // a thread may read 12 bytes past (start of the block after the tile) + 8
-        uint32_t hi = ((D.blk_index[C.first_block + C.count * T::NBLK] >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
+        uint32_t hi = ((JDA_G(const uint32_t, D.blk_index)[C.first_block + C.count * T::NBLK] >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
         const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;      // never past the padded allocation
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
@@ -516,7 +526,7 @@ template <int MODE>
 JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t t, uint8_t *lds, uint32_t win_cap)
 {
     typedef jda_lds_layout<MODE> L;
-    const jda_chunk16_alias *blob = (const jda_chunk16_alias *)D.tables;
+    const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, D.tables);
     jda_chunk16_alias *tab = (jda_chunk16_alias *)(lds + L::TAB_OFF);
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;
     // quant + zigzag: blob[10240, 10816) -> LT_QUANT
@@ -530,7 +540,7 @@ JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t 
     }
     if (t < 8) ((uint32_t *)(lds + L::CNT_OFF))[t] = 0;
     const uint32_t len = C.win_len < win_cap ? C.win_len : win_cap;
-    jda_window_fill(D.scan, C.win_lo, len, lds + L::WIN_OFF, t);
+    jda_window_fill(JDA_G(const uint8_t, D.scan), C.win_lo, len, lds + L::WIN_OFF, t);
 }
 
 // ---- P1 ---------------------------------------------------------------------------------------
@@ -545,25 +555,26 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
     const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
     const uint8_t *tab = lds + L::TAB_OFF;
     jda_tables TB;
-    TB.dc = tab + JDA_LT_DC + D.dc_id[c] * 1024;
-    TB.ac_short = (const uint16_t *)(tab + JDA_LT_AC) + D.ac_id[c] * 1024;
-    TB.ac_long = (const uint16_t *)(D.tables + JDA_TB_AC) + D.ac_id[c] * 2048 + 1024;
+    const uint32_t dc_id = jda_pick3(D.dc_id, c), ac_id = jda_pick3(D.ac_id, c);
+    TB.dc = tab + JDA_LT_DC + dc_id * 1024;
+    TB.ac_short = (const uint16_t *)(tab + JDA_LT_AC) + ac_id * 1024;
+    TB.ac_long = JDA_G(const uint16_t, D.tables + JDA_TB_AC) + ac_id * 2048 + 1024;
     TB.zigzag = tab + JDA_LT_ZIGZAG;
-    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + D.q_id[c] * 64;
+    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64;
     int16_t *coef = (int16_t *)(lds + L::COEF_OFF + t * JDA_COEF_STRIDE);
-    uint8_t *plane = lds + L::PLANE_OFF + m * L::PLANE_STRIDE + b * 64;
+    uint8_t *plane = (uint8_t *)coef;                            // samples overwrite the block's own slot
 
     jda_bitreader br;
-    br.base = D.scan;
+    br.base = JDA_G(const uint8_t, D.scan);
     br.win = lds + L::WIN_OFF;
     br.win_lo = C.win_lo;
     br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
     const uint32_t gb = C.first_block + t;
-    const uint32_t ix = D.blk_index[gb];
+    const uint32_t ix = JDA_G(const uint32_t, D.blk_index)[gb];
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
     br.bits = jda_load_be64(br, br.pos);
-    int32_t pred = D.blk_dc[gb];
+    int32_t pred = JDA_G(const int16_t, D.blk_dc)[gb];
 
     const int shift = D.scale_shift;
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
@@ -573,12 +584,12 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
         const uint32_t flags = jda_decode_block<5>(br, TB, coef, pred);
-        *(jda_u32_alias *)plane = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
-                                             : jda_idct_2x2(coef, quant);
+        const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
+                                       : jda_idct_2x2(coef, quant);
+        *(jda_u32_alias *)plane = px;
         return;
     }
     const uint32_t flags = jda_decode_block<64>(br, TB, coef, pred);
-    ((uint32_t *)(lds + L::INFO_OFF))[t] = flags;
     uint32_t *cnt = (uint32_t *)(lds + L::CNT_OFF);
     uint8_t *rowlist = lds + L::ROWLIST_OFF;
     if (flags == 0) {                                            // DC-only block (:5146-5154): row class 3
@@ -613,7 +624,7 @@ JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, uint8_t *ld
     const uint32_t blk = item >> 3, col = item & 7u;
     const uint32_t b = blk % T::NBLK;
     const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
-    const int16_t *quant = (const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT) + D.q_id[c] * 64 + col;
+    const int16_t *quant = (const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64 + col;
     int16_t *coef = (int16_t *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE) + col;
     int32_t cv[8], qv[8], r[8];
 #pragma unroll
@@ -642,7 +653,6 @@ JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
 template <int MODE, int RC>
 JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *lds, uint32_t n_blocks)
 {
-    typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
     const uint8_t *list = lds + L::ROWLIST_OFF + RC * JDA_TILE_BLOCKS;
     for (uint32_t i = t; i < n_blocks * 8; i += JDA_WG_THREADS) {
@@ -656,8 +666,11 @@ JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *lds, uint32_t n_blocks)
             sv[4] = (int16_t)bq; sv[5] = (int16_t)(bq >> 16); sv[6] = (int16_t)(bq >> 32); sv[7] = (int16_t)(bq >> 48);
         } else { sv[4] = sv[5] = sv[6] = sv[7] = 0; }
         const jda_row8 p = jda_idct_row<RC>(sv);
-        const uint32_t m = blk / T::NBLK, b = blk - m * T::NBLK;
-        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::PLANE_OFF + m * L::PLANE_STRIDE + b * 64 + row * 8);
+        // in place (jpeg.inl:2682): row r's 8 bytes land on bytes [8r, 8r+8) of the block, i.e. on row
+        // r/2's int16 data -- safe because the 8 rows of a block are handled by 8 adjacent lanes of one
+        // wavefront in the same instruction (all reads precede all writes), and on the sequential host
+        // emulator rows are visited in ascending order
+        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 8);
         dst[0] = p.lo; dst[1] = p.hi;
     }
 }
@@ -671,19 +684,19 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
     jda_p3_row_class<MODE, 0>(t, lds, cnt[2]);
     jda_p3_row_class<MODE, 1>(t, lds, cnt[3]);
     jda_p3_row_class<MODE, 2>(t, lds, cnt[4]);
-    // DC-only blocks: all 64 samples = RT((pred * q0) >> 5)  (:5146-5154); 2 threads x 32 bytes per block
+    // DC-only blocks: all 64 samples = RT((pred * q0) >> 5)  (:5146-5154); one thread per block (rare)
     const uint8_t *list = lds + L::ROWLIST_OFF + 3 * JDA_TILE_BLOCKS;
     const uint32_t n_dc = cnt[5];
-    for (uint32_t i = t; i < n_dc * 2; i += JDA_WG_THREADS) {
-        const uint32_t blk = list[i >> 1], halfblk = i & 1u;
-        const uint32_t m = blk / T::NBLK, b = blk - m * T::NBLK;
+    for (uint32_t i = t; i < n_dc; i += JDA_WG_THREADS) {
+        const uint32_t blk = list[i];
+        const uint32_t b = blk % T::NBLK;
         const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
-        const int32_t q0 = ((const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT))[D.q_id[c] * 64];
+        const int32_t q0 = ((const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT))[jda_pick3(D.q_id, c) * 64];
         const int32_t dc = *(const int16_t *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE);
         const uint32_t v = jda_range_limit5(dc * q0) * 0x01010101u;
-        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::PLANE_OFF + m * L::PLANE_STRIDE + b * 64 + halfblk * 32);
+        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE);
 #pragma unroll
-        for (int k = 0; k < 8; k++) dst[k] = v;
+        for (int k = 0; k < 16; k++) dst[k] = v;
     }
 }
 
@@ -692,21 +705,31 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
 JDA_HD uint32_t jda_recip22(uint32_t d) { return ((1u << 22) + d - 1u) / d; }
 
 // ---- P4: colour conversion + coalesced stores ------------------------------------------------------
-// four converted pixels -> memory in the requested format, clipped at the right edge
-JDA_HD void jda_store4(uint8_t *row, uint32_t X, uint32_t out_w, int pt, const uint32_t v[4])
+// four converted pixels -> memory in the requested format.  CLIP: the group may cross the right edge.
+template <int PT, bool CLIP>
+JDA_HD void jda_store4(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, const uint32_t v[4])
 {
-    const uint32_t n = X + 4 <= out_w ? 4u : out_w - X;
-    if (pt == JDA_RGB8888) {
-        jda_u32_alias *d = (jda_u32_alias *)(row + (size_t)X * 4);
+    const uint32_t n = (!CLIP || X + 4 <= out_w) ? 4u : out_w - X;
+    if (PT == JDA_RGB8888) {
+        jda_u32_alias JDA_GLOBAL *d = (jda_u32_alias JDA_GLOBAL *)(row + (size_t)X * 4);
         if (n == 4) { d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
         else for (uint32_t j = 0; j < n; j++) d[j] = v[j];
-    } else if (pt == JDA_EIGHT_BIT_GRAYSCALE) {
-        if (n == 4) *(jda_u32_alias *)(row + X) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    } else if (PT == JDA_EIGHT_BIT_GRAYSCALE) {
+        if (n == 4) *(jda_u32_alias JDA_GLOBAL *)(row + X) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
         else for (uint32_t j = 0; j < n; j++) row[X + j] = (uint8_t)v[j];
     } else {
-        if (n == 4) { jda_u32_alias *d = (jda_u32_alias *)(row + (size_t)X * 2); d[0] = v[0] | (v[1] << 16); d[1] = v[2] | (v[3] << 16); }
-        else for (uint32_t j = 0; j < n; j++) ((uint16_t *)(row + (size_t)X * 2))[j] = (uint16_t)v[j];
+        if (n == 4) { jda_u32_alias JDA_GLOBAL *d = (jda_u32_alias JDA_GLOBAL *)(row + (size_t)X * 2); d[0] = v[0] | (v[1] << 16); d[1] = v[2] | (v[3] << 16); }
+        else for (uint32_t j = 0; j < n; j++) ((uint16_t JDA_GLOBAL *)(row + (size_t)X * 2))[j] = (uint16_t)v[j];
     }
+}
+
+// runtime pixel type -> the templated store (used by the generic path only)
+template <bool CLIP>
+JDA_HD void jda_store4_rt(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, int pt, const uint32_t v[4])
+{
+    if (pt == JDA_RGB8888) jda_store4<JDA_RGB8888, CLIP>(row, X, out_w, v);
+    else if (pt == JDA_EIGHT_BIT_GRAYSCALE) jda_store4<JDA_EIGHT_BIT_GRAYSCALE, CLIP>(row, X, out_w, v);
+    else jda_store4<JDA_RGB565_LITTLE_ENDIAN, CLIP>(row, X, out_w, v);
 }
 
 // one chroma sample shared by a 2x2 (or 1x1) group: the products of jpeg.inl:3158-3161, already
@@ -719,10 +742,11 @@ JDA_HD jda_chroma jda_chroma_terms(uint32_t cb8, uint32_t cr8)
     t.r = (5742 * cr) >> 12; t.g = (-1409 * cb - 2925 * cr) >> 12; t.b = (7258 * cb) >> 12;
     return t;
 }
-JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t, int pt)
+template <int PT>
+JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t)
 {
     const int32_t y = (int32_t)y8;
-    if (pt == JDA_RGB8888) {
+    if (PT == JDA_RGB8888) {
         const int32_t r = jda_clamp255(t.r + y);
         int32_t g = jda_clamp255(t.g + y);
         const int32_t b = jda_clamp255(t.b + y);
@@ -734,60 +758,79 @@ JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t, int pt)
     const int32_t g = jda_clamp255(jda_sext10_at(t.g + y, 0));
     const int32_t b = jda_clamp255(jda_sext10_at(t.b + y, 0));
     uint32_t v = (uint32_t)((r >> 3) << 11) | (uint32_t)((g >> 2) << 5) | (uint32_t)(b >> 3);
-    if (pt == JDA_RGB565_BIG_ENDIAN) v = ((v & 0xffu) << 8) | (v >> 8);
+    if (PT == JDA_RGB565_BIG_ENDIAN) v = ((v & 0xffu) << 8) | (v >> 8);
     return v;
 }
 
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
 // pixel group (the two rows share their chroma samples); items are dealt to the threads in row-major
 // order so that consecutive threads store consecutive 16-byte groups.
+template <int PT, bool CLIP>
 JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
                             uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
 {
-    const int pt = D.pixel_type;
     const uint32_t groups = tile_w >> 2;                          // 4-pixel groups per row (tile_w is a multiple of 16)
     const uint32_t inv = jda_recip22(groups);
+    uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
     for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
         const uint32_t rp = (i * inv) >> 22, x4 = (i - rp * groups) * 4;
         const uint32_t Y0 = y_base + 2 * rp, X = x_base + x4;
-        if (Y0 >= D.out_rows || X >= D.out_w) continue;
+        if (CLIP && (Y0 >= D.out_rows || X >= D.out_w)) continue;
         const uint32_t m = x4 >> 4, bx = x4 & 15u;
         const uint8_t *P = plane_base + m * plane_stride;
-        const uint8_t *py = P + 64 * ((rp >> 2) * 2 + (bx >> 3)) + ((2 * rp) & 7u) * 8 + (bx & 7u);
+        const uint8_t *py = P + JDA_COEF_STRIDE * ((rp >> 2) * 2 + (bx >> 3)) + ((2 * rp) & 7u) * 8 + (bx & 7u);
         const uint32_t ya = *(const jda_u32_alias *)py, yb = *(const jda_u32_alias *)(py + 8);
         const uint32_t ci = rp * 8 + (bx >> 1);
-        const uint32_t cb2 = *(const uint16_t *)(P + 256 + ci), cr2 = *(const uint16_t *)(P + 320 + ci);
+        const uint32_t cb2 = *(const uint16_t *)(P + 4 * JDA_COEF_STRIDE + ci), cr2 = *(const uint16_t *)(P + 5 * JDA_COEF_STRIDE + ci);
         const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
         const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
         uint32_t v0[4], v1[4];
-        v0[0] = jda_rgb_pixel(ya & 255u, c0, pt);          v0[1] = jda_rgb_pixel((ya >> 8) & 255u, c0, pt);
-        v0[2] = jda_rgb_pixel((ya >> 16) & 255u, c1, pt);  v0[3] = jda_rgb_pixel(ya >> 24, c1, pt);
-        v1[0] = jda_rgb_pixel(yb & 255u, c0, pt);          v1[1] = jda_rgb_pixel((yb >> 8) & 255u, c0, pt);
-        v1[2] = jda_rgb_pixel((yb >> 16) & 255u, c1, pt);  v1[3] = jda_rgb_pixel(yb >> 24, c1, pt);
-        uint8_t *row0 = D.out + (size_t)Y0 * D.out_pitch;
-        jda_store4(row0, X, D.out_w, pt, v0);
-        if (Y0 + 1 < D.out_rows) jda_store4(row0 + D.out_pitch, X, D.out_w, pt, v1);
+        v0[0] = jda_rgb_pixel<PT>(ya & 255u, c0);          v0[1] = jda_rgb_pixel<PT>((ya >> 8) & 255u, c0);
+        v0[2] = jda_rgb_pixel<PT>((ya >> 16) & 255u, c1);  v0[3] = jda_rgb_pixel<PT>(ya >> 24, c1);
+        v1[0] = jda_rgb_pixel<PT>(yb & 255u, c0);          v1[1] = jda_rgb_pixel<PT>((yb >> 8) & 255u, c0);
+        v1[2] = jda_rgb_pixel<PT>((yb >> 16) & 255u, c1);  v1[3] = jda_rgb_pixel<PT>(yb >> 24, c1);
+        uint8_t JDA_GLOBAL *row0 = out + (size_t)Y0 * D.out_pitch;
+        jda_store4<PT, CLIP>(row0, X, D.out_w, v0);
+        if (!CLIP || Y0 + 1 < D.out_rows) jda_store4<PT, CLIP>(row0 + D.out_pitch, X, D.out_w, v1);
     }
 }
 
 // full-size 4:4:4 colour output (JPEGPutMCU11 scalar body, jpeg.inl:3519-3559)
+template <int PT, bool CLIP>
 JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
                             uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
 {
-    const int pt = D.pixel_type;
     const uint32_t groups = tile_w >> 2;
     const uint32_t inv = jda_recip22(groups);
+    uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
     for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
         const uint32_t r = (i * inv) >> 22, x4 = (i - r * groups) * 4;
         const uint32_t Y = y_base + r, X = x_base + x4;
-        if (Y >= D.out_rows || X >= D.out_w) continue;
+        if (CLIP && (Y >= D.out_rows || X >= D.out_w)) continue;
         const uint8_t *P = plane_base + (x4 >> 3) * plane_stride + r * 8 + (x4 & 7u);
-        const uint32_t y = *(const jda_u32_alias *)P, cb = *(const jda_u32_alias *)(P + 64), cr = *(const jda_u32_alias *)(P + 128);
+        const uint32_t y = *(const jda_u32_alias *)P, cb = *(const jda_u32_alias *)(P + JDA_COEF_STRIDE), cr = *(const jda_u32_alias *)(P + 2 * JDA_COEF_STRIDE);
         uint32_t v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            v[j] = jda_rgb_pixel((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u), pt);
-        jda_store4(D.out + (size_t)Y * D.out_pitch, X, D.out_w, pt, v);
+            v[j] = jda_rgb_pixel<PT>((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u));
+        jda_store4<PT, CLIP>(out + (size_t)Y * D.out_pitch, X, D.out_w, v);
+    }
+}
+
+// pixel type and clipping are decided once per tile (uniform), so the item loops are branch-free
+template <int MODE, bool CLIP>
+JDA_HD void jda_p4_full_colour(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                               uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    const int pt = D.pixel_type;
+    if (MODE == JDA_MODE_420) {
+        if (pt == JDA_RGB8888) jda_p4_420_full<JDA_RGB8888, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+        else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_420_full<JDA_RGB565_LITTLE_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+        else jda_p4_420_full<JDA_RGB565_BIG_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+    } else {
+        if (pt == JDA_RGB8888) jda_p4_444_full<JDA_RGB8888, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+        else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_444_full<JDA_RGB565_LITTLE_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+        else jda_p4_444_full<JDA_RGB565_BIG_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
     }
 }
 
@@ -817,7 +860,7 @@ JDA_HD void jda_p4_generic(const jda_dev_desc &D, uint32_t t, const uint8_t *pla
                 v[j] = jda_output_pixel<MODE>(plane_base + m * plane_stride, x - (m << mw_log2), row, shift, pt);
             }
         }
-        jda_store4(D.out + (size_t)Y * D.out_pitch, X, D.out_w, pt, v);
+        jda_store4_rt<true>(JDA_G(uint8_t, D.out) + (size_t)Y * D.out_pitch, X, D.out_w, pt, v);
     }
 }
 
@@ -833,11 +876,11 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
     const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
     const uint8_t *plane_base = lds + L::PLANE_OFF;
     const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
-    if (MODE == JDA_MODE_420 && shift == 0 && colour_out)
-        jda_p4_420_full(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
-    else if (MODE == JDA_MODE_444 && shift == 0 && colour_out)
-        jda_p4_444_full(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
-    else
+    if (MODE != JDA_MODE_GRAY && shift == 0 && colour_out) {
+        const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;   // no clipping in this tile
+        if (inside) jda_p4_full_colour<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        else jda_p4_full_colour<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    } else
         jda_p4_generic<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
 

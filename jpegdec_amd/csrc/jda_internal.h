@@ -21,6 +21,15 @@
 // kinds of MCU the kernels are specialised for
 enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2 };
 
+// Pointers stored in descriptors are loaded from memory, so the compiler cannot know they point to
+// global memory and would emit slow generic (flat_*) accesses; device code casts them with JDA_G().
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JDA_GLOBAL __attribute__((address_space(1)))
+#else
+#define JDA_GLOBAL
+#endif
+#define JDA_G(T, p) ((T JDA_GLOBAL *)(p))
+
 // ---- device-side descriptors ----
 struct jda_dev_desc {             // one per image of a batch, 96 bytes
     const uint8_t *scan;          // filtered entropy-coded bytes (4-byte aligned, padded)

@@ -39,9 +39,9 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
 
     jda_p0_stage<MODE>(D, C, t, lds, JDA_WIN_BYTES);
     __syncthreads();
-    jda_p1_entropy<MODE>(D, C, t, lds, JDA_WIN_BYTES);
+    if (!(D.pad_[0] & 4)) jda_p1_entropy<MODE>(D, C, t, lds, JDA_WIN_BYTES);
     __syncthreads();
-    if (D.scale_shift < 2) {
+    if (D.scale_shift < 2 && !(D.pad_[0] & 4)) {
         if (!(D.pad_[0] & 2)) {
             jda_p2_columns<MODE, FAST>(D, t, lds);
             __syncthreads();
