@@ -87,22 +87,20 @@ def main():
     ap.add_argument("--options", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the control collectives (nccl = RCCL)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from jpegdec_amd.sharding import Group, env_rank_world
+
+    rank, world, local_rank = env_rank_world()
     if world != args.gpus and rank == 0:
         print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
-
-    dist = None
-    if world > 1:
+    on_gpu_backend = args.dist_backend == "nccl"
+    if world > 1 and on_gpu_backend:
         import torch
-        import torch.distributed as dist_mod
 
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl")      # RCCL on ROCm
-        dist = dist_mod
+    group = Group(backend=args.dist_backend, device="cuda" if (world > 1 and on_gpu_backend) else None)   # RCCL over xGMI; control traffic only
 
     import jpegdec_amd as J
 
@@ -113,7 +111,8 @@ def main():
     # ---- inputs: `distinct` synthetic JPEGs, prepared on the host, `batch` resident copies in HBM
     jpegs = [cached_jpeg(args.width, args.height, args.subsampling, 1234 + i) for i in range(args.distinct)]
     bits_px = 8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * args.width * args.height)
-    ctx = J.Context(local_rank)     # raises without a GPU: there is no CPU fallback
+    n_dev = max(1, J.load_library().jda_device_count())
+    ctx = J.Context(local_rank % n_dev)     # one process per GPU; raises without a GPU: there is no CPU fallback
     t_prep0 = time.perf_counter()
     prepared = [J.PreparedImage(j) for j in jpegs]
     t_prep = (time.perf_counter() - t_prep0) / len(jpegs)
@@ -129,29 +128,27 @@ def main():
     st = batch.stats
 
     def barrier():
-        ctx.sync()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        ctx.sync()                       # our launches go to the context's own HIP stream
+        if world > 1:
+            group.barrier()
+            if on_gpu_backend:
+                import torch
+
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         batch.decode()
     barrier()
     t0 = time.perf_counter()
-    ctx.timer_start()
+    ctx.timer_start()                    # HIP events on the launch stream
     for _ in range(args.steps):
         batch.decode()
     ctx.timer_stop()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_ms = ctx.timer_elapsed_ms() / args.steps           # HIP events on the launch stream
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.max(t1 - t0)         # slowest rank
+    kernel_ms = ctx.timer_elapsed_ms() / args.steps
+    total_pixels = group.sum(st["source_pixels"])       # whole job, all ranks
 
     # ---- parity spot check outside the timed region: first image of this rank vs the oracle
     parity = None
@@ -171,7 +168,7 @@ def main():
             parity = {"checker": "unavailable: %s" % e, "bit_exact": None}
 
     cpu = None
-    if not args.no_cpu_baseline and rank == 0:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
         try:
             cpu = cpu_baseline(jpegs, pt, threads=os.cpu_count() or 1)
         except Exception as e:
@@ -179,7 +176,7 @@ def main():
 
     if rank == 0:
         px_per_step = st["source_pixels"]
-        value = px_per_step * args.steps * world / elapsed / 1e6
+        value = total_pixels * args.steps / elapsed / 1e6
         # algorithmic bytes per launch: output + filtered scan + 4 B/MCU index
         n_mcus = sum(p.n_mcus for p in prepared) * (args.batch // len(prepared)) + sum(
             p.n_mcus for p in prepared[: args.batch % len(prepared)])
@@ -229,8 +226,7 @@ def main():
         d.close()
     ctx.free(out_base)
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":
