@@ -182,6 +182,15 @@ def main():
             p.n_mcus for p in prepared[: args.batch % len(prepared)])
         algo_bytes = st["output_bytes"] + st["scan_bytes"] + 4 * n_mcus
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM traffic per launch: PMC counters cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 --pmc passes of the same workload (profiles/), scaled to
+        # this batch; null for any other workload
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_v2_1_pmc_traffic.json")
+        if (os.path.exists(tp) and (args.width, args.height, args.subsampling, args.pixel_type, args.options)
+                == (4096, 4096, "4:2:0", "rgb8888", 0)):
+            traffic = json.load(open(tp))["hbm_bytes_per_image"] * args.batch
+            traffic_src = "profiles/r01_v2_1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
         line = {
             "metric": "Mpixels/s decoded",
             "value": value,
@@ -209,8 +218,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "jda_decode_strips",
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel": "jda_decode_tiles<MODE,FAST>",
                 "kernel_ms_per_launch": kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
