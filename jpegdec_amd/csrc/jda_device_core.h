@@ -549,8 +549,10 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
-    const uint32_t m = t / T::NBLK, b = t - m * T::NBLK;         // MCU within tile, block within MCU
-    if (m >= C.count) return;
+    if (t >= C.count * T::NBLK) return;
+    // lane schedule: thread t decodes the tile's t-th longest block (host-sorted, see jda_prepare)
+    const uint32_t lb = JDA_G(const uint8_t, D.blk_perm)[C.first_block + t];
+    const uint32_t m = lb / T::NBLK, b = lb - m * T::NBLK;       // MCU within tile, block within MCU
     if (MODE != JDA_MODE_GRAY && D.gray_from_color && b >= (uint32_t)T::NLUMA) return;   // :5225-5233 chroma never decoded
     const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
     const uint8_t *tab = lds + L::TAB_OFF;
@@ -561,7 +563,7 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
     TB.ac_long = JDA_G(const uint16_t, D.tables + JDA_TB_AC) + ac_id * 2048 + 1024;
     TB.zigzag = tab + JDA_LT_ZIGZAG;
     const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64;
-    int16_t *coef = (int16_t *)(lds + L::COEF_OFF + t * JDA_COEF_STRIDE);
+    int16_t *coef = (int16_t *)(lds + L::COEF_OFF + lb * JDA_COEF_STRIDE);
     uint8_t *plane = (uint8_t *)coef;                            // samples overwrite the block's own slot
 
     jda_bitreader br;
@@ -569,7 +571,7 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
     br.win = lds + L::WIN_OFF;
     br.win_lo = C.win_lo;
     br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
-    const uint32_t gb = C.first_block + t;
+    const uint32_t gb = C.first_block + lb;
     const uint32_t ix = JDA_G(const uint32_t, D.blk_index)[gb];
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
@@ -593,7 +595,7 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
     uint32_t *cnt = (uint32_t *)(lds + L::CNT_OFF);
     uint8_t *rowlist = lds + L::ROWLIST_OFF;
     if (flags == 0) {                                            // DC-only block (:5146-5154): row class 3
-        rowlist[3 * JDA_TILE_BLOCKS + jda_lds_add(&cnt[5], 1)] = (uint8_t)t;
+        rowlist[3 * JDA_TILE_BLOCKS + jda_lds_add(&cnt[5], 1)] = (uint8_t)lb;
         return;
     }
     // columns that hold data (column 0 always, :2555); rows 4-7 empty selects the short column stage
@@ -607,12 +609,12 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
     for (uint32_t col = 0; col < 8; col++) {
         if (colmask & (1u << col)) {
             const uint32_t slot = half ? base + j : (JDA_COLLIST_ENTRIES - 1u) - (base + j);   // two lists, one array
-            collist[slot] = (uint16_t)((t << 3) | col);
+            collist[slot] = (uint16_t)((lb << 3) | col);
             j++;
         }
     }
     const uint32_t rc = (flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u);       // :2686-2688
-    rowlist[rc * JDA_TILE_BLOCKS + jda_lds_add(&cnt[2 + rc], 1)] = (uint8_t)t;
+    rowlist[rc * JDA_TILE_BLOCKS + jda_lds_add(&cnt[2 + rc], 1)] = (uint8_t)lb;
 }
 
 // ---- P2 ---------------------------------------------------------------------------------------

@@ -53,6 +53,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     D.scan = jda_image_scan(img, &n);
     D.blk_index = jda_image_block_index(img, &n);
     D.blk_dc = jda_image_block_dc(img);
+    D.blk_perm = jda_image_block_perm(img);
     D.tables = jda_image_tables(img, &n);
     std::vector<jda_strip> strips;
     jda_append_strips(strips, 0, D.mcus_x, D.mcus_y, D.mode);
