@@ -92,6 +92,48 @@ JDA_HD uint32_t jda_alignbyte(uint32_t hi, uint32_t lo, uint32_t byte_shift)
 #define JDA_OPAQUE(x) ((void)0)
 #endif
 
+// ---- packed 16-bit helpers (two pixels per VALU instruction in the colour stage) ---------------
+// v_perm_b32: result byte i = byte (sel >> 8i & 0xff) of the 8-byte pool {hi = bytes 4-7, lo = bytes 0-3};
+// selector 0x0c gives 0x00 and 0x0d gives 0xff.
+JDA_HD uint32_t jda_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t pool = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t k = (sel >> (8 * i)) & 0xffu;
+        const uint32_t b = k < 8 ? (uint32_t)(pool >> (8 * k)) & 0xffu : (k == 0x0c ? 0u : 0xffu);
+        r |= b << (8 * i);
+    }
+    return r;
+#endif
+}
+// two independent 16-bit adds (v_pk_add_u16)
+JDA_HD uint32_t jda_pk_add16(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short jda_us2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(jda_us2, a) + __builtin_bit_cast(jda_us2, b));
+#else
+    return ((a + b) & 0xffffu) | ((a & 0xffff0000u) + (b & 0xffff0000u));
+#endif
+}
+// two signed 16-bit values -> two bytes saturated to 0..255 in bits 15:0, bits 31:16 zero (v_sat_pk_u8_i16)
+JDA_HD uint32_t jda_sat_pk_u8(uint32_t a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+#else
+    const int32_t lo = (int16_t)(a & 0xffffu), hi = (int16_t)(a >> 16);
+    const uint32_t l = lo < 0 ? 0u : (lo > 255 ? 255u : (uint32_t)lo), h = hi < 0 ? 0u : (hi > 255 ? 255u : (uint32_t)hi);
+    return l | (h << 8);
+#endif
+}
+
 // sign-extended 10-bit field starting at bit `lo` (the reference's "& 0x3ff" table index)
 JDA_HD int32_t jda_sext10_at(int32_t v, int lo) { return (int32_t)((uint32_t)v << (22 - lo)) >> 22; }
 JDA_HD int32_t jda_clamp255(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -739,9 +781,12 @@ JDA_HD void jda_store4_rt(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, i
 struct jda_chroma { int32_t r, g, b; };
 JDA_HD jda_chroma jda_chroma_terms(uint32_t cb8, uint32_t cr8)
 {
-    const int32_t cb = (int32_t)cb8 - 128, cr = (int32_t)cr8 - 128;
+    // k * (c - 128) == k * c - 128 k : the level shift folds into the multiply-add's constant
+    const int32_t cb = (int32_t)cb8, cr = (int32_t)cr8;
     jda_chroma t;
-    t.r = (5742 * cr) >> 12; t.g = (-1409 * cb - 2925 * cr) >> 12; t.b = (7258 * cb) >> 12;
+    t.r = (5742 * cr - 5742 * 128) >> 12;
+    t.g = (-1409 * cb - 2925 * cr + (1409 + 2925) * 128) >> 12;
+    t.b = (7258 * cb - 7258 * 128) >> 12;
     return t;
 }
 template <int PT>
@@ -763,6 +808,21 @@ JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t)
     if (PT == JDA_RGB565_BIG_ENDIAN) v = ((v & 0xffu) << 8) | (v >> 8);
     return v;
 }
+
+// Two horizontally adjacent RGB8888 pixels at once.  ypair = Y0 | Y1 << 16; tr/tg/tb = the (already
+// >> 12) chroma terms of pixel 0 in bits 15:0 and of pixel 1 in bits 31:16.  R,G,B = clamp(Y + term),
+// exactly jpeg.inl:3162-3174 (true 0..255 clamp), two pixels per instruction.
+JDA_HD void jda_rgba_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t tb, uint32_t &px0, uint32_t &px1)
+{
+    const uint32_t r2 = jda_sat_pk_u8(jda_pk_add16(ypair, tr));   // [R0, R1, 0, 0]
+    const uint32_t g2 = jda_sat_pk_u8(jda_pk_add16(ypair, tg));
+    const uint32_t b2 = jda_sat_pk_u8(jda_pk_add16(ypair, tb));
+    const uint32_t rg = jda_perm(g2, r2, 0x05010400u);            // [R0, G0, R1, G1]
+    px0 = jda_perm(b2, rg, 0x0d040100u);                          // [R0, G0, B0, 0xff]
+    px1 = jda_perm(b2, rg, 0x0d050302u);                          // [R1, G1, B1, 0xff]
+}
+JDA_HD uint32_t jda_dup16(int32_t v) { return jda_perm(0, (uint32_t)v, 0x01000100u); }        // low half in both halves
+JDA_HD uint32_t jda_pack16(int32_t lo, int32_t hi) { return jda_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
 // pixel group (the two rows share their chroma samples); items are dealt to the threads in row-major
@@ -787,10 +847,19 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
         const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
         uint32_t v0[4], v1[4];
-        v0[0] = jda_rgb_pixel<PT>(ya & 255u, c0);          v0[1] = jda_rgb_pixel<PT>((ya >> 8) & 255u, c0);
-        v0[2] = jda_rgb_pixel<PT>((ya >> 16) & 255u, c1);  v0[3] = jda_rgb_pixel<PT>(ya >> 24, c1);
-        v1[0] = jda_rgb_pixel<PT>(yb & 255u, c0);          v1[1] = jda_rgb_pixel<PT>((yb >> 8) & 255u, c0);
-        v1[2] = jda_rgb_pixel<PT>((yb >> 16) & 255u, c1);  v1[3] = jda_rgb_pixel<PT>(yb >> 24, c1);
+        if (PT == JDA_RGB8888) {
+            const uint32_t r0 = jda_dup16(c0.r), g0 = jda_dup16(c0.g), b0 = jda_dup16(c0.b);
+            const uint32_t r1 = jda_dup16(c1.r), g1 = jda_dup16(c1.g), b1 = jda_dup16(c1.b);
+            jda_rgba_pair(jda_perm(0, ya, 0x0c010c00u), r0, g0, b0, v0[0], v0[1]);
+            jda_rgba_pair(jda_perm(0, ya, 0x0c030c02u), r1, g1, b1, v0[2], v0[3]);
+            jda_rgba_pair(jda_perm(0, yb, 0x0c010c00u), r0, g0, b0, v1[0], v1[1]);
+            jda_rgba_pair(jda_perm(0, yb, 0x0c030c02u), r1, g1, b1, v1[2], v1[3]);
+        } else {
+            v0[0] = jda_rgb_pixel<PT>(ya & 255u, c0);          v0[1] = jda_rgb_pixel<PT>((ya >> 8) & 255u, c0);
+            v0[2] = jda_rgb_pixel<PT>((ya >> 16) & 255u, c1);  v0[3] = jda_rgb_pixel<PT>(ya >> 24, c1);
+            v1[0] = jda_rgb_pixel<PT>(yb & 255u, c0);          v1[1] = jda_rgb_pixel<PT>((yb >> 8) & 255u, c0);
+            v1[2] = jda_rgb_pixel<PT>((yb >> 16) & 255u, c1);  v1[3] = jda_rgb_pixel<PT>(yb >> 24, c1);
+        }
         uint8_t JDA_GLOBAL *row0 = out + (size_t)Y0 * D.out_pitch;
         jda_store4<PT, CLIP>(row0, X, D.out_w, v0);
         if (!CLIP || Y0 + 1 < D.out_rows) jda_store4<PT, CLIP>(row0 + D.out_pitch, X, D.out_w, v1);
@@ -812,9 +881,17 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint8_t *P = plane_base + (x4 >> 3) * plane_stride + r * 8 + (x4 & 7u);
         const uint32_t y = *(const jda_u32_alias *)P, cb = *(const jda_u32_alias *)(P + JDA_COEF_STRIDE), cr = *(const jda_u32_alias *)(P + 2 * JDA_COEF_STRIDE);
         uint32_t v[4];
+        if (PT == JDA_RGB8888) {
+            jda_chroma c[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            v[j] = jda_rgb_pixel<PT>((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u));
+            for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
+            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), jda_pack16(c[0].r, c[1].r), jda_pack16(c[0].g, c[1].g), jda_pack16(c[0].b, c[1].b), v[0], v[1]);
+            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), jda_pack16(c[2].r, c[3].r), jda_pack16(c[2].g, c[3].g), jda_pack16(c[2].b, c[3].b), v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                v[j] = jda_rgb_pixel<PT>((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u));
+        }
         jda_store4<PT, CLIP>(out + (size_t)Y * D.out_pitch, X, D.out_w, v);
     }
 }

@@ -17,12 +17,21 @@
 #include "jda_device_core.h"
 #include "jda_plan.h"
 
+// optional phase trace (profiling aid, off unless jda_internal_set_trace() was called): per traced
+// workgroup and wave, the shader clock at each phase boundary
+__device__ unsigned long long *g_jda_trace = nullptr;
+#define JDA_TRACE_STRIDE 64
+#define JDA_TRACE(slot) do { if (trace && lane0) trace[(blockIdx.x / JDA_TRACE_STRIDE * 3 + (t >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+
 template <int MODE, bool FAST>
 __global__ __launch_bounds__(JDA_WG_THREADS)
 void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t t = threadIdx.x;
+    unsigned long long *trace = (blockIdx.x % JDA_TRACE_STRIDE == 0) ? g_jda_trace : nullptr;
+    const bool lane0 = (t & 63u) == 0;
+    JDA_TRACE(0);
 
     // tile record and image descriptor are workgroup-uniform: keep them in SGPRs
     const jda_strip *tp = tiles + blockIdx.x;
@@ -37,19 +46,30 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
     C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
 
+    JDA_TRACE(1);
     jda_p0_stage<MODE>(D, C, t, lds, JDA_WIN_BYTES);
+    JDA_TRACE(2);
     __syncthreads();
+    JDA_TRACE(3);
     if (!(D.pad_[0] & 4)) jda_p1_entropy<MODE>(D, C, t, lds, JDA_WIN_BYTES);
+    JDA_TRACE(4);
     __syncthreads();
+    JDA_TRACE(5);
     if (D.scale_shift < 2 && !(D.pad_[0] & 4)) {
         if (!(D.pad_[0] & 2)) {
             jda_p2_columns<MODE, FAST>(D, t, lds);
+            JDA_TRACE(6);
             __syncthreads();
+            JDA_TRACE(7);
             jda_p3_rows<MODE>(D, t, lds);
+            JDA_TRACE(8);
         }
         __syncthreads();
+        JDA_TRACE(9);
     }
     if (!(D.pad_[0] & 1)) jda_p4_output<MODE>(D, S, C, t, lds);
+    JDA_TRACE(10);
+    if (trace) { __builtin_amdgcn_s_waitcnt(0); JDA_TRACE(11); }   // + time for this wave's stores to be acknowledged
 }
 
 template <int MODE, bool FAST>
@@ -65,6 +85,11 @@ static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint
     }
     hipLaunchKernelGGL((jda_decode_tiles<MODE, FAST>), dim3(n_tiles), dim3(JDA_WG_THREADS), lds_bytes, stream, descs, tiles);
     return hipGetLastError();
+}
+
+extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_trace), &dev_buf, sizeof(dev_buf));
 }
 
 // Launch entry used by jda_runtime.cpp.
