@@ -586,15 +586,36 @@ JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t 
 }
 
 // ---- P1 ---------------------------------------------------------------------------------------
+// What a thread needs from HBM before it can start decoding its block: issued at kernel entry so the
+// two dependent loads (lane schedule -> index entry) overlap P0's table / window staging.
+struct jda_p1_inputs { uint32_t lb, ix; int32_t pred; bool active; };
+
 template <int MODE>
-JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t t, uint8_t *lds, uint32_t win_cap)
+JDA_HD jda_p1_inputs jda_p1_prefetch(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t t)
+{
+    typedef jda_mode_traits<MODE> T;
+    jda_p1_inputs in;
+    in.lb = 0; in.ix = 0; in.pred = 0;
+    in.active = t < C.count * T::NBLK;
+    if (in.active) {
+        // lane schedule: thread t decodes the tile's t-th longest block (host-sorted, see jda_prepare)
+        in.lb = JDA_G(const uint8_t, D.blk_perm)[C.first_block + t];
+        const uint32_t gb = C.first_block + in.lb;
+        in.ix = JDA_G(const uint32_t, D.blk_index)[gb];
+        in.pred = JDA_G(const int16_t, D.blk_dc)[gb];
+    }
+    return in;
+}
+
+template <int MODE>
+JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, uint8_t *lds, uint32_t win_cap)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
-    if (t >= C.count * T::NBLK) return;
-    // lane schedule: thread t decodes the tile's t-th longest block (host-sorted, see jda_prepare)
-    const uint32_t lb = JDA_G(const uint8_t, D.blk_perm)[C.first_block + t];
+    if (!in.active) return;
+    const uint32_t lb = in.lb;
     const uint32_t m = lb / T::NBLK, b = lb - m * T::NBLK;       // MCU within tile, block within MCU
+    (void)m;
     if (MODE != JDA_MODE_GRAY && D.gray_from_color && b >= (uint32_t)T::NLUMA) return;   // :5225-5233 chroma never decoded
     const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
     const uint8_t *tab = lds + L::TAB_OFF;
@@ -613,12 +634,11 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_
     br.win = lds + L::WIN_OFF;
     br.win_lo = C.win_lo;
     br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
-    const uint32_t gb = C.first_block + lb;
-    const uint32_t ix = JDA_G(const uint32_t, D.blk_index)[gb];
+    const uint32_t ix = in.ix;
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
     br.bits = jda_load_be64(br, br.pos);
-    int32_t pred = JDA_G(const int16_t, D.blk_dc)[gb];
+    int32_t pred = in.pred;
 
     const int shift = D.scale_shift;
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)

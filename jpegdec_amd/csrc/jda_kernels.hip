@@ -46,12 +46,13 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
     C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
 
+    const jda_p1_inputs p1in = jda_p1_prefetch<MODE>(D, C, t);   // in flight while P0 stages LDS
     JDA_TRACE(1);
     jda_p0_stage<MODE>(D, C, t, lds, JDA_WIN_BYTES);
     JDA_TRACE(2);
     __syncthreads();
     JDA_TRACE(3);
-    if (!(D.pad_[0] & 4)) jda_p1_entropy<MODE>(D, C, t, lds, JDA_WIN_BYTES);
+    if (!(D.pad_[0] & 4)) jda_p1_entropy<MODE>(D, C, p1in, lds, JDA_WIN_BYTES);
     JDA_TRACE(4);
     __syncthreads();
     JDA_TRACE(5);

@@ -29,7 +29,7 @@ static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles
         memset(lds, 0xA5, L::TOTAL_BYTES);       // poison: LDS is not zero-initialised on the GPU either
         const jda_tile_ctx C = jda_tile_setup<MODE>(D, S);
         for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p0_stage<MODE>(D, C, t, lds, g_window_bytes);
-        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p1_entropy<MODE>(D, C, t, lds, g_window_bytes);
+        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p1_entropy<MODE>(D, C, jda_p1_prefetch<MODE>(D, C, t), lds, g_window_bytes);
         if (D.scale_shift < 2) {
             for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p2_columns<MODE, FAST>(D, t, lds);
             for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p3_rows<MODE>(D, t, lds);
