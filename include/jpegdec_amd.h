@@ -100,9 +100,6 @@ const jda_image_info *jda_image_get_info(const jda_image *img);
 const uint8_t *jda_image_scan(const jda_image *img, uint32_t *len);
 const uint32_t *jda_image_block_index(const jda_image *img, uint32_t *n_mcus_ok);
 const int16_t *jda_image_block_dc(const jda_image *img);
-/* lane schedule (n_blocks bytes): for every tile of 192 consecutive blocks of an MCU row, the block ids
- * 0..191 of the tile ordered by decreasing Huffman symbol count (pure scheduling hint for the kernels) */
-const uint8_t *jda_image_block_perm(const jda_image *img);
 /* the table blob uploaded to the GPU: DC LUTs 2x1024 B, AC LUTs 2x2048 uint16, quant 4x64 int16 */
 const uint8_t *jda_image_tables(const jda_image *img, uint32_t *bytes);
 /* number of places where the reference's un-refilled magnitude read drops low bits

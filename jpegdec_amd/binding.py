@@ -55,7 +55,6 @@ _PROTOTYPES = [
     ("jda_image_scan", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_block_index", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_block_dc", _P, [_P]),
-    ("jda_image_block_perm", _P, [_P]),
     ("jda_image_tables", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_truncation_events", C.c_uint32, [_P]),
     ("jda_output_geometry", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 5),
@@ -173,10 +172,6 @@ class PreparedImage:
     def block_dc(self) -> np.ndarray:
         p = self.lib.jda_image_block_dc(self.handle)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(self.n_blocks,)).copy()
-
-    def block_perm(self) -> np.ndarray:
-        p = self.lib.jda_image_block_perm(self.handle)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n_blocks,)).copy()
 
     def tables(self) -> np.ndarray:
         n = C.c_uint32(0)

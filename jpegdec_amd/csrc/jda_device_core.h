@@ -28,42 +28,44 @@
 #define JDA_HD static inline __attribute__((always_inline))
 #endif
 
-// ---- workgroup tile and LDS layout ------------------------------------------------------------
-// One 192-thread workgroup (3 wavefronts) decodes one "tile": 192 consecutive 8x8 blocks of one MCU
-// row = 32 MCUs of 4:2:0, 64 MCUs of 4:4:4 or 192 MCUs of a gray image.
-#define JDA_WG_THREADS 192
-#define JDA_TILE_BLOCKS 192
+// ---- tile and LDS layout -------------------------------------------------------------------------
+// One wavefront (64 threads) decodes one "tile": up to 64 consecutive 8x8 blocks of one MCU row =
+// 10 MCUs of 4:2:0 (60 blocks), 21 MCUs of 4:4:4 (63 blocks) or 64 MCUs of a gray image.  The four
+// wavefronts of a workgroup share nothing but the image's tables in LDS, so after the tables are
+// staged there is no workgroup barrier: every phase boundary is a wave-local fence.
+#define JDA_TILE_THREADS 64
+#define JDA_WAVES_PER_WG 4
 #define JDA_COEF_STRIDE 136      // bytes per block in LDS: 64 int16 + 8 pad (row reads stay 8-byte aligned)
-#define JDA_WIN_BYTES 2048       // LDS window over the tile's slice of the filtered scan
-#define JDA_COLLIST_ENTRIES 1536 // 192 blocks x 8 columns, uint16 each
+#define JDA_WIN_BYTES 768        // per-wave LDS window over the tile's slice of the filtered scan
+#define JDA_COLLIST_ENTRIES 512  // 64 blocks x 8 columns, uint16 each
 
 template <int MODE> struct jda_mode_traits;
 template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
 template <> struct jda_mode_traits<JDA_MODE_444>  { enum { NLUMA = 1, NBLK = 3, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
 template <> struct jda_mode_traits<JDA_MODE_420>  { enum { NLUMA = 4, NBLK = 6, MCU_W = 16, MCU_H = 16, MCU_W_LOG2 = 4 }; };
 
-// LDS copy of the table blob: DC LUTs, the SHORT halves of the AC LUTs (codes that do not start
-// with six 1 bits; the long halves are rare and stay in global memory), quantisers, zigzag.
+// LDS copy of the table blob (one per workgroup): DC LUTs, the SHORT halves of the AC LUTs (codes
+// that do not start with six 1 bits; the long halves are rare and stay in global memory),
+// quantisers, zigzag.
 #define JDA_LT_DC      0         // 2 x 1024
 #define JDA_LT_AC      2048      // 2 x 1024 uint16
 #define JDA_LT_QUANT   6144      // 4 x 64 int16
 #define JDA_LT_ZIGZAG  6656      // 64
 #define JDA_LT_BYTES   6720
 
-template <int MODE> struct jda_lds_layout {
+template <int MODE> struct jda_lds_layout {       // the per-WAVE region
     enum {
-        MCUS = JDA_TILE_BLOCKS / jda_mode_traits<MODE>::NBLK,        // MCUs per tile
-        TAB_OFF = 0,
+        MCUS = JDA_TILE_THREADS / jda_mode_traits<MODE>::NBLK,       // MCUs per tile: 10 / 21 / 64
+        BLOCKS = MCUS * jda_mode_traits<MODE>::NBLK,                 // blocks per tile: 60 / 63 / 64
         // one 136-byte slot per block: int16[64] coefficients, later (first 64 bytes) its 8x8 samples --
         // the row stage stores its bytes over the block it has just read, as the reference does (:2682)
-        COEF_OFF = JDA_LT_BYTES,
-        ROWLIST_OFF = COEF_OFF + JDA_TILE_BLOCKS * JDA_COEF_STRIDE,  // 4 classes x 192 block ids (uint8)
-        CNT_OFF = ROWLIST_OFF + 4 * JDA_TILE_BLOCKS,                // 8 uint32 counters
+        COEF_OFF = 0,
+        ROWLIST_OFF = COEF_OFF + JDA_TILE_THREADS * JDA_COEF_STRIDE, // 4 classes x 64 block ids (uint8)
+        CNT_OFF = ROWLIST_OFF + 4 * JDA_TILE_THREADS,               // 8 uint32 counters
         COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
         WIN_OFF = COLLIST_OFF + JDA_COLLIST_ENTRIES * 2,
-        TOTAL_BYTES = WIN_OFF + JDA_WIN_BYTES,                      // 39,264 B: four workgroups per CU
+        WAVE_BYTES = WIN_OFF + JDA_WIN_BYTES,                       // 10,784 B
         PLANE_OFF = COEF_OFF,
-        BLOCK_STRIDE = JDA_COEF_STRIDE,                             // bytes between consecutive blocks' samples
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE // bytes between consecutive MCUs' samples
     };
 };
@@ -183,15 +185,15 @@ JDA_HD void jda_refill(jda_bitreader &br)
     }
 }
 
-// Cooperative copy of the tile's part of the scan into the LDS window: thread t copies the 16-byte
-// chunks t, t+192, ...  Every thread of the workgroup calls it; a barrier follows.
+// Cooperative copy of the tile's part of the scan into the wave's LDS window: lane l copies the
+// 16-byte chunks l, l+64, ...  Every lane of the wave calls it; a wave fence follows.
 struct jda_chunk16 { uint32_t w[4]; };
 typedef jda_chunk16 __attribute__((may_alias)) jda_chunk16_alias;
 JDA_HD void jda_window_fill(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint8_t *win, uint32_t lane)
 {
     const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
     jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
-    for (uint32_t i = lane; i < (win_len >> 4); i += JDA_WG_THREADS) dst[i] = src[i];
+    for (uint32_t i = lane; i < (win_len >> 4); i += JDA_TILE_THREADS) dst[i] = src[i];
 }
 
 // EXTEND of the next s bits of the (un-refilled) window (jpeg.inl:2249-2252, 2155-2158)
@@ -509,8 +511,8 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 
 
 // ================================================================================================
-// Tile phases.  Every thread of the 192-thread workgroup runs each phase; a workgroup barrier
-// separates consecutive phases (the host emulator runs all threads of a phase, then the next).
+// Tile phases.  Every lane of the tile's wavefront runs each phase; a wave-local fence separates
+// consecutive phases (the host emulator runs all 64 lanes of a phase, then the next).
 //
 //   P0  tables -> LDS, the tile's slice of the scan -> LDS window, zero the list counters
 //   P1  thread = block: Huffman/RLE expand into the block's int16[64] in LDS (JPEGDecodeMCU,
@@ -534,7 +536,7 @@ JDA_HD uint32_t jda_pick3(const uint8_t ids[3], uint32_t c)
 
 struct jda_tile_ctx {                 // wave-uniform facts about the tile, computed once per thread
     uint32_t first_mcu;               // linear MCU index of the tile's first MCU
-    uint32_t count;                   // MCUs of the tile that are decoded (<= MCUS, clipped by n_mcus_ok)
+    uint32_t count;                   // MCUs of the tile that are decoded (<= MCUS, clipped by n_mcus_ok; 0 = padding tile)
     uint32_t first_block;             // linear block index of the tile's first block
     uint32_t win_lo, win_len;         // bytes of the scan staged in LDS
 };
@@ -564,15 +566,14 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
 }
 
 // ---- P0 ---------------------------------------------------------------------------------------
-template <int MODE>
-JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t t, uint8_t *lds, uint32_t win_cap)
+// tables: once per workgroup (tid = thread in workgroup, nthreads = workgroup size)
+JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds)
 {
-    typedef jda_lds_layout<MODE> L;
     const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, D.tables);
-    jda_chunk16_alias *tab = (jda_chunk16_alias *)(lds + L::TAB_OFF);
+    jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;
     // quant + zigzag: blob[10240, 10816) -> LT_QUANT
-    for (uint32_t i = t; i < JDA_LT_BYTES / 16; i += JDA_WG_THREADS) {
+    for (uint32_t i = tid; i < JDA_LT_BYTES / 16; i += nthreads) {
         uint32_t src;
         if (i < 128) src = i;                                   // DC
         else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
@@ -580,9 +581,16 @@ JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t 
         else src = (JDA_TB_QUANT >> 4) + (i - 384);
         tab[i] = blob[src];
     }
-    if (t < 8) ((uint32_t *)(lds + L::CNT_OFF))[t] = 0;
+}
+
+// per wave: zero the list counters, stage the tile's slice of the scan
+template <int MODE>
+JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t t, uint8_t *wl, uint32_t win_cap)
+{
+    typedef jda_lds_layout<MODE> L;
+    if (t < 8) ((uint32_t *)(wl + L::CNT_OFF))[t] = 0;
     const uint32_t len = C.win_len < win_cap ? C.win_len : win_cap;
-    jda_window_fill(JDA_G(const uint8_t, D.scan), C.win_lo, len, lds + L::WIN_OFF, t);
+    jda_window_fill(JDA_G(const uint8_t, D.scan), C.win_lo, len, wl + L::WIN_OFF, t);
 }
 
 // ---- P1 ---------------------------------------------------------------------------------------
@@ -598,8 +606,7 @@ JDA_HD jda_p1_inputs jda_p1_prefetch(const jda_dev_desc &D, const jda_tile_ctx &
     in.lb = 0; in.ix = 0; in.pred = 0;
     in.active = t < C.count * T::NBLK;
     if (in.active) {
-        // lane schedule: thread t decodes the tile's t-th longest block (host-sorted, see jda_prepare)
-        in.lb = JDA_G(const uint8_t, D.blk_perm)[C.first_block + t];
+        in.lb = t;
         const uint32_t gb = C.first_block + in.lb;
         in.ix = JDA_G(const uint32_t, D.blk_index)[gb];
         in.pred = JDA_G(const int16_t, D.blk_dc)[gb];
@@ -608,7 +615,7 @@ JDA_HD jda_p1_inputs jda_p1_prefetch(const jda_dev_desc &D, const jda_tile_ctx &
 }
 
 template <int MODE>
-JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, uint8_t *lds, uint32_t win_cap)
+JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const uint8_t *tab, uint8_t *wl, uint32_t win_cap)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
@@ -618,7 +625,6 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
     (void)m;
     if (MODE != JDA_MODE_GRAY && D.gray_from_color && b >= (uint32_t)T::NLUMA) return;   // :5225-5233 chroma never decoded
     const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
-    const uint8_t *tab = lds + L::TAB_OFF;
     jda_tables TB;
     const uint32_t dc_id = jda_pick3(D.dc_id, c), ac_id = jda_pick3(D.ac_id, c);
     TB.dc = tab + JDA_LT_DC + dc_id * 1024;
@@ -626,12 +632,12 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
     TB.ac_long = JDA_G(const uint16_t, D.tables + JDA_TB_AC) + ac_id * 2048 + 1024;
     TB.zigzag = tab + JDA_LT_ZIGZAG;
     const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64;
-    int16_t *coef = (int16_t *)(lds + L::COEF_OFF + lb * JDA_COEF_STRIDE);
+    int16_t *coef = (int16_t *)(wl + L::COEF_OFF + lb * JDA_COEF_STRIDE);
     uint8_t *plane = (uint8_t *)coef;                            // samples overwrite the block's own slot
 
     jda_bitreader br;
     br.base = JDA_G(const uint8_t, D.scan);
-    br.win = lds + L::WIN_OFF;
+    br.win = wl + L::WIN_OFF;
     br.win_lo = C.win_lo;
     br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
     const uint32_t ix = in.ix;
@@ -654,10 +660,10 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
         return;
     }
     const uint32_t flags = jda_decode_block<64>(br, TB, coef, pred);
-    uint32_t *cnt = (uint32_t *)(lds + L::CNT_OFF);
-    uint8_t *rowlist = lds + L::ROWLIST_OFF;
+    uint32_t *cnt = (uint32_t *)(wl + L::CNT_OFF);
+    uint8_t *rowlist = wl + L::ROWLIST_OFF;
     if (flags == 0) {                                            // DC-only block (:5146-5154): row class 3
-        rowlist[3 * JDA_TILE_BLOCKS + jda_lds_add(&cnt[5], 1)] = (uint8_t)lb;
+        rowlist[3 * JDA_TILE_THREADS + jda_lds_add(&cnt[5], 1)] = (uint8_t)lb;
         return;
     }
     // columns that hold data (column 0 always, :2555); rows 4-7 empty selects the short column stage
@@ -665,7 +671,7 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
     const uint32_t ncols = jda_popcount8(colmask);
     const bool half = (flags & 0x2000u) == 0;
     const uint32_t base = jda_lds_add(&cnt[half ? 0 : 1], ncols);
-    uint16_t *collist = (uint16_t *)(lds + L::COLLIST_OFF);
+    uint16_t *collist = (uint16_t *)(wl + L::COLLIST_OFF);
     uint32_t j = 0;
 #pragma unroll
     for (uint32_t col = 0; col < 8; col++) {
@@ -676,20 +682,20 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
         }
     }
     const uint32_t rc = (flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u);       // :2686-2688
-    rowlist[rc * JDA_TILE_BLOCKS + jda_lds_add(&cnt[2 + rc], 1)] = (uint8_t)lb;
+    rowlist[rc * JDA_TILE_THREADS + jda_lds_add(&cnt[2 + rc], 1)] = (uint8_t)lb;
 }
 
 // ---- P2 ---------------------------------------------------------------------------------------
 template <int MODE, bool FAST, bool HALF>
-JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, uint8_t *lds)
+JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, const uint8_t *tab, uint8_t *wl)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
     const uint32_t blk = item >> 3, col = item & 7u;
     const uint32_t b = blk % T::NBLK;
     const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
-    const int16_t *quant = (const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64 + col;
-    int16_t *coef = (int16_t *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE) + col;
+    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64 + col;
+    int16_t *coef = (int16_t *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE) + col;
     int32_t cv[8], qv[8], r[8];
 #pragma unroll
     for (int row = 0; row < 8; row++) {
@@ -702,26 +708,26 @@ JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, uint8_t *ld
 }
 
 template <int MODE, bool FAST>
-JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
+JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, const uint8_t *tab, uint8_t *wl)
 {
     typedef jda_lds_layout<MODE> L;
-    const uint32_t *cnt = (const uint32_t *)(lds + L::CNT_OFF);
-    const uint16_t *collist = (const uint16_t *)(lds + L::COLLIST_OFF);
+    const uint32_t *cnt = (const uint32_t *)(wl + L::CNT_OFF);
+    const uint16_t *collist = (const uint16_t *)(wl + L::COLLIST_OFF);
     const uint32_t n_half = cnt[0], n_full = cnt[1];
-    for (uint32_t i = t; i < n_half; i += JDA_WG_THREADS) jda_p2_column_item<MODE, FAST, true>(D, collist[i], lds);
-    for (uint32_t i = t; i < n_full; i += JDA_WG_THREADS)
-        jda_p2_column_item<MODE, FAST, false>(D, collist[(JDA_COLLIST_ENTRIES - 1u) - i], lds);
+    for (uint32_t i = t; i < n_half; i += JDA_TILE_THREADS) jda_p2_column_item<MODE, FAST, true>(D, collist[i], tab, wl);
+    for (uint32_t i = t; i < n_full; i += JDA_TILE_THREADS)
+        jda_p2_column_item<MODE, FAST, false>(D, collist[(JDA_COLLIST_ENTRIES - 1u) - i], tab, wl);
 }
 
 // ---- P3 ---------------------------------------------------------------------------------------
 template <int MODE, int RC>
-JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *lds, uint32_t n_blocks)
+JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *wl, uint32_t n_blocks)
 {
     typedef jda_lds_layout<MODE> L;
-    const uint8_t *list = lds + L::ROWLIST_OFF + RC * JDA_TILE_BLOCKS;
-    for (uint32_t i = t; i < n_blocks * 8; i += JDA_WG_THREADS) {
+    const uint8_t *list = wl + L::ROWLIST_OFF + RC * JDA_TILE_THREADS;
+    for (uint32_t i = t; i < n_blocks * 8; i += JDA_TILE_THREADS) {
         const uint32_t blk = list[i >> 3], row = i & 7u;
-        const jda_u64_alias *src = (const jda_u64_alias *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 16);
+        const jda_u64_alias *src = (const jda_u64_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 16);
         int32_t sv[8];
         const uint64_t a = src[0];
         sv[0] = (int16_t)a; sv[1] = (int16_t)(a >> 16); sv[2] = (int16_t)(a >> 32); sv[3] = (int16_t)(a >> 48);
@@ -734,31 +740,31 @@ JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *lds, uint32_t n_blocks)
         // r/2's int16 data -- safe because the 8 rows of a block are handled by 8 adjacent lanes of one
         // wavefront in the same instruction (all reads precede all writes), and on the sequential host
         // emulator rows are visited in ascending order
-        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 8);
+        jda_u32_alias *dst = (jda_u32_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 8);
         dst[0] = p.lo; dst[1] = p.hi;
     }
 }
 
 template <int MODE>
-JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, uint8_t *lds)
+JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, const uint8_t *tab, uint8_t *wl)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
-    const uint32_t *cnt = (const uint32_t *)(lds + L::CNT_OFF);
-    jda_p3_row_class<MODE, 0>(t, lds, cnt[2]);
-    jda_p3_row_class<MODE, 1>(t, lds, cnt[3]);
-    jda_p3_row_class<MODE, 2>(t, lds, cnt[4]);
+    const uint32_t *cnt = (const uint32_t *)(wl + L::CNT_OFF);
+    jda_p3_row_class<MODE, 0>(t, wl, cnt[2]);
+    jda_p3_row_class<MODE, 1>(t, wl, cnt[3]);
+    jda_p3_row_class<MODE, 2>(t, wl, cnt[4]);
     // DC-only blocks: all 64 samples = RT((pred * q0) >> 5)  (:5146-5154); one thread per block (rare)
-    const uint8_t *list = lds + L::ROWLIST_OFF + 3 * JDA_TILE_BLOCKS;
+    const uint8_t *list = wl + L::ROWLIST_OFF + 3 * JDA_TILE_THREADS;
     const uint32_t n_dc = cnt[5];
-    for (uint32_t i = t; i < n_dc; i += JDA_WG_THREADS) {
+    for (uint32_t i = t; i < n_dc; i += JDA_TILE_THREADS) {
         const uint32_t blk = list[i];
         const uint32_t b = blk % T::NBLK;
         const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
-        const int32_t q0 = ((const int16_t *)(lds + L::TAB_OFF + JDA_LT_QUANT))[jda_pick3(D.q_id, c) * 64];
-        const int32_t dc = *(const int16_t *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE);
+        const int32_t q0 = ((const int16_t *)(tab + JDA_LT_QUANT))[jda_pick3(D.q_id, c) * 64];
+        const int32_t dc = *(const int16_t *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE);
         const uint32_t v = jda_range_limit5(dc * q0) * 0x01010101u;
-        jda_u32_alias *dst = (jda_u32_alias *)(lds + L::COEF_OFF + blk * JDA_COEF_STRIDE);
+        jda_u32_alias *dst = (jda_u32_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE);
 #pragma unroll
         for (int k = 0; k < 16; k++) dst[k] = v;
     }
@@ -770,10 +776,21 @@ JDA_HD uint32_t jda_recip22(uint32_t d) { return ((1u << 22) + d - 1u) / d; }
 
 // ---- P4: colour conversion + coalesced stores ------------------------------------------------------
 // four converted pixels -> memory in the requested format.  CLIP: the group may cross the right edge.
+// nvalid: how many of the four belong to this tile (a tile's width need not be a multiple of 4, and
+// its neighbour -- another wavefront -- owns the pixels right of it).
 template <int PT, bool CLIP>
-JDA_HD void jda_store4(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, const uint32_t v[4])
+JDA_HD void jda_store4(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, const uint32_t v[4], uint32_t nvalid = 4)
 {
-    const uint32_t n = (!CLIP || X + 4 <= out_w) ? 4u : out_w - X;
+    uint32_t n = (!CLIP || X + 4 <= out_w) ? 4u : out_w - X;
+    if (CLIP && nvalid < n) n = nvalid;
+    if (CLIP && (X & 3u)) {                              // tile starts off a 4-pixel boundary: element stores
+        for (uint32_t j = 0; j < n; j++) {
+            if (PT == JDA_RGB8888) ((jda_u32_alias JDA_GLOBAL *)(row + (size_t)X * 4))[j] = v[j];
+            else if (PT == JDA_EIGHT_BIT_GRAYSCALE) row[X + j] = (uint8_t)v[j];
+            else ((uint16_t JDA_GLOBAL *)(row + (size_t)X * 2))[j] = (uint16_t)v[j];
+        }
+        return;
+    }
     if (PT == JDA_RGB8888) {
         jda_u32_alias JDA_GLOBAL *d = (jda_u32_alias JDA_GLOBAL *)(row + (size_t)X * 4);
         if (n == 4) { d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
@@ -789,11 +806,11 @@ JDA_HD void jda_store4(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, cons
 
 // runtime pixel type -> the templated store (used by the generic path only)
 template <bool CLIP>
-JDA_HD void jda_store4_rt(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, int pt, const uint32_t v[4])
+JDA_HD void jda_store4_rt(uint8_t JDA_GLOBAL *row, uint32_t X, uint32_t out_w, int pt, const uint32_t v[4], uint32_t nvalid)
 {
-    if (pt == JDA_RGB8888) jda_store4<JDA_RGB8888, CLIP>(row, X, out_w, v);
-    else if (pt == JDA_EIGHT_BIT_GRAYSCALE) jda_store4<JDA_EIGHT_BIT_GRAYSCALE, CLIP>(row, X, out_w, v);
-    else jda_store4<JDA_RGB565_LITTLE_ENDIAN, CLIP>(row, X, out_w, v);
+    if (pt == JDA_RGB8888) jda_store4<JDA_RGB8888, CLIP>(row, X, out_w, v, nvalid);
+    else if (pt == JDA_EIGHT_BIT_GRAYSCALE) jda_store4<JDA_EIGHT_BIT_GRAYSCALE, CLIP>(row, X, out_w, v, nvalid);
+    else jda_store4<JDA_RGB565_LITTLE_ENDIAN, CLIP>(row, X, out_w, v, nvalid);
 }
 
 // one chroma sample shared by a 2x2 (or 1x1) group: the products of jpeg.inl:3158-3161, already
@@ -854,7 +871,7 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
     const uint32_t groups = tile_w >> 2;                          // 4-pixel groups per row (tile_w is a multiple of 16)
     const uint32_t inv = jda_recip22(groups);
     uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
-    for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
+    for (uint32_t i = t; i < groups * 8; i += JDA_TILE_THREADS) {
         const uint32_t rp = (i * inv) >> 22, x4 = (i - rp * groups) * 4;
         const uint32_t Y0 = y_base + 2 * rp, X = x_base + x4;
         if (CLIP && (Y0 >= D.out_rows || X >= D.out_w)) continue;
@@ -894,7 +911,7 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
     const uint32_t groups = tile_w >> 2;
     const uint32_t inv = jda_recip22(groups);
     uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
-    for (uint32_t i = t; i < groups * 8; i += JDA_WG_THREADS) {
+    for (uint32_t i = t; i < groups * 8; i += JDA_TILE_THREADS) {
         const uint32_t r = (i * inv) >> 22, x4 = (i - r * groups) * 4;
         const uint32_t Y = y_base + r, X = x_base + x4;
         if (CLIP && (Y >= D.out_rows || X >= D.out_w)) continue;
@@ -945,7 +962,7 @@ JDA_HD void jda_p4_generic(const jda_dev_desc &D, uint32_t t, const uint8_t *pla
     const int pt = D.pixel_type;
     const uint32_t groups = (tile_w + 3) >> 2;
     const uint32_t inv = jda_recip22(groups);
-    for (uint32_t i = t; i < groups * mh; i += JDA_WG_THREADS) {
+    for (uint32_t i = t; i < groups * mh; i += JDA_TILE_THREADS) {
         const uint32_t row = (i * inv) >> 22, x4 = (i - row * groups) * 4;
         const uint32_t Y = y_base + row, X = x_base + x4;
         if (Y >= D.out_rows || X >= D.out_w) continue;
@@ -959,12 +976,12 @@ JDA_HD void jda_p4_generic(const jda_dev_desc &D, uint32_t t, const uint8_t *pla
                 v[j] = jda_output_pixel<MODE>(plane_base + m * plane_stride, x - (m << mw_log2), row, shift, pt);
             }
         }
-        jda_store4_rt<true>(JDA_G(uint8_t, D.out) + (size_t)Y * D.out_pitch, X, D.out_w, pt, v);
+        jda_store4_rt<true>(JDA_G(uint8_t, D.out) + (size_t)Y * D.out_pitch, X, D.out_w, pt, v, tile_w - x4 < 4u ? tile_w - x4 : 4u);
     }
 }
 
 template <int MODE>
-JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *lds)
+JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *wl)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
@@ -973,7 +990,7 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
     const uint32_t mw = (uint32_t)T::MCU_W >> shift, mh = (uint32_t)T::MCU_H >> shift;   // MCU tile in output px
     const uint32_t tile_w = C.count * mw;                         // output pixels per row of the tile
     const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
-    const uint8_t *plane_base = lds + L::PLANE_OFF;
+    const uint8_t *plane_base = wl + L::PLANE_OFF;
     const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
     if (MODE != JDA_MODE_GRAY && shift == 0 && colour_out) {
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;   // no clipping in this tile

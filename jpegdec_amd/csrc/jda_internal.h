@@ -15,7 +15,6 @@
 #define JDA_TB_ZIGZAG    10752    // 64 bytes         (cZigZag2: zigzag position -> natural index)
 #define JDA_TABLE_BYTES  10816
 
-#define JDA_TILE_BLOCKS_HOST 192 // blocks per workgroup tile (= JDA_TILE_BLOCKS of the kernels)
 #define JDA_SCAN_PAD     32       // zero bytes after the filtered scan (window loads overrun)
 #define JDA_INDEX_OFF_BITS 7      // index entry = (byte position << 7) | bit offset (0..64)
 
@@ -36,7 +35,6 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     const uint8_t *scan;          // filtered entropy-coded bytes (4-byte aligned, padded)
     const uint32_t *blk_index;    // n_blocks+1 entries: (byte position << 7) | bit offset at each block start
     const int16_t *blk_dc;        // n_blocks: the block's DC predictor on entry
-    const uint8_t *blk_perm;      // n_blocks: per tile, block ids (0..191) in decreasing symbol-count order
     const uint8_t *tables;        // JDA_TABLE_BYTES
     uint8_t *out;                 // output surface
     uint32_t out_pitch;           // bytes
@@ -54,11 +52,11 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     uint8_t pad_[1];
 };
 
-struct jda_strip {                // one workgroup's tile: <= 192 consecutive blocks (32/64/192 MCUs) of one MCU row
+struct jda_strip {                // one wavefront's tile: <= 64 consecutive blocks (10/21/64 MCUs) of one MCU row
     uint32_t image;               // index into the descriptor array
     uint32_t mcu_y;
     uint32_t mcu_x0;
-    uint32_t count;               // MCUs in the tile
+    uint32_t count;               // MCUs in the tile (0 = padding entry)
 };
 
 #endif

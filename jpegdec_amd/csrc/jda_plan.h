@@ -54,11 +54,15 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     return JDA_SUCCESS;
 }
 
-// Tiles of one image: each MCU row is cut into runs of 192 blocks (32 MCUs of 4:2:0, 64 of 4:4:4,
-// 192 of gray); one workgroup decodes one tile.
+// Tiles of one image: each MCU row is cut into runs of <= 64 blocks (10 MCUs of 4:2:0, 21 of 4:4:4,
+// 64 of gray); one wavefront decodes one tile, four tiles make a workgroup.  The list is padded
+// with empty tiles per image so that a workgroup never spans two images (it stages one table set).
+#define JDA_TILES_PER_WG 4
+inline uint32_t jda_mcus_per_tile(int mode) { return mode == JDA_MODE_420 ? 10u : (mode == JDA_MODE_444 ? 21u : 64u); }
+
 inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode)
 {
-    const uint32_t per = mode == JDA_MODE_420 ? 32u : (mode == JDA_MODE_444 ? 64u : 192u);
+    const uint32_t per = jda_mcus_per_tile(mode);
     for (uint32_t y = 0; y < mcus_y; y++)
         for (uint32_t x = 0; x < mcus_x; x += per) {
             jda_strip s;
@@ -66,6 +70,11 @@ inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_
             s.count = mcus_x - x < per ? mcus_x - x : per;
             v.push_back(s);
         }
+    while (v.size() % JDA_TILES_PER_WG) {
+        jda_strip s;
+        s.image = image; s.mcu_y = 0; s.mcu_x0 = 0; s.count = 0;
+        v.push_back(s);
+    }
 }
 
 #endif

@@ -30,7 +30,7 @@ struct jda_ctx {
 struct jda_dev_image {
     uint8_t *base;            // one allocation: tables | index | dc | scan
     size_t bytes;
-    size_t off_tables, off_index, off_dc, off_perm, off_scan;
+    size_t off_tables, off_index, off_dc, off_scan;
     jda_image_info info;
     uint32_t scan_len, n_mcus_ok;
     uint8_t dc_id[3], ac_id[3], q_id[3];
@@ -162,8 +162,7 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     d->off_tables = 0;
     d->off_index = align16(tbytes);
     d->off_dc = d->off_index + align16((n_blocks + 1) * sizeof(uint32_t));
-    d->off_perm = d->off_dc + align16(n_blocks * sizeof(int16_t));
-    d->off_scan = d->off_perm + align16(n_blocks);
+    d->off_scan = d->off_dc + align16(n_blocks * sizeof(int16_t));
     d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
     hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&d->base, d->bytes);
@@ -173,7 +172,6 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     memcpy(stage.data() + d->off_tables, tables, tbytes);
     memcpy(stage.data() + d->off_index, index, (n_blocks + 1) * sizeof(uint32_t));
     memcpy(stage.data() + d->off_dc, dc, n_blocks * sizeof(int16_t));
-    memcpy(stage.data() + d->off_perm, jda_image_block_perm(img), n_blocks);
     memcpy(stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
     e = hipMemcpyAsync(d->base, stage.data(), d->bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -231,7 +229,6 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         D.tables = im->base + im->off_tables;
         D.blk_index = (const uint32_t *)(im->base + im->off_index);
         D.blk_dc = (const int16_t *)(im->base + im->off_dc);
-        D.blk_perm = im->base + im->off_perm;
         D.scan = im->base + im->off_scan;
         D.out = (uint8_t *)O.pixels;
         D.out_pitch = (uint32_t)O.pitch_bytes;
@@ -244,7 +241,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         st.source_pixels += (int64_t)I.width * I.height;
         st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
         st.scan_bytes += im->scan_len;
-        st.index_bytes += (int64_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu * 7;
+        st.index_bytes += (int64_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu * 6;
         st.table_bytes += JDA_TABLE_BYTES;
     }
     jda_batch *b = new (std::nothrow) jda_batch;
@@ -260,7 +257,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)strips[m].size();
+        st.n_workgroups += (int32_t)(strips[m].size() / JDA_TILES_PER_WG);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {

@@ -13,28 +13,34 @@
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
 
+static int g_reverse_tiles = 0;   // tests run the tiles in reverse order too: results must not depend on which wave finishes first
+extern "C" void hostsim_set_reverse(int on) { g_reverse_tiles = on; }
 static uint32_t g_window_bytes = JDA_WIN_BYTES;   // tests shrink it to exercise the HBM fall-back of the bit reader
 extern "C" void hostsim_set_window(uint32_t bytes) { g_window_bytes = bytes > JDA_WIN_BYTES ? JDA_WIN_BYTES : (bytes & ~15u); }
 
-// one workgroup = 192 threads stepping through the kernel's phases; a phase runs for every thread
-// before the next one starts (= the __syncthreads() between them)
+// one wavefront = 64 lanes stepping through the kernel's phases; a phase runs for every lane before
+// the next one starts (= the wave-local fence between them)
 template <int MODE, bool FAST>
 static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles)
 {
     typedef jda_lds_layout<MODE> L;
-    std::vector<uint64_t> lds_store((L::TOTAL_BYTES + 7) / 8);
-    uint8_t *lds = (uint8_t *)lds_store.data();
-    for (size_t i = 0; i < tiles.size(); i++) {
+    std::vector<uint64_t> tab_store((JDA_LT_BYTES + 7) / 8), lds_store((L::WAVE_BYTES + 7) / 8);
+    uint8_t *tab = (uint8_t *)tab_store.data(), *wl = (uint8_t *)lds_store.data();
+    for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables(D, tid, 256, tab);
+    for (size_t ii = 0; ii < tiles.size(); ii++) {
+        const size_t i = g_reverse_tiles ? tiles.size() - 1 - ii : ii;
         const jda_strip &S = tiles[i];
-        memset(lds, 0xA5, L::TOTAL_BYTES);       // poison: LDS is not zero-initialised on the GPU either
+        memset(wl, 0xA5, L::WAVE_BYTES);         // poison: LDS is not zero-initialised on the GPU either
         const jda_tile_ctx C = jda_tile_setup<MODE>(D, S);
-        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p0_stage<MODE>(D, C, t, lds, g_window_bytes);
-        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p1_entropy<MODE>(D, C, jda_p1_prefetch<MODE>(D, C, t), lds, g_window_bytes);
+        jda_p1_inputs in[JDA_TILE_THREADS];
+        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) in[t] = jda_p1_prefetch<MODE>(D, C, t);
+        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p0_stage<MODE>(D, C, t, wl, g_window_bytes);
+        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p1_entropy<MODE>(D, C, in[t], tab, wl, g_window_bytes);
         if (D.scale_shift < 2) {
-            for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p2_columns<MODE, FAST>(D, t, lds);
-            for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p3_rows<MODE>(D, t, lds);
+            for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p2_columns<MODE, FAST>(D, t, tab, wl);
+            for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p3_rows<MODE>(D, t, tab, wl);
         }
-        for (uint32_t t = 0; t < JDA_WG_THREADS; t++) jda_p4_output<MODE>(D, S, C, t, lds);
+        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p4_output<MODE>(D, S, C, t, wl);
     }
 }
 
@@ -53,7 +59,6 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     D.scan = jda_image_scan(img, &n);
     D.blk_index = jda_image_block_index(img, &n);
     D.blk_dc = jda_image_block_dc(img);
-    D.blk_perm = jda_image_block_perm(img);
     D.tables = jda_image_tables(img, &n);
     std::vector<jda_strip> strips;
     jda_append_strips(strips, 0, D.mcus_x, D.mcus_y, D.mode);

@@ -36,19 +36,6 @@ def test_prepare_matches_oracle_stage_by_stage(name, oracle, product_lib):
     assert nok == p.n_mcus and n == len(flags) == p.n_blocks
     assert np.array_equal(idx[:-1] >> 7, oracle.blk_state[:, 0]) and np.array_equal(idx[:-1] & 127, oracle.blk_state[:, 1])
     assert np.array_equal(p.block_dc().astype(np.int32), oracle.blk_pred)
-    # lane schedule: per 192-block tile a permutation of the tile's block ids, longest blocks first
-    perm = p.block_perm()
-    nz = (coefs[:, 1:] != 0).sum(axis=1)
-    per_tile = 192 // p.info.blocks_per_mcu
-    for y in range(p.info.mcus_y):
-        for x0 in range(0, p.info.mcus_x, per_tile):
-            cnt = min(per_tile, p.info.mcus_x - x0)
-            first = (y * p.info.mcus_x + x0) * p.info.blocks_per_mcu
-            nb = cnt * p.info.blocks_per_mcu
-            ids = perm[first:first + nb].astype(int)
-            assert sorted(ids) == list(range(nb))
-            # symbol count = non-zero ACs + EOB (+ ZRLs): never increasing by more than the ZRL slack
-            assert nz[first + ids[0]] >= nz[first + ids[-1]]
     bpm = p.info.blocks_per_mcu                      # MCU starts are the first block of each MCU
     assert np.array_equal(idx[:-1:bpm] >> 7, state[:, 0]) and np.array_equal(idx[:-1:bpm] & 127, state[:, 1])
     p.close()

@@ -19,6 +19,25 @@ def hostsim(built_checkers):
     return lib
 
 
+@pytest.mark.parametrize("name", ["c444_600x16", "c444_333x217", "c420_1100x48", "gray_1600x16"])
+def test_tile_order_does_not_matter(name, hostsim, oracle):
+    """Tiles are decoded by independent wavefronts in any order: run them backwards and shrink the scan
+    window so the HBM fall-back of the bit reader is exercised too."""
+    jpeg = jpeg_for(name)
+    hostsim.hostsim_set_reverse(1)
+    hostsim.hostsim_set_window(64)
+    try:
+        for pt, opt in all_modes(name):
+            rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+            assert hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+            assert np.array_equal(got, want), (name, pt, opt)
+    finally:
+        hostsim.hostsim_set_reverse(0)
+        hostsim.hostsim_set_window(1 << 20)
+
+
 @pytest.mark.parametrize("name", sorted(SYNTH_CASES))
 def test_wave_emulation_equals_oracle(name, hostsim, oracle):
     jpeg = jpeg_for(name)

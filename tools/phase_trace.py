@@ -24,20 +24,20 @@ dev = [J.DeviceImage(ctx, prep[i % 2]) for i in range(nb)]
 b = J.Batch(ctx, dev, [(out + i * img_bytes, pitch, g["canvas_w"], g["canvas_h"]) for i in range(nb)], [J.RGB8888] * nb, [0] * nb)
 n_wg = b.stats["n_workgroups"]
 n_tr = (n_wg + 63) // 64
-buf = ctx.malloc(n_tr * 3 * 16 * 8)
-ctx.memset(buf, 0, n_tr * 3 * 16 * 8)
+buf = ctx.malloc(n_tr * 4 * 16 * 8)
+ctx.memset(buf, 0, n_tr * 4 * 16 * 8)
 b.decode(); ctx.sync()
 lib.jda_internal_set_trace.argtypes = [C.c_void_p]
 assert lib.jda_internal_set_trace(buf) == 0
 b.decode(); ctx.sync()
-tr = ctx.to_host(buf, n_tr * 3 * 16 * 8).view(np.uint64).reshape(n_tr, 3, 16).astype(np.int64)
+tr = ctx.to_host(buf, n_tr * 4 * 16 * 8).view(np.uint64).reshape(n_tr, 4, 16).astype(np.int64)
 lib.jda_internal_set_trace(None)
-names = ["entry->setup", "P0 issue", "P0 barrier", "P1", "P1 barrier", "P2", "P2 barrier", "P3", "P3 barrier", "P4", "store drain"]
-d = np.diff(tr[:, :, :12], axis=2)               # (wg, wave, 11)
-ok = (tr[:, :, 11] > 0).all(axis=1)
+names = ["entry->setup", "P0 issue", "P0 barrier", "P1", "P2", "P3", "P4"]
+d = np.diff(tr[:, :, :8], axis=2)                # (wg, wave, 7)
+ok = (tr[:, :, 7] > 0).all(axis=1)
 d = d[ok]
 print("traced workgroups:", d.shape[0], "of", n_tr)
-tot = (tr[ok][:, :, 11] - tr[ok][:, :, 0])
+tot = (tr[ok][:, :, 7] - tr[ok][:, :, 0])
 for k, nm in enumerate(names):
     print("%-14s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (nm, d[:, :, k].mean(), np.median(d[:, :, k]), np.percentile(d[:, :, k], 90)))
 print("%-14s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % ("TOTAL", tot.mean(), np.median(tot), np.percentile(tot, 90)))
