@@ -36,7 +36,7 @@
 #define JDA_TILE_THREADS 64
 #define JDA_WAVES_PER_WG 4
 #define JDA_COEF_STRIDE 136      // bytes per block in LDS: 64 int16 + 8 pad (row reads stay 8-byte aligned)
-#define JDA_WIN_BYTES 768        // per-wave LDS window over the tile's slice of the filtered scan
+#define JDA_WIN_BYTES 768        // per-wave LDS window over the tile's slice of the filtered scan (x2: double buffered)
 #define JDA_COLLIST_ENTRIES 512  // 64 blocks x 8 columns, uint16 each
 
 template <int MODE> struct jda_mode_traits;
@@ -64,7 +64,7 @@ template <int MODE> struct jda_lds_layout {       // the per-WAVE region
         CNT_OFF = ROWLIST_OFF + 4 * JDA_TILE_THREADS,               // 8 uint32 counters
         COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
         WIN_OFF = COLLIST_OFF + JDA_COLLIST_ENTRIES * 2,
-        WAVE_BYTES = WIN_OFF + JDA_WIN_BYTES,                       // 10,784 B
+        WAVE_BYTES = WIN_OFF + 2 * JDA_WIN_BYTES,                   // 11,552 B: the next tile's scan slice is staged while this one decodes
         PLANE_OFF = COEF_OFF,
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE // bytes between consecutive MCUs' samples
     };
@@ -189,6 +189,29 @@ JDA_HD void jda_refill(jda_bitreader &br)
 // 16-byte chunks l, l+64, ...  Every lane of the wave calls it; a wave fence follows.
 struct jda_chunk16 { uint32_t w[4]; };
 typedef jda_chunk16 __attribute__((may_alias)) jda_chunk16_alias;
+// the same copy split in two so the HBM load can be issued early and the LDS store done late
+// (JDA_WIN_BYTES <= 64 lanes x 16 bytes: one chunk per lane)
+JDA_HD jda_chunk16 jda_window_load(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint32_t lane)
+{
+    jda_chunk16 c;
+    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+    if (lane < (win_len >> 4)) {
+        const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
+        const jda_chunk16_alias v = src[lane];
+        c.w[0] = v.w[0]; c.w[1] = v.w[1]; c.w[2] = v.w[2]; c.w[3] = v.w[3];
+    }
+    return c;
+}
+JDA_HD void jda_window_store(uint8_t *win, uint32_t win_len, uint32_t lane, const jda_chunk16 &c)
+{
+    if (lane < (win_len >> 4)) {
+        jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
+        jda_chunk16_alias v;
+        v.w[0] = c.w[0]; v.w[1] = c.w[1]; v.w[2] = c.w[2]; v.w[3] = c.w[3];
+        dst[lane] = v;
+    }
+}
+
 JDA_HD void jda_window_fill(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint8_t *win, uint32_t lane)
 {
     const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
@@ -541,6 +564,30 @@ struct jda_tile_ctx {                 // wave-uniform facts about the tile, comp
     uint32_t win_lo, win_len;         // bytes of the scan staged in LDS
 };
 
+// same, from index entries already in registers: ix_first = index[first block of the tile],
+// ix_end = index[first block after the tile]
+template <int MODE>
+JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &S, uint32_t ix_first, uint32_t ix_end)
+{
+    typedef jda_mode_traits<MODE> T;
+    jda_tile_ctx C;
+    C.first_mcu = S.mcu_y * D.mcus_x + S.mcu_x0;
+    C.count = S.count;
+    if (C.first_mcu >= D.n_mcus_ok) C.count = 0;
+    else if (C.first_mcu + C.count > D.n_mcus_ok) C.count = D.n_mcus_ok - C.first_mcu;
+    C.first_block = C.first_mcu * T::NBLK;
+    C.win_lo = 0; C.win_len = 0;
+    if (C.count) {
+        C.win_lo = (ix_first >> JDA_INDEX_OFF_BITS) & ~15u;
+        uint32_t hi = ((ix_end >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
+        const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;
+        if (hi > cap) hi = cap;
+        C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
+        if (C.win_len > JDA_WIN_BYTES) C.win_len = JDA_WIN_BYTES;
+    }
+    return C;
+}
+
 template <int MODE>
 JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
 {
@@ -615,7 +662,8 @@ JDA_HD jda_p1_inputs jda_p1_prefetch(const jda_dev_desc &D, const jda_tile_ctx &
 }
 
 template <int MODE>
-JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const uint8_t *tab, uint8_t *wl, uint32_t win_cap)
+JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const uint8_t *tab, uint8_t *wl,
+                           const uint8_t *win, uint32_t win_cap)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
@@ -637,7 +685,7 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
 
     jda_bitreader br;
     br.base = JDA_G(const uint8_t, D.scan);
-    br.win = wl + L::WIN_OFF;
+    br.win = win;
     br.win_lo = C.win_lo;
     br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
     const uint32_t ix = in.ix;

@@ -16,6 +16,7 @@
 //   P4  lanes tile the tile's output rows: YCbCr -> RGB and 16-byte stores to consecutive addresses.
 // No MFMA: the IDCT is shift/add integer work and the path is bound by the 4 B/pixel it writes.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "jda_device_core.h"
 #include "jda_plan.h"
@@ -62,7 +63,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     JDA_TRACE(2);
     __syncthreads();                                  // the only workgroup barrier: tables are in LDS
     JDA_TRACE(3);
-    if (!(D.pad_[0] & 4)) jda_p1_entropy<MODE>(D, C, p1in, tab, wl, JDA_WIN_BYTES);
+    if (!(D.pad_[0] & 4)) jda_p1_entropy<MODE>(D, C, p1in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
     JDA_WAVE_SYNC();
     JDA_TRACE(4);
     if (D.scale_shift < 2 && !(D.pad_[0] & 6)) {
@@ -93,6 +94,163 @@ static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant (the default): the grid is sized to what is resident (3 workgroups per CU) and
+// every workgroup walks a contiguous run of tile quads.  While a wavefront decodes tile j it fetches
+// everything tile j+1 needs -- tile record, per-lane index entries, the scan slice -- in three
+// stages slotted between the phases, so a tile never waits on the record -> index -> scan chain
+// (three dependent HBM latencies, ~18 % of a tile's life in the one-tile-per-workgroup kernel) and
+// the tables are staged once per image, not once per workgroup.
+template <int MODE> struct jda_next_tile {
+    jda_strip S;
+    jda_p1_inputs in;
+    uint32_t ix_end;
+};
+
+template <int MODE>
+__device__ __forceinline__ jda_strip jda_load_record(const jda_strip *tp)
+{
+    jda_strip S;
+    S.image = __builtin_amdgcn_readfirstlane(tp->image);
+    S.mcu_y = __builtin_amdgcn_readfirstlane(tp->mcu_y);
+    S.mcu_x0 = __builtin_amdgcn_readfirstlane(tp->mcu_x0);
+    S.count = __builtin_amdgcn_readfirstlane(tp->count);
+    return S;
+}
+
+// per-lane index / DC entries of a tile + the entry just past it (for the window bounds)
+template <int MODE>
+__device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, const jda_strip &S, uint32_t lane,
+                                                      jda_p1_inputs &in, uint32_t &ix_end)
+{
+    typedef jda_mode_traits<MODE> T;
+    uint32_t count = S.count;
+    const uint32_t first_mcu = S.mcu_y * D.mcus_x + S.mcu_x0;
+    if (first_mcu >= D.n_mcus_ok) count = 0;
+    else if (first_mcu + count > D.n_mcus_ok) count = D.n_mcus_ok - first_mcu;
+    const uint32_t first_block = first_mcu * T::NBLK, nb = count * T::NBLK;
+    in.lb = lane; in.ix = 0; in.pred = 0; ix_end = 0;
+    in.active = lane < nb;
+    if (in.active) {
+        in.ix = JDA_G(const uint32_t, D.blk_index)[first_block + lane];
+        in.pred = JDA_G(const int16_t, D.blk_dc)[first_block + lane];
+    }
+    if (nb) ix_end = JDA_G(const uint32_t, D.blk_index)[first_block + nb];     // uniform address
+}
+
+template <int MODE, bool FAST>
+__global__ __launch_bounds__(64 * JDA_WAVES_PER_WG)
+void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typedef jda_lds_layout<MODE> L;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t per = (n_quads + gridDim.x - 1) / gridDim.x;
+    uint32_t q = blockIdx.x * per;
+    const uint32_t q_end = q + per < n_quads ? q + per : n_quads;
+    if (q >= q_end) return;
+    uint8_t *tab = lds;
+    uint8_t *wl = lds + JDA_LT_BYTES + wave * L::WAVE_BYTES;
+
+    // ---- prologue: everything for the first tile
+    jda_strip S = jda_load_record<MODE>(tiles + (size_t)q * JDA_WAVES_PER_WG + wave);
+    const jda_dev_desc *Dp = descs + S.image;
+    uint32_t staged_image = S.image;
+    jda_p0_tables(*Dp, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
+    jda_p1_inputs in;
+    uint32_t ix_end;
+    jda_issue_index_loads<MODE>(*Dp, S, lane, in, ix_end);
+    jda_tile_ctx C = jda_tile_setup_from<MODE>(*Dp, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ix_end));
+    C.count = __builtin_amdgcn_readfirstlane(C.count);
+    C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
+    C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
+    uint32_t buf = 0;
+    jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dp->scan), C.win_lo, C.win_len, lane));
+    if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
+    __syncthreads();                                  // tables staged
+
+    for (;;) {
+        const jda_dev_desc &D = *Dp;
+        const bool have_next = q + 1 < q_end;
+        // stage A: next tile's record (a wave-uniform 16-byte load)
+        const jda_strip *np_ = tiles + (size_t)(q + 1) * JDA_WAVES_PER_WG + wave;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        if (have_next) { r0 = np_->image; r1 = np_->mcu_y; r2 = np_->mcu_x0; r3 = np_->count; }
+
+        jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF + buf * JDA_WIN_BYTES, JDA_WIN_BYTES);
+        JDA_WAVE_SYNC();
+
+        // stage B: the record is here -> per-lane index entries of the next tile
+        jda_strip Sn;
+        Sn.image = __builtin_amdgcn_readfirstlane(r0); Sn.mcu_y = __builtin_amdgcn_readfirstlane(r1);
+        Sn.mcu_x0 = __builtin_amdgcn_readfirstlane(r2); Sn.count = __builtin_amdgcn_readfirstlane(r3);
+        const jda_dev_desc *Dn = have_next ? descs + Sn.image : Dp;
+        jda_p1_inputs inn;
+        uint32_t ixn_end = 0;
+        inn.lb = lane; inn.ix = 0; inn.pred = 0; inn.active = false;
+        if (have_next) jda_issue_index_loads<MODE>(*Dn, Sn, lane, inn, ixn_end);
+
+        if (D.scale_shift < 2) {
+            jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
+            JDA_WAVE_SYNC();
+        }
+
+        // stage C: index entries are here -> window bounds -> the next tile's scan slice (HBM -> registers)
+        jda_tile_ctx Cn = C;
+        jda_chunk16 chunk;
+        chunk.w[0] = chunk.w[1] = chunk.w[2] = chunk.w[3] = 0;
+        if (have_next) {
+            Cn = jda_tile_setup_from<MODE>(*Dn, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
+            Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
+            Cn.win_lo = __builtin_amdgcn_readfirstlane(Cn.win_lo);
+            Cn.win_len = __builtin_amdgcn_readfirstlane(Cn.win_len);
+            chunk = jda_window_load(JDA_G(const uint8_t, Dn->scan), Cn.win_lo, Cn.win_len, lane);
+        }
+
+        if (D.scale_shift < 2) {
+            jda_p3_rows<MODE>(D, lane, tab, wl);
+            JDA_WAVE_SYNC();
+        }
+
+        // stage D: scan slice -> the other LDS window; list counters reset for the next tile
+        if (have_next) jda_window_store(wl + L::WIN_OFF + (buf ^ 1u) * JDA_WIN_BYTES, Cn.win_len, lane, chunk);
+        if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
+
+        jda_p4_output<MODE>(D, S, C, lane, wl);
+        if (!have_next) break;
+        if (Sn.image != staged_image) {               // image boundary (same for all four waves of the quad)
+            __syncthreads();
+            jda_p0_tables(*Dn, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
+            __syncthreads();
+            staged_image = Sn.image;
+        }
+        S = Sn; C = Cn; in = inn; Dp = Dn; buf ^= 1u; q++;
+        JDA_WAVE_SYNC();
+    }
+}
+
+template <int MODE, bool FAST>
+static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
+{
+    const int lds_bytes = JDA_LT_BYTES + JDA_WAVES_PER_WG * jda_lds_layout<MODE>::WAVE_BYTES;
+    static int grid_cap = 0;
+    if (!grid_cap) {
+        hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int per_cu = (160 * 1024) / lds_bytes;
+        grid_cap = cus * (per_cu > 0 ? per_cu : 1);
+    }
+    const uint32_t n_quads = n_tiles / JDA_WAVES_PER_WG;
+    const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
+    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST>), dim3(grid), dim3(64 * JDA_WAVES_PER_WG), lds_bytes, stream,
+                       descs, tiles, n_quads);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_trace), &dev_buf, sizeof(dev_buf));
@@ -103,12 +261,24 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_de
                                         uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
+    static int simple = -1;                           // JDA_KERNEL=simple selects the one-tile-per-wave kernel (A/B, tracing)
+    if (simple < 0) { const char *e = getenv("JDA_KERNEL"); simple = (e && e[0] == 's') ? 1 : 0; }
+    if (simple) {
+        switch (mode * 2 + (fast_mul ? 1 : 0)) {
+        case JDA_MODE_GRAY * 2 + 0: return launch<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_GRAY * 2 + 1: return launch<JDA_MODE_GRAY, true>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_444 * 2 + 0: return launch<JDA_MODE_444, false>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_444 * 2 + 1: return launch<JDA_MODE_444, true>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 2 + 0: return launch<JDA_MODE_420, false>(descs, tiles, n_tiles, stream);
+        default: return launch<JDA_MODE_420, true>(descs, tiles, n_tiles, stream);
+        }
+    }
     switch (mode * 2 + (fast_mul ? 1 : 0)) {
-    case JDA_MODE_GRAY * 2 + 0: return launch<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_GRAY * 2 + 1: return launch<JDA_MODE_GRAY, true>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_444 * 2 + 0: return launch<JDA_MODE_444, false>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_444 * 2 + 1: return launch<JDA_MODE_444, true>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_420 * 2 + 0: return launch<JDA_MODE_420, false>(descs, tiles, n_tiles, stream);
-    default: return launch<JDA_MODE_420, true>(descs, tiles, n_tiles, stream);
+    case JDA_MODE_GRAY * 2 + 0: return launch_persistent<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);
+    case JDA_MODE_GRAY * 2 + 1: return launch_persistent<JDA_MODE_GRAY, true>(descs, tiles, n_tiles, stream);
+    case JDA_MODE_444 * 2 + 0: return launch_persistent<JDA_MODE_444, false>(descs, tiles, n_tiles, stream);
+    case JDA_MODE_444 * 2 + 1: return launch_persistent<JDA_MODE_444, true>(descs, tiles, n_tiles, stream);
+    case JDA_MODE_420 * 2 + 0: return launch_persistent<JDA_MODE_420, false>(descs, tiles, n_tiles, stream);
+    default: return launch_persistent<JDA_MODE_420, true>(descs, tiles, n_tiles, stream);
     }
 }
