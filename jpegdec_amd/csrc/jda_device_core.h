@@ -136,6 +136,9 @@ JDA_HD uint32_t jda_sat_pk_u8(uint32_t a)
 #endif
 }
 
+JDA_HD uint32_t jda_dup16(int32_t v) { return jda_perm(0, (uint32_t)v, 0x01000100u); }        // low half in both halves
+JDA_HD uint32_t jda_pack16(int32_t lo, int32_t hi) { return jda_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
+
 // sign-extended 10-bit field starting at bit `lo` (the reference's "& 0x3ff" table index)
 JDA_HD int32_t jda_sext10_at(int32_t v, int lo) { return (int32_t)((uint32_t)v << (22 - lo)) >> 22; }
 JDA_HD int32_t jda_clamp255(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -366,11 +369,16 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
         const int32_t u12 = ((z10 * -669) >> 8) + z5;
         t6 = u12 - t7; t5 = u11 - t6; t4 = u10 + t5;
     }
-    jda_row8 r;                                                      // :2786-2793
-    r.lo = jda_range_limit5(t0 + t7) | (jda_range_limit5(t1 + t6) << 8) |
-           (jda_range_limit5(t2 + t5) << 16) | (jda_range_limit5(t3 - t4) << 24);
-    r.hi = jda_range_limit5(t3 + t4) | (jda_range_limit5(t2 - t5) << 8) |
-           (jda_range_limit5(t1 - t6) << 16) | (jda_range_limit5(t0 - t7) << 24);
+    // :2786-2793  ucRangeTable[(v >> 5) & 0x3ff] for the eight outputs, two per instruction:
+    // 10-bit sign-extended field (the table's wrap), +128, saturate to a byte
+    const int32_t o0 = t0 + t7, o1 = t1 + t6, o2 = t2 + t5, o3 = t3 - t4, o4 = t3 + t4, o5 = t2 - t5, o6 = t1 - t6, o7 = t0 - t7;
+    const uint32_t p01 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o0, 5), jda_sext10_at(o1, 5)), 0x00800080u));
+    const uint32_t p23 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o2, 5), jda_sext10_at(o3, 5)), 0x00800080u));
+    const uint32_t p45 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o4, 5), jda_sext10_at(o5, 5)), 0x00800080u));
+    const uint32_t p67 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o6, 5), jda_sext10_at(o7, 5)), 0x00800080u));
+    jda_row8 r;
+    r.lo = p01 | (p23 << 16);
+    r.hi = p45 | (p67 << 16);
     return r;
 }
 
@@ -906,8 +914,6 @@ JDA_HD void jda_rgba_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t tb,
     px0 = jda_perm(b2, rg, 0x0d040100u);                          // [R0, G0, B0, 0xff]
     px1 = jda_perm(b2, rg, 0x0d050302u);                          // [R1, G1, B1, 0xff]
 }
-JDA_HD uint32_t jda_dup16(int32_t v) { return jda_perm(0, (uint32_t)v, 0x01000100u); }        // low half in both halves
-JDA_HD uint32_t jda_pack16(int32_t lo, int32_t hi) { return jda_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
 // pixel group (the two rows share their chroma samples); items are dealt to the threads in row-major
