@@ -186,11 +186,11 @@ def main():
         # comes from the committed rocprofv3 --pmc passes of the same workload (profiles/), scaled to
         # this batch; null for any other workload
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_v2_1_pmc_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
         if (os.path.exists(tp) and (args.width, args.height, args.subsampling, args.pixel_type, args.options)
                 == (4096, 4096, "4:2:0", "rgb8888", 0)):
             traffic = json.load(open(tp))["hbm_bytes_per_image"] * args.batch
-            traffic_src = "profiles/r01_v2_1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
+            traffic_src = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
         line = {
             "metric": "Mpixels/s decoded",
             "value": value,
@@ -207,6 +207,7 @@ def main():
             "config": {
                 "workload": "batch of %d %dx%d baseline %s JPEGs per GPU -> %s, inputs resident in HBM"
                             % (args.batch, args.width, args.height, args.subsampling, args.pixel_type),
+                "images_per_gpu_per_step": args.batch,
                 "distinct_images": len(jpegs),
                 "bits_per_pixel": round(bits_px, 3),
                 "options": args.options,
@@ -220,7 +221,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "jda_decode_tiles<MODE,FAST>",
+                "kernel": "jda_decode_tiles_persistent<MODE,FAST>",
                 "kernel_ms_per_launch": kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

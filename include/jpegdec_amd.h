@@ -117,6 +117,14 @@ int jda_output_geometry(const jda_image_info *info, int32_t pixel_type, int32_t 
 int jda_draw_plan(const jda_image_info *info, int32_t pixel_type, int32_t options, int32_t max_mcus,
                   int32_t uses_dma, int32_t *rects, int32_t max_rects);
 
+/* The same with a crop rectangle (JPEG_setCropArea, jpeg.inl:682-727; skip logic :5111, :5134-5137).
+ * jda_crop_round applies the reference's MCU rounding to a request in place.  crop = {x, y, w, h}
+ * already rounded, or NULL.  rects[8*i..] = x, y, iWidth, iHeight, iWidthUsed, iBpp, src_x, src_y with
+ * (src_x, src_y) the strip's position in the decoded canvas. */
+void jda_crop_round(const jda_image_info *info, int32_t *x, int32_t *y, int32_t *w, int32_t *h);
+int jda_draw_plan_ex(const jda_image_info *info, int32_t pixel_type, int32_t options, int32_t max_mcus,
+                     int32_t uses_dma, const int32_t *crop, int32_t *rects, int32_t max_rects);
+
 /* ------------------------------------------------------------------ device runtime */
 
 typedef struct jda_ctx jda_ctx;        /* one per process per GPU: device, stream, events */

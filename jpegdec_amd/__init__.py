@@ -19,8 +19,10 @@ from .binding import (  # noqa: F401
     DeviceImage,
     JdaError,
     PreparedImage,
+    crop_round,
     decode_to_host,
     draw_plan,
+    draw_plan_ex,
     library_path,
     load_library,
     output_geometry,

@@ -59,6 +59,8 @@ _PROTOTYPES = [
     ("jda_image_truncation_events", C.c_uint32, [_P]),
     ("jda_output_geometry", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 5),
     ("jda_draw_plan", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
+    ("jda_crop_round", None, [C.POINTER(ImageInfo)] + [C.POINTER(C.c_int32)] * 4),
+    ("jda_draw_plan_ex", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     ("jda_device_count", C.c_int, []),
     ("jda_create", _P, [C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_destroy", None, [_P]),
@@ -124,6 +126,20 @@ def draw_plan(info: ImageInfo, pixel_type=RGB8888, options=0, max_mcus=0, uses_d
     rects = np.zeros((1 << 16, 6), dtype=np.int32)
     n = load_library().jda_draw_plan(C.byref(info), pixel_type, options, max_mcus, 1 if uses_dma else 0,
                                      rects.ctypes.data_as(_P), rects.shape[0])
+    return rects[: max(n, 0)].copy()
+
+
+def crop_round(info: ImageInfo, x, y, w, h):
+    v = [C.c_int32(a) for a in (x, y, w, h)]
+    load_library().jda_crop_round(C.byref(info), *[C.byref(a) for a in v])
+    return tuple(a.value for a in v)
+
+
+def draw_plan_ex(info: ImageInfo, pixel_type=RGB8888, options=0, max_mcus=0, uses_dma=False, crop=None):
+    rects = np.zeros((1 << 16, 8), dtype=np.int32)
+    carr = (C.c_int32 * 4)(*crop) if crop is not None else None
+    n = load_library().jda_draw_plan_ex(C.byref(info), pixel_type, options, max_mcus, 1 if uses_dma else 0,
+                                        carr, rects.ctypes.data_as(_P), rects.shape[0])
     return rects[: max(n, 0)].copy()
 
 

@@ -179,22 +179,12 @@ void JPEGDEC::setPixelType(int iType)
 
 void JPEGDEC::setMaxOutputSize(int iMaxMCUs) { _jpeg->max_mcus = iMaxMCUs < 1 ? 1 : iMaxMCUs; }
 
-// Crop rectangle rounding to MCU boundaries (jpeg.inl:682-727).  Stored and reported; decode()
-// of a cropped area is a "next" row and is refused rather than approximated.
+// Crop rectangle, rounded to MCU boundaries as the reference does (jpeg.inl:682-727)
 void JPEGDEC::setCropArea(int x, int y, int w, int h)
 {
-    const int mw = _jpeg->info.mcu_w ? _jpeg->info.mcu_w : 8, mh = _jpeg->info.mcu_h ? _jpeg->info.mcu_h : 8;
-    if (x < 0) x = 0;
-    if (y < 0) y = 0;
-    if (w & (mw - 1)) w = (w & ~(mw - 1)) + mw;
-    if (h & (mh - 1)) h = (h & ~(mh - 1)) + mh;
-    if (x > _jpeg->info.width - mw) x = _jpeg->info.width - mw;
-    if (y > _jpeg->info.height - mh) y = _jpeg->info.height - mh;
-    if (x + w > _jpeg->info.width) w = _jpeg->info.width - mw;
-    if (y + h > _jpeg->info.height) h = _jpeg->info.height - mh;
-    x &= ~(mw - 1);
-    y &= ~(mh - 1);
-    _jpeg->crop_x = x; _jpeg->crop_y = y; _jpeg->crop_w = w; _jpeg->crop_h = h;
+    int32_t cx = x, cy = y, cw = w, ch = h;
+    jda_crop_round(&_jpeg->info, &cx, &cy, &cw, &ch);
+    _jpeg->crop_x = cx; _jpeg->crop_y = cy; _jpeg->crop_w = cw; _jpeg->crop_h = ch;
 }
 
 void JPEGDEC::getCropArea(int *x, int *y, int *w, int *h)
@@ -211,9 +201,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     s->xoff = x; s->yoff = y; s->options = iOptions;
     if (!s->opened) { s->error = JPEG_INVALID_PARAMETER; return 0; }
     if (s->pixel_type > EIGHT_BIT_GRAYSCALE || (iOptions & JPEG_EXIF_THUMBNAIL)) { s->error = JPEG_UNSUPPORTED_FEATURE; return 0; }
-    if (s->crop_x != 0 || s->crop_y != 0 || s->crop_w != s->info.width || s->crop_h != s->info.height) {
-        s->error = JPEG_UNSUPPORTED_FEATURE; return 0;
-    }
+    const bool cropped = s->crop_x != 0 || s->crop_y != 0 || s->crop_w != s->info.width || s->crop_h != s->info.height;
     int pt = s->pixel_type;
     if ((iOptions & JPEG_LUMA_ONLY) && pt < EIGHT_BIT_GRAYSCALE) pt = s->pixel_type = EIGHT_BIT_GRAYSCALE;   // jpeg.inl:4991-4993
     int bpp, ow, oh, cw, ch;
@@ -231,16 +219,60 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
     if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
 
-    if (s->framebuffer) {                              // jpeg.inl:5114-5124: pitch = image width, no callbacks
-        const int fb_px = s->info.width;               // iCropCX, also for scaled output
-        const int copy_px = cw < fb_px ? cw : fb_px;
-        for (int r = 0; r < ch; r++)
-            memcpy((uint8_t *)s->framebuffer + (size_t)r * fb_px * bpp, canvas.data() + (size_t)r * cw * bpp, (size_t)copy_px * bpp);
+    const int shift = (iOptions & JPEG_SCALE_HALF) ? 1 : (iOptions & JPEG_SCALE_QUARTER) ? 2 : (iOptions & JPEG_SCALE_EIGHTH) ? 3 : 0;
+    const int mw = s->info.mcu_w >> shift, mh = s->info.mcu_h >> shift;
+    // MCU rows the reference walks (jpeg.inl:5014-5037); a crop that reaches below the last MCU row makes it
+    // decode whatever follows the scan and fail -- here the real rows are delivered and the same error returned
+    int rows_mcu = (s->crop_y + s->crop_h + s->info.mcu_h - 1) / s->info.mcu_h;
+    const bool overrun = rows_mcu > s->info.mcus_y;
+    if (overrun) rows_mcu = s->info.mcus_y;
+
+    if (s->framebuffer) {
+        // jpeg.inl:5114-5124 + :5134-5137: no callbacks; the kept MCUs of a row are laid side by side at a pitch
+        // of iCropCX pixels (unscaled, also for scaled output).  The reference keeps the MCU at
+        // x*mcuCX == iCropX+iCropCX too ('>' at :5135) and the last MCU of a ragged width, so a row of MCUs can be
+        // wider than the pitch.  What happens to the part past the pitch depends on the JPEGPutMCU* variant:
+        //  - the scaled paths and JPEGPutMCU8BitGray for 8x8 MCUs (:2799-2840) do not clip: the overhang lands at
+        //    the start of the next buffer row, after that row's own pixels were written ("wrap", replayed in the
+        //    same order here; only the overhang of the very last row is dropped instead of overrunning the buffer);
+        //  - the full-size colour paths and 4:2:0 clip at the pitch (:3017-3030, :3079-3095, :3520-3524, :4318-4330).
+        // Known divergence: a 4:4:4 image whose width is not a multiple of 8, full size, RGB565/RGB8888: the
+        // reference's clipped last MCU advances pCb/pCr but not pY per row (:3521-3557), so its last partial MCU
+        // column mixes luma of the wrong pixels; this path delivers the correct pixels there.
+        const bool wrap = shift != 0 || (pt == EIGHT_BIT_GRAYSCALE && s->info.mcu_w == 8);
+        const int pitch_px = s->crop_w;
+        int x0 = 0, x1 = -1;
+        for (int x = 0; x < s->info.mcus_x; x++) {
+            if (x * mw < s->crop_x || x * mw > s->crop_x + s->crop_w) continue;
+            if (x1 < 0) x0 = x;
+            x1 = x;
+        }
+        const int strip_px = x1 < 0 ? 0 : (x1 - x0 + 1) * mw;
+        const int main_px = strip_px < pitch_px ? strip_px : pitch_px;
+        int over_px = wrap ? strip_px - main_px : 0;
+        if (over_px > pitch_px) over_px = pitch_px;
+        long last_row = -1;
+        for (int y = 0; y < rows_mcu; y++) if (y * mh >= s->crop_y) last_row = (long)y * mh - s->crop_y + mh - 1;
+        uint8_t *fb0 = (uint8_t *)s->framebuffer;
+        for (int y = 0; y < rows_mcu; y++) {
+            if (y * mh < s->crop_y) continue;                    // bSkipRow, :5111
+            const long ty = (long)y * mh - s->crop_y;
+            // 1-byte pixels: the row start is computed in 16-bit units, usPixels += ty*iPitch/2 (:5118-5119),
+            // so an odd ty*iPitch starts one byte early
+            uint8_t *fb = fb0 - ((bpp == 1) ? ((ty * pitch_px) & 1) : 0);
+            for (int pass = 0; pass < 2; pass++)
+                for (int rr = 0; rr < mh; rr++) {
+                    const uint8_t *src = canvas.data() + ((size_t)(y * mh + rr) * cw + (size_t)x0 * mw) * bpp;
+                    if (pass == 0) memcpy(fb + (size_t)(ty + rr) * pitch_px * bpp, src, (size_t)main_px * bpp);
+                    else if (over_px > 0 && ty + rr + 1 <= last_row)
+                        memcpy(fb + (size_t)(ty + rr + 1) * pitch_px * bpp, src + (size_t)main_px * bpp, (size_t)over_px * bpp);
+                }
+        }
     } else if (s->draw) {
-        std::vector<int32_t> rects(6 * 65536);
-        int n = jda_draw_plan(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0, rects.data(), 65536);
-        const int shift = (iOptions & JPEG_SCALE_HALF) ? 1 : (iOptions & JPEG_SCALE_QUARTER) ? 2 : (iOptions & JPEG_SCALE_EIGHTH) ? 3 : 0;
-        const int mh = s->info.mcu_h >> shift;
+        std::vector<int32_t> rects(8 * 65536);
+        const int32_t crop[4] = { s->crop_x, s->crop_y, s->crop_w, s->crop_h };
+        int n = jda_draw_plan_ex(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0,
+                                 cropped ? crop : NULL, rects.data(), 65536);
         // with JPEG_USES_DMA (and no user cap on the MCU count) the strip ping-pongs between the two halves
         bool dma = (iOptions & JPEG_USES_DMA) != 0;
         {   // the halves only alternate when the user cap did not win (jpeg.inl:5071-5076)
@@ -253,17 +285,17 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         int half = 0;
         if (n > 65536) n = 65536;
         for (int i = 0; i < n; i++) {
-            const int32_t *r = &rects[(size_t)6 * i];
+            const int32_t *r = &rects[(size_t)8 * i];
             uint16_t *buf = s->strip + (dma ? half * (MAX_BUFFERED_PIXELS / 2) : 0);
             const int row_bytes = r[2] * bpp;
             for (int rr = 0; rr < mh; rr++) {
-                const int cy_ = r[1] + rr;
+                const int cy_ = r[7] + rr;                       // strip position in the decoded canvas
                 uint8_t *dst = (uint8_t *)buf + (size_t)rr * row_bytes;
                 if (cy_ >= ch) { memset(dst, 0, (size_t)row_bytes); continue; }
-                int avail = (cw - r[0]) * bpp;
+                int avail = (cw - r[6]) * bpp;
                 if (avail > row_bytes) avail = row_bytes;
                 if (avail < 0) avail = 0;
-                memcpy(dst, canvas.data() + ((size_t)cy_ * cw + r[0]) * bpp, (size_t)avail);
+                memcpy(dst, canvas.data() + ((size_t)cy_ * cw + r[6]) * bpp, (size_t)avail);
                 if (avail < row_bytes) memset(dst + avail, 0, (size_t)(row_bytes - avail));
             }
             JPEGDRAW jd;
@@ -275,6 +307,6 @@ int JPEGDEC::decode(int x, int y, int iOptions)
             if (!keep_going) break;
         }
     }
-    if (partial) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
+    if (partial || overrun) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
     return 1;
 }

@@ -240,7 +240,7 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int per_cu = (160 * 1024) / lds_bytes;
         grid_cap = cus * (per_cu > 0 ? per_cu : 1);
     }

@@ -88,11 +88,11 @@ jda_ctx *jda_create(int32_t device, int32_t *err)
 void jda_destroy(jda_ctx *ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    hipEventDestroy(ctx->ev_start);
-    hipEventDestroy(ctx->ev_stop);
-    hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->ev_start);
+    (void)hipEventDestroy(ctx->ev_stop);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -103,7 +103,7 @@ void *jda_malloc(jda_ctx *ctx, size_t bytes)
 {
     if (!ctx) return NULL;
     void *p = NULL;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
     if (e != hipSuccess) { set_err(ctx, e, "hipMalloc"); return NULL; }
     return p;
@@ -111,7 +111,7 @@ void *jda_malloc(jda_ctx *ctx, size_t bytes)
 
 void jda_free(jda_ctx *ctx, void *dptr)
 {
-    if (ctx && dptr) { hipSetDevice(ctx->device); hipFree(dptr); }
+    if (ctx && dptr) { (void)hipSetDevice(ctx->device); (void)hipFree(dptr); }
 }
 
 int jda_memset(jda_ctx *ctx, void *dptr, int value, size_t bytes)
@@ -164,7 +164,7 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     d->off_dc = d->off_index + align16((n_blocks + 1) * sizeof(uint32_t));
     d->off_scan = d->off_dc + align16(n_blocks * sizeof(int16_t));
     d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&d->base, d->bytes);
     if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); delete d; *err = JDA_ERROR_MEMORY; return NULL; }
     // stage through one pinned-size host buffer so it is a single H2D copy
@@ -175,7 +175,7 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
     memcpy(stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
     e = hipMemcpyAsync(d->base, stage.data(), d->bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { set_err(ctx, e, "hipMemcpy(image)"); hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
+    if (e != hipSuccess) { set_err(ctx, e, "hipMemcpy(image)"); (void)hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
     *err = JDA_SUCCESS;
     return d;
 }
@@ -183,8 +183,8 @@ jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg)
 {
     if (!dimg) return;
-    if (ctx) hipSetDevice(ctx->device);
-    if (dimg->base) hipFree(dimg->base);
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (dimg->base) (void)hipFree(dimg->base);
     delete dimg;
 }
 
@@ -248,7 +248,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     if (!b) { *err = JDA_ERROR_MEMORY; return NULL; }
     memset(b, 0, sizeof(*b));
     b->n_images = n;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
     if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
     for (int m = 0; m < 6 && e == hipSuccess; m++) {
@@ -274,9 +274,9 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
 void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
 {
     if (!b) return;
-    if (ctx) hipSetDevice(ctx->device);
-    if (b->d_descs) hipFree(b->d_descs);
-    for (int m = 0; m < 6; m++) if (b->d_strips[m]) hipFree(b->d_strips[m]);
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (b->d_descs) (void)hipFree(b->d_descs);
+    for (int m = 0; m < 6; m++) if (b->d_strips[m]) (void)hipFree(b->d_strips[m]);
     delete b;
 }
 
@@ -354,7 +354,7 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
     jda_batch *b = jda_batch_create(ctx, 1, &dimg, &O, &pixel_type, &options, &err);
     rc = err;
     if (b) {
-        if (!complete) hipMemsetAsync(dout, 0, (size_t)dpitch * ch, ctx->stream);
+        if (!complete) (void)hipMemsetAsync(dout, 0, (size_t)dpitch * ch, ctx->stream);
         rc = jda_batch_decode(ctx, b);
         if (rc == JDA_SUCCESS) {
             const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;

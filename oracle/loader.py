@@ -138,8 +138,8 @@ class RefDecoder:
         h = (inf["height"] + adj) >> sh
         return 1, np.ascontiguousarray(r["canvas"][:h, : w * bpp])
 
-    def decode_fb(self, data: bytes, pixel_type=RGB8888, options=0):
-        """Framebuffer-mode decode; returns (rc, buffer rows_padded x (W*bpp))."""
+    def decode_fb(self, data: bytes, pixel_type=RGB8888, options=0, crop=None):
+        """Framebuffer-mode decode; returns (rc, flat buffer; pitch = W (or the cropped width) * bpp)."""
         inf = self.info(data)
         if not inf["ok"]:
             return -1, None
@@ -151,8 +151,10 @@ class RefDecoder:
         rows = cy * mh + mh  # generous: reference overruns rows
         fb = np.zeros((rows + 8, inf["width"] * bpp + 64), dtype=np.uint8).reshape(-1)
         err = C.c_int(0)
-        rc = self.lib.ref_decode_fb(data, len(data), pixel_type, options,
-                                    fb.ctypes.data_as(C.c_void_p), C.byref(err))
+        croparr = (C.c_int * 4)(*crop) if crop is not None else None
+        rc = self.lib.ref_decode_fb_crop(data, len(data), pixel_type, options, croparr,
+                                         fb.ctypes.data_as(C.c_void_p), C.byref(err))
+        self.last_error = err.value
         return rc, fb
 
     def bench(self, datas, pixel_type=RGB8888, options=0, reps=1, threads=1):

@@ -144,8 +144,17 @@ int ref_decode_cb(const uint8_t *data, int len, int pixel_type, int options, int
 
 // Framebuffer-mode decode (jpeg.inl:5114-5124): caller buffer, pitch = image width,
 // rows rounded up to an MCU multiple by the caller.
+int ref_decode_fb_crop(const uint8_t *data, int len, int pixel_type, int options, const int *crop,
+                       void *fb, int *last_error);
 int ref_decode_fb(const uint8_t *data, int len, int pixel_type, int options,
                   void *fb, int *last_error)
+{
+    return ref_decode_fb_crop(data, len, pixel_type, options, NULL, fb, last_error);
+}
+
+// the same with setCropArea(crop[0..3]) first: the buffer pitch becomes the cropped width
+int ref_decode_fb_crop(const uint8_t *data, int len, int pixel_type, int options, const int *crop,
+                       void *fb, int *last_error)
 {
     JPEGDEC *j = new JPEGDEC();
     int rc = j->openFLASH(data, len, draw_nop);
@@ -156,6 +165,7 @@ int ref_decode_fb(const uint8_t *data, int len, int pixel_type, int options,
     }
     j->setPixelType(pixel_type);
     j->setFramebuffer(fb);
+    if (crop) j->setCropArea(crop[0], crop[1], crop[2], crop[3]);
     rc = j->decode(0, 0, options);
     if (last_error) *last_error = j->getLastError();
     j->close();

@@ -111,3 +111,27 @@ def test_output_geometry(product_lib):
     assert p.geometry(J.RGB8888, 0) == dict(bpp=4, out_w=333, out_h=217, canvas_w=336, canvas_h=224)
     assert p.geometry(J.RGB565_LE, J.SCALE_HALF) == dict(bpp=2, out_w=167, out_h=109, canvas_w=168, canvas_h=112)
     assert p.geometry(J.RGB8888, J.LUMA_ONLY | J.SCALE_EIGHTH) == dict(bpp=1, out_w=42, out_h=28, canvas_w=42, canvas_h=28)
+
+
+@pytest.mark.needs_reference
+def test_cropped_draw_plan_matches_the_reference(ref_scalar):
+    """jda_crop_round + jda_draw_plan_ex against the JPEGDRAW log of the reference run with setCropArea."""
+    import ctypes as C
+    import jpegdec_amd as J
+    from jpegdec_amd.binding import ImageInfo, load_library
+    checked = 0
+    for name in ["c420_333x217", "c444_333x217", "gray_333x217", "c420_640x368_rstrow", "c420_1280x720"]:
+        jpeg = jpeg_for(name)
+        info = ImageInfo()
+        assert load_library().jda_parse(jpeg, len(jpeg), C.byref(info)) == 0
+        for crop in [(50, 50, 125, 170), (0, 0, 64, 64), (100, 20, 200, 100), (16, 16, 16, 16), (300, 200, 400, 300)]:
+            rounded = J.crop_round(info, *crop)
+            for pt in (0, 2, 3):
+                for opt in (0, 128):
+                    r = ref_scalar.decode_cb(jpeg, pt, opt, crop=crop, want_log=True)
+                    plan = J.draw_plan_ex(info, pt, opt, uses_dma=bool(opt & 128), crop=rounded)
+                    if r["rc"] != 1:
+                        continue            # crop below the last MCU row: reference decodes past the scan and fails
+                    assert np.array_equal(r["log"], plan[:, :6]), (name, crop, pt, opt)
+                    checked += 1
+    assert checked > 50

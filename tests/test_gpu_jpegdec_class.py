@@ -69,3 +69,69 @@ def test_error_codes(product_class):
     assert product_class.info(good[:100])["lasterror"] == 4          # JPEG_INVALID_FILE
     bad = bytearray(good); bad[good.index(b"\xff\xc0") + 1] = 0xC1
     assert product_class.info(bytes(bad))["lasterror"] == 3          # JPEG_UNSUPPORTED_FEATURE
+
+
+CROPS = [(50, 50, 125, 170), (0, 0, 64, 64), (100, 20, 200, 100), (16, 16, 16, 16), (0, 180, 64, 30)]
+
+
+@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "c444_600x16", "c420_1280x720", "gray_333x217"])
+def test_crop_area_matches_the_reference(name, product_class, ref_scalar):
+    """setCropArea (jpeg.inl:682-727) + the skip/draw bookkeeping of :5111, :5134-5137, :5300-5336 --
+    the reference's own test 2 (MacOS/JPEGDEC_Test/JPEGDEC_Test/main.cpp) checks the drawn union only;
+    here every strip and every pixel is compared with the reference itself."""
+    jpeg = jpeg_for(name)
+    checked = 0
+    for crop in CROPS:
+        for pt, opt in ((RGB565_LE, 0), (RGB8888, 0), (GRAY8, 0)):
+            if name.startswith("gray") and pt == RGB8888:
+                continue                              # reference writes 16-bit pixels at 32 bpp here (SURVEY C.5)
+            b = ref_scalar.decode_cb(jpeg, pt, opt, crop=crop, want_log=True)
+            a = product_class.decode_cb(jpeg, pt, opt, crop=crop, want_log=True)
+            if b["rc"] != 1:
+                # crop reaching below the last MCU row: the reference runs off the scan and fails
+                assert (a["rc"], a["last_error"]) == (b["rc"], b["last_error"]) == (0, 2), (name, crop)
+                continue
+            assert a["rc"] == 1 and a["last_error"] == 0
+            assert np.array_equal(a["log"], b["log"]), (name, crop, pt)
+            assert np.array_equal(a["canvas"], b["canvas"]), (name, crop, pt)
+            checked += 1
+    assert checked >= 6
+
+
+@pytest.mark.parametrize("name,crop", [("c420_333x217", None), ("c444_333x217", None), ("gray_333x217", None),
+                                       ("c420_640x368_rstrow", (50, 50, 125, 170)), ("c420_1280x720", (100, 20, 200, 100)),
+                                       ("c444_600x16", (16, 0, 64, 16)), ("gray_1600x16", (16, 0, 64, 16))])
+def test_framebuffer_ragged_and_cropped(name, crop, product_class, ref_scalar):
+    """Framebuffer mode with a width that is not an MCU multiple, or with a crop: MCUs past the pitch wrap
+    into the next buffer row or are clipped exactly as the reference's JPEGPutMCU* variants leave them
+    (jpeg.inl:5114-5124; see the comment in jpegdec_amd/csrc/JPEGDEC.cpp)."""
+    import ctypes as C
+    import jpegdec_amd as J
+    from jpegdec_amd.binding import ImageInfo, load_library
+    from oracle.loader import SCALE_EIGHTH
+    jpeg = jpeg_for(name)
+    inf = ref_scalar.info(jpeg)
+    info = ImageInfo(); load_library().jda_parse(jpeg, len(jpeg), C.byref(info))
+    checked = 0
+    for opt in (0, SCALE_HALF, SCALE_QUARTER, SCALE_EIGHTH):
+        for pt in (RGB565_LE, RGB8888, GRAY8):
+            if inf["subsample"] == 0 and pt == RGB8888:
+                continue                              # grayscale + RGB8888: reference writes 16-bit pixels (SURVEY C.5)
+            if name == "c444_333x217" and opt == 0 and pt != GRAY8:
+                continue                              # reference bug in the clipped last MCU (jpeg.inl:3521-3557), documented divergence
+            rb, fb_ref = ref_scalar.decode_fb(jpeg, pt, opt, crop=crop)
+            ra, fb_got = product_class.decode_fb(jpeg, pt, opt, crop=crop)
+            assert ra == rb == 1
+            bpp = {RGB565_LE: 2, RGB8888: 4, GRAY8: 1}[pt]
+            sh = {0: 0, SCALE_HALF: 1, SCALE_QUARTER: 2, SCALE_EIGHTH: 3}[opt]
+            mh = info.mcu_h >> sh
+            cx_, cy_, cw_, chh = J.crop_round(info, *crop) if crop else (0, 0, inf["width"], inf["height"])
+            rows_mcu = min((cy_ + chh + info.mcu_h - 1) // info.mcu_h, info.mcus_y)
+            kept = [y for y in range(rows_mcu) if y * mh >= cy_]
+            if not kept:
+                assert not fb_got.any() and not fb_ref.any()
+                continue
+            n = (kept[-1] * mh - cy_ + mh) * cw_ * bpp
+            assert np.array_equal(fb_got[:n], fb_ref[:n]), (name, crop, pt, opt)
+            checked += 1
+    assert checked >= 6
