@@ -31,6 +31,37 @@ __device__ unsigned long long *g_jda_trace = nullptr;
 // compiler is all that is needed -- no s_barrier
 #define JDA_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// The image descriptor is wave-uniform.  Read through the global pointer the compiler has to assume
+// that the kernel's own stores may change it: every field access became a vector load followed by
+// s_waitcnt vmcnt(0) -- a full memory round trip that also drains the output stores in flight (one
+// per item of the colour stage's loop).  Copy it once per image into a local whose fields are
+// readfirstlane'd, i.e. live in SGPRs.
+__device__ __forceinline__ uint32_t jda_uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <typename P> __device__ __forceinline__ P jda_uni_ptr(P p)
+{
+    const uint64_t v = (uint64_t)p;
+    return (P)(((uint64_t)jda_uni32((uint32_t)(v >> 32)) << 32) | jda_uni32((uint32_t)v));
+}
+__device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
+{
+    const jda_dev_desc JDA_GLOBAL *g = JDA_G(const jda_dev_desc, p);
+    jda_dev_desc L;
+    L.scan = jda_uni_ptr(g->scan); L.blk_index = jda_uni_ptr(g->blk_index); L.blk_dc = jda_uni_ptr(g->blk_dc);
+    L.tables = jda_uni_ptr(g->tables); L.out = jda_uni_ptr(g->out);
+    L.out_pitch = jda_uni32(g->out_pitch); L.out_w = jda_uni32(g->out_w); L.out_rows = jda_uni32(g->out_rows);
+    L.mcus_x = jda_uni32(g->mcus_x); L.mcus_y = jda_uni32(g->mcus_y); L.n_mcus_ok = jda_uni32(g->n_mcus_ok);
+    L.scan_len = jda_uni32(g->scan_len);
+    L.mode = (uint8_t)jda_uni32(g->mode); L.ncomp = (uint8_t)jda_uni32(g->ncomp);
+    L.pixel_type = (uint8_t)jda_uni32(g->pixel_type); L.scale_shift = (uint8_t)jda_uni32(g->scale_shift);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        L.dc_id[i] = (uint8_t)jda_uni32(g->dc_id[i]); L.ac_id[i] = (uint8_t)jda_uni32(g->ac_id[i]); L.q_id[i] = (uint8_t)jda_uni32(g->q_id[i]);
+    }
+    L.gray_from_color = (uint8_t)jda_uni32(g->gray_from_color); L.fast_mul = (uint8_t)jda_uni32(g->fast_mul);
+    L.pad_[0] = (uint8_t)jda_uni32(g->pad_[0]);
+    return L;
+}
+
 template <int MODE, bool FAST>
 __global__ __launch_bounds__(64 * JDA_WAVES_PER_WG)
 void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles)
@@ -48,7 +79,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     S.mcu_y = __builtin_amdgcn_readfirstlane(tp->mcu_y);
     S.mcu_x0 = __builtin_amdgcn_readfirstlane(tp->mcu_x0);
     S.count = __builtin_amdgcn_readfirstlane(tp->count);
-    const jda_dev_desc &D = descs[S.image];           // the four tiles of a workgroup belong to one image
+    const jda_dev_desc D = jda_desc_uniform(descs + S.image);   // the four tiles of a workgroup belong to one image
     jda_tile_ctx C = jda_tile_setup<MODE>(D, S);
     C.count = __builtin_amdgcn_readfirstlane(C.count);
     C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
@@ -155,23 +186,23 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 
     // ---- prologue: everything for the first tile
     jda_strip S = jda_load_record<MODE>(tiles + (size_t)q * JDA_WAVES_PER_WG + wave);
-    const jda_dev_desc *Dp = descs + S.image;
+    jda_dev_desc Dc = jda_desc_uniform(descs + S.image);
     uint32_t staged_image = S.image;
-    jda_p0_tables(*Dp, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
+    jda_p0_tables(Dc, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
     jda_p1_inputs in;
     uint32_t ix_end;
-    jda_issue_index_loads<MODE>(*Dp, S, lane, in, ix_end);
-    jda_tile_ctx C = jda_tile_setup_from<MODE>(*Dp, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ix_end));
+    jda_issue_index_loads<MODE>(Dc, S, lane, in, ix_end);
+    jda_tile_ctx C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ix_end));
     C.count = __builtin_amdgcn_readfirstlane(C.count);
     C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
     C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
     uint32_t buf = 0;
-    jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dp->scan), C.win_lo, C.win_len, lane));
+    jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane));
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
     __syncthreads();                                  // tables staged
 
     for (;;) {
-        const jda_dev_desc &D = *Dp;
+        const jda_dev_desc &D = Dc;
         const bool have_next = q + 1 < q_end;
         // stage A: next tile's record (a wave-uniform 16-byte load)
         const jda_strip *np_ = tiles + (size_t)(q + 1) * JDA_WAVES_PER_WG + wave;
@@ -185,11 +216,12 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         jda_strip Sn;
         Sn.image = __builtin_amdgcn_readfirstlane(r0); Sn.mcu_y = __builtin_amdgcn_readfirstlane(r1);
         Sn.mcu_x0 = __builtin_amdgcn_readfirstlane(r2); Sn.count = __builtin_amdgcn_readfirstlane(r3);
-        const jda_dev_desc *Dn = have_next ? descs + Sn.image : Dp;
+        jda_dev_desc Dn = Dc;
+        if (have_next && Sn.image != S.image) Dn = jda_desc_uniform(descs + Sn.image);    // image boundary (uniform branch)
         jda_p1_inputs inn;
         uint32_t ixn_end = 0;
         inn.lb = lane; inn.ix = 0; inn.pred = 0; inn.active = false;
-        if (have_next) jda_issue_index_loads<MODE>(*Dn, Sn, lane, inn, ixn_end);
+        if (have_next) jda_issue_index_loads<MODE>(Dn, Sn, lane, inn, ixn_end);
 
         if (D.scale_shift < 2) {
             jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
@@ -201,11 +233,11 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         jda_chunk16 chunk;
         chunk.w[0] = chunk.w[1] = chunk.w[2] = chunk.w[3] = 0;
         if (have_next) {
-            Cn = jda_tile_setup_from<MODE>(*Dn, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
+            Cn = jda_tile_setup_from<MODE>(Dn, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
             Cn.win_lo = __builtin_amdgcn_readfirstlane(Cn.win_lo);
             Cn.win_len = __builtin_amdgcn_readfirstlane(Cn.win_len);
-            chunk = jda_window_load(JDA_G(const uint8_t, Dn->scan), Cn.win_lo, Cn.win_len, lane);
+            chunk = jda_window_load(JDA_G(const uint8_t, Dn.scan), Cn.win_lo, Cn.win_len, lane);
         }
 
         if (D.scale_shift < 2) {
@@ -221,11 +253,11 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         if (!have_next) break;
         if (Sn.image != staged_image) {               // image boundary (same for all four waves of the quad)
             __syncthreads();
-            jda_p0_tables(*Dn, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
+            jda_p0_tables(Dn, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
             __syncthreads();
             staged_image = Sn.image;
         }
-        S = Sn; C = Cn; in = inn; Dp = Dn; buf ^= 1u; q++;
+        S = Sn; C = Cn; in = inn; Dc = Dn; buf ^= 1u; q++;
         JDA_WAVE_SYNC();
     }
 }
