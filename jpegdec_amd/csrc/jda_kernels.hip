@@ -29,7 +29,7 @@ __device__ unsigned long long *g_jda_trace = nullptr;
 
 // wave-local phase boundary: LDS operations of one wavefront complete in order, so ordering the
 // compiler is all that is needed -- no s_barrier
-#define JDA_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define JDA_WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 // The image descriptor is wave-uniform.  Read through the global pointer the compiler has to assume
 // that the kernel's own stores may change it: every field access became a vector load followed by
@@ -129,8 +129,8 @@ static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint
 // ------------------------------------------------------------------------------------------------
 // Persistent variant (the default): the grid is sized to what is resident (3 workgroups per CU) and
 // every workgroup walks a contiguous run of tile quads.  While a wavefront decodes tile j it fetches
-// everything tile j+1 needs -- tile record, per-lane index entries, the scan slice -- in three
-// stages slotted between the phases, so a tile never waits on the record -> index -> scan chain
+// what tile j+1 needs -- per-lane index entries during the entropy phase, the scan slice during the
+// column stage -- and the record of tile j+2, so a tile never waits on the record -> index -> scan chain
 // (three dependent HBM latencies, ~18 % of a tile's life in the one-tile-per-workgroup kernel) and
 // the tables are staged once per image, not once per workgroup.
 template <int MODE> struct jda_next_tile {
@@ -201,21 +201,18 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
     __syncthreads();                                  // tables staged
 
+    // the record of the tile after this one (wave-uniform)
+    jda_strip Sn = S;
+    if (q + 1 < q_end) Sn = jda_load_record<MODE>(tiles + (size_t)(q + 1) * JDA_WAVES_PER_WG + wave);
+
     for (;;) {
         const jda_dev_desc &D = Dc;
         const bool have_next = q + 1 < q_end;
-        // stage A: next tile's record (a wave-uniform 16-byte load)
-        const jda_strip *np_ = tiles + (size_t)(q + 1) * JDA_WAVES_PER_WG + wave;
+        // stage A: the record two tiles ahead (a wave-uniform 16-byte load, consumed at the bottom of the loop)
+        const jda_strip *np_ = tiles + (size_t)(q + 2) * JDA_WAVES_PER_WG + wave;
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        if (have_next) { r0 = np_->image; r1 = np_->mcu_y; r2 = np_->mcu_x0; r3 = np_->count; }
-
-        jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF + buf * JDA_WIN_BYTES, JDA_WIN_BYTES);
-        JDA_WAVE_SYNC();
-
-        // stage B: the record is here -> per-lane index entries of the next tile
-        jda_strip Sn;
-        Sn.image = __builtin_amdgcn_readfirstlane(r0); Sn.mcu_y = __builtin_amdgcn_readfirstlane(r1);
-        Sn.mcu_x0 = __builtin_amdgcn_readfirstlane(r2); Sn.count = __builtin_amdgcn_readfirstlane(r3);
+        if (q + 2 < q_end) { r0 = np_->image; r1 = np_->mcu_y; r2 = np_->mcu_x0; r3 = np_->count; }
+        // stage B: per-lane index entries of the next tile; in flight during this tile's entropy phase
         jda_dev_desc Dn = Dc;
         if (have_next && Sn.image != S.image) Dn = jda_desc_uniform(descs + Sn.image);    // image boundary (uniform branch)
         jda_p1_inputs inn;
@@ -223,15 +220,15 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         inn.lb = lane; inn.ix = 0; inn.pred = 0; inn.active = false;
         if (have_next) jda_issue_index_loads<MODE>(Dn, Sn, lane, inn, ixn_end);
 
-        if (D.scale_shift < 2) {
-            jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
-            JDA_WAVE_SYNC();
-        }
+        jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF + buf * JDA_WIN_BYTES, JDA_WIN_BYTES);
+        JDA_WAVE_SYNC();
 
-        // stage C: index entries are here -> window bounds -> the next tile's scan slice (HBM -> registers)
+        // stage C: index entries are here -> window bounds -> the next tile's scan slice (HBM -> registers),
+        // in flight during the column stage
         jda_tile_ctx Cn = C;
         jda_chunk16 chunk;
         chunk.w[0] = chunk.w[1] = chunk.w[2] = chunk.w[3] = 0;
+        asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end));      // the index loads have landed: settle their waits here
         if (have_next) {
             Cn = jda_tile_setup_from<MODE>(Dn, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
@@ -241,13 +238,18 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         }
 
         if (D.scale_shift < 2) {
-            jda_p3_rows<MODE>(D, lane, tab, wl);
+            jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
             JDA_WAVE_SYNC();
         }
 
-        // stage D: scan slice -> the other LDS window; list counters reset for the next tile
+        // stage D: scan slice -> the other LDS window
         if (have_next) jda_window_store(wl + L::WIN_OFF + (buf ^ 1u) * JDA_WIN_BYTES, Cn.win_len, lane, chunk);
-        if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
+
+        if (D.scale_shift < 2) {
+            jda_p3_rows<MODE>(D, lane, tab, wl);
+            JDA_WAVE_SYNC();
+        }
+        if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;      // list counters reset for the next tile
 
         jda_p4_output<MODE>(D, S, C, lane, wl);
         if (!have_next) break;
@@ -258,6 +260,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
             staged_image = Sn.image;
         }
         S = Sn; C = Cn; in = inn; Dc = Dn; buf ^= 1u; q++;
+        Sn.image = __builtin_amdgcn_readfirstlane(r0); Sn.mcu_y = __builtin_amdgcn_readfirstlane(r1);
+        Sn.mcu_x0 = __builtin_amdgcn_readfirstlane(r2); Sn.count = __builtin_amdgcn_readfirstlane(r3);
         JDA_WAVE_SYNC();
     }
 }
