@@ -34,10 +34,11 @@
 // wavefronts of a workgroup share nothing but the image's tables in LDS, so after the tables are
 // staged there is no workgroup barrier: every phase boundary is a wave-local fence.
 #define JDA_TILE_THREADS 64
-#define JDA_WAVES_PER_WG 4
+#ifndef JDA_P1_TRACE
+#define JDA_P1_TRACE(slot) ((void)0)      // profiling hook, defined by jda_kernels.hip
+#endif
 #define JDA_COEF_STRIDE 136      // bytes per block in LDS: 64 int16 + 8 pad (row reads stay 8-byte aligned)
-#define JDA_WIN_BYTES 768        // per-wave LDS window over the tile's slice of the filtered scan (x2: double buffered)
-#define JDA_COLLIST_ENTRIES 512  // 64 blocks x 8 columns, uint16 each
+#define JDA_WIN_BYTES 512        // per-wave LDS window over the tile's slice of the filtered scan (x2: double buffered)
 
 template <int MODE> struct jda_mode_traits;
 template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
@@ -51,7 +52,8 @@ template <> struct jda_mode_traits<JDA_MODE_420>  { enum { NLUMA = 4, NBLK = 6, 
 #define JDA_LT_AC      2048      // 2 x 1024 uint16
 #define JDA_LT_QUANT   6144      // 4 x 64 int16
 #define JDA_LT_ZIGZAG  6656      // 64
-#define JDA_LT_BYTES   6720
+#define JDA_LT_ZZ16    6720      // 64 x uint16: natural index n | column bit (1 << (n & 7)) << 8, built while staging
+#define JDA_LT_BYTES   6848
 
 template <int MODE> struct jda_lds_layout {       // the per-WAVE region
     enum {
@@ -60,13 +62,16 @@ template <int MODE> struct jda_lds_layout {       // the per-WAVE region
         // one 136-byte slot per block: int16[64] coefficients, later (first 64 bytes) its 8x8 samples --
         // the row stage stores its bytes over the block it has just read, as the reference does (:2682)
         COEF_OFF = 0,
-        ROWLIST_OFF = COEF_OFF + JDA_TILE_THREADS * JDA_COEF_STRIDE, // 4 classes x 64 block ids (uint8)
+        ROWLIST_OFF = COEF_OFF + BLOCKS * JDA_COEF_STRIDE,           // 4 classes x 64 block ids (uint8)
         CNT_OFF = ROWLIST_OFF + 4 * JDA_TILE_THREADS,               // 8 uint32 counters
         COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
-        WIN_OFF = COLLIST_OFF + JDA_COLLIST_ENTRIES * 2,
-        WAVE_BYTES = WIN_OFF + 2 * JDA_WIN_BYTES,                   // 11,552 B: the next tile's scan slice is staged while this one decodes
+        COLLIST_ENTRIES = BLOCKS * 8,                               // every column of every block
+        WIN_OFF = COLLIST_OFF + COLLIST_ENTRIES * 2,
+        WAVE_BYTES = WIN_OFF + 2 * JDA_WIN_BYTES,                   // 10,432 B (4:2:0): the next tile's scan slice is staged while this one decodes
         PLANE_OFF = COEF_OFF,
-        PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE // bytes between consecutive MCUs' samples
+        PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE, // bytes between consecutive MCUs' samples
+        // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy
+        WAVES = (160 * 1024 - JDA_LT_BYTES) / WAVE_BYTES > 16 ? 16 : (160 * 1024 - JDA_LT_BYTES) / WAVE_BYTES
     };
 };
 
@@ -242,6 +247,47 @@ JDA_HD uint32_t jda_lds_add(uint32_t *p, uint32_t v)
 #endif
 }
 
+// ---- wave-level combine (list building without LDS atomics) -------------------------------------
+// On the GPU these are DPP / ballot operations over the 64 lanes of the wavefront.  The host emulator
+// steps lanes one after another, so it hands in the value of every lane (all[]) and the same results
+// are computed by plain loops.
+// Exclusive prefix sum of v over the lanes below `lane`, and the sum over all lanes.
+JDA_HD uint32_t jda_wave_excl_sum(uint32_t v, uint32_t lane, const uint32_t *all, uint32_t &total)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)all; (void)lane;
+    int x = (int)v;                                  // inclusive scan: row_shr 1,2,4,8 then row_bcast 15 / 31 (gfx9 DPP)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+    return (uint32_t)x - v;
+#else
+    uint32_t below = 0, sum = 0;
+    for (uint32_t l = 0; l < JDA_TILE_THREADS; l++) { if (l < lane) below += all[l]; sum += all[l]; }
+    total = sum;
+    return below;
+#endif
+}
+// How many lanes below `lane` have cls[l] == c, and how many lanes in all (c = 0..3; cls 4 = none).
+JDA_HD uint32_t jda_wave_class_rank(uint32_t my_cls, uint32_t c, uint32_t lane, const uint32_t *all_cls, uint32_t &count)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)all_cls; (void)lane;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(my_cls == c);
+    count = (uint32_t)__builtin_popcountll(m);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+    uint32_t below = 0, n = 0;
+    for (uint32_t l = 0; l < JDA_TILE_THREADS; l++) if (all_cls[l] == c) { n++; if (l < lane) below++; }
+    count = n;
+    return below;
+#endif
+}
+
 JDA_HD uint32_t jda_popcount8(uint32_t v)
 {
     return (uint32_t)__builtin_popcount(v & 0xffu);
@@ -258,6 +304,7 @@ struct jda_tables {
     const uint16_t *ac_short; // LDS: 1024 entries
     const uint16_t JDA_GLOBAL *ac_long;  // global: 1024 entries (codes starting 111111)
     const uint8_t *zigzag;    // LDS
+    const uint16_t *zz16;     // LDS: n | column bit << 8
 };
 
 template <int LIMIT>
@@ -312,6 +359,98 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
         jda_refill(br);
     }
     return flags;
+}
+
+// ---- the same, for a tile whose whole scan slice is in the LDS window (the normal case) ----------
+// No lane can leave the window, so the reader needs no bounds check and no HBM path, and the block
+// decode below is written without divergent branches: P1 is bound by the latency of its dependent
+// chain (stream bits -> LUT -> bit offset -> stream bits), not by instruction issue, and every
+// exec-mask region in that chain costs a VALU->SALU->branch round trip.
+JDA_HD uint64_t jda_load_be64_win(const uint8_t *wbase, uint32_t pos)     // wbase = win - win_lo
+{
+    const jda_u32_alias *p = (const jda_u32_alias *)(wbase + (pos & ~3u));
+    return jda_be64_from_words(p[0], p[1], p[2], pos);
+}
+// jpeg.inl:2110-2114 under a predicate.  bits == load(pos) always holds, so reloading at an unchanged
+// position is a no-op and the load needs no select.
+JDA_HD void jda_refill_win(jda_bitreader &br, const uint8_t *wbase, bool enable)
+{
+    const bool go = enable && br.off > 47;
+    br.pos += go ? (br.off >> 3) : 0u;
+    br.off = go ? (br.off & 7u) : br.off;
+    br.bits = jda_load_be64_win(wbase, br.pos);
+}
+// x >> n for n in 0..32 (hardware shifts take n mod 32; a result for n == 32 is never used)
+JDA_HD uint32_t jda_shr_upto32(uint32_t x, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x >> (n & 31u);
+#else
+    return n >= 32 ? 0u : x >> n;
+#endif
+}
+// EXTEND (jpeg.inl:2249-2252) of the s bits at the top of the 32-bit word t
+JDA_HD int32_t jda_extend_top(uint32_t t, uint32_t s)
+{
+    const uint32_t v = jda_shr_upto32(t, 32u - s);
+    const uint32_t neg = ~(uint32_t)((int32_t)t >> 31);          // all ones when the leading bit is 0
+    return (int32_t)(v + (neg & ((0xffffffffu << s) + 1u)));
+}
+
+template <int LIMIT>
+JDA_HD uint32_t jda_decode_block_win(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill)
+{
+    const uint8_t *wbase = br.win - br.win_lo;
+    uint32_t fl = 0;                                     // OR of zz16 entries of the stored coefficients
+    jda_refill_win(br, wbase, true);
+    if (LIMIT == 64) {
+        if (zero_fill) {
+            jda_u64_alias *z = (jda_u64_alias *)coef;
+#pragma unroll
+            for (int i = 0; i < 16; i++) z[i] = 0;
+        }
+    } else if (LIMIT == 5) {
+        coef[1] = 0; coef[8] = 0; coef[9] = 0;
+    }
+    // DC  (:2129-2165), predicated
+    uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
+    code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
+    uint32_t e = T.dc[code];
+    const int32_t folded = (int8_t)T.dc[code + 512];
+    br.off += e >> 4;
+    const uint32_t s = e & 0xfu;
+    const bool take = s != 0 && folded == 0;             // magnitude bits follow in the stream (refill first, :2149)
+    jda_refill_win(br, wbase, take);
+    const int32_t mag = jda_extend_top((uint32_t)((br.bits << (br.off & 63u)) >> 32), s);
+    pred += s == 0 ? 0 : (folded ? folded : mag);
+    br.off += take ? s : 0u;
+    if (LIMIT == 1) return 0;
+    coef[0] = (int16_t)pred;
+    int k = 1;
+    jda_refill_win(br, wbase, true);
+    for (;;) {
+        // the next 32 bits of the window; zeros enter at the bottom exactly as in the reference's
+        // (ulBits << ulBitOff), so truncated magnitudes come out truncated
+        const uint32_t w = (uint32_t)((br.bits << br.off) >> 32);
+        e = T.ac_short[w >> 22];
+        if (__builtin_expect(w >= 0xfc000000u, 0)) e = T.ac_long[(w >> 16) & 0x3ffu];     // rare: codes starting 111111
+        const uint32_t len = e >> 8;
+        e &= 0xffu;
+        if (e == 0) { br.off += len; break; }
+        k += (int)(e >> 4);
+        const uint32_t ms = e & 0xfu;
+        const bool store = k < LIMIT && ms != 0;
+        const uint32_t t = T.zz16[k & 63];
+        const int32_t v = jda_extend_top(w << len, ms);
+        fl |= store ? t : 0u;
+        coef[store ? (t & 63u) : 64u] = (int16_t)v;      // slot 64 = the block's padding
+        br.off += len + ms;
+        k++;
+        jda_refill_win(br, wbase, true);
+        if (k >= LIMIT) break;
+    }
+    // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested
+    return (fl >> 8) | ((fl & 0x20u) << 8);
 }
 
 // Multiplication by an IDCT constant.  FAST: both operands are known to fit in 24 signed bits (the
@@ -570,6 +709,7 @@ struct jda_tile_ctx {                 // wave-uniform facts about the tile, comp
     uint32_t count;                   // MCUs of the tile that are decoded (<= MCUS, clipped by n_mcus_ok; 0 = padding tile)
     uint32_t first_block;             // linear block index of the tile's first block
     uint32_t win_lo, win_len;         // bytes of the scan staged in LDS
+    uint32_t win_need;                // bytes the tile's lanes can touch (> win_len: some reads go to HBM)
 };
 
 // same, from index entries already in registers: ix_first = index[first block of the tile],
@@ -584,13 +724,14 @@ JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &
     if (C.first_mcu >= D.n_mcus_ok) C.count = 0;
     else if (C.first_mcu + C.count > D.n_mcus_ok) C.count = D.n_mcus_ok - C.first_mcu;
     C.first_block = C.first_mcu * T::NBLK;
-    C.win_lo = 0; C.win_len = 0;
+    C.win_lo = 0; C.win_len = 0; C.win_need = 0;
     if (C.count) {
         C.win_lo = (ix_first >> JDA_INDEX_OFF_BITS) & ~15u;
         uint32_t hi = ((ix_end >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
         const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
+        C.win_need = C.win_len;
         if (C.win_len > JDA_WIN_BYTES) C.win_len = JDA_WIN_BYTES;
     }
     return C;
@@ -606,7 +747,7 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
     if (C.first_mcu >= D.n_mcus_ok) C.count = 0;
     else if (C.first_mcu + C.count > D.n_mcus_ok) C.count = D.n_mcus_ok - C.first_mcu;
     C.first_block = C.first_mcu * T::NBLK;
-    C.win_lo = 0; C.win_len = 0;
+    C.win_lo = 0; C.win_len = 0; C.win_need = 0;
     if (C.count) {
         // the tile's blocks are consecutive in the scan: stage one contiguous run of bytes
         C.win_lo = (JDA_G(const uint32_t, D.blk_index)[C.first_block] >> JDA_INDEX_OFF_BITS) & ~15u;
@@ -615,6 +756,7 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
         const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;      // never past the padded allocation
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
+        C.win_need = C.win_len;
         if (C.win_len > JDA_WIN_BYTES) C.win_len = JDA_WIN_BYTES;
     }
     return C;
@@ -628,7 +770,11 @@ JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads
     jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;
     // quant + zigzag: blob[10240, 10816) -> LT_QUANT
-    for (uint32_t i = tid; i < JDA_LT_BYTES / 16; i += nthreads) {
+    if (tid < 64) {                                              // zigzag + flag bits of A.2 in one lookup
+        const uint32_t n = JDA_G(const uint8_t, D.tables)[JDA_TB_ZIGZAG + tid];
+        ((uint16_t *)(tab_lds + JDA_LT_ZZ16))[tid] = (uint16_t)(n | ((1u << (n & 7u)) << 8));
+    }
+    for (uint32_t i = tid; i < JDA_LT_ZZ16 / 16; i += nthreads) {
         uint32_t src;
         if (i < 128) src = i;                                   // DC
         else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
@@ -669,17 +815,22 @@ JDA_HD jda_p1_inputs jda_p1_prefetch(const jda_dev_desc &D, const jda_tile_ctx &
     return in;
 }
 
+// Result of a lane's P1: the block's occupancy flags (A.2; 0 = DC-only), or JDA_NO_LIST when the lane has
+// nothing for the IDCT work lists (no block, chroma of a luma-only decode, 1/4 and 1/8 scale).
+#define JDA_NO_LIST 0xffffffffu
+
 template <int MODE>
-JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const uint8_t *tab, uint8_t *wl,
-                           const uint8_t *win, uint32_t win_cap)
+JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const uint8_t *tab, uint8_t *wl,
+                               const uint8_t *win, uint32_t win_cap)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
-    if (!in.active) return;
+    if (!in.active) return JDA_NO_LIST;
+    JDA_P1_TRACE(10);
     const uint32_t lb = in.lb;
     const uint32_t m = lb / T::NBLK, b = lb - m * T::NBLK;       // MCU within tile, block within MCU
     (void)m;
-    if (MODE != JDA_MODE_GRAY && D.gray_from_color && b >= (uint32_t)T::NLUMA) return;   // :5225-5233 chroma never decoded
+    if (MODE != JDA_MODE_GRAY && D.gray_from_color && b >= (uint32_t)T::NLUMA) return JDA_NO_LIST;   // :5225-5233 chroma never decoded
     const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
     jda_tables TB;
     const uint32_t dc_id = jda_pick3(D.dc_id, c), ac_id = jda_pick3(D.ac_id, c);
@@ -687,6 +838,7 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
     TB.ac_short = (const uint16_t *)(tab + JDA_LT_AC) + ac_id * 1024;
     TB.ac_long = JDA_G(const uint16_t, D.tables + JDA_TB_AC) + ac_id * 2048 + 1024;
     TB.zigzag = tab + JDA_LT_ZIGZAG;
+    TB.zz16 = (const uint16_t *)(tab + JDA_LT_ZZ16);
     const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64;
     int16_t *coef = (int16_t *)(wl + L::COEF_OFF + lb * JDA_COEF_STRIDE);
     uint8_t *plane = (uint8_t *)coef;                            // samples overwrite the block's own slot
@@ -702,43 +854,86 @@ JDA_HD void jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const j
     br.bits = jda_load_be64(br, br.pos);
     int32_t pred = in.pred;
 
+    JDA_P1_TRACE(8);
     const int shift = D.scale_shift;
+    const bool win_only = C.win_need <= br.win_len;             // wave-uniform: the whole slice is in LDS
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
-        jda_decode_block<1>(br, TB, coef, pred);
+        if (win_only) jda_decode_block_win<1>(br, TB, coef, pred, true); else jda_decode_block<1>(br, TB, coef, pred);
         *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
-        return;
+        return JDA_NO_LIST;
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
-        const uint32_t flags = jda_decode_block<5>(br, TB, coef, pred);
+        const uint32_t flags = win_only ? jda_decode_block_win<5>(br, TB, coef, pred, true) : jda_decode_block<5>(br, TB, coef, pred);
         const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
                                        : jda_idct_2x2(coef, quant);
         *(jda_u32_alias *)plane = px;
-        return;
+        return JDA_NO_LIST;
     }
-    const uint32_t flags = jda_decode_block<64>(br, TB, coef, pred);
+    const uint32_t flags = win_only ? jda_decode_block_win<64>(br, TB, coef, pred, true) : jda_decode_block<64>(br, TB, coef, pred);
+    JDA_P1_TRACE(9);
+    return flags;
+}
+
+// The work lists of the IDCT stages, built by the whole wavefront at once (every lane calls this, with
+// its jda_p1_entropy result): the non-empty columns of every block -> two column lists (rows 4-7 empty
+// or not, jpeg.inl:2561), every block -> one of the three row-variant lists (:2686-2688) or the DC-only
+// list (:5146-5154).  Positions come from a wave prefix sum / ballots; order within a list is irrelevant.
+// all_flags: host emulation only (the flags of all 64 lanes).
+template <int MODE>
+JDA_HD void jda_p1_lists(uint32_t lane, uint32_t flags, const uint32_t *all_flags, uint8_t *wl)
+{
+    typedef jda_lds_layout<MODE> L;
     uint32_t *cnt = (uint32_t *)(wl + L::CNT_OFF);
     uint8_t *rowlist = wl + L::ROWLIST_OFF;
-    if (flags == 0) {                                            // DC-only block (:5146-5154): row class 3
-        rowlist[3 * JDA_TILE_THREADS + jda_lds_add(&cnt[5], 1)] = (uint8_t)lb;
-        return;
-    }
+    uint16_t *collist = (uint16_t *)(wl + L::COLLIST_OFF);
+    const bool listed = flags != JDA_NO_LIST;
+    const bool has_ac = listed && flags != 0;
     // columns that hold data (column 0 always, :2555); rows 4-7 empty selects the short column stage
-    const uint32_t colmask = (flags & 0xffu) | 1u;
+    const uint32_t colmask = has_ac ? ((flags & 0xffu) | 1u) : 0u;
     const uint32_t ncols = jda_popcount8(colmask);
     const bool half = (flags & 0x2000u) == 0;
-    const uint32_t base = jda_lds_add(&cnt[half ? 0 : 1], ncols);
-    uint16_t *collist = (uint16_t *)(wl + L::COLLIST_OFF);
-    uint32_t j = 0;
+    // one scan for both lists: short-stage columns in the low half of the word, full-stage in the high half
+    const uint32_t mine = half ? ncols : (ncols << 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t *all_mine = nullptr, *all_cls = nullptr;
+#else
+    uint32_t all_mine[JDA_TILE_THREADS], all_cls[JDA_TILE_THREADS];
+    for (uint32_t l = 0; l < JDA_TILE_THREADS; l++) {
+        const uint32_t f = all_flags[l];
+        const bool ac = f != JDA_NO_LIST && f != 0;
+        const uint32_t n = ac ? jda_popcount8((f & 0xffu) | 1u) : 0u;
+        all_mine[l] = (f & 0x2000u) == 0 ? n : (n << 16);
+        all_cls[l] = f == JDA_NO_LIST ? 4u : (f == 0 ? 3u : ((f & 0xf0u) ? 2u : ((f & 0xfcu) ? 1u : 0u)));
+    }
+#endif
+    uint32_t total;
+    const uint32_t below = jda_wave_excl_sum(mine, lane, all_mine, total);
+    const uint32_t base = half ? (below & 0xffffu) : (below >> 16);
+    // two lists in one array: the short-stage list grows up from 0, the full-stage list down from the end;
+    // columns a block does not have are written to a scratch word instead (no divergent branches)
+    int32_t slot = half ? (int32_t)base : (int32_t)(L::COLLIST_ENTRIES - 1u) - (int32_t)base;
+    const int32_t step = half ? 1 : -1;
+    uint16_t *scratch = (uint16_t *)&cnt[6];
 #pragma unroll
     for (uint32_t col = 0; col < 8; col++) {
-        if (colmask & (1u << col)) {
-            const uint32_t slot = half ? base + j : (JDA_COLLIST_ENTRIES - 1u) - (base + j);   // two lists, one array
-            collist[slot] = (uint16_t)((lb << 3) | col);
-            j++;
-        }
+        const bool has = (colmask >> col) & 1u;
+        uint16_t *dst = has ? collist + slot : scratch;
+        *dst = (uint16_t)((lane << 3) | col);
+        slot += has ? step : 0;
     }
-    const uint32_t rc = (flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u);       // :2686-2688
-    rowlist[rc * JDA_TILE_THREADS + jda_lds_add(&cnt[2 + rc], 1)] = (uint8_t)lb;
+    const uint32_t cls = !listed ? 4u : (flags == 0 ? 3u : ((flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u)));
+    uint32_t n0, n1, n2, n3;
+    const uint32_t r0 = jda_wave_class_rank(cls, 0, lane, all_cls, n0);
+    const uint32_t r1 = jda_wave_class_rank(cls, 1, lane, all_cls, n1);
+    const uint32_t r2 = jda_wave_class_rank(cls, 2, lane, all_cls, n2);
+    const uint32_t r3 = jda_wave_class_rank(cls, 3, lane, all_cls, n3);
+    const uint32_t rank = cls == 0 ? r0 : (cls == 1 ? r1 : (cls == 2 ? r2 : r3));
+    uint8_t *rdst = listed ? rowlist + cls * JDA_TILE_THREADS + rank : (uint8_t *)&cnt[7];
+    *rdst = (uint8_t)lane;
+    if (lane == 0) {
+        cnt[0] = total & 0xffffu; cnt[1] = total >> 16;
+        cnt[2] = n0; cnt[3] = n1; cnt[4] = n2; cnt[5] = n3;
+    }
 }
 
 // ---- P2 ---------------------------------------------------------------------------------------
@@ -772,7 +967,7 @@ JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, const uint8_t *tab
     const uint32_t n_half = cnt[0], n_full = cnt[1];
     for (uint32_t i = t; i < n_half; i += JDA_TILE_THREADS) jda_p2_column_item<MODE, FAST, true>(D, collist[i], tab, wl);
     for (uint32_t i = t; i < n_full; i += JDA_TILE_THREADS)
-        jda_p2_column_item<MODE, FAST, false>(D, collist[(JDA_COLLIST_ENTRIES - 1u) - i], tab, wl);
+        jda_p2_column_item<MODE, FAST, false>(D, collist[(L::COLLIST_ENTRIES - 1u) - i], tab, wl);
 }
 
 // ---- P3 ---------------------------------------------------------------------------------------
@@ -882,6 +1077,33 @@ JDA_HD jda_chroma jda_chroma_terms(uint32_t cb8, uint32_t cr8)
     t.b = (7258 * cb - 7258 * 128) >> 12;
     return t;
 }
+// The same three terms, each duplicated into both 16-bit halves of a word (the operand of the packed
+// pixel-pair adds).  x >> 12 == (16 x) >> 16, and the upper half of a word is picked by the byte
+// permute that duplicates it: multiply-add + permute per term, no shift.
+struct jda_chroma2 { uint32_t r, g, b; };
+// un-shifted terms (16 x the products); the wanted value sits in bits 31:16
+JDA_HD jda_chroma2 jda_chroma_terms16(uint32_t cb8, uint32_t cr8)
+{
+    const int32_t cb = (int32_t)cb8, cr = (int32_t)cr8;
+    jda_chroma2 t;
+    t.r = (uint32_t)(16 * 5742 * cr - 16 * 5742 * 128);
+    t.g = (uint32_t)(-16 * 1409 * cb - 16 * 2925 * cr + 16 * (1409 + 2925) * 128);
+    t.b = (uint32_t)(16 * 7258 * cb - 16 * 7258 * 128);
+    return t;
+}
+JDA_HD uint32_t jda_pack_hi16(uint32_t lo, uint32_t hi) { return jda_perm(hi, lo, 0x07060302u); }   // {hi[31:16], lo[31:16]}
+JDA_HD jda_chroma2 jda_chroma_terms_dup(uint32_t cb8, uint32_t cr8)
+{
+    const int32_t cb = (int32_t)cb8, cr = (int32_t)cr8;
+    const uint32_t r16 = (uint32_t)(16 * 5742 * cr - 16 * 5742 * 128);
+    const uint32_t g16 = (uint32_t)(-16 * 1409 * cb - 16 * 2925 * cr + 16 * (1409 + 2925) * 128);
+    const uint32_t b16 = (uint32_t)(16 * 7258 * cb - 16 * 7258 * 128);
+    jda_chroma2 t;                                        // (dup of bits 31:16)
+    t.r = jda_perm(0, r16, 0x03020302u);
+    t.g = jda_perm(0, g16, 0x03020302u);
+    t.b = jda_perm(0, b16, 0x03020302u);
+    return t;
+}
 template <int PT>
 JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t)
 {
@@ -935,17 +1157,17 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint32_t ya = *(const jda_u32_alias *)py, yb = *(const jda_u32_alias *)(py + 8);
         const uint32_t ci = rp * 8 + (bx >> 1);
         const uint32_t cb2 = *(const uint16_t *)(P + 4 * JDA_COEF_STRIDE + ci), cr2 = *(const uint16_t *)(P + 5 * JDA_COEF_STRIDE + ci);
-        const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
-        const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
         uint32_t v0[4], v1[4];
         if (PT == JDA_RGB8888) {
-            const uint32_t r0 = jda_dup16(c0.r), g0 = jda_dup16(c0.g), b0 = jda_dup16(c0.b);
-            const uint32_t r1 = jda_dup16(c1.r), g1 = jda_dup16(c1.g), b1 = jda_dup16(c1.b);
-            jda_rgba_pair(jda_perm(0, ya, 0x0c010c00u), r0, g0, b0, v0[0], v0[1]);
-            jda_rgba_pair(jda_perm(0, ya, 0x0c030c02u), r1, g1, b1, v0[2], v0[3]);
-            jda_rgba_pair(jda_perm(0, yb, 0x0c010c00u), r0, g0, b0, v1[0], v1[1]);
-            jda_rgba_pair(jda_perm(0, yb, 0x0c030c02u), r1, g1, b1, v1[2], v1[3]);
+            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
+            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
+            jda_rgba_pair(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b, v0[0], v0[1]);
+            jda_rgba_pair(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b, v0[2], v0[3]);
+            jda_rgba_pair(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b, v1[0], v1[1]);
+            jda_rgba_pair(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b, v1[2], v1[3]);
         } else {
+            const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
+            const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
             v0[0] = jda_rgb_pixel<PT>(ya & 255u, c0);          v0[1] = jda_rgb_pixel<PT>((ya >> 8) & 255u, c0);
             v0[2] = jda_rgb_pixel<PT>((ya >> 16) & 255u, c1);  v0[3] = jda_rgb_pixel<PT>(ya >> 24, c1);
             v1[0] = jda_rgb_pixel<PT>(yb & 255u, c0);          v1[1] = jda_rgb_pixel<PT>((yb >> 8) & 255u, c0);
@@ -973,11 +1195,11 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint32_t y = *(const jda_u32_alias *)P, cb = *(const jda_u32_alias *)(P + JDA_COEF_STRIDE), cr = *(const jda_u32_alias *)(P + 2 * JDA_COEF_STRIDE);
         uint32_t v[4];
         if (PT == JDA_RGB8888) {
-            jda_chroma c[4];
+            jda_chroma2 c[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
-            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), jda_pack16(c[0].r, c[1].r), jda_pack16(c[0].g, c[1].g), jda_pack16(c[0].b, c[1].b), v[0], v[1]);
-            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), jda_pack16(c[2].r, c[3].r), jda_pack16(c[2].g, c[3].g), jda_pack16(c[2].b, c[3].b), v[2], v[3]);
+            for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms16((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
+            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
+            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++)

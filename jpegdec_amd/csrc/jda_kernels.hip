@@ -18,14 +18,22 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+__device__ unsigned long long *g_jda_trace = nullptr;
+// inside P1 (lane 0 of wave 0 of every 16th workgroup; the last tile decoded wins).  Costs a global load per
+// hook, so only in -DJDA_PROFILE_P1 builds.
+#ifdef JDA_PROFILE_P1
+#define JDA_P1_TRACE(slot) do { if (g_jda_trace && threadIdx.x == 0 && blockIdx.x % 16 == 0) g_jda_trace[(blockIdx.x / 16 * 4) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#endif
 #include "jda_device_core.h"
 #include "jda_plan.h"
 
 // optional phase trace (profiling aid, off unless jda_internal_set_trace() was called): per traced
 // workgroup and wave, the shader clock at each phase boundary
-__device__ unsigned long long *g_jda_trace = nullptr;
-#define JDA_TRACE_STRIDE 64
-#define JDA_TRACE(slot) do { if (trace && lane == 0) trace[(blockIdx.x / JDA_TRACE_STRIDE * JDA_WAVES_PER_WG + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define JDA_TRACE_STRIDE 16
+#define JDA_TRACE(slot) do { if (trace && lane == 0 && wave < 4) trace[(blockIdx.x / JDA_TRACE_STRIDE * 4 + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+
+// the same inside the persistent kernel: the second tile a traced workgroup decodes (steady state)
+#define JDA_PTRACE(slot) do { if (trace && iter == 1 && lane == 0 && wave < 4) trace[(blockIdx.x / JDA_TRACE_STRIDE * 4 + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 
 // wave-local phase boundary: LDS operations of one wavefront complete in order, so ordering the
 // compiler is all that is needed -- no s_barrier
@@ -63,7 +71,7 @@ __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
 }
 
 template <int MODE, bool FAST>
-__global__ __launch_bounds__(64 * JDA_WAVES_PER_WG)
+__global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
 void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -73,7 +81,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     JDA_TRACE(0);
 
     // tile record and image descriptor are wave-uniform: keep them in SGPRs
-    const jda_strip *tp = tiles + (size_t)blockIdx.x * JDA_WAVES_PER_WG + wave;
+    const jda_strip *tp = tiles + (size_t)blockIdx.x * jda_lds_layout<MODE>::WAVES + wave;
     jda_strip S;
     S.image = __builtin_amdgcn_readfirstlane(tp->image);
     S.mcu_y = __builtin_amdgcn_readfirstlane(tp->mcu_y);
@@ -89,12 +97,14 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     uint8_t *wl = lds + JDA_LT_BYTES + wave * L::WAVE_BYTES;
     const jda_p1_inputs p1in = jda_p1_prefetch<MODE>(D, C, lane);   // in flight while LDS is staged
     JDA_TRACE(1);
-    jda_p0_tables(D, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
+    jda_p0_tables(D, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
     jda_p0_stage<MODE>(D, C, lane, wl, JDA_WIN_BYTES);
     JDA_TRACE(2);
     __syncthreads();                                  // the only workgroup barrier: tables are in LDS
     JDA_TRACE(3);
-    if (!(D.pad_[0] & 4)) jda_p1_entropy<MODE>(D, C, p1in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
+    uint32_t p1flags = JDA_NO_LIST;
+    if (!(D.pad_[0] & 4)) p1flags = jda_p1_entropy<MODE>(D, C, p1in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
+    if (D.scale_shift < 2) jda_p1_lists<MODE>(lane, p1flags, nullptr, wl);
     JDA_WAVE_SYNC();
     JDA_TRACE(4);
     if (D.scale_shift < 2 && !(D.pad_[0] & 6)) {
@@ -112,7 +122,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
 template <int MODE, bool FAST>
 static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    const int lds_bytes = JDA_LT_BYTES + JDA_WAVES_PER_WG * jda_lds_layout<MODE>::WAVE_BYTES;
+    const int lds_bytes = JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles<MODE, FAST>,
@@ -120,7 +130,7 @@ static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((jda_decode_tiles<MODE, FAST>), dim3(n_tiles / JDA_WAVES_PER_WG), dim3(64 * JDA_WAVES_PER_WG),
+    hipLaunchKernelGGL((jda_decode_tiles<MODE, FAST>), dim3(n_tiles / jda_lds_layout<MODE>::WAVES), dim3(64 * jda_lds_layout<MODE>::WAVES),
                        lds_bytes, stream, descs, tiles);
     return hipGetLastError();
 }
@@ -171,7 +181,7 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
 }
 
 template <int MODE, bool FAST>
-__global__ __launch_bounds__(64 * JDA_WAVES_PER_WG)
+__global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
 void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -185,10 +195,10 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     uint8_t *wl = lds + JDA_LT_BYTES + wave * L::WAVE_BYTES;
 
     // ---- prologue: everything for the first tile
-    jda_strip S = jda_load_record<MODE>(tiles + (size_t)q * JDA_WAVES_PER_WG + wave);
+    jda_strip S = jda_load_record<MODE>(tiles + (size_t)q * jda_lds_layout<MODE>::WAVES + wave);
     jda_dev_desc Dc = jda_desc_uniform(descs + S.image);
     uint32_t staged_image = S.image;
-    jda_p0_tables(Dc, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
+    jda_p0_tables(Dc, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
     jda_p1_inputs in;
     uint32_t ix_end;
     jda_issue_index_loads<MODE>(Dc, S, lane, in, ix_end);
@@ -203,13 +213,16 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 
     // the record of the tile after this one (wave-uniform)
     jda_strip Sn = S;
-    if (q + 1 < q_end) Sn = jda_load_record<MODE>(tiles + (size_t)(q + 1) * JDA_WAVES_PER_WG + wave);
+    if (q + 1 < q_end) Sn = jda_load_record<MODE>(tiles + (size_t)(q + 1) * jda_lds_layout<MODE>::WAVES + wave);
 
+    unsigned long long *trace = (blockIdx.x % JDA_TRACE_STRIDE == 0) ? g_jda_trace : nullptr;
+    uint32_t iter = 0;
     for (;;) {
         const jda_dev_desc &D = Dc;
+        JDA_PTRACE(0);
         const bool have_next = q + 1 < q_end;
         // stage A: the record two tiles ahead (a wave-uniform 16-byte load, consumed at the bottom of the loop)
-        const jda_strip *np_ = tiles + (size_t)(q + 2) * JDA_WAVES_PER_WG + wave;
+        const jda_strip *np_ = tiles + (size_t)(q + 2) * jda_lds_layout<MODE>::WAVES + wave;
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         if (q + 2 < q_end) { r0 = np_->image; r1 = np_->mcu_y; r2 = np_->mcu_x0; r3 = np_->count; }
         // stage B: per-lane index entries of the next tile; in flight during this tile's entropy phase
@@ -220,8 +233,11 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         inn.lb = lane; inn.ix = 0; inn.pred = 0; inn.active = false;
         if (have_next) jda_issue_index_loads<MODE>(Dn, Sn, lane, inn, ixn_end);
 
-        jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF + buf * JDA_WIN_BYTES, JDA_WIN_BYTES);
+        JDA_PTRACE(1);
+        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF + buf * JDA_WIN_BYTES, JDA_WIN_BYTES);
+        if (D.scale_shift < 2) jda_p1_lists<MODE>(lane, p1flags, nullptr, wl);
         JDA_WAVE_SYNC();
+        JDA_PTRACE(2);
 
         // stage C: index entries are here -> window bounds -> the next tile's scan slice (HBM -> registers),
         // in flight during the column stage
@@ -237,25 +253,31 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
             chunk = jda_window_load(JDA_G(const uint8_t, Dn.scan), Cn.win_lo, Cn.win_len, lane);
         }
 
+        JDA_PTRACE(3);
         if (D.scale_shift < 2) {
             jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
             JDA_WAVE_SYNC();
         }
+        JDA_PTRACE(4);
 
         // stage D: scan slice -> the other LDS window
         if (have_next) jda_window_store(wl + L::WIN_OFF + (buf ^ 1u) * JDA_WIN_BYTES, Cn.win_len, lane, chunk);
 
+        JDA_PTRACE(5);
         if (D.scale_shift < 2) {
             jda_p3_rows<MODE>(D, lane, tab, wl);
             JDA_WAVE_SYNC();
         }
+        JDA_PTRACE(6);
         if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;      // list counters reset for the next tile
 
         jda_p4_output<MODE>(D, S, C, lane, wl);
+        JDA_PTRACE(7);
+        iter++;
         if (!have_next) break;
         if (Sn.image != staged_image) {               // image boundary (same for all four waves of the quad)
             __syncthreads();
-            jda_p0_tables(Dn, threadIdx.x, 64 * JDA_WAVES_PER_WG, tab);
+            jda_p0_tables(Dn, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
             __syncthreads();
             staged_image = Sn.image;
         }
@@ -269,7 +291,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 template <int MODE, bool FAST>
 static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    const int lds_bytes = JDA_LT_BYTES + JDA_WAVES_PER_WG * jda_lds_layout<MODE>::WAVE_BYTES;
+    const int lds_bytes = JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES;
     static int grid_cap = 0;
     if (!grid_cap) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST>,
@@ -280,9 +302,9 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
         const int per_cu = (160 * 1024) / lds_bytes;
         grid_cap = cus * (per_cu > 0 ? per_cu : 1);
     }
-    const uint32_t n_quads = n_tiles / JDA_WAVES_PER_WG;
+    const uint32_t n_quads = n_tiles / jda_lds_layout<MODE>::WAVES;
     const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
-    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST>), dim3(grid), dim3(64 * JDA_WAVES_PER_WG), lds_bytes, stream,
+    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST>), dim3(grid), dim3(64 * jda_lds_layout<MODE>::WAVES), lds_bytes, stream,
                        descs, tiles, n_quads);
     return hipGetLastError();
 }
@@ -292,7 +314,7 @@ extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_trace), &dev_buf, sizeof(dev_buf));
 }
 
-// Launch entry used by jda_runtime.cpp.  n_tiles is a multiple of JDA_WAVES_PER_WG (padded per image).
+// Launch entry used by jda_runtime.cpp.  n_tiles is a multiple of jda_lds_layout<MODE>::WAVES (padded per image).
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_desc *descs, const jda_strip *tiles,
                                         uint32_t n_tiles, hipStream_t stream)
 {

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "jda_internal.h"
+#include "jda_device_core.h"     // the LDS layout decides how many wavefronts (= tiles) share a workgroup
 
 extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
@@ -55,9 +56,14 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
 }
 
 // Tiles of one image: each MCU row is cut into runs of <= 64 blocks (10 MCUs of 4:2:0, 21 of 4:4:4,
-// 64 of gray); one wavefront decodes one tile, four tiles make a workgroup.  The list is padded
-// with empty tiles per image so that a workgroup never spans two images (it stages one table set).
-#define JDA_TILES_PER_WG 4
+// 64 of gray); one wavefront decodes one tile, and a workgroup is as many wavefronts as fit in a CU's LDS
+// next to one copy of the tables (15 for 4:2:0, 14 otherwise).  The list is padded with empty tiles per
+// image so that a workgroup never spans two images (it stages one table set).
+inline uint32_t jda_tiles_per_wg(int mode)
+{
+    return mode == JDA_MODE_420 ? (uint32_t)jda_lds_layout<JDA_MODE_420>::WAVES
+         : mode == JDA_MODE_444 ? (uint32_t)jda_lds_layout<JDA_MODE_444>::WAVES : (uint32_t)jda_lds_layout<JDA_MODE_GRAY>::WAVES;
+}
 inline uint32_t jda_mcus_per_tile(int mode) { return mode == JDA_MODE_420 ? 10u : (mode == JDA_MODE_444 ? 21u : 64u); }
 
 inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode)
@@ -70,7 +76,7 @@ inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_
             s.count = mcus_x - x < per ? mcus_x - x : per;
             v.push_back(s);
         }
-    while (v.size() % JDA_TILES_PER_WG) {
+    while (v.size() % jda_tiles_per_wg(mode)) {
         jda_strip s;
         s.image = image; s.mcu_y = 0; s.mcu_x0 = 0; s.count = 0;
         v.push_back(s);

@@ -257,7 +257,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)(strips[m].size() / JDA_TILES_PER_WG);
+        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 2));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
