@@ -38,7 +38,8 @@
 #define JDA_P1_TRACE(slot) ((void)0)      // profiling hook, defined by jda_kernels.hip
 #endif
 #define JDA_COEF_STRIDE 136      // bytes per block in LDS: 64 int16 + 8 pad (row reads stay 8-byte aligned)
-#define JDA_WIN_BYTES 512        // per-wave LDS window over the tile's slice of the filtered scan (x2: double buffered)
+#define JDA_WIN_BYTES 576        // per-wave LDS window over the tile's slice of the filtered scan (only P1 reads it, so the
+                                 // next tile's slice can be stored as soon as this tile's P1 is over)
 
 template <int MODE> struct jda_mode_traits;
 template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
@@ -62,12 +63,12 @@ template <int MODE> struct jda_lds_layout {       // the per-WAVE region
         // one 136-byte slot per block: int16[64] coefficients, later (first 64 bytes) its 8x8 samples --
         // the row stage stores its bytes over the block it has just read, as the reference does (:2682)
         COEF_OFF = 0,
-        ROWLIST_OFF = COEF_OFF + BLOCKS * JDA_COEF_STRIDE,           // 4 classes x 64 block ids (uint8)
-        CNT_OFF = ROWLIST_OFF + 4 * JDA_TILE_THREADS,               // 8 uint32 counters
+        ROWLIST_OFF = COEF_OFF + BLOCKS * JDA_COEF_STRIDE,           // 64 block ids (uint8), grouped by row class
+        CNT_OFF = ROWLIST_OFF + JDA_TILE_THREADS,                   // 8 uint32 counters
         COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
         COLLIST_ENTRIES = BLOCKS * 8,                               // every column of every block
         WIN_OFF = COLLIST_OFF + COLLIST_ENTRIES * 2,
-        WAVE_BYTES = WIN_OFF + 2 * JDA_WIN_BYTES,                   // 10,432 B (4:2:0): the next tile's scan slice is staged while this one decodes
+        WAVE_BYTES = WIN_OFF + JDA_WIN_BYTES,                       // 9,792 B (4:2:0)
         PLANE_OFF = COEF_OFF,
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE, // bytes between consecutive MCUs' samples
         // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy
@@ -928,7 +929,9 @@ JDA_HD void jda_p1_lists(uint32_t lane, uint32_t flags, const uint32_t *all_flag
     const uint32_t r2 = jda_wave_class_rank(cls, 2, lane, all_cls, n2);
     const uint32_t r3 = jda_wave_class_rank(cls, 3, lane, all_cls, n3);
     const uint32_t rank = cls == 0 ? r0 : (cls == 1 ? r1 : (cls == 2 ? r2 : r3));
-    uint8_t *rdst = listed ? rowlist + cls * JDA_TILE_THREADS + rank : (uint8_t *)&cnt[7];
+    // one array, classes back to back: 0 | 1 | 2 | DC-only
+    const uint32_t cbase = cls == 0 ? 0u : (cls == 1 ? n0 : (cls == 2 ? n0 + n1 : n0 + n1 + n2));
+    uint8_t *rdst = listed ? rowlist + cbase + rank : (uint8_t *)&cnt[7];
     *rdst = (uint8_t)lane;
     if (lane == 0) {
         cnt[0] = total & 0xffffu; cnt[1] = total >> 16;
@@ -972,10 +975,10 @@ JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, const uint8_t *tab
 
 // ---- P3 ---------------------------------------------------------------------------------------
 template <int MODE, int RC>
-JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *wl, uint32_t n_blocks)
+JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *wl, uint32_t first, uint32_t n_blocks)
 {
     typedef jda_lds_layout<MODE> L;
-    const uint8_t *list = wl + L::ROWLIST_OFF + RC * JDA_TILE_THREADS;
+    const uint8_t *list = wl + L::ROWLIST_OFF + first;
     for (uint32_t i = t; i < n_blocks * 8; i += JDA_TILE_THREADS) {
         const uint32_t blk = list[i >> 3], row = i & 7u;
         const jda_u64_alias *src = (const jda_u64_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 16);
@@ -1002,11 +1005,12 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, const uint8_t *tab, u
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
     const uint32_t *cnt = (const uint32_t *)(wl + L::CNT_OFF);
-    jda_p3_row_class<MODE, 0>(t, wl, cnt[2]);
-    jda_p3_row_class<MODE, 1>(t, wl, cnt[3]);
-    jda_p3_row_class<MODE, 2>(t, wl, cnt[4]);
+    const uint32_t n0 = cnt[2], n1 = cnt[3], n2 = cnt[4];
+    jda_p3_row_class<MODE, 0>(t, wl, 0, n0);
+    jda_p3_row_class<MODE, 1>(t, wl, n0, n1);
+    jda_p3_row_class<MODE, 2>(t, wl, n0 + n1, n2);
     // DC-only blocks: all 64 samples = RT((pred * q0) >> 5)  (:5146-5154); one thread per block (rare)
-    const uint8_t *list = wl + L::ROWLIST_OFF + 3 * JDA_TILE_THREADS;
+    const uint8_t *list = wl + L::ROWLIST_OFF + n0 + n1 + n2;
     const uint32_t n_dc = cnt[5];
     for (uint32_t i = t; i < n_dc; i += JDA_TILE_THREADS) {
         const uint32_t blk = list[i];

@@ -206,7 +206,6 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     C.count = __builtin_amdgcn_readfirstlane(C.count);
     C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
     C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
-    uint32_t buf = 0;
     jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane));
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
     __syncthreads();                                  // tables staged
@@ -234,7 +233,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         if (have_next) jda_issue_index_loads<MODE>(Dn, Sn, lane, inn, ixn_end);
 
         JDA_PTRACE(1);
-        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF + buf * JDA_WIN_BYTES, JDA_WIN_BYTES);
+        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
         if (D.scale_shift < 2) jda_p1_lists<MODE>(lane, p1flags, nullptr, wl);
         JDA_WAVE_SYNC();
         JDA_PTRACE(2);
@@ -260,8 +259,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         }
         JDA_PTRACE(4);
 
-        // stage D: scan slice -> the other LDS window
-        if (have_next) jda_window_store(wl + L::WIN_OFF + (buf ^ 1u) * JDA_WIN_BYTES, Cn.win_len, lane, chunk);
+        // stage D: scan slice -> the LDS window (this tile's P1, its only reader, is over)
+        if (have_next) jda_window_store(wl + L::WIN_OFF, Cn.win_len, lane, chunk);
 
         JDA_PTRACE(5);
         if (D.scale_shift < 2) {
@@ -281,7 +280,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
             __syncthreads();
             staged_image = Sn.image;
         }
-        S = Sn; C = Cn; in = inn; Dc = Dn; buf ^= 1u; q++;
+        S = Sn; C = Cn; in = inn; Dc = Dn; q++;
         Sn.image = __builtin_amdgcn_readfirstlane(r0); Sn.mcu_y = __builtin_amdgcn_readfirstlane(r1);
         Sn.mcu_x0 = __builtin_amdgcn_readfirstlane(r2); Sn.count = __builtin_amdgcn_readfirstlane(r3);
         JDA_WAVE_SYNC();

@@ -57,7 +57,7 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
 
 // Tiles of one image: each MCU row is cut into runs of <= 64 blocks (10 MCUs of 4:2:0, 21 of 4:4:4,
 // 64 of gray); one wavefront decodes one tile, and a workgroup is as many wavefronts as fit in a CU's LDS
-// next to one copy of the tables (15 for 4:2:0, 14 otherwise).  The list is padded with empty tiles per
+// next to one copy of the tables (16 for 4:2:0, 15 otherwise).  The list is padded with empty tiles per
 // image so that a workgroup never spans two images (it stages one table set).
 inline uint32_t jda_tiles_per_wg(int mode)
 {
