@@ -128,6 +128,30 @@ JDA_HD uint32_t jda_pk_add16(uint32_t a, uint32_t b)
     return ((a + b) & 0xffffu) | ((a & 0xffff0000u) + (b & 0xffff0000u));
 #endif
 }
+// two independent 16-bit subtracts (v_pk_sub_u16)
+JDA_HD uint32_t jda_pk_sub16(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short jda_us2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(jda_us2, a) - __builtin_bit_cast(jda_us2, b));
+#else
+    return ((a - b) & 0xffffu) | (((a & 0xffff0000u) - (b & 0xffff0000u)) & 0xffff0000u);
+#endif
+}
+// per 16-bit lane: the sign-extended 10-bit field at bits 14:5  (v_pk_lshlrev_b16 1, v_pk_ashrrev_i16 6)
+JDA_HD uint32_t jda_pk_sext10_at5(uint32_t a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short jda_s2 __attribute__((ext_vector_type(2)));
+    jda_s2 v = __builtin_bit_cast(jda_s2, a);
+    v = v << 1;
+    v = v >> 6;
+    return __builtin_bit_cast(uint32_t, v);
+#else
+    const int32_t lo = (int16_t)(uint16_t)((a & 0xffffu) << 1) >> 6, hi = (int16_t)(uint16_t)(((a >> 16) & 0xffffu) << 1) >> 6;
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+#endif
+}
 // two signed 16-bit values -> two bytes saturated to 0..255 in bits 15:0, bits 31:16 zero (v_sat_pk_u8_i16)
 JDA_HD uint32_t jda_sat_pk_u8(uint32_t a)
 {
@@ -509,16 +533,20 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
         const int32_t u12 = ((z10 * -669) >> 8) + z5;
         t6 = u12 - t7; t5 = u11 - t6; t4 = u10 + t5;
     }
-    // :2786-2793  ucRangeTable[(v >> 5) & 0x3ff] for the eight outputs, two per instruction:
-    // 10-bit sign-extended field (the table's wrap), +128, saturate to a byte
-    const int32_t o0 = t0 + t7, o1 = t1 + t6, o2 = t2 + t5, o3 = t3 - t4, o4 = t3 + t4, o5 = t2 - t5, o6 = t1 - t6, o7 = t0 - t7;
-    const uint32_t p01 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o0, 5), jda_sext10_at(o1, 5)), 0x00800080u));
-    const uint32_t p23 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o2, 5), jda_sext10_at(o3, 5)), 0x00800080u));
-    const uint32_t p45 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o4, 5), jda_sext10_at(o5, 5)), 0x00800080u));
-    const uint32_t p67 = jda_sat_pk_u8(jda_pk_add16(jda_pack16(jda_sext10_at(o6, 5), jda_sext10_at(o7, 5)), 0x00800080u));
+    // :2745-2793  the eight outputs t_a +- t_b and ucRangeTable[(v >> 5) & 0x3ff], two per instruction.
+    // Only bits 14:5 of an output reach the table index, so the final adds can be done modulo 2^16 on
+    // packed pairs: (o0,o1) = (t0,t1) + (t7,t6), (o7,o6) = (t0,t1) - (t7,t6), (o2,o3) = (t2,t3) + (t5,-t4),
+    // (o5,o4) = (t2,t3) - (t5,-t4).  Then the 10-bit sign-extended field (the table's wrap: << 1, >> 6
+    // arithmetic on 16-bit lanes), + 128, saturate to a byte.
+    const uint32_t p01 = jda_pack16(t0, t1), p23 = jda_pack16(t2, t3);
+    const uint32_t q76 = jda_pack16(t7, t6), q54 = jda_pack16(t5, -t4);
+    const uint32_t s01 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_add16(p01, q76)), 0x00800080u));
+    const uint32_t s76 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_sub16(p01, q76)), 0x00800080u));
+    const uint32_t s23 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_add16(p23, q54)), 0x00800080u));
+    const uint32_t s54 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_sub16(p23, q54)), 0x00800080u));
     jda_row8 r;
-    r.lo = p01 | (p23 << 16);
-    r.hi = p45 | (p67 << 16);
+    r.lo = jda_perm(s23, s01, 0x05040100u);          // bytes o0 o1 o2 o3
+    r.hi = jda_perm(s76, s54, 0x04050001u);          // bytes o4 o5 o6 o7  (s54 = [o5,o4], s76 = [o7,o6])
     return r;
 }
 
@@ -1029,6 +1057,16 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, const uint8_t *tab, u
 // i * d < 2^22 (here i < 16 * d and d <= 384, so i * d < 2.4M) and i * ceil(2^22 / d) < 2^32
 JDA_HD uint32_t jda_recip22(uint32_t d) { return ((1u << 22) + d - 1u) / d; }
 
+// low 32 bits of the product of two values below 2^24 (v_mul_u32_u24, full rate)
+JDA_HD uint32_t jda_umul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xffffffu) * (b & 0xffffffu);
+#endif
+}
+
 // ---- P4: colour conversion + coalesced stores ------------------------------------------------------
 // four converted pixels -> memory in the requested format.  CLIP: the group may cross the right edge.
 // nvalid: how many of the four belong to this tile (a tile's width need not be a multiple of 4, and
@@ -1151,16 +1189,23 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
     const uint32_t groups = tile_w >> 2;                          // 4-pixel groups per row (tile_w is a multiple of 16)
     const uint32_t inv = jda_recip22(groups);
     uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
+    const uint32_t pitch = D.out_pitch;
+    // byte offset of the tile's first pixel: 32-bit arithmetic from here on (surfaces are < 4 GiB, checked
+    // by jda_batch_create), so an address is the uniform base + one 32-bit lane offset
+    const uint32_t bpp = PT == JDA_RGB8888 ? 4u : 2u;
+    const uint32_t tile_off = y_base * pitch + x_base * bpp;
     for (uint32_t i = t; i < groups * 8; i += JDA_TILE_THREADS) {
-        const uint32_t rp = (i * inv) >> 22, x4 = (i - rp * groups) * 4;
+        const uint32_t rp = jda_umul24(i, inv) >> 22, g = i - jda_umul24(rp, groups);   // row pair, 4-pixel group in the row
+        const uint32_t x4 = g * 4;
         const uint32_t Y0 = y_base + 2 * rp, X = x_base + x4;
         if (CLIP && (Y0 >= D.out_rows || X >= D.out_w)) continue;
-        const uint32_t m = x4 >> 4, bx = x4 & 15u;
-        const uint8_t *P = plane_base + m * plane_stride;
-        const uint8_t *py = P + JDA_COEF_STRIDE * ((rp >> 2) * 2 + (bx >> 3)) + ((2 * rp) & 7u) * 8 + (bx & 7u);
-        const uint32_t ya = *(const jda_u32_alias *)py, yb = *(const jda_u32_alias *)(py + 8);
-        const uint32_t ci = rp * 8 + (bx >> 1);
-        const uint32_t cb2 = *(const uint16_t *)(P + 4 * JDA_COEF_STRIDE + ci), cr2 = *(const uint16_t *)(P + 5 * JDA_COEF_STRIDE + ci);
+        // LDS byte offsets within the tile's planes: MCU g>>2; luma block (rp>>2)*2 + ((g>>1)&1), row 2rp&7,
+        // column (g&1)*4; chroma row rp, column (g&3)*2
+        const uint32_t po = jda_umul24(g >> 2, plane_stride);
+        const uint32_t yo = po + (rp >> 2) * (2 * JDA_COEF_STRIDE) + (rp & 3u) * 16 + ((g >> 1) & 1u) * JDA_COEF_STRIDE + (g & 1u) * 4;
+        const uint32_t co = po + 4 * JDA_COEF_STRIDE + rp * 8 + (g & 3u) * 2;
+        const uint32_t ya = *(const jda_u32_alias *)(plane_base + yo), yb = *(const jda_u32_alias *)(plane_base + yo + 8);
+        const uint32_t cb2 = *(const uint16_t *)(plane_base + co), cr2 = *(const uint16_t *)(plane_base + co + JDA_COEF_STRIDE);
         uint32_t v0[4], v1[4];
         if (PT == JDA_RGB8888) {
             const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
@@ -1177,9 +1222,24 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
             v1[0] = jda_rgb_pixel<PT>(yb & 255u, c0);          v1[1] = jda_rgb_pixel<PT>((yb >> 8) & 255u, c0);
             v1[2] = jda_rgb_pixel<PT>((yb >> 16) & 255u, c1);  v1[3] = jda_rgb_pixel<PT>(yb >> 24, c1);
         }
-        uint8_t JDA_GLOBAL *row0 = out + (size_t)Y0 * D.out_pitch;
-        jda_store4<PT, CLIP>(row0, X, D.out_w, v0);
-        if (!CLIP || Y0 + 1 < D.out_rows) jda_store4<PT, CLIP>(row0 + D.out_pitch, X, D.out_w, v1);
+        if (!CLIP) {                                              // whole groups, 16 / 8 bytes per row
+            const uint32_t off = tile_off + jda_umul24(rp, 2 * pitch) + x4 * bpp, off1 = off + pitch;
+            if (PT == JDA_RGB8888) {
+                jda_chunk16_alias q0, q1;
+                q0.w[0] = v0[0]; q0.w[1] = v0[1]; q0.w[2] = v0[2]; q0.w[3] = v0[3];
+                q1.w[0] = v1[0]; q1.w[1] = v1[1]; q1.w[2] = v1[2]; q1.w[3] = v1[3];
+                *(jda_chunk16_alias JDA_GLOBAL *)(out + off) = q0;
+                *(jda_chunk16_alias JDA_GLOBAL *)(out + off1) = q1;
+            } else {
+                jda_u64_alias JDA_GLOBAL *d0 = (jda_u64_alias JDA_GLOBAL *)(out + off), *d1 = (jda_u64_alias JDA_GLOBAL *)(out + off1);
+                *d0 = (uint64_t)(v0[0] | (v0[1] << 16)) | ((uint64_t)(v0[2] | (v0[3] << 16)) << 32);
+                *d1 = (uint64_t)(v1[0] | (v1[1] << 16)) | ((uint64_t)(v1[2] | (v1[3] << 16)) << 32);
+            }
+        } else {
+            uint8_t JDA_GLOBAL *row0 = out + (size_t)Y0 * pitch;
+            jda_store4<PT, CLIP>(row0, X, D.out_w, v0);
+            if (Y0 + 1 < D.out_rows) jda_store4<PT, CLIP>(row0 + pitch, X, D.out_w, v1);
+        }
     }
 }
 

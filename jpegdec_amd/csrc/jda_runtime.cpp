@@ -234,7 +234,9 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         D.out_pitch = (uint32_t)O.pitch_bytes;
         D.out_w = (uint32_t)(O.width_px < cw ? O.width_px : cw);
         D.out_rows = (uint32_t)(O.rows < ch ? O.rows : ch);
-        if (!O.pixels || ((uintptr_t)O.pixels & 15) || (O.pitch_bytes & 15) || O.pitch_bytes < (int)D.out_w * bpp) {
+        // the kernels address a surface with 32-bit byte offsets: MCU-padded rows x pitch must stay below 4 GiB
+        if (!O.pixels || ((uintptr_t)O.pixels & 15) || (O.pitch_bytes & 15) || O.pitch_bytes < (int)D.out_w * bpp ||
+            (uint64_t)(ch + 16) * (uint64_t)O.pitch_bytes >= (1ull << 32) || O.pitch_bytes >= (1 << 23)) {
             *err = JDA_INVALID_PARAMETER; return NULL;
         }
         jda_append_strips(strips[D.mode * 2 + (D.fast_mul ? 1 : 0)], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode);
