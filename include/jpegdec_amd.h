@@ -88,6 +88,16 @@ typedef struct jda_image jda_image;
  * image will be decoded with (they do not change the index; they are validated here).
  * Returns NULL on failure with *err set.  The JPEG buffer is not referenced after return. */
 jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
+
+/* The same with options.  JDA_PREPARE_DEVICE_PRESCAN: when the stream carries restart markers (DRI,
+ * jpeg.inl:1715-1718, 5337-5348) skip the serial Huffman pre-scan on the host; the per-block index is then
+ * made on the GPU, one lane per restart interval, when the image is uploaded (jda_upload), which falls back
+ * to the host pre-scan by itself if the device walk cannot guarantee bit-exact results.  Without restart
+ * markers the flag has no effect. */
+#define JDA_PREPARE_DEVICE_PRESCAN 1
+jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
+/* 1 while the image's block index has not been made yet (deferred to jda_upload). */
+int jda_image_prescan_pending(const jda_image *img);
 void jda_image_free(jda_image *img);
 
 const jda_image_info *jda_image_get_info(const jda_image *img);
@@ -144,8 +154,13 @@ int jda_memset(jda_ctx *ctx, void *dptr, int value, size_t bytes);
 int jda_copy_to_host(jda_ctx *ctx, void *host, const void *dptr, size_t bytes);   /* synchronous */
 int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes); /* synchronous */
 
-/* H2D: tables + index + filtered scan of one prepared image into one HBM allocation. */
-jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err);
+/* H2D: tables + index + filtered scan of one prepared image into one HBM allocation.  For an image prepared
+ * with JDA_PREPARE_DEVICE_PRESCAN whose index is still pending, the index is made here on the GPU (one lane
+ * per restart interval); if that walk meets a symbol whose magnitude bits could straddle the reference's
+ * 64-bit window (code length + size >= 18), a marker that is not where the MCU count puts it, or a corrupt
+ * interval, the serial host pre-scan is run instead (the image object is completed in place). */
+jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err);
+int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: the restart-marker fast path produced the index */
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg);
 size_t jda_dev_image_bytes(const jda_dev_image *dimg);
 

@@ -8,6 +8,7 @@ every decode call fails loudly when the HIP library or a GPU is missing.
 from .binding import (  # noqa: F401
     GRAY8,
     LUMA_ONLY,
+    PREPARE_DEVICE_PRESCAN,
     RGB565_BE,
     RGB565_LE,
     RGB8888,

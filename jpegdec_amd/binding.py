@@ -50,6 +50,9 @@ _P = C.c_void_p
 _PROTOTYPES = [
     ("jda_parse", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(ImageInfo)]),
     ("jda_prepare", _P, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_prepare_ex", _P, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_image_prescan_pending", C.c_int, [_P]),
+    ("jda_dev_image_prescan_on_device", C.c_int, [_P]),
     ("jda_image_free", None, [_P]),
     ("jda_image_get_info", C.POINTER(ImageInfo), [_P]),
     ("jda_image_scan", _P, [_P, C.POINTER(C.c_uint32)]),
@@ -143,13 +146,19 @@ def draw_plan_ex(info: ImageInfo, pixel_type=RGB8888, options=0, max_mcus=0, use
     return rects[: max(n, 0)].copy()
 
 
-class PreparedImage:
-    """Host-side result of parse + LUT build + scan filter + serial pre-scan (jda_prepare)."""
+PREPARE_DEVICE_PRESCAN = 1
 
-    def __init__(self, jpeg: bytes):
+
+class PreparedImage:
+    """Host-side result of parse + LUT build + scan filter + serial pre-scan (jda_prepare).
+
+    device_prescan=True (jda_prepare_ex, JDA_PREPARE_DEVICE_PRESCAN): for a stream with restart markers the
+    serial pre-scan is left to the GPU (done by DeviceImage / jda_upload); `prescan_pending` tells."""
+
+    def __init__(self, jpeg: bytes, device_prescan: bool = False):
         self.lib = load_library()
         err = C.c_int32(0)
-        self.handle = self.lib.jda_prepare(jpeg, len(jpeg), C.byref(err))
+        self.handle = self.lib.jda_prepare_ex(jpeg, len(jpeg), PREPARE_DEVICE_PRESCAN if device_prescan else 0, C.byref(err))
         if not self.handle:
             raise JdaError(err.value, "jda_prepare")
         self.info = self.lib.jda_image_get_info(self.handle).contents
@@ -168,6 +177,10 @@ class PreparedImage:
     @property
     def n_mcus(self):
         return self.info.mcus_x * self.info.mcus_y
+
+    @property
+    def prescan_pending(self) -> bool:
+        return bool(self.lib.jda_image_prescan_pending(self.handle))
 
     def scan(self) -> np.ndarray:
         n = C.c_uint32(0)
@@ -262,6 +275,7 @@ class DeviceImage:
             raise JdaError(err.value, "jda_upload")
         self.info = ImageInfo.from_buffer_copy(prepared.info)
         self.nbytes = ctx.lib.jda_dev_image_bytes(self.handle)
+        self.prescan_on_device = bool(ctx.lib.jda_dev_image_prescan_on_device(self.handle))
 
     def close(self):
         if self.handle:

@@ -386,6 +386,148 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
     return flags;
 }
 
+// ---- walk of one restart interval in skip mode (the GPU side of the pre-scan) -------
+// One lane per restart interval: the interval starts on a byte boundary (right after an RSTn marker the
+// host's filter removed) with zero DC predictors (jpeg.inl:5337-5348), so its symbols can be walked
+// without the intervals before it.  The lane follows JPEGDecodeMCU with iMCU < 0 (:2115-2116: decode
+// symbols, store nothing) and records for every block the reader phase and DC predictor on entry -- the
+// per-block index the host pre-scan makes, entry for entry.
+// What an interval cannot know locally is the reference's window phase: at a restart the reference only
+// rounds ulBitOff up to a byte (no refill), so (pBuf, ulBitOff) at the interval's first bit is
+// (start - j, 8j) with j decided by the previous interval, and the phase decides which magnitude reads get
+// truncated.  Two passes settle it exactly:
+//   MAP   walk with all six possible phases in flight (8j for j = 0..5; 48/56/64 refill at once and join 0): only
+//         symbol lengths matter, the six bit offsets live in the bytes of one 64-bit word.  Result: for
+//         each start phase the phase the NEXT interval starts with.
+//   (host: compose the maps from interval 0, whose phase is 0 -- n_intervals table lookups)
+//   EXACT walk from the now known phase: identical to the serial host pre-scan.
+struct jda_prescan_params {
+    const uint8_t *scan;             // filtered scan (global), padded
+    const uint8_t *tables;           // table blob (global)
+    const uint32_t *restart_pos;     // n_intervals entries
+    const uint8_t *start_phase;      // EXACT: n_intervals entries (bit offset 8j the interval starts with)
+    uint32_t *phase_map;             // MAP out: n_intervals words, 4 bits per start phase j = 0..5: (bit offset the next interval starts with) / 8
+    uint32_t *blk_index;             // EXACT out: n_blocks + 1
+    int16_t *blk_dc;                 // EXACT out: n_blocks
+    uint32_t *stats;                 // EXACT out: [0] first bad MCU (min), [1] marker mismatch, [2] max AC category, [3] max |DC|, [4] truncated reads
+    uint32_t scan_len, n_intervals, n_mcus, interval_mcus;
+    uint8_t nluma, nblocks, dc_id[3], ac_id[3];
+};
+struct jda_prescan_result { uint32_t first_bad, mismatch, max_ac_bits, max_abs_dc, trunc_events, phase_map; };
+
+// six bit offsets, one per byte: refill (jpeg.inl:2110-2114) and advance
+JDA_HD uint64_t jda_ph_refill(uint64_t x)
+{
+    const uint64_t K = 0x010101010101ull;
+    const uint64_t ge48 = ((x + (0x80u - 48u) * K) & (0x80u * K)) >> 7;   // offsets stay below 128: no carry between bytes
+    const uint64_t m = ge48 * 0xffu;
+    return (x & ~m) | (x & m & (0x07u * K));
+}
+
+template <bool EXACT>
+JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k)
+{
+    jda_prescan_result R;
+    R.first_bad = 0xffffffffu; R.mismatch = 0; R.max_ac_bits = 0; R.max_abs_dc = 0; R.trunc_events = 0; R.phase_map = 0;
+    const uint8_t JDA_GLOBAL *tables = JDA_G(const uint8_t, P.tables);
+    const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
+    uint32_t JDA_GLOBAL *blk_index = JDA_G(uint32_t, P.blk_index);
+    int16_t JDA_GLOBAL *blk_dc = JDA_G(int16_t, P.blk_dc);
+    const uint32_t start_off = EXACT ? (uint32_t)JDA_G(const uint8_t, P.start_phase)[k] : 0u;
+    jda_bitreader br;
+    br.base = JDA_G(const uint8_t, P.scan);
+    br.win = nullptr; br.win_lo = 0; br.win_len = 0;            // no LDS window: every load goes to memory
+    br.pos = rpos[k] - (start_off >> 3);
+    br.off = start_off;
+    br.bits = jda_load_be64(br, br.pos);
+    const uint64_t K = 0x010101010101ull;
+    uint64_t ph = 0x282018100800ull;                             // MAP: the offsets 0, 8, .., 40
+    const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 8;
+    const uint32_t first_mcu = k * P.interval_mcus;
+    const uint32_t count = P.n_mcus - first_mcu < P.interval_mcus ? P.n_mcus - first_mcu : P.interval_mcus;
+    int32_t pred[3] = { 0, 0, 0 };
+    bool bad = false;
+    uint32_t m = 0;
+#define JDA_PS_REFILL() do { jda_refill(br); if (!EXACT) ph = jda_ph_refill(ph); if (br.pos > limit_pos) bad = true; } while (0)
+#define JDA_PS_ADVANCE(n) do { br.off += (n); if (!EXACT) ph += (uint64_t)(n) * K; } while (0)
+    for (; m < count && !bad; m++) {
+        for (uint32_t b = 0; b < P.nblocks && !bad; b++) {
+            const uint32_t c = b < P.nluma ? 0u : b - P.nluma + 1u;
+            int32_t &pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
+            if (pr < -32768 || pr > 32767) { bad = true; break; }
+            if (EXACT) {
+                const size_t gb = (size_t)(first_mcu + m) * P.nblocks + b;
+                blk_index[gb] = (br.pos << JDA_INDEX_OFF_BITS) | br.off;
+                blk_dc[gb] = (int16_t)pr;
+            }
+            const uint32_t dci = c == 0 ? P.dc_id[0] : (c == 1 ? P.dc_id[1] : P.dc_id[2]);
+            const uint32_t aci = c == 0 ? P.ac_id[0] : (c == 1 ? P.ac_id[1] : P.ac_id[2]);
+            const uint8_t JDA_GLOBAL *dcl = tables + JDA_TB_DC + dci * 1024;
+            const uint16_t JDA_GLOBAL *acl = (const uint16_t JDA_GLOBAL *)(tables + JDA_TB_AC) + aci * 2048;
+            JDA_PS_REFILL();
+            if (bad) break;
+            uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
+            code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
+            uint32_t e = dcl[code];
+            if (e == 0) { bad = true; break; }                   // :2137-2138
+            JDA_PS_ADVANCE(e >> 4);
+            const uint32_t s = e & 0xfu;
+            if (s) {
+                const int32_t folded = (int8_t)dcl[code + 512];
+                if (folded) pr += folded;
+                else {
+                    JDA_PS_REFILL();
+                    if (bad) break;
+                    pr += jda_take_extend(br.bits, br.off, s);
+                    JDA_PS_ADVANCE(s);
+                }
+            }
+            { const uint32_t a = (uint32_t)(pr < 0 ? -pr : pr); if (a > R.max_abs_dc) R.max_abs_dc = a; }
+            int kk = 1;
+            while (kk < 64) {
+                JDA_PS_REFILL();
+                if (bad) break;
+                code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
+                code = code >= 0xfc00u ? ((code & 0x3ffu) + 1024u) : (code >> 6);
+                e = acl[code];
+                if (e == 0) { bad = true; break; }               // :2237-2238
+                JDA_PS_ADVANCE(e >> 8);
+                e &= 0xffu;
+                if (e == 0) break;                               // EOB (no refill follows)
+                kk += (int)(e >> 4);
+                const uint32_t ms = e & 0xfu;
+                if (ms && kk < 64 && br.off + ms > 64) R.trunc_events++;
+                if (ms > R.max_ac_bits && kk < 64) R.max_ac_bits = ms;
+                JDA_PS_ADVANCE(ms);
+                kk++;
+                JDA_PS_REFILL();                                 // :2259-2264 (bottom of the loop; matters before a restart)
+            }
+        }
+        if (bad) break;
+    }
+#undef JDA_PS_REFILL
+#undef JDA_PS_ADVANCE
+    if (bad) { R.first_bad = first_mcu + m; return R; }
+    if (!EXACT) {
+        // :5339-5346: round each offset up to a byte: 0, 8, .., 64 (48 and up behave like 0 from the next block's
+        // first refill on, but the recorded phase keeps the reference's own value)
+        uint32_t map = 0;
+        for (int j = 0; j < 6; j++) {
+            uint32_t o = (uint32_t)(ph >> (8 * j)) & 0xffu;
+            o = (o + 7u) & ~7u;
+            map |= (o >> 3) << (4 * j);
+        }
+        R.phase_map = map;
+        return R;
+    }
+    // the interval must end (rounded up to a byte) where the next one starts: the reference counts MCUs and
+    // never looks at marker positions, so a stream whose markers sit elsewhere must take the serial path
+    const uint32_t end_byte = br.pos + ((br.off + 7u) >> 3);
+    if (k + 1 < P.n_intervals) { if (end_byte != rpos[k + 1]) R.mismatch = 1; }
+    else blk_index[(size_t)P.n_mcus * P.nblocks] = (br.pos << JDA_INDEX_OFF_BITS) | br.off;
+    return R;
+}
+
 // ---- the same, for a tile whose whole scan slice is in the LDS window (the normal case) ----------
 // No lane can leave the window, so the reader needs no bounds check and no HBM path, and the block
 // decode below is written without divergent branches: P1 is bound by the latency of its dependent

@@ -308,6 +308,37 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device half of the pre-scan for streams with restart markers: one lane per restart
+// interval walks its Huffman symbols in skip mode -- first to find how the reference's window phase
+// propagates across the interval (MAP), then, with every interval's phase known, to write the per-block
+// index exactly as the serial host pre-scan would (EXACT).  Latency-bound scalar work (a lane owns a whole
+// interval), so it pays when many intervals / images are in flight; it replaces ~15 ms of serial host work
+// per 4096x4096 image.
+template <bool EXACT>
+__global__ __launch_bounds__(64)
+void jda_prescan_intervals(jda_prescan_params P)
+{
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= P.n_intervals) return;
+    const jda_prescan_result R = jda_prescan_interval<EXACT>(P, k);
+    if (!EXACT) { P.phase_map[k] = R.phase_map; return; }
+    uint32_t *st = P.stats;
+    if (R.first_bad != 0xffffffffu) atomicMin(&st[0], R.first_bad);
+    if (R.mismatch) atomicOr(&st[1], 1u);
+    atomicMax(&st[2], R.max_ac_bits);
+    atomicMax(&st[3], R.max_abs_dc);
+    if (R.trunc_events) atomicAdd(&st[4], R.trunc_events);
+}
+
+extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *P, int exact, hipStream_t stream)
+{
+    const dim3 grid((P->n_intervals + 63u) / 64u), block(64);
+    if (exact) hipLaunchKernelGGL(jda_prescan_intervals<true>, grid, block, 0, stream, *P);
+    else hipLaunchKernelGGL(jda_prescan_intervals<false>, grid, block, 0, stream, *P);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_trace), &dev_buf, sizeof(dev_buf));

@@ -17,6 +17,11 @@
 #include "jda_plan.h"
 
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
+extern "C" const uint32_t *jda_image_restart_positions(const jda_image *img, uint32_t *n);
+extern "C" void jda_image_run_host_prescan(jda_image *img);
+extern "C" int jda_image_index_on_device(const jda_image *img);
+extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
+extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *P, int exact, hipStream_t stream);
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
 
@@ -35,6 +40,7 @@ struct jda_dev_image {
     uint32_t scan_len, n_mcus_ok;
     uint8_t dc_id[3], ac_id[3], q_id[3];
     uint8_t fast_mul;
+    uint8_t prescan_on_device;   // the block index was made by jda_prescan_intervals (restart-marker fast path)
 };
 
 struct jda_batch {
@@ -138,47 +144,100 @@ int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes)
     return JDA_SUCCESS;
 }
 
-jda_dev_image *jda_upload(jda_ctx *ctx, const jda_image *img, int32_t *err)
+jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err)
 {
     int32_t dummy;
     if (!err) err = &dummy;
     if (!ctx || !img) { *err = ctx ? JDA_INVALID_PARAMETER : JDA_ERROR_NO_DEVICE; return NULL; }
     const jda_image_info &I = *jda_image_get_info(img);
-    uint32_t scan_len = 0, nok = 0, tbytes = 0;
+    uint32_t scan_len = 0, nok = 0, tbytes = 0, n_int = 0;
     const uint8_t *scan = jda_image_scan(img, &scan_len);
-    const uint32_t *index = jda_image_block_index(img, &nok);
-    const int16_t *dc = jda_image_block_dc(img);
     const uint8_t *tables = jda_image_tables(img, &tbytes);
     const size_t n_blocks = (size_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu;
+    const bool on_device = jda_image_index_on_device(img) != 0;      // index to be made by jda_prescan_intervals
+    const uint32_t *rpos = jda_image_restart_positions(img, &n_int);
 
     jda_dev_image *d = new (std::nothrow) jda_dev_image;
     if (!d) { *err = JDA_ERROR_MEMORY; return NULL; }
     memset(d, 0, sizeof(*d));
     d->info = I;
     d->scan_len = scan_len;
-    d->n_mcus_ok = nok;
     jda_image_component_ids(img, d->dc_id, d->ac_id, d->q_id);
-    d->fast_mul = (uint8_t)jda_image_fast_mul(img);
     d->off_tables = 0;
     d->off_index = align16(tbytes);
     d->off_dc = d->off_index + align16((n_blocks + 1) * sizeof(uint32_t));
     d->off_scan = d->off_dc + align16(n_blocks * sizeof(int16_t));
     d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
+    // the device pre-scan's extras ride along behind the image: restart positions, phase map, start phases, results
+    const size_t off_rpos = d->bytes, off_map = off_rpos + align16((size_t)n_int * 4);
+    const size_t off_phase = off_map + align16((size_t)n_int * 4), off_stats = off_phase + align16((size_t)n_int);
+    const size_t alloc = on_device ? off_stats + 32 : d->bytes;
     (void)hipSetDevice(ctx->device);
-    hipError_t e = hipMalloc((void **)&d->base, d->bytes);
+    hipError_t e = hipMalloc((void **)&d->base, alloc);
     if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); delete d; *err = JDA_ERROR_MEMORY; return NULL; }
-    // stage through one pinned-size host buffer so it is a single H2D copy
-    std::vector<uint8_t> stage(d->bytes, 0);
+    // stage through one host buffer so it is a single H2D copy
+    std::vector<uint8_t> stage(alloc, 0);
     memcpy(stage.data() + d->off_tables, tables, tbytes);
-    memcpy(stage.data() + d->off_index, index, (n_blocks + 1) * sizeof(uint32_t));
-    memcpy(stage.data() + d->off_dc, dc, n_blocks * sizeof(int16_t));
     memcpy(stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
-    e = hipMemcpyAsync(d->base, stage.data(), d->bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { set_err(ctx, e, "hipMemcpy(image)"); (void)hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
+    if (on_device) {
+        memcpy(stage.data() + off_rpos, rpos, (size_t)n_int * 4);
+        const uint32_t init[5] = { 0xffffffffu, 0, 0, 0, 0 };
+        memcpy(stage.data() + off_stats, init, sizeof(init));
+    }
+    bool device_index = false;
+    if (on_device) {
+        jda_prescan_params P;
+        memset(&P, 0, sizeof(P));
+        P.scan = d->base + d->off_scan; P.tables = d->base + d->off_tables;
+        P.restart_pos = (const uint32_t *)(d->base + off_rpos);
+        P.phase_map = (uint32_t *)(d->base + off_map); P.start_phase = d->base + off_phase;
+        P.blk_index = (uint32_t *)(d->base + d->off_index); P.blk_dc = (int16_t *)(d->base + d->off_dc);
+        P.stats = (uint32_t *)(d->base + off_stats);
+        P.scan_len = scan_len; P.n_intervals = n_int; P.n_mcus = (uint32_t)(I.mcus_x * I.mcus_y);
+        P.interval_mcus = (uint32_t)I.restart_interval;
+        P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu == 6 ? 4 : 1);
+        for (int c = 0; c < 3; c++) { P.dc_id[c] = d->dc_id[c]; P.ac_id[c] = d->ac_id[c]; }
+        std::vector<uint32_t> map(n_int);
+        std::vector<uint8_t> phase(n_int);
+        uint32_t st[5] = { 0, 0, 0, 0, 0 };
+        e = hipMemcpyAsync(d->base, stage.data(), alloc, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = jda_launch_prescan(&P, 0, ctx->stream);                               // MAP
+        if (e == hipSuccess) e = hipMemcpyAsync(map.data(), d->base + off_map, (size_t)n_int * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) {
+            uint32_t j = 0;                                   // the scan starts with pBuf at its first byte, ulBitOff 0 (:4996-4998)
+            for (uint32_t k = 0; k < n_int; k++) { phase[k] = (uint8_t)(8u * j); j = (map[k] >> (4u * (j > 5u ? 0u : j))) & 15u; }
+            e = hipMemcpyAsync(d->base + off_phase, phase.data(), n_int, hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (e == hipSuccess) e = jda_launch_prescan(&P, 1, ctx->stream);                               // EXACT
+        if (e == hipSuccess) e = hipMemcpyAsync(st, d->base + off_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { set_err(ctx, e, "device pre-scan"); (void)hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
+        // a marker that is not where the MCU count puts it, or a corrupt interval: the serial host pre-scan
+        // reproduces what the reference does with such a stream
+        if (st[0] == 0xffffffffu && st[1] == 0) {
+            jda_image_adopt_prescan(img, (uint32_t)(I.mcus_x * I.mcus_y), st[2], (int32_t)st[3], st[4]);
+            d->prescan_on_device = 1;
+            device_index = true;
+        } else jda_image_run_host_prescan(img);
+    }
+    if (!device_index) {
+        const uint32_t *index = jda_image_block_index(img, &nok);
+        memcpy(stage.data() + d->off_index, index, (n_blocks + 1) * sizeof(uint32_t));
+        memcpy(stage.data() + d->off_dc, jda_image_block_dc(img), n_blocks * sizeof(int16_t));
+        e = hipMemcpyAsync(d->base, stage.data(), d->bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { set_err(ctx, e, "hipMemcpy(image)"); (void)hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
+    }
+    uint32_t nok2 = 0;
+    (void)jda_image_block_index(img, &nok2);
+    d->n_mcus_ok = nok2;
+    d->fast_mul = (uint8_t)jda_image_fast_mul(img);
     *err = JDA_SUCCESS;
     return d;
 }
+
+int jda_dev_image_prescan_on_device(const jda_dev_image *dimg) { return dimg ? dimg->prescan_on_device : 0; }
 
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg)
 {
@@ -335,18 +394,18 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     int32_t err = JDA_SUCCESS;
-    jda_image *img = jda_prepare(jpeg, len, &err);
+    jda_image *img = jda_prepare_ex(jpeg, len, JDA_PREPARE_DEVICE_PRESCAN, &err);   // restart markers: index made on the GPU
     if (!img) return err;
     const jda_image_info &I = *jda_image_get_info(img);
     int bpp, ow, oh, cw, ch;
     int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
     if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
-    uint32_t nok = 0;
-    jda_image_block_index(img, &nok);
-    const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
     const int dpitch = (int)align16((size_t)cw * bpp);
     const int drows = rows < ch ? rows : ch;
     jda_dev_image *dimg = jda_upload(ctx, img, &err);
+    uint32_t nok = 0;
+    jda_image_block_index(img, &nok);                   // (after the upload: a deferred pre-scan has run by now)
+    const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
     jda_image_free(img);
     if (!dimg) return err;
     void *dout = jda_malloc(ctx, (size_t)dpitch * ch);

@@ -19,6 +19,8 @@ SYNTH_CASES = {
     "gray_1100x24": dict(width=1100, height=24, subsampling="gray", seed=19),        # 138 MCUs per row: one partial tile
     "gray_1600x16": dict(width=1600, height=16, subsampling="gray", seed=23),        # a full 192-MCU gray tile + remainder
     "c444_600x16": dict(width=600, height=16, subsampling="4:4:4", seed=24),         # a full 64-MCU 4:4:4 tile + remainder
+    "c444_384x192_q100_rst7": dict(width=384, height=192, subsampling="4:4:4", seed=36, quality=100, restart_blocks=7),  # truncated reads + restarts
+    "c420_512x256_q98_rstrow": dict(width=512, height=256, subsampling="4:2:0", seed=31, quality=98, restart_rows=1),
     "c420_16x16": dict(width=16, height=16, subsampling="4:2:0", seed=20),           # single MCU
     "c444_8x8_q30": dict(width=8, height=8, subsampling="4:4:4", seed=21, quality=30),
     "c420_1280x720": dict(width=1280, height=720, subsampling="4:2:0", seed=1234),   # BASELINE config 2 shape

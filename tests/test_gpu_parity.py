@@ -89,3 +89,31 @@ def test_clip_to_image_size(gpu_ctx, oracle):
     assert np.array_equal(got[: g["out_h"], : g["out_w"] * 4], want[: g["out_h"], : g["out_w"] * 4])
     assert (got[g["out_h"]:, :] == 0x5A).all() and (got[:, g["out_w"] * 4:] == 0x5A).all()
     b.close(); d.close(); gpu_ctx.free(ptr)
+
+
+@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow"])
+def test_restart_marker_fast_path(name, gpu_ctx, oracle):
+    """JDA_PREPARE_DEVICE_PRESCAN leaves the Huffman pre-scan of a stream with restart markers to
+    the GPU (jda_upload: phase-map pass + exact pass, one lane per restart interval).  Same pixels as the
+    oracle, and the path really was taken."""
+    import jpegdec_amd as J
+    jpeg = jpeg_for(name)
+    prep = J.PreparedImage(jpeg, device_prescan=True)
+    assert prep.prescan_pending
+    dimg = J.DeviceImage(gpu_ctx, prep)
+    assert dimg.prescan_on_device and not prep.prescan_pending
+    for pt, opt in ((J.RGB8888, 0), (J.RGB565_LE, 0), (J.GRAY8, J.SCALE_HALF)):
+        if name.startswith("gray") and pt == J.RGB8888:
+            continue
+        rc, want, _ = oracle.decode_canvas(jpeg, pt, opt)
+        g = prep.geometry(pt, opt)
+        pitch = (want.shape[1] + 15) // 16 * 16
+        out = gpu_ctx.malloc(pitch * want.shape[0])
+        b = J.Batch(gpu_ctx, [dimg], [(out, pitch, g["canvas_w"], g["canvas_h"])], [pt], [opt])
+        b.decode(); gpu_ctx.sync()
+        got = gpu_ctx.to_host(out, pitch * want.shape[0]).reshape(want.shape[0], pitch)[:, : want.shape[1]]
+        assert np.array_equal(got, want), (name, pt, opt)
+        gpu_ctx.free(out)
+    # a stream without markers: the flag changes nothing
+    plain = J.PreparedImage(jpeg_for("c420_333x217"), device_prescan=True)
+    assert not plain.prescan_pending

@@ -49,3 +49,30 @@ def test_wave_emulation_equals_oracle(name, hostsim, oracle):
         hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
         assert hrc == 0
         assert np.array_equal(got, want), (name, pt, opt, int(np.count_nonzero(got != want)))
+
+
+@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow"])
+def test_restart_interval_prescan_equals_oracle(name, hostsim, oracle):
+    """with restart markers the per-block index is made by the device-side interval walk
+    (jda_prescan_interval, one lane per restart interval) instead of the serial host pre-scan (two passes: window-phase map, then the exact walk).  The
+    index must equal the serial one entry for entry and the decode must be the oracle's, byte for byte."""
+    jpeg = jpeg_for(name)
+    hostsim.hostsim_set_device_prescan(1)
+    try:
+        for pt, opt in all_modes(name):
+            rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+            hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert hrc == 0 and hostsim.hostsim_prescan_used() == 1
+            assert hostsim.hostsim_index_equal() == 1          # phase, DC predictor and truncation count of every block
+            assert np.array_equal(got, want), (name, pt, opt)
+        # a stream without restart markers silently takes the serial pre-scan
+        plain = jpeg_for("c420_333x217")
+        rc, want, err = oracle.decode_canvas(plain, 2, 0)
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(plain, 2, 0)
+        assert hostsim.hostsim_decode(plain, len(plain), 2, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert hostsim.hostsim_prescan_used() == 0 and np.array_equal(got, want)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
