@@ -29,18 +29,19 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cached_jpeg(width, height, subsampling, seed, quality=85):
+def cached_jpeg(width, height, subsampling, seed, quality=85, restart_rows=0):
     """Synthetic input (jpegdec_amd/synth.py recipe), cached under bench_cache/ so the GPU box does
     not spend its minutes on Pillow."""
     from jpegdec_amd.synth import synth_jpeg
 
     d = os.path.join(ROOT, "bench_cache")
     os.makedirs(d, exist_ok=True)
-    name = "synth_%dx%d_%s_q%d_s%d.jpg" % (width, height, subsampling.replace(":", ""), quality, seed)
+    name = "synth_%dx%d_%s_q%d_s%d%s.jpg" % (width, height, subsampling.replace(":", ""), quality, seed,
+                                             "_rst%d" % restart_rows if restart_rows else "")
     path = os.path.join(d, name)
     if os.path.exists(path):
         return open(path, "rb").read()
-    data = synth_jpeg(width, height, subsampling, seed=seed, quality=quality)
+    data = synth_jpeg(width, height, subsampling, seed=seed, quality=quality, restart_rows=restart_rows)
     with open(path + ".tmp%d" % os.getpid(), "wb") as f:
         f.write(data)
     os.replace(path + ".tmp%d" % os.getpid(), path)
@@ -85,6 +86,8 @@ def main():
     ap.add_argument("--subsampling", default="4:2:0", choices=["4:2:0", "4:4:4", "gray"])
     ap.add_argument("--pixel-type", default="rgb8888", choices=["rgb8888", "rgb565", "gray8"])
     ap.add_argument("--options", type=int, default=0)
+    ap.add_argument("--restart-rows", type=int, default=0, help="encode the inputs with a restart marker every N MCU rows (0 = none, the headline config)")
+    ap.add_argument("--device-prescan", action="store_true", help="JDA_PREPARE_DEVICE_PRESCAN: with restart markers the block index is made on the GPU at upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the control collectives (nccl = RCCL)")
@@ -109,21 +112,23 @@ def main():
         pt = J.GRAY8   # JPEGPutMCUGray never writes 32-bit pixels
 
     # ---- inputs: `distinct` synthetic JPEGs, prepared on the host, `batch` resident copies in HBM
-    jpegs = [cached_jpeg(args.width, args.height, args.subsampling, 1234 + i) for i in range(args.distinct)]
+    jpegs = [cached_jpeg(args.width, args.height, args.subsampling, 1234 + i, restart_rows=args.restart_rows) for i in range(args.distinct)]
     bits_px = 8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * args.width * args.height)
     n_dev = max(1, J.load_library().jda_device_count())
     ctx = J.Context(local_rank % n_dev)     # one process per GPU; raises without a GPU: there is no CPU fallback
     t_prep0 = time.perf_counter()
-    prepared = [J.PreparedImage(j) for j in jpegs]
+    prepared = [J.PreparedImage(j, device_prescan=args.device_prescan) for j in jpegs]
     t_prep = (time.perf_counter() - t_prep0) / len(jpegs)
     geo = prepared[0].geometry(pt, args.options)
     pitch = (geo["canvas_w"] * geo["bpp"] + 15) & ~15
     img_bytes = pitch * geo["canvas_h"]
     dev_images, outputs = [], []
     out_base = ctx.malloc(img_bytes * args.batch)
+    t_up0 = time.perf_counter()
+    dev_images = J.upload_batch(ctx, [prepared[i % len(prepared)] for i in range(args.batch)])
     for i in range(args.batch):
-        dev_images.append(J.DeviceImage(ctx, prepared[i % len(prepared)]))
         outputs.append((out_base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]))
+    t_up = (time.perf_counter() - t_up0) / args.batch      # H2D (+ the device pre-scan when it is used), the whole batch at once
     batch = J.Batch(ctx, dev_images, outputs, [pt] * args.batch, [args.options] * args.batch)
     st = batch.stats
 
@@ -228,6 +233,8 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "host_prepare_ms_per_image": t_prep * 1e3,
+            "upload_ms_per_image": t_up * 1e3,
+            "device_prescan": bool(dev_images[0].prescan_on_device),
             "kernel_only_mpix_s": px_per_step / (kernel_ms * 1e-3) / 1e6,
         }
         print(json.dumps(line))

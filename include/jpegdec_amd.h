@@ -160,6 +160,10 @@ int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes)
  * 64-bit window (code length + size >= 18), a marker that is not where the MCU count puts it, or a corrupt
  * interval, the serial host pre-scan is run instead (the image object is completed in place). */
 jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err);
+/* The same for n images at once: all pending block indexes are made in two launches (the per-interval walk is
+ * latency-bound, so throughput comes from the number of restart intervals in flight).  out[i] = device image.
+ * Returns JDA_SUCCESS or the first error (then every out[i] is NULL). */
+int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out);
 int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: the restart-marker fast path produced the index */
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg);
 size_t jda_dev_image_bytes(const jda_dev_image *dimg);

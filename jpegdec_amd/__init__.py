@@ -28,4 +28,5 @@ from .binding import (  # noqa: F401
     load_library,
     output_geometry,
     parse,
+    upload_batch,
 )

@@ -53,6 +53,7 @@ _PROTOTYPES = [
     ("jda_prepare_ex", _P, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_image_prescan_pending", C.c_int, [_P]),
     ("jda_dev_image_prescan_on_device", C.c_int, [_P]),
+    ("jda_upload_batch", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
     ("jda_image_free", None, [_P]),
     ("jda_image_get_info", C.POINTER(ImageInfo), [_P]),
     ("jda_image_scan", _P, [_P, C.POINTER(C.c_uint32)]),
@@ -267,10 +268,10 @@ class Context:
 class DeviceImage:
     """Inputs of one image resident in HBM (jda_upload)."""
 
-    def __init__(self, ctx: Context, prepared: PreparedImage):
+    def __init__(self, ctx: Context, prepared: PreparedImage, _handle=None):
         self.ctx = ctx
         err = C.c_int32(0)
-        self.handle = ctx.lib.jda_upload(ctx.handle, prepared.handle, C.byref(err))
+        self.handle = _handle if _handle else ctx.lib.jda_upload(ctx.handle, prepared.handle, C.byref(err))
         if not self.handle:
             raise JdaError(err.value, "jda_upload")
         self.info = ImageInfo.from_buffer_copy(prepared.info)
@@ -281,6 +282,17 @@ class DeviceImage:
         if self.handle:
             self.ctx.lib.jda_dev_image_free(self.ctx.handle, self.handle)
             self.handle = None
+
+
+def upload_batch(ctx: Context, prepared_list):
+    """jda_upload_batch: all images in one go (pending block indexes are made on the GPU in two launches)."""
+    n = len(prepared_list)
+    himgs = (_P * n)(*[p.handle for p in prepared_list])
+    outs = (_P * n)()
+    rc = ctx.lib.jda_upload_batch(ctx.handle, n, himgs, outs)
+    if rc != 0:
+        raise JdaError(rc, "jda_upload_batch")
+    return [DeviceImage(ctx, prepared_list[i], _handle=outs[i]) for i in range(n)]
 
 
 class Batch:

@@ -317,8 +317,9 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
 // per 4096x4096 image.
 template <bool EXACT>
 __global__ __launch_bounds__(64)
-void jda_prescan_intervals(jda_prescan_params P)
+void jda_prescan_intervals(const jda_prescan_params *__restrict__ params)
 {
+    const jda_prescan_params P = params[blockIdx.y];            // one image per grid row
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= P.n_intervals) return;
     const jda_prescan_result R = jda_prescan_interval<EXACT>(P, k);
@@ -331,11 +332,13 @@ void jda_prescan_intervals(jda_prescan_params P)
     if (R.trunc_events) atomicAdd(&st[4], R.trunc_events);
 }
 
-extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *P, int exact, hipStream_t stream)
+// params: device array of n_images descriptors; max_intervals: the largest n_intervals among them
+extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream)
 {
-    const dim3 grid((P->n_intervals + 63u) / 64u), block(64);
-    if (exact) hipLaunchKernelGGL(jda_prescan_intervals<true>, grid, block, 0, stream, *P);
-    else hipLaunchKernelGGL(jda_prescan_intervals<false>, grid, block, 0, stream, *P);
+    if (n_images == 0 || max_intervals == 0) return hipSuccess;
+    const dim3 grid((max_intervals + 63u) / 64u, n_images), block(64);
+    if (exact) hipLaunchKernelGGL(jda_prescan_intervals<true>, grid, block, 0, stream, params);
+    else hipLaunchKernelGGL(jda_prescan_intervals<false>, grid, block, 0, stream, params);
     return hipGetLastError();
 }
 

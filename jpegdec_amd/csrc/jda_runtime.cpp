@@ -21,7 +21,7 @@ extern "C" const uint32_t *jda_image_restart_positions(const jda_image *img, uin
 extern "C" void jda_image_run_host_prescan(jda_image *img);
 extern "C" int jda_image_index_on_device(const jda_image *img);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
-extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *P, int exact, hipStream_t stream);
+extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
 
@@ -144,96 +144,158 @@ int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes)
     return JDA_SUCCESS;
 }
 
+// Upload n prepared images.  Images whose block index is still pending (JDA_PREPARE_DEVICE_PRESCAN + restart
+// markers) get it made on the GPU, all of them in two launches (phase-map pass, exact pass: one lane per
+// restart interval, one grid row per image) -- the walk is latency-bound per lane, so it is the number of
+// intervals in flight that makes it fast.  out[i] receives the device image (NULL on failure).
+int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (n <= 0 || !imgs || !out) return JDA_INVALID_PARAMETER;
+    (void)hipSetDevice(ctx->device);
+    struct Item {
+        jda_dev_image *d; std::vector<uint8_t> stage; bool on_device; uint32_t n_int;
+        size_t off_rpos, off_map, off_phase, off_stats, alloc, n_blocks; uint32_t tbytes;
+        std::vector<uint32_t> map; std::vector<uint8_t> phase; uint32_t st[5];
+    };
+    std::vector<Item> items((size_t)n);
+    int rc = JDA_SUCCESS;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n; i++) out[i] = NULL;
+    auto fail_all = [&](int code) {
+        for (int i = 0; i < n; i++) { if (items[i].d) { if (items[i].d->base) (void)hipFree(items[i].d->base); delete items[i].d; items[i].d = NULL; } out[i] = NULL; }
+        return code;
+    };
+    std::vector<jda_prescan_params> params;
+    std::vector<int> params_owner;
+    uint32_t max_int = 0;
+    for (int i = 0; i < n && rc == JDA_SUCCESS; i++) {
+        Item &it = items[i];
+        jda_image *img = imgs[i];
+        if (!img) { rc = JDA_INVALID_PARAMETER; break; }
+        const jda_image_info &I = *jda_image_get_info(img);
+        uint32_t scan_len = 0, nok = 0;
+        const uint8_t *scan = jda_image_scan(img, &scan_len);
+        const uint8_t *tables = jda_image_tables(img, &it.tbytes);
+        it.n_blocks = (size_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu;
+        it.on_device = jda_image_index_on_device(img) != 0;      // index to be made by jda_prescan_intervals
+        const uint32_t *rpos = jda_image_restart_positions(img, &it.n_int);
+        jda_dev_image *d = new (std::nothrow) jda_dev_image;
+        if (!d) { rc = JDA_ERROR_MEMORY; break; }
+        memset(d, 0, sizeof(*d));
+        it.d = d;
+        d->info = I;
+        d->scan_len = scan_len;
+        jda_image_component_ids(img, d->dc_id, d->ac_id, d->q_id);
+        d->off_tables = 0;
+        d->off_index = align16(it.tbytes);
+        d->off_dc = d->off_index + align16((it.n_blocks + 1) * sizeof(uint32_t));
+        d->off_scan = d->off_dc + align16(it.n_blocks * sizeof(int16_t));
+        d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
+        // the device pre-scan's extras ride along behind the image: restart positions, phase map, start phases, results
+        it.off_rpos = d->bytes; it.off_map = it.off_rpos + align16((size_t)it.n_int * 4);
+        it.off_phase = it.off_map + align16((size_t)it.n_int * 4); it.off_stats = it.off_phase + align16((size_t)it.n_int);
+        it.alloc = it.on_device ? it.off_stats + 32 : d->bytes;
+        e = hipMalloc((void **)&d->base, it.alloc);
+        if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
+        // stage through one host buffer so it is a single H2D copy
+        it.stage.assign(it.alloc, 0);
+        memcpy(it.stage.data() + d->off_tables, tables, it.tbytes);
+        memcpy(it.stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
+        if (it.on_device) {
+            memcpy(it.stage.data() + it.off_rpos, rpos, (size_t)it.n_int * 4);
+            const uint32_t init[5] = { 0xffffffffu, 0, 0, 0, 0 };
+            memcpy(it.stage.data() + it.off_stats, init, sizeof(init));
+            jda_prescan_params P;
+            memset(&P, 0, sizeof(P));
+            P.scan = d->base + d->off_scan; P.tables = d->base + d->off_tables;
+            P.restart_pos = (const uint32_t *)(d->base + it.off_rpos);
+            P.phase_map = (uint32_t *)(d->base + it.off_map); P.start_phase = d->base + it.off_phase;
+            P.blk_index = (uint32_t *)(d->base + d->off_index); P.blk_dc = (int16_t *)(d->base + d->off_dc);
+            P.stats = (uint32_t *)(d->base + it.off_stats);
+            P.scan_len = scan_len; P.n_intervals = it.n_int; P.n_mcus = (uint32_t)(I.mcus_x * I.mcus_y);
+            P.interval_mcus = (uint32_t)I.restart_interval;
+            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu == 6 ? 4 : 1);
+            for (int c = 0; c < 3; c++) { P.dc_id[c] = d->dc_id[c]; P.ac_id[c] = d->ac_id[c]; }
+            params.push_back(P); params_owner.push_back(i);
+            if (it.n_int > max_int) max_int = it.n_int;
+            it.map.resize(it.n_int); it.phase.resize(it.n_int);
+        } else {
+            const uint32_t *index = jda_image_block_index(img, &nok);
+            memcpy(it.stage.data() + d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
+            memcpy(it.stage.data() + d->off_dc, jda_image_block_dc(img), it.n_blocks * sizeof(int16_t));
+        }
+        e = hipMemcpyAsync(d->base, it.stage.data(), it.alloc, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { rc = set_err(ctx, e, "hipMemcpy(image)"); break; }
+    }
+    if (rc != JDA_SUCCESS) { (void)hipStreamSynchronize(ctx->stream); return fail_all(rc); }
+
+    jda_prescan_params *d_params = NULL;
+    if (!params.empty()) {
+        e = hipMalloc((void **)&d_params, params.size() * sizeof(jda_prescan_params));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), params.size() * sizeof(jda_prescan_params), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = jda_launch_prescan(d_params, (uint32_t)params.size(), max_int, 0, ctx->stream);          // MAP
+        for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
+            Item &it = items[params_owner[p]];
+            e = hipMemcpyAsync(it.map.data(), it.d->base + it.off_map, (size_t)it.n_int * 4, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
+            Item &it = items[params_owner[p]];
+            uint32_t j = 0;                                   // the scan starts with pBuf at its first byte, ulBitOff 0 (:4996-4998)
+            for (uint32_t k = 0; k < it.n_int; k++) { it.phase[k] = (uint8_t)(8u * j); j = (it.map[k] >> (4u * (j > 5u ? 0u : j))) & 15u; }
+            e = hipMemcpyAsync(it.d->base + it.off_phase, it.phase.data(), it.n_int, hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (e == hipSuccess) e = jda_launch_prescan(d_params, (uint32_t)params.size(), max_int, 1, ctx->stream);          // EXACT
+        for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
+            Item &it = items[params_owner[p]];
+            e = hipMemcpyAsync(it.st, it.d->base + it.off_stats, sizeof(it.st), hipMemcpyDeviceToHost, ctx->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_params) (void)hipFree(d_params);
+    if (e != hipSuccess) return fail_all(set_err(ctx, e, "jda_upload_batch"));
+
+    // a marker that is not where the MCU count puts it, or a corrupt interval: the serial host pre-scan reproduces
+    // what the reference does with such a stream
+    bool reupload = false;
+    for (size_t p = 0; p < params.size(); p++) {
+        const int i = params_owner[p];
+        Item &it = items[i];
+        const jda_image_info &I = *jda_image_get_info(imgs[i]);
+        if (it.st[0] == 0xffffffffu && it.st[1] == 0) {
+            jda_image_adopt_prescan(imgs[i], (uint32_t)(I.mcus_x * I.mcus_y), it.st[2], (int32_t)it.st[3], it.st[4]);
+            it.d->prescan_on_device = 1;
+        } else {
+            jda_image_run_host_prescan(imgs[i]);
+            uint32_t nok = 0;
+            const uint32_t *index = jda_image_block_index(imgs[i], &nok);
+            memcpy(it.stage.data() + it.d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
+            memcpy(it.stage.data() + it.d->off_dc, jda_image_block_dc(imgs[i]), it.n_blocks * sizeof(int16_t));
+            e = hipMemcpyAsync(it.d->base + it.d->off_index, it.stage.data() + it.d->off_index, it.d->off_scan - it.d->off_index, hipMemcpyHostToDevice, ctx->stream);
+            reupload = true;
+            if (e != hipSuccess) break;
+        }
+    }
+    if (reupload && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail_all(set_err(ctx, e, "jda_upload_batch(re-upload)"));
+    for (int i = 0; i < n; i++) {
+        uint32_t nok = 0;
+        (void)jda_image_block_index(imgs[i], &nok);
+        items[i].d->n_mcus_ok = nok;
+        items[i].d->fast_mul = (uint8_t)jda_image_fast_mul(imgs[i]);
+        out[i] = items[i].d;
+    }
+    return JDA_SUCCESS;
+}
+
 jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err)
 {
     int32_t dummy;
     if (!err) err = &dummy;
     if (!ctx || !img) { *err = ctx ? JDA_INVALID_PARAMETER : JDA_ERROR_NO_DEVICE; return NULL; }
-    const jda_image_info &I = *jda_image_get_info(img);
-    uint32_t scan_len = 0, nok = 0, tbytes = 0, n_int = 0;
-    const uint8_t *scan = jda_image_scan(img, &scan_len);
-    const uint8_t *tables = jda_image_tables(img, &tbytes);
-    const size_t n_blocks = (size_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu;
-    const bool on_device = jda_image_index_on_device(img) != 0;      // index to be made by jda_prescan_intervals
-    const uint32_t *rpos = jda_image_restart_positions(img, &n_int);
-
-    jda_dev_image *d = new (std::nothrow) jda_dev_image;
-    if (!d) { *err = JDA_ERROR_MEMORY; return NULL; }
-    memset(d, 0, sizeof(*d));
-    d->info = I;
-    d->scan_len = scan_len;
-    jda_image_component_ids(img, d->dc_id, d->ac_id, d->q_id);
-    d->off_tables = 0;
-    d->off_index = align16(tbytes);
-    d->off_dc = d->off_index + align16((n_blocks + 1) * sizeof(uint32_t));
-    d->off_scan = d->off_dc + align16(n_blocks * sizeof(int16_t));
-    d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
-    // the device pre-scan's extras ride along behind the image: restart positions, phase map, start phases, results
-    const size_t off_rpos = d->bytes, off_map = off_rpos + align16((size_t)n_int * 4);
-    const size_t off_phase = off_map + align16((size_t)n_int * 4), off_stats = off_phase + align16((size_t)n_int);
-    const size_t alloc = on_device ? off_stats + 32 : d->bytes;
-    (void)hipSetDevice(ctx->device);
-    hipError_t e = hipMalloc((void **)&d->base, alloc);
-    if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); delete d; *err = JDA_ERROR_MEMORY; return NULL; }
-    // stage through one host buffer so it is a single H2D copy
-    std::vector<uint8_t> stage(alloc, 0);
-    memcpy(stage.data() + d->off_tables, tables, tbytes);
-    memcpy(stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
-    if (on_device) {
-        memcpy(stage.data() + off_rpos, rpos, (size_t)n_int * 4);
-        const uint32_t init[5] = { 0xffffffffu, 0, 0, 0, 0 };
-        memcpy(stage.data() + off_stats, init, sizeof(init));
-    }
-    bool device_index = false;
-    if (on_device) {
-        jda_prescan_params P;
-        memset(&P, 0, sizeof(P));
-        P.scan = d->base + d->off_scan; P.tables = d->base + d->off_tables;
-        P.restart_pos = (const uint32_t *)(d->base + off_rpos);
-        P.phase_map = (uint32_t *)(d->base + off_map); P.start_phase = d->base + off_phase;
-        P.blk_index = (uint32_t *)(d->base + d->off_index); P.blk_dc = (int16_t *)(d->base + d->off_dc);
-        P.stats = (uint32_t *)(d->base + off_stats);
-        P.scan_len = scan_len; P.n_intervals = n_int; P.n_mcus = (uint32_t)(I.mcus_x * I.mcus_y);
-        P.interval_mcus = (uint32_t)I.restart_interval;
-        P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu == 6 ? 4 : 1);
-        for (int c = 0; c < 3; c++) { P.dc_id[c] = d->dc_id[c]; P.ac_id[c] = d->ac_id[c]; }
-        std::vector<uint32_t> map(n_int);
-        std::vector<uint8_t> phase(n_int);
-        uint32_t st[5] = { 0, 0, 0, 0, 0 };
-        e = hipMemcpyAsync(d->base, stage.data(), alloc, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = jda_launch_prescan(&P, 0, ctx->stream);                               // MAP
-        if (e == hipSuccess) e = hipMemcpyAsync(map.data(), d->base + off_map, (size_t)n_int * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) {
-            uint32_t j = 0;                                   // the scan starts with pBuf at its first byte, ulBitOff 0 (:4996-4998)
-            for (uint32_t k = 0; k < n_int; k++) { phase[k] = (uint8_t)(8u * j); j = (map[k] >> (4u * (j > 5u ? 0u : j))) & 15u; }
-            e = hipMemcpyAsync(d->base + off_phase, phase.data(), n_int, hipMemcpyHostToDevice, ctx->stream);
-        }
-        if (e == hipSuccess) e = jda_launch_prescan(&P, 1, ctx->stream);                               // EXACT
-        if (e == hipSuccess) e = hipMemcpyAsync(st, d->base + off_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { set_err(ctx, e, "device pre-scan"); (void)hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
-        // a marker that is not where the MCU count puts it, or a corrupt interval: the serial host pre-scan
-        // reproduces what the reference does with such a stream
-        if (st[0] == 0xffffffffu && st[1] == 0) {
-            jda_image_adopt_prescan(img, (uint32_t)(I.mcus_x * I.mcus_y), st[2], (int32_t)st[3], st[4]);
-            d->prescan_on_device = 1;
-            device_index = true;
-        } else jda_image_run_host_prescan(img);
-    }
-    if (!device_index) {
-        const uint32_t *index = jda_image_block_index(img, &nok);
-        memcpy(stage.data() + d->off_index, index, (n_blocks + 1) * sizeof(uint32_t));
-        memcpy(stage.data() + d->off_dc, jda_image_block_dc(img), n_blocks * sizeof(int16_t));
-        e = hipMemcpyAsync(d->base, stage.data(), d->bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { set_err(ctx, e, "hipMemcpy(image)"); (void)hipFree(d->base); delete d; *err = JDA_ERROR_HIP; return NULL; }
-    }
-    uint32_t nok2 = 0;
-    (void)jda_image_block_index(img, &nok2);
-    d->n_mcus_ok = nok2;
-    d->fast_mul = (uint8_t)jda_image_fast_mul(img);
-    *err = JDA_SUCCESS;
+    jda_dev_image *d = NULL;
+    *err = jda_upload_batch(ctx, 1, &img, &d);
     return d;
 }
 

@@ -114,6 +114,21 @@ def test_restart_marker_fast_path(name, gpu_ctx, oracle):
         got = gpu_ctx.to_host(out, pitch * want.shape[0]).reshape(want.shape[0], pitch)[:, : want.shape[1]]
         assert np.array_equal(got, want), (name, pt, opt)
         gpu_ctx.free(out)
+    # several images at once (jda_upload_batch): markers and no markers mixed
+    preps = [J.PreparedImage(jpeg_for(nm), device_prescan=True) for nm in (name, "c420_333x217", name)]
+    dimgs = J.upload_batch(gpu_ctx, preps)
+    assert [d.prescan_on_device for d in dimgs] == [True, False, True]
+    for p_, d_, nm in zip(preps, dimgs, (name, "c420_333x217", name)):
+        pt = J.GRAY8 if nm.startswith("gray") else J.RGB8888
+        rc, want, _ = oracle.decode_canvas(jpeg_for(nm), pt, 0)
+        g = p_.geometry(pt, 0)
+        pitch = (want.shape[1] + 15) // 16 * 16
+        out = gpu_ctx.malloc(pitch * want.shape[0])
+        b = J.Batch(gpu_ctx, [d_], [(out, pitch, g["canvas_w"], g["canvas_h"])], [pt], [0])
+        b.decode(); gpu_ctx.sync()
+        got = gpu_ctx.to_host(out, pitch * want.shape[0]).reshape(want.shape[0], pitch)[:, : want.shape[1]]
+        assert np.array_equal(got, want), (nm, "batch upload")
+        gpu_ctx.free(out)
     # a stream without markers: the flag changes nothing
     plain = J.PreparedImage(jpeg_for("c420_333x217"), device_prescan=True)
     assert not plain.prescan_pending
