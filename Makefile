@@ -7,7 +7,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 CXX   ?= g++
 ARCH  ?= gfx950
 CSRC  = jpegdec_amd/csrc
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fwrapv -Wall -Wno-unused-function -Iinclude
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fwrapv -pthread -Wall -Wno-unused-function -Iinclude
 LIB = jpegdec_amd/libjpegdec_amd.so
 LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
 LIB_DEPS = $(LIB_SRCS) $(CSRC)/jda_internal.h $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h include/jpegdec_amd.h include/JPEGDEC.h
@@ -23,7 +23,7 @@ oracle:
 
 hostsim: tests/hostsim/libjda_hostsim.so
 tests/hostsim/libjda_hostsim.so: tests/hostsim/hostsim.cpp $(CSRC)/jda_frontend.cpp $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h $(CSRC)/jda_internal.h
-	$(CXX) -O2 -std=c++17 -fPIC -shared -fwrapv -Wall -Wno-unused-function -Wno-unknown-pragmas -Iinclude -o $@ tests/hostsim/hostsim.cpp $(CSRC)/jda_frontend.cpp
+	$(CXX) -O2 -std=c++17 -fPIC -shared -fwrapv -Wall -Wno-unused-function -Wno-unknown-pragmas -Iinclude -pthread -o $@ tests/hostsim/hostsim.cpp $(CSRC)/jda_frontend.cpp
 
 # the reference-API driver (oracle/ref_shim.cpp) built against the product's JPEGDEC class -- test infrastructure
 classshim: tests/libjpegdec_class_shim.so

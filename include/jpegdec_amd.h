@@ -96,6 +96,10 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
  * markers the flag has no effect. */
 #define JDA_PREPARE_DEVICE_PRESCAN 1
 jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
+/* jda_prepare_ex for n images on `threads` host threads (<= 0: all hardware threads); out[i] / errs[i] per image
+ * (errs may be NULL).  Returns JDA_SUCCESS or the first error met. */
+int jda_prepare_batch(int32_t n, const uint8_t *const *jpegs, const int32_t *lens, int32_t flags, int32_t threads,
+                      jda_image **out, int32_t *errs);
 /* 1 while the image's block index has not been made yet (deferred to jda_upload). */
 int jda_image_prescan_pending(const jda_image *img);
 void jda_image_free(jda_image *img);

@@ -28,5 +28,6 @@ from .binding import (  # noqa: F401
     load_library,
     output_geometry,
     parse,
+    prepare_batch,
     upload_batch,
 )

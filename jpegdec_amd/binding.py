@@ -52,6 +52,7 @@ _PROTOTYPES = [
     ("jda_prepare", _P, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_prepare_ex", _P, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_image_prescan_pending", C.c_int, [_P]),
+    ("jda_prepare_batch", C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("jda_dev_image_prescan_on_device", C.c_int, [_P]),
     ("jda_upload_batch", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
     ("jda_image_free", None, [_P]),
@@ -156,10 +157,10 @@ class PreparedImage:
     device_prescan=True (jda_prepare_ex, JDA_PREPARE_DEVICE_PRESCAN): for a stream with restart markers the
     serial pre-scan is left to the GPU (done by DeviceImage / jda_upload); `prescan_pending` tells."""
 
-    def __init__(self, jpeg: bytes, device_prescan: bool = False):
+    def __init__(self, jpeg: bytes, device_prescan: bool = False, _handle=None):
         self.lib = load_library()
         err = C.c_int32(0)
-        self.handle = self.lib.jda_prepare_ex(jpeg, len(jpeg), PREPARE_DEVICE_PRESCAN if device_prescan else 0, C.byref(err))
+        self.handle = _handle if _handle else self.lib.jda_prepare_ex(jpeg, len(jpeg), PREPARE_DEVICE_PRESCAN if device_prescan else 0, C.byref(err))
         if not self.handle:
             raise JdaError(err.value, "jda_prepare")
         self.info = self.lib.jda_image_get_info(self.handle).contents
@@ -282,6 +283,24 @@ class DeviceImage:
         if self.handle:
             self.ctx.lib.jda_dev_image_free(self.ctx.handle, self.handle)
             self.handle = None
+
+
+def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0):
+    """jda_prepare_batch: the images are prepared on `threads` host threads (0 = all)."""
+    lib = load_library()
+    n = len(jpegs)
+    arr = (C.c_char_p * n)(*jpegs)
+    lens = (C.c_int32 * n)(*[len(j) for j in jpegs])
+    outs = (_P * n)()
+    errs = (C.c_int32 * n)()
+    rc = lib.jda_prepare_batch(n, arr, lens, PREPARE_DEVICE_PRESCAN if device_prescan else 0, threads, outs, errs)
+    res = [PreparedImage(jpegs[i], _handle=outs[i]) if outs[i] else None for i in range(n)]
+    if rc != 0:
+        for r in res:
+            if r is not None:
+                r.close()
+        raise JdaError(rc, "jda_prepare_batch")
+    return res
 
 
 def upload_batch(ctx: Context, prepared_list):

@@ -424,8 +424,9 @@ JDA_HD uint64_t jda_ph_refill(uint64_t x)
     return (x & ~m) | (x & m & (0x07u * K));
 }
 
+// lds_tables: the table blob staged in LDS by the caller's workgroup (GPU), or NULL to read P.tables from memory
 template <bool EXACT>
-JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k)
+JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k, const uint8_t *lds_tables = nullptr)
 {
     jda_prescan_result R;
     R.first_bad = 0xffffffffu; R.mismatch = 0; R.max_ac_bits = 0; R.max_abs_dc = 0; R.trunc_events = 0; R.phase_map = 0;
@@ -462,18 +463,19 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
             }
             const uint32_t dci = c == 0 ? P.dc_id[0] : (c == 1 ? P.dc_id[1] : P.dc_id[2]);
             const uint32_t aci = c == 0 ? P.ac_id[0] : (c == 1 ? P.ac_id[1] : P.ac_id[2]);
-            const uint8_t JDA_GLOBAL *dcl = tables + JDA_TB_DC + dci * 1024;
-            const uint16_t JDA_GLOBAL *acl = (const uint16_t JDA_GLOBAL *)(tables + JDA_TB_AC) + aci * 2048;
+            const uint32_t dc_off = JDA_TB_DC + dci * 1024, ac_off = JDA_TB_AC + aci * 4096;
+#define JDA_PS_TAB8(o) (lds_tables ? (uint32_t)lds_tables[o] : (uint32_t)tables[o])
+#define JDA_PS_TAB16(o) (lds_tables ? (uint32_t)*(const uint16_t *)(lds_tables + (o)) : (uint32_t)*(const uint16_t JDA_GLOBAL *)(tables + (o)))
             JDA_PS_REFILL();
             if (bad) break;
             uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
             code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
-            uint32_t e = dcl[code];
+            uint32_t e = JDA_PS_TAB8(dc_off + code);
             if (e == 0) { bad = true; break; }                   // :2137-2138
             JDA_PS_ADVANCE(e >> 4);
             const uint32_t s = e & 0xfu;
             if (s) {
-                const int32_t folded = (int8_t)dcl[code + 512];
+                const int32_t folded = (int8_t)JDA_PS_TAB8(dc_off + code + 512);
                 if (folded) pr += folded;
                 else {
                     JDA_PS_REFILL();
@@ -489,7 +491,7 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
                 if (bad) break;
                 code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
                 code = code >= 0xfc00u ? ((code & 0x3ffu) + 1024u) : (code >> 6);
-                e = acl[code];
+                e = JDA_PS_TAB16(ac_off + code * 2);
                 if (e == 0) { bad = true; break; }               // :2237-2238
                 JDA_PS_ADVANCE(e >> 8);
                 e &= 0xffu;
@@ -507,6 +509,8 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
     }
 #undef JDA_PS_REFILL
 #undef JDA_PS_ADVANCE
+#undef JDA_PS_TAB8
+#undef JDA_PS_TAB16
     if (bad) { R.first_bad = first_mcu + m; return R; }
     if (!EXACT) {
         // :5339-5346: round each offset up to a byte: 0, 8, .., 64 (48 and up behave like 0 from the next block's

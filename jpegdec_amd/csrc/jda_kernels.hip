@@ -319,10 +319,17 @@ template <bool EXACT>
 __global__ __launch_bounds__(64)
 void jda_prescan_intervals(const jda_prescan_params *__restrict__ params)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t tab[JDA_TABLE_BYTES];   // the LUTs: two dependent lookups per symbol
     const jda_prescan_params P = params[blockIdx.y];            // one image per grid row
+    {
+        const jda_chunk16_alias JDA_GLOBAL *src = JDA_G(const jda_chunk16_alias, P.tables);
+        jda_chunk16_alias *dst = (jda_chunk16_alias *)tab;
+        for (uint32_t i = threadIdx.x; i < JDA_TABLE_BYTES / 16; i += 64u) dst[i] = src[i];
+    }
+    __syncthreads();
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= P.n_intervals) return;
-    const jda_prescan_result R = jda_prescan_interval<EXACT>(P, k);
+    const jda_prescan_result R = jda_prescan_interval<EXACT>(P, k, tab);
     if (!EXACT) { P.phase_map[k] = R.phase_map; return; }
     uint32_t *st = P.stats;
     if (R.first_bad != 0xffffffffu) atomicMin(&st[0], R.first_bad);

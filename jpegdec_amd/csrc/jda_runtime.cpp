@@ -29,6 +29,8 @@ struct jda_ctx {
     int device;
     hipStream_t stream;
     hipEvent_t ev_start, ev_stop;
+    uint8_t *pinned;          // page-locked staging for uploads (grow-only, reused)
+    size_t pinned_cap;
     char last_error[256];
 };
 
@@ -99,6 +101,7 @@ void jda_destroy(jda_ctx *ctx)
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }
 
@@ -154,7 +157,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     if (n <= 0 || !imgs || !out) return JDA_INVALID_PARAMETER;
     (void)hipSetDevice(ctx->device);
     struct Item {
-        jda_dev_image *d; std::vector<uint8_t> stage; bool on_device; uint32_t n_int;
+        jda_dev_image *d; uint8_t *stage; std::vector<uint8_t> heap; bool on_device; uint32_t n_int;
         size_t off_rpos, off_map, off_phase, off_stats, alloc, n_blocks; uint32_t tbytes;
         std::vector<uint32_t> map; std::vector<uint8_t> phase; uint32_t st[5];
     };
@@ -169,6 +172,28 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     std::vector<jda_prescan_params> params;
     std::vector<int> params_owner;
     uint32_t max_int = 0;
+    // staging: slices of one page-locked buffer (H2D at link speed, truly asynchronous); when it is full the
+    // copies in flight are drained and it is reused from the start
+    const size_t kPinnedMax = (size_t)512 << 20;
+    size_t pin_off = 0;
+    auto pin_slice = [&](size_t bytes) -> uint8_t * {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > kPinnedMax) return NULL;
+        if (bytes > ctx->pinned_cap) {
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+            ctx->pinned = NULL; ctx->pinned_cap = 0;
+            size_t want = bytes * 8 < kPinnedMax ? bytes * 8 : kPinnedMax;      // room for a few images in flight
+            if (want < bytes) want = bytes;
+            if (hipHostMalloc((void **)&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { ctx->pinned = NULL; return NULL; }
+            ctx->pinned_cap = want;
+            pin_off = 0;
+        }
+        if (pin_off + bytes > ctx->pinned_cap) { (void)hipStreamSynchronize(ctx->stream); pin_off = 0; }
+        uint8_t *p = ctx->pinned + pin_off;
+        pin_off += bytes;
+        return p;
+    };
     for (int i = 0; i < n && rc == JDA_SUCCESS; i++) {
         Item &it = items[i];
         jda_image *img = imgs[i];
@@ -199,13 +224,14 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         e = hipMalloc((void **)&d->base, it.alloc);
         if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
         // stage through one host buffer so it is a single H2D copy
-        it.stage.assign(it.alloc, 0);
-        memcpy(it.stage.data() + d->off_tables, tables, it.tbytes);
-        memcpy(it.stage.data() + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
+        it.stage = pin_slice(it.alloc);
+        if (!it.stage) { it.heap.assign(it.alloc, 0); it.stage = it.heap.data(); }
+        memcpy(it.stage + d->off_tables, tables, it.tbytes);
+        memcpy(it.stage + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
         if (it.on_device) {
-            memcpy(it.stage.data() + it.off_rpos, rpos, (size_t)it.n_int * 4);
+            memcpy(it.stage + it.off_rpos, rpos, (size_t)it.n_int * 4);
             const uint32_t init[5] = { 0xffffffffu, 0, 0, 0, 0 };
-            memcpy(it.stage.data() + it.off_stats, init, sizeof(init));
+            memcpy(it.stage + it.off_stats, init, sizeof(init));
             jda_prescan_params P;
             memset(&P, 0, sizeof(P));
             P.scan = d->base + d->off_scan; P.tables = d->base + d->off_tables;
@@ -222,10 +248,10 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.map.resize(it.n_int); it.phase.resize(it.n_int);
         } else {
             const uint32_t *index = jda_image_block_index(img, &nok);
-            memcpy(it.stage.data() + d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
-            memcpy(it.stage.data() + d->off_dc, jda_image_block_dc(img), it.n_blocks * sizeof(int16_t));
+            memcpy(it.stage + d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
+            memcpy(it.stage + d->off_dc, jda_image_block_dc(img), it.n_blocks * sizeof(int16_t));
         }
-        e = hipMemcpyAsync(d->base, it.stage.data(), it.alloc, hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(d->base, it.stage, it.alloc, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { rc = set_err(ctx, e, "hipMemcpy(image)"); break; }
     }
     if (rc != JDA_SUCCESS) { (void)hipStreamSynchronize(ctx->stream); return fail_all(rc); }
@@ -270,9 +296,8 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             jda_image_run_host_prescan(imgs[i]);
             uint32_t nok = 0;
             const uint32_t *index = jda_image_block_index(imgs[i], &nok);
-            memcpy(it.stage.data() + it.d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
-            memcpy(it.stage.data() + it.d->off_dc, jda_image_block_dc(imgs[i]), it.n_blocks * sizeof(int16_t));
-            e = hipMemcpyAsync(it.d->base + it.d->off_index, it.stage.data() + it.d->off_index, it.d->off_scan - it.d->off_index, hipMemcpyHostToDevice, ctx->stream);
+            e = hipMemcpyAsync(it.d->base + it.d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(it.d->base + it.d->off_dc, jda_image_block_dc(imgs[i]), it.n_blocks * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream);
             reupload = true;
             if (e != hipSuccess) break;
         }
