@@ -45,6 +45,8 @@ template <int MODE> struct jda_mode_traits;
 template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
 template <> struct jda_mode_traits<JDA_MODE_444>  { enum { NLUMA = 1, NBLK = 3, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
 template <> struct jda_mode_traits<JDA_MODE_420>  { enum { NLUMA = 4, NBLK = 6, MCU_W = 16, MCU_H = 16, MCU_W_LOG2 = 4 }; };
+template <> struct jda_mode_traits<JDA_MODE_422>  { enum { NLUMA = 2, NBLK = 4, MCU_W = 16, MCU_H = 8, MCU_W_LOG2 = 4 }; };   // Y0 Y1 (side by side) Cb Cr
+template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, MCU_W = 8, MCU_H = 16, MCU_W_LOG2 = 3 }; };   // Y0 Y1 (one above the other) Cb Cr
 
 // LDS copy of the table blob (one per workgroup): DC LUTs, the SHORT halves of the AC LUTs (codes
 // that do not start with six 1 bits; the long halves are rare and stay in global memory),
@@ -822,6 +824,36 @@ JDA_HD jda_ycc jda_fetch(const uint8_t *planes, uint32_t px, uint32_t py, int sh
             o.cr = planes[JDA_COEF_STRIDE * 5 + cidx];
             o.y = (shift == 1) ? (o.y << 10) : (o.y << 12);
         } else if (shift == 1) o.y = (o.y + 2) >> 2;                                        // :2979-2999
+    } else if (MODE == JDA_MODE_422 || MODE == JDA_MODE_440) {
+        // two luma blocks side by side (4:2:2, JPEGPutMCU21 jpeg.inl:4721-4868) or one above the other (4:4:0,
+        // JPEGPutMCU12 :4546-4719); chroma blocks in slots 2, 3.  a = coordinate along which the blocks are stacked
+        // and the chroma is subsampled, c = the other one.
+        const bool horiz = MODE == JDA_MODE_422;
+        const uint32_t bsz = 8u >> shift;
+        const uint32_t a = horiz ? px : py, c = horiz ? py : px;
+        const uint32_t q = a / bsz, ba = a & (bsz - 1);
+        Y = planes + JDA_COEF_STRIDE * q;
+        const uint32_t bx = horiz ? ba : c, by = horiz ? c : ba;          // position inside the luma block
+        const uint8_t *Cb = planes + 2 * JDA_COEF_STRIDE, *Cr = planes + 3 * JDA_COEF_STRIDE;
+        uint32_t cb = 128, cr = 128;
+        if (shift == 0) {
+            o.y = Y[by * 8 + bx];
+            cidx = horiz ? (py * 8 + q * 4 + (bx >> 1)) : ((py >> 1) * 8 + px);
+            cb = Cb[cidx]; cr = Cr[cidx];
+        } else if (shift == 1) {
+            const uint8_t *s = Y + by * 16 + bx * 2;
+            o.y = s[0] + s[1] + s[8] + s[9];
+            // the chroma of the two source pixels across the non-subsampled direction is averaged, + 1 (:4743-4744, :4567-4568)
+            cidx = horiz ? (py * 16 + q * 4 + bx) : (py * 8 + px * 2);
+            const uint32_t step = horiz ? 8u : 1u;
+            if (!luma) { cb = (Cb[cidx] + Cb[cidx + step] + 1u) >> 1; cr = (Cr[cidx] + Cr[cidx + step] + 1u) >> 1; }
+        } else if (shift == 2) {
+            o.y = Y[by * 2 + bx];
+            cidx = horiz ? (py * 2 + q) : (q * 2 + px);                   // :4789-4838, :4610-4682
+            cb = Cb[cidx]; cr = Cr[cidx];
+        } else { o.y = Y[0]; cb = Cb[0]; cr = Cr[0]; }
+        if (!luma) { o.cb = (int32_t)cb; o.cr = (int32_t)cr; o.y = (shift == 1) ? (o.y << 10) : (o.y << 12); }
+        else if (shift == 1) o.y = (o.y + 2) >> 2;                         // JPEGPutMCU8BitGray :2857-2873, :2907-2923
     } else {
         if (shift == 0) { cidx = py * 8 + px; o.y = Y[cidx]; }
         else if (shift == 1) {
@@ -1478,7 +1510,7 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
     const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
     const uint8_t *plane_base = wl + L::PLANE_OFF;
     const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
-    if (MODE != JDA_MODE_GRAY && shift == 0 && colour_out) {
+    if ((MODE == JDA_MODE_444 || MODE == JDA_MODE_420) && shift == 0 && colour_out) {      // specialised full-size colour paths
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;   // no clipping in this tile
         if (inside) jda_p4_full_colour<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_full_colour<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);

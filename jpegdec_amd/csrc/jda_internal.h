@@ -19,7 +19,7 @@
 #define JDA_INDEX_OFF_BITS 7      // index entry = (byte position << 7) | bit offset (0..64)
 
 // kinds of MCU the kernels are specialised for
-enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2 };
+enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2, JDA_MODE_422 = 3 /* h2v1, MCU 16x8 */, JDA_MODE_440 = 4 /* h1v2, MCU 8x16 */, JDA_N_MODES = 5 };
 
 // Pointers stored in descriptors are loaded from memory, so the compiler cannot know they point to
 // global memory and would emit slow generic (flat_*) accesses; device code casts them with JDA_G().

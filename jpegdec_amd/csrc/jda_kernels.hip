@@ -361,22 +361,21 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_de
     if (n_tiles == 0) return hipSuccess;
     static int simple = -1;                           // JDA_KERNEL=simple selects the one-tile-per-wave kernel (A/B, tracing)
     if (simple < 0) { const char *e = getenv("JDA_KERNEL"); simple = (e && e[0] == 's') ? 1 : 0; }
-    if (simple) {
-        switch (mode * 2 + (fast_mul ? 1 : 0)) {
-        case JDA_MODE_GRAY * 2 + 0: return launch<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_GRAY * 2 + 1: return launch<JDA_MODE_GRAY, true>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_444 * 2 + 0: return launch<JDA_MODE_444, false>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_444 * 2 + 1: return launch<JDA_MODE_444, true>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 2 + 0: return launch<JDA_MODE_420, false>(descs, tiles, n_tiles, stream);
-        default: return launch<JDA_MODE_420, true>(descs, tiles, n_tiles, stream);
-        }
+#define JDA_LAUNCH_CASES(FN)                                                                                  \
+    switch (mode * 2 + (fast_mul ? 1 : 0)) {                                                                  \
+    case JDA_MODE_GRAY * 2 + 0: return FN<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);                \
+    case JDA_MODE_GRAY * 2 + 1: return FN<JDA_MODE_GRAY, true>(descs, tiles, n_tiles, stream);                 \
+    case JDA_MODE_444 * 2 + 0: return FN<JDA_MODE_444, false>(descs, tiles, n_tiles, stream);                  \
+    case JDA_MODE_444 * 2 + 1: return FN<JDA_MODE_444, true>(descs, tiles, n_tiles, stream);                   \
+    case JDA_MODE_420 * 2 + 0: return FN<JDA_MODE_420, false>(descs, tiles, n_tiles, stream);                  \
+    case JDA_MODE_420 * 2 + 1: return FN<JDA_MODE_420, true>(descs, tiles, n_tiles, stream);                   \
+    case JDA_MODE_422 * 2 + 0: return FN<JDA_MODE_422, false>(descs, tiles, n_tiles, stream);                  \
+    case JDA_MODE_422 * 2 + 1: return FN<JDA_MODE_422, true>(descs, tiles, n_tiles, stream);                   \
+    case JDA_MODE_440 * 2 + 0: return FN<JDA_MODE_440, false>(descs, tiles, n_tiles, stream);                  \
+    case JDA_MODE_440 * 2 + 1: return FN<JDA_MODE_440, true>(descs, tiles, n_tiles, stream);                   \
+    default: return hipErrorInvalidValue;                                                                     \
     }
-    switch (mode * 2 + (fast_mul ? 1 : 0)) {
-    case JDA_MODE_GRAY * 2 + 0: return launch_persistent<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_GRAY * 2 + 1: return launch_persistent<JDA_MODE_GRAY, true>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_444 * 2 + 0: return launch_persistent<JDA_MODE_444, false>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_444 * 2 + 1: return launch_persistent<JDA_MODE_444, true>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_420 * 2 + 0: return launch_persistent<JDA_MODE_420, false>(descs, tiles, n_tiles, stream);
-    default: return launch_persistent<JDA_MODE_420, true>(descs, tiles, n_tiles, stream);
-    }
+    if (simple) { JDA_LAUNCH_CASES(launch) }
+    JDA_LAUNCH_CASES(launch_persistent)
+#undef JDA_LAUNCH_CASES
 }

@@ -17,6 +17,8 @@ extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
 inline int jda_mode_of(const jda_image_info &I)
 {
     if (I.subsample == 0x22) return JDA_MODE_420;
+    if (I.subsample == 0x21) return JDA_MODE_422;
+    if (I.subsample == 0x12) return JDA_MODE_440;
     if (I.subsample == 0x11) return JDA_MODE_444;
     return JDA_MODE_GRAY;
 }
@@ -61,10 +63,18 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
 // image so that a workgroup never spans two images (it stages one table set).
 inline uint32_t jda_tiles_per_wg(int mode)
 {
-    return mode == JDA_MODE_420 ? (uint32_t)jda_lds_layout<JDA_MODE_420>::WAVES
-         : mode == JDA_MODE_444 ? (uint32_t)jda_lds_layout<JDA_MODE_444>::WAVES : (uint32_t)jda_lds_layout<JDA_MODE_GRAY>::WAVES;
+    switch (mode) {
+    case JDA_MODE_420: return (uint32_t)jda_lds_layout<JDA_MODE_420>::WAVES;
+    case JDA_MODE_444: return (uint32_t)jda_lds_layout<JDA_MODE_444>::WAVES;
+    case JDA_MODE_422: return (uint32_t)jda_lds_layout<JDA_MODE_422>::WAVES;
+    case JDA_MODE_440: return (uint32_t)jda_lds_layout<JDA_MODE_440>::WAVES;
+    default: return (uint32_t)jda_lds_layout<JDA_MODE_GRAY>::WAVES;
+    }
 }
-inline uint32_t jda_mcus_per_tile(int mode) { return mode == JDA_MODE_420 ? 10u : (mode == JDA_MODE_444 ? 21u : 64u); }
+inline uint32_t jda_mcus_per_tile(int mode)
+{
+    return mode == JDA_MODE_420 ? 10u : mode == JDA_MODE_444 ? 21u : (mode == JDA_MODE_422 || mode == JDA_MODE_440) ? 16u : 64u;
+}
 
 inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode)
 {

@@ -48,8 +48,8 @@ struct jda_dev_image {
 struct jda_batch {
     int32_t n_images;
     jda_dev_desc *d_descs;
-    jda_strip *d_strips[6];   // per (mode, fast_mul): index = mode * 2 + fast
-    uint32_t n_strips[6];
+    jda_strip *d_strips[2 * JDA_N_MODES];   // per (mode, fast_mul): index = mode * 2 + fast
+    uint32_t n_strips[2 * JDA_N_MODES];
     jda_batch_stats stats;
 };
 
@@ -241,7 +241,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             P.stats = (uint32_t *)(d->base + it.off_stats);
             P.scan_len = scan_len; P.n_intervals = it.n_int; P.n_mcus = (uint32_t)(I.mcus_x * I.mcus_y);
             P.interval_mcus = (uint32_t)I.restart_interval;
-            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu == 6 ? 4 : 1);
+            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
             for (int c = 0; c < 3; c++) { P.dc_id[c] = d->dc_id[c]; P.ac_id[c] = d->ac_id[c]; }
             params.push_back(P); params_owner.push_back(i);
             if (it.n_int > max_int) max_int = it.n_int;
@@ -345,7 +345,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     if (!ctx) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
     if (n <= 0 || !images || !outputs) { *err = JDA_INVALID_PARAMETER; return NULL; }
     std::vector<jda_dev_desc> descs((size_t)n);
-    std::vector<jda_strip> strips[6];
+    std::vector<jda_strip> strips[2 * JDA_N_MODES];
     jda_batch_stats st;
     memset(&st, 0, sizeof(st));
     for (int i = 0; i < n; i++) {
@@ -399,7 +399,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
     if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
-    for (int m = 0; m < 6 && e == hipSuccess; m++) {
+    for (int m = 0; m < 2 * JDA_N_MODES && e == hipSuccess; m++) {
         b->n_strips[m] = (uint32_t)strips[m].size();
         if (!b->n_strips[m]) continue;
         e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
@@ -424,7 +424,7 @@ void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (b->d_descs) (void)hipFree(b->d_descs);
-    for (int m = 0; m < 6; m++) if (b->d_strips[m]) (void)hipFree(b->d_strips[m]);
+    for (int m = 0; m < 2 * JDA_N_MODES; m++) if (b->d_strips[m]) (void)hipFree(b->d_strips[m]);
     delete b;
 }
 
@@ -432,7 +432,7 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     if (!b) return JDA_INVALID_PARAMETER;
-    for (int m = 0; m < 6; m++) {
+    for (int m = 0; m < 2 * JDA_N_MODES; m++) {
         if (!b->n_strips[m]) continue;
         JDA_HIP(ctx, jda_launch_decode(m >> 1, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
     }

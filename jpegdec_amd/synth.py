@@ -73,12 +73,185 @@ def encode_jpeg(pixels: np.ndarray, quality: int = 85, subsampling="4:2:0", opti
 
 def synth_jpeg(width: int, height: int, subsampling="4:2:0", seed: int = 1234, quality: int = 85,
                optimize: bool = False, restart_rows: int = 0, restart_blocks: int = 0) -> bytes:
-    """subsampling: '4:2:0' | '4:4:4' | '4:2:2' | 'gray'."""
+    """subsampling: '4:2:0' | '4:4:4' | '4:2:2' | '4:4:0' | 'gray'.  4:4:0 (luma sampled 1x2) goes through
+    encode_jpeg_custom (restart_blocks = its restart interval in MCUs)."""
     ch = 1 if subsampling == "gray" else 3
     px = value_noise_image(width, height, ch, seed)
+    if subsampling == "4:4:0":
+        return encode_jpeg_custom(px, quality, (1, 2), restart_interval=restart_blocks)
     return encode_jpeg(px, quality, subsampling if ch == 3 else None, optimize, restart_rows,
                        restart_blocks)
 
 
 def bits_per_pixel(jpeg: bytes, width: int, height: int) -> float:
     return 8.0 * len(jpeg) / float(width * height)
+
+
+# ---- a small baseline encoder of our own -------------------------------------------------------
+# Pillow/libjpeg-turbo cannot be asked for every sampling layout the decoder accepts (4:4:0 = luma
+# sampled 1x2), and offers no control over the entropy coding.  This encoder (numpy DCT, Annex-K
+# Huffman tables taken from a Pillow-written file, no optimisation) writes any luma H x V in {1,2} with
+# 1x1 chroma, optional restart intervals, and is only meant for small test inputs.
+def _annex_k_tables():
+    """(quant_luma, quant_chroma at quality 50 in zigzag order, {(class,id): (bits[16], vals)}) parsed from a Pillow JPEG."""
+    from PIL import Image
+
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(buf, format="JPEG", quality=50, optimize=False)
+    d = buf.getvalue()
+    q, huff = {}, {}
+    i = 2
+    while i < len(d):
+        assert d[i] == 0xFF
+        m = d[i + 1]
+        if m == 0xDA:
+            break
+        ln = (d[i + 2] << 8) | d[i + 3]
+        seg = d[i + 4:i + 2 + ln]
+        if m == 0xDB:
+            j = 0
+            while j < len(seg):
+                q[seg[j] & 15] = np.frombuffer(seg[j + 1:j + 65], np.uint8).astype(np.int32)
+                j += 65
+        elif m == 0xC4:
+            j = 0
+            while j < len(seg):
+                tc, th = seg[j] >> 4, seg[j] & 15
+                bits = list(seg[j + 1:j + 17])
+                n = sum(bits)
+                huff[(tc, th)] = (bits, list(seg[j + 17:j + 17 + n]))
+                j += 17 + n
+        i += 2 + ln
+    return q[0], q[1], huff
+
+
+_ZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+           28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54,
+           47, 55, 62, 63]
+
+
+def _codes(bits, vals):
+    table, code, k = {}, 0, 0
+    for ln in range(1, 17):
+        for _ in range(bits[ln - 1]):
+            table[vals[k]] = (code, ln)
+            code += 1
+            k += 1
+        code <<= 1
+    return table
+
+
+def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), restart_interval: int = 0) -> bytes:
+    """Baseline JPEG of an HxWx3 RGB image with luma sampling factors luma_hv = (H, V) and 1x1 chroma:
+    (1,1) 4:4:4, (2,1) 4:2:2, (1,2) 4:4:0, (2,2) 4:2:0."""
+    hs, vs = luma_hv
+    h, w = pixels.shape[:2]
+    rgb = pixels.astype(np.float64)
+    ycc = [0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2],
+           -0.168736 * rgb[..., 0] - 0.331264 * rgb[..., 1] + 0.5 * rgb[..., 2] + 128.0,
+           0.5 * rgb[..., 0] - 0.418688 * rgb[..., 1] - 0.081312 * rgb[..., 2] + 128.0]
+    mw, mh = 8 * hs, 8 * vs
+    cx, cy = (w + mw - 1) // mw, (h + mh - 1) // mh
+    planes = []
+    for c, p in enumerate(ycc):
+        p = np.pad(p, ((0, cy * mh - h), (0, cx * mw - w)), mode="edge")
+        if c:                                   # box-filter the chroma down
+            p = p.reshape(cy * mh // vs, vs, cx * mw // hs, hs).mean(axis=(1, 3))
+        planes.append(p - 128.0)
+    ql, qc, huff = _annex_k_tables()
+    scale = 5000 // quality if quality < 50 else 200 - 2 * quality
+    qt = [np.clip((t * scale + 50) // 100, 1, 255) for t in (ql, qc)]
+    k = np.arange(8)
+    dct = np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16) * np.where(k[:, None] == 0, np.sqrt(1 / 8), 0.5)
+    nat_q = []
+    for t in qt:
+        n = np.zeros(64, np.int32)
+        n[_ZIGZAG] = t
+        nat_q.append(n.reshape(8, 8))
+
+    def blocks(p, q):
+        hh, ww = p.shape
+        b = p.reshape(hh // 8, 8, ww // 8, 8).transpose(0, 2, 1, 3)
+        coef = np.einsum("ij,abjk,lk->abil", dct, b, dct)
+        return np.rint(coef / q).astype(np.int32)
+
+    cb = [blocks(planes[0], nat_q[0]), blocks(planes[1], nat_q[1]), blocks(planes[2], nat_q[1])]
+    dc_t = [_codes(*huff[(0, 0)]), _codes(*huff[(0, 1)])]
+    ac_t = [_codes(*huff[(1, 0)]), _codes(*huff[(1, 1)])]
+    out = bytearray()
+    acc, nacc = 0, 0
+
+    def put(code, ln):
+        nonlocal acc, nacc
+        acc = (acc << ln) | (code & ((1 << ln) - 1))
+        nacc += ln
+        while nacc >= 8:
+            byte = (acc >> (nacc - 8)) & 0xFF
+            out.append(byte)
+            if byte == 0xFF:
+                out.append(0)
+            nacc -= 8
+        acc &= (1 << nacc) - 1
+
+    def mag(v):
+        a = abs(int(v))
+        s = a.bit_length()
+        return s, (int(v) if v >= 0 else int(v) + (1 << s) - 1)
+
+    def emit_block(blk, t, pred):
+        zz = blk.reshape(64)[_ZIGZAG]
+        s, bits = mag(zz[0] - pred)
+        put(*dc_t[t][s])
+        if s:
+            put(bits, s)
+        run = 0
+        last = max([i for i in range(1, 64) if zz[i]] or [0])
+        for i in range(1, last + 1):
+            if zz[i] == 0:
+                run += 1
+                continue
+            while run > 15:
+                put(*ac_t[t][0xF0])
+                run -= 16
+            s, bits = mag(zz[i])
+            put(*ac_t[t][(run << 4) | s])
+            put(bits, s)
+            run = 0
+        if last < 63:
+            put(*ac_t[t][0])
+        return int(zz[0])
+
+    pred = [0, 0, 0]
+    n_mcu = 0
+    rst = 0
+    for my in range(cy):
+        for mx in range(cx):
+            if restart_interval and n_mcu and n_mcu % restart_interval == 0:
+                if nacc:
+                    put((1 << (8 - nacc)) - 1, 8 - nacc)
+                out += bytes([0xFF, 0xD0 + (rst & 7)])
+                rst += 1
+                pred = [0, 0, 0]
+            for by in range(vs):
+                for bx in range(hs):
+                    pred[0] = emit_block(cb[0][my * vs + by, mx * hs + bx], 0, pred[0])
+            pred[1] = emit_block(cb[1][my, mx], 1, pred[1])
+            pred[2] = emit_block(cb[2][my, mx], 1, pred[2])
+            n_mcu += 1
+    if nacc:
+        put((1 << (8 - nacc)) - 1, 8 - nacc)
+
+    def seg(marker, payload):
+        return bytes([0xFF, marker]) + (len(payload) + 2).to_bytes(2, "big") + bytes(payload)
+
+    hdr = bytearray(b"\xff\xd8")
+    hdr += seg(0xE0, b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    hdr += seg(0xDB, bytes([0]) + bytes(int(v) for v in qt[0]) + bytes([1]) + bytes(int(v) for v in qt[1]))
+    hdr += seg(0xC0, bytes([8]) + h.to_bytes(2, "big") + w.to_bytes(2, "big") + bytes([3, 1, (hs << 4) | vs, 0, 2, 0x11, 1, 3, 0x11, 1]))
+    for (tc, th), (bits, vals) in sorted(huff.items()):
+        hdr += seg(0xC4, bytes([(tc << 4) | th]) + bytes(bits) + bytes(vals))
+    if restart_interval:
+        hdr += seg(0xDD, restart_interval.to_bytes(2, "big"))
+    hdr += seg(0xDA, bytes([3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0]))
+    # pad small files: the reference rejects anything under 256 bytes (jpeg.inl:1598)
+    return bytes(hdr) + bytes(out) + b"\xff\xd9"

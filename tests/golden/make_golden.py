@@ -39,6 +39,8 @@ def main():
             for opt in OPTIONS:
                 if entry["info"]["subsample"] == 0 and pt == 2:
                     continue                      # gray JPEG + RGB8888: reference emits 565 with iBpp=32
+                if entry["info"]["subsample"] == 0x12 and pt == 2 and (opt & 4):
+                    continue                      # 4:4:0, 1/4 scale, RGB8888: undefined behaviour in the reference (jpeg.inl:4620)
                 r = ref.decode_cb(jpeg, pt, opt)
                 assert r["rc"] == 1, (name, pt, opt)
                 inf, sh, bpp = r["info"], r["scale_shift"], r["bpp"]

@@ -80,7 +80,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         P.blk_index = dev_index.data(); P.blk_dc = dev_dc.data(); P.stats = NULL;
         P.scan_len = sl; P.n_intervals = n_int; P.n_mcus = (uint32_t)(I->mcus_x * I->mcus_y);
         P.interval_mcus = (uint32_t)I->restart_interval;
-        P.nblocks = (uint8_t)I->blocks_per_mcu; P.nluma = (uint8_t)(I->blocks_per_mcu == 6 ? 4 : 1);
+        P.nblocks = (uint8_t)I->blocks_per_mcu; P.nluma = (uint8_t)(I->blocks_per_mcu - (I->ncomp == 3 ? 2 : 0));
         uint8_t q_id[3];
         jda_image_component_ids(img, P.dc_id, P.ac_id, q_id);
         // MAP pass -> compose the phases -> EXACT pass, as jda_upload does
@@ -134,7 +134,11 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     case JDA_MODE_444 * 2: run_tiles<JDA_MODE_444, false>(D, strips); break;
     case JDA_MODE_444 * 2 + 1: run_tiles<JDA_MODE_444, true>(D, strips); break;
     case JDA_MODE_420 * 2: run_tiles<JDA_MODE_420, false>(D, strips); break;
-    default: run_tiles<JDA_MODE_420, true>(D, strips); break;
+    case JDA_MODE_420 * 2 + 1: run_tiles<JDA_MODE_420, true>(D, strips); break;
+    case JDA_MODE_422 * 2: run_tiles<JDA_MODE_422, false>(D, strips); break;
+    case JDA_MODE_422 * 2 + 1: run_tiles<JDA_MODE_422, true>(D, strips); break;
+    case JDA_MODE_440 * 2: run_tiles<JDA_MODE_440, false>(D, strips); break;
+    default: run_tiles<JDA_MODE_440, true>(D, strips); break;
     }
     const jda_image_info *I = jda_image_get_info(img);
     rc = (D.n_mcus_ok == (uint32_t)(I->mcus_x * I->mcus_y)) ? JDA_SUCCESS : JDA_DECODE_ERROR;

@@ -91,7 +91,8 @@ def test_clip_to_image_size(gpu_ctx, oracle):
     b.close(); d.close(); gpu_ctx.free(ptr)
 
 
-@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow"])
+@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow",
+                                  "c422_1100x24_rstrow", "c440_300x64_rst5"])
 def test_restart_marker_fast_path(name, gpu_ctx, oracle):
     """JDA_PREPARE_DEVICE_PRESCAN leaves the Huffman pre-scan of a stream with restart markers to
     the GPU (jda_upload: phase-map pass + exact pass, one lane per restart interval).  Same pixels as the

@@ -51,7 +51,8 @@ def test_wave_emulation_equals_oracle(name, hostsim, oracle):
         assert np.array_equal(got, want), (name, pt, opt, int(np.count_nonzero(got != want)))
 
 
-@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow"])
+@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow",
+                                  "c422_1100x24_rstrow", "c440_300x64_rst5"])
 def test_restart_interval_prescan_equals_oracle(name, hostsim, oracle):
     """with restart markers the per-block index is made by the device-side interval walk
     (jda_prescan_interval, one lane per restart interval) instead of the serial host pre-scan (two passes: window-phase map, then the exact walk).  The

@@ -19,6 +19,8 @@ def _compare_all_modes(jpeg, oracle, ref):
         for opt in OPTIONS:
             if inf["subsample"] == 0 and pt == RGB8888:
                 continue
+            if inf["subsample"] == 0x12 and pt == RGB8888 and (opt & 4):
+                continue                          # reference UB (jpeg.inl:4620 writes through the address of a local)
             r = ref.decode_cb(jpeg, pt, opt)
             rc, canvas, err = oracle.decode_canvas(jpeg, pt, opt)
             assert r["rc"] == 1 and rc == 1
