@@ -120,13 +120,15 @@ def main():
     prepared = [J.PreparedImage(j, device_prescan=args.device_prescan) for j in jpegs]
     t_prep = (time.perf_counter() - t_prep0) / len(jpegs)
     # the same on all host threads (jda_prepare_batch): what the host stage sustains for a batch
-    n_par = max(len(jpegs), min(4 * args.batch, 4 * (os.cpu_count() or 1)))
-    t_par0 = time.perf_counter()
-    par = J.prepare_batch([jpegs[i % len(jpegs)] for i in range(n_par)], device_prescan=args.device_prescan, threads=0)
-    t_par = (time.perf_counter() - t_par0) / n_par
-    for p_ in par:
-        p_.close()
-    del par
+    t_par = float("nan")
+    if world == 1:                                       # (N > 1: the ranks would only fight over the same host cores)
+        n_par = max(len(jpegs), min(4 * args.batch, 4 * (os.cpu_count() or 1)))
+        t_par0 = time.perf_counter()
+        par = J.prepare_batch([jpegs[i % len(jpegs)] for i in range(n_par)], device_prescan=args.device_prescan, threads=0)
+        t_par = (time.perf_counter() - t_par0) / n_par
+        for p_ in par:
+            p_.close()
+        del par
     geo = prepared[0].geometry(pt, args.options)
     pitch = (geo["canvas_w"] * geo["bpp"] + 15) & ~15
     img_bytes = pitch * geo["canvas_h"]
@@ -241,7 +243,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "host_prepare_ms_per_image": t_prep * 1e3,
-            "host_prepare_all_threads_ms_per_image": t_par * 1e3,
+            "host_prepare_all_threads_ms_per_image": (t_par * 1e3) if t_par == t_par else None,
             "host_threads": os.cpu_count(),
             "upload_ms_per_image": t_up * 1e3,
             "device_prescan": bool(dev_images[0].prescan_on_device),
