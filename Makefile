@@ -30,8 +30,13 @@ classshim: tests/libjpegdec_class_shim.so
 tests/libjpegdec_class_shim.so: oracle/ref_shim.cpp include/JPEGDEC.h $(LIB)
 	$(CXX) -O2 -std=c++17 -fPIC -shared -w -DSHIM_PRODUCT -Iinclude -o $@ oracle/ref_shim.cpp -Ljpegdec_amd -ljpegdec_amd -lpthread -Wl,-rpath,'$$ORIGIN/../jpegdec_amd'
 
+# a plain C program on the C flavour of the API (JPEG_openFile / JPEG_decode / ...), compiled with the C compiler
+cuser: tests/capi_c/c_user
+tests/capi_c/c_user: tests/capi_c/c_user.c include/JPEGDEC.h $(LIB)
+	$(CC) -std=c99 -O2 -Wall -Iinclude -o $@ tests/capi_c/c_user.c -Ljpegdec_amd -ljpegdec_amd -Wl,-rpath,'$$ORIGIN/../../jpegdec_amd'
+
 clean:
-	rm -f $(LIB) tests/hostsim/libjda_hostsim.so
+	rm -f $(LIB) tests/hostsim/libjda_hostsim.so tests/capi_c/c_user
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim classshim clean
+.PHONY: all lib oracle hostsim classshim cuser clean

@@ -116,4 +116,39 @@ class JPEGDEC {
 };
 
 #endif // __cplusplus
+
+// ---- the C flavour of the API (reference src/JPEGDEC.h:288-309, bodies src/jpeg.inl:564-739).  The reference
+// offers it to C translation units that include jpeg.inl; here the functions live in libjpegdec_amd.so and are
+// callable from C and C++ alike.  JPEGIMAGE is caller-allocated as in the reference (there: the 18 KB decoder
+// state; here: a small handle -- the state lives behind it and is released by JPEG_close or the next open).
+typedef struct jpeg_image_tag {
+    uint32_t magic;          /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
+    void *impl;
+} JPEGIMAGE;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int JPEG_openRAM(JPEGIMAGE *pJPEG, uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw);
+int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *pfnDraw);
+void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer);
+void JPEG_setCropArea(JPEGIMAGE *pJPEG, int x, int y, int w, int h);
+void JPEG_getCropArea(JPEGIMAGE *pJPEG, int *x, int *y, int *w, int *h);
+int JPEG_getWidth(JPEGIMAGE *pJPEG);
+int JPEG_getHeight(JPEGIMAGE *pJPEG);
+int JPEG_decode(JPEGIMAGE *pJPEG, int x, int y, int iOptions);
+int JPEG_decodeDither(JPEGIMAGE *pJPEG, uint8_t *pDither, int iOptions);
+void JPEG_close(JPEGIMAGE *pJPEG);
+int JPEG_getLastError(JPEGIMAGE *pJPEG);
+int JPEG_getOrientation(JPEGIMAGE *pJPEG);
+int JPEG_getBpp(JPEGIMAGE *pJPEG);
+int JPEG_getSubSample(JPEGIMAGE *pJPEG);
+int JPEG_hasThumb(JPEGIMAGE *pJPEG);
+int JPEG_getThumbWidth(JPEGIMAGE *pJPEG);
+int JPEG_getThumbHeight(JPEGIMAGE *pJPEG);
+void JPEG_setPixelType(JPEGIMAGE *pJPEG, int iType);
+void JPEG_setMaxOutputSize(JPEGIMAGE *pJPEG, int iMaxMCUs);
+#ifdef __cplusplus
+}
+#endif
 #endif

@@ -310,3 +310,49 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     if (partial || overrun) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
     return 1;
 }
+
+
+// ---- C flavour (reference src/jpeg.inl:564-739): thin wrappers over the class; the caller's JPEGIMAGE holds the object
+#define JPEGIMAGE_MAGIC 0x4a444131u   /* "JDA1" */
+static JPEGDEC *c_obj(JPEGIMAGE *p) { return (p && p->magic == JPEGIMAGE_MAGIC) ? (JPEGDEC *)p->impl : NULL; }
+static JPEGDEC *c_fresh(JPEGIMAGE *p)
+{
+    if (!p) return NULL;
+    if (p->magic == JPEGIMAGE_MAGIC && p->impl) delete (JPEGDEC *)p->impl;      // re-open: the reference memsets its state (:569)
+    p->impl = new (std::nothrow) JPEGDEC();
+    p->magic = p->impl ? JPEGIMAGE_MAGIC : 0;
+    return (JPEGDEC *)p->impl;
+}
+extern "C" {
+int JPEG_openRAM(JPEGIMAGE *pJPEG, uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw)
+{
+    JPEGDEC *j = c_fresh(pJPEG);
+    return j ? j->openRAM(pData, iDataSize, pfnDraw) : 0;
+}
+int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *pfnDraw)
+{
+    JPEGDEC *j = c_fresh(pJPEG);
+    return j ? j->open(szFilename, pfnDraw) : 0;
+}
+void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer) { if (JPEGDEC *j = c_obj(pJPEG)) j->setFramebuffer(pFramebuffer); }
+void JPEG_setCropArea(JPEGIMAGE *pJPEG, int x, int y, int w, int h) { if (JPEGDEC *j = c_obj(pJPEG)) j->setCropArea(x, y, w, h); }
+void JPEG_getCropArea(JPEGIMAGE *pJPEG, int *x, int *y, int *w, int *h) { if (JPEGDEC *j = c_obj(pJPEG)) j->getCropArea(x, y, w, h); }
+int JPEG_getWidth(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getWidth() : 0; }
+int JPEG_getHeight(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getHeight() : 0; }
+int JPEG_decode(JPEGIMAGE *pJPEG, int x, int y, int iOptions) { JPEGDEC *j = c_obj(pJPEG); return j ? j->decode(x, y, iOptions) : 0; }
+int JPEG_decodeDither(JPEGIMAGE *pJPEG, uint8_t *pDither, int iOptions) { JPEGDEC *j = c_obj(pJPEG); return j ? j->decodeDither(pDither, iOptions) : 0; }
+void JPEG_close(JPEGIMAGE *pJPEG)
+{
+    if (JPEGDEC *j = c_obj(pJPEG)) { j->close(); delete j; }
+    if (pJPEG) { pJPEG->impl = NULL; pJPEG->magic = 0; }
+}
+int JPEG_getLastError(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getLastError() : JPEG_INVALID_PARAMETER; }
+int JPEG_getOrientation(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getOrientation() : 0; }
+int JPEG_getBpp(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getBpp() : 0; }
+int JPEG_getSubSample(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getSubSample() : 0; }
+int JPEG_hasThumb(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->hasThumb() : 0; }
+int JPEG_getThumbWidth(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getThumbWidth() : 0; }
+int JPEG_getThumbHeight(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getThumbHeight() : 0; }
+void JPEG_setPixelType(JPEGIMAGE *pJPEG, int iType) { if (JPEGDEC *j = c_obj(pJPEG)) j->setPixelType(iType); }
+void JPEG_setMaxOutputSize(JPEGIMAGE *pJPEG, int iMaxMCUs) { if (JPEGDEC *j = c_obj(pJPEG)) j->setMaxOutputSize(iMaxMCUs); }
+}
