@@ -74,7 +74,10 @@ typedef struct jda_image_info {
     int32_t mcu_w, mcu_h;         /* MCU size in source pixels */
     int32_t mcus_x, mcus_y;       /* MCU grid (jpeg.inl:5013-5037) */
     int32_t scan_offset;          /* byte offset of the entropy-coded data */
-    int32_t blocks_per_mcu;       /* 1 gray, 3 for 4:4:4, 6 for 4:2:0 (Y.. Cb Cr in scan order) */
+    int32_t blocks_per_mcu;       /* 1 gray, 3 for 4:4:4, 4 for 4:2:2 / 4:4:0, 6 for 4:2:0 (Y.. Cb Cr in scan order) */
+    int32_t has_thumb;            /* EXIF IFD1 present (jpeg.inl:1667-1675) */
+    int32_t thumb_w, thumb_h;     /* EXIF tags 256 / 257 (0 when absent, as in the reference) */
+    int32_t thumb_offset;         /* file offset of the embedded thumbnail JPEG (tag 513 + TIFF base) */
 } jda_image_info;
 
 /* Header parse only.  Accept/reject rules follow JPEGParseInfo (jpeg.inl:1572-1785). */

@@ -22,7 +22,8 @@ class JdaError(RuntimeError):
 class ImageInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "ncomp", "subsample", "bpp", "jpeg_type", "restart_interval",
-        "orientation", "mcu_w", "mcu_h", "mcus_x", "mcus_y", "scan_offset", "blocks_per_mcu")]
+        "orientation", "mcu_w", "mcu_h", "mcus_x", "mcus_y", "scan_offset", "blocks_per_mcu",
+        "has_thumb", "thumb_w", "thumb_h", "thumb_offset")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -166,9 +166,9 @@ int JPEGDEC::getHeight() { return _jpeg->info.height; }
 int JPEGDEC::getBpp() { return _jpeg->info.bpp; }
 int JPEGDEC::getSubSample() { return _jpeg->info.subsample; }
 int JPEGDEC::getJPEGType() { return _jpeg->info.jpeg_type ? JPEG_MODE_PROGRESSIVE : JPEG_MODE_BASELINE; }
-int JPEGDEC::hasThumb() { return 0; }          // EXIF thumbnails: host-only metadata, not on this path
-int JPEGDEC::getThumbWidth() { return 0; }
-int JPEGDEC::getThumbHeight() { return 0; }
+int JPEGDEC::hasThumb() { return _jpeg->info.has_thumb; }
+int JPEGDEC::getThumbWidth() { return _jpeg->info.thumb_w; }
+int JPEGDEC::getThumbHeight() { return _jpeg->info.thumb_h; }
 int JPEGDEC::getPixelType() { return _jpeg->pixel_type; }
 
 void JPEGDEC::setPixelType(int iType)
@@ -200,7 +200,20 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     jpegdec_amd_state *s = _jpeg;
     s->xoff = x; s->yoff = y; s->options = iOptions;
     if (!s->opened) { s->error = JPEG_INVALID_PARAMETER; return 0; }
-    if (s->pixel_type > EIGHT_BIT_GRAYSCALE || (iOptions & JPEG_EXIF_THUMBNAIL)) { s->error = JPEG_UNSUPPORTED_FEATURE; return 0; }
+    if (s->pixel_type > EIGHT_BIT_GRAYSCALE) { s->error = JPEG_UNSUPPORTED_FEATURE; return 0; }
+    if (iOptions & JPEG_EXIF_THUMBNAIL) {              // jpeg.inl:4967-4976: decode the JPEG embedded in the EXIF block instead
+        if (s->info.thumb_offset == 0 || s->info.thumb_w == 0) { s->error = JPEG_INVALID_PARAMETER; return 0; }
+        if (s->info.thumb_offset >= s->size) { s->error = JPEG_INVALID_FILE; return 0; }
+        jda_image_info ti;
+        const int prc = jda_parse(s->data + s->info.thumb_offset, s->size - s->info.thumb_offset, &ti);   // JPEGParseInfo(pJPEG, 1)
+        if (prc != JDA_SUCCESS) { s->error = prc; return 0; }
+        // the reference parses the thumbnail over its own state: the object now describes the thumbnail
+        ti.has_thumb = s->info.has_thumb; ti.thumb_w = s->info.thumb_w; ti.thumb_h = s->info.thumb_h; ti.thumb_offset = 0;
+        s->data += s->info.thumb_offset; s->size -= s->info.thumb_offset;
+        s->info = ti;
+        s->crop_w = ti.width; s->crop_h = ti.height;
+        iOptions &= ~JPEG_EXIF_THUMBNAIL;
+    }
     const bool cropped = s->crop_x != 0 || s->crop_y != 0 || s->crop_w != s->info.width || s->crop_h != s->info.height;
     int pt = s->pixel_type;
     if ((iOptions & JPEG_LUMA_ONLY) && pt < EIGHT_BIT_GRAYSCALE) pt = s->pixel_type = EIGHT_BIT_GRAYSCALE;   // jpeg.inl:4991-4993

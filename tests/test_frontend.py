@@ -135,3 +135,21 @@ def test_cropped_draw_plan_matches_the_reference(ref_scalar):
                     assert np.array_equal(r["log"], plan[:, :6]), (name, crop, pt, opt)
                     checked += 1
     assert checked > 50
+
+
+@pytest.mark.needs_reference
+def test_exif_thumbnail_metadata_matches_the_reference(ref_scalar):
+    from jpegdec_amd.synth import synth_jpeg
+    from tests.exif_util import with_exif_thumbnail
+    main, th = synth_jpeg(160, 120, "4:2:0", seed=3), synth_jpeg(64, 48, "4:2:0", seed=4)
+    for be in (False, True):
+        for dims in (True, False):
+            for orient in (1, 6, 8):
+                j = with_exif_thumbnail(main, th, 64, 48, orientation=orient, big_endian=be, with_dims=dims)
+                info = ImageInfo()
+                assert load_library().jda_parse(j, len(j), C.byref(info)) == 0
+                r = ref_scalar.info(j)
+                assert (info.has_thumb, info.thumb_w, info.thumb_h, info.orientation) == (r["hasthumb"], r["thumbw"], r["thumbh"], r["orientation"])
+                assert j[info.thumb_offset:info.thumb_offset + 2] == b"\xff\xd8"
+    plain = ImageInfo()
+    assert load_library().jda_parse(main, len(main), C.byref(plain)) == 0 and plain.has_thumb == 0

@@ -135,3 +135,27 @@ def test_framebuffer_ragged_and_cropped(name, crop, product_class, ref_scalar):
             assert np.array_equal(fb_got[:n], fb_ref[:n]), (name, crop, pt, opt)
             checked += 1
     assert checked >= 6
+
+
+def test_exif_thumbnail(product_class, ref_scalar):
+    """hasThumb / getThumbWidth / getThumbHeight and decode(JPEG_EXIF_THUMBNAIL) (jpeg.inl:1654-1678, 4967-4976):
+    the embedded JPEG is decoded instead of the main image; without the IFD1 size tags the reference refuses."""
+    from jpegdec_amd.synth import synth_jpeg
+    from tests.exif_util import with_exif_thumbnail
+    main, th = synth_jpeg(320, 240, "4:2:0", seed=3), synth_jpeg(64, 48, "4:2:2", seed=4)
+    for be in (False, True):
+        j = with_exif_thumbnail(main, th, 64, 48, big_endian=be)
+        a, b = product_class.info(j), ref_scalar.info(j)
+        assert (a["hasthumb"], a["thumbw"], a["thumbh"], a["orientation"]) == (b["hasthumb"], b["thumbw"], b["thumbh"], b["orientation"]) == (1, 64, 48, 6)
+        for pt, opt in ((RGB8888, 32), (RGB565_LE, 32 | SCALE_HALF), (GRAY8, 32)):
+            ra = product_class.decode_cb(j, pt, opt, want_log=True)
+            rb = ref_scalar.decode_cb(j, pt, opt, want_log=True)
+            assert ra["rc"] == rb["rc"] == 1
+            assert np.array_equal(ra["log"], rb["log"])
+            assert np.array_equal(ra["canvas"][:48], rb["canvas"][:48]), (be, pt, opt)
+    j = with_exif_thumbnail(main, th, 64, 48, with_dims=False)
+    ra, rb = product_class.decode_cb(j, RGB8888, 32), ref_scalar.decode_cb(j, RGB8888, 32)
+    assert (ra["rc"], ra["last_error"]) == (rb["rc"], rb["last_error"]) == (0, 1)
+    # the main image still decodes as before
+    ra, rb = product_class.decode_cb(j, RGB8888, 0), ref_scalar.decode_cb(j, RGB8888, 0)
+    assert ra["rc"] == rb["rc"] == 1 and np.array_equal(ra["canvas"][:240], rb["canvas"][:240])
