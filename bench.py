@@ -248,6 +248,8 @@ def main():
             "upload_ms_per_image": t_up * 1e3,
             "device_prescan": bool(dev_images[0].prescan_on_device),
             "kernel_only_mpix_s": px_per_step / (kernel_ms * 1e-3) / 1e6,
+            # host prepare (all threads) + upload + kernel, one after the other (no overlap between the stages)
+            "end_to_end_mpix_s_no_overlap": (args.width * args.height / 1e6) / ((t_par if t_par == t_par else t_prep) + t_up + kernel_ms * 1e-3 / args.batch),
         }
         print(json.dumps(line))
 

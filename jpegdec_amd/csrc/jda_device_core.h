@@ -5,14 +5,15 @@
 // used ONLY by the unit tests to check the kernel logic where no GPU exists).  The product path
 // never runs this on the CPU.
 //
-// One wavefront decodes one "strip": up to 64 consecutive MCUs of one MCU row.
-//   phase A (lane = MCU, lane-private): for each block of the MCU
-//        Huffman/RLE expand into a lane-private 8x8 int16 block in LDS   <- JPEGDecodeMCU  jpeg.inl:2090-2274
-//        dequant + fixed-point IDCT + range limit -> 64 bytes in LDS     <- JPEGIDCT       jpeg.inl:2278-2798
-//                                                                           DC-only bypass jpeg.inl:5146-5154
-//   phase B (lanes tile the strip's output rows so that stores are coalesced)
-//        YCbCr -> RGB565/RGB8888/gray, chroma upsample, 1/2-1/4-1/8     <- JPEGPutMCU*    jpeg.inl:2799-4544
-//                                                                           JPEGPixel*     jpeg.inl:3101-3278
+// One wavefront decodes one tile: up to 64 consecutive 8x8 blocks of one MCU row (10 MCUs of 4:2:0).
+//   P1  lane = block: Huffman/RLE expand into the block's int16[64] slot in LDS   <- JPEGDecodeMCU  jpeg.inl:2090-2274
+//       + the wave builds the IDCT work lists (prefix sum / ballots)
+//   P2  lane = (block, non-empty column): dequant + IDCT column stage           <- JPEGIDCT       jpeg.inl:2553-2679
+//   P3  lane = (block, row): IDCT row stage + range limit -> 64 bytes in place   <- JPEGIDCT       jpeg.inl:2680-2797
+//                                                                                  DC-only bypass jpeg.inl:5146-5154
+//   P4  lanes tile the output rows: YCbCr -> RGB565/RGB8888/gray, chroma        <- JPEGPutMCU*    jpeg.inl:2799-4868
+//       upsample, 1/2-1/4-1/8, coalesced stores                                    JPEGPixel*     jpeg.inl:3101-3278
+// plus the per-restart-interval symbol walk of the device pre-scan (jda_prescan_interval).
 // The bit reader reproduces the reference's 64-bit window and refill rule exactly, so that the
 // low-bit truncation of SURVEY.md fact 6 is reproduced by construction.
 #ifndef JDA_DEVICE_CORE_H
@@ -260,18 +261,6 @@ JDA_HD int32_t jda_take_extend(uint64_t bits, uint32_t off, uint32_t s)
     const uint32_t top = (uint32_t)((bits << off) >> 32);      // zeros enter when off + s > 64
     const uint32_t v = top >> (32 - s);
     return (top & 0x80000000u) ? (int32_t)v : (int32_t)v - (int32_t)((1u << s) - 1u);
-}
-
-// LDS atomic add (list append); on the host emulator threads run one after another
-JDA_HD uint32_t jda_lds_add(uint32_t *p, uint32_t v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-    const uint32_t old = *p;
-    *p = old + v;
-    return old;
-#endif
 }
 
 // ---- wave-level combine (list building without LDS atomics) -------------------------------------
@@ -897,7 +886,7 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 //       work lists.  Scaled 1/4 and 1/8 outputs are finished here (2x2 IDCT or DC fill).
 //   P2  thread = (block, non-empty column): dequant + column stage of the IDCT (jpeg.inl:2553-2679).
 //       Empty columns cost nothing -- the reference's own shortcut (:2555-2560), made data-parallel
-//       by compacting the work items with LDS atomics.
+//       by compacting the work items (wave prefix sum / ballots, jda_p1_lists).
 //   P3  thread = (block, row): row stage + range limit (jpeg.inl:2680-2797), blocks grouped by the
 //       reference's row variant so that a pass never mixes variants.  8 samples -> the MCU's plane.
 //   P4  threads tile the output rows: colour conversion and coalesced stores (JPEGPutMCU*).

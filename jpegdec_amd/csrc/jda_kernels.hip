@@ -1,20 +1,20 @@
 // jda_kernels.hip -- gfx950 (CDNA4) kernels of the decode path.  Written for wave64 only.
 //
-// jda_decode_tiles<MODE, FAST>: a 256-thread workgroup = 4 independent wavefronts that share only
-// the image's tables in LDS; each wavefront decodes one tile = up to 64 consecutive 8x8 blocks of
-// one MCU row (10 MCUs of 4:2:0).  10.8 KB of LDS per wave + 6.7 KB of tables per workgroup ->
-// three workgroups (12 wavefronts) per CU.  After the tables are staged there is no workgroup
-// barrier: phases are separated by wave-local fences, so wavefronts drift freely.
-//   P0  Huffman LUTs (short halves), quantisers, zigzag -> LDS (per workgroup); the tile's slice of
-//       the filtered scan -> the wave's LDS window; coalesced 16-byte loads (compressed bytes leave
-//       HBM once);
+// jda_decode_tiles_persistent<MODE, FAST> (and the one-tile-per-wave jda_decode_tiles kept for profiling):
+// a workgroup is as many independent wavefronts as fit in a CU's LDS next to one copy of the image's
+// tables (16 x 9.8 KB + 6.8 KB for 4:2:0 = one 1024-thread workgroup per CU); each wavefront decodes one
+// tile = up to 64 consecutive 8x8 blocks of one MCU row (10 MCUs of 4:2:0).  After the tables are staged
+// there is no workgroup barrier: phases are separated by wave-local fences, so wavefronts drift freely.
 //   P1  lane = block: Huffman/RLE expand from the per-block index entry into the block's int16[64]
-//       in LDS (coefficients never touch HBM); blocks are classified and their non-empty columns
-//       appended to work lists with LDS atomics;
+//       in LDS (coefficients never touch HBM); the wave then builds the IDCT work lists with a DPP
+//       prefix sum and ballots (non-empty columns, row-variant classes);
 //   P2  lane = (block, non-empty column): dequant + IDCT column stage, in place;
 //   P3  lane = (block, row): IDCT row stage + range limit, grouped by the reference's row variant;
 //   P4  lanes tile the tile's output rows: YCbCr -> RGB and 16-byte stores to consecutive addresses.
-// No MFMA: the IDCT is shift/add integer work and the path is bound by the 4 B/pixel it writes.
+// While a wavefront decodes tile n it prefetches tile n+1's index entries and scan slice (HBM -> registers
+// -> LDS) and tile n+2's record.
+// jda_prescan_intervals<EXACT>: the device half of the pre-scan for streams with restart markers.
+// No MFMA: the IDCT is shift/add integer work; the decode kernel is bound by VALU issue.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
