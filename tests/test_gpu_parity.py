@@ -133,3 +133,33 @@ def test_restart_marker_fast_path(name, gpu_ctx, oracle):
     # a stream without markers: the flag changes nothing
     plain = J.PreparedImage(jpeg_for("c420_333x217"), device_prescan=True)
     assert not plain.prescan_pending
+
+
+def test_corrupted_scans_on_the_gpu(gpu_ctx, oracle):
+    """A few corrupted streams through the real kernels (the CPU suite runs many more through the wave emulator):
+    same verdict as the oracle, same pixels where it decodes, and nothing hangs."""
+    checked = 0
+    for name in ("c420_333x217", "c422_333x217", "c420_640x368_rstrow"):
+        base = bytearray(jpeg_for(name))
+        sos = bytes(base).index(b"\xff\xda")
+        rng = np.random.default_rng(31)
+        for it in range(12):
+            b = bytearray(base)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+            jb = bytes(b)
+            try:
+                p = J.PreparedImage(jb)
+            except J.JdaError:
+                continue
+            idx, nok = p.block_index()
+            over_read = (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan())
+            rc, got, g = J.decode_to_host(gpu_ctx, jb, J.RGB8888, 0)
+            orc, want, err = oracle.decode_canvas(jb, J.RGB8888, 0)
+            assert rc in (0, 2)
+            if not over_read:
+                assert (rc == 0) == (orc == 1), (name, it, rc, orc, err)
+                if orc == 1:
+                    assert np.array_equal(got, want), (name, it)
+                    checked += 1
+    assert checked >= 5

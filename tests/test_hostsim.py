@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import jpegdec_amd as J
 from tests.cases import SYNTH_CASES, all_modes, jpeg_for
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -77,3 +78,39 @@ def test_restart_interval_prescan_equals_oracle(name, hostsim, oracle):
         assert hostsim.hostsim_prescan_used() == 0 and np.array_equal(got, want)
     finally:
         hostsim.hostsim_set_device_prescan(0)
+
+
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "c422_333x217", "c420_640x368_rstrow"])
+def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
+    """The reference's fuzz idea (MacOS/JPEGDEC_Test/main.cpp:262-300) turned into a parity test: random byte
+    corruptions inside the entropy-coded data.  A corrupted scan usually still "decodes" -- to garbage that
+    exercises every odd path (runs past 63, 11-15 bit magnitudes, predictor wrap, stray markers) -- and the
+    kernel logic must produce the oracle's garbage bit for bit, and fail on the same streams.
+    Out of contract: a stream that runs out of data before the last MCU; the reference then
+    decodes whatever its 2 KiB file buffer still holds, here the image ends with JPEG_DECODE_ERROR."""
+    base = bytearray(jpeg_for(name))
+    sos = bytes(base).index(b"\xff\xda")
+    rng = np.random.default_rng(11)
+    agree = 0
+    for it in range(80):
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+        jb = bytes(b)
+        try:
+            p = J.PreparedImage(jb)
+        except J.JdaError:
+            continue
+        idx, nok = p.block_index()
+        if (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan()):
+            continue                                   # consumed more bits than the scan holds: out of contract
+        for pt, opt in ((2, 0), (0, 2)):
+            rc, want, err = oracle.decode_canvas(jb, pt, opt)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jb, pt, opt)
+            hrc = hostsim.hostsim_decode(jb, len(jb), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert (rc == 1) == (hrc == 0), (name, it, pt, opt, rc, err, hrc)
+            if rc == 1:
+                assert np.array_equal(got, want), (name, it, pt, opt)
+                agree += 1
+    assert agree >= 20

@@ -76,3 +76,36 @@ def test_closed_form_tables_equal_reference_literals(oracle):
         assert arr(nm) == [L.orc_range565(comp, i) for i in range(1024)], nm
     assert arr("iScaleBits") == [L.orc_aan_scale(i) for i in range(64)]
     assert arr("cZigZag2") == [L.orc_zigzag_to_natural(i) for i in range(64)]
+
+
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "gray_333x217", "c422_333x217", "c440_200x120"])
+def test_oracle_equals_reference_on_corrupted_scans(name, oracle, ref_scalar):
+    """Random byte corruptions inside the entropy-coded data: as long as the stream does not run out of bits the
+    oracle must reproduce the reference's output (garbage included) and its verdict.  (A stream that over-reads
+    makes the reference decode stale bytes of its 2 KiB file buffer: out of contract)"""
+    import jpegdec_amd as J
+    base = bytearray(jpeg_for(name))
+    sos = bytes(base).index(b"\xff\xda")
+    rng = np.random.default_rng(23)
+    checked = 0
+    for it in range(60):
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+        jb = bytes(b)
+        try:
+            p = J.PreparedImage(jb)
+        except J.JdaError:
+            continue
+        idx, nok = p.block_index()
+        if (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan()):
+            continue
+        pt = 3 if name.startswith("gray") else 2
+        r = ref_scalar.decode_cb(jb, pt, 0)
+        rc, canvas, err = oracle.decode_canvas(jb, pt, 0)
+        assert (r["rc"] == 1) == (rc == 1), (name, it, r["rc"], r["last_error"], rc, err)
+        if rc == 1:
+            h = ref_scalar.info(jb)["height"]
+            assert np.array_equal(canvas[:h], r["canvas"][:h, : canvas.shape[1]]), (name, it)
+            checked += 1
+    assert checked >= 10
