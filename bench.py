@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic images cycled through the batch")
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--height", type=int, default=4096)
-    ap.add_argument("--subsampling", default="4:2:0", choices=["4:2:0", "4:4:4", "gray"])
+    ap.add_argument("--subsampling", default="4:2:0", choices=["4:2:0", "4:4:4", "4:2:2", "gray"])
     ap.add_argument("--pixel-type", default="rgb8888", choices=["rgb8888", "rgb565", "gray8"])
     ap.add_argument("--options", type=int, default=0)
     ap.add_argument("--restart-rows", type=int, default=0, help="encode the inputs with a restart marker every N MCU rows (0 = none, the headline config)")

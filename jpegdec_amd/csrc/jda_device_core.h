@@ -1440,6 +1440,42 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
     }
 }
 
+// full-size 4:2:2 colour output (JPEGPutMCU21 full-size body, jpeg.inl:4839-4867): a work item is 4 pixels of one
+// row; pixels 0-1 share one chroma sample, pixels 2-3 the next
+template <int PT, bool CLIP>
+JDA_HD void jda_p4_422_full(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                            uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    const uint32_t groups = tile_w >> 2;                          // tile_w is a multiple of 16
+    const uint32_t inv = jda_recip22(groups);
+    uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
+    for (uint32_t i = t; i < groups * 8; i += JDA_TILE_THREADS) {
+        const uint32_t r = jda_umul24(i, inv) >> 22, g = i - jda_umul24(r, groups);
+        const uint32_t x4 = g * 4;
+        const uint32_t Y = y_base + r, X = x_base + x4;
+        if (CLIP && (Y >= D.out_rows || X >= D.out_w)) continue;
+        // MCU g>>2, luma block (g>>1)&1, columns (g&1)*4..; chroma row r, columns ((g>>1)&1)*4 + (g&1)*2 ..
+        const uint32_t po = jda_umul24(g >> 2, plane_stride);
+        const uint32_t yo = po + ((g >> 1) & 1u) * JDA_COEF_STRIDE + r * 8 + (g & 1u) * 4;
+        const uint32_t co = po + 2 * JDA_COEF_STRIDE + r * 8 + (g & 3u) * 2;
+        const uint32_t y = *(const jda_u32_alias *)(plane_base + yo);
+        const uint32_t cb2 = *(const uint16_t *)(plane_base + co), cr2 = *(const uint16_t *)(plane_base + co + JDA_COEF_STRIDE);
+        uint32_t v[4];
+        if (PT == JDA_RGB8888) {
+            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
+            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
+            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), d0.r, d0.g, d0.b, v[0], v[1]);
+            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), d1.r, d1.g, d1.b, v[2], v[3]);
+        } else {
+            const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
+            const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
+            v[0] = jda_rgb_pixel<PT>(y & 255u, c0);          v[1] = jda_rgb_pixel<PT>((y >> 8) & 255u, c0);
+            v[2] = jda_rgb_pixel<PT>((y >> 16) & 255u, c1);  v[3] = jda_rgb_pixel<PT>(y >> 24, c1);
+        }
+        jda_store4<PT, CLIP>(out + (size_t)Y * D.out_pitch, X, D.out_w, v);
+    }
+}
+
 // pixel type and clipping are decided once per tile (uniform), so the item loops are branch-free
 template <int MODE, bool CLIP>
 JDA_HD void jda_p4_full_colour(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
@@ -1450,6 +1486,10 @@ JDA_HD void jda_p4_full_colour(const jda_dev_desc &D, uint32_t t, const uint8_t 
         if (pt == JDA_RGB8888) jda_p4_420_full<JDA_RGB8888, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
         else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_420_full<JDA_RGB565_LITTLE_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
         else jda_p4_420_full<JDA_RGB565_BIG_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+    } else if (MODE == JDA_MODE_422) {
+        if (pt == JDA_RGB8888) jda_p4_422_full<JDA_RGB8888, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+        else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_422_full<JDA_RGB565_LITTLE_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
+        else jda_p4_422_full<JDA_RGB565_BIG_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
     } else {
         if (pt == JDA_RGB8888) jda_p4_444_full<JDA_RGB8888, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
         else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_444_full<JDA_RGB565_LITTLE_ENDIAN, CLIP>(D, t, plane_base, plane_stride, tile_w, x_base, y_base);
@@ -1499,7 +1539,7 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
     const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
     const uint8_t *plane_base = wl + L::PLANE_OFF;
     const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
-    if ((MODE == JDA_MODE_444 || MODE == JDA_MODE_420) && shift == 0 && colour_out) {      // specialised full-size colour paths
+    if ((MODE == JDA_MODE_444 || MODE == JDA_MODE_420 || MODE == JDA_MODE_422) && shift == 0 && colour_out) {      // specialised full-size colour paths
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;   // no clipping in this tile
         if (inside) jda_p4_full_colour<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_full_colour<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
