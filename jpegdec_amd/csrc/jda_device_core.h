@@ -1476,6 +1476,40 @@ JDA_HD void jda_p4_422_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
     }
 }
 
+// full-size 8-bit gray output of any source layout (JPEGPutMCU8BitGray full-size bodies, jpeg.inl:2828-2837,
+// :2893-2902, :2943-2952, :3000-3034): the luma samples are the pixels.  A work item is one row of one luma block
+// (8 bytes); items are dealt row-major so that consecutive lanes store consecutive 8-byte chunks.
+template <int MODE, bool CLIP>
+JDA_HD void jda_p4_gray8_full(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                              uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t nbx = (uint32_t)T::MCU_W / 8u;                 // luma blocks across an MCU: 1 or 2
+    const uint32_t chunks = tile_w >> 3;                          // 8-pixel chunks per row of the tile
+    const uint32_t inv = jda_recip22(chunks);
+    uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
+    const uint32_t pitch = D.out_pitch;
+    const uint32_t tile_off = y_base * pitch + x_base;
+    for (uint32_t i = t; i < chunks * (uint32_t)T::MCU_H; i += JDA_TILE_THREADS) {
+        const uint32_t r = jda_umul24(i, inv) >> 22, c = i - jda_umul24(r, chunks);
+        const uint32_t m = nbx == 2 ? (c >> 1) : c, bxq = nbx == 2 ? (c & 1u) : 0u;
+        const uint32_t q = (r >> 3) * nbx + bxq;                  // luma block inside the MCU
+        const jda_u32_alias *src = (const jda_u32_alias *)(plane_base + jda_umul24(m, plane_stride) + q * JDA_COEF_STRIDE + (r & 7u) * 8);
+        const uint32_t lo = src[0], hi = src[1];
+        const uint32_t X = x_base + c * 8, Y = y_base + r;
+        if (!CLIP) {
+            *(jda_u64_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + c * 8) = (uint64_t)lo | ((uint64_t)hi << 32);
+        } else {
+            if (Y >= D.out_rows || X >= D.out_w) continue;
+            uint8_t JDA_GLOBAL *row = out + (size_t)Y * pitch;
+            const uint32_t n = X + 8 <= D.out_w ? 8u : D.out_w - X;
+            const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+            if (n == 8) *(jda_u64_alias JDA_GLOBAL *)(row + X) = v;
+            else for (uint32_t j = 0; j < n; j++) row[X + j] = (uint8_t)(v >> (8 * j));
+        }
+    }
+}
+
 // pixel type and clipping are decided once per tile (uniform), so the item loops are branch-free
 template <int MODE, bool CLIP>
 JDA_HD void jda_p4_full_colour(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
@@ -1543,6 +1577,10 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;   // no clipping in this tile
         if (inside) jda_p4_full_colour<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_full_colour<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    } else if (shift == 0 && !colour_out) {                       // 8-bit gray, full size: the luma samples are the pixels
+        const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;
+        if (inside) jda_p4_gray8_full<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        else jda_p4_gray8_full<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
     } else
         jda_p4_generic<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
