@@ -17,4 +17,6 @@ run "C5  batch   16 x 8192x8192 gray  -> GRAY8 scale 1/8" --batch 16 --width 819
 run "metric batch 64 x 4096x4096 4:2:0 -> RGB8888" 
 run "metric, RGB565 output" --pixel-type rgb565
 run "metric, restart marker per MCU row + device pre-scan" --restart-rows 1 --device-prescan
+run "4096x4096 4:2:2 -> RGB8888" --subsampling 4:2:2
+run "metric image -> GRAY8" --pixel-type gray8
 cat $out
