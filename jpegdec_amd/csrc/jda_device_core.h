@@ -1076,9 +1076,13 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
 // list (:5146-5154).  Positions come from a wave prefix sum / ballots; order within a list is irrelevant.
 // all_flags: host emulation only (the flags of all 64 lanes).
 template <int MODE>
-JDA_HD void jda_p1_lists(uint32_t lane, uint32_t flags, const uint32_t *all_flags, uint8_t *wl)
+JDA_HD void jda_p1_lists(const jda_dev_desc &D, uint32_t lane, uint32_t flags, const uint32_t *all_flags, uint8_t *wl)
 {
+    typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
+    // a column item carries its block's quantiser table id, so that the column stage need not work it out per item
+    const uint32_t bq = lane % (uint32_t)T::NBLK;
+    const uint32_t qsel = jda_pick3(D.q_id, bq < (uint32_t)T::NLUMA ? 0u : bq - T::NLUMA + 1u) << 9;
     uint32_t *cnt = (uint32_t *)(wl + L::CNT_OFF);
     uint8_t *rowlist = wl + L::ROWLIST_OFF;
     uint16_t *collist = (uint16_t *)(wl + L::COLLIST_OFF);
@@ -1114,7 +1118,7 @@ JDA_HD void jda_p1_lists(uint32_t lane, uint32_t flags, const uint32_t *all_flag
     for (uint32_t col = 0; col < 8; col++) {
         const bool has = (colmask >> col) & 1u;
         uint16_t *dst = has ? collist + slot : scratch;
-        *dst = (uint16_t)((lane << 3) | col);
+        *dst = (uint16_t)(qsel | (lane << 3) | col);
         slot += has ? step : 0;
     }
     const uint32_t cls = !listed ? 4u : (flags == 0 ? 3u : ((flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u)));
@@ -1140,10 +1144,9 @@ JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, const uint8
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
-    const uint32_t blk = item >> 3, col = item & 7u;
-    const uint32_t b = blk % T::NBLK;
-    const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
-    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64 + col;
+    const uint32_t blk = (item >> 3) & 63u, col = item & 7u;      // item = quantiser table << 9 | block << 3 | column
+    (void)D; (void)sizeof(T);
+    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + (item >> 9) * 64 + col;
     int16_t *coef = (int16_t *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE) + col;
     int32_t cv[8], qv[8], r[8];
 #pragma unroll

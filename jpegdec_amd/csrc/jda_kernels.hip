@@ -104,7 +104,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     JDA_TRACE(3);
     uint32_t p1flags = JDA_NO_LIST;
     if (!(D.pad_[0] & 4)) p1flags = jda_p1_entropy<MODE>(D, C, p1in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
-    if (D.scale_shift < 2) jda_p1_lists<MODE>(lane, p1flags, nullptr, wl);
+    if (D.scale_shift < 2) jda_p1_lists<MODE>(D, lane, p1flags, nullptr, wl);
     JDA_WAVE_SYNC();
     JDA_TRACE(4);
     if (D.scale_shift < 2 && !(D.pad_[0] & 6)) {
@@ -234,7 +234,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 
         JDA_PTRACE(1);
         const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
-        if (D.scale_shift < 2) jda_p1_lists<MODE>(lane, p1flags, nullptr, wl);
+        if (D.scale_shift < 2) jda_p1_lists<MODE>(D, lane, p1flags, nullptr, wl);
         JDA_WAVE_SYNC();
         JDA_PTRACE(2);
 
