@@ -1349,6 +1349,36 @@ JDA_HD void jda_rgba_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t tb,
     px1 = jda_perm(b2, rg, 0x0d050302u);                          // [R1, G1, B1, 0xff]
 }
 
+// per 16-bit lane: clamp a signed value to 0..255 (v_pk_max_i16, v_pk_min_i16)
+JDA_HD uint32_t jda_pk_clamp255(uint32_t a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short jda_s2 __attribute__((ext_vector_type(2)));
+    jda_s2 v = __builtin_bit_cast(jda_s2, a);
+    const jda_s2 lo = { 0, 0 }, hi = { 255, 255 };
+    v = __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi);
+    return __builtin_bit_cast(uint32_t, v);
+#else
+    int32_t l = (int16_t)(a & 0xffffu), h = (int16_t)(a >> 16);
+    l = l < 0 ? 0 : (l > 255 ? 255 : l); h = h < 0 ? 0 : (h > 255 ? 255 : h);
+    return (uint32_t)l | ((uint32_t)h << 16);
+#endif
+}
+// Two horizontally adjacent RGB565 pixels at once (JPEGPixelLE / BE, jpeg.inl:3101-3156): pixel 0 in bits 15:0,
+// pixel 1 in bits 31:16.  The reference indexes 10-bit-wrapping tables with (Y + term) & 0x3ff; for 8-bit
+// samples Y + term stays inside -227..480, where the wrap is the identity, so the tables reduce to a clamp
+// and the field extraction (r >> 3) << 11 | (g >> 2) << 5 | b >> 3 works on both 16-bit lanes of a word.
+template <int PT>
+JDA_HD uint32_t jda_565_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t tb)
+{
+    const uint32_t r2 = jda_pk_clamp255(jda_pk_add16(ypair, tr));
+    const uint32_t g2 = jda_pk_clamp255(jda_pk_add16(ypair, tg));
+    const uint32_t b2 = jda_pk_clamp255(jda_pk_add16(ypair, tb));
+    uint32_t v = ((r2 & 0x00f800f8u) << 8) | ((g2 & 0x00fc00fcu) << 3) | ((b2 >> 3) & 0x001f001fu);
+    if (PT == JDA_RGB565_BIG_ENDIAN) v = jda_perm(0, v, 0x02030001u);      // swap the bytes of each pixel (:3149)
+    return v;
+}
+
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
 // pixel group (the two rows share their chroma samples); items are dealt to the threads in row-major
 // order so that consecutive threads store consecutive 16-byte groups.
@@ -1384,13 +1414,15 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
             jda_rgba_pair(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b, v0[2], v0[3]);
             jda_rgba_pair(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b, v1[0], v1[1]);
             jda_rgba_pair(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b, v1[2], v1[3]);
-        } else {
-            const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
-            const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
-            v0[0] = jda_rgb_pixel<PT>(ya & 255u, c0);          v0[1] = jda_rgb_pixel<PT>((ya >> 8) & 255u, c0);
-            v0[2] = jda_rgb_pixel<PT>((ya >> 16) & 255u, c1);  v0[3] = jda_rgb_pixel<PT>(ya >> 24, c1);
-            v1[0] = jda_rgb_pixel<PT>(yb & 255u, c0);          v1[1] = jda_rgb_pixel<PT>((yb >> 8) & 255u, c0);
-            v1[2] = jda_rgb_pixel<PT>((yb >> 16) & 255u, c1);  v1[3] = jda_rgb_pixel<PT>(yb >> 24, c1);
+        } else {                                                  // RGB565: v[0], v[2] hold pixel pairs
+            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
+            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
+            const uint32_t a01 = jda_565_pair<PT>(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b);
+            const uint32_t a23 = jda_565_pair<PT>(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b);
+            const uint32_t b01 = jda_565_pair<PT>(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b);
+            const uint32_t b23 = jda_565_pair<PT>(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b);
+            v0[0] = a01 & 0xffffu; v0[1] = a01 >> 16; v0[2] = a23 & 0xffffu; v0[3] = a23 >> 16;
+            v1[0] = b01 & 0xffffu; v1[1] = b01 >> 16; v1[2] = b23 & 0xffffu; v1[3] = b23 >> 16;
         }
         if (!CLIP) {                                              // whole groups, 16 / 8 bytes per row
             const uint32_t off = tile_off + jda_umul24(rp, 2 * pitch) + x4 * bpp, off1 = off + pitch;
@@ -1470,10 +1502,11 @@ JDA_HD void jda_p4_422_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
             jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), d0.r, d0.g, d0.b, v[0], v[1]);
             jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), d1.r, d1.g, d1.b, v[2], v[3]);
         } else {
-            const jda_chroma c0 = jda_chroma_terms(cb2 & 255u, cr2 & 255u);
-            const jda_chroma c1 = jda_chroma_terms(cb2 >> 8, cr2 >> 8);
-            v[0] = jda_rgb_pixel<PT>(y & 255u, c0);          v[1] = jda_rgb_pixel<PT>((y >> 8) & 255u, c0);
-            v[2] = jda_rgb_pixel<PT>((y >> 16) & 255u, c1);  v[3] = jda_rgb_pixel<PT>(y >> 24, c1);
+            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
+            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
+            const uint32_t a01 = jda_565_pair<PT>(jda_perm(0, y, 0x0c010c00u), d0.r, d0.g, d0.b);
+            const uint32_t a23 = jda_565_pair<PT>(jda_perm(0, y, 0x0c030c02u), d1.r, d1.g, d1.b);
+            v[0] = a01 & 0xffffu; v[1] = a01 >> 16; v[2] = a23 & 0xffffu; v[3] = a23 >> 16;
         }
         jda_store4<PT, CLIP>(out + (size_t)Y * D.out_pitch, X, D.out_w, v);
     }
