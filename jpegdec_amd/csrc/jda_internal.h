@@ -52,11 +52,14 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     uint8_t pad_[1];
 };
 
-struct jda_strip {                // one wavefront's tile: <= 64 consecutive blocks (10/21/64 MCUs) of one MCU row
+struct jda_strip {                // one wavefront's tile: <= 64 consecutive blocks (10/21/64 MCUs) of one MCU row; 16 bytes
     uint32_t image;               // index into the descriptor array
-    uint32_t mcu_y;
-    uint32_t mcu_x0;
-    uint32_t count;               // MCUs in the tile (0 = padding entry)
+    uint16_t mcu_y;               // (a JPEG has at most 65535 / 8 MCU rows and columns)
+    uint16_t mcu_x0;
+    uint8_t count;                // MCUs in the tile (0 = padding entry)
+    uint8_t first;                // 1: the first tile of its image (the wavefront that draws it restages the tables)
+    uint16_t pad_;
+    uint32_t ord;                 // position of the image among the images of this launch's tile list (0, 1, 2, ..)
 };
 
 #endif

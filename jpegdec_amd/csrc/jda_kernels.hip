@@ -19,6 +19,9 @@
 #include <stdlib.h>
 
 __device__ unsigned long long *g_jda_trace = nullptr;
+// optional per-wave start/finish stamps of the persistent kernel (profiling aid, tools/wg_balance.py): the constant
+// 100 MHz clock (s_memrealtime) at entry and exit of every wave -> how evenly the static tile split loads the CUs
+__device__ unsigned long long *g_jda_wgtrace = nullptr;
 // inside P1 (lane 0 of wave 0 of every 16th workgroup; the last tile decoded wins).  Costs a global load per
 // hook, so only in -DJDA_PROFILE_P1 builds.
 #ifdef JDA_PROFILE_P1
@@ -70,6 +73,23 @@ __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
     return L;
 }
 
+// a tile record (16 bytes, wave-uniform address) -> SGPRs
+__device__ __forceinline__ jda_strip jda_unpack_record(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    jda_strip S;
+    S.image = jda_uni32(w0);
+    const uint32_t yx = jda_uni32(w1), cf = jda_uni32(w2);
+    S.mcu_y = (uint16_t)(yx & 0xffffu); S.mcu_x0 = (uint16_t)(yx >> 16);
+    S.count = (uint8_t)(cf & 0xffu); S.first = (uint8_t)((cf >> 8) & 0xffu); S.pad_ = 0;
+    S.ord = jda_uni32(w3);
+    return S;
+}
+__device__ __forceinline__ jda_strip jda_load_record(const jda_strip *tp)
+{
+    const uint32_t JDA_GLOBAL *w = JDA_G(const uint32_t, tp);
+    return jda_unpack_record(w[0], w[1], w[2], w[3]);
+}
+
 template <int MODE, bool FAST>
 __global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
 void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles)
@@ -81,12 +101,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     JDA_TRACE(0);
 
     // tile record and image descriptor are wave-uniform: keep them in SGPRs
-    const jda_strip *tp = tiles + (size_t)blockIdx.x * jda_lds_layout<MODE>::WAVES + wave;
-    jda_strip S;
-    S.image = __builtin_amdgcn_readfirstlane(tp->image);
-    S.mcu_y = __builtin_amdgcn_readfirstlane(tp->mcu_y);
-    S.mcu_x0 = __builtin_amdgcn_readfirstlane(tp->mcu_x0);
-    S.count = __builtin_amdgcn_readfirstlane(tp->count);
+    const jda_strip S = jda_load_record(tiles + (size_t)blockIdx.x * jda_lds_layout<MODE>::WAVES + wave);
     const jda_dev_desc D = jda_desc_uniform(descs + S.image);   // the four tiles of a workgroup belong to one image
     jda_tile_ctx C = jda_tile_setup<MODE>(D, S);
     C.count = __builtin_amdgcn_readfirstlane(C.count);
@@ -137,27 +152,22 @@ static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint
 
 
 // ------------------------------------------------------------------------------------------------
-// Persistent variant (the default): the grid is sized to what is resident (3 workgroups per CU) and
-// every workgroup walks a contiguous run of tile quads.  While a wavefront decodes tile j it fetches
-// what tile j+1 needs -- per-lane index entries during the entropy phase, the scan slice during the
-// column stage -- and the record of tile j+2, so a tile never waits on the record -> index -> scan chain
-// (three dependent HBM latencies, ~18 % of a tile's life in the one-tile-per-workgroup kernel) and
-// the tables are staged once per image, not once per workgroup.
-template <int MODE> struct jda_next_tile {
-    jda_strip S;
-    jda_p1_inputs in;
-    uint32_t ix_end;
-};
-
+// Persistent variant (the default): one workgroup per CU (sized by LDS), each given a contiguous run of the
+// batch's tiles.  The wavefronts of a workgroup DRAW their tiles from that run through a counter in LDS: the
+// SIMD arbiter does not share issue slots fairly, so with a fixed tile list per wavefront some wavefronts were
+// done after 65 % of the kernel's time and their SIMDs ran the rest under-occupied (tools/wg_balance.py).
+// While a wavefront decodes tile j it fetches what tile j+1 needs -- per-lane index entries during the entropy
+// phase, the scan slice during the column stage -- and draws tile j+2 and loads its record, so a tile never
+// waits on the record -> index -> scan chain (three dependent HBM latencies).  The tables in LDS belong to one
+// image; tiles are drawn in order, so every wavefront meets an image boundary of the run exactly once: all
+// wait at a barrier, the wavefront that drew the new image's first tile restages the tables, second barrier.
+// A wavefront that runs out of tiles still walks the remaining boundaries (the barrier counts every wave).
 template <int MODE>
-__device__ __forceinline__ jda_strip jda_load_record(const jda_strip *tp)
+__device__ __forceinline__ uint32_t jda_draw_tile(uint32_t *ctr, uint32_t lane)
 {
-    jda_strip S;
-    S.image = __builtin_amdgcn_readfirstlane(tp->image);
-    S.mcu_y = __builtin_amdgcn_readfirstlane(tp->mcu_y);
-    S.mcu_x0 = __builtin_amdgcn_readfirstlane(tp->mcu_x0);
-    S.count = __builtin_amdgcn_readfirstlane(tp->count);
-    return S;
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(ctr, 1u);            // ds_add_rtn_u32
+    return jda_uni32(v);
 }
 
 // per-lane index / DC entries of a tile + the entry just past it (for the window bounds)
@@ -180,6 +190,16 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
     if (nb) ix_end = JDA_G(const uint32_t, D.blk_index)[first_block + nb];     // uniform address
 }
 
+// Bring the staged tables up to image `target` of the run (see above).  P / DP: the tile this wavefront is about
+// to decode and its image's descriptor (have == false: the wavefront has no tile left).
+#define JDA_ADVANCE_TABLES(target, have, P, DP)                                                         \
+    while (staged < (target)) {                                                                           \
+        __syncthreads();                              /* nobody reads the old tables any more */          \
+        if ((have) && (P).first && (P).ord == staged + 1u) jda_p0_tables((DP), lane, 64u, tab);           \
+        __syncthreads();                                                                                  \
+        staged++;                                                                                         \
+    }
+
 template <int MODE, bool FAST>
 __global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
 void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads)
@@ -188,17 +208,34 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     typedef jda_lds_layout<MODE> L;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t per = (n_quads + gridDim.x - 1) / gridDim.x;
-    uint32_t q = blockIdx.x * per;
-    const uint32_t q_end = q + per < n_quads ? q + per : n_quads;
-    if (q >= q_end) return;
+    const uint32_t q0 = blockIdx.x * per;
+    const uint32_t q_end = q0 + per < n_quads ? q0 + per : n_quads;
+    if (q0 >= q_end) return;
+    const uint32_t t_begin = q0 * (uint32_t)L::WAVES, t_end = q_end * (uint32_t)L::WAVES;   // this workgroup's run of tiles
+    unsigned long long *wgtrace = g_jda_wgtrace;
+    if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u] = wall_clock64();
     uint8_t *tab = lds;
     uint8_t *wl = lds + JDA_LT_BYTES + wave * L::WAVE_BYTES;
+    uint32_t *ctr = (uint32_t *)(lds + JDA_LT_BYTES + L::WAVES * L::WAVE_BYTES);            // the run's draw counter
 
-    // ---- prologue: everything for the first tile
-    jda_strip S = jda_load_record<MODE>(tiles + (size_t)q * jda_lds_layout<MODE>::WAVES + wave);
-    jda_dev_desc Dc = jda_desc_uniform(descs + S.image);
-    uint32_t staged_image = S.image;
+    // ---- prologue: the tables of the run's first image, the counter
+    if (threadIdx.x == 0) *ctr = t_begin;
+    const jda_strip R0 = jda_load_record(tiles + t_begin);
+    uint32_t staged = R0.ord;                                                            // image (ordinal) whose tables are in LDS
+    const uint32_t last_ord = jda_load_record(tiles + (t_end - 1u)).ord;
+    jda_dev_desc Dc = jda_desc_uniform(descs + R0.image);
     jda_p0_tables(Dc, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
+    __syncthreads();                                  // tables staged, counter set
+
+    uint32_t i_cur = jda_draw_tile<MODE>(ctr, lane);
+    if (i_cur >= t_end) {                             // more wavefronts than tiles: only keep the barriers company
+        jda_strip none = R0;
+        JDA_ADVANCE_TABLES(last_ord, false, none, Dc);
+        return;
+    }
+    uint32_t i_nxt = jda_draw_tile<MODE>(ctr, lane);
+    jda_strip S = jda_load_record(tiles + i_cur);
+    if (S.image != R0.image) Dc = jda_desc_uniform(descs + S.image);
     jda_p1_inputs in;
     uint32_t ix_end;
     jda_issue_index_loads<MODE>(Dc, S, lane, in, ix_end);
@@ -208,22 +245,23 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
     jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane));
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
-    __syncthreads();                                  // tables staged
-
-    // the record of the tile after this one (wave-uniform)
     jda_strip Sn = S;
-    if (q + 1 < q_end) Sn = jda_load_record<MODE>(tiles + (size_t)(q + 1) * jda_lds_layout<MODE>::WAVES + wave);
+    if (i_nxt < t_end) Sn = jda_load_record(tiles + i_nxt);
+    JDA_ADVANCE_TABLES(S.ord, true, S, Dc);
+    JDA_WAVE_SYNC();
 
     unsigned long long *trace = (blockIdx.x % JDA_TRACE_STRIDE == 0) ? g_jda_trace : nullptr;
     uint32_t iter = 0;
     for (;;) {
         const jda_dev_desc &D = Dc;
         JDA_PTRACE(0);
-        const bool have_next = q + 1 < q_end;
-        // stage A: the record two tiles ahead (a wave-uniform 16-byte load, consumed at the bottom of the loop)
-        const jda_strip *np_ = tiles + (size_t)(q + 2) * jda_lds_layout<MODE>::WAVES + wave;
+        const bool have_next = i_nxt < t_end;
+        // stage A: draw the tile after the next one and start loading its record (wave-uniform 16 bytes, consumed at
+        // the bottom of the loop)
+        uint32_t i_nn = t_end;
+        if (have_next) i_nn = jda_draw_tile<MODE>(ctr, lane);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        if (q + 2 < q_end) { r0 = np_->image; r1 = np_->mcu_y; r2 = np_->mcu_x0; r3 = np_->count; }
+        if (i_nn < t_end) { const uint32_t JDA_GLOBAL *w = JDA_G(const uint32_t, tiles + i_nn); r0 = w[0]; r1 = w[1]; r2 = w[2]; r3 = w[3]; }
         // stage B: per-lane index entries of the next tile; in flight during this tile's entropy phase
         jda_dev_desc Dn = Dc;
         if (have_next && Sn.image != S.image) Dn = jda_desc_uniform(descs + Sn.image);    // image boundary (uniform branch)
@@ -274,23 +312,19 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         JDA_PTRACE(7);
         iter++;
         if (!have_next) break;
-        if (Sn.image != staged_image) {               // image boundary (same for all four waves of the quad)
-            __syncthreads();
-            jda_p0_tables(Dn, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
-            __syncthreads();
-            staged_image = Sn.image;
-        }
-        S = Sn; C = Cn; in = inn; Dc = Dn; q++;
-        Sn.image = __builtin_amdgcn_readfirstlane(r0); Sn.mcu_y = __builtin_amdgcn_readfirstlane(r1);
-        Sn.mcu_x0 = __builtin_amdgcn_readfirstlane(r2); Sn.count = __builtin_amdgcn_readfirstlane(r3);
+        JDA_ADVANCE_TABLES(Sn.ord, true, Sn, Dn);     // image boundary: every wavefront of the workgroup passes here once
+        S = Sn; C = Cn; in = inn; Dc = Dn; i_nxt = i_nn;
+        Sn = jda_unpack_record(r0, r1, r2, r3);
         JDA_WAVE_SYNC();
     }
+    JDA_ADVANCE_TABLES(last_ord, false, S, Dc);        // boundaries after this wavefront's last tile
+    if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u + 1u] = wall_clock64();
 }
 
 template <int MODE, bool FAST>
 static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    const int lds_bytes = JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES;
+    const int lds_bytes = JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16;   // + the draw counter
     static int grid_cap = 0;
     if (!grid_cap) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST>,
@@ -347,6 +381,11 @@ extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint3
     if (exact) hipLaunchKernelGGL(jda_prescan_intervals<true>, grid, block, 0, stream, params);
     else hipLaunchKernelGGL(jda_prescan_intervals<false>, grid, block, 0, stream, params);
     return hipGetLastError();
+}
+
+extern "C" hipError_t jda_internal_set_wgtrace(unsigned long long *dev_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_wgtrace), &dev_buf, sizeof(dev_buf));
 }
 
 extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)

@@ -79,16 +79,22 @@ inline uint32_t jda_mcus_per_tile(int mode)
 inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode)
 {
     const uint32_t per = jda_mcus_per_tile(mode);
+    const uint32_t ord = v.empty() ? 0u : v.back().ord + 1u;      // images are appended one after the other
+    bool first = true;
     for (uint32_t y = 0; y < mcus_y; y++)
         for (uint32_t x = 0; x < mcus_x; x += per) {
             jda_strip s;
-            s.image = image; s.mcu_y = y; s.mcu_x0 = x;
-            s.count = mcus_x - x < per ? mcus_x - x : per;
+            memset(&s, 0, sizeof(s));
+            s.image = image; s.mcu_y = (uint16_t)y; s.mcu_x0 = (uint16_t)x;
+            s.count = (uint8_t)(mcus_x - x < per ? mcus_x - x : per);
+            s.first = first ? 1 : 0; s.ord = ord;
+            first = false;
             v.push_back(s);
         }
     while (v.size() % jda_tiles_per_wg(mode)) {
         jda_strip s;
-        s.image = image; s.mcu_y = 0; s.mcu_x0 = 0; s.count = 0;
+        memset(&s, 0, sizeof(s));
+        s.image = image; s.ord = ord;
         v.push_back(s);
     }
 }
