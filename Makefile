@@ -7,7 +7,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 CXX   ?= g++
 ARCH  ?= gfx950
 CSRC  = jpegdec_amd/csrc
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fwrapv -pthread -Wall -Wno-unused-function -Iinclude
+EXTRA ?=
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fwrapv -pthread -Wall -Wno-unused-function -Iinclude $(EXTRA)
 LIB = jpegdec_amd/libjpegdec_amd.so
 LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
 LIB_DEPS = $(LIB_SRCS) $(CSRC)/jda_internal.h $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h include/jpegdec_amd.h include/JPEGDEC.h

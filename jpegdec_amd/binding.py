@@ -41,7 +41,8 @@ class BatchStats(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjpegdec_amd.so")
+    # JDA_LIBRARY: another build of the same library (kernel A/B runs on the GPU box, tools/gpu_ab.sh)
+    return os.environ.get("JDA_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjpegdec_amd.so")
 
 
 _lib = None

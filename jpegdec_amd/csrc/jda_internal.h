@@ -42,14 +42,19 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     uint32_t mcus_x, mcus_y;
     uint32_t n_mcus_ok;           // MCUs the pre-scan validated (others are not decoded)
     uint32_t scan_len;
-    uint8_t mode;                 // JDA_MODE_*
-    uint8_t ncomp;
-    uint8_t pixel_type;           // JDA_RGB565_* / RGB8888 / EIGHT_BIT_GRAYSCALE (after LUMA_ONLY folding)
-    uint8_t scale_shift;          // 0..3
-    uint8_t dc_id[3], ac_id[3], q_id[3];
-    uint8_t gray_from_color;      // colour JPEG decoded to GRAY8: chroma blocks are not decoded
-    uint8_t fast_mul;             // 1: every IDCT multiply operand fits 24 bits (host-checked bound)
-    uint8_t pad_[1];
+    union {                       // 16 bytes of small fields; the kernels carry them as four dwords in SGPRs (cfg)
+        struct {
+            uint8_t mode;                 // JDA_MODE_*
+            uint8_t ncomp;
+            uint8_t pixel_type;           // JDA_RGB565_* / RGB8888 / EIGHT_BIT_GRAYSCALE (after LUMA_ONLY folding)
+            uint8_t scale_shift;          // 0..3
+            uint8_t dc_id[3], ac_id[3], q_id[3];
+            uint8_t gray_from_color;      // colour JPEG decoded to GRAY8: chroma blocks are not decoded
+            uint8_t fast_mul;             // 1: every IDCT multiply operand fits 24 bits (host-checked bound)
+            uint8_t pad_[1];
+        };
+        uint32_t cfg[4];
+    };
 };
 
 struct jda_strip {                // one wavefront's tile: <= 64 consecutive blocks (10/21/64 MCUs) of one MCU row; 16 bytes

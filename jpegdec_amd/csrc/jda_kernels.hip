@@ -36,7 +36,11 @@ __device__ unsigned long long *g_jda_wgtrace = nullptr;
 #define JDA_TRACE(slot) do { if (trace && lane == 0 && wave < 4) trace[(blockIdx.x / JDA_TRACE_STRIDE * 4 + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 
 // the same inside the persistent kernel: the second tile a traced workgroup decodes (steady state)
+#ifdef JDA_PHASE_TRACE      // (make lib EXTRA=-DJDA_PHASE_TRACE; the stamps cost SGPRs, so they are not in the product build)
 #define JDA_PTRACE(slot) do { if (trace && iter == 1 && lane == 0 && wave < 4) trace[(blockIdx.x / JDA_TRACE_STRIDE * 4 + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define JDA_PTRACE(slot) ((void)0)
+#endif
 
 // wave-local phase boundary: LDS operations of one wavefront complete in order, so ordering the
 // compiler is all that is needed -- no s_barrier
@@ -62,14 +66,8 @@ __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
     L.out_pitch = jda_uni32(g->out_pitch); L.out_w = jda_uni32(g->out_w); L.out_rows = jda_uni32(g->out_rows);
     L.mcus_x = jda_uni32(g->mcus_x); L.mcus_y = jda_uni32(g->mcus_y); L.n_mcus_ok = jda_uni32(g->n_mcus_ok);
     L.scan_len = jda_uni32(g->scan_len);
-    L.mode = (uint8_t)jda_uni32(g->mode); L.ncomp = (uint8_t)jda_uni32(g->ncomp);
-    L.pixel_type = (uint8_t)jda_uni32(g->pixel_type); L.scale_shift = (uint8_t)jda_uni32(g->scale_shift);
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        L.dc_id[i] = (uint8_t)jda_uni32(g->dc_id[i]); L.ac_id[i] = (uint8_t)jda_uni32(g->ac_id[i]); L.q_id[i] = (uint8_t)jda_uni32(g->q_id[i]);
-    }
-    L.gray_from_color = (uint8_t)jda_uni32(g->gray_from_color); L.fast_mul = (uint8_t)jda_uni32(g->fast_mul);
-    L.pad_[0] = (uint8_t)jda_uni32(g->pad_[0]);
+    for (int i = 0; i < 4; i++) L.cfg[i] = jda_uni32(g->cfg[i]);      // mode .. pad_: sixteen byte fields in four SGPRs
     return L;
 }
 
@@ -237,25 +235,37 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     jda_strip S = jda_load_record(tiles + i_cur);
     if (S.image != R0.image) Dc = jda_desc_uniform(descs + S.image);
     jda_p1_inputs in;
-    uint32_t ix_end;
-    jda_issue_index_loads<MODE>(Dc, S, lane, in, ix_end);
-    jda_tile_ctx C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ix_end));
-    C.count = __builtin_amdgcn_readfirstlane(C.count);
-    C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
-    C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
-    jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane));
+    jda_tile_ctx C;
+    // everything a tile needs before its P1, fetched with nothing to overlap it (first tile of a wavefront, first
+    // tile after an image boundary): index entries -> window bounds -> scan slice into the LDS window
+#define JDA_TILE_COLD_START()                                                                                     \
+    do {                                                                                                          \
+        uint32_t ixe_;                                                                                            \
+        jda_issue_index_loads<MODE>(Dc, S, lane, in, ixe_);                                                       \
+        C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ixe_)); \
+        C.count = __builtin_amdgcn_readfirstlane(C.count);                                                        \
+        C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);                                                      \
+        C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);                                                    \
+        jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane)); \
+    } while (0)
+    JDA_TILE_COLD_START();
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
     jda_strip Sn = S;
     if (i_nxt < t_end) Sn = jda_load_record(tiles + i_nxt);
     JDA_ADVANCE_TABLES(S.ord, true, S, Dc);
     JDA_WAVE_SYNC();
 
+#ifdef JDA_PHASE_TRACE
     unsigned long long *trace = (blockIdx.x % JDA_TRACE_STRIDE == 0) ? g_jda_trace : nullptr;
     uint32_t iter = 0;
+#endif
     for (;;) {
         const jda_dev_desc &D = Dc;
         JDA_PTRACE(0);
         const bool have_next = i_nxt < t_end;
+        // the software pipeline runs inside an image; the first tile of the next image starts cold (below) -- keeping a
+        // second descriptor in SGPRs for that one tile cost more (SGPR spills) than the overlap was worth
+        const bool pipelined = have_next && Sn.image == S.image;
         // stage A: draw the tile after the next one and start loading its record (wave-uniform 16 bytes, consumed at
         // the bottom of the loop)
         uint32_t i_nn = t_end;
@@ -263,12 +273,10 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         if (i_nn < t_end) { const uint32_t JDA_GLOBAL *w = JDA_G(const uint32_t, tiles + i_nn); r0 = w[0]; r1 = w[1]; r2 = w[2]; r3 = w[3]; }
         // stage B: per-lane index entries of the next tile; in flight during this tile's entropy phase
-        jda_dev_desc Dn = Dc;
-        if (have_next && Sn.image != S.image) Dn = jda_desc_uniform(descs + Sn.image);    // image boundary (uniform branch)
         jda_p1_inputs inn;
         uint32_t ixn_end = 0;
         inn.lb = lane; inn.ix = 0; inn.pred = 0; inn.active = false;
-        if (have_next) jda_issue_index_loads<MODE>(Dn, Sn, lane, inn, ixn_end);
+        if (pipelined) jda_issue_index_loads<MODE>(D, Sn, lane, inn, ixn_end);
 
         JDA_PTRACE(1);
         const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
@@ -282,12 +290,12 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         jda_chunk16 chunk;
         chunk.w[0] = chunk.w[1] = chunk.w[2] = chunk.w[3] = 0;
         asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end));      // the index loads have landed: settle their waits here
-        if (have_next) {
-            Cn = jda_tile_setup_from<MODE>(Dn, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
+        if (pipelined) {
+            Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
             Cn.win_lo = __builtin_amdgcn_readfirstlane(Cn.win_lo);
             Cn.win_len = __builtin_amdgcn_readfirstlane(Cn.win_len);
-            chunk = jda_window_load(JDA_G(const uint8_t, Dn.scan), Cn.win_lo, Cn.win_len, lane);
+            chunk = jda_window_load(JDA_G(const uint8_t, D.scan), Cn.win_lo, Cn.win_len, lane);
         }
 
         JDA_PTRACE(3);
@@ -298,7 +306,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         JDA_PTRACE(4);
 
         // stage D: scan slice -> the LDS window (this tile's P1, its only reader, is over)
-        if (have_next) jda_window_store(wl + L::WIN_OFF, Cn.win_len, lane, chunk);
+        if (pipelined) jda_window_store(wl + L::WIN_OFF, Cn.win_len, lane, chunk);
 
         JDA_PTRACE(5);
         if (D.scale_shift < 2) {
@@ -310,13 +318,22 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 
         jda_p4_output<MODE>(D, S, C, lane, wl);
         JDA_PTRACE(7);
+#ifdef JDA_PHASE_TRACE
         iter++;
+#endif
         if (!have_next) break;
-        JDA_ADVANCE_TABLES(Sn.ord, true, Sn, Dn);     // image boundary: every wavefront of the workgroup passes here once
-        S = Sn; C = Cn; in = inn; Dc = Dn; i_nxt = i_nn;
+        S = Sn; i_nxt = i_nn;
         Sn = jda_unpack_record(r0, r1, r2, r3);
+        if (pipelined) { C = Cn; in = inn; }
+        else {                                        // image boundary: every wavefront of the workgroup passes here once
+            Dc = jda_desc_uniform(descs + S.image);
+            JDA_ADVANCE_TABLES(S.ord, true, S, Dc);
+            JDA_WAVE_SYNC();
+            JDA_TILE_COLD_START();
+        }
         JDA_WAVE_SYNC();
     }
+#undef JDA_TILE_COLD_START
     JDA_ADVANCE_TABLES(last_ord, false, S, Dc);        // boundaries after this wavefront's last tile
     if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u + 1u] = wall_clock64();
 }
