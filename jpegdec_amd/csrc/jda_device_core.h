@@ -1379,9 +1379,79 @@ JDA_HD uint32_t jda_565_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t 
     return v;
 }
 
+// Addresses of the colour stage's work items for a FULL 4:2:0 tile (10 MCUs = 160 x 16 pixels = 320 items of 4x2
+// pixels = exactly five passes of the wavefront): item i = lane + 64 * pass always lands on the same LDS offsets and
+// on the same offset from the tile's first output pixel, so the index arithmetic (a third of the stage's VALU work)
+// is done once per image and kept in registers.  Only the output offset depends on the image (pitch, pixel size).
+#define JDA_P4_PASSES 5
+struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES], co[JDA_P4_PASSES], rel[JDA_P4_PASSES]; };
+JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, uint32_t pitch, uint32_t bpp)
+{
+#pragma unroll
+    for (int it = 0; it < JDA_P4_PASSES; it++) {
+        const uint32_t i = t + 64u * (uint32_t)it, rp = i / 40u, g = i - rp * 40u;
+        const uint32_t po = (g >> 2) * plane_stride;
+        P.yo[it] = po + (rp >> 2) * (2 * JDA_COEF_STRIDE) + (rp & 3u) * 16 + ((g >> 1) & 1u) * JDA_COEF_STRIDE + (g & 1u) * 4;
+        P.co[it] = po + 4 * JDA_COEF_STRIDE + rp * 8 + (g & 3u) * 2;
+        P.rel[it] = rp * 2u * pitch + g * 4u * bpp;
+    }
+}
+
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
 // pixel group (the two rows share their chroma samples); items are dealt to the threads in row-major
 // order so that consecutive threads store consecutive 16-byte groups.
+// the eight pixels of one item: ya / yb = four luma samples of the upper / lower row, cb2 / cr2 = two chroma samples each
+template <int PT>
+JDA_HD void jda_p4_420_item(uint32_t ya, uint32_t yb, uint32_t cb2, uint32_t cr2, uint32_t v0[4], uint32_t v1[4])
+{
+    const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
+    const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
+    if (PT == JDA_RGB8888) {
+        jda_rgba_pair(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b, v0[0], v0[1]);
+        jda_rgba_pair(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b, v0[2], v0[3]);
+        jda_rgba_pair(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b, v1[0], v1[1]);
+        jda_rgba_pair(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b, v1[2], v1[3]);
+    } else {                                                  // RGB565: v[0], v[1] hold pixel pairs
+        v0[0] = jda_565_pair<PT>(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b);
+        v0[1] = jda_565_pair<PT>(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b);
+        v1[0] = jda_565_pair<PT>(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b);
+        v1[1] = jda_565_pair<PT>(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b);
+        v0[2] = v0[3] = v1[2] = v1[3] = 0;
+    }
+}
+// item -> memory, whole groups: 16 (RGB8888) or 8 (RGB565) bytes per row
+template <int PT>
+JDA_HD void jda_p4_420_store(uint8_t JDA_GLOBAL *out, uint32_t off, uint32_t off1, const uint32_t v0[4], const uint32_t v1[4])
+{
+    if (PT == JDA_RGB8888) {
+        jda_chunk16_alias q0, q1;
+        q0.w[0] = v0[0]; q0.w[1] = v0[1]; q0.w[2] = v0[2]; q0.w[3] = v0[3];
+        q1.w[0] = v1[0]; q1.w[1] = v1[1]; q1.w[2] = v1[2]; q1.w[3] = v1[3];
+        *(jda_chunk16_alias JDA_GLOBAL *)(out + off) = q0;
+        *(jda_chunk16_alias JDA_GLOBAL *)(out + off1) = q1;
+    } else {
+        *(jda_u64_alias JDA_GLOBAL *)(out + off) = (uint64_t)v0[0] | ((uint64_t)v0[1] << 32);
+        *(jda_u64_alias JDA_GLOBAL *)(out + off1) = (uint64_t)v1[0] | ((uint64_t)v1[1] << 32);
+    }
+}
+
+// a full, unclipped tile: five passes with the precomputed item addresses
+template <int PT>
+JDA_HD void jda_p4_420_full10(const jda_dev_desc &D, const jda_p4_pre &P, const uint8_t *plane_base, uint32_t x_base, uint32_t y_base)
+{
+    const uint32_t bpp = PT == JDA_RGB8888 ? 4u : 2u;
+    const uint32_t pitch = D.out_pitch;
+    uint8_t JDA_GLOBAL *tile = JDA_G(uint8_t, D.out) + (y_base * pitch + x_base * bpp);      // uniform
+#pragma unroll
+    for (int it = 0; it < JDA_P4_PASSES; it++) {
+        const uint32_t ya = *(const jda_u32_alias *)(plane_base + P.yo[it]), yb = *(const jda_u32_alias *)(plane_base + P.yo[it] + 8);
+        const uint32_t cb2 = *(const uint16_t *)(plane_base + P.co[it]), cr2 = *(const uint16_t *)(plane_base + P.co[it] + JDA_COEF_STRIDE);
+        uint32_t v0[4], v1[4];
+        jda_p4_420_item<PT>(ya, yb, cb2, cr2, v0, v1);
+        jda_p4_420_store<PT>(tile, P.rel[it], P.rel[it] + pitch, v0, v1);
+    }
+}
+
 template <int PT, bool CLIP>
 JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
                             uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
@@ -1407,37 +1477,16 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint32_t ya = *(const jda_u32_alias *)(plane_base + yo), yb = *(const jda_u32_alias *)(plane_base + yo + 8);
         const uint32_t cb2 = *(const uint16_t *)(plane_base + co), cr2 = *(const uint16_t *)(plane_base + co + JDA_COEF_STRIDE);
         uint32_t v0[4], v1[4];
-        if (PT == JDA_RGB8888) {
-            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
-            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
-            jda_rgba_pair(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b, v0[0], v0[1]);
-            jda_rgba_pair(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b, v0[2], v0[3]);
-            jda_rgba_pair(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b, v1[0], v1[1]);
-            jda_rgba_pair(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b, v1[2], v1[3]);
-        } else {                                                  // RGB565: v[0], v[2] hold pixel pairs
-            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
-            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
-            const uint32_t a01 = jda_565_pair<PT>(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b);
-            const uint32_t a23 = jda_565_pair<PT>(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b);
-            const uint32_t b01 = jda_565_pair<PT>(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b);
-            const uint32_t b23 = jda_565_pair<PT>(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b);
-            v0[0] = a01 & 0xffffu; v0[1] = a01 >> 16; v0[2] = a23 & 0xffffu; v0[3] = a23 >> 16;
-            v1[0] = b01 & 0xffffu; v1[1] = b01 >> 16; v1[2] = b23 & 0xffffu; v1[3] = b23 >> 16;
-        }
+        jda_p4_420_item<PT>(ya, yb, cb2, cr2, v0, v1);
         if (!CLIP) {                                              // whole groups, 16 / 8 bytes per row
-            const uint32_t off = tile_off + jda_umul24(rp, 2 * pitch) + x4 * bpp, off1 = off + pitch;
-            if (PT == JDA_RGB8888) {
-                jda_chunk16_alias q0, q1;
-                q0.w[0] = v0[0]; q0.w[1] = v0[1]; q0.w[2] = v0[2]; q0.w[3] = v0[3];
-                q1.w[0] = v1[0]; q1.w[1] = v1[1]; q1.w[2] = v1[2]; q1.w[3] = v1[3];
-                *(jda_chunk16_alias JDA_GLOBAL *)(out + off) = q0;
-                *(jda_chunk16_alias JDA_GLOBAL *)(out + off1) = q1;
-            } else {
-                jda_u64_alias JDA_GLOBAL *d0 = (jda_u64_alias JDA_GLOBAL *)(out + off), *d1 = (jda_u64_alias JDA_GLOBAL *)(out + off1);
-                *d0 = (uint64_t)(v0[0] | (v0[1] << 16)) | ((uint64_t)(v0[2] | (v0[3] << 16)) << 32);
-                *d1 = (uint64_t)(v1[0] | (v1[1] << 16)) | ((uint64_t)(v1[2] | (v1[3] << 16)) << 32);
-            }
+            const uint32_t off = tile_off + jda_umul24(rp, 2 * pitch) + x4 * bpp;
+            jda_p4_420_store<PT>(out, off, off + pitch, v0, v1);
         } else {
+            if (PT != JDA_RGB8888) {                              // pixel pairs -> single pixels for the clipped stores
+                const uint32_t a01 = v0[0], a23 = v0[1], b01 = v1[0], b23 = v1[1];
+                v0[0] = a01 & 0xffffu; v0[1] = a01 >> 16; v0[2] = a23 & 0xffffu; v0[3] = a23 >> 16;
+                v1[0] = b01 & 0xffffu; v1[1] = b01 >> 16; v1[2] = b23 & 0xffffu; v1[3] = b23 >> 16;
+            }
             uint8_t JDA_GLOBAL *row0 = out + (size_t)Y0 * pitch;
             jda_store4<PT, CLIP>(row0, X, D.out_w, v0);
             if (Y0 + 1 < D.out_rows) jda_store4<PT, CLIP>(row0 + pitch, X, D.out_w, v1);
@@ -1597,8 +1646,20 @@ JDA_HD void jda_p4_generic(const jda_dev_desc &D, uint32_t t, const uint8_t *pla
     }
 }
 
+// the precomputed item addresses belong to an image (pitch, pixel size): made when a wavefront meets a new image
 template <int MODE>
-JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *wl)
+JDA_HD void jda_p4_prepare(jda_p4_pre &P, const jda_dev_desc &D, uint32_t t)
+{
+    typedef jda_lds_layout<MODE> L;
+    if (MODE == JDA_MODE_420) jda_p4_precompute(P, t, L::PLANE_STRIDE, D.out_pitch, D.pixel_type == JDA_RGB8888 ? 4u : 2u);
+    else {
+#pragma unroll
+        for (int it = 0; it < JDA_P4_PASSES; it++) P.yo[it] = P.co[it] = P.rel[it] = 0;
+    }
+}
+
+template <int MODE>
+JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *wl, const jda_p4_pre &P)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
@@ -1611,6 +1672,13 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
     const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
     if ((MODE == JDA_MODE_444 || MODE == JDA_MODE_420 || MODE == JDA_MODE_422) && shift == 0 && colour_out) {      // specialised full-size colour paths
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;   // no clipping in this tile
+        if (MODE == JDA_MODE_420 && inside && C.count == (uint32_t)L::MCUS) {          // the common case: a full tile
+            const int pt = D.pixel_type;
+            if (pt == JDA_RGB8888) jda_p4_420_full10<JDA_RGB8888>(D, P, plane_base, x_base, y_base);
+            else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_420_full10<JDA_RGB565_LITTLE_ENDIAN>(D, P, plane_base, x_base, y_base);
+            else jda_p4_420_full10<JDA_RGB565_BIG_ENDIAN>(D, P, plane_base, x_base, y_base);
+            return;
+        }
         if (inside) jda_p4_full_colour<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_full_colour<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
     } else if (shift == 0 && !colour_out) {                       // 8-bit gray, full size: the luma samples are the pixels

@@ -128,7 +128,9 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
         JDA_WAVE_SYNC();
         JDA_TRACE(6);
     }
-    if (!(D.pad_[0] & 1)) jda_p4_output<MODE>(D, S, C, lane, wl);
+    jda_p4_pre P4;
+    jda_p4_prepare<MODE>(P4, D, lane);
+    if (!(D.pad_[0] & 1)) jda_p4_output<MODE>(D, S, C, lane, wl, P4);
     JDA_TRACE(7);
 }
 
@@ -249,6 +251,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane)); \
     } while (0)
     JDA_TILE_COLD_START();
+    jda_p4_pre P4;                                    // the colour stage's item addresses for this image (pitch, pixel size)
+    jda_p4_prepare<MODE>(P4, Dc, lane);
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
     jda_strip Sn = S;
     if (i_nxt < t_end) Sn = jda_load_record(tiles + i_nxt);
@@ -316,7 +320,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         JDA_PTRACE(6);
         if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;      // list counters reset for the next tile
 
-        jda_p4_output<MODE>(D, S, C, lane, wl);
+        jda_p4_output<MODE>(D, S, C, lane, wl, P4);
         JDA_PTRACE(7);
 #ifdef JDA_PHASE_TRACE
         iter++;
@@ -330,6 +334,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
             JDA_ADVANCE_TABLES(S.ord, true, S, Dc);
             JDA_WAVE_SYNC();
             JDA_TILE_COLD_START();
+            jda_p4_prepare<MODE>(P4, Dc, lane);
         }
         JDA_WAVE_SYNC();
     }

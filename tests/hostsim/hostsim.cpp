@@ -43,7 +43,11 @@ static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles
             for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p2_columns<MODE, FAST>(D, t, tab, wl);
             for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p3_rows<MODE>(D, t, tab, wl);
         }
-        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p4_output<MODE>(D, S, C, t, wl);
+        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) {
+            jda_p4_pre P4;
+            jda_p4_prepare<MODE>(P4, D, t);
+            jda_p4_output<MODE>(D, S, C, t, wl, P4);
+        }
     }
 }
 
