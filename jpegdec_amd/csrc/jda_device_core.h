@@ -53,11 +53,24 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
 // that do not start with six 1 bits; the long halves are rare and stay in global memory),
 // quantisers, zigzag.
 #define JDA_LT_DC      0         // 2 x 1024
-#define JDA_LT_AC      2048      // 2 x 1024 uint16
+#define JDA_LT_AC      2048      // 2 x 1024 uint16, re-laid out while staging (jda_ac_entry)
 #define JDA_LT_QUANT   6144      // 4 x 64 int16
-#define JDA_LT_ZIGZAG  6656      // 64
-#define JDA_LT_ZZ16    6720      // 64 x uint16: natural index n | column bit (1 << (n & 7)) << 8, built while staging
-#define JDA_LT_BYTES   6848
+#define JDA_LT_ZZ      6656      // 144 x uint16, built while staging: where the coefficient at zigzag position j goes
+#define JDA_ZZ_ENTRIES 144       //   j < 64: (column bit 1 << (n & 7)) << 8 | 2 n (n = natural index: the byte offset in the
+                                 //   block); j >= 64 (past the block, or 64 + j for a symbol that stores nothing): 128 = the
+                                 //   block's padding, no flags.  j <= 63 + 15 + 64.
+#define JDA_ZZ_DUMP    128u
+#define JDA_LT_BYTES   6944
+
+// AC LUT entry as the kernels keep it in LDS: length << 11 | nostore << 10 | R << 4 | S, made from the reference's
+// (length << 8) | RS.  nostore = a symbol with S == 0 that is not EOB (ZRL): bits 10:4 then read R + 64, which steers
+// the zigzag lookup to the padding entry -- the store needs no condition (jpeg.inl:2246-2256: "if (S && k < limit)").
+JDA_HD uint32_t jda_ac_entry(uint32_t raw)
+{
+    const uint32_t rs = raw & 0xffu, len = raw >> 8;
+    const uint32_t nostore = ((rs & 0xfu) == 0u && rs != 0u) ? 1u : 0u;
+    return (len << 11) | (nostore << 10) | rs;
+}
 
 template <int MODE> struct jda_lds_layout {       // the per-WAVE region
     enum {
@@ -182,10 +195,9 @@ JDA_HD uint32_t jda_range_limit5(int32_t v) { return (uint32_t)jda_clamp255(jda_
 // assembled from three aligned dword loads.
 JDA_HD uint64_t jda_be64_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t pos)
 {
-    const uint32_t sh = pos & 3u;
-    const uint32_t a = jda_alignbyte(w1, w0, sh);
-    const uint32_t b = jda_alignbyte(w2, w1, sh);
-    return ((uint64_t)__builtin_bswap32(a) << 32) | __builtin_bswap32(b);
+    // byte alignment and byte swap in one permute per half: result byte 3 = stream byte sh, .. byte 0 = stream byte sh + 3
+    const uint32_t sel = 0x00010203u + (pos & 3u) * 0x01010101u;
+    return ((uint64_t)jda_perm(w1, w0, sel) << 32) | jda_perm(w2, w1, sel);
 }
 
 // The workgroup's view of the filtered scan: bytes [win_lo, win_lo + win_len) are staged in LDS (copied
@@ -317,10 +329,9 @@ JDA_HD uint32_t jda_popcount8(uint32_t v)
 // coef: the block's int16[64] in LDS (natural order).  Returns the reference's u16MCUFlags.
 struct jda_tables {
     const uint8_t *dc;        // LDS: 1024-byte DC LUT of this block's component
-    const uint16_t *ac_short; // LDS: 1024 entries
-    const uint16_t JDA_GLOBAL *ac_long;  // global: 1024 entries (codes starting 111111)
-    const uint8_t *zigzag;    // LDS
-    const uint16_t *zz16;     // LDS: n | column bit << 8
+    const uint16_t *ac_short; // LDS: 1024 entries in the jda_ac_entry layout
+    const uint16_t JDA_GLOBAL *ac_long;  // global: 1024 entries (codes starting 111111), the reference's layout
+    const uint16_t *zz;       // LDS: JDA_ZZ_ENTRIES entries (see JDA_LT_ZZ)
 };
 
 template <int LIMIT>
@@ -358,15 +369,15 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
     jda_refill(br);
     while (k < LIMIT) {
         code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
-        if (code >= 0xfc00u) e = T.ac_long[code & 0x3ffu];           // usHuffAC[1024 + ...]  :2232-2233
+        if (code >= 0xfc00u) e = jda_ac_entry(T.ac_long[code & 0x3ffu]);   // usHuffAC[1024 + ...]  :2232-2233
         else e = T.ac_short[code >> 6];
-        br.off += e >> 8;
+        br.off += e >> 11;
         e &= 0xffu;
         if (e == 0) break;                              // EOB (no refill follows)
         k += (int)(e >> 4);
         const uint32_t ms = e & 0xfu;
         if (k < LIMIT && ms) {
-            const uint32_t n = T.zigzag[k];
+            const uint32_t n = (T.zz[k] & 0xffu) >> 1;
             flags |= (1u << (n & 7u)) | (n << 8);
             coef[n] = (int16_t)jda_take_extend(br.bits, br.off, ms);
         }
@@ -595,24 +606,25 @@ JDA_HD uint32_t jda_decode_block_win(jda_bitreader &br, const jda_tables &T, int
         // (ulBits << ulBitOff), so truncated magnitudes come out truncated
         const uint32_t w = (uint32_t)((br.bits << br.off) >> 32);
         e = T.ac_short[w >> 22];
-        if (__builtin_expect(w >= 0xfc000000u, 0)) e = T.ac_long[(w >> 16) & 0x3ffu];     // rare: codes starting 111111
-        const uint32_t len = e >> 8;
-        e &= 0xffu;
-        if (e == 0) { br.off += len; break; }
-        k += (int)(e >> 4);
+        if (__builtin_expect(w >= 0xfc000000u, 0)) e = jda_ac_entry(T.ac_long[(w >> 16) & 0x3ffu]);     // rare: codes starting 111111
+        const uint32_t len = e >> 11;
+        if ((e & 0xffu) == 0) { br.off += len; break; }
+        // the zigzag lookup decides where the value goes: position k + R of the block, or the padding when that is past
+        // the block or the symbol carries no value (ZRL: bits 10:4 of the entry read R + 64)
+        const uint32_t kk = (uint32_t)k + ((e >> 4) & 0x7fu);
+        uint32_t t = T.zz[kk];
+        if (LIMIT != 64 && kk >= (uint32_t)LIMIT) t = JDA_ZZ_DUMP;     // 1/4 scale keeps zigzag 1..4 only (:2117-2119)
         const uint32_t ms = e & 0xfu;
-        const bool store = k < LIMIT && ms != 0;
-        const uint32_t t = T.zz16[k & 63];
         const int32_t v = jda_extend_top(w << len, ms);
-        fl |= store ? t : 0u;
-        coef[store ? (t & 63u) : 64u] = (int16_t)v;      // slot 64 = the block's padding
+        fl |= t;
+        *(int16_t *)((uint8_t *)coef + (t & 0xffu)) = (int16_t)v;
         br.off += len + ms;
-        k++;
+        k += (int)((e >> 4) & 0xfu) + 1;
         jda_refill_win(br, wbase, true);
         if (k >= LIMIT) break;
     }
-    // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested
-    return (fl >> 8) | ((fl & 0x20u) << 8);
+    // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested; fl holds 2n in 7:0
+    return (fl >> 8) | ((fl & 0x40u) << 7);
 }
 
 // Multiplication by an IDCT constant.  FAST: both operands are known to fit in 24 signed bits (the
@@ -966,17 +978,26 @@ JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads
     jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;
     // quant + zigzag: blob[10240, 10816) -> LT_QUANT
-    if (tid < 64) {                                              // zigzag + flag bits of A.2 in one lookup
-        const uint32_t n = JDA_G(const uint8_t, D.tables)[JDA_TB_ZIGZAG + tid];
-        ((uint16_t *)(tab_lds + JDA_LT_ZZ16))[tid] = (uint16_t)(n | ((1u << (n & 7u)) << 8));
+    for (uint32_t j = tid; j < JDA_ZZ_ENTRIES; j += nthreads) {  // zigzag + flag bits of A.2 in one lookup
+        uint32_t v = JDA_ZZ_DUMP;
+        if (j < 64) {
+            const uint32_t n = JDA_G(const uint8_t, D.tables)[JDA_TB_ZIGZAG + j];
+            v = (n << 1) | ((1u << (n & 7u)) << 8);
+        }
+        ((uint16_t *)(tab_lds + JDA_LT_ZZ))[j] = (uint16_t)v;
     }
-    for (uint32_t i = tid; i < JDA_LT_ZZ16 / 16; i += nthreads) {
+    for (uint32_t i = tid; i < JDA_LT_ZZ / 16; i += nthreads) {
         uint32_t src;
         if (i < 128) src = i;                                   // DC
         else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
         else if (i < 384) src = (JDA_TB_AC >> 4) + 256 + (i - 256); // AC table 1, short half
         else src = (JDA_TB_QUANT >> 4) + (i - 384);
-        tab[i] = blob[src];
+        jda_chunk16_alias c = blob[src];
+        if (i >= 128 && i < 384) {                              // AC entries -> the kernels' layout
+#pragma unroll
+            for (int k = 0; k < 4; k++) c.w[k] = jda_ac_entry(c.w[k] & 0xffffu) | (jda_ac_entry(c.w[k] >> 16) << 16);
+        }
+        tab[i] = c;
     }
 }
 
@@ -1033,8 +1054,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     TB.dc = tab + JDA_LT_DC + dc_id * 1024;
     TB.ac_short = (const uint16_t *)(tab + JDA_LT_AC) + ac_id * 1024;
     TB.ac_long = JDA_G(const uint16_t, D.tables + JDA_TB_AC) + ac_id * 2048 + 1024;
-    TB.zigzag = tab + JDA_LT_ZIGZAG;
-    TB.zz16 = (const uint16_t *)(tab + JDA_LT_ZZ16);
+    TB.zz = (const uint16_t *)(tab + JDA_LT_ZZ);
     const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64;
     int16_t *coef = (int16_t *)(wl + L::COEF_OFF + lb * JDA_COEF_STRIDE);
     uint8_t *plane = (uint8_t *)coef;                            // samples overwrite the block's own slot
