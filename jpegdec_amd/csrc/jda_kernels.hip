@@ -249,6 +249,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);                                                      \
         C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);                                                    \
         jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane)); \
+        asm volatile("" : "+v"(in.ix), "+v"(in.pred));   /* nothing in flight when the loop (re)starts */                                \
     } while (0)
     JDA_TILE_COLD_START();
     jda_p4_pre P4;                                    // the colour stage's item addresses for this image (pitch, pixel size)
@@ -293,7 +294,10 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         jda_tile_ctx Cn = C;
         jda_chunk16 chunk;
         chunk.w[0] = chunk.w[1] = chunk.w[2] = chunk.w[3] = 0;
-        asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end));      // the index loads have landed: settle their waits here
+        // the index loads and the record have landed: settle their waits HERE.  Left to the compiler, the record's wait
+        // lands after P4 (where it is consumed) as s_waitcnt vmcnt(0) -- the counter is shared with stores on gfx9, so the
+        // wavefront would sit out the write acknowledgements of its own tile before starting the next one
+        asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
         if (pipelined) {
             Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
@@ -309,7 +313,10 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         }
         JDA_PTRACE(4);
 
-        // stage D: scan slice -> the LDS window (this tile's P1, its only reader, is over)
+        // stage D: scan slice -> the LDS window (this tile's P1, its only reader, is over).  The load is settled for every
+        // lane, also those that store nothing: a load the compiler still counts as pending at the loop's back edge costs
+        // an s_waitcnt vmcnt(0) at the top of the next tile, i.e. behind this tile's output stores
+        asm volatile("" : "+v"(chunk.w[0]), "+v"(chunk.w[1]), "+v"(chunk.w[2]), "+v"(chunk.w[3]));
         if (pipelined) jda_window_store(wl + L::WIN_OFF, Cn.win_len, lane, chunk);
 
         JDA_PTRACE(5);
