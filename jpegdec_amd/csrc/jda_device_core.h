@@ -888,6 +888,182 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 }
 
 
+// ---- device pre-scan WITHOUT restart markers ------------------------------------------
+// The filtered scan is cut into segments of JDA_SEG_BYTES; one lane walks one segment's Huffman symbols in skip mode.
+// A lane does not know the decoder state at its segment's first bit -- (bit offset of the next symbol, block within the
+// MCU, zigzag position) -- so it guesses "a block starts here" and walks: Huffman streams re-synchronise by themselves
+// after a few symbols, and an EOB re-synchronises the zigzag position.  The passes:
+//   SPEC   lane i walks segment i from its current idea of the entry state and hands the state at the segment's end to
+//          segment i + 1.  Segment 0's entry state is known, so round r makes segments 0..r exact at the latest; with
+//          self-synchronisation everything is exact after a few rounds.  A round that changes nothing is the fixed point
+//          E[i+1] = walk(i, E[i]) with E[0] true, i.e. the serial decoder's states (induction over i).
+//   COUNT  from the exact entry states: block starts and per-component DC sums of every segment, and how the reference's
+//          window phase propagates across it (all eight byte lags in flight, as jda_prescan_interval's MAP pass)
+//   (exclusive sums / composition over the segments: first block ordinal, DC predictors, window phase at every entry)
+//   WRITE  the walk again, now writing the per-block index and DC predictors exactly as the serial host pre-scan does.
+// State at a symbol boundary (after the reference's bottom-of-loop refill, before its next top-of-loop refill):
+//   bits 5:0 bit offset from the segment's first bit (entry: how far the previous segment's last symbol reached in),
+//   bits 8:6 block within the MCU, bits 14:9 zigzag position k (0 = the next symbol is a DC code).
+#define JDA_SEG_BYTES 256u
+#define JDA_SEG_BITS  (JDA_SEG_BYTES * 8u)
+#define JDA_SEG_SLOT  268u           // bytes a lane reads: its segment + 12 bytes of the next; 67 dwords per lane in LDS (odd: no bank conflicts)
+#define JDA_SEG_DEAD  0x7fffffffu    // state of a walk that met an invalid code (bit 31 is the rounds' "changed" mark)
+#define JDA_SEG_CHANGED 0x80000000u // entry-state word: "differs from the previous round's" (the walker's own bits are 14:0)
+enum { JDA_SEG_SPEC = 0, JDA_SEG_COUNT = 1, JDA_SEG_WRITE = 2 };
+
+struct jda_segscan_params {          // one per image
+    const uint8_t *scan;             // filtered scan (global), zero padded to n_segs * JDA_SEG_BYTES + 16
+    const uint8_t *tables;           // table blob (global)
+    uint32_t *entry_cur, *entry_nxt; // n_segs + 1 entry states each; swapped between rounds
+    uint32_t *seg_sum;               // COUNT out, 6 words per segment: block starts, DC sums [3], phase map, bad
+    const uint32_t *seg_start;       // WRITE in, 5 words per segment: first block ordinal, DC predictors [3], byte lag j of the reference window
+    uint32_t *blk_index;             // WRITE out: n_blocks_total + 1
+    int16_t *blk_dc;                 // WRITE out: n_blocks_total
+    uint32_t *stats;                 // [0] bad, [1] terminal entry written, [2] max AC category, [3] max |DC|, [4] truncated reads, [5] states changed in this round
+    uint32_t scan_len, n_segs, n_blocks_total, first_round;
+    uint8_t nluma, nblocks, dc_id[3], ac_id[3];
+};
+struct jda_seg_sum { uint32_t nblk; int32_t dcsum[3]; uint32_t phase_map, bad; };
+struct jda_seg_stats { uint32_t bad, terminal, max_ac_bits, max_abs_dc, trunc_events; };
+
+// the next 32 bits of the stream at bit `bit` of the lane's slot (dword-aligned reads; big-endian bit order)
+JDA_HD uint32_t jda_seg_fetch(const uint8_t *slot, uint32_t bit)
+{
+    const jda_u32_alias *d = (const jda_u32_alias *)(slot + ((bit >> 5) << 2));
+    const uint64_t v = ((uint64_t)__builtin_bswap32(d[0]) << 32) | __builtin_bswap32(d[1]);
+    return (uint32_t)((v << (bit & 31u)) >> 32);
+}
+// eight bit offsets, one per byte: the reference's refill (jpeg.inl:2110-2114) on each
+JDA_HD uint64_t jda_ph8_refill(uint64_t x)
+{
+    const uint64_t K = 0x0101010101010101ull;
+    const uint64_t ge48 = ((x + (0x80u - 48u) * K) & (0x80u * K)) >> 7;   // offsets stay below 128: no carry between bytes
+    const uint64_t m = ge48 * 0xffu;
+    return (x & ~m) | (x & m & (0x07u * K));
+}
+
+// lt: the tables in the kernels' LDS layout (JDA_LT_*); slot: the segment's bytes (JDA_SEG_SLOT readable)
+template <int OP>
+JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint8_t *slot, const uint8_t *lt,
+                             jda_seg_sum &S, jda_seg_stats &ST)
+{
+    S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0;
+    if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
+    uint32_t p = entry & 63u, b = (entry >> 6) & 7u, k = (entry >> 9) & 63u;
+    const uint16_t JDA_GLOBAL *ac_long_base = JDA_G(const uint16_t, P.tables + JDA_TB_AC);
+    const uint64_t K8 = 0x0101010101010101ull;
+    // WRITE: the reference reader (pBuf, ulBitOff), the block ordinal and the DC predictors at the entry
+    uint32_t pos = 0, off = 0, g = 0;
+    int32_t pred[3] = { 0, 0, 0 };
+    const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 8;
+    uint64_t ph = 0;                                                // COUNT: offsets (p & 7) + 8 j, j = 0..7
+    if (OP == JDA_SEG_WRITE) {
+        const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)seg * 5;
+        g = st[0]; pred[0] = (int32_t)st[1]; pred[1] = (int32_t)st[2]; pred[2] = (int32_t)st[3];
+        const uint32_t j = st[4], p_abs = seg * JDA_SEG_BITS + p;
+        pos = (p_abs >> 3) - j; off = (p_abs & 7u) + 8u * j;
+    }
+    if (OP == JDA_SEG_COUNT) ph = 0x3830282018100800ull + (uint64_t)(p & 7u) * K8;
+#define JDA_SG_REFILL() do { if (OP == JDA_SEG_WRITE) { if (off > 47) { pos += off >> 3; off &= 7u; if (pos > limit_pos) bad = true; } } \
+                             else if (OP == JDA_SEG_COUNT) ph = jda_ph8_refill(ph); } while (0)
+#define JDA_SG_ADVANCE(n) do { if (OP == JDA_SEG_WRITE) off += (n); else if (OP == JDA_SEG_COUNT) ph += (uint64_t)(n) * K8; } while (0)
+    bool bad = false, done = false;
+    while (p < JDA_SEG_BITS) {
+        const uint32_t c = b < P.nluma ? 0u : b - P.nluma + 1u;
+        if (k == 0) {                                               // a block starts here (jpeg.inl:2129-2165)
+            if (OP == JDA_SEG_COUNT) S.nblk++;
+            if (OP == JDA_SEG_WRITE) {
+                if (g >= P.n_blocks_total) {                        // past the image: the state after the last block closes the index
+                    if (g == P.n_blocks_total) { JDA_G(uint32_t, P.blk_index)[g] = (pos << JDA_INDEX_OFF_BITS) | off; ST.terminal = 1; }
+                    done = true;
+                    break;
+                }
+                const int32_t pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
+                if (pr < -32768 || pr > 32767) { bad = true; break; }
+                JDA_G(uint32_t, P.blk_index)[g] = (pos << JDA_INDEX_OFF_BITS) | off;
+                JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
+                g++;
+            }
+            JDA_SG_REFILL();
+            if (bad) break;
+            const uint32_t w = jda_seg_fetch(slot, p);
+            uint32_t code = w >> 20;
+            code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
+            const uint32_t dci = c == 0 ? P.dc_id[0] : (c == 1 ? P.dc_id[1] : P.dc_id[2]);
+            const uint8_t *dc = lt + JDA_LT_DC + dci * 1024;
+            const uint32_t e = dc[code];
+            if (e == 0) {                                           // :2137-2138
+                // a speculative walk that is not on the decoder's path yet may meet anything: step on one bit and keep
+                // looking (a walk that gave up would hand "dead" down the chain of segments, one per round)
+                if (OP == JDA_SEG_SPEC) { p += 1; continue; }
+                bad = true; break;
+            }
+            const uint32_t len = e >> 4, s = e & 0xfu;
+            const int32_t folded = (int8_t)dc[code + 512];
+            int32_t diff = 0;
+            JDA_SG_ADVANCE(len);
+            p += len;
+            if (s) {
+                if (folded) diff = folded;                          // code and magnitude in one LUT step (:1132-1152)
+                else {
+                    JDA_SG_REFILL();                                // :2149-2154
+                    if (bad) break;
+                    diff = jda_extend_top(w << len, s);
+                    JDA_SG_ADVANCE(s);
+                    p += s;
+                }
+            }
+            if (OP == JDA_SEG_COUNT) { if (c == 0) S.dcsum[0] += diff; else if (c == 1) S.dcsum[1] += diff; else S.dcsum[2] += diff; }
+            if (OP == JDA_SEG_WRITE) {
+                int32_t &pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
+                pr += diff;
+                const uint32_t a = (uint32_t)(pr < 0 ? -pr : pr);
+                if (a > ST.max_abs_dc) ST.max_abs_dc = a;
+            }
+            k = 1;
+        } else {                                                    // an AC symbol (:2223-2265)
+            JDA_SG_REFILL();
+            if (bad) break;
+            const uint32_t w = jda_seg_fetch(slot, p);
+            const uint32_t aci = c == 0 ? P.ac_id[0] : (c == 1 ? P.ac_id[1] : P.ac_id[2]);
+            uint32_t e;
+            if (w >= 0xfc000000u) e = jda_ac_entry(ac_long_base[aci * 2048 + 1024 + ((w >> 16) & 0x3ffu)]);
+            else e = ((const uint16_t *)(lt + JDA_LT_AC))[aci * 1024 + (w >> 22)];
+            if (e == 0) {                                           // :2237-2238
+                if (OP == JDA_SEG_SPEC) { p += 1; k = 0; continue; }
+                bad = true; break;
+            }
+            const uint32_t len = e >> 11, rs = e & 0xffu;
+            JDA_SG_ADVANCE(len);
+            p += len;
+            if (rs == 0) { k = 0; b = b + 1u == P.nblocks ? 0u : b + 1u; }       // EOB: no refill follows
+            else {
+                const uint32_t ms = rs & 0xfu, kk = k + (rs >> 4);
+                if (OP == JDA_SEG_WRITE) {
+                    if (ms && kk < 64 && off + ms > 64) ST.trunc_events++;
+                    if (ms > ST.max_ac_bits && kk < 64) ST.max_ac_bits = ms;
+                }
+                JDA_SG_ADVANCE(ms);
+                p += ms;
+                k = kk + 1u;
+                JDA_SG_REFILL();                                    // :2259-2264 (bottom of the loop)
+                if (bad) break;
+                if (k >= 64) { k = 0; b = b + 1u == P.nblocks ? 0u : b + 1u; }
+            }
+        }
+    }
+#undef JDA_SG_REFILL
+#undef JDA_SG_ADVANCE
+    if (bad) { S.bad = 1; ST.bad = 1; return JDA_SEG_DEAD; }
+    if (OP == JDA_SEG_COUNT) {
+        uint32_t map = 0;
+        for (int j = 0; j < 8; j++) map |= (((uint32_t)(ph >> (8 * j)) & 0xffu) >> 3) << (3 * j);
+        S.phase_map = map;
+    }
+    (void)done;
+    return (p - JDA_SEG_BITS) | (b << 6) | (k << 9);
+}
+
 // ================================================================================================
 // Tile phases.  Every lane of the tile's wavefront runs each phase; a wave-local fence separates
 // consecutive phases (the host emulator runs all 64 lanes of a phase, then the next).
@@ -972,16 +1148,18 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
 
 // ---- P0 ---------------------------------------------------------------------------------------
 // tables: once per workgroup (tid = thread in workgroup, nthreads = workgroup size)
-JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds)
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds);
+JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds) { jda_p0_tables_from(D.tables, tid, nthreads, tab_lds); }
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds)
 {
-    const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, D.tables);
+    const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, tables);
     jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;
     // quant + zigzag: blob[10240, 10816) -> LT_QUANT
     for (uint32_t j = tid; j < JDA_ZZ_ENTRIES; j += nthreads) {  // zigzag + flag bits of A.2 in one lookup
         uint32_t v = JDA_ZZ_DUMP;
         if (j < 64) {
-            const uint32_t n = JDA_G(const uint8_t, D.tables)[JDA_TB_ZIGZAG + j];
+            const uint32_t n = JDA_G(const uint8_t, tables)[JDA_TB_ZIGZAG + j];
             v = (n << 1) | ((1u << (n & 7u)) << 8);
         }
         ((uint16_t *)(tab_lds + JDA_LT_ZZ))[j] = (uint16_t)v;

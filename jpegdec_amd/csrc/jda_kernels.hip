@@ -412,6 +412,95 @@ extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint3
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device pre-scan for streams WITHOUT restart markers (the algorithm is described at jda_seg_walk): one
+// lane per 256-byte segment of the filtered scan, a wavefront's 64 consecutive segments staged in LDS with one
+// coalesced copy (268-byte slots: a lane's reads run a few bytes into the next segment; the odd dword stride keeps
+// the lanes on different banks), four wavefronts per workgroup around one copy of the tables.
+#define JDA_SEG_WAVE_LDS (64u * JDA_SEG_SLOT)
+
+template <int OP>
+__global__ __launch_bounds__(256)
+void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const jda_segscan_params P = params[blockIdx.y];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t seg0 = (blockIdx.x * 4u + wave) * 64u, seg = seg0 + lane;
+    if (blockIdx.x * 256u >= P.n_segs) return;                       // (uniform per workgroup: images of a batch differ in size)
+    uint8_t *tab = lds;
+    uint8_t *slots = lds + JDA_LT_BYTES + wave * JDA_SEG_WAVE_LDS;
+    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab);
+    const bool in_range = seg < P.n_segs;
+    // what this lane has to do
+    uint32_t *e_cur = (round & 1u) ? P.entry_nxt : P.entry_cur, *e_nxt = (round & 1u) ? P.entry_cur : P.entry_nxt;
+    uint32_t entry = 0;
+    bool need = in_range;
+    if (OP == JDA_SEG_SPEC) {
+        if (in_range) { entry = e_cur[seg]; need = round == 0 || (entry & JDA_SEG_CHANGED) != 0; }
+    } else if (in_range) entry = ((round & 1u) ? P.entry_nxt : P.entry_cur)[seg];
+    if (OP == JDA_SEG_WRITE && in_range && P.seg_start[(size_t)seg * 5] > P.n_blocks_total) need = false;   // past the image
+    const bool wave_works = __builtin_amdgcn_ballot_w64(need) != 0;
+    if (wave_works) {                                                // the wavefront's 64 segments -> LDS
+        const uint32_t JDA_GLOBAL *src = JDA_G(const uint32_t, P.scan);
+        for (uint32_t t = lane; t < 64u * (JDA_SEG_SLOT / 4u); t += 64u) {
+            const uint32_t sl = t / (JDA_SEG_SLOT / 4u), w = t - sl * (JDA_SEG_SLOT / 4u);
+            uint32_t v = 0;
+            if (seg0 + sl < P.n_segs) v = src[(size_t)(seg0 + sl) * (JDA_SEG_BYTES / 4u) + w];
+            *(jda_u32_alias *)(slots + sl * JDA_SEG_SLOT + w * 4u) = v;
+        }
+    }
+    __syncthreads();                                                 // tables and slots are in LDS
+    if (!in_range) return;
+    const uint8_t *slot = slots + lane * JDA_SEG_SLOT;
+    jda_seg_sum S;
+    jda_seg_stats ST;
+    ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0;
+    if (OP == JDA_SEG_SPEC) {
+        const uint32_t old = e_cur[seg + 1] & ~JDA_SEG_CHANGED;
+        uint32_t out = old;
+        if (need) {
+            const uint32_t x = jda_seg_walk<JDA_SEG_SPEC>(P, seg, entry & ~JDA_SEG_CHANGED, slot, tab, S, ST) & ~JDA_SEG_CHANGED;
+            out = x;
+            if (x != old) { out |= JDA_SEG_CHANGED; atomicAdd(&P.stats[8 + round], 1u); }
+        }
+        e_nxt[seg + 1] = out;
+        if (seg == 0) e_nxt[0] = 0;                                  // the scan starts at a block start (jpeg.inl:4996-4998)
+    } else if (OP == JDA_SEG_COUNT) {
+        (void)jda_seg_walk<JDA_SEG_COUNT>(P, seg, entry & ~JDA_SEG_CHANGED, slot, tab, S, ST);
+        uint32_t *o = P.seg_sum + (size_t)seg * 6;
+        o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
+    } else if (need) {
+        (void)jda_seg_walk<JDA_SEG_WRITE>(P, seg, entry & ~JDA_SEG_CHANGED, slot, tab, S, ST);
+        if (ST.bad) atomicOr(&P.stats[0], 1u);
+        if (ST.terminal) atomicAdd(&P.stats[1], 1u);
+        if (ST.max_ac_bits) atomicMax(&P.stats[2], ST.max_ac_bits);
+        if (ST.max_abs_dc) atomicMax(&P.stats[3], ST.max_abs_dc);
+        if (ST.trunc_events) atomicAdd(&P.stats[4], ST.trunc_events);
+    }
+}
+
+// op: JDA_SEG_SPEC (round = 0, 1, ..: the entry-state buffers swap roles every round), JDA_SEG_COUNT / JDA_SEG_WRITE (round = the
+// number of SPEC rounds that ran: tells which buffer holds the final states)
+extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream)
+{
+    if (n_images == 0 || max_segs == 0) return hipSuccess;
+    const int lds_bytes = JDA_LT_BYTES + 4 * JDA_SEG_WAVE_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_COUNT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_WRITE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid((max_segs + 255u) / 256u, n_images), block(256);
+    if (op == JDA_SEG_SPEC) hipLaunchKernelGGL(jda_segscan<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
+    else if (op == JDA_SEG_COUNT) hipLaunchKernelGGL(jda_segscan<JDA_SEG_COUNT>, grid, block, lds_bytes, stream, params, round);
+    else hipLaunchKernelGGL(jda_segscan<JDA_SEG_WRITE>, grid, block, lds_bytes, stream, params, round);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t jda_internal_set_wgtrace(unsigned long long *dev_buf)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_wgtrace), &dev_buf, sizeof(dev_buf));

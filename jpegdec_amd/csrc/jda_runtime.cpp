@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -22,6 +23,7 @@ extern "C" void jda_image_run_host_prescan(jda_image *img);
 extern "C" int jda_image_index_on_device(const jda_image *img);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
 extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
+extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
 
@@ -31,6 +33,7 @@ struct jda_ctx {
     hipEvent_t ev_start, ev_stop;
     uint8_t *pinned;          // page-locked staging for uploads (grow-only, reused)
     size_t pinned_cap;
+    int last_segscan_rounds;  // speculative rounds the last marker-less device pre-scan needed (diagnostics)
     char last_error[256];
 };
 
@@ -160,6 +163,9 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         jda_dev_image *d; uint8_t *stage; std::vector<uint8_t> heap; bool on_device; uint32_t n_int;
         size_t off_rpos, off_map, off_phase, off_stats, alloc, n_blocks; uint32_t tbytes;
         std::vector<uint32_t> map; std::vector<uint8_t> phase; uint32_t st[5];
+        // streams without restart markers (8f N2): segments of the scan, see jda_seg_walk
+        bool seg_mode; uint32_t n_segs; size_t off_ea, off_eb, off_sum, off_start, off_sstats; bool dev_ok;
+        std::vector<uint32_t> seg_sum, seg_start; uint32_t sst[64];
     };
     std::vector<Item> items((size_t)n);
     int rc = JDA_SUCCESS;
@@ -172,6 +178,9 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     std::vector<jda_prescan_params> params;
     std::vector<int> params_owner;
     uint32_t max_int = 0;
+    std::vector<jda_segscan_params> seg_params;
+    std::vector<int> seg_owner;
+    uint32_t max_segs = 0;
     // staging: slices of one page-locked buffer (H2D at link speed, truly asynchronous); when it is full the
     // copies in flight are drained and it is reused from the start
     const size_t kPinnedMax = (size_t)512 << 20;
@@ -221,8 +230,46 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         it.off_rpos = d->bytes; it.off_map = it.off_rpos + align16((size_t)it.n_int * 4);
         it.off_phase = it.off_map + align16((size_t)it.n_int * 4); it.off_stats = it.off_phase + align16((size_t)it.n_int);
         it.alloc = it.on_device ? it.off_stats + 32 : d->bytes;
+        it.seg_mode = it.on_device && I.restart_interval == 0;
+        it.dev_ok = false; it.n_segs = 0;
+        if (it.seg_mode) {
+            // the scan is read in whole 256-byte segments (+ a few bytes): zero padded behind its last byte; then the
+            // entry states (two buffers), the per-segment sums and start values, the result words
+            it.n_segs = scan_len / JDA_SEG_BYTES + 1u;
+            d->bytes = d->off_scan + align16(std::max((size_t)scan_len + JDA_SCAN_PAD, (size_t)it.n_segs * JDA_SEG_BYTES + 16));
+            it.off_ea = d->bytes; it.off_eb = it.off_ea + align16(((size_t)it.n_segs + 1) * 4);
+            it.off_sum = it.off_eb + align16(((size_t)it.n_segs + 1) * 4); it.off_start = it.off_sum + align16((size_t)it.n_segs * 24);
+            it.off_sstats = it.off_start + align16((size_t)it.n_segs * 20);
+            it.alloc = it.off_sstats + 256;
+        }
         e = hipMalloc((void **)&d->base, it.alloc);
         if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
+        if (it.seg_mode) {
+            // only the tables and the scan travel; everything behind the scan's last byte starts as zeros (padding, round-0
+            // entry states, counters).  The index is written by the WRITE pass.
+            const size_t up = align16(it.tbytes) + align16((size_t)scan_len);
+            it.stage = pin_slice(up);
+            if (!it.stage) { it.heap.assign(up, 0); it.stage = it.heap.data(); }
+            memcpy(it.stage, tables, it.tbytes);
+            memcpy(it.stage + align16(it.tbytes), scan, scan_len);
+            e = hipMemcpyAsync(d->base + d->off_tables, it.stage, it.tbytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d->base + d->off_scan, it.stage + align16(it.tbytes), scan_len, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d->base + d->off_scan + scan_len, 0, it.alloc - (d->off_scan + scan_len), ctx->stream);
+            if (e != hipSuccess) { rc = set_err(ctx, e, "hipMemcpy(image)"); break; }
+            jda_segscan_params SP;
+            memset(&SP, 0, sizeof(SP));
+            SP.scan = d->base + d->off_scan; SP.tables = d->base + d->off_tables;
+            SP.entry_cur = (uint32_t *)(d->base + it.off_ea); SP.entry_nxt = (uint32_t *)(d->base + it.off_eb);
+            SP.seg_sum = (uint32_t *)(d->base + it.off_sum); SP.seg_start = (const uint32_t *)(d->base + it.off_start);
+            SP.blk_index = (uint32_t *)(d->base + d->off_index); SP.blk_dc = (int16_t *)(d->base + d->off_dc);
+            SP.stats = (uint32_t *)(d->base + it.off_sstats);
+            SP.scan_len = scan_len; SP.n_segs = it.n_segs; SP.n_blocks_total = (uint32_t)it.n_blocks;
+            SP.nblocks = (uint8_t)I.blocks_per_mcu; SP.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
+            for (int c = 0; c < 3; c++) { SP.dc_id[c] = d->dc_id[c]; SP.ac_id[c] = d->ac_id[c]; }
+            seg_params.push_back(SP); seg_owner.push_back(i);
+            if (it.n_segs > max_segs) max_segs = it.n_segs;
+            continue;
+        }
         // stage through one host buffer so it is a single H2D copy
         it.stage = pin_slice(it.alloc);
         if (!it.stage) { it.heap.assign(it.alloc, 0); it.stage = it.heap.data(); }
@@ -278,8 +325,70 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             e = hipMemcpyAsync(it.st, it.d->base + it.off_stats, sizeof(it.st), hipMemcpyDeviceToHost, ctx->stream);
         }
     }
+    // ---- streams without restart markers: speculative rounds until nothing changes, COUNT, sums on the host, WRITE
+    jda_segscan_params *d_seg = NULL;
+    if (!seg_params.empty() && e == hipSuccess) {
+        const uint32_t ns = (uint32_t)seg_params.size();
+        e = hipMalloc((void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg_params.data(), seg_params.size() * sizeof(jda_segscan_params), hipMemcpyHostToDevice, ctx->stream);
+        const uint32_t kMaxRounds = 48;                     // (the result words hold a change counter per round: 8 + 48 <= 64)
+        uint32_t rounds = 0;
+        bool settled = false;
+        while (e == hipSuccess && rounds < kMaxRounds && !settled) {
+            e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_SPEC, rounds, ctx->stream);
+            rounds++;
+            if (e == hipSuccess && rounds >= 3 && (rounds & 1u)) {      // look at the change counters every other round
+                for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
+                    Item &it = items[seg_owner[p]];
+                    e = hipMemcpyAsync(it.sst, it.d->base + it.off_sstats, sizeof(it.sst), hipMemcpyDeviceToHost, ctx->stream);
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                settled = true;
+                for (uint32_t p = 0; p < ns; p++) if (items[seg_owner[p]].sst[8 + rounds - 1] != 0) settled = false;
+            }
+        }
+        ctx->last_segscan_rounds = (int)rounds;
+        if (e == hipSuccess) e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_COUNT, rounds, ctx->stream);
+        for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
+            Item &it = items[seg_owner[p]];
+            it.seg_sum.resize((size_t)it.n_segs * 6); it.seg_start.assign((size_t)it.n_segs * 5, 0);
+            e = hipMemcpyAsync(it.seg_sum.data(), it.d->base + it.off_sum, (size_t)it.n_segs * 24, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
+            Item &it = items[seg_owner[p]];
+            // exclusive sums over the segments: first block ordinal, DC predictors, and the reference window's byte lag
+            // (the scan starts with pBuf at its first byte and ulBitOff 0, jpeg.inl:4996-4998)
+            uint64_t g = 0;
+            int32_t pred[3] = { 0, 0, 0 };
+            uint32_t j = 0;
+            bool ok = settled;
+            for (uint32_t i = 0; i < it.n_segs; i++) {
+                uint32_t *st = &it.seg_start[(size_t)i * 5];
+                const uint32_t *su = &it.seg_sum[(size_t)i * 6];
+                st[0] = g > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)g; st[1] = (uint32_t)pred[0]; st[2] = (uint32_t)pred[1]; st[3] = (uint32_t)pred[2]; st[4] = j;
+                g += su[0];
+                if (su[5]) {                                  // an invalid code: harmless only behind the image's last block
+                    if (g < (uint64_t)it.n_blocks + 1) ok = false;
+                    for (uint32_t r = i + 1; r < it.n_segs; r++) it.seg_start[(size_t)r * 5] = 0xfffffff0u;
+                    break;
+                }
+                pred[0] += (int32_t)su[1]; pred[1] += (int32_t)su[2]; pred[2] += (int32_t)su[3];
+                j = (su[4] >> (3u * j)) & 7u;
+            }
+            if (g < (uint64_t)it.n_blocks + 1) ok = false;   // the scan ends before the image does
+            it.dev_ok = ok;
+            e = hipMemcpyAsync(it.d->base + it.off_start, it.seg_start.data(), (size_t)it.n_segs * 20, hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (e == hipSuccess) e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_WRITE, rounds, ctx->stream);
+        for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
+            Item &it = items[seg_owner[p]];
+            e = hipMemcpyAsync(it.sst, it.d->base + it.off_sstats, sizeof(it.sst), hipMemcpyDeviceToHost, ctx->stream);
+        }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_params) (void)hipFree(d_params);
+    if (d_seg) (void)hipFree(d_seg);
     if (e != hipSuccess) return fail_all(set_err(ctx, e, "jda_upload_batch"));
 
     // a marker that is not where the MCU count puts it, or a corrupt interval: the serial host pre-scan reproduces
@@ -300,6 +409,22 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             if (e == hipSuccess) e = hipMemcpyAsync(it.d->base + it.d->off_dc, jda_image_block_dc(imgs[i]), it.n_blocks * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream);
             reupload = true;
             if (e != hipSuccess) break;
+        }
+    }
+    for (size_t p = 0; p < seg_owner.size() && e == hipSuccess; p++) {
+        const int i = seg_owner[p];
+        Item &it = items[i];
+        const jda_image_info &I = *jda_image_get_info(imgs[i]);
+        if (it.dev_ok && it.sst[0] == 0 && it.sst[1] == 1) {            // no bad code before the end, the closing index entry written once
+            jda_image_adopt_prescan(imgs[i], (uint32_t)(I.mcus_x * I.mcus_y), it.sst[2], (int32_t)it.sst[3], it.sst[4]);
+            it.d->prescan_on_device = 1;
+        } else {                                                         // corrupt or truncated stream: the serial pre-scan knows what the reference does
+            jda_image_run_host_prescan(imgs[i]);
+            uint32_t nok = 0;
+            const uint32_t *index = jda_image_block_index(imgs[i], &nok);
+            e = hipMemcpyAsync(it.d->base + it.d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(it.d->base + it.d->off_dc, jda_image_block_dc(imgs[i]), it.n_blocks * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream);
+            reupload = true;
         }
     }
     if (reupload && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -60,6 +60,8 @@ static uint32_t g_prescan_trunc = 0;
 extern "C" void hostsim_set_device_prescan(int on) { g_device_prescan = on; }
 extern "C" int hostsim_prescan_used(void) { return g_prescan_used; }
 extern "C" void jda_image_run_host_prescan(jda_image *img);
+static int g_segscan_rounds = 0;     // speculative rounds of the last marker-less device pre-scan
+extern "C" int hostsim_segscan_rounds(void) { return g_segscan_rounds; }
 static int g_index_equal = -1;       // after a device-pre-scanned decode: 1 if its index == the serial host pre-scan's
 extern "C" int hostsim_index_equal(void) { return g_index_equal; }
 
@@ -72,7 +74,132 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     std::vector<uint32_t> dev_index;
     std::vector<int16_t> dev_dc;
     g_prescan_used = 0;
-    if (jda_image_prescan_pending(img)) {          // what jda_upload does, lane by lane
+    if (jda_image_prescan_pending(img) && jda_image_get_info(img)->restart_interval == 0) {
+        // stream without restart markers (8f N2): what jda_upload_batch + jda_segscan do, lane by lane
+        const jda_image_info *I = jda_image_get_info(img);
+        const size_t nb = (size_t)I->mcus_x * I->mcus_y * I->blocks_per_mcu;
+        dev_index.assign(nb + 1, 0xdeadbeefu); dev_dc.assign(nb, 0x7777);
+        uint32_t sl = 0, tb = 0;
+        const uint8_t *scan = jda_image_scan(img, &sl);
+        const uint8_t *tables = jda_image_tables(img, &tb);
+        const uint32_t n_segs = sl / JDA_SEG_BYTES + 1u;
+        std::vector<uint32_t> padded(((size_t)n_segs * JDA_SEG_BYTES + 16) / 4 + 1, 0);
+        memcpy(padded.data(), scan, sl);
+        std::vector<uint64_t> lt_store((JDA_LT_BYTES + 7) / 8);
+        uint8_t *lt = (uint8_t *)lt_store.data();
+        for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables_from(tables, tid, 256, lt);
+        std::vector<uint32_t> ea(n_segs + 1, 0), eb(n_segs + 1, 0), seg_sum((size_t)n_segs * 6), seg_start((size_t)n_segs * 5, 0);
+        jda_segscan_params P;
+        memset(&P, 0, sizeof(P));
+        P.scan = (const uint8_t *)padded.data(); P.tables = tables;
+        P.seg_sum = seg_sum.data(); P.seg_start = seg_start.data();
+        P.blk_index = dev_index.data(); P.blk_dc = dev_dc.data();
+        P.scan_len = sl; P.n_segs = n_segs; P.n_blocks_total = (uint32_t)nb;
+        P.nblocks = (uint8_t)I->blocks_per_mcu; P.nluma = (uint8_t)(I->blocks_per_mcu - (I->ncomp == 3 ? 2 : 0));
+        uint8_t q_id[3];
+        jda_image_component_ids(img, P.dc_id, P.ac_id, q_id);
+        jda_seg_sum S;
+        jda_seg_stats ST;
+        memset(&ST, 0, sizeof(ST));
+        uint32_t rounds = 0;
+        bool settled = false;
+        uint32_t *cur = ea.data(), *nxt = eb.data();
+        while (rounds < 48 && !settled) {                       // SPEC rounds, exactly as the kernel's lanes do them
+            uint32_t changed = 0;
+            for (uint32_t seg = 0; seg < n_segs; seg++) {
+                const uint32_t entry = cur[seg];
+                const bool need = rounds == 0 || (entry & JDA_SEG_CHANGED) != 0;
+                const uint32_t old = cur[seg + 1] & ~JDA_SEG_CHANGED;
+                uint32_t out = old;
+                if (need) {
+                    const uint8_t *slot = (const uint8_t *)padded.data() + (size_t)seg * JDA_SEG_BYTES;
+                    const uint32_t x = jda_seg_walk<JDA_SEG_SPEC>(P, seg, entry & ~JDA_SEG_CHANGED, slot, lt, S, ST) & ~JDA_SEG_CHANGED;
+                    out = x;
+                    if (x != old) { out |= JDA_SEG_CHANGED; changed++; }
+                }
+                nxt[seg + 1] = out;
+            }
+            nxt[0] = 0;
+            std::swap(cur, nxt);
+            rounds++;
+            if (changed == 0) settled = true;
+        }
+        g_segscan_rounds = (int)rounds;
+        if (getenv("HOSTSIM_SEGDEBUG")) {       // how fast do the states become the true ones?
+            std::vector<uint32_t> truth(cur, cur + n_segs + 1), a(n_segs + 1, 0), b2(n_segs + 1, 0);
+            for (auto &t : truth) t &= ~JDA_SEG_CHANGED;
+            uint32_t *c2 = a.data(), *n2 = b2.data();
+            for (uint32_t r = 0; r < 12; r++) {
+                for (uint32_t seg = 0; seg < n_segs; seg++) {
+                    const uint8_t *slot = (const uint8_t *)padded.data() + (size_t)seg * JDA_SEG_BYTES;
+                    n2[seg + 1] = jda_seg_walk<JDA_SEG_SPEC>(P, seg, c2[seg], slot, lt, S, ST);
+                }
+                n2[0] = 0;
+                std::swap(c2, n2);
+                uint32_t good = 0, dead = 0;
+                for (uint32_t i = 0; i <= n_segs; i++) { good += c2[i] == truth[i]; dead += c2[i] == JDA_SEG_DEAD; }
+                fprintf(stderr, "round %u: %u of %u states true, %u dead\n", r, good, n_segs + 1, dead);
+            }
+        }
+        memset(&ST, 0, sizeof(ST));
+        for (uint32_t seg = 0; seg < n_segs; seg++) {           // COUNT
+            const uint8_t *slot = (const uint8_t *)padded.data() + (size_t)seg * JDA_SEG_BYTES;
+            (void)jda_seg_walk<JDA_SEG_COUNT>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST);
+            uint32_t *o = &seg_sum[(size_t)seg * 6];
+            o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
+        }
+        bool ok = settled;
+        {   // the host's sums (jda_upload_batch)
+            uint64_t g = 0;
+            int32_t pred[3] = { 0, 0, 0 };
+            uint32_t j = 0;
+            for (uint32_t i = 0; i < n_segs; i++) {
+                uint32_t *st = &seg_start[(size_t)i * 5];
+                const uint32_t *su = &seg_sum[(size_t)i * 6];
+                st[0] = g > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)g; st[1] = (uint32_t)pred[0]; st[2] = (uint32_t)pred[1]; st[3] = (uint32_t)pred[2]; st[4] = j;
+                g += su[0];
+                if (su[5]) {
+                    if (g < (uint64_t)nb + 1) ok = false;
+                    for (uint32_t r = i + 1; r < n_segs; r++) seg_start[(size_t)r * 5] = 0xfffffff0u;
+                    break;
+                }
+                pred[0] += (int32_t)su[1]; pred[1] += (int32_t)su[2]; pred[2] += (int32_t)su[3];
+                j = (su[4] >> (3u * j)) & 7u;
+            }
+            if (g < (uint64_t)nb + 1) ok = false;
+        }
+        memset(&ST, 0, sizeof(ST));
+        uint32_t terminal = 0;
+        for (uint32_t seg = 0; seg < n_segs; seg++) {           // WRITE
+            if (seg_start[(size_t)seg * 5] > P.n_blocks_total) continue;
+            const uint8_t *slot = (const uint8_t *)padded.data() + (size_t)seg * JDA_SEG_BYTES;
+            jda_seg_stats T1;
+            memset(&T1, 0, sizeof(T1));
+            (void)jda_seg_walk<JDA_SEG_WRITE>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1);
+            ST.bad |= T1.bad; terminal += T1.terminal; ST.trunc_events += T1.trunc_events;
+            if (T1.max_ac_bits > ST.max_ac_bits) ST.max_ac_bits = T1.max_ac_bits;
+            if (T1.max_abs_dc > ST.max_abs_dc) ST.max_abs_dc = T1.max_abs_dc;
+        }
+        if (ok && !ST.bad && terminal == 1) {
+            g_prescan_trunc = ST.trunc_events;
+            jda_image_adopt_prescan(img, (uint32_t)(I->mcus_x * I->mcus_y), ST.max_ac_bits, (int32_t)ST.max_abs_dc, ST.trunc_events);
+            g_prescan_used = 2;
+            int32_t e2 = 0;
+            jda_image *ref = jda_prepare(jpeg, len, &e2);
+            uint32_t nn = 0;
+            const uint32_t *hi = ref ? jda_image_block_index(ref, &nn) : NULL;
+            g_index_equal = ref && memcmp(hi, dev_index.data(), (nb + 1) * 4) == 0 && memcmp(jda_image_block_dc(ref), dev_dc.data(), nb * 2) == 0 &&
+                            jda_image_truncation_events(ref) == ST.trunc_events && jda_image_fast_mul(ref) == jda_image_fast_mul(img) ? 1 : 0;
+            if (ref && getenv("HOSTSIM_DEBUG")) {
+                for (size_t i = 0; i <= nb; i++) if (hi[i] != dev_index[i] || (i < nb && jda_image_block_dc(ref)[i] != dev_dc[i])) { fprintf(stderr, "first diff at block %zu of %zu: host %u/%u dc %d, dev %u/%u dc %d\n", i, nb, hi[i] >> 7, hi[i] & 127, i < nb ? jda_image_block_dc(ref)[i] : 0, dev_index[i] >> 7, dev_index[i] & 127, i < nb ? dev_dc[i] : 0); break; }
+                fprintf(stderr, "rounds %u trunc host %u dev %u\n", rounds, jda_image_truncation_events(ref), ST.trunc_events);
+            }
+            if (ref) jda_image_free(ref);
+        } else {                                                // corrupt / truncated: the serial pre-scan, as jda_upload_batch does
+            jda_image_run_host_prescan(img);
+            dev_index.clear(); dev_dc.clear();
+        }
+    } else if (jda_image_prescan_pending(img)) {          // what jda_upload does, lane by lane
         const jda_image_info *I = jda_image_get_info(img);
         const size_t nb = (size_t)I->mcus_x * I->mcus_y * I->blocks_per_mcu;
         dev_index.assign(nb + 1, 0xdeadbeefu); dev_dc.assign(nb, 0x7777);
@@ -104,11 +231,14 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             if (R.max_ac_bits > max_ac) max_ac = R.max_ac_bits;
             if (R.max_abs_dc > max_dc) max_dc = R.max_abs_dc;
         }
-        if (first_bad != 0xffffffffu || mismatch) { jda_image_free(img); return -100 - (int)(mismatch * 2); }
+        if (first_bad != 0xffffffffu || mismatch) {        // as jda_upload_batch: the serial pre-scan knows what the reference does
+            jda_image_run_host_prescan(img);
+            dev_index.clear(); dev_dc.clear();
+        } else {
         g_prescan_trunc = trunc;
         jda_image_adopt_prescan(img, P.n_mcus, max_ac, (int32_t)max_dc, trunc);
         g_prescan_used = 1;
-        {   // the EXACT pass must reproduce the serial pre-scan entry for entry
+        // the EXACT pass must reproduce the serial pre-scan entry for entry
             int32_t e2 = 0;
             jda_image *ref = jda_prepare(jpeg, len, &e2);
             uint32_t nn = 0;

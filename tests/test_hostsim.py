@@ -69,13 +69,31 @@ def test_restart_interval_prescan_equals_oracle(name, hostsim, oracle):
             assert hrc == 0 and hostsim.hostsim_prescan_used() == 1
             assert hostsim.hostsim_index_equal() == 1          # phase, DC predictor and truncation count of every block
             assert np.array_equal(got, want), (name, pt, opt)
-        # a stream without restart markers silently takes the serial pre-scan
-        plain = jpeg_for("c420_333x217")
-        rc, want, err = oracle.decode_canvas(plain, 2, 0)
-        got = np.full_like(want, 0x33)
-        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(plain, 2, 0)
-        assert hostsim.hostsim_decode(plain, len(plain), 2, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
-        assert hostsim.hostsim_prescan_used() == 0 and np.array_equal(got, want)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+
+
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "gray_333x217", "c420_256x256_q98", "c444_256x256_q100_opt",
+                                  "c420_1100x48", "gray_1600x16", "c420_16x16", "c444_8x8_q30", "c420_1280x720", "c422_333x217",
+                                  "c440_200x120", "c420_250x250_q10"])
+def test_markerless_prescan_equals_serial(name, hostsim, oracle):
+    """without restart markers the per-block index is made by the segment walk (jda_seg_walk: one lane per 256
+    bytes of the scan, speculative rounds until the decoder states at the segment boundaries stop changing, then the
+    count pass, the host's sums and the write pass -- emulated here lane by lane exactly as jda_upload_batch + jda_segscan
+    run them).  The index must equal the serial pre-scan's entry for entry (reader phase, DC predictor, closing entry,
+    truncation count, 24-bit-multiply verdict) and the decode must be the oracle's."""
+    jpeg = jpeg_for(name)
+    hostsim.hostsim_set_device_prescan(1)
+    try:
+        for pt, opt in ((2, 0), (0, 2), (3, 8)):
+            rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+            hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert hrc == 0 and hostsim.hostsim_prescan_used() == 2
+            assert hostsim.hostsim_index_equal() == 1
+            assert hostsim.hostsim_segscan_rounds() <= 20, hostsim.hostsim_segscan_rounds()      # self-synchronisation, not a serial crawl
+            assert np.array_equal(got, want), (name, pt, opt)
     finally:
         hostsim.hostsim_set_device_prescan(0)
 
@@ -93,6 +111,9 @@ def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
     rng = np.random.default_rng(11)
     agree = 0
     for it in range(80):
+        # every other stream goes through the device pre-scans (segment walk / restart intervals): a stream they cannot
+        # reproduce exactly must send them back to the serial pre-scan
+        hostsim.hostsim_set_device_prescan(it & 1)
         b = bytearray(base)
         for _ in range(int(rng.integers(1, 4))):
             b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
@@ -113,4 +134,5 @@ def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
             if rc == 1:
                 assert np.array_equal(got, want), (name, it, pt, opt)
                 agree += 1
+    hostsim.hostsim_set_device_prescan(0)
     assert agree >= 20
