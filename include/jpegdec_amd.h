@@ -162,16 +162,22 @@ int jda_copy_to_host(jda_ctx *ctx, void *host, const void *dptr, size_t bytes); 
 int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes); /* synchronous */
 
 /* H2D: tables + index + filtered scan of one prepared image into one HBM allocation.  For an image prepared
- * with JDA_PREPARE_DEVICE_PRESCAN whose index is still pending, the index is made here on the GPU (one lane
- * per restart interval); if that walk meets a symbol whose magnitude bits could straddle the reference's
- * 64-bit window (code length + size >= 18), a marker that is not where the MCU count puts it, or a corrupt
- * interval, the serial host pre-scan is run instead (the image object is completed in place). */
+ * with JDA_PREPARE_DEVICE_PRESCAN whose index is still pending, the index is made here on the GPU, equal to
+ * the serial pre-scan's entry for entry: with restart markers one lane per restart interval; without, one
+ * lane per 256 bytes of the scan, whose decoder states settle by self-synchronisation in a few speculative
+ * rounds.  A marker that is not where the MCU count puts it, a corrupt or truncated stream, or states that do
+ * not settle send the image to the serial host pre-scan instead (the image object is completed in place). */
 jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err);
 /* The same for n images at once: all pending block indexes are made in two launches (the per-interval walk is
  * latency-bound, so throughput comes from the number of restart intervals in flight).  out[i] = device image.
  * Returns JDA_SUCCESS or the first error (then every out[i] is NULL). */
 int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out);
-int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: the restart-marker fast path produced the index */
+int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: a device pre-scan produced the index */
+/* copy the per-block index (n_blocks + 1 entries) and DC predictors (n_blocks) of a resident image back to the host
+ * (either pointer may be NULL); n_blocks = mcus_x * mcus_y * blocks_per_mcu.  Synchronous. */
+int jda_dev_image_read_index(jda_ctx *ctx, const jda_dev_image *dimg, uint32_t *index, int16_t *dc);
+uint32_t jda_dev_image_mcus_ok(const jda_dev_image *dimg);        /* MCUs the pre-scan validated */
+int jda_last_prescan_rounds(const jda_ctx *ctx);   /* speculative rounds of the last marker-less device pre-scan (diagnostics) */
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg);
 size_t jda_dev_image_bytes(const jda_dev_image *dimg);
 

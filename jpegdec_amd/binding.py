@@ -56,6 +56,9 @@ _PROTOTYPES = [
     ("jda_image_prescan_pending", C.c_int, [_P]),
     ("jda_prepare_batch", C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("jda_dev_image_prescan_on_device", C.c_int, [_P]),
+    ("jda_last_prescan_rounds", C.c_int, [_P]),
+    ("jda_dev_image_read_index", C.c_int, [_P, _P, _P, _P]),
+    ("jda_dev_image_mcus_ok", C.c_uint32, [_P]),
     ("jda_upload_batch", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
     ("jda_image_free", None, [_P]),
     ("jda_image_get_info", C.POINTER(ImageInfo), [_P]),
@@ -280,6 +283,17 @@ class DeviceImage:
         self.info = ImageInfo.from_buffer_copy(prepared.info)
         self.nbytes = ctx.lib.jda_dev_image_bytes(self.handle)
         self.prescan_on_device = bool(ctx.lib.jda_dev_image_prescan_on_device(self.handle))
+        self.n_mcus_ok = int(ctx.lib.jda_dev_image_mcus_ok(self.handle))
+
+    def read_index(self):
+        """(index[n_blocks + 1] uint32, dc[n_blocks] int16) as they stand in HBM"""
+        nb = self.info.mcus_x * self.info.mcus_y * self.info.blocks_per_mcu
+        idx = np.zeros(nb + 1, np.uint32)
+        dc = np.zeros(nb, np.int16)
+        rc = self.ctx.lib.jda_dev_image_read_index(self.ctx.handle, self.handle, idx.ctypes.data_as(C.c_void_p), dc.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise JdaError(rc, "jda_dev_image_read_index")
+        return idx, dc
 
     def close(self):
         if self.handle:

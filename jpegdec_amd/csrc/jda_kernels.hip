@@ -480,6 +480,76 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
     }
 }
 
+// Exclusive sums over the segments of one image (one wavefront per image, 64 segments per step): first block ordinal and
+// DC predictors at every segment's entry (wave prefix sums + a carry), and the reference window's byte lag (composition of
+// the segments' phase maps: eight values wide, so it is walked lane by lane with readlane -- 64 scalar steps per 64
+// segments).  A segment that met an invalid code ends the sums: harmless only behind the image's last block.
+// Result words: stats[6] = 1 when the index can be written (enough blocks, no bad code before the end).
+__device__ __forceinline__ uint32_t jda_wave_incl_sum_u32(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x;
+}
+
+__global__ __launch_bounds__(64)
+void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
+{
+    const jda_segscan_params P = params[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    uint32_t *seg_start = const_cast<uint32_t *>(P.seg_start);
+    uint32_t g_carry = 0, p0 = 0, p1 = 0, p2 = 0, j = 0;          // wave-uniform running values
+    bool ended = false, ok = true;
+    for (uint32_t base = 0; base < P.n_segs; base += 64u) {
+        const uint32_t seg = base + lane;
+        const bool in = seg < P.n_segs;
+        uint32_t nblk = 0, d0 = 0, d1 = 0, d2 = 0, map = 0x00fac688u /* identity: j -> j */, bad = 0;
+        if (in && !ended) {
+            const uint32_t *su = P.seg_sum + (size_t)seg * 6;
+            nblk = su[0]; d0 = su[1]; d1 = su[2]; d2 = su[3]; map = su[4]; bad = su[5];
+        }
+        // the first bad segment of this step (its own block count still counts; nothing behind it does)
+        const uint64_t badmask = __builtin_amdgcn_ballot_w64(bad != 0);
+        const uint32_t first_bad = badmask ? (uint32_t)__builtin_ctzll(badmask) : 64u;
+        if (lane > first_bad) { nblk = 0; d0 = d1 = d2 = 0; }
+        const uint32_t in_g = jda_wave_incl_sum_u32(nblk), in0 = jda_wave_incl_sum_u32(d0), in1 = jda_wave_incl_sum_u32(d1), in2 = jda_wave_incl_sum_u32(d2);
+        // window lag at every lane's entry: serial composition over the 64 maps of this step
+        uint32_t my_j = 0, jj = j;
+        for (uint32_t l = 0; l < 64u; l++) {
+            if (lane == l) my_j = jj;
+            const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)map, (int)l);
+            jj = (m >> (3u * jj)) & 7u;
+        }
+        if (in) {
+            uint32_t *st = seg_start + (size_t)seg * 5;
+            const bool dead = ended || lane > first_bad;            // behind a bad code: the write pass skips these
+            const uint32_t gs = g_carry + in_g - nblk;
+            st[0] = dead ? 0xfffffff0u : (gs > 0xfffffff0u ? 0xfffffff0u : gs);
+            st[1] = p0 + in0 - d0; st[2] = p1 + in1 - d1; st[3] = p2 + in2 - d2; st[4] = my_j;
+        }
+        g_carry += (uint32_t)__builtin_amdgcn_readlane((int)in_g, 63);
+        p0 += (uint32_t)__builtin_amdgcn_readlane((int)in0, 63);
+        p1 += (uint32_t)__builtin_amdgcn_readlane((int)in1, 63);
+        p2 += (uint32_t)__builtin_amdgcn_readlane((int)in2, 63);
+        j = jj;
+        if (!ended && badmask) { ended = true; if (g_carry < P.n_blocks_total + 1u) ok = false; }
+    }
+    if (g_carry < P.n_blocks_total + 1u) ok = false;               // the scan ends before the image does
+    if (lane == 0) P.stats[6] = ok ? 1u : 0u;
+}
+
+extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream)
+{
+    if (n_images == 0) return hipSuccess;
+    hipLaunchKernelGGL(jda_segscan_sums, dim3(n_images), dim3(64), 0, stream, params);
+    return hipGetLastError();
+}
+
 // op: JDA_SEG_SPEC (round = 0, 1, ..: the entry-state buffers swap roles every round), JDA_SEG_COUNT / JDA_SEG_WRITE (round = the
 // number of SPEC rounds that ran: tells which buffer holds the final states)
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream)

@@ -9,9 +9,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "jda_internal.h"
@@ -24,6 +27,7 @@ extern "C" int jda_image_index_on_device(const jda_image *img);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
 extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
+extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
 
@@ -154,9 +158,20 @@ int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes)
 // markers) get it made on the GPU, all of them in two launches (phase-map pass, exact pass: one lane per
 // restart interval, one grid row per image) -- the walk is latency-bound per lane, so it is the number of
 // intervals in flight that makes it fast.  out[i] receives the device image (NULL on failure).
+static double now_ms()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
+    const bool trace = getenv("JDA_UPLOAD_TRACE") != NULL;          // stage timings on stderr (diagnostics)
+    const double t_begin = now_ms();
+    double t_mark = t_begin;
+#define JDA_UP_MARK(what) do { if (trace) { (void)hipStreamSynchronize(ctx->stream); const double t_ = now_ms(); fprintf(stderr, "jda_upload_batch: %-28s %8.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
     if (n <= 0 || !imgs || !out) return JDA_INVALID_PARAMETER;
     (void)hipSetDevice(ctx->device);
     struct Item {
@@ -165,7 +180,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         std::vector<uint32_t> map; std::vector<uint8_t> phase; uint32_t st[5];
         // streams without restart markers (8f N2): segments of the scan, see jda_seg_walk
         bool seg_mode; uint32_t n_segs; size_t off_ea, off_eb, off_sum, off_start, off_sstats; bool dev_ok;
-        std::vector<uint32_t> seg_sum, seg_start; uint32_t sst[64];
+        uint32_t sst[64];
     };
     std::vector<Item> items((size_t)n);
     int rc = JDA_SUCCESS;
@@ -185,10 +200,34 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     // copies in flight are drained and it is reused from the start
     const size_t kPinnedMax = (size_t)512 << 20;
     size_t pin_off = 0;
+    // host copies into the page-locked buffer are the bulk of an upload's host time: they are collected and done by a
+    // few threads, and each image's H2D copies are enqueued when its bytes are in place
+    struct StageJob { uint8_t *dst; const uint8_t *src; size_t bytes; int image; };
+    std::vector<StageJob> stage_jobs;
+    hipError_t stage_err = hipSuccess;
+    auto flush_stage_jobs = [&]() {
+        if (stage_jobs.empty()) return;
+        const size_t nj = stage_jobs.size();
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = std::min<size_t>(std::min<size_t>(nj, 8), hw ? hw : 1);
+        std::atomic<size_t> next(0);
+        auto work = [&]() { for (size_t k; (k = next.fetch_add(1)) < nj;) memcpy(stage_jobs[k].dst, stage_jobs[k].src, stage_jobs[k].bytes); };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (size_t k = 0; k < nj && stage_err == hipSuccess; k++) {
+            Item &it = items[stage_jobs[k].image];
+            stage_err = hipMemcpyAsync(it.d->base + it.d->off_tables, it.stage, it.tbytes, hipMemcpyHostToDevice, ctx->stream);
+            if (stage_err == hipSuccess) stage_err = hipMemcpyAsync(it.d->base + it.d->off_scan, stage_jobs[k].dst, stage_jobs[k].bytes, hipMemcpyHostToDevice, ctx->stream);
+        }
+        stage_jobs.clear();
+    };
     auto pin_slice = [&](size_t bytes) -> uint8_t * {
         bytes = (bytes + 255) & ~(size_t)255;
         if (bytes > kPinnedMax) return NULL;
         if (bytes > ctx->pinned_cap) {
+            flush_stage_jobs();
             (void)hipStreamSynchronize(ctx->stream);
             if (ctx->pinned) (void)hipHostFree(ctx->pinned);
             ctx->pinned = NULL; ctx->pinned_cap = 0;
@@ -198,7 +237,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             ctx->pinned_cap = want;
             pin_off = 0;
         }
-        if (pin_off + bytes > ctx->pinned_cap) { (void)hipStreamSynchronize(ctx->stream); pin_off = 0; }
+        if (pin_off + bytes > ctx->pinned_cap) { flush_stage_jobs(); (void)hipStreamSynchronize(ctx->stream); pin_off = 0; }
         uint8_t *p = ctx->pinned + pin_off;
         pin_off += bytes;
         return p;
@@ -251,9 +290,13 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.stage = pin_slice(up);
             if (!it.stage) { it.heap.assign(up, 0); it.stage = it.heap.data(); }
             memcpy(it.stage, tables, it.tbytes);
-            memcpy(it.stage + align16(it.tbytes), scan, scan_len);
-            e = hipMemcpyAsync(d->base + d->off_tables, it.stage, it.tbytes, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(d->base + d->off_scan, it.stage + align16(it.tbytes), scan_len, hipMemcpyHostToDevice, ctx->stream);
+            // the scan's copy into the page-locked slice is left to the staging threads (below): job = (dst, src, bytes, image)
+            if (it.heap.empty()) { stage_jobs.push_back({ it.stage + align16(it.tbytes), scan, (size_t)scan_len, i }); }
+            else {
+                memcpy(it.stage + align16(it.tbytes), scan, scan_len);
+                e = hipMemcpyAsync(d->base + d->off_tables, it.stage, it.tbytes, hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(d->base + d->off_scan, it.stage + align16(it.tbytes), scan_len, hipMemcpyHostToDevice, ctx->stream);
+            }
             if (e == hipSuccess) e = hipMemsetAsync(d->base + d->off_scan + scan_len, 0, it.alloc - (d->off_scan + scan_len), ctx->stream);
             if (e != hipSuccess) { rc = set_err(ctx, e, "hipMemcpy(image)"); break; }
             jda_segscan_params SP;
@@ -301,7 +344,10 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         e = hipMemcpyAsync(d->base, it.stage, it.alloc, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { rc = set_err(ctx, e, "hipMemcpy(image)"); break; }
     }
+    flush_stage_jobs();
+    if (rc == JDA_SUCCESS && stage_err != hipSuccess) rc = set_err(ctx, stage_err, "hipMemcpy(image)");
     if (rc != JDA_SUCCESS) { (void)hipStreamSynchronize(ctx->stream); return fail_all(rc); }
+    JDA_UP_MARK("alloc + stage + H2D");
 
     jda_prescan_params *d_params = NULL;
     if (!params.empty()) {
@@ -348,38 +394,12 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             }
         }
         ctx->last_segscan_rounds = (int)rounds;
+        JDA_UP_MARK("speculative rounds");
         if (e == hipSuccess) e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_COUNT, rounds, ctx->stream);
-        for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
-            Item &it = items[seg_owner[p]];
-            it.seg_sum.resize((size_t)it.n_segs * 6); it.seg_start.assign((size_t)it.n_segs * 5, 0);
-            e = hipMemcpyAsync(it.seg_sum.data(), it.d->base + it.off_sum, (size_t)it.n_segs * 24, hipMemcpyDeviceToHost, ctx->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
-            Item &it = items[seg_owner[p]];
-            // exclusive sums over the segments: first block ordinal, DC predictors, and the reference window's byte lag
-            // (the scan starts with pBuf at its first byte and ulBitOff 0, jpeg.inl:4996-4998)
-            uint64_t g = 0;
-            int32_t pred[3] = { 0, 0, 0 };
-            uint32_t j = 0;
-            bool ok = settled;
-            for (uint32_t i = 0; i < it.n_segs; i++) {
-                uint32_t *st = &it.seg_start[(size_t)i * 5];
-                const uint32_t *su = &it.seg_sum[(size_t)i * 6];
-                st[0] = g > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)g; st[1] = (uint32_t)pred[0]; st[2] = (uint32_t)pred[1]; st[3] = (uint32_t)pred[2]; st[4] = j;
-                g += su[0];
-                if (su[5]) {                                  // an invalid code: harmless only behind the image's last block
-                    if (g < (uint64_t)it.n_blocks + 1) ok = false;
-                    for (uint32_t r = i + 1; r < it.n_segs; r++) it.seg_start[(size_t)r * 5] = 0xfffffff0u;
-                    break;
-                }
-                pred[0] += (int32_t)su[1]; pred[1] += (int32_t)su[2]; pred[2] += (int32_t)su[3];
-                j = (su[4] >> (3u * j)) & 7u;
-            }
-            if (g < (uint64_t)it.n_blocks + 1) ok = false;   // the scan ends before the image does
-            it.dev_ok = ok;
-            e = hipMemcpyAsync(it.d->base + it.off_start, it.seg_start.data(), (size_t)it.n_segs * 20, hipMemcpyHostToDevice, ctx->stream);
-        }
+        JDA_UP_MARK("count pass");
+        if (e == hipSuccess) e = jda_launch_segscan_sums(d_seg, ns, ctx->stream);      // first block ordinal, DC predictors, window lag per segment
+        for (uint32_t p = 0; p < ns; p++) items[seg_owner[p]].dev_ok = settled;
+        JDA_UP_MARK("sums");
         if (e == hipSuccess) e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_WRITE, rounds, ctx->stream);
         for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
             Item &it = items[seg_owner[p]];
@@ -387,6 +407,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    JDA_UP_MARK("write pass + D2H");
     if (d_params) (void)hipFree(d_params);
     if (d_seg) (void)hipFree(d_seg);
     if (e != hipSuccess) return fail_all(set_err(ctx, e, "jda_upload_batch"));
@@ -415,7 +436,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         const int i = seg_owner[p];
         Item &it = items[i];
         const jda_image_info &I = *jda_image_get_info(imgs[i]);
-        if (it.dev_ok && it.sst[0] == 0 && it.sst[1] == 1) {            // no bad code before the end, the closing index entry written once
+        if (it.dev_ok && it.sst[6] == 1 && it.sst[0] == 0 && it.sst[1] == 1) {   // states settled, enough blocks, no bad code before the end, the closing index entry written once
             jda_image_adopt_prescan(imgs[i], (uint32_t)(I.mcus_x * I.mcus_y), it.sst[2], (int32_t)it.sst[3], it.sst[4]);
             it.d->prescan_on_device = 1;
         } else {                                                         // corrupt or truncated stream: the serial pre-scan knows what the reference does
@@ -450,6 +471,19 @@ jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err)
 }
 
 int jda_dev_image_prescan_on_device(const jda_dev_image *dimg) { return dimg ? dimg->prescan_on_device : 0; }
+int jda_last_prescan_rounds(const jda_ctx *ctx) { return ctx ? ctx->last_segscan_rounds : 0; }
+uint32_t jda_dev_image_mcus_ok(const jda_dev_image *dimg) { return dimg ? dimg->n_mcus_ok : 0; }
+int jda_dev_image_read_index(jda_ctx *ctx, const jda_dev_image *dimg, uint32_t *index, int16_t *dc)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (!dimg) return JDA_INVALID_PARAMETER;
+    (void)hipSetDevice(ctx->device);
+    const size_t nb = (size_t)dimg->info.mcus_x * dimg->info.mcus_y * dimg->info.blocks_per_mcu;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && index) e = hipMemcpy(index, dimg->base + dimg->off_index, (nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && dc) e = hipMemcpy(dc, dimg->base + dimg->off_dc, nb * sizeof(int16_t), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? JDA_SUCCESS : set_err(ctx, e, "jda_dev_image_read_index");
+}
 
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg)
 {

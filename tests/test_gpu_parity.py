@@ -118,7 +118,7 @@ def test_restart_marker_fast_path(name, gpu_ctx, oracle):
     # several images at once (jda_upload_batch): markers and no markers mixed
     preps = [J.PreparedImage(jpeg_for(nm), device_prescan=True) for nm in (name, "c420_333x217", name)]
     dimgs = J.upload_batch(gpu_ctx, preps)
-    assert [d.prescan_on_device for d in dimgs] == [True, False, True]
+    assert [d.prescan_on_device for d in dimgs] == [True, True, True]     # (the marker-less one by the segment walk, 8f N2)
     for p_, d_, nm in zip(preps, dimgs, (name, "c420_333x217", name)):
         pt = J.GRAY8 if nm.startswith("gray") else J.RGB8888
         rc, want, _ = oracle.decode_canvas(jpeg_for(nm), pt, 0)
@@ -130,9 +130,72 @@ def test_restart_marker_fast_path(name, gpu_ctx, oracle):
         got = gpu_ctx.to_host(out, pitch * want.shape[0]).reshape(want.shape[0], pitch)[:, : want.shape[1]]
         assert np.array_equal(got, want), (nm, "batch upload")
         gpu_ctx.free(out)
-    # a stream without markers: the flag changes nothing
-    plain = J.PreparedImage(jpeg_for("c420_333x217"), device_prescan=True)
-    assert not plain.prescan_pending
+
+
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "gray_333x217", "c420_256x256_q98", "c444_256x256_q100_opt",
+                                  "c420_1100x48", "gray_1600x16", "c420_16x16", "c444_8x8_q30", "c420_1280x720", "c422_333x217",
+                                  "c440_200x120", "c420_250x250_q10"])
+def test_markerless_device_prescan(name, gpu_ctx, oracle):
+    """JDA_PREPARE_DEVICE_PRESCAN on a stream WITHOUT restart markers: the per-block index is made on the GPU
+    by the segment walk (jda_segscan: speculative rounds, count, write).  The index in HBM must equal the serial host
+    pre-scan's byte for byte (reader phase of every block, DC predictors, closing entry), and the pixels the oracle's."""
+    import jpegdec_amd as J
+    jpeg = jpeg_for(name)
+    prep = J.PreparedImage(jpeg, device_prescan=True)
+    assert prep.prescan_pending
+    dimg = J.DeviceImage(gpu_ctx, prep)
+    assert dimg.prescan_on_device and not prep.prescan_pending
+    assert 1 <= gpu_ctx.lib.jda_last_prescan_rounds(gpu_ctx.handle) <= 24
+    host = J.PreparedImage(jpeg)                       # serial pre-scan
+    want_idx, nok = host.block_index()
+    got_idx, got_dc = dimg.read_index()
+    assert np.array_equal(got_idx, want_idx)
+    assert np.array_equal(got_dc, host.block_dc())
+    for pt, opt in ((J.RGB8888, 0), (J.RGB565_LE, J.SCALE_HALF), (J.GRAY8, J.SCALE_EIGHTH)):
+        if name.startswith("gray") and pt == J.RGB8888:
+            continue
+        rc, want, _ = oracle.decode_canvas(jpeg, pt, opt)
+        g = prep.geometry(pt, opt)
+        pitch = (want.shape[1] + 15) // 16 * 16
+        out = gpu_ctx.malloc(pitch * want.shape[0])
+        b = J.Batch(gpu_ctx, [dimg], [(out, pitch, g["canvas_w"], g["canvas_h"])], [pt], [opt])
+        b.decode(); gpu_ctx.sync()
+        got = gpu_ctx.to_host(out, pitch * want.shape[0]).reshape(want.shape[0], pitch)[:, : want.shape[1]]
+        assert np.array_equal(got, want), (name, pt, opt)
+        b.close(); gpu_ctx.free(out)
+    dimg.close()
+
+
+def test_markerless_device_prescan_batch_and_fallback(gpu_ctx, oracle):
+    """Many images of different sizes in one jda_upload_batch (one launch per pass for all of them), and corrupted streams
+    among them: those must come out exactly as through the serial pre-scan (the device walk hands them back)."""
+    import jpegdec_amd as J
+    names = ["c420_1280x720", "c444_8x8_q30", "gray_1600x16", "c420_333x217", "c444_256x256_q100_opt", "c420_16x16"]
+    jpegs = [jpeg_for(n) for n in names]
+    base = bytearray(jpeg_for("c420_333x217"))
+    sos = bytes(base).index(b"\xff\xda")
+    rng = np.random.default_rng(5)
+    for it in range(10):                                 # corrupted variants
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+        try:
+            J.PreparedImage(bytes(b)).close()
+        except J.JdaError:
+            continue
+        jpegs.append(bytes(b))
+    preps = [J.PreparedImage(j, device_prescan=True) for j in jpegs]
+    dimgs = J.upload_batch(gpu_ctx, preps)
+    assert all(d.prescan_on_device for d in dimgs[: len(names)])
+    for j, p_, d_ in zip(jpegs, preps, dimgs):
+        host = J.PreparedImage(j)
+        want_idx, nok = host.block_index()
+        got_idx, got_dc = d_.read_index()
+        nb = nok * p_.info.blocks_per_mcu
+        assert np.array_equal(got_idx[:nb], want_idx[:nb])
+        assert np.array_equal(got_dc[:nb], host.block_dc()[:nb])
+        assert d_.n_mcus_ok == nok
+        d_.close(); host.close()
 
 
 def test_corrupted_scans_on_the_gpu(gpu_ctx, oracle):
