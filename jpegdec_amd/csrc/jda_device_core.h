@@ -539,20 +539,6 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
 // decode below is written without divergent branches: P1 is bound by the latency of its dependent
 // chain (stream bits -> LUT -> bit offset -> stream bits), not by instruction issue, and every
 // exec-mask region in that chain costs a VALU->SALU->branch round trip.
-JDA_HD uint64_t jda_load_be64_win(const uint8_t *wbase, uint32_t pos)     // wbase = win - win_lo
-{
-    const jda_u32_alias *p = (const jda_u32_alias *)(wbase + (pos & ~3u));
-    return jda_be64_from_words(p[0], p[1], p[2], pos);
-}
-// jpeg.inl:2110-2114 under a predicate.  bits == load(pos) always holds, so reloading at an unchanged
-// position is a no-op and the load needs no select.
-JDA_HD void jda_refill_win(jda_bitreader &br, const uint8_t *wbase, bool enable)
-{
-    const bool go = enable && br.off > 47;
-    br.pos += go ? (br.off >> 3) : 0u;
-    br.off = go ? (br.off & 7u) : br.off;
-    br.bits = jda_load_be64_win(wbase, br.pos);
-}
 // x >> n for n in 0..32 (hardware shifts take n mod 32; a result for n == 32 is never used)
 JDA_HD uint32_t jda_shr_upto32(uint32_t x, uint32_t n)
 {
@@ -570,12 +556,46 @@ JDA_HD int32_t jda_extend_top(uint32_t t, uint32_t s)
     return (int32_t)(v + (neg & ((0xffffffffu << s) + 1u)));
 }
 
-template <int LIMIT>
-JDA_HD uint32_t jda_decode_block_win(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill)
+// The reader of the window-only path.  It does NOT keep the reference's 64-bit window: it keeps its own 64 bits
+// (hi:lo, refilled a dword at a time, the next dword prefetched one refill ahead so that no LDS round trip sits between two
+// symbols), and only the reference's ulBitOff (roff) to know which magnitude reads the reference truncates: with ulBitOff = x
+// after the code, (ulBits << x) holds 64 - x stream bits and zeros below, so a magnitude of s > 64 - x bits loses its low
+// s - (64 - x) bits.  That is rare (a handful per image), so it is a branch, not arithmetic on every symbol.
+struct jda_wreader {
+    uint32_t hi, lo, nxt;    // 64 stream bits + the dword after them (big-endian order restored)
+    uint32_t boff;           // bits of hi already consumed (< 32 between symbols)
+    uint32_t roff;           // the reference's ulBitOff
+    const uint8_t *wp;       // LDS address nxt came from
+};
+JDA_HD uint32_t jda_wr_be32(const uint8_t *p) { return __builtin_bswap32(*(const jda_u32_alias *)p); }
+JDA_HD void jda_wr_init(jda_wreader &R, const uint8_t *wbase, uint32_t pos, uint32_t off)
 {
-    const uint8_t *wbase = br.win - br.win_lo;
-    uint32_t fl = 0;                                     // OR of zz16 entries of the stored coefficients
-    jda_refill_win(br, wbase, true);
+    const uint32_t bit = (pos << 3) + off;
+    const uint8_t *p = wbase + ((bit >> 5) << 2);
+    R.hi = jda_wr_be32(p); R.lo = jda_wr_be32(p + 4); R.nxt = jda_wr_be32(p + 8);
+    R.wp = p + 8; R.boff = bit & 31u; R.roff = off;
+}
+JDA_HD uint32_t jda_wr_peek(const jda_wreader &R) { return (uint32_t)(((((uint64_t)R.hi << 32) | R.lo) << R.boff) >> 32); }
+// n <= 31 bits consumed: slide a dword when hi is used up; the reference's refill (jpeg.inl:2110-2114) is a pure counter here
+JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n)
+{
+    R.boff += n;
+    const bool go = R.boff >= 32u;
+    R.hi = go ? R.lo : R.hi;
+    R.lo = go ? R.nxt : R.lo;
+    R.boff &= 31u;
+    R.wp += go ? 4 : 0;
+    R.nxt = jda_wr_be32(R.wp);                          // (re)loaded every time: unchanged address, unchanged value
+}
+JDA_HD void jda_wr_ref_refill(jda_wreader &R) { R.roff = R.roff > 47u ? (R.roff & 7u) : R.roff; }
+
+template <int LIMIT>
+JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill)
+{
+    jda_wreader R;
+    jda_wr_init(R, wbase, pos, off);
+    uint32_t fl = 0;                                     // OR of zz entries of the stored coefficients
+    jda_wr_ref_refill(R);
     if (LIMIT == 64) {
         if (zero_fill) {
             jda_u64_alias *z = (jda_u64_alias *)coef;
@@ -585,42 +605,46 @@ JDA_HD uint32_t jda_decode_block_win(jda_bitreader &br, const jda_tables &T, int
     } else if (LIMIT == 5) {
         coef[1] = 0; coef[8] = 0; coef[9] = 0;
     }
-    // DC  (:2129-2165), predicated
-    uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
+    // DC  (:2129-2165).  Code (<= 16 bits) and magnitude (<= 15) are both inside the 32 peeked bits; the reference
+    // refills before the magnitude read (:2149), so a DC value is never truncated.
+    uint32_t w = jda_wr_peek(R);
+    uint32_t code = w >> 20;
     code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
     uint32_t e = T.dc[code];
     const int32_t folded = (int8_t)T.dc[code + 512];
-    br.off += e >> 4;
-    const uint32_t s = e & 0xfu;
-    const bool take = s != 0 && folded == 0;             // magnitude bits follow in the stream (refill first, :2149)
-    jda_refill_win(br, wbase, take);
-    const int32_t mag = jda_extend_top((uint32_t)((br.bits << (br.off & 63u)) >> 32), s);
+    const uint32_t dlen = e >> 4, s = e & 0xfu;
+    const bool take = s != 0 && folded == 0;             // magnitude bits follow in the stream
+    const int32_t mag = jda_extend_top(w << dlen, s);
     pred += s == 0 ? 0 : (folded ? folded : mag);
-    br.off += take ? s : 0u;
+    R.roff += dlen;
+    if (take) { jda_wr_ref_refill(R); R.roff += s; }
+    jda_wr_consume(R, dlen + (take ? s : 0u));
     if (LIMIT == 1) return 0;
     coef[0] = (int16_t)pred;
     int k = 1;
-    jda_refill_win(br, wbase, true);
+    jda_wr_ref_refill(R);
     for (;;) {
-        // the next 32 bits of the window; zeros enter at the bottom exactly as in the reference's
-        // (ulBits << ulBitOff), so truncated magnitudes come out truncated
-        const uint32_t w = (uint32_t)((br.bits << br.off) >> 32);
+        w = jda_wr_peek(R);
         e = T.ac_short[w >> 22];
         if (__builtin_expect(w >= 0xfc000000u, 0)) e = jda_ac_entry(T.ac_long[(w >> 16) & 0x3ffu]);     // rare: codes starting 111111
         const uint32_t len = e >> 11;
-        if ((e & 0xffu) == 0) { br.off += len; break; }
+        if ((e & 0xffu) == 0) break;                     // EOB (the block's reader state is not needed any more)
         // the zigzag lookup decides where the value goes: position k + R of the block, or the padding when that is past
         // the block or the symbol carries no value (ZRL: bits 10:4 of the entry read R + 64)
         const uint32_t kk = (uint32_t)k + ((e >> 4) & 0x7fu);
         uint32_t t = T.zz[kk];
         if (LIMIT != 64 && kk >= (uint32_t)LIMIT) t = JDA_ZZ_DUMP;     // 1/4 scale keeps zigzag 1..4 only (:2117-2119)
         const uint32_t ms = e & 0xfu;
-        const int32_t v = jda_extend_top(w << len, ms);
+        uint32_t m = w << len;
+        const uint32_t x = R.roff + len;                 // the reference's ulBitOff at its magnitude read (:2249)
+        if (__builtin_expect(x + ms > 64u, 0)) m &= ~(0xffffffffu >> (64u - x));      // its window ends inside the magnitude
+        const int32_t v = jda_extend_top(m, ms);
         fl |= t;
         *(int16_t *)((uint8_t *)coef + (t & 0xffu)) = (int16_t)v;
-        br.off += len + ms;
+        R.roff = x + ms;
+        jda_wr_consume(R, len + ms);
         k += (int)((e >> 4) & 0xfu) + 1;
-        jda_refill_win(br, wbase, true);
+        jda_wr_ref_refill(R);
         if (k >= LIMIT) break;
     }
     // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested; fl holds 2n in 7:0
@@ -1245,25 +1269,29 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     const uint32_t ix = in.ix;
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
-    br.bits = jda_load_be64(br, br.pos);
+    const uint8_t *wbase = br.win - br.win_lo;
     int32_t pred = in.pred;
 
     JDA_P1_TRACE(8);
     const int shift = D.scale_shift;
     const bool win_only = C.win_need <= br.win_len;             // wave-uniform: the whole slice is in LDS
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
-        if (win_only) jda_decode_block_win<1>(br, TB, coef, pred, true); else jda_decode_block<1>(br, TB, coef, pred);
+        if (win_only) jda_decode_block_win<1>(br.pos, br.off, wbase, TB, coef, pred, true); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred); }
         *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
         return JDA_NO_LIST;
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
-        const uint32_t flags = win_only ? jda_decode_block_win<5>(br, TB, coef, pred, true) : jda_decode_block<5>(br, TB, coef, pred);
+        uint32_t flags;
+        if (win_only) flags = jda_decode_block_win<5>(br.pos, br.off, wbase, TB, coef, pred, true);
+        else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred); }
         const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
                                        : jda_idct_2x2(coef, quant);
         *(jda_u32_alias *)plane = px;
         return JDA_NO_LIST;
     }
-    const uint32_t flags = win_only ? jda_decode_block_win<64>(br, TB, coef, pred, true) : jda_decode_block<64>(br, TB, coef, pred);
+    uint32_t flags;
+    if (win_only) flags = jda_decode_block_win<64>(br.pos, br.off, wbase, TB, coef, pred, true);
+    else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred); }
     JDA_P1_TRACE(9);
     return flags;
 }
