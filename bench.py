@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--pixel-type", default="rgb8888", choices=["rgb8888", "rgb565", "gray8"])
     ap.add_argument("--options", type=int, default=0)
     ap.add_argument("--restart-rows", type=int, default=0, help="encode the inputs with a restart marker every N MCU rows (0 = none, the headline config)")
-    ap.add_argument("--device-prescan", action="store_true", help="JDA_PREPARE_DEVICE_PRESCAN: with restart markers the block index is made on the GPU at upload")
+    ap.add_argument("--device-prescan", action="store_true", help="JDA_PREPARE_DEVICE_PRESCAN: the block index is made on the GPU at upload (restart intervals, or the self-synchronising segment walk)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the control collectives (nccl = RCCL)")
@@ -139,6 +139,7 @@ def main():
     for i in range(args.batch):
         outputs.append((out_base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]))
     t_up = (time.perf_counter() - t_up0) / args.batch      # H2D (+ the device pre-scan when it is used), the whole batch at once
+    prescan_rounds = int(ctx.lib.jda_last_prescan_rounds(ctx.handle)) if args.device_prescan else 0
     batch = J.Batch(ctx, dev_images, outputs, [pt] * args.batch, [args.options] * args.batch)
     st = batch.stats
 
@@ -247,6 +248,7 @@ def main():
             "host_threads": os.cpu_count(),
             "upload_ms_per_image": t_up * 1e3,
             "device_prescan": bool(dev_images[0].prescan_on_device),
+            "device_prescan_rounds": prescan_rounds,      # speculative rounds of the marker-less segment walk (0: not used)
             "kernel_only_mpix_s": px_per_step / (kernel_ms * 1e-3) / 1e6,
             # host prepare (all threads) + upload + kernel, one after the other (no overlap between the stages)
             "end_to_end_mpix_s_no_overlap": (args.width * args.height / 1e6) / ((t_par if t_par == t_par else t_prep) + t_up + kernel_ms * 1e-3 / args.batch),
