@@ -78,7 +78,14 @@ typedef struct jda_image_info {
     int32_t has_thumb;            /* EXIF IFD1 present (jpeg.inl:1667-1675) */
     int32_t thumb_w, thumb_h;     /* EXIF tags 256 / 257 (0 when absent, as in the reference) */
     int32_t thumb_offset;         /* file offset of the embedded thumbnail JPEG (tag 513 + TIFF base) */
+    int32_t scan_start, scan_end; /* Ss, Se of the first scan (jpeg.inl:1416-1417) */
+    int32_t approx;               /* Ah << 4 | Al of the first scan (jpeg.inl:1418-1420) */
 } jda_image_info;
+
+/* The option bits an image is really decoded with: a progressive file (jpeg_type 1) is decoded from its first (DC)
+ * scan only, as a 1/8 thumbnail -- JPEG_SCALE_EIGHTH is OR-ed in (jpeg.inl:4964-4966) before the HALF / QUARTER /
+ * EIGHTH chain (:4978-4990) picks the first bit that is set. */
+int32_t jda_effective_options(const jda_image_info *info, int32_t options);
 
 /* Header parse only.  Accept/reject rules follow JPEGParseInfo (jpeg.inl:1572-1785). */
 int jda_parse(const uint8_t *jpeg, int32_t len, jda_image_info *info);

@@ -23,7 +23,7 @@ class ImageInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "ncomp", "subsample", "bpp", "jpeg_type", "restart_interval",
         "orientation", "mcu_w", "mcu_h", "mcus_x", "mcus_y", "scan_offset", "blocks_per_mcu",
-        "has_thumb", "thumb_w", "thumb_h", "thumb_offset")]
+        "has_thumb", "thumb_w", "thumb_h", "thumb_offset", "scan_start", "scan_end", "approx")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -57,6 +57,7 @@ _PROTOTYPES = [
     ("jda_prepare_batch", C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("jda_dev_image_prescan_on_device", C.c_int, [_P]),
     ("jda_last_prescan_rounds", C.c_int, [_P]),
+    ("jda_effective_options", C.c_int32, [_P, C.c_int32]),
     ("jda_dev_image_read_index", C.c_int, [_P, _P, _P, _P]),
     ("jda_dev_image_mcus_ok", C.c_uint32, [_P]),
     ("jda_upload_batch", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P)]),

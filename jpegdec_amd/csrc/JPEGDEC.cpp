@@ -232,7 +232,8 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
     if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
 
-    const int shift = (iOptions & JPEG_SCALE_HALF) ? 1 : (iOptions & JPEG_SCALE_QUARTER) ? 2 : (iOptions & JPEG_SCALE_EIGHTH) ? 3 : 0;
+    const int eff = jda_effective_options(&s->info, iOptions);      // a progressive file is a 1/8 thumbnail (jpeg.inl:4964-4966)
+    const int shift = (eff & JPEG_SCALE_HALF) ? 1 : (eff & JPEG_SCALE_QUARTER) ? 2 : (eff & JPEG_SCALE_EIGHTH) ? 3 : 0;
     const int mw = s->info.mcu_w >> shift, mh = s->info.mcu_h >> shift;
     // MCU rows the reference walks (jpeg.inl:5014-5037); a crop that reaches below the last MCU row makes it
     // decode whatever follows the scan and fail -- here the real rows are delivered and the same error returned

@@ -334,8 +334,10 @@ struct jda_tables {
     const uint16_t *zz;       // LDS: JDA_ZZ_ENTRIES entries (see JDA_LT_ZZ)
 };
 
+// dc_only / al: the scan holds DC symbols only (first scan of a progressive file, JPEGDecodeMCU_P jpeg.inl:1819-2084 with
+// Ss = Se = 0) and their differences are shifted left by Al (:1884); a baseline scan has dc_only = false, al = 0.
 template <int LIMIT>
-JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred)
+JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred, bool dc_only = false, uint32_t al = 0)
 {
     uint32_t flags = 0;
     jda_refill(br);
@@ -357,12 +359,13 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
         if (folded) pred += folded;
         else {
             jda_refill(br);
-            pred += jda_take_extend(br.bits, br.off, s);
+            pred += (int32_t)((uint32_t)jda_take_extend(br.bits, br.off, s) << al);
             br.off += s;
         }
     }
     if (LIMIT == 1) return 0;
     coef[0] = (int16_t)pred;
+    if (dc_only) return 0;
     // AC  (:2223-2265).  The reference refills at the top AND the bottom of every iteration; the top
     // one is a no-op after a bottom one, so one refill before the loop + one per iteration is identical.
     int k = 1;
@@ -590,7 +593,8 @@ JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n)
 JDA_HD void jda_wr_ref_refill(jda_wreader &R) { R.roff = R.roff > 47u ? (R.roff & 7u) : R.roff; }
 
 template <int LIMIT>
-JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill)
+JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill,
+                                     bool dc_only = false, uint32_t al = 0)
 {
     jda_wreader R;
     jda_wr_init(R, wbase, pos, off);
@@ -614,13 +618,14 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     const int32_t folded = (int8_t)T.dc[code + 512];
     const uint32_t dlen = e >> 4, s = e & 0xfu;
     const bool take = s != 0 && folded == 0;             // magnitude bits follow in the stream
-    const int32_t mag = jda_extend_top(w << dlen, s);
+    const int32_t mag = (int32_t)((uint32_t)jda_extend_top(w << dlen, s) << al);
     pred += s == 0 ? 0 : (folded ? folded : mag);
     R.roff += dlen;
     if (take) { jda_wr_ref_refill(R); R.roff += s; }
     jda_wr_consume(R, dlen + (take ? s : 0u));
     if (LIMIT == 1) return 0;
     coef[0] = (int16_t)pred;
+    if (dc_only) return 0;                               // no AC symbol in this scan: a DC-only block (flags 0)
     int k = 1;
     jda_wr_ref_refill(R);
     for (;;) {
@@ -1271,27 +1276,29 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
     const uint8_t *wbase = br.win - br.win_lo;
     int32_t pred = in.pred;
+    const bool dc_only = (D.pad_[0] & JDA_DESC_DC_ONLY) != 0;     // wave-uniform (progressive thumbnail)
+    const uint32_t al = (uint32_t)D.pad_[0] >> 4;
 
     JDA_P1_TRACE(8);
     const int shift = D.scale_shift;
     const bool win_only = C.win_need <= br.win_len;             // wave-uniform: the whole slice is in LDS
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
-        if (win_only) jda_decode_block_win<1>(br.pos, br.off, wbase, TB, coef, pred, true); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred); }
+        if (win_only) jda_decode_block_win<1>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al); }
         *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
         return JDA_NO_LIST;
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
         uint32_t flags;
-        if (win_only) flags = jda_decode_block_win<5>(br.pos, br.off, wbase, TB, coef, pred, true);
-        else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred); }
+        if (win_only) flags = jda_decode_block_win<5>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+        else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred, dc_only, al); }
         const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
                                        : jda_idct_2x2(coef, quant);
         *(jda_u32_alias *)plane = px;
         return JDA_NO_LIST;
     }
     uint32_t flags;
-    if (win_only) flags = jda_decode_block_win<64>(br.pos, br.off, wbase, TB, coef, pred, true);
-    else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred); }
+    if (win_only) flags = jda_decode_block_win<64>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+    else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred, dc_only, al); }
     JDA_P1_TRACE(9);
     return flags;
 }

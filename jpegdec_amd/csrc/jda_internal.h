@@ -57,6 +57,10 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     };
 };
 
+// descriptor byte pad_[0]: bits 2:0 profiling switches, bit 3 = the scan holds DC symbols only (the first scan of a
+// progressive file, decoded as a thumbnail: jpeg.inl:4964-4966), bits 7:4 = Al, the point transform of those DC differences
+#define JDA_DESC_DC_ONLY 8u
+
 struct jda_strip {                // one wavefront's tile: <= 64 consecutive blocks (10/21/64 MCUs) of one MCU row; 16 bytes
     uint32_t image;               // index into the descriptor array
     uint16_t mcu_y;               // (a JPEG has at most 65535 / 8 MCU rows and columns)

@@ -14,6 +14,13 @@ extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, ui
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
 
 
+// descriptor byte pad_[0]: bits 2:0 profiling switches (JDA_DEBUG_SKIP), bit 3 = the scan holds DC symbols only (first scan
+// of a progressive file), bits 7:4 = Al, the point transform of those DC differences (jpeg.inl:1884)
+inline uint8_t jda_desc_stream_bits(const jda_image_info &I)
+{
+    return I.jpeg_type == 1 ? (uint8_t)(JDA_DESC_DC_ONLY | ((I.approx & 15) << 4)) : (uint8_t)0;
+}
+
 inline int jda_mode_of(const jda_image_info &I)
 {
     if (I.subsample == 0x22) return JDA_MODE_420;
@@ -34,6 +41,7 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     int bpp, ow, oh, cw, ch;
     int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
     if (rc != JDA_SUCCESS) return rc;
+    options = jda_effective_options(&I, options);                   // progressive: 1/8 thumbnail from the DC scan
     D.mode = (uint8_t)jda_mode_of(I);
     D.ncomp = (uint8_t)I.ncomp;
     // gray JPEG with an RGB8888 request is drawn as RGB565 by the reference
@@ -42,6 +50,7 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pixel_type == JDA_EIGHT_BIT_GRAYSCALE);
     jda_image_component_ids(img, D.dc_id, D.ac_id, D.q_id);
     D.fast_mul = (uint8_t)jda_image_fast_mul(img);
+    D.pad_[0] = jda_desc_stream_bits(I);
     D.mcus_x = (uint32_t)I.mcus_x;
     D.mcus_y = (uint32_t)I.mcus_y;
     uint32_t nok = 0, slen = 0;

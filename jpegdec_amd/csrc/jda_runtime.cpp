@@ -512,14 +512,14 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         if (!im) { *err = JDA_INVALID_PARAMETER; return NULL; }
         const jda_image_info &I = im->info;
         const int pt_req = pixel_types ? pixel_types[i] : JDA_RGB8888;
-        const int opt = options ? options[i] : 0;
+        const int opt = jda_effective_options(&I, options ? options[i] : 0);      // progressive: 1/8 thumbnail from the DC scan
         jda_dev_desc &D = descs[(size_t)i];
         memset(&D, 0, sizeof(D));
         if (pt_req < 0 || pt_req > JDA_EIGHT_BIT_GRAYSCALE) { *err = JDA_INVALID_PARAMETER; return NULL; }
         int pt = pt_req;
         if ((opt & JDA_LUMA_ONLY) && pt < JDA_EIGHT_BIT_GRAYSCALE) pt = JDA_EIGHT_BIT_GRAYSCALE;   // jpeg.inl:4991-4993
         int bpp, ow, oh, cw, ch;
-        if (jda_output_geometry(&I, pt, opt, &bpp, &ow, &oh, &cw, &ch) != JDA_SUCCESS) { *err = JDA_INVALID_PARAMETER; return NULL; }
+        { const int grc = jda_output_geometry(&I, pt, opt, &bpp, &ow, &oh, &cw, &ch); if (grc != JDA_SUCCESS) { *err = grc; return NULL; } }
         const jda_output &O = outputs[i];
         D.mode = (uint8_t)jda_mode_of(I);
         D.ncomp = (uint8_t)I.ncomp;
@@ -528,7 +528,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE);
         memcpy(D.dc_id, im->dc_id, 3); memcpy(D.ac_id, im->ac_id, 3); memcpy(D.q_id, im->q_id, 3);
         D.fast_mul = im->fast_mul;
-        { const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = dbg ? (uint8_t)atoi(dbg) : 0; }   // profiling aid: 1 = no phase B, 2 = no IDCT
+        { const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = (uint8_t)((dbg ? (atoi(dbg) & 7) : 0) | jda_desc_stream_bits(I)); }   // profiling aid: 1 = no P4, 2 = no IDCT, 4 = no P1
         D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
         D.n_mcus_ok = im->n_mcus_ok; D.scan_len = im->scan_len;
         D.tables = im->base + im->off_tables;

@@ -54,12 +54,13 @@ def value_noise_image(width: int, height: int, channels: int = 3, seed: int = 12
 
 
 def encode_jpeg(pixels: np.ndarray, quality: int = 85, subsampling="4:2:0", optimize: bool = False,
-                restart_rows: int = 0, restart_blocks: int = 0) -> bytes:
-    """pixels: HxW (gray) or HxWx3 (RGB) uint8 -> baseline JPEG bytes."""
+                restart_rows: int = 0, restart_blocks: int = 0, progressive: bool = False) -> bytes:
+    """pixels: HxW (gray) or HxWx3 (RGB) uint8 -> baseline (or, progressive=True, libjpeg's default progressive
+    script: first scan = the DC scan of all components, Al = 1) JPEG bytes."""
     from PIL import Image
 
     im = Image.fromarray(pixels)
-    kw = dict(format="JPEG", quality=quality, optimize=optimize, progressive=False)
+    kw = dict(format="JPEG", quality=quality, optimize=optimize, progressive=progressive)
     if pixels.ndim == 3:
         kw["subsampling"] = {"4:4:4": 0, "4:2:2": 1, "4:2:0": 2}[subsampling]
     if restart_rows:
@@ -72,7 +73,7 @@ def encode_jpeg(pixels: np.ndarray, quality: int = 85, subsampling="4:2:0", opti
 
 
 def synth_jpeg(width: int, height: int, subsampling="4:2:0", seed: int = 1234, quality: int = 85,
-               optimize: bool = False, restart_rows: int = 0, restart_blocks: int = 0) -> bytes:
+               optimize: bool = False, restart_rows: int = 0, restart_blocks: int = 0, progressive: bool = False) -> bytes:
     """subsampling: '4:2:0' | '4:4:4' | '4:2:2' | '4:4:0' | 'gray'.  4:4:0 (luma sampled 1x2) goes through
     encode_jpeg_custom (restart_blocks = its restart interval in MCUs)."""
     ch = 1 if subsampling == "gray" else 3
@@ -80,7 +81,7 @@ def synth_jpeg(width: int, height: int, subsampling="4:2:0", seed: int = 1234, q
     if subsampling == "4:4:0":
         return encode_jpeg_custom(px, quality, (1, 2), restart_interval=restart_blocks)
     return encode_jpeg(px, quality, subsampling if ch == 3 else None, optimize, restart_rows,
-                       restart_blocks)
+                       restart_blocks, progressive)
 
 
 def bits_per_pixel(jpeg: bytes, width: int, height: int) -> float:

@@ -36,6 +36,7 @@ typedef struct orc_info {
     int quant_id[4], dc_id[4], ac_id[4];
     int scan_offset;      /* byte offset of the first entropy-coded byte */
     int error;            /* ORC_* */
+    int scan_start, scan_end, approx;   /* Ss, Se, Ah << 4 | Al of the first scan (jpeg.inl:1416-1420) */
 } orc_info;
 
 /* header parse (jpeg.inl:1572-1785).  returns 1 ok / 0 fail (error in info->error) */

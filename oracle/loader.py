@@ -95,7 +95,8 @@ class RefDecoder:
         if not inf["ok"]:
             return dict(rc=-1, canvas=None, n_calls=0, dma_reuse=0, last_error=inf["lasterror"], log=None)
         mw, mh = mcu_dims(inf["subsample"])
-        sh = scale_shift(options) if inf["jpegtype"] == 0 else 3
+        # a progressive file gets JPEG_SCALE_EIGHTH OR-ed in (jpeg.inl:4964-4966) before the HALF / QUARTER / EIGHTH chain
+        sh = scale_shift(options) if inf["jpegtype"] == 0 else scale_shift(options | SCALE_EIGHTH)
         pt = GRAY8 if (options & LUMA_ONLY and pixel_type < GRAY8) else pixel_type
         bpp = BYTES_PER_PIXEL[pt]
         if inf["subsample"] == 0 and pt == RGB8888:
@@ -198,7 +199,7 @@ class OracleDecoder:
             _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int), ("subsample", C.c_int),
                         ("mode", C.c_int), ("restart_interval", C.c_int), ("quant_id", C.c_int * 4),
                         ("dc_id", C.c_int * 4), ("ac_id", C.c_int * 4), ("scan_offset", C.c_int),
-                        ("error", C.c_int)]
+                        ("error", C.c_int), ("scan_start", C.c_int), ("scan_end", C.c_int), ("approx", C.c_int)]
 
         self.Info = Info
         L.orc_get_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(Info)]
@@ -248,6 +249,8 @@ class OracleDecoder:
     def canvas_geometry(self, data: bytes, pixel_type=RGB8888, options=0):
         inf = self.info(data)
         mw, mh = mcu_dims(inf["subsample"])
+        if inf["mode"] == 0xC2:
+            options |= SCALE_EIGHTH                     # a progressive file is decoded as a 1/8 thumbnail (jpeg.inl:4964-4966)
         sh = scale_shift(options)
         pt = GRAY8 if (options & LUMA_ONLY and pixel_type < GRAY8) else pixel_type
         bpp = BYTES_PER_PIXEL[pt]

@@ -32,6 +32,16 @@ SYNTH_CASES = {
     "c420_250x250_q10": dict(width=250, height=250, subsampling="4:2:0", seed=22, quality=10),  # many DC-only blocks
 }
 
+# progressive files (decoded from their first, DC-only scan as a 1/8 thumbnail, jpeg.inl:4964-4966)
+PROGRESSIVE_CASES = {
+    "p420_200x120": dict(width=200, height=120, subsampling="4:2:0", seed=51, progressive=True),
+    "p444_333x217": dict(width=333, height=217, subsampling="4:4:4", seed=52, progressive=True),
+    "p422_640x368": dict(width=640, height=368, subsampling="4:2:2", seed=53, progressive=True),
+    "pgray_100x100": dict(width=100, height=100, subsampling="gray", seed=54, progressive=True),
+    "p420_1280x720_q95": dict(width=1280, height=720, subsampling="4:2:0", seed=55, quality=95, progressive=True),
+}
+SYNTH_ALL = dict(SYNTH_CASES, **PROGRESSIVE_CASES)
+
 PIXEL_TYPES = (0, 1, 2, 3)                 # RGB565_LE, RGB565_BE, RGB8888, GRAY8
 OPTIONS = (0, 2, 4, 8, 64, 64 | 2)         # full, 1/2, 1/4, 1/8, luma-only, luma-only 1/2
 
@@ -41,7 +51,7 @@ def jpeg_for(name: str) -> bytes:
     path = os.path.join(GOLDEN_DIR, name + ".jpg")
     if os.path.exists(path):               # committed fixture wins (keeps tests independent of Pillow's version)
         return open(path, "rb").read()
-    return synth_jpeg(**SYNTH_CASES[name])
+    return synth_jpeg(**SYNTH_ALL[name])
 
 
 def all_modes(name):
@@ -49,4 +59,20 @@ def all_modes(name):
         for opt in OPTIONS:
             if name.startswith("c440") and pt == 2 and (opt & 4):
                 continue       # JPEGPutMCU12, 1/4 scale, RGB8888 writes through the address of a local (jpeg.inl:4620): UB in the reference
+            yield pt, opt
+
+
+def progressive_modes(name):
+    """pixel type x options a progressive file can be decoded with: everything except what the reference itself cannot do
+    -- a colour file to 8-bit gray (it crashes: JPEGDecodeMCU_P(MCU_SKIP) stores far outside the object) and
+    JPEG_SCALE_QUARTER (uninitialised sample bytes in its output); see DESIGN.md 3."""
+    gray = name.startswith("pgray")
+    for pt in PIXEL_TYPES:
+        for opt in OPTIONS:
+            if (opt & 4) and not (opt & 2):
+                continue
+            if not gray and (pt == 3 or (opt & 64)):
+                continue
+            if gray and pt == 2:
+                continue       # gray JPEG + RGB8888: the reference emits 565 with iBpp = 32 (SURVEY C.5)
             yield pt, opt

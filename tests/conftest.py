@@ -64,3 +64,13 @@ def gpu_ctx(product_lib):
     ctx = jpegdec_amd.Context(0)   # raises JdaError(NO_DEVICE) without a GPU: gpu tests must not silently pass
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def hostsim(built_checkers):
+    """tests/hostsim: the kernels' per-lane logic compiled for the CPU (a wave emulator; test infrastructure only)."""
+    import ctypes as C
+
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "hostsim", "libjda_hostsim.so"))
+    lib.hostsim_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return lib

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 from jpegdec_amd.synth import synth_jpeg  # noqa: E402
 from oracle.loader import RefDecoder, digest  # noqa: E402
-from tests.cases import OPTIONS, PIXEL_TYPES, SYNTH_CASES  # noqa: E402
+from tests.cases import OPTIONS, PIXEL_TYPES, PROGRESSIVE_CASES, SYNTH_CASES, progressive_modes  # noqa: E402
 
 
 def main():
@@ -49,6 +49,26 @@ def main():
                 frame = r["canvas"][:h, : w * bpp]
                 entry["frames"]["%d:%d" % (pt, opt)] = {"sha": digest(frame), "w": w, "h": h, "bpp": bpp,
                                                         "draw_calls": r["n_calls"]}
+        out[name] = entry
+        print(name, len(jpeg), len(entry["frames"]))
+    for name, kw in sorted(PROGRESSIVE_CASES.items()):       # first-scan (DC-only) thumbnails
+        path = os.path.join(HERE, name + ".jpg")
+        if os.path.exists(path):
+            jpeg = open(path, "rb").read()
+        else:
+            jpeg = synth_jpeg(**kw)
+            if len(jpeg) <= 160 * 1024:
+                with open(path, "wb") as f:
+                    f.write(jpeg)
+        entry = {"jpeg_sha": digest(jpeg), "jpeg_len": len(jpeg), "info": ref.info(jpeg), "frames": {}}
+        for pt, opt in progressive_modes(name):
+            r = ref.decode_cb(jpeg, pt, opt)
+            assert r["rc"] == 1, (name, pt, opt)
+            inf, sh, bpp = r["info"], r["scale_shift"], r["bpp"]
+            adj = (1 << sh) - 1
+            w, h = (inf["width"] + adj) >> sh, (inf["height"] + adj) >> sh
+            frame = r["canvas"][:h, : w * bpp]
+            entry["frames"]["%d:%d" % (pt, opt)] = {"sha": digest(frame), "w": w, "h": h, "bpp": bpp, "draw_calls": r["n_calls"]}
         out[name] = entry
         print(name, len(jpeg), len(entry["frames"]))
     with open(os.path.join(HERE, "golden.json"), "w") as f:

@@ -40,6 +40,24 @@ def test_draw_callbacks_deliver_the_oracle_frame(name, product_class, oracle):
         assert np.array_equal(r["log"], oracle.draw_plan(jpeg, pt, opt)), (name, pt, opt)   # same JPEGDRAW sequence
 
 
+@pytest.mark.parametrize("name", ["p420_200x120", "p444_333x217", "pgray_100x100"])
+def test_progressive_file_is_a_dc_thumbnail(name, product_class, oracle):
+    """SURVEY 8f N4 through the class: getJPEGType() says progressive, decode() delivers the 1/8 thumbnail of the first
+    (DC) scan with the reference's JPEGDRAW sequence (jpeg.inl:4964-4966)."""
+    from tests.cases import progressive_modes
+    jpeg = jpeg_for(name)
+    inf = product_class.info(jpeg)
+    assert inf["ok"] == 1 and inf["jpegtype"] == 1
+    for pt, opt in progressive_modes(name):
+        r = product_class.decode_cb(jpeg, pt, opt, want_log=True)
+        assert r["rc"] == 1 and r["last_error"] == 0, (name, pt, opt, r["last_error"])
+        rc, want, _ = oracle.decode_canvas(jpeg, pt, opt)
+        sh = r["scale_shift"]
+        h = (inf["height"] + (1 << sh) - 1) >> sh
+        assert np.array_equal(r["canvas"][:h, : want.shape[1]], want[:h]), (name, pt, opt)
+        assert np.array_equal(r["log"], oracle.draw_plan(jpeg, pt, opt)), (name, pt, opt)
+
+
 def test_same_behaviour_as_the_real_reference(product_class, ref_scalar):
     jpeg = jpeg_for("c420_333x217")
     for pt, opt, mm in ((RGB565_LE, 0, 0), (RGB8888, 0, 3), (GRAY8, SCALE_HALF, 0), (RGB565_LE, USES_DMA, 0)):

@@ -25,6 +25,25 @@ def test_decode_bit_exact_all_modes(name, gpu_ctx, oracle):
             name, pt, opt, int(np.count_nonzero(got != want)))
 
 
+@pytest.mark.parametrize("name", ["p420_200x120", "p444_333x217", "p422_640x368", "pgray_100x100", "p420_1280x720_q95"])
+def test_progressive_thumbnails(name, gpu_ctx, oracle):
+    """a progressive file is decoded from its first (DC) scan as a 1/8 thumbnail (1/2 when asked for):
+    DC symbols only, differences shifted by Al, every block through the DC bypass -- bit-exact with the oracle
+    (which tests/test_progressive.py pins to the real reference).  What the reference cannot do is refused."""
+    from tests.cases import progressive_modes
+    jpeg = jpeg_for(name)
+    for pt, opt in progressive_modes(name):
+        rc, got, g = J.decode_to_host(gpu_ctx, jpeg, pt, opt)
+        assert rc == 0, (name, pt, opt, rc)
+        orc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+        assert orc == 1
+        assert got.shape == want.shape and np.array_equal(got, want), (name, pt, opt)
+    if not name.startswith("pgray"):
+        with pytest.raises(J.JdaError) as e:
+            J.decode_to_host(gpu_ctx, jpeg, J.GRAY8, 0)
+        assert e.value.code == 3
+
+
 def test_matches_real_reference_when_present(gpu_ctx, ref_scalar):
     """Same comparison against the unmodified reference (scalar integer build) if oracle/_ref travelled."""
     for name in ("c420_333x217", "c444_256x256_q100_opt", "gray_64x64_rst3", "c420_1280x720"):

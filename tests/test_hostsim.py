@@ -13,13 +13,6 @@ from tests.cases import SYNTH_CASES, all_modes, jpeg_for
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def hostsim(built_checkers):
-    lib = C.CDLL(os.path.join(ROOT, "tests", "hostsim", "libjda_hostsim.so"))
-    lib.hostsim_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
-    return lib
-
-
 @pytest.mark.parametrize("name", ["c444_600x16", "c444_333x217", "c420_1100x48", "gray_1600x16"])
 def test_tile_order_does_not_matter(name, hostsim, oracle):
     """Tiles are decoded by independent wavefronts in any order: run them backwards and shrink the scan
