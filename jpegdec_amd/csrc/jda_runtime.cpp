@@ -28,8 +28,10 @@ extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint
 extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
-extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, const jda_dev_desc *descs, const jda_strip *strips,
+extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
+// launch lists of a batch: one per (mode, fast_mul, kernel variant); index = (mode * 2 + fast) * 2 + variant
+#define JDA_N_LISTS (4 * JDA_N_MODES)
 
 struct jda_ctx {
     int device;
@@ -55,8 +57,8 @@ struct jda_dev_image {
 struct jda_batch {
     int32_t n_images;
     jda_dev_desc *d_descs;
-    jda_strip *d_strips[2 * JDA_N_MODES];   // per (mode, fast_mul): index = mode * 2 + fast
-    uint32_t n_strips[2 * JDA_N_MODES];
+    jda_strip *d_strips[JDA_N_LISTS];
+    uint32_t n_strips[JDA_N_LISTS];
     jda_batch_stats stats;
 };
 
@@ -504,7 +506,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     if (!ctx) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
     if (n <= 0 || !images || !outputs) { *err = JDA_INVALID_PARAMETER; return NULL; }
     std::vector<jda_dev_desc> descs((size_t)n);
-    std::vector<jda_strip> strips[2 * JDA_N_MODES];
+    std::vector<jda_strip> strips[JDA_N_LISTS];
     jda_batch_stats st;
     memset(&st, 0, sizeof(st));
     for (int i = 0; i < n; i++) {
@@ -544,7 +546,10 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
             (uint64_t)(ch + 16) * (uint64_t)O.pitch_bytes >= (1ull << 32) || O.pitch_bytes >= (1 << 23)) {
             *err = JDA_INVALID_PARAMETER; return NULL;
         }
-        jda_append_strips(strips[D.mode * 2 + (D.fast_mul ? 1 : 0)], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode);
+        // kernel variant 1: the plain case -- full size, RGB8888, every block decoded -- runs a kernel in which these
+        // descriptor fields are compile-time constants (jda_desc_uniform<1>)
+        const int variant = (D.scale_shift == 0 && D.pixel_type == JDA_RGB8888 && !D.gray_from_color && D.pad_[0] == 0 && D.fast_mul) ? 1 : 0;
+        jda_append_strips(strips[(D.mode * 2 + (D.fast_mul ? 1 : 0)) * 2 + variant], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode);
         st.source_pixels += (int64_t)I.width * I.height;
         st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
         st.scan_bytes += im->scan_len;
@@ -558,13 +563,13 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
     if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
-    for (int m = 0; m < 2 * JDA_N_MODES && e == hipSuccess; m++) {
+    for (int m = 0; m < JDA_N_LISTS && e == hipSuccess; m++) {
         b->n_strips[m] = (uint32_t)strips[m].size();
         if (!b->n_strips[m]) continue;
         e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 2));
+        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 4));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -583,7 +588,7 @@ void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (b->d_descs) (void)hipFree(b->d_descs);
-    for (int m = 0; m < 2 * JDA_N_MODES; m++) if (b->d_strips[m]) (void)hipFree(b->d_strips[m]);
+    for (int m = 0; m < JDA_N_LISTS; m++) if (b->d_strips[m]) (void)hipFree(b->d_strips[m]);
     delete b;
 }
 
@@ -591,9 +596,9 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     if (!b) return JDA_INVALID_PARAMETER;
-    for (int m = 0; m < 2 * JDA_N_MODES; m++) {
+    for (int m = 0; m < JDA_N_LISTS; m++) {
         if (!b->n_strips[m]) continue;
-        JDA_HIP(ctx, jda_launch_decode(m >> 1, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
+        JDA_HIP(ctx, jda_launch_decode(m >> 2, (m >> 1) & 1, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
     }
     return JDA_SUCCESS;
 }
