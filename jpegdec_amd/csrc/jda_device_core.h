@@ -1218,6 +1218,35 @@ JDA_HD void jda_p0_stage(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t 
     jda_window_fill(JDA_G(const uint8_t, D.scan), C.win_lo, len, wl + L::WIN_OFF, t);
 }
 
+// What a lane of P1 needs that depends only on the image and on the lane -- its block's place in the MCU decides the
+// component, hence the Huffman LUTs and the quantiser table -- worked out when a wavefront meets a new image (LDS
+// addresses are 32 bits: five registers), not once per tile.
+struct jda_lane_pre {          // (offsets, not pointers: a pointer carried around the tile loop loses its address space)
+    uint32_t dc_off;          // byte offset in the LDS table copy: DC LUT of the lane's component
+    uint32_t ac_off;          // its AC LUT (short half)
+    uint32_t ac_long_off;     // byte offset of the AC LUT's long half in the table blob (global)
+    uint32_t quant_off;       // byte offset of its quantiser table in the LDS table copy
+    uint32_t qsel;            // quantiser table id << 9 (the column work items carry it)
+    uint32_t chroma;          // the lane's block is a chroma block
+};
+template <int MODE>
+JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t lane, const uint8_t *tab)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t b = lane % (uint32_t)T::NBLK;                  // block within the MCU
+    const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
+    // (jda_pick3 reads the three ids into values first: a select between the array's elements becomes a dynamically
+    // indexed load, and that sends the whole descriptor from SGPRs to scratch memory)
+    const uint32_t dc_id = jda_pick3(D.dc_id, c), ac_id = jda_pick3(D.ac_id, c), q_id = jda_pick3(D.q_id, c);
+    (void)tab;
+    LP.dc_off = JDA_LT_DC + dc_id * 1024;
+    LP.ac_off = JDA_LT_AC + ac_id * 2048;
+    LP.ac_long_off = JDA_TB_AC + (ac_id * 2048 + 1024) * 2;
+    LP.quant_off = JDA_LT_QUANT + q_id * 128;
+    LP.qsel = q_id << 9;
+    LP.chroma = b >= (uint32_t)T::NLUMA ? 1u : 0u;
+}
+
 // ---- P1 ---------------------------------------------------------------------------------------
 // What a thread needs from HBM before it can start decoding its block: issued at kernel entry so the
 // two dependent loads (lane schedule -> index entry) overlap P0's table / window staging.
@@ -1244,25 +1273,20 @@ JDA_HD jda_p1_inputs jda_p1_prefetch(const jda_dev_desc &D, const jda_tile_ctx &
 #define JDA_NO_LIST 0xffffffffu
 
 template <int MODE>
-JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const uint8_t *tab, uint8_t *wl,
+JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const jda_lane_pre &LP, const uint8_t *tab, uint8_t *wl,
                                const uint8_t *win, uint32_t win_cap)
 {
-    typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
     if (!in.active) return JDA_NO_LIST;
     JDA_P1_TRACE(10);
-    const uint32_t lb = in.lb;
-    const uint32_t m = lb / T::NBLK, b = lb - m * T::NBLK;       // MCU within tile, block within MCU
-    (void)m;
-    if (MODE != JDA_MODE_GRAY && D.gray_from_color && b >= (uint32_t)T::NLUMA) return JDA_NO_LIST;   // :5225-5233 chroma never decoded
-    const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
+    const uint32_t lb = in.lb;                                   // (== the lane: LP was made for it)
+    if (MODE != JDA_MODE_GRAY && D.gray_from_color && LP.chroma) return JDA_NO_LIST;   // :5225-5233 chroma never decoded
     jda_tables TB;
-    const uint32_t dc_id = jda_pick3(D.dc_id, c), ac_id = jda_pick3(D.ac_id, c);
-    TB.dc = tab + JDA_LT_DC + dc_id * 1024;
-    TB.ac_short = (const uint16_t *)(tab + JDA_LT_AC) + ac_id * 1024;
-    TB.ac_long = JDA_G(const uint16_t, D.tables + JDA_TB_AC) + ac_id * 2048 + 1024;
+    TB.dc = tab + LP.dc_off;
+    TB.ac_short = (const uint16_t *)(tab + LP.ac_off);
+    TB.ac_long = (const uint16_t JDA_GLOBAL *)(JDA_G(const uint8_t, D.tables) + LP.ac_long_off);
     TB.zz = (const uint16_t *)(tab + JDA_LT_ZZ);
-    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + jda_pick3(D.q_id, c) * 64;
+    const int16_t *quant = (const int16_t *)(tab + LP.quant_off);
     int16_t *coef = (int16_t *)(wl + L::COEF_OFF + lb * JDA_COEF_STRIDE);
     uint8_t *plane = (uint8_t *)coef;                            // samples overwrite the block's own slot
 
@@ -1309,13 +1333,11 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
 // list (:5146-5154).  Positions come from a wave prefix sum / ballots; order within a list is irrelevant.
 // all_flags: host emulation only (the flags of all 64 lanes).
 template <int MODE>
-JDA_HD void jda_p1_lists(const jda_dev_desc &D, uint32_t lane, uint32_t flags, const uint32_t *all_flags, uint8_t *wl)
+JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t lane, uint32_t flags, const uint32_t *all_flags, uint8_t *wl)
 {
-    typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
-    // a column item carries its block's quantiser table id, so that the column stage need not work it out per item
-    const uint32_t bq = lane % (uint32_t)T::NBLK;
-    const uint32_t qsel = jda_pick3(D.q_id, bq < (uint32_t)T::NLUMA ? 0u : bq - T::NLUMA + 1u) << 9;
+    (void)D;
+    const uint32_t qsel = LP.qsel;          // a column item carries its block's quantiser table id, so that the column stage need not work it out per item
     uint32_t *cnt = (uint32_t *)(wl + L::CNT_OFF);
     uint8_t *rowlist = wl + L::ROWLIST_OFF;
     uint16_t *collist = (uint16_t *)(wl + L::COLLIST_OFF);

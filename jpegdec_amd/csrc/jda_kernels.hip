@@ -120,8 +120,10 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     __syncthreads();                                  // the only workgroup barrier: tables are in LDS
     JDA_TRACE(3);
     uint32_t p1flags = JDA_NO_LIST;
-    if (!(D.pad_[0] & 4)) p1flags = jda_p1_entropy<MODE>(D, C, p1in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
-    if (D.scale_shift < 2) jda_p1_lists<MODE>(D, lane, p1flags, nullptr, wl);
+    jda_lane_pre LP;
+    jda_lane_prepare<MODE>(LP, D, lane, tab);
+    if (!(D.pad_[0] & 4)) p1flags = jda_p1_entropy<MODE>(D, C, p1in, LP, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
+    if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, wl);
     JDA_WAVE_SYNC();
     JDA_TRACE(4);
     if (D.scale_shift < 2 && !(D.pad_[0] & 6)) {
@@ -258,6 +260,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     JDA_TILE_COLD_START();
     jda_p4_pre P4;                                    // the colour stage's item addresses for this image (pitch, pixel size)
     jda_p4_prepare<MODE>(P4, Dc, lane);
+    jda_lane_pre LP;                                  // the lane's Huffman LUTs / quantiser table in this image
+    jda_lane_prepare<MODE>(LP, Dc, lane, tab);
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
     jda_strip Sn = S;
     if (i_nxt < t_end) Sn = jda_load_record(tiles + i_nxt);
@@ -288,8 +292,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         if (pipelined) jda_issue_index_loads<MODE>(D, Sn, lane, inn, ixn_end);
 
         JDA_PTRACE(1);
-        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
-        if (D.scale_shift < 2) jda_p1_lists<MODE>(D, lane, p1flags, nullptr, wl);
+        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
+        if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, wl);
         JDA_WAVE_SYNC();
         JDA_PTRACE(2);
 
@@ -346,6 +350,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
             JDA_WAVE_SYNC();
             JDA_TILE_COLD_START();
             jda_p4_prepare<MODE>(P4, Dc, lane);
+            jda_lane_prepare<MODE>(LP, Dc, lane, tab);
         }
         JDA_WAVE_SYNC();
     }
