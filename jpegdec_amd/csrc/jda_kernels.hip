@@ -363,6 +363,7 @@ template <int MODE, bool FAST, int VARIANT>
 static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
     const int lds_bytes = JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16;   // + the draw counter
+    static_assert(JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
     static int grid_cap = 0;
     if (!grid_cap) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT>,
