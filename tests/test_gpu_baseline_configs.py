@@ -83,3 +83,25 @@ def test_c5_8192_gray_all_scales(gpu_ctx, oracle):
         _check(got, jpeg, J.GRAY8, opt, oracle)
     (got565,) = _decode_batch(gpu_ctx, [jpeg], [J.RGB565_BE], [J.SCALE_EIGHTH])
     _check(got565, jpeg, J.RGB565_BE, J.SCALE_EIGHTH, oracle)
+
+
+def test_device_prescan_at_full_sizes(gpu_ctx):
+    """SURVEY 8f N2 at BASELINE sizes: a mixed batch (720p, 1080p, 4096x4096 4:2:0 and 4:4:4, 8192x8192 gray) uploaded with
+    JDA_PREPARE_DEVICE_PRESCAN in ONE jda_upload_batch -- every per-block index made on the GPU must equal the serial host
+    pre-scan's (size-independent property: equality of the whole index, DC predictors and MCU count)."""
+    jpegs = [bench.cached_jpeg(1280, 720, "4:2:0", 1234), bench.cached_jpeg(1920, 1080, "4:2:0", 1235),
+             bench.cached_jpeg(4096, 4096, "4:2:0", 1234), bench.cached_jpeg(4096, 4096, "4:4:4", 1234),
+             bench.cached_jpeg(8192, 8192, "gray", 1234), bench.cached_jpeg(1280, 720, "4:2:0", 1236)]
+    preps = [J.PreparedImage(j, device_prescan=True) for j in jpegs]
+    assert all(p.prescan_pending for p in preps)
+    dimgs = J.upload_batch(gpu_ctx, preps)
+    rounds = gpu_ctx.lib.jda_last_prescan_rounds(gpu_ctx.handle)
+    assert 1 <= rounds <= 24, rounds
+    for j, d in zip(jpegs, dimgs):
+        assert d.prescan_on_device
+        host = J.PreparedImage(j)
+        want_idx, nok = host.block_index()
+        got_idx, got_dc = d.read_index()
+        assert d.n_mcus_ok == nok
+        assert np.array_equal(got_idx, want_idx) and np.array_equal(got_dc, host.block_dc())
+        d.close(); host.close()
