@@ -168,6 +168,36 @@ JDA_HD uint32_t jda_pk_sext10_at5(uint32_t a)
     return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
 #endif
 }
+// per 16-bit lane: the range limit of a sample whose 10-bit field (bits 14:5) is in OFFSET-BINARY form (signed value + 512):
+// shift the field to the top, subtract 384 << 6 with unsigned saturation (v_pk_sub_u16 clamp), shift down by 6 -> max(value +
+// 128, 0) in 0..639, which v_sat_pk_u8_i16 then caps at 255: ucRangeTable's clamp(sext10 + 128) (jpeg.inl:159-222) in three
+// packed instructions + the pack.  The offset (512 << 5 = 16384) is added once per block, to the DC term of the column stage.
+#define JDA_ROW_BIAS 16384
+// -> the limited sample in the HIGH byte of each 16-bit lane (the low byte is junk; the byte permute that assembles a row
+// picks bytes 1 and 3)
+JDA_HD uint32_t jda_pk_limit_offset10(uint32_t a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short jda_us2 __attribute__((ext_vector_type(2)));
+    jda_us2 v = __builtin_bit_cast(jda_us2, a);
+    v = v << 1;                                              // the field to bits 15:6
+    const jda_us2 k = { 24576, 24576 };
+    v = __builtin_elementwise_sub_sat(v, k);                // max(value + 128, 0) << 6          (v_pk_sub_u16 clamp)
+    uint32_t r = __builtin_bit_cast(uint32_t, v), four = 4u;
+    asm("v_pk_mad_u16 %0, %1, %2, 0 op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(r), "v"(four));   // x 4, saturating: high byte = min(.., 255)
+    return r;
+#else
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+        uint32_t x = ((a >> (16 * h)) << 1) & 0xffffu;
+        x = x > 24576u ? x - 24576u : 0u;
+        x *= 4u;
+        if (x > 0xffffu) x = 0xffffu;
+        r |= x << (16 * h);
+    }
+    return r;
+#endif
+}
 // two signed 16-bit values -> two bytes saturated to 0..255 in bits 15:0, bits 31:16 zero (v_sat_pk_u8_i16)
 JDA_HD uint32_t jda_sat_pk_u8(uint32_t a)
 {
@@ -718,24 +748,27 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
     // arithmetic on 16-bit lanes), + 128, saturate to a byte.
     const uint32_t p01 = jda_pack16(t0, t1), p23 = jda_pack16(t2, t3);
     const uint32_t q76 = jda_pack16(t7, t6), q54 = jda_pack16(t5, -t4);
-    const uint32_t s01 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_add16(p01, q76)), 0x00800080u));
-    const uint32_t s76 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_sub16(p01, q76)), 0x00800080u));
-    const uint32_t s23 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_add16(p23, q54)), 0x00800080u));
-    const uint32_t s54 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(jda_pk_sub16(p23, q54)), 0x00800080u));
+    // (the block's samples carry JDA_ROW_BIAS from the column stage: their 10-bit field is in offset-binary form)
+    const uint32_t s01 = jda_pk_limit_offset10(jda_pk_add16(p01, q76));      // samples in bytes 1 and 3
+    const uint32_t s76 = jda_pk_limit_offset10(jda_pk_sub16(p01, q76));
+    const uint32_t s23 = jda_pk_limit_offset10(jda_pk_add16(p23, q54));
+    const uint32_t s54 = jda_pk_limit_offset10(jda_pk_sub16(p23, q54));
     jda_row8 r;
-    r.lo = jda_perm(s23, s01, 0x05040100u);          // bytes o0 o1 o2 o3
-    r.hi = jda_perm(s76, s54, 0x04050001u);          // bytes o4 o5 o6 o7  (s54 = [o5,o4], s76 = [o7,o6])
+    r.lo = jda_perm(s23, s01, 0x07050301u);          // bytes o0 o1 o2 o3
+    r.hi = jda_perm(s76, s54, 0x05070103u);          // bytes o4 o5 o6 o7  (s54 = [o5,o4], s76 = [o7,o6])
     return r;
 }
 
 // Column stage for one column (jpeg.inl:2561-2676): c[r] = raw coefficient of row r, q[r] its
 // prescaled quantiser; results truncated to int16 as the reference stores them back.
+// bias: JDA_ROW_BIAS for column 0, else 0 -- it rides on the DC term through the (linear) even part into every sample of the
+// block's row 0 .. 7 / column 0 input of the row stage, where only bits 14:5 of a result matter (jda_pk_limit_offset10)
 template <bool FAST, bool HALF>
-JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], int32_t out[8])
+JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], int32_t out[8], int32_t bias)
 {
     int32_t t0, t1, t2, t3, t4, t5, t6, t7;
     if (HALF) {                                              // :2561-2601
-        const int32_t a = c[0] * q[0];
+        const int32_t a = c[0] * q[0] + bias;
         const int32_t b = c[2] * q[2];
         const int32_t m = jda_mulc<FAST>(b, 106) >> 8;
         t0 = a + b; t3 = a - b; t1 = a + m; t2 = a - m;
@@ -758,7 +791,7 @@ JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], int32_t out[8])
         }
     } else {                                                         // :2602-2676
         // the reference's zero tests on rows 4..7 only skip work; the arithmetic is identical
-        const int32_t e0 = c[0] * q[0], e4 = c[4] * q[4];
+        const int32_t e0 = c[0] * q[0] + bias, e4 = c[4] * q[4];
         const int32_t t10 = e0 + e4, t11 = e0 - e4;
         const int32_t e2 = c[2] * q[2], e6 = c[6] * q[6];
         const int32_t t13 = e2 + e6;
@@ -1409,7 +1442,7 @@ JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, const uint8
         if (HALF && row >= 4) { cv[row] = 0; qv[row] = 0; }
         else { cv[row] = coef[row * 8]; qv[row] = quant[row * 8]; }
     }
-    jda_idct_col<FAST, HALF>(cv, qv, r);
+    jda_idct_col<FAST, HALF>(cv, qv, r, col == 0 ? JDA_ROW_BIAS : 0);
 #pragma unroll
     for (int row = 0; row < 8; row++) coef[row * 8] = (int16_t)r[row];
 }
