@@ -91,6 +91,45 @@ def test_batch_of_mixed_images_resident(gpu_ctx, oracle):
         gpu_ctx.free(ptr)
 
 
+def test_many_small_images_in_one_launch(gpu_ctx, oracle):
+    """Hundreds of small images with different Huffman / quantiser tables in one launch: a workgroup's run of tiles then
+    spans many images, its wavefronts draw tiles across image boundaries (tables restaged by whichever wavefront drew the
+    new image's first tile, wavefronts without tiles keeping the barriers company) -- every image must still come out
+    exactly, in the general kernel (mixed formats) and in the plain-case variant (RGB8888 full size)."""
+    names420 = ["c420_16x16", "c420_250x250_q10", "c420_333x217", "c420_256x256_q98", "c420_1100x48"]
+    names444 = ["c444_8x8_q30", "c444_600x16", "c444_256x256_q100_opt", "c444_333x217"]
+    for names, variants in ((names420, "plain"), (names420, "mixed"), (names444, "plain")):
+        n = 240
+        seq = [names[(i * 7 + i // 5) % len(names)] for i in range(n)]
+        pts = [J.RGB8888 if variants == "plain" else (J.RGB8888, J.RGB565_LE, J.RGB565_BE)[i % 3] for i in range(n)]
+        opts = [0 if variants == "plain" else (0, J.SCALE_HALF, 0, J.SCALE_EIGHTH)[i % 4] for i in range(n)]
+        prep = {nm: J.PreparedImage(jpeg_for(nm)) for nm in names}
+        devs = {nm: J.DeviceImage(gpu_ctx, prep[nm]) for nm in names}
+        outs, ptrs, geos = [], [], []
+        for nm, pt, opt in zip(seq, pts, opts):
+            g = prep[nm].geometry(pt, opt)
+            pitch = (g["canvas_w"] * g["bpp"] + 15) & ~15
+            ptr = gpu_ctx.malloc(pitch * g["canvas_h"])
+            outs.append((ptr, pitch, g["canvas_w"], g["canvas_h"]))
+            ptrs.append(ptr); geos.append((g, pitch))
+        batch = J.Batch(gpu_ctx, [devs[nm] for nm in seq], outs, pts, opts)
+        batch.decode(); gpu_ctx.sync()
+        want_cache = {}
+        for i, (nm, pt, opt, ptr, (g, pitch)) in enumerate(zip(seq, pts, opts, ptrs, geos)):
+            got = gpu_ctx.to_host(ptr, pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[:, : g["canvas_w"] * g["bpp"]]
+            key = (nm, pt, opt)
+            if key not in want_cache:
+                rc, want, _ = oracle.decode_canvas(jpeg_for(nm), pt, opt)
+                assert rc == 1
+                want_cache[key] = want
+            assert np.array_equal(got, want_cache[key]), (variants, i, nm, pt, opt)
+        batch.close()
+        for ptr in ptrs:
+            gpu_ctx.free(ptr)
+        for d in devs.values():
+            d.close()
+
+
 def test_clip_to_image_size(gpu_ctx, oracle):
     """width_px / rows clip: writing only W x H pixels leaves the rest of the surface untouched."""
     jpeg = jpeg_for("c420_333x217")
