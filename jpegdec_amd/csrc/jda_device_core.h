@@ -39,8 +39,9 @@
 #define JDA_P1_TRACE(slot) ((void)0)      // profiling hook, defined by jda_kernels.hip
 #endif
 #define JDA_COEF_STRIDE 136      // bytes per block in LDS: 64 int16 + 8 pad (row reads stay 8-byte aligned)
-#define JDA_WIN_BYTES 576        // per-wave LDS window over the tile's slice of the filtered scan (only P1 reads it, so the
-                                 // next tile's slice can be stored as soon as this tile's P1 is over)
+// per-wave LDS window over the tile's slice of the filtered scan: jda_lds_layout<MODE>::WIN_BYTES.  Only P1 reads it, and the
+// column work list is only alive from the end of P1 to the end of P2 -- so the two share their bytes: the next tile's slice
+// is stored when this tile's column stage is over.
 
 template <int MODE> struct jda_mode_traits;
 template <> struct jda_mode_traits<JDA_MODE_GRAY> { enum { NLUMA = 1, NBLK = 1, MCU_W = 8, MCU_H = 8, MCU_W_LOG2 = 3 }; };
@@ -54,13 +55,16 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
 // quantisers, zigzag.
 #define JDA_LT_DC      0         // 2 x 1024
 #define JDA_LT_AC      2048      // 2 x 1024 uint16, re-laid out while staging (jda_ac_entry)
-#define JDA_LT_QUANT   6144      // 4 x 64 int16
-#define JDA_LT_ZZ      6656      // 144 x uint16, built while staging: where the coefficient at zigzag position j goes
+// The prescaled quantiser tables (4 x 64 int16) sit in the DC LUTs' unused bytes: a DC LUT (the reference's layout, jpeg.inl:1098-1152)
+// is indexed 0..61 and 128..255 (+ 512 for the folded values), so bytes 256..511 of each 1024-byte LUT are never read --
+// room for two 128-byte tables each.  512 bytes less per workgroup is what lets 16 wavefronts of the 64-block tile layouts fit.
+#define JDA_LT_QUANT_OFF(q) ((((q) >> 1) * 1024u) + 256u + (((q) & 1u) * 128u))
+#define JDA_LT_ZZ      6144      // 144 x uint16, built while staging: where the coefficient at zigzag position j goes
 #define JDA_ZZ_ENTRIES 144       //   j < 64: (column bit 1 << (n & 7)) << 8 | 2 n (n = natural index: the byte offset in the
                                  //   block); j >= 64 (past the block, or 64 + j for a symbol that stores nothing): 128 = the
                                  //   block's padding, no flags.  j <= 63 + 15 + 64.
 #define JDA_ZZ_DUMP    128u
-#define JDA_LT_BYTES   6944
+#define JDA_LT_BYTES   6432
 
 // AC LUT entry as the kernels keep it in LDS: length << 11 | nostore << 10 | R << 4 | S, made from the reference's
 // (length << 8) | RS.  nostore = a symbol with S == 0 that is not EOB (ZRL): bits 10:4 then read R + 64, which steers
@@ -83,8 +87,9 @@ template <int MODE> struct jda_lds_layout {       // the per-WAVE region
         CNT_OFF = ROWLIST_OFF + JDA_TILE_THREADS,                   // 8 uint32 counters
         COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
         COLLIST_ENTRIES = BLOCKS * 8,                               // every column of every block
-        WIN_OFF = COLLIST_OFF + COLLIST_ENTRIES * 2,
-        WAVE_BYTES = WIN_OFF + JDA_WIN_BYTES,                       // 9,792 B (4:2:0)
+        WIN_OFF = COLLIST_OFF,                                      // (shared with the column list, see above)
+        WIN_BYTES = (COLLIST_ENTRIES * 2) / 16 * 16 > 1024 ? 1024 : (COLLIST_ENTRIES * 2) / 16 * 16,   // one 16-byte chunk per lane at most
+        WAVE_BYTES = COLLIST_OFF + COLLIST_ENTRIES * 2,             // 9,216 B (4:2:0)
         PLANE_OFF = COEF_OFF,
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE, // bytes between consecutive MCUs' samples
         // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy
@@ -268,7 +273,7 @@ JDA_HD void jda_refill(jda_bitreader &br)
 struct jda_chunk16 { uint32_t w[4]; };
 typedef jda_chunk16 __attribute__((may_alias)) jda_chunk16_alias;
 // the same copy split in two so the HBM load can be issued early and the LDS store done late
-// (JDA_WIN_BYTES <= 64 lanes x 16 bytes: one chunk per lane)
+// (WIN_BYTES <= 64 lanes x 16 bytes: one chunk per lane)
 JDA_HD jda_chunk16 jda_window_load(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint32_t lane)
 {
     jda_chunk16 c;
@@ -1178,7 +1183,7 @@ JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
         C.win_need = C.win_len;
-        if (C.win_len > JDA_WIN_BYTES) C.win_len = JDA_WIN_BYTES;
+        if (C.win_len > (uint32_t)jda_lds_layout<MODE>::WIN_BYTES) C.win_len = (uint32_t)jda_lds_layout<MODE>::WIN_BYTES;
     }
     return C;
 }
@@ -1203,7 +1208,7 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
         C.win_need = C.win_len;
-        if (C.win_len > JDA_WIN_BYTES) C.win_len = JDA_WIN_BYTES;
+        if (C.win_len > (uint32_t)jda_lds_layout<MODE>::WIN_BYTES) C.win_len = (uint32_t)jda_lds_layout<MODE>::WIN_BYTES;
     }
     return C;
 }
@@ -1217,7 +1222,7 @@ JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nth
     const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, tables);
     jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;
-    // quant + zigzag: blob[10240, 10816) -> LT_QUANT
+    // quant: blob[10240, 10752) -> the DC LUTs' unused bytes; zigzag: built below
     for (uint32_t j = tid; j < JDA_ZZ_ENTRIES; j += nthreads) {  // zigzag + flag bits of A.2 in one lookup
         uint32_t v = JDA_ZZ_DUMP;
         if (j < 64) {
@@ -1228,10 +1233,12 @@ JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nth
     }
     for (uint32_t i = tid; i < JDA_LT_ZZ / 16; i += nthreads) {
         uint32_t src;
-        if (i < 128) src = i;                                   // DC
+        if (i < 128) {                                          // DC LUTs; chunks 16..31 of each (bytes 256..511) take two quantiser tables
+            const uint32_t within = i & 63u;
+            src = (within >= 16u && within < 32u) ? (JDA_TB_QUANT >> 4) + (i >> 6) * 16u + (within - 16u) : i;
+        }
         else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
-        else if (i < 384) src = (JDA_TB_AC >> 4) + 256 + (i - 256); // AC table 1, short half
-        else src = (JDA_TB_QUANT >> 4) + (i - 384);
+        else src = (JDA_TB_AC >> 4) + 256 + (i - 256);          // AC table 1, short half
         jda_chunk16_alias c = blob[src];
         if (i >= 128 && i < 384) {                              // AC entries -> the kernels' layout
 #pragma unroll
@@ -1259,7 +1266,7 @@ struct jda_lane_pre {          // (offsets, not pointers: a pointer carried arou
     uint32_t ac_off;          // its AC LUT (short half)
     uint32_t ac_long_off;     // byte offset of the AC LUT's long half in the table blob (global)
     uint32_t quant_off;       // byte offset of its quantiser table in the LDS table copy
-    uint32_t qsel;            // quantiser table id << 9 (the column work items carry it)
+    uint32_t qsel;            // (offset of the quantiser table / 128) << 9: the column work items carry it
     uint32_t chroma;          // the lane's block is a chroma block
 };
 template <int MODE>
@@ -1275,8 +1282,8 @@ JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t l
     LP.dc_off = JDA_LT_DC + dc_id * 1024;
     LP.ac_off = JDA_LT_AC + ac_id * 2048;
     LP.ac_long_off = JDA_TB_AC + (ac_id * 2048 + 1024) * 2;
-    LP.quant_off = JDA_LT_QUANT + q_id * 128;
-    LP.qsel = q_id << 9;
+    LP.quant_off = JDA_LT_QUANT_OFF(q_id);
+    LP.qsel = (JDA_LT_QUANT_OFF(q_id) >> 7) << 9;                 // (the table's offset in units of 128 bytes)
     LP.chroma = b >= (uint32_t)T::NLUMA ? 1u : 0u;
 }
 
@@ -1434,7 +1441,7 @@ JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, const uint8
     typedef jda_lds_layout<MODE> L;
     const uint32_t blk = (item >> 3) & 63u, col = item & 7u;      // item = quantiser table << 9 | block << 3 | column
     (void)D; (void)sizeof(T);
-    const int16_t *quant = (const int16_t *)(tab + JDA_LT_QUANT) + (item >> 9) * 64 + col;
+    const int16_t *quant = (const int16_t *)(tab + (item >> 9) * 128u) + col;    // item = (quantiser table offset / 128) << 9 | block << 3 | column
     int16_t *coef = (int16_t *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE) + col;
     int32_t cv[8], qv[8], r[8];
 #pragma unroll
@@ -1502,7 +1509,7 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, const uint8_t *tab, u
         const uint32_t blk = list[i];
         const uint32_t b = blk % T::NBLK;
         const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
-        const int32_t q0 = ((const int16_t *)(tab + JDA_LT_QUANT))[jda_pick3(D.q_id, c) * 64];
+        const int32_t q0 = *(const int16_t *)(tab + JDA_LT_QUANT_OFF(jda_pick3(D.q_id, c)));
         const int32_t dc = *(const int16_t *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE);
         const uint32_t v = jda_range_limit5(dc * q0) * 0x01010101u;
         jda_u32_alias *dst = (jda_u32_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE);

@@ -115,14 +115,14 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     const jda_p1_inputs p1in = jda_p1_prefetch<MODE>(D, C, lane);   // in flight while LDS is staged
     JDA_TRACE(1);
     jda_p0_tables(D, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
-    jda_p0_stage<MODE>(D, C, lane, wl, JDA_WIN_BYTES);
+    jda_p0_stage<MODE>(D, C, lane, wl, L::WIN_BYTES);
     JDA_TRACE(2);
     __syncthreads();                                  // the only workgroup barrier: tables are in LDS
     JDA_TRACE(3);
     uint32_t p1flags = JDA_NO_LIST;
     jda_lane_pre LP;
     jda_lane_prepare<MODE>(LP, D, lane, tab);
-    if (!(D.pad_[0] & 4)) p1flags = jda_p1_entropy<MODE>(D, C, p1in, LP, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
+    if (!(D.pad_[0] & 4)) p1flags = jda_p1_entropy<MODE>(D, C, p1in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
     if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, wl);
     JDA_WAVE_SYNC();
     JDA_TRACE(4);
@@ -295,7 +295,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // wave priorities: the phase that is a dependent chain (P1) and the one that feeds the memory pipe (P4) go first,
         // the arithmetic-dense IDCT fills the issue slots they leave (measured: 0.6-1 % over "oldest wave first")
         __builtin_amdgcn_s_setprio(3);
-        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, JDA_WIN_BYTES);
+        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
         if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, wl);
         __builtin_amdgcn_s_setprio(1);
         JDA_WAVE_SYNC();

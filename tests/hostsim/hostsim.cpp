@@ -16,8 +16,8 @@
 
 static int g_reverse_tiles = 0;   // tests run the tiles in reverse order too: results must not depend on which wave finishes first
 extern "C" void hostsim_set_reverse(int on) { g_reverse_tiles = on; }
-static uint32_t g_window_bytes = JDA_WIN_BYTES;   // tests shrink it to exercise the HBM fall-back of the bit reader
-extern "C" void hostsim_set_window(uint32_t bytes) { g_window_bytes = bytes > JDA_WIN_BYTES ? JDA_WIN_BYTES : (bytes & ~15u); }
+static uint32_t g_window_bytes = 1024;   // tests shrink it to exercise the HBM fall-back of the bit reader (each layout caps it at its WIN_BYTES)
+extern "C" void hostsim_set_window(uint32_t bytes) { g_window_bytes = bytes > 1024 ? 1024 : (bytes & ~15u); }
 
 // one wavefront = 64 lanes stepping through the kernel's phases; a phase runs for every lane before
 // the next one starts (= the wave-local fence between them)
