@@ -184,7 +184,13 @@ int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: a device
  * (either pointer may be NULL); n_blocks = mcus_x * mcus_y * blocks_per_mcu.  Synchronous. */
 int jda_dev_image_read_index(jda_ctx *ctx, const jda_dev_image *dimg, uint32_t *index, int16_t *dc);
 uint32_t jda_dev_image_mcus_ok(const jda_dev_image *dimg);        /* MCUs the pre-scan validated */
-int jda_last_prescan_rounds(const jda_ctx *ctx);   /* speculative rounds of the last marker-less device pre-scan (diagnostics) */
+int jda_last_prescan_rounds(const jda_ctx *ctx);
+/* The marker / byte-stuffing filter (JPEGFilter, jpeg.inl:1431-1540) run on the GPU over a host buffer, result back on the
+ * host: out must hold len bytes; *out_len = filtered length; restart_pos[0] = 0 and restart_pos[k] = filtered offset at
+ * which the k-th RSTn marker stood (first restart_cap entries), *n_restarts = markers seen.  What jda_upload_batch uses for
+ * images prepared with JDA_PREPARE_DEVICE_FILTER; exposed for callers that want the filtered scan, and for the tests. */
+int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t *out, int32_t *out_len,
+                         uint32_t *restart_pos, int32_t restart_cap, int32_t *n_restarts);   /* speculative rounds of the last marker-less device pre-scan (diagnostics) */
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg);
 size_t jda_dev_image_bytes(const jda_dev_image *dimg);
 

@@ -24,6 +24,7 @@ from .binding import (  # noqa: F401
     decode_to_host,
     draw_plan,
     draw_plan_ex,
+    filter_on_device,
     library_path,
     load_library,
     output_geometry,

@@ -57,6 +57,7 @@ _PROTOTYPES = [
     ("jda_prepare_batch", C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("jda_dev_image_prescan_on_device", C.c_int, [_P]),
     ("jda_last_prescan_rounds", C.c_int, [_P]),
+    ("jda_filter_on_device", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
     ("jda_effective_options", C.c_int32, [_P, C.c_int32]),
     ("jda_dev_image_read_index", C.c_int, [_P, _P, _P, _P]),
     ("jda_dev_image_mcus_ok", C.c_uint32, [_P]),
@@ -370,3 +371,14 @@ def decode_to_host(ctx: Context, jpeg: bytes, pixel_type=RGB8888, options=0):
     rc = ctx.lib.jda_decode_to_host(ctx.handle, jpeg, len(jpeg), pixel_type, options,
                                     canvas.ctypes.data_as(_P), canvas.shape[1], canvas.shape[0])
     return rc, canvas, g
+
+
+def filter_on_device(ctx: Context, raw: bytes, restart_cap: int = 1 << 16):
+    """JPEGFilter on the GPU (jda_filter_on_device): (filtered bytes, restart positions incl. the leading 0)."""
+    out = np.zeros(max(len(raw), 1), np.uint8)
+    n, nr = C.c_int32(0), C.c_int32(0)
+    rpos = np.zeros(restart_cap, np.uint32)
+    rc = ctx.lib.jda_filter_on_device(ctx.handle, raw, len(raw), out.ctypes.data_as(_P), C.byref(n), rpos.ctypes.data_as(_P), restart_cap, C.byref(nr))
+    if rc != 0:
+        raise JdaError(rc, "jda_filter_on_device")
+    return out[: n.value].tobytes(), rpos[: min(nr.value + 1, restart_cap)].copy(), nr.value

@@ -71,4 +71,14 @@ struct jda_strip {                // one wavefront's tile: <= 64 consecutive blo
     uint32_t ord;                 // position of the image among the images of this launch's tile list (0, 1, 2, ..)
 };
 
+// device marker / stuffing filter (jda_filter_scan), one per image
+struct jda_filter_params {
+    const uint8_t *raw;          // unfiltered entropy-coded segment (from the first SOS payload byte to the end of the file)
+    uint8_t *out;                // filtered scan (zero-initialised by the caller: the padding behind it stays zero)
+    uint32_t *restart_pos;       // [0] = 0, then the filtered offset at which each RSTn marker stood (first restart_cap entries)
+    uint32_t *result;            // [0] filtered length, [1] number of RSTn markers
+    uint32_t raw_len, restart_cap;
+};
+
+
 #endif

@@ -586,6 +586,108 @@ extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint3
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The marker / byte-stuffing filter on the device (JPEGFilter, jpeg.inl:1431-1540, over the whole scan: FF 00 -> FF, FF xx
+// (xx != 0, also FF FF) -> both bytes dropped, a trailing FF dropped; the offsets at which RSTn markers stood are kept).
+// It is a two-state machine over the bytes -- "normal" / "the previous byte was an unpaired FF" -- so it parallelises as a
+// scan of state-transition functions: every thread runs its 16 bytes from both possible incoming states (end state,
+// bytes emitted, markers seen), a workgroup-wide scan composes them, and a second walk from the now known state writes.
+// One workgroup per image walks the scan in 16 KB steps, carrying state and output offset.
+struct jda_fsm { uint32_t w0, w1; };   // w0: end state for incoming 0 | for incoming 1 << 1 | emitted (in 0) << 2 | emitted (in 1) << 17; w1: markers (in 0) | (in 1) << 16
+__device__ __forceinline__ jda_fsm jda_fsm_compose(jda_fsm A, jda_fsm B)     // A first, then B
+{
+    const uint32_t m0 = A.w0 & 1u, m1 = (A.w0 >> 1) & 1u;
+    const uint32_t e0 = (B.w0 >> m0) & 1u, e1 = (B.w0 >> m1) & 1u;
+    const uint32_t n0 = ((A.w0 >> 2) & 0x7fffu) + ((B.w0 >> (2 + 15 * m0)) & 0x7fffu);
+    const uint32_t n1 = ((A.w0 >> 17) & 0x7fffu) + ((B.w0 >> (2 + 15 * m1)) & 0x7fffu);
+    const uint32_t r0 = (A.w1 & 0xffffu) + ((B.w1 >> (16 * m0)) & 0xffffu);
+    const uint32_t r1 = (A.w1 >> 16) + ((B.w1 >> (16 * m1)) & 0xffffu);
+    jda_fsm R;
+    R.w0 = e0 | (e1 << 1) | (n0 << 2) | (n1 << 17);
+    R.w1 = r0 | (r1 << 16);
+    return R;
+}
+
+__global__ __launch_bounds__(1024)
+void jda_filter_scan(const jda_filter_params *__restrict__ params)
+{
+    __shared__ jda_fsm sc[2][1024];
+    const jda_filter_params P = params[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    uint32_t state = 0, out_base = 0, rst_base = 0;                 // carried from step to step (uniform)
+    if (tid == 0 && P.restart_cap) P.restart_pos[0] = 0;
+    for (uint32_t base = 0; base < P.raw_len; base += 16384u) {
+        const uint32_t off = base + tid * 16u;
+        const uint32_t valid = off >= P.raw_len ? 0u : (P.raw_len - off < 16u ? P.raw_len - off : 16u);
+        uint32_t b[4] = { 0, 0, 0, 0 };
+        if (valid) {                                              // (the raw buffer is padded to a multiple of 16 bytes)
+            const jda_chunk16_alias v = *(const jda_chunk16_alias JDA_GLOBAL *)(JDA_G(const uint8_t, P.raw) + off);
+            b[0] = v.w[0]; b[1] = v.w[1]; b[2] = v.w[2]; b[3] = v.w[3];
+        }
+        // this thread's bytes from both incoming states
+        uint32_t s0 = 0, s1 = 1, n0 = 0, n1 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const bool live = k < valid, ff = c == 0xffu, zero = c == 0u, rst = (c & 0xf8u) == 0xd0u;
+            if (live) {
+                n0 += s0 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r0 += (s0 && rst) ? 1u : 0u; s0 = s0 ? 0u : (ff ? 1u : 0u);
+                n1 += s1 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r1 += (s1 && rst) ? 1u : 0u; s1 = s1 ? 0u : (ff ? 1u : 0u);
+            }
+        }
+        jda_fsm X;
+        X.w0 = s0 | (s1 << 1) | (n0 << 2) | (n1 << 17);
+        X.w1 = r0 | (r1 << 16);
+        // inclusive scan of the transition functions over the 1024 threads
+        uint32_t cur = 0;
+        sc[0][tid] = X;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {
+            jda_fsm v = sc[cur][tid];
+            if (tid >= d) v = jda_fsm_compose(sc[cur][tid - d], v);
+            sc[cur ^ 1][tid] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        // this thread's incoming state and offsets: the functions of all threads before it, applied to the step's state
+        uint32_t st = state, o = out_base, rp = rst_base;
+        if (tid) {
+            const jda_fsm E = sc[cur][tid - 1];
+            st = (E.w0 >> state) & 1u;
+            o += (E.w0 >> (2 + 15 * state)) & 0x7fffu;
+            rp += (E.w1 >> (16 * state)) & 0xffffu;
+        }
+        const jda_fsm T = sc[cur][1023];
+        uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, P.out);
+        uint32_t JDA_GLOBAL *rpos = JDA_G(uint32_t, P.restart_pos);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            if (k < valid) {
+                if (st) {                                         // c follows an unpaired FF
+                    if (c == 0u) out[o++] = 0xffu;                // FF 00 -> FF
+                    else if ((c & 0xf8u) == 0xd0u) { rp++; if (rp < P.restart_cap) rpos[rp] = o; }     // RSTn: the next interval starts here
+                    st = 0;
+                } else if (c == 0xffu) st = 1;
+                else out[o++] = (uint8_t)c;
+            }
+        }
+        const uint32_t old = state;                                // the whole step, applied to the state it started in
+        state = (T.w0 >> old) & 1u;
+        out_base += (T.w0 >> (2 + 15 * old)) & 0x7fffu;
+        rst_base += (T.w1 >> (16 * old)) & 0xffffu;
+        __syncthreads();
+    }
+    if (tid == 0) { P.result[0] = out_base; P.result[1] = rst_base; }
+}
+
+extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, hipStream_t stream)
+{
+    if (n_images == 0) return hipSuccess;
+    hipLaunchKernelGGL(jda_filter_scan, dim3(n_images), dim3(1024), 0, stream, params);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t jda_internal_set_wgtrace(unsigned long long *dev_buf)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_wgtrace), &dev_buf, sizeof(dev_buf));

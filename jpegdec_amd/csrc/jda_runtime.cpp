@@ -27,6 +27,7 @@ extern "C" int jda_image_index_on_device(const jda_image *img);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
 extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
+extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
@@ -475,6 +476,37 @@ jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err)
 int jda_dev_image_prescan_on_device(const jda_dev_image *dimg) { return dimg ? dimg->prescan_on_device : 0; }
 int jda_last_prescan_rounds(const jda_ctx *ctx) { return ctx ? ctx->last_segscan_rounds : 0; }
 uint32_t jda_dev_image_mcus_ok(const jda_dev_image *dimg) { return dimg ? dimg->n_mcus_ok : 0; }
+
+int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t *out, int32_t *out_len,
+                         uint32_t *restart_pos, int32_t restart_cap, int32_t *n_restarts)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (!raw || len < 0 || !out || !out_len) return JDA_INVALID_PARAMETER;
+    (void)hipSetDevice(ctx->device);
+    const size_t raw_cap = align16((size_t)len) + 16, rcap = restart_cap > 0 ? (size_t)restart_cap : 1;
+    const size_t off_out = raw_cap, off_rpos = off_out + align16((size_t)len + 16), off_res = off_rpos + align16(rcap * 4), off_par = off_res + 16;
+    uint8_t *d = NULL;
+    hipError_t e = hipMalloc((void **)&d, off_par + sizeof(jda_filter_params));
+    if (e != hipSuccess) return set_err(ctx, e, "hipMalloc(filter)");
+    jda_filter_params P;
+    P.raw = d; P.out = d + off_out; P.restart_pos = (uint32_t *)(d + off_rpos); P.result = (uint32_t *)(d + off_res);
+    P.raw_len = (uint32_t)len; P.restart_cap = (uint32_t)rcap;
+    e = hipMemsetAsync(d, 0, off_par, ctx->stream);
+    if (e == hipSuccess && len) e = hipMemcpyAsync(d, raw, (size_t)len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + off_par, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(d + off_par), 1, ctx->stream);
+    uint32_t res[2] = { 0, 0 };
+    if (e == hipSuccess) e = hipMemcpyAsync(res, d + off_res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && res[0]) e = hipMemcpy(out, d + off_out, res[0], hipMemcpyDeviceToHost);
+    if (e == hipSuccess && restart_pos && restart_cap > 0)
+        e = hipMemcpy(restart_pos, d + off_rpos, (size_t)std::min<uint32_t>(res[1] + 1, (uint32_t)restart_cap) * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_err(ctx, e, "jda_filter_on_device");
+    *out_len = (int32_t)res[0];
+    if (n_restarts) *n_restarts = (int32_t)res[1];
+    return JDA_SUCCESS;
+}
 int jda_dev_image_read_index(jda_ctx *ctx, const jda_dev_image *dimg, uint32_t *index, int16_t *dc)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;

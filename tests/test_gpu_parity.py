@@ -284,3 +284,50 @@ def test_corrupted_scans_on_the_gpu(gpu_ctx, oracle):
                     assert np.array_equal(got, want), (name, it)
                     checked += 1
     assert checked >= 5
+
+
+def test_marker_filter_on_the_gpu(gpu_ctx, oracle):
+    """JPEGFilter (jpeg.inl:1431-1540) as a scan of two-state transition functions on the GPU (jda_filter_scan): byte for byte
+    the host filter's output, restart-marker offsets included -- on real scans, and on synthetic byte streams dense with FF
+    runs of every length and phase (also across the 16-byte thread and 16 KB step boundaries, and at the very end)."""
+    import jpegdec_amd as J
+    for name in ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "gray_64x64_rst3", "c420_1280x720"):
+        jpeg = jpeg_for(name)
+        p = J.PreparedImage(jpeg)
+        raw = jpeg[p.info.scan_offset:]
+        got, rpos, nr = J.filter_on_device(gpu_ctx, raw)
+        assert got == p.scan().tobytes() == oracle.filter(raw), name
+        assert np.array_equal(rpos, _host_restart_positions(raw)), name
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        n = int(rng.integers(0, 70000)) if trial else 0
+        raw = rng.integers(0, 256, n, dtype=np.uint8)
+        # salt with FF runs, FF 00, RSTn markers; some exactly at 16-byte / 16 KB boundaries
+        for _ in range(n // 37):
+            at = int(rng.integers(0, max(n - 8, 1)))
+            kind = int(rng.integers(0, 5))
+            run = int(rng.integers(1, 7))
+            raw[at:at + run] = 0xFF
+            if kind == 0 and at + run < n: raw[at + run] = 0x00
+            if kind == 1 and at + run < n: raw[at + run] = 0xD0 + int(rng.integers(0, 8))
+        for edge in (15, 16, 16383, 16384, 32767, n - 1, n - 2):
+            if 0 <= edge < n and rng.integers(0, 2): raw[edge] = 0xFF
+        rawb = raw.tobytes()
+        got, rpos, nr = J.filter_on_device(gpu_ctx, rawb)
+        assert got == oracle.filter(rawb), (trial, n)
+        assert np.array_equal(rpos, _host_restart_positions(rawb)), (trial, n)
+
+
+def _host_restart_positions(raw: bytes):
+    """what jda_prepare's filter records: the filtered offset of every RSTn marker, preceded by 0"""
+    pos, o, i, n = [0], 0, 0, len(raw)
+    while i < n:
+        if raw[i] != 0xFF:
+            o += 1; i += 1
+        else:
+            if i + 1 < n and raw[i + 1] == 0:
+                o += 1
+            elif i + 1 < n and (raw[i + 1] & 0xF8) == 0xD0:
+                pos.append(o)
+            i += 2
+    return np.array(pos, np.uint32)
