@@ -124,11 +124,15 @@ const jda_image_info *jda_image_get_info(const jda_image *img);
 const uint8_t *jda_image_scan(const jda_image *img, uint32_t *len);
 const uint32_t *jda_image_block_index(const jda_image *img, uint32_t *n_mcus_ok);
 const int16_t *jda_image_block_dc(const jda_image *img);
-/* the table blob uploaded to the GPU: DC LUTs 2x1024 B, AC LUTs 2x2048 uint16, quant 4x64 int16 */
+/* the table blob uploaded to the GPU: DC LUTs 2x1024 B, AC LUTs 2x2048 uint16, quant 4x64 int16, zigzag 64 B,
+ * and (ours) the end-of-block code of each AC table, 2 x uint32 = (32 - length) << 16 | code */
 const uint8_t *jda_image_tables(const jda_image *img, uint32_t *bytes);
 /* number of places where the reference's un-refilled magnitude read drops low bits
  * (SURVEY.md fact 6); informational */
 uint32_t jda_image_truncation_events(const jda_image *img);
+/* 1: an AC table codes the end-of-block symbol more than once (malformed DHT; jpeg.inl:1066-1275 builds its LUTs per
+ * code and decodes it all the same): the kernels then take their general bit reader; informational */
+uint32_t jda_image_general_p1(const jda_image *img);
 
 /* Geometry of the decoded surface for (pixel_type, options): bytes per pixel, and the
  * MCU-padded canvas size in output pixels (what the reference's draw callbacks tile). */

@@ -69,6 +69,7 @@ _PROTOTYPES = [
     ("jda_image_block_dc", _P, [_P]),
     ("jda_image_tables", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_truncation_events", C.c_uint32, [_P]),
+    ("jda_image_general_p1", C.c_uint32, [_P]),
     ("jda_output_geometry", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 5),
     ("jda_draw_plan", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     ("jda_crop_round", None, [C.POINTER(ImageInfo)] + [C.POINTER(C.c_int32)] * 4),
@@ -218,6 +219,10 @@ class PreparedImage:
 
     def truncation_events(self) -> int:
         return self.lib.jda_image_truncation_events(self.handle)
+
+    def general_p1(self) -> bool:
+        """An AC table codes EOB twice: the kernels cannot find EOB by one compare and take their general bit reader."""
+        return bool(self.lib.jda_image_general_p1(self.handle))
 
     def geometry(self, pixel_type=RGB8888, options=0):
         return output_geometry(self.info, pixel_type, options)

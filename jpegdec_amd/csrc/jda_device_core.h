@@ -59,6 +59,7 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
 // is indexed 0..61 and 128..255 (+ 512 for the folded values), so bytes 256..511 of each 1024-byte LUT are never read --
 // room for two 128-byte tables each.  512 bytes less per workgroup is what lets 16 wavefronts of the 64-block tile layouts fit.
 #define JDA_LT_QUANT_OFF(q) ((((q) >> 1) * 1024u) + 256u + (((q) & 1u) * 128u))
+#define JDA_LT_EOB     64        // 2 x uint32: JDA_TB_EOB, in never-read bytes of DC LUT 0
 #define JDA_LT_ZZ      6144      // 144 x uint16, built while staging: where the coefficient at zigzag position j goes
 #define JDA_ZZ_ENTRIES 144       //   j < 64: (column bit 1 << (n & 7)) << 8 | 2 n (n = natural index: the byte offset in the
                                  //   block); j >= 64 (past the block, or 64 + j for a symbol that stores nothing): 128 = the
@@ -66,14 +67,18 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
 #define JDA_ZZ_DUMP    128u
 #define JDA_LT_BYTES   6432
 
-// AC LUT entry as the kernels keep it in LDS: length << 11 | nostore << 10 | R << 4 | S, made from the reference's
-// (length << 8) | RS.  nostore = a symbol with S == 0 that is not EOB (ZRL): bits 10:4 then read R + 64, which steers
-// the zigzag lookup to the padding entry -- the store needs no condition (jpeg.inl:2246-2256: "if (S && k < limit)").
+// AC LUT entry as the kernels keep it in LDS, made from the reference's (length << 8) | RS:
+//   length << 12 | S << 8 | Z,   Z = 2 (R + 64 nostore)  -- or 0xff for EOB and for "no such code" (raw 0: length 0)
+// nostore = a symbol with S == 0 that is not EOB (ZRL).  Z is the byte offset the symbol adds to the zigzag lookup
+// (2-byte entries): R + 64 steers it to the padding entry, so the store needs no condition (jpeg.inl:2246-2256:
+// "if (S && k < limit)"), and bits 4:1 of Z are still R for the position update.  One byte compare finds EOB.
+#define JDA_AC_EOB 0xffu
 JDA_HD uint32_t jda_ac_entry(uint32_t raw)
 {
     const uint32_t rs = raw & 0xffu, len = raw >> 8;
-    const uint32_t nostore = ((rs & 0xfu) == 0u && rs != 0u) ? 1u : 0u;
-    return (len << 11) | (nostore << 10) | rs;
+    if (rs == 0u) return (len << 12) | JDA_AC_EOB;
+    const uint32_t r = rs >> 4, sz = rs & 0xfu;
+    return (len << 12) | (sz << 8) | ((r + (sz == 0u ? 64u : 0u)) << 1);
 }
 
 template <int MODE> struct jda_lds_layout {       // the per-WAVE region
@@ -252,8 +257,10 @@ JDA_HD uint64_t jda_load_be64(const jda_bitreader &br, uint32_t pos)
     const uint32_t a = pos & ~3u;
     const uint32_t rel = a - br.win_lo;
     if (rel + 12u <= br.win_len) {                      // (a < win_lo wraps to a huge rel: falls through)
+        // the LDS window holds the stream as byte-swapped dwords (jda_window_store): only the byte alignment is left
         const jda_u32_alias *p = (const jda_u32_alias *)(br.win + rel);
-        return jda_be64_from_words(p[0], p[1], p[2], pos);
+        const uint32_t sel = 0x07060504u - (pos & 3u) * 0x01010101u;
+        return ((uint64_t)jda_perm(p[0], p[1], sel) << 32) | jda_perm(p[1], p[2], sel);
     }
     const jda_u32_alias JDA_GLOBAL *p = (const jda_u32_alias JDA_GLOBAL *)(br.base + a);
     return jda_be64_from_words(p[0], p[1], p[2], pos);
@@ -289,8 +296,8 @@ JDA_HD void jda_window_store(uint8_t *win, uint32_t win_len, uint32_t lane, cons
 {
     if (lane < (win_len >> 4)) {
         jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
-        jda_chunk16_alias v;
-        v.w[0] = c.w[0]; v.w[1] = c.w[1]; v.w[2] = c.w[2]; v.w[3] = c.w[3];
+        jda_chunk16_alias v;                            // every dword with the stream's first byte on top: P1's bit buffer takes them as they are
+        v.w[0] = __builtin_bswap32(c.w[0]); v.w[1] = __builtin_bswap32(c.w[1]); v.w[2] = __builtin_bswap32(c.w[2]); v.w[3] = __builtin_bswap32(c.w[3]);
         dst[lane] = v;
     }
 }
@@ -299,7 +306,11 @@ JDA_HD void jda_window_fill(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uin
 {
     const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
     jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
-    for (uint32_t i = lane; i < (win_len >> 4); i += JDA_TILE_THREADS) dst[i] = src[i];
+    for (uint32_t i = lane; i < (win_len >> 4); i += JDA_TILE_THREADS) {
+        jda_chunk16_alias v = src[i];
+        v.w[0] = __builtin_bswap32(v.w[0]); v.w[1] = __builtin_bswap32(v.w[1]); v.w[2] = __builtin_bswap32(v.w[2]); v.w[3] = __builtin_bswap32(v.w[3]);
+        dst[i] = v;
+    }
 }
 
 // EXTEND of the next s bits of the (un-refilled) window (jpeg.inl:2249-2252, 2155-2158)
@@ -367,6 +378,7 @@ struct jda_tables {
     const uint16_t *ac_short; // LDS: 1024 entries in the jda_ac_entry layout
     const uint16_t JDA_GLOBAL *ac_long;  // global: 1024 entries (codes starting 111111), the reference's layout
     const uint16_t *zz;       // LDS: JDA_ZZ_ENTRIES entries (see JDA_LT_ZZ)
+    uint32_t eob_sh, eob_code;   // the window-only reader finds EOB by comparing stream bits (jda_lane_pre)
 };
 
 // dc_only / al: the scan holds DC symbols only (first scan of a progressive file, JPEGDecodeMCU_P jpeg.inl:1819-2084 with
@@ -409,11 +421,10 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
         code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
         if (code >= 0xfc00u) e = jda_ac_entry(T.ac_long[code & 0x3ffu]);   // usHuffAC[1024 + ...]  :2232-2233
         else e = T.ac_short[code >> 6];
-        br.off += e >> 11;
-        e &= 0xffu;
-        if (e == 0) break;                              // EOB (no refill follows)
-        k += (int)(e >> 4);
-        const uint32_t ms = e & 0xfu;
+        br.off += e >> 12;
+        if ((e & 0xffu) == JDA_AC_EOB) break;           // EOB (no refill follows)
+        k += (int)((e >> 1) & 0xfu);
+        const uint32_t ms = (e >> 8) & 0xfu;
         if (k < LIMIT && ms) {
             const uint32_t n = (T.zz[k] & 0xffu) >> 1;
             flags |= (1u << (n & 7u)) | (n << 8);
@@ -596,45 +607,54 @@ JDA_HD int32_t jda_extend_top(uint32_t t, uint32_t s)
 
 // The reader of the window-only path.  It does NOT keep the reference's 64-bit window: it keeps its own 64 bits
 // (hi:lo, refilled a dword at a time, the next dword prefetched one refill ahead so that no LDS round trip sits between two
-// symbols), and only the reference's ulBitOff (roff) to know which magnitude reads the reference truncates: with ulBitOff = x
-// after the code, (ulBits << x) holds 64 - x stream bits and zeros below, so a magnitude of s > 64 - x bits loses its low
-// s - (64 - x) bits.  That is rare (a handful per image), so it is a branch, not arithmetic on every symbol.
+// symbols; the window in LDS holds byte-swapped dwords, so they are taken as they are).  `left` = bits of hi not consumed yet,
+// 0..31 -- hi may be used up completely, never untouched -- so that the next 32 stream bits are one v_alignbit_b32.
 struct jda_wreader {
-    uint32_t hi, lo, nxt;    // 64 stream bits + the dword after them (big-endian order restored)
-    uint32_t boff;           // bits of hi already consumed (< 32 between symbols)
-    uint32_t roff;           // the reference's ulBitOff
+    uint32_t hi, lo, nxt;    // 64 stream bits + the dword after them
+    uint32_t left;           // bits of hi still to come
     const uint8_t *wp;       // LDS address nxt came from
 };
-JDA_HD uint32_t jda_wr_be32(const uint8_t *p) { return __builtin_bswap32(*(const jda_u32_alias *)p); }
+JDA_HD uint32_t jda_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)      // low 32 bits of {hi, lo} >> sh, sh = 0..31
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
+#endif
+}
 JDA_HD void jda_wr_init(jda_wreader &R, const uint8_t *wbase, uint32_t pos, uint32_t off)
 {
-    const uint32_t bit = (pos << 3) + off;
-    const uint8_t *p = wbase + ((bit >> 5) << 2);
-    R.hi = jda_wr_be32(p); R.lo = jda_wr_be32(p + 4); R.nxt = jda_wr_be32(p + 8);
-    R.wp = p + 8; R.boff = bit & 31u; R.roff = off;
+    const int32_t bit = (int32_t)((pos << 3) + off);
+    // the dword holding the last consumed bit (for bit 0 of the window: the four bytes in front of it -- other LDS data, all "consumed")
+    const uint8_t *p = wbase + (((bit - 1) >> 5) * 4);
+    R.hi = *(const jda_u32_alias *)p; R.lo = *(const jda_u32_alias *)(p + 4); R.nxt = *(const jda_u32_alias *)(p + 8);
+    R.wp = p + 8; R.left = (uint32_t)(-bit) & 31u;
 }
-JDA_HD uint32_t jda_wr_peek(const jda_wreader &R) { return (uint32_t)(((((uint64_t)R.hi << 32) | R.lo) << R.boff) >> 32); }
-// n <= 31 bits consumed: slide a dword when hi is used up; the reference's refill (jpeg.inl:2110-2114) is a pure counter here
+JDA_HD uint32_t jda_wr_peek(const jda_wreader &R) { return jda_alignbit(R.hi, R.lo, R.left); }
+// n <= 31 bits consumed: slide a dword when hi is used up and more
 JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n)
 {
-    R.boff += n;
-    const bool go = R.boff >= 32u;
+    const bool go = n > R.left;
+    R.left = (R.left - n) & 31u;
     R.hi = go ? R.lo : R.hi;
     R.lo = go ? R.nxt : R.lo;
-    R.boff &= 31u;
     R.wp += go ? 4 : 0;
-    R.nxt = jda_wr_be32(R.wp);                          // (re)loaded every time: unchanged address, unchanged value
+    R.nxt = *(const jda_u32_alias *)R.wp;               // (re)loaded every time: unchanged address, unchanged value
 }
-JDA_HD void jda_wr_ref_refill(jda_wreader &R) { R.roff = R.roff > 47u ? (R.roff & 7u) : R.roff; }
+// the reference's refill (jpeg.inl:2110-2114) as far as its ulBitOff is concerned
+JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) : roff; }
 
-template <int LIMIT>
+// EXACT = false leaves the reference's ulBitOff out (five instructions less per symbol): only right for a block in which the
+// reference truncates no magnitude read -- nothing in the index says so yet, so every caller passes true.
+// zero_fill: clear the block first.
+template <int LIMIT, bool EXACT>
 JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill,
-                                     bool dc_only = false, uint32_t al = 0)
+                                     bool dc_only, uint32_t al)
 {
     jda_wreader R;
     jda_wr_init(R, wbase, pos, off);
     uint32_t fl = 0;                                     // OR of zz entries of the stored coefficients
-    jda_wr_ref_refill(R);
+    uint32_t roff = EXACT ? jda_ref_refill(off) : 0u;   // the reference's ulBitOff
     if (LIMIT == 64) {
         if (zero_fill) {
             jda_u64_alias *z = (jda_u64_alias *)coef;
@@ -655,37 +675,46 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     const bool take = s != 0 && folded == 0;             // magnitude bits follow in the stream
     const int32_t mag = (int32_t)((uint32_t)jda_extend_top(w << dlen, s) << al);
     pred += s == 0 ? 0 : (folded ? folded : mag);
-    R.roff += dlen;
-    if (take) { jda_wr_ref_refill(R); R.roff += s; }
+    if (EXACT) {
+        roff += dlen;
+        if (take) roff = jda_ref_refill(roff) + s;
+    }
     jda_wr_consume(R, dlen + (take ? s : 0u));
     if (LIMIT == 1) return 0;
     coef[0] = (int16_t)pred;
     if (dc_only) return 0;                               // no AC symbol in this scan: a DC-only block (flags 0)
-    int k = 1;
-    jda_wr_ref_refill(R);
-    for (;;) {
-        w = jda_wr_peek(R);
-        e = T.ac_short[w >> 22];
+    uint32_t k2 = 2;                                     // twice the zigzag position: the byte offset into the zigzag table
+    if (EXACT) roff = jda_ref_refill(roff);
+    // EOB is recognised on the stream bits themselves -- one code per table, checked by the host (JDA_DESC_GENERAL_P1) --
+    // before the symbol is looked up: a block costs one trip per coefficient symbol, none for its EOB, and the wavefront
+    // runs as many trips as its longest block needs.  (A block of a decoded MCU holds no invalid code: the pre-scan ends
+    // the image at the first bad MCU.)
+    w = jda_wr_peek(R);
+    if ((w >> T.eob_sh) != T.eob_code) for (;;) {
+        uint32_t li = w >> 22;
+        JDA_OPAQUE(li);                                  // (keeps it a shift + a shift-add: the compiler's own form is shift, mask, add)
+        e = T.ac_short[li];
         if (__builtin_expect(w >= 0xfc000000u, 0)) e = jda_ac_entry(T.ac_long[(w >> 16) & 0x3ffu]);     // rare: codes starting 111111
-        const uint32_t len = e >> 11;
-        if ((e & 0xffu) == 0) break;                     // EOB (the block's reader state is not needed any more)
         // the zigzag lookup decides where the value goes: position k + R of the block, or the padding when that is past
-        // the block or the symbol carries no value (ZRL: bits 10:4 of the entry read R + 64)
-        const uint32_t kk = (uint32_t)k + ((e >> 4) & 0x7fu);
-        uint32_t t = T.zz[kk];
-        if (LIMIT != 64 && kk >= (uint32_t)LIMIT) t = JDA_ZZ_DUMP;     // 1/4 scale keeps zigzag 1..4 only (:2117-2119)
-        const uint32_t ms = e & 0xfu;
+        // the block or the symbol carries no value (ZRL: the entry's low byte reads 2 (R + 64))
+        const uint32_t kk2 = k2 + (e & 0xffu);
+        uint32_t t = *(const uint16_t *)((const uint8_t *)T.zz + kk2);
+        if (LIMIT != 64 && kk2 >= 2u * (uint32_t)LIMIT) t = JDA_ZZ_DUMP;     // 1/4 scale keeps zigzag 1..4 only (:2117-2119)
+        const uint32_t len = e >> 12, ms = (e >> 8) & 0xfu;
         uint32_t m = w << len;
-        const uint32_t x = R.roff + len;                 // the reference's ulBitOff at its magnitude read (:2249)
-        if (__builtin_expect(x + ms > 64u, 0)) m &= ~(0xffffffffu >> (64u - x));      // its window ends inside the magnitude
+        const uint32_t n = len + ms;
+        if (EXACT) {
+            roff += n;                                   // the reference's ulBitOff after its magnitude read (:2249-2252)
+            if (__builtin_expect(roff > 64u, 0)) m &= ~(0xffffffffu >> (64u + ms - roff));      // its window ended inside the magnitude
+            roff = jda_ref_refill(roff);
+        }
         const int32_t v = jda_extend_top(m, ms);
         fl |= t;
         *(int16_t *)((uint8_t *)coef + (t & 0xffu)) = (int16_t)v;
-        R.roff = x + ms;
-        jda_wr_consume(R, len + ms);
-        k += (int)((e >> 4) & 0xfu) + 1;
-        jda_wr_ref_refill(R);
-        if (k >= LIMIT) break;
+        jda_wr_consume(R, n);
+        k2 += (e & 0x1eu) + 2u;
+        w = jda_wr_peek(R);
+        if (k2 >= 2u * (uint32_t)LIMIT || (w >> T.eob_sh) == T.eob_code) break;
     }
     // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested; fl holds 2n in 7:0
     return (fl >> 8) | ((fl & 0x40u) << 7);
@@ -1096,16 +1125,16 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             uint32_t e;
             if (w >= 0xfc000000u) e = jda_ac_entry(ac_long_base[aci * 2048 + 1024 + ((w >> 16) & 0x3ffu)]);
             else e = ((const uint16_t *)(lt + JDA_LT_AC))[aci * 1024 + (w >> 22)];
-            if (e == 0) {                                           // :2237-2238
+            if (e == JDA_AC_EOB) {                                  // no such code (length 0)  :2237-2238
                 if (OP == JDA_SEG_SPEC) { p += 1; k = 0; continue; }
                 bad = true; break;
             }
-            const uint32_t len = e >> 11, rs = e & 0xffu;
+            const uint32_t len = e >> 12;
             JDA_SG_ADVANCE(len);
             p += len;
-            if (rs == 0) { k = 0; b = b + 1u == P.nblocks ? 0u : b + 1u; }       // EOB: no refill follows
+            if ((e & 0xffu) == JDA_AC_EOB) { k = 0; b = b + 1u == P.nblocks ? 0u : b + 1u; }       // EOB: no refill follows
             else {
-                const uint32_t ms = rs & 0xfu, kk = k + (rs >> 4);
+                const uint32_t ms = (e >> 8) & 0xfu, kk = k + ((e >> 1) & 0xfu);
                 if (OP == JDA_SEG_WRITE) {
                     if (ms && kk < 64 && off + ms > 64) ST.trunc_events++;
                     if (ms > ST.max_ac_bits && kk < 64) ST.max_ac_bits = ms;
@@ -1236,6 +1265,7 @@ JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nth
         if (i < 128) {                                          // DC LUTs; chunks 16..31 of each (bytes 256..511) take two quantiser tables
             const uint32_t within = i & 63u;
             src = (within >= 16u && within < 32u) ? (JDA_TB_QUANT >> 4) + (i >> 6) * 16u + (within - 16u) : i;
+            if (i == (JDA_LT_EOB >> 4)) src = JDA_TB_EOB >> 4;      // (bytes 64..127 of a DC LUT are never read either)
         }
         else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
         else src = (JDA_TB_AC >> 4) + 256 + (i - 256);          // AC table 1, short half
@@ -1268,6 +1298,7 @@ struct jda_lane_pre {          // (offsets, not pointers: a pointer carried arou
     uint32_t quant_off;       // byte offset of its quantiser table in the LDS table copy
     uint32_t qsel;            // (offset of the quantiser table / 128) << 9: the column work items carry it
     uint32_t chroma;          // the lane's block is a chroma block
+    uint32_t eob_sh, eob_code;   // the next symbol is EOB when (next 32 stream bits >> eob_sh) == eob_code (JDA_TB_EOB)
 };
 template <int MODE>
 JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t lane, const uint8_t *tab)
@@ -1278,7 +1309,8 @@ JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t l
     // (jda_pick3 reads the three ids into values first: a select between the array's elements becomes a dynamically
     // indexed load, and that sends the whole descriptor from SGPRs to scratch memory)
     const uint32_t dc_id = jda_pick3(D.dc_id, c), ac_id = jda_pick3(D.ac_id, c), q_id = jda_pick3(D.q_id, c);
-    (void)tab;
+    const uint32_t eob = *(const jda_u32_alias *)(tab + JDA_LT_EOB + 4u * ac_id);   // (the image's tables must be staged)
+    LP.eob_sh = eob >> 16; LP.eob_code = eob & 0xffffu;
     LP.dc_off = JDA_LT_DC + dc_id * 1024;
     LP.ac_off = JDA_LT_AC + ac_id * 2048;
     LP.ac_long_off = JDA_TB_AC + (ac_id * 2048 + 1024) * 2;
@@ -1326,6 +1358,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     TB.ac_short = (const uint16_t *)(tab + LP.ac_off);
     TB.ac_long = (const uint16_t JDA_GLOBAL *)(JDA_G(const uint8_t, D.tables) + LP.ac_long_off);
     TB.zz = (const uint16_t *)(tab + JDA_LT_ZZ);
+    TB.eob_sh = LP.eob_sh; TB.eob_code = LP.eob_code;
     const int16_t *quant = (const int16_t *)(tab + LP.quant_off);
     int16_t *coef = (int16_t *)(wl + L::COEF_OFF + lb * JDA_COEF_STRIDE);
     uint8_t *plane = (uint8_t *)coef;                            // samples overwrite the block's own slot
@@ -1345,15 +1378,16 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
 
     JDA_P1_TRACE(8);
     const int shift = D.scale_shift;
-    const bool win_only = C.win_need <= br.win_len;             // wave-uniform: the whole slice is in LDS
+    // wave-uniform: the whole slice is in LDS (and the tables allow the window-only reader's EOB test)
+    const bool win_only = C.win_need <= br.win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
-        if (win_only) jda_decode_block_win<1>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al); }
+        if (win_only) jda_decode_block_win<1, true>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al); }
         *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
         return JDA_NO_LIST;
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
         uint32_t flags;
-        if (win_only) flags = jda_decode_block_win<5>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+        if (win_only) flags = jda_decode_block_win<5, true>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
         else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred, dc_only, al); }
         const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
                                        : jda_idct_2x2(coef, quant);
@@ -1361,7 +1395,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
         return JDA_NO_LIST;
     }
     uint32_t flags;
-    if (win_only) flags = jda_decode_block_win<64>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+    if (win_only) flags = jda_decode_block_win<64, true>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
     else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred, dc_only, al); }
     JDA_P1_TRACE(9);
     return flags;

@@ -13,7 +13,10 @@
 #define JDA_TB_AC        2048     // 2 x 2048 uint16  (usHuffAC)
 #define JDA_TB_QUANT     10240    // 4 x 64 int16     (sQuantTable after JPEGFixQuantD)
 #define JDA_TB_ZIGZAG    10752    // 64 bytes         (cZigZag2: zigzag position -> natural index)
-#define JDA_TABLE_BYTES  10816
+#define JDA_TB_EOB       10816    // 2 x uint32       (ours: the end-of-block code of each AC table, (32 - length) << 16 | code,
+                                  //                   so that P1 recognises EOB by comparing stream bits; JDA_EOB_NONE = no such code)
+#define JDA_EOB_NONE     ((31u << 16) | 2u)      // a one-bit field never reads 2
+#define JDA_TABLE_BYTES  10832
 
 #define JDA_SCAN_PAD     32       // zero bytes after the filtered scan (window loads overrun)
 #define JDA_INDEX_OFF_BITS 7      // index entry = (byte position << 7) | bit offset (0..64)
@@ -57,9 +60,12 @@ struct jda_dev_desc {             // one per image of a batch, 96 bytes
     };
 };
 
-// descriptor byte pad_[0]: bits 2:0 profiling switches, bit 3 = the scan holds DC symbols only (the first scan of a
+// descriptor byte pad_[0]: bits 1:0 profiling switches, bit 2 below, bit 3 = the scan holds DC symbols only (the first scan of a
 // progressive file, decoded as a thumbnail: jpeg.inl:4964-4966), bits 7:4 = Al, the point transform of those DC differences
 #define JDA_DESC_DC_ONLY 8u
+// bit 2 = P1 must take its general bit reader: an AC table codes the end-of-block symbol more than once (a malformed but
+// decodable DHT), so one compare of stream bits cannot recognise EOB
+#define JDA_DESC_GENERAL_P1 4u
 
 struct jda_strip {                // one wavefront's tile: <= 64 consecutive blocks (10/21/64 MCUs) of one MCU row; 16 bytes
     uint32_t image;               // index into the descriptor array

@@ -122,11 +122,11 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     uint32_t p1flags = JDA_NO_LIST;
     jda_lane_pre LP;
     jda_lane_prepare<MODE>(LP, D, lane, tab);
-    if (!(D.pad_[0] & 4)) p1flags = jda_p1_entropy<MODE>(D, C, p1in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
+    p1flags = jda_p1_entropy<MODE>(D, C, p1in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
     if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, wl);
     JDA_WAVE_SYNC();
     JDA_TRACE(4);
-    if (D.scale_shift < 2 && !(D.pad_[0] & 6)) {
+    if (D.scale_shift < 2 && !(D.pad_[0] & 2)) {
         jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
         JDA_WAVE_SYNC();
         JDA_TRACE(5);
@@ -260,12 +260,12 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     JDA_TILE_COLD_START();
     jda_p4_pre P4;                                    // the colour stage's item addresses for this image (pitch, pixel size)
     jda_p4_prepare<MODE>(P4, Dc, lane);
-    jda_lane_pre LP;                                  // the lane's Huffman LUTs / quantiser table in this image
-    jda_lane_prepare<MODE>(LP, Dc, lane, tab);
     if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;
     jda_strip Sn = S;
     if (i_nxt < t_end) Sn = jda_load_record(tiles + i_nxt);
     JDA_ADVANCE_TABLES(S.ord, true, S, Dc);
+    jda_lane_pre LP;                                  // the lane's Huffman LUTs / quantiser table / EOB code in this image (reads the staged tables)
+    jda_lane_prepare<MODE>(LP, Dc, lane, tab);
     JDA_WAVE_SYNC();
 
 #ifdef JDA_PHASE_TRACE

@@ -12,9 +12,10 @@
 
 extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
+extern "C" uint32_t jda_image_general_p1(const jda_image *img);
 
 
-// descriptor byte pad_[0]: bits 2:0 profiling switches (JDA_DEBUG_SKIP), bit 3 = the scan holds DC symbols only (first scan
+// descriptor byte pad_[0]: bits 1:0 profiling switches (JDA_DEBUG_SKIP), bit 2 = JDA_DESC_GENERAL_P1, bit 3 = the scan holds DC symbols only (first scan
 // of a progressive file), bits 7:4 = Al, the point transform of those DC differences (jpeg.inl:1884)
 inline uint8_t jda_desc_stream_bits(const jda_image_info &I)
 {
@@ -50,7 +51,7 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pixel_type == JDA_EIGHT_BIT_GRAYSCALE);
     jda_image_component_ids(img, D.dc_id, D.ac_id, D.q_id);
     D.fast_mul = (uint8_t)jda_image_fast_mul(img);
-    D.pad_[0] = jda_desc_stream_bits(I);
+    D.pad_[0] = (uint8_t)(jda_desc_stream_bits(I) | (jda_image_general_p1(img) ? JDA_DESC_GENERAL_P1 : 0u));
     D.mcus_x = (uint32_t)I.mcus_x;
     D.mcus_y = (uint32_t)I.mcus_y;
     uint32_t nok = 0, slen = 0;

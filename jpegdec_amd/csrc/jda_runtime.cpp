@@ -21,6 +21,7 @@
 #include "jda_plan.h"
 
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
+extern "C" uint32_t jda_image_general_p1(const jda_image *img);
 extern "C" const uint32_t *jda_image_restart_positions(const jda_image *img, uint32_t *n);
 extern "C" void jda_image_run_host_prescan(jda_image *img);
 extern "C" int jda_image_index_on_device(const jda_image *img);
@@ -52,6 +53,7 @@ struct jda_dev_image {
     uint32_t scan_len, n_mcus_ok;
     uint8_t dc_id[3], ac_id[3], q_id[3];
     uint8_t fast_mul;
+    uint8_t general_p1;          // JDA_DESC_GENERAL_P1
     uint8_t prescan_on_device;   // the block index was made by jda_prescan_intervals (restart-marker fast path)
 };
 
@@ -263,6 +265,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         d->info = I;
         d->scan_len = scan_len;
         jda_image_component_ids(img, d->dc_id, d->ac_id, d->q_id);
+        d->general_p1 = (uint8_t)jda_image_general_p1(img);
         d->off_tables = 0;
         d->off_index = align16(it.tbytes);
         d->off_dc = d->off_index + align16((it.n_blocks + 1) * sizeof(uint32_t));
@@ -562,7 +565,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE);
         memcpy(D.dc_id, im->dc_id, 3); memcpy(D.ac_id, im->ac_id, 3); memcpy(D.q_id, im->q_id, 3);
         D.fast_mul = im->fast_mul;
-        { const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = (uint8_t)((dbg ? (atoi(dbg) & 7) : 0) | jda_desc_stream_bits(I)); }   // profiling aid: 1 = no P4, 2 = no IDCT, 4 = no P1
+        { const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = (uint8_t)((dbg ? (atoi(dbg) & 3) : 0) | jda_desc_stream_bits(I) | (im->general_p1 ? JDA_DESC_GENERAL_P1 : 0u)); }   // profiling aid: 1 = no P4, 2 = no IDCT
         D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
         D.n_mcus_ok = im->n_mcus_ok; D.scan_len = im->scan_len;
         D.tables = im->base + im->off_tables;

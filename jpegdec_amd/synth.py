@@ -142,9 +142,12 @@ def _codes(bits, vals):
     return table
 
 
-def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), restart_interval: int = 0) -> bytes:
+def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), restart_interval: int = 0,
+                       dup_eob: bool = False) -> bytes:
     """Baseline JPEG of an HxWx3 RGB image with luma sampling factors luma_hv = (H, V) and 1x1 chroma:
-    (1,1) 4:4:4, (2,1) 4:2:2, (1,2) 4:4:0, (2,2) 4:2:0."""
+    (1,1) 4:4:4, (2,1) 4:2:2, (1,2) 4:4:0, (2,2) 4:2:0.
+    dup_eob: both AC tables code the end-of-block symbol twice (a second, 16-bit code) and every other block ends with
+    the second one -- a malformed but decodable DHT (decoders with per-code LUTs do not notice)."""
     hs, vs = luma_hv
     h, w = pixels.shape[:2]
     rgb = pixels.astype(np.float64)
@@ -178,7 +181,20 @@ def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), re
 
     cb = [blocks(planes[0], nat_q[0]), blocks(planes[1], nat_q[1]), blocks(planes[2], nat_q[1])]
     dc_t = [_codes(*huff[(0, 0)]), _codes(*huff[(0, 1)])]
+    eob2 = [None, None]
+    if dup_eob:
+        for th in (0, 1):
+            bits, vals = huff[(1, th)]
+            bits = list(bits)
+            bits[15] += 1                       # one more 16-bit code, the last of the table: symbol 0x00 again
+            huff[(1, th)] = (bits, list(vals) + [0])
     ac_t = [_codes(*huff[(1, 0)]), _codes(*huff[(1, 1)])]
+    if dup_eob:
+        for th in (0, 1):
+            eob2[th] = ac_t[th][0]              # (_codes keeps the last code of a repeated symbol)
+            bits, vals = huff[(1, th)]
+            ac_t[th][0] = _codes(bits[:15] + [bits[15] - 1], vals[:-1])[0]
+    n_eob = [0]
     out = bytearray()
     acc, nacc = 0, 0
 
@@ -219,7 +235,8 @@ def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), re
             put(bits, s)
             run = 0
         if last < 63:
-            put(*ac_t[t][0])
+            n_eob[0] += 1
+            put(*(eob2[t] if dup_eob and (n_eob[0] & 1) else ac_t[t][0]))
         return int(zz[0])
 
     pred = [0, 0, 0]

@@ -331,3 +331,28 @@ def _host_restart_positions(raw: bytes):
                 pos.append(o)
             i += 2
     return np.array(pos, np.uint32)
+
+
+@pytest.mark.parametrize("luma_hv", [(2, 2), (1, 1), (2, 1), (1, 2)])
+def test_duplicate_eob_code_general_reader(luma_hv, gpu_ctx, oracle):
+    """An AC table that codes the end-of-block symbol twice (malformed DHT; the reference's per-code LUTs decode it):
+    P1's one-compare EOB test cannot be used, the host flags the image (JDA_DESC_GENERAL_P1) and the kernels take their
+    general bit reader.  Same bytes as the oracle (pinned to the real reference on these files by
+    tests/test_oracle_vs_ref.py); a device pre-scan makes the same index."""
+    from jpegdec_amd.synth import encode_jpeg_custom, value_noise_image
+    jpeg = encode_jpeg_custom(value_noise_image(333, 217, 3, 78), 85, luma_hv, dup_eob=True)
+    prep = J.PreparedImage(jpeg)
+    assert prep.general_p1()
+    prep.close()
+    for pt, opt in ((J.RGB8888, 0), (J.RGB565_BE, 0), (J.RGB8888, J.SCALE_HALF), (J.GRAY8, J.SCALE_QUARTER), (J.RGB565_LE, J.SCALE_EIGHTH)):
+        if luma_hv == (1, 2) and pt == J.RGB8888 and opt == J.SCALE_QUARTER:
+            continue
+        rc, got, g = J.decode_to_host(gpu_ctx, jpeg, pt, opt)
+        assert rc == 0
+        orc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+        assert orc == 1 and np.array_equal(got, want), (luma_hv, pt, opt)
+    dev = J.PreparedImage(jpeg, device_prescan=True)
+    host = J.PreparedImage(jpeg)
+    dimg = J.DeviceImage(gpu_ctx, dev)
+    assert np.array_equal(dimg.read_index()[0], host.block_index()[0])
+    dimg.close(); dev.close(); host.close()

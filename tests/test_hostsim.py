@@ -129,3 +129,23 @@ def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
                 agree += 1
     hostsim.hostsim_set_device_prescan(0)
     assert agree >= 20
+
+
+@pytest.mark.parametrize("luma_hv", [(2, 2), (1, 1), (2, 1)])
+def test_duplicate_eob_code_takes_the_general_reader(luma_hv, hostsim, oracle):
+    """P1 recognises EOB by comparing stream bits with the table's one EOB code.  A DHT that codes symbol 0x00 twice
+    (malformed, but the reference's per-code LUTs decode it, jpeg.inl:1066-1275) is flagged by the host
+    (JDA_DESC_GENERAL_P1) and decoded through the general bit reader: still the oracle's bytes."""
+    from jpegdec_amd.synth import encode_jpeg_custom, value_noise_image
+    jpeg = encode_jpeg_custom(value_noise_image(200, 120, 3, 77), 85, luma_hv, dup_eob=True)
+    plain = encode_jpeg_custom(value_noise_image(200, 120, 3, 77), 85, luma_hv)
+    p, q = J.PreparedImage(jpeg), J.PreparedImage(plain)
+    assert p.general_p1() and not q.general_p1()
+    p.close(); q.close()
+    for pt, opt in ((J.RGB8888, 0), (J.RGB565_LE, J.SCALE_HALF), (J.GRAY8, J.SCALE_QUARTER)):
+        rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+        assert rc == 1
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+        assert hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert np.array_equal(got, want), (luma_hv, pt, opt)

@@ -109,3 +109,10 @@ def test_oracle_equals_reference_on_corrupted_scans(name, oracle, ref_scalar):
             assert np.array_equal(canvas[:h], r["canvas"][:h, : canvas.shape[1]]), (name, it)
             checked += 1
     assert checked >= 10
+
+
+@pytest.mark.parametrize("luma_hv", [(2, 2), (1, 1), (2, 1), (1, 2)])
+def test_oracle_equals_reference_duplicate_eob_code(luma_hv, oracle, ref_scalar):
+    """A DHT that codes the end-of-block symbol twice: the reference's per-code LUTs decode it; so must the oracle."""
+    from jpegdec_amd.synth import encode_jpeg_custom, value_noise_image
+    _compare_all_modes(encode_jpeg_custom(value_noise_image(333, 217, 3, 78), 85, luma_hv, dup_eob=True), oracle, ref_scalar)
