@@ -59,6 +59,7 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
 // is indexed 0..61 and 128..255 (+ 512 for the folded values), so bytes 256..511 of each 1024-byte LUT are never read --
 // room for two 128-byte tables each.  512 bytes less per workgroup is what lets 16 wavefronts of the 64-block tile layouts fit.
 #define JDA_LT_QUANT_OFF(q) ((((q) >> 1) * 1024u) + 256u + (((q) & 1u) * 128u))
+#define JDA_LT_NIB     96        // 16 x uint16: the set bits of a nibble, lowest first, as 3-bit fields (jda_p1_lists); same DC LUT bytes
 #define JDA_LT_EOB     64        // 2 x uint32: JDA_TB_EOB, in never-read bytes of DC LUT 0
 #define JDA_LT_ZZ      6144      // 144 x uint16, built while staging: where the coefficient at zigzag position j goes
 #define JDA_ZZ_ENTRIES 144       //   j < 64: (column bit 1 << (n & 7)) << 8 | 2 n (n = natural index: the byte offset in the
@@ -88,13 +89,15 @@ template <int MODE> struct jda_lds_layout {       // the per-WAVE region
         // one 136-byte slot per block: int16[64] coefficients, later (first 64 bytes) its 8x8 samples --
         // the row stage stores its bytes over the block it has just read, as the reference does (:2682)
         COEF_OFF = 0,
-        ROWLIST_OFF = COEF_OFF + BLOCKS * JDA_COEF_STRIDE,           // 64 block ids (uint8), grouped by row class
-        CNT_OFF = ROWLIST_OFF + JDA_TILE_THREADS,                   // 8 uint32 counters
-        COLLIST_OFF = CNT_OFF + 32,                                 // uint16 items
+        COLLIST_OFF = COEF_OFF + BLOCKS * JDA_COEF_STRIDE,           // uint16 items
         COLLIST_ENTRIES = BLOCKS * 8,                               // every column of every block
         WIN_OFF = COLLIST_OFF,                                      // (shared with the column list, see above)
         WIN_BYTES = (COLLIST_ENTRIES * 2) / 16 * 16 > 1024 ? 1024 : (COLLIST_ENTRIES * 2) / 16 * 16,   // one 16-byte chunk per lane at most
-        WAVE_BYTES = COLLIST_OFF + COLLIST_ENTRIES * 2,             // 9,216 B (4:2:0)
+        // the row list comes right after the column list: a block writes eight column items whatever it has (jda_p1_lists),
+        // up to seven past the list's end, i.e. into row list bytes that are only written afterwards
+        ROWLIST_OFF = COLLIST_OFF + COLLIST_ENTRIES * 2,            // 64 block ids (uint8), grouped by row class
+        CNT_OFF = ROWLIST_OFF + JDA_TILE_THREADS,                   // 8 uint32 counters
+        WAVE_BYTES = CNT_OFF + 32,                                  // 9,216 B (4:2:0)
         PLANE_OFF = COEF_OFF,
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE, // bytes between consecutive MCUs' samples
         // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy
@@ -122,8 +125,10 @@ JDA_HD uint32_t jda_alignbyte(uint32_t hi, uint32_t lo, uint32_t byte_shift)
 // (observed on MI355X: low bits of the blue channel corrupted).  Breaking the pattern costs nothing.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define JDA_OPAQUE(x) asm("" : "+v"(x))
+#define JDA_STORE_ORDER() asm volatile("" ::: "memory")      // the compiler keeps memory accesses on their side of it (LDS serves a wavefront's accesses in order)
 #else
 #define JDA_OPAQUE(x) ((void)0)
+#define JDA_STORE_ORDER() ((void)0)
 #endif
 
 // ---- packed 16-bit helpers (two pixels per VALU instruction in the colour stage) ---------------
@@ -1243,6 +1248,13 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
 }
 
 // ---- P0 ---------------------------------------------------------------------------------------
+// the set bits of the nibble m, lowest first, in 3-bit fields (unused fields 0)
+JDA_HD uint32_t jda_nibble_list(uint32_t m)
+{
+    uint32_t r = 0, n = 0;
+    for (uint32_t b = 0; b < 4; b++) if ((m >> b) & 1u) { r |= b << (3u * n); n++; }
+    return r;
+}
 // tables: once per workgroup (tid = thread in workgroup, nthreads = workgroup size)
 JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds);
 JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds) { jda_p0_tables_from(D.tables, tid, nthreads, tab_lds); }
@@ -1266,6 +1278,13 @@ JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nth
             const uint32_t within = i & 63u;
             src = (within >= 16u && within < 32u) ? (JDA_TB_QUANT >> 4) + (i >> 6) * 16u + (within - 16u) : i;
             if (i == (JDA_LT_EOB >> 4)) src = JDA_TB_EOB >> 4;      // (bytes 64..127 of a DC LUT are never read either)
+            if (i == (JDA_LT_NIB >> 4) || i == (JDA_LT_NIB >> 4) + 1u) {
+                jda_chunk16_alias nb;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) nb.w[k] = jda_nibble_list((i - (JDA_LT_NIB >> 4)) * 8u + 2u * k) | (jda_nibble_list((i - (JDA_LT_NIB >> 4)) * 8u + 2u * k + 1u) << 16);
+                tab[i] = nb;
+                continue;
+            }
         }
         else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
         else src = (JDA_TB_AC >> 4) + 256 + (i - 256);          // AC table 1, short half
@@ -1299,6 +1318,7 @@ struct jda_lane_pre {          // (offsets, not pointers: a pointer carried arou
     uint32_t qsel;            // (offset of the quantiser table / 128) << 9: the column work items carry it
     uint32_t chroma;          // the lane's block is a chroma block
     uint32_t eob_sh, eob_code;   // the next symbol is EOB when (next 32 stream bits >> eob_sh) == eob_code (JDA_TB_EOB)
+    uint32_t item_pre;        // qsel | lane << 3: a column work item of the lane's block, less its column
 };
 template <int MODE>
 JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t lane, const uint8_t *tab)
@@ -1316,6 +1336,7 @@ JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t l
     LP.ac_long_off = JDA_TB_AC + (ac_id * 2048 + 1024) * 2;
     LP.quant_off = JDA_LT_QUANT_OFF(q_id);
     LP.qsel = (JDA_LT_QUANT_OFF(q_id) >> 7) << 9;                 // (the table's offset in units of 128 bytes)
+    LP.item_pre = LP.qsel | (lane << 3);
     LP.chroma = b >= (uint32_t)T::NLUMA ? 1u : 0u;
 }
 
@@ -1407,11 +1428,10 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
 // list (:5146-5154).  Positions come from a wave prefix sum / ballots; order within a list is irrelevant.
 // all_flags: host emulation only (the flags of all 64 lanes).
 template <int MODE>
-JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t lane, uint32_t flags, const uint32_t *all_flags, uint8_t *wl)
+JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t lane, uint32_t flags, const uint32_t *all_flags, const uint8_t *tab, uint8_t *wl)
 {
     typedef jda_lds_layout<MODE> L;
     (void)D;
-    const uint32_t qsel = LP.qsel;          // a column item carries its block's quantiser table id, so that the column stage need not work it out per item
     uint32_t *cnt = (uint32_t *)(wl + L::CNT_OFF);
     uint8_t *rowlist = wl + L::ROWLIST_OFF;
     uint16_t *collist = (uint16_t *)(wl + L::COLLIST_OFF);
@@ -1437,18 +1457,26 @@ JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t
 #endif
     uint32_t total;
     const uint32_t below = jda_wave_excl_sum(mine, lane, all_mine, total);
-    const uint32_t base = half ? (below & 0xffffu) : (below >> 16);
-    // two lists in one array: the short-stage list grows up from 0, the full-stage list down from the end;
-    // columns a block does not have are written to a scratch word instead (no divergent branches)
-    int32_t slot = half ? (int32_t)base : (int32_t)(L::COLLIST_ENTRIES - 1u) - (int32_t)base;
-    const int32_t step = half ? 1 : -1;
-    uint16_t *scratch = (uint16_t *)&cnt[6];
+    // One array: the short-stage items, then the full-stage items.  A block's columns, lowest first, come out of a
+    // 16-entry table as 3-bit fields (low nibble, then high nibble + 4), and the block stores EIGHT items from its
+    // place on, whatever it has: what it stores past its own items lands on the places of blocks after it -- stored
+    // by a later instruction (the eight stores run from the last item to the first, and a later block's item at the
+    // same place has a smaller ordinal) -- or past the end of the list (unused entries, then at most 14 bytes of the
+    // row list, which is written below).  No condition per column.  A block without columns stores at the end.
+    const uint32_t n_half = total & 0xffffu, n_all = n_half + (total >> 16);
+    uint32_t base = half ? (below & 0xffffu) : n_half + (below >> 16);
+    if (ncols == 0) base = n_all;
+    const uint16_t *nib = (const uint16_t *)(tab + JDA_LT_NIB);
+    const uint32_t lo = colmask & 15u, hi = colmask >> 4;
+    const uint32_t plist = (uint32_t)nib[lo] | (((uint32_t)nib[hi] + 0x924u) << (3u * jda_popcount8(lo)));
+    uint16_t *dst = collist + base;
 #pragma unroll
-    for (uint32_t col = 0; col < 8; col++) {
-        const bool has = (colmask >> col) & 1u;
-        uint16_t *dst = has ? collist + slot : scratch;
-        *dst = (uint16_t)(qsel | (lane << 3) | col);
-        slot += has ? step : 0;
+    for (int k = 7; k >= 0; k--) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if ((uint32_t)k >= ncols) continue;          // (the emulator steps the lanes one after another: no overrun there)
+#endif
+        dst[k] = (uint16_t)(LP.item_pre | ((plist >> (3 * k)) & 7u));
+        JDA_STORE_ORDER();                           // the ORDER of the eight stores is what makes the overruns harmless
     }
     const uint32_t cls = !listed ? 4u : (flags == 0 ? 3u : ((flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u)));
     uint32_t n0, n1, n2, n3;
@@ -1462,7 +1490,7 @@ JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t
     uint8_t *rdst = listed ? rowlist + cbase + rank : (uint8_t *)&cnt[7];
     *rdst = (uint8_t)lane;
     if (lane == 0) {
-        cnt[0] = total & 0xffffu; cnt[1] = total >> 16;
+        cnt[0] = n_half; cnt[1] = total >> 16;
         cnt[2] = n0; cnt[3] = n1; cnt[4] = n2; cnt[5] = n3;
     }
 }
@@ -1497,7 +1525,7 @@ JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, const uint8_t *tab
     const uint32_t n_half = cnt[0], n_full = cnt[1];
     for (uint32_t i = t; i < n_half; i += JDA_TILE_THREADS) jda_p2_column_item<MODE, FAST, true>(D, collist[i], tab, wl);
     for (uint32_t i = t; i < n_full; i += JDA_TILE_THREADS)
-        jda_p2_column_item<MODE, FAST, false>(D, collist[(L::COLLIST_ENTRIES - 1u) - i], tab, wl);
+        jda_p2_column_item<MODE, FAST, false>(D, collist[n_half + i], tab, wl);
 }
 
 // ---- P3 ---------------------------------------------------------------------------------------

@@ -123,7 +123,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     jda_lane_pre LP;
     jda_lane_prepare<MODE>(LP, D, lane, tab);
     p1flags = jda_p1_entropy<MODE>(D, C, p1in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
-    if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, wl);
+    if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
     JDA_WAVE_SYNC();
     JDA_TRACE(4);
     if (D.scale_shift < 2 && !(D.pad_[0] & 2)) {
@@ -213,9 +213,11 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     typedef jda_lds_layout<MODE> L;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t per = (n_quads + gridDim.x - 1) / gridDim.x;
-    const uint32_t q0 = blockIdx.x * per;
-    const uint32_t q_end = q0 + per < n_quads ? q0 + per : n_quads;
+    // runs of n_quads / grid groups of tiles, the remainder one more each for the first workgroups (rounding the run length up
+    // instead left the last workgroups of a 64-image batch with half a run and none: 0.6 % of the kernel's time)
+    const uint32_t per = n_quads / gridDim.x, rem = n_quads % gridDim.x;
+    const uint32_t q0 = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
+    const uint32_t q_end = q0 + per + (blockIdx.x < rem ? 1u : 0u);
     if (q0 >= q_end) return;
     const uint32_t t_begin = q0 * (uint32_t)L::WAVES, t_end = q_end * (uint32_t)L::WAVES;   // this workgroup's run of tiles
     unsigned long long *wgtrace = g_jda_wgtrace;
@@ -296,7 +298,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // the arithmetic-dense IDCT fills the issue slots they leave (measured: 0.6-1 % over "oldest wave first")
         __builtin_amdgcn_s_setprio(3);
         const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
-        if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, wl);
+        if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
         __builtin_amdgcn_s_setprio(1);
         JDA_WAVE_SYNC();
         JDA_PTRACE(2);

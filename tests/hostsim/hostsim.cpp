@@ -41,7 +41,7 @@ static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles
         for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_lane_prepare<MODE>(LP[t], D, t, tab);
         for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) flags[t] = jda_p1_entropy<MODE>(D, C, in[t], LP[t], tab, wl, wl + L::WIN_OFF, g_window_bytes);
         if (D.scale_shift < 2) {
-            for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p1_lists<MODE>(D, LP[t], t, flags[t], flags, wl);
+            for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p1_lists<MODE>(D, LP[t], t, flags[t], flags, tab, wl);
             for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p2_columns<MODE, FAST>(D, t, tab, wl);
             for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p3_rows<MODE>(D, t, tab, wl);
         }
