@@ -67,21 +67,30 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
                                  //   block's padding, no flags.  j <= 63 + 15 + 64.
 #define JDA_ZZ_DUMP    128u
 #define JDA_LT_BYTES   6432
+#define JDA_LT_LONG    JDA_LT_BYTES   // 2 x 1024 uint16: the long halves of the AC LUTs (codes starting 111111), same entry layout -- staged
+#define JDA_LT_LONG_BYTES 4096        // only by the layouts that have the room (jda_lds_layout<MODE>::LONG_LDS); the others read the blob
 
 // AC LUT entry as the kernels keep it in LDS, made from the reference's (length << 8) | RS:
-//   length << 12 | S << 8 | Z,   Z = 2 (R + 64 nostore)  -- or 0xff for EOB and for "no such code" (raw 0: length 0)
+//   (length - 1) << 12 | S << 8 | Z,   Z = 2 (R + 64 nostore)  -- or 0xff for EOB, 0xfe for "no such code" (raw 0)
+// (a code has 1..16 bits: four bits hold length - 1)
 // nostore = a symbol with S == 0 that is not EOB (ZRL).  Z is the byte offset the symbol adds to the zigzag lookup
 // (2-byte entries): R + 64 steers it to the padding entry, so the store needs no condition (jpeg.inl:2246-2256:
 // "if (S && k < limit)"), and bits 4:1 of Z are still R for the position update.  One byte compare finds EOB.
 #define JDA_AC_EOB 0xffu
+#define JDA_AC_NONE 0xfeu
+#define JDA_AC_STOPS(e) (((e) & 0xfeu) == 0xfeu)      // EOB or no code: the block's symbols end here
 JDA_HD uint32_t jda_ac_entry(uint32_t raw)
 {
     const uint32_t rs = raw & 0xffu, len = raw >> 8;
-    if (rs == 0u) return (len << 12) | JDA_AC_EOB;
+    if (len == 0u) return JDA_AC_NONE;
+    if (rs == 0u) return ((len - 1u) << 12) | JDA_AC_EOB;
     const uint32_t r = rs >> 4, sz = rs & 0xfu;
-    return (len << 12) | (sz << 8) | ((r + (sz == 0u ? 64u : 0u)) << 1);
+    return ((len - 1u) << 12) | (sz << 8) | ((r + (sz == 0u ? 64u : 0u)) << 1);
 }
 
+#ifndef JDA_LONG_LDS_MODES
+#define JDA_LONG_LDS_MODES 0x1fu     // bit per JDA_MODE_*: the layouts that stage the long AC halves
+#endif
 template <int MODE> struct jda_lds_layout {       // the per-WAVE region
     enum {
         MCUS = JDA_TILE_THREADS / jda_mode_traits<MODE>::NBLK,       // MCUs per tile: 10 / 21 / 64
@@ -100,8 +109,14 @@ template <int MODE> struct jda_lds_layout {       // the per-WAVE region
         WAVE_BYTES = CNT_OFF + 32,                                  // 9,216 B (4:2:0)
         PLANE_OFF = COEF_OFF,
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE, // bytes between consecutive MCUs' samples
-        // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy
-        WAVES = (160 * 1024 - JDA_LT_BYTES) / WAVE_BYTES > 16 ? 16 : (160 * 1024 - JDA_LT_BYTES) / WAVE_BYTES
+        // Codes that start 111111 -- every code of 10 bits and more of the Annex K tables -- are looked up in the long halves of
+        // the AC LUTs.  They are some percent of the symbols, i.e. SOME lane of a wavefront meets one in most trips of the
+        // entropy loop: from the table blob in HBM that was a global load per trip, behind a wait that also drains the
+        // tile's output stores.  So the long halves are staged too
+        LONG_LDS = JDA_LONG_LDS_MODES >> MODE & 1,
+        TAB_BYTES = JDA_LT_BYTES + (LONG_LDS ? JDA_LT_LONG_BYTES : 0),
+        // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy (and the 16-byte draw counter)
+        WAVES = (160 * 1024 - TAB_BYTES - 16) / WAVE_BYTES > 16 ? 16 : (160 * 1024 - TAB_BYTES - 16) / WAVE_BYTES
     };
 };
 
@@ -382,6 +397,7 @@ struct jda_tables {
     const uint8_t *dc;        // LDS: 1024-byte DC LUT of this block's component
     const uint16_t *ac_short; // LDS: 1024 entries in the jda_ac_entry layout
     const uint16_t JDA_GLOBAL *ac_long;  // global: 1024 entries (codes starting 111111), the reference's layout
+    const uint16_t *ac_long_lds;         // LDS: the same in the jda_ac_entry layout (layouts with LONG_LDS)
     const uint16_t *zz;       // LDS: JDA_ZZ_ENTRIES entries (see JDA_LT_ZZ)
     uint32_t eob_sh, eob_code;   // the window-only reader finds EOB by comparing stream bits (jda_lane_pre)
 };
@@ -426,8 +442,8 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
         code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
         if (code >= 0xfc00u) e = jda_ac_entry(T.ac_long[code & 0x3ffu]);   // usHuffAC[1024 + ...]  :2232-2233
         else e = T.ac_short[code >> 6];
-        br.off += e >> 12;
-        if ((e & 0xffu) == JDA_AC_EOB) break;           // EOB (no refill follows)
+        if (JDA_AC_STOPS(e)) break;                     // EOB (no refill follows; the block's reader state is not needed any more)
+        br.off += (e >> 12) + 1u;
         k += (int)((e >> 1) & 0xfu);
         const uint32_t ms = (e >> 8) & 0xfu;
         if (k < LIMIT && ms) {
@@ -652,7 +668,7 @@ JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) 
 // EXACT = false leaves the reference's ulBitOff out (five instructions less per symbol): only right for a block in which the
 // reference truncates no magnitude read -- nothing in the index says so yet, so every caller passes true.
 // zero_fill: clear the block first.
-template <int LIMIT, bool EXACT>
+template <int LIMIT, bool EXACT, bool LONG_LDS>
 JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill,
                                      bool dc_only, uint32_t al)
 {
@@ -694,18 +710,29 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     // before the symbol is looked up: a block costs one trip per coefficient symbol, none for its EOB, and the wavefront
     // runs as many trips as its longest block needs.  (A block of a decoded MCU holds no invalid code: the pre-scan ends
     // the image at the first bad MCU.)
+    // A symbol's value is stored one trip later, while the next symbol's lookup is under way: the zigzag entry it needs was
+    // asked for a trip earlier and LDS answers in order, so the trip waits for LDS once, not twice.  (The first trip stores a
+    // zero to the block's padding.)
+    uint16_t t_prev = JDA_ZZ_DUMP;
+    int32_t v_prev = 0;
     w = jda_wr_peek(R);
     if ((w >> T.eob_sh) != T.eob_code) for (;;) {
         uint32_t li = w >> 22;
         JDA_OPAQUE(li);                                  // (keeps it a shift + a shift-add: the compiler's own form is shift, mask, add)
-        e = T.ac_short[li];
-        if (__builtin_expect(w >= 0xfc000000u, 0)) e = jda_ac_entry(T.ac_long[(w >> 16) & 0x3ffu]);     // rare: codes starting 111111
+        if (LONG_LDS) {
+            // codes starting 111111 (usHuffAC[1024 + ...], :2232-2233) sit in the second LDS table: one lookup, no branch
+            const uint16_t *ps = T.ac_short + li, *pl = T.ac_long_lds + ((w >> 16) & 0x3ffu);
+            e = *(w >= 0xfc000000u ? pl : ps);
+        } else e = T.ac_short[li];
+        fl |= t_prev;
+        *(int16_t *)((uint8_t *)coef + (t_prev & 0xffu)) = (int16_t)v_prev;
+        if (!LONG_LDS) { if (__builtin_expect(w >= 0xfc000000u, 0)) e = jda_ac_entry(T.ac_long[(w >> 16) & 0x3ffu]); }
         // the zigzag lookup decides where the value goes: position k + R of the block, or the padding when that is past
         // the block or the symbol carries no value (ZRL: the entry's low byte reads 2 (R + 64))
         const uint32_t kk2 = k2 + (e & 0xffu);
         uint32_t t = *(const uint16_t *)((const uint8_t *)T.zz + kk2);
         if (LIMIT != 64 && kk2 >= 2u * (uint32_t)LIMIT) t = JDA_ZZ_DUMP;     // 1/4 scale keeps zigzag 1..4 only (:2117-2119)
-        const uint32_t len = e >> 12, ms = (e >> 8) & 0xfu;
+        const uint32_t len = (e >> 12) + 1u, ms = (e >> 8) & 0xfu;
         uint32_t m = w << len;
         const uint32_t n = len + ms;
         if (EXACT) {
@@ -713,14 +740,15 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
             if (__builtin_expect(roff > 64u, 0)) m &= ~(0xffffffffu >> (64u + ms - roff));      // its window ended inside the magnitude
             roff = jda_ref_refill(roff);
         }
-        const int32_t v = jda_extend_top(m, ms);
-        fl |= t;
-        *(int16_t *)((uint8_t *)coef + (t & 0xffu)) = (int16_t)v;
+        v_prev = jda_extend_top(m, ms);
+        t_prev = (uint16_t)t;
         jda_wr_consume(R, n);
         k2 += (e & 0x1eu) + 2u;
         w = jda_wr_peek(R);
         if (k2 >= 2u * (uint32_t)LIMIT || (w >> T.eob_sh) == T.eob_code) break;
     }
+    fl |= t_prev;
+    *(int16_t *)((uint8_t *)coef + (t_prev & 0xffu)) = (int16_t)v_prev;
     // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested; fl holds 2n in 7:0
     return (fl >> 8) | ((fl & 0x40u) << 7);
 }
@@ -1130,11 +1158,11 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             uint32_t e;
             if (w >= 0xfc000000u) e = jda_ac_entry(ac_long_base[aci * 2048 + 1024 + ((w >> 16) & 0x3ffu)]);
             else e = ((const uint16_t *)(lt + JDA_LT_AC))[aci * 1024 + (w >> 22)];
-            if (e == JDA_AC_EOB) {                                  // no such code (length 0)  :2237-2238
+            if (e == JDA_AC_NONE) {                                 // no such code  :2237-2238
                 if (OP == JDA_SEG_SPEC) { p += 1; k = 0; continue; }
                 bad = true; break;
             }
-            const uint32_t len = e >> 12;
+            const uint32_t len = (e >> 12) + 1u;
             JDA_SG_ADVANCE(len);
             p += len;
             if ((e & 0xffu) == JDA_AC_EOB) { k = 0; b = b + 1u == P.nblocks ? 0u : b + 1u; }       // EOB: no refill follows
@@ -1256,9 +1284,10 @@ JDA_HD uint32_t jda_nibble_list(uint32_t m)
     return r;
 }
 // tables: once per workgroup (tid = thread in workgroup, nthreads = workgroup size)
-JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds);
-JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds) { jda_p0_tables_from(D.tables, tid, nthreads, tab_lds); }
-JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds)
+// with_long: also the long halves of the AC LUTs (JDA_LT_LONG; tab_lds then holds JDA_LT_BYTES + JDA_LT_LONG_BYTES)
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false);
+JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false) { jda_p0_tables_from(D.tables, tid, nthreads, tab_lds, with_long); }
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long)
 {
     const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, tables);
     jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
@@ -1271,6 +1300,14 @@ JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nth
             v = (n << 1) | ((1u << (n & 7u)) << 8);
         }
         ((uint16_t *)(tab_lds + JDA_LT_ZZ))[j] = (uint16_t)v;
+    }
+    if (with_long) {
+        for (uint32_t i = tid; i < JDA_LT_LONG_BYTES / 16; i += nthreads) {         // table i / 128, chunk i % 128 of its long half
+            jda_chunk16_alias c = blob[(JDA_TB_AC >> 4) + (i >> 7) * 256u + 128u + (i & 127u)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) c.w[k] = jda_ac_entry(c.w[k] & 0xffffu) | (jda_ac_entry(c.w[k] >> 16) << 16);
+            tab[(JDA_LT_LONG >> 4) + i] = c;
+        }
     }
     for (uint32_t i = tid; i < JDA_LT_ZZ / 16; i += nthreads) {
         uint32_t src;
@@ -1378,6 +1415,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     TB.dc = tab + LP.dc_off;
     TB.ac_short = (const uint16_t *)(tab + LP.ac_off);
     TB.ac_long = (const uint16_t JDA_GLOBAL *)(JDA_G(const uint8_t, D.tables) + LP.ac_long_off);
+    TB.ac_long_lds = (const uint16_t *)(tab + JDA_LT_LONG + (LP.ac_off - JDA_LT_AC));      // (AC table id x 2048 bytes in both)
     TB.zz = (const uint16_t *)(tab + JDA_LT_ZZ);
     TB.eob_sh = LP.eob_sh; TB.eob_code = LP.eob_code;
     const int16_t *quant = (const int16_t *)(tab + LP.quant_off);
@@ -1402,13 +1440,13 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     // wave-uniform: the whole slice is in LDS (and the tables allow the window-only reader's EOB test)
     const bool win_only = C.win_need <= br.win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
-        if (win_only) jda_decode_block_win<1, true>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al); }
+        if (win_only) jda_decode_block_win<1, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al); }
         *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
         return JDA_NO_LIST;
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
         uint32_t flags;
-        if (win_only) flags = jda_decode_block_win<5, true>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+        if (win_only) flags = jda_decode_block_win<5, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
         else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred, dc_only, al); }
         const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
                                        : jda_idct_2x2(coef, quant);
@@ -1416,7 +1454,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
         return JDA_NO_LIST;
     }
     uint32_t flags;
-    if (win_only) flags = jda_decode_block_win<64, true>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+    if (win_only) flags = jda_decode_block_win<64, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
     else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred, dc_only, al); }
     JDA_P1_TRACE(9);
     return flags;

@@ -111,10 +111,10 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
     C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
 
     uint8_t *tab = lds;
-    uint8_t *wl = lds + JDA_LT_BYTES + wave * L::WAVE_BYTES;
+    uint8_t *wl = lds + L::TAB_BYTES + wave * L::WAVE_BYTES;
     const jda_p1_inputs p1in = jda_p1_prefetch<MODE>(D, C, lane);   // in flight while LDS is staged
     JDA_TRACE(1);
-    jda_p0_tables(D, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
+    jda_p0_tables(D, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab, jda_lds_layout<MODE>::LONG_LDS != 0);
     jda_p0_stage<MODE>(D, C, lane, wl, L::WIN_BYTES);
     JDA_TRACE(2);
     __syncthreads();                                  // the only workgroup barrier: tables are in LDS
@@ -143,7 +143,7 @@ void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *_
 template <int MODE, bool FAST>
 static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    const int lds_bytes = JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES;
+    const int lds_bytes = jda_lds_layout<MODE>::TAB_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles<MODE, FAST>,
@@ -201,7 +201,7 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
 #define JDA_ADVANCE_TABLES(target, have, P, DP)                                                         \
     while (staged < (target)) {                                                                           \
         __syncthreads();                              /* nobody reads the old tables any more */          \
-        if ((have) && (P).first && (P).ord == staged + 1u) jda_p0_tables((DP), lane, 64u, tab);           \
+        if ((have) && (P).first && (P).ord == staged + 1u) jda_p0_tables((DP), lane, 64u, tab, L::LONG_LDS != 0);         \
         __syncthreads();                                                                                  \
         staged++;                                                                                         \
     }
@@ -223,8 +223,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     unsigned long long *wgtrace = g_jda_wgtrace;
     if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u] = wall_clock64();
     uint8_t *tab = lds;
-    uint8_t *wl = lds + JDA_LT_BYTES + wave * L::WAVE_BYTES;
-    uint32_t *ctr = (uint32_t *)(lds + JDA_LT_BYTES + L::WAVES * L::WAVE_BYTES);            // the run's draw counter
+    uint8_t *wl = lds + L::TAB_BYTES + wave * L::WAVE_BYTES;
+    uint32_t *ctr = (uint32_t *)(lds + L::TAB_BYTES + L::WAVES * L::WAVE_BYTES);            // the run's draw counter
 
     // ---- prologue: the tables of the run's first image, the counter
     if (threadIdx.x == 0) *ctr = t_begin;
@@ -232,7 +232,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     uint32_t staged = R0.ord;                                                            // image (ordinal) whose tables are in LDS
     const uint32_t last_ord = jda_load_record(tiles + (t_end - 1u)).ord;
     jda_dev_desc Dc = jda_desc_uniform<VARIANT>(descs + R0.image);
-    jda_p0_tables(Dc, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab);
+    jda_p0_tables(Dc, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab, L::LONG_LDS != 0);
     __syncthreads();                                  // tables staged, counter set
 
     uint32_t i_cur = jda_draw_tile<MODE>(ctr, lane);
@@ -369,8 +369,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 template <int MODE, bool FAST, int VARIANT>
 static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    const int lds_bytes = JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16;   // + the draw counter
-    static_assert(JDA_LT_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
+    const int lds_bytes = jda_lds_layout<MODE>::TAB_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16;   // + the draw counter
+    static_assert(jda_lds_layout<MODE>::TAB_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
     static int grid_cap = 0;
     if (!grid_cap) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT>,
