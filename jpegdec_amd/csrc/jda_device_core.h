@@ -528,11 +528,7 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
             const uint32_t c = b < P.nluma ? 0u : b - P.nluma + 1u;
             int32_t &pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
             if (pr < -32768 || pr > 32767) { bad = true; break; }
-            if (EXACT) {
-                const size_t gb = (size_t)(first_mcu + m) * P.nblocks + b;
-                blk_index[gb] = (br.pos << JDA_INDEX_OFF_BITS) | br.off;
-                blk_dc[gb] = (int16_t)pr;
-            }
+            const size_t gb = (size_t)(first_mcu + m) * P.nblocks + b;
             const uint32_t dci = c == 0 ? P.dc_id[0] : (c == 1 ? P.dc_id[1] : P.dc_id[2]);
             const uint32_t aci = c == 0 ? P.ac_id[0] : (c == 1 ? P.ac_id[1] : P.ac_id[2]);
             const uint32_t dc_off = JDA_TB_DC + dci * 1024, ac_off = JDA_TB_AC + aci * 4096;
@@ -540,6 +536,8 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
 #define JDA_PS_TAB16(o) (lds_tables ? (uint32_t)*(const uint16_t *)(lds_tables + (o)) : (uint32_t)*(const uint16_t JDA_GLOBAL *)(tables + (o)))
             JDA_PS_REFILL();
             if (bad) break;
+            uint32_t entry = (br.pos << JDA_INDEX_OFF_BITS) | br.off;      // the reader after the block's opening refill
+            if (EXACT) { blk_index[gb] = entry; blk_dc[gb] = (int16_t)pr; }
             uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
             code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
             uint32_t e = JDA_PS_TAB8(dc_off + code);
@@ -570,7 +568,10 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
                 if (e == 0) break;                               // EOB (no refill follows)
                 kk += (int)(e >> 4);
                 const uint32_t ms = e & 0xfu;
-                if (ms && kk < 64 && br.off + ms > 64) R.trunc_events++;
+                if (ms && kk < 64 && br.off + ms > 64) {
+                    R.trunc_events++;
+                    if (EXACT && !(entry & JDA_INDEX_TRUNC)) { entry |= JDA_INDEX_TRUNC; blk_index[gb] = entry; }
+                }
                 if (ms > R.max_ac_bits && kk < 64) R.max_ac_bits = ms;
                 JDA_PS_ADVANCE(ms);
                 kk++;
@@ -665,8 +666,8 @@ JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n)
 // the reference's refill (jpeg.inl:2110-2114) as far as its ulBitOff is concerned
 JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) : roff; }
 
-// EXACT = false leaves the reference's ulBitOff out (five instructions less per symbol): only right for a block in which the
-// reference truncates no magnitude read -- nothing in the index says so yet, so every caller passes true.
+// EXACT = false leaves the reference's ulBitOff out (five instructions and a branch less per symbol): only right for a block
+// in which the reference truncates no magnitude read, i.e. one whose index entry lacks JDA_INDEX_TRUNC.
 // zero_fill: clear the block first.
 template <int LIMIT, bool EXACT, bool LONG_LDS>
 JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill,
@@ -751,6 +752,17 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     *(int16_t *)((uint8_t *)coef + (t_prev & 0xffu)) = (int16_t)v_prev;
     // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested; fl holds 2n in 7:0
     return (fl >> 8) | ((fl & 0x40u) << 7);
+}
+
+// Does some lane of the wavefront (of those that are here) say yes?  The host emulator steps the lanes one after another:
+// there a lane answers for itself (the exact decoder is right for every block, the short one for every unflagged block).
+JDA_HD bool jda_wave_any(bool v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(v) != 0ull;
+#else
+    return v;
+#endif
 }
 
 // Multiplication by an IDCT constant.  FAST: both operands are known to fit in 24 signed bits (the
@@ -1055,6 +1067,14 @@ struct jda_segscan_params {          // one per image
 struct jda_seg_sum { uint32_t nblk; int32_t dcsum[3]; uint32_t phase_map, bad; };
 struct jda_seg_stats { uint32_t bad, terminal, max_ac_bits, max_abs_dc, trunc_events; };
 
+JDA_HD void jda_atomic_or_u32(uint32_t *p, uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p |= v;                                         // (the emulator steps the lanes one after another)
+#endif
+}
 // the next 32 bits of the stream at bit `bit` of the lane's slot (dword-aligned reads; big-endian bit order)
 JDA_HD uint32_t jda_seg_fetch(const uint8_t *slot, uint32_t bit)
 {
@@ -1071,7 +1091,7 @@ JDA_HD uint64_t jda_ph8_refill(uint64_t x)
     return (x & ~m) | (x & m & (0x07u * K));
 }
 
-// lt: the tables in the kernels' LDS layout (JDA_LT_*); slot: the segment's bytes (JDA_SEG_SLOT readable)
+// lt: the tables in the kernels' LDS layout (JDA_LT_*, long AC halves included); slot: the segment's bytes (JDA_SEG_SLOT readable)
 template <int OP>
 JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint8_t *slot, const uint8_t *lt,
                              jda_seg_sum &S, jda_seg_stats &ST)
@@ -1079,7 +1099,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
     uint32_t p = entry & 63u, b = (entry >> 6) & 7u, k = (entry >> 9) & 63u;
-    const uint16_t JDA_GLOBAL *ac_long_base = JDA_G(const uint16_t, P.tables + JDA_TB_AC);
+    const uint16_t *ac_long_lds = (const uint16_t *)(lt + JDA_LT_LONG);          // (lt holds the long halves too)
     const uint64_t K8 = 0x0101010101010101ull;
     // WRITE: the reference reader (pBuf, ulBitOff), the block ordinal and the DC predictors at the entry
     uint32_t pos = 0, off = 0, g = 0;
@@ -1109,12 +1129,14 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                 }
                 const int32_t pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
                 if (pr < -32768 || pr > 32767) { bad = true; break; }
-                JDA_G(uint32_t, P.blk_index)[g] = (pos << JDA_INDEX_OFF_BITS) | off;
                 JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
                 g++;
             }
             JDA_SG_REFILL();
             if (bad) break;
+            // the reader after the block's opening refill.  ORed into a zeroed index: the block's truncation flag may come from
+            // the lane of a later segment, before or after this
+            if (OP == JDA_SEG_WRITE) jda_atomic_or_u32(P.blk_index + (g - 1u), (pos << JDA_INDEX_OFF_BITS) | off);
             const uint32_t w = jda_seg_fetch(slot, p);
             uint32_t code = w >> 20;
             code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
@@ -1156,8 +1178,10 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             const uint32_t w = jda_seg_fetch(slot, p);
             const uint32_t aci = c == 0 ? P.ac_id[0] : (c == 1 ? P.ac_id[1] : P.ac_id[2]);
             uint32_t e;
-            if (w >= 0xfc000000u) e = jda_ac_entry(ac_long_base[aci * 2048 + 1024 + ((w >> 16) & 0x3ffu)]);
-            else e = ((const uint16_t *)(lt + JDA_LT_AC))[aci * 1024 + (w >> 22)];
+            {
+                const uint16_t *ps = (const uint16_t *)(lt + JDA_LT_AC) + aci * 1024 + (w >> 22), *pl = ac_long_lds + aci * 1024 + ((w >> 16) & 0x3ffu);
+                e = *(w >= 0xfc000000u ? pl : ps);                      // one lookup, no branch (codes starting 111111: the long half)
+            }
             if (e == JDA_AC_NONE) {                                 // no such code  :2237-2238
                 if (OP == JDA_SEG_SPEC) { p += 1; k = 0; continue; }
                 bad = true; break;
@@ -1169,7 +1193,10 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             else {
                 const uint32_t ms = (e >> 8) & 0xfu, kk = k + ((e >> 1) & 0xfu);
                 if (OP == JDA_SEG_WRITE) {
-                    if (ms && kk < 64 && off + ms > 64) ST.trunc_events++;
+                    if (ms && kk < 64 && off + ms > 64) {                        // flag the block (g - 1: it may have begun in an earlier segment)
+                        ST.trunc_events++;
+                        jda_atomic_or_u32(P.blk_index + (g - 1u), JDA_INDEX_TRUNC);
+                    }
                     if (ms > ST.max_ac_bits && kk < 64) ST.max_ac_bits = ms;
                 }
                 JDA_SG_ADVANCE(ms);
@@ -1429,7 +1456,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
     const uint32_t ix = in.ix;
     br.pos = ix >> JDA_INDEX_OFF_BITS;
-    br.off = ix & ((1u << JDA_INDEX_OFF_BITS) - 1u);
+    br.off = ix & (JDA_INDEX_TRUNC - 1u);
     const uint8_t *wbase = br.win - br.win_lo;
     int32_t pred = in.pred;
     const bool dc_only = (D.pad_[0] & JDA_DESC_DC_ONLY) != 0;     // wave-uniform (progressive thumbnail)
@@ -1454,7 +1481,12 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
         return JDA_NO_LIST;
     }
     uint32_t flags;
-    if (win_only) flags = jda_decode_block_win<64, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+    if (win_only) {
+        // the reference's ulBitOff is followed only in a tile that holds a block with a truncated magnitude read (the
+        // pre-scan flags those: a fraction of a percent of the blocks of a photograph, none of most synthetic images)
+        if (jda_wave_any((ix & JDA_INDEX_TRUNC) != 0u)) flags = jda_decode_block_win<64, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+        else flags = jda_decode_block_win<64, false, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+    }
     else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred, dc_only, al); }
     JDA_P1_TRACE(9);
     return flags;

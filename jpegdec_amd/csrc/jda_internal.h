@@ -19,7 +19,10 @@
 #define JDA_TABLE_BYTES  10832
 
 #define JDA_SCAN_PAD     32       // zero bytes after the filtered scan (window loads overrun)
-#define JDA_INDEX_OFF_BITS 7      // index entry = (byte position << 7) | bit offset (0..64)
+#define JDA_INDEX_OFF_BITS 7      // index entry = (byte position << 7) | flags/bit offset: the reference's bit reader AFTER the block's
+                                  // opening refill (jpeg.inl:2110-2114; bit offset 0..47 in bits 5:0), bit 6 = JDA_INDEX_TRUNC.  (The closing
+                                  // entry behind the last block is the reader as the last block left it: offset 0..64, no flag.)
+#define JDA_INDEX_TRUNC 0x40u     // the reference truncates a magnitude read of this block: P1 must follow its ulBitOff
 
 // kinds of MCU the kernels are specialised for
 enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2, JDA_MODE_422 = 3 /* h2v1, MCU 16x8 */, JDA_MODE_440 = 4 /* h1v2, MCU 8x16 */, JDA_N_MODES = 5 };

@@ -446,8 +446,8 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
     const uint32_t seg0 = (blockIdx.x * 4u + wave) * 64u, seg = seg0 + lane;
     if (blockIdx.x * 256u >= P.n_segs) return;                       // (uniform per workgroup: images of a batch differ in size)
     uint8_t *tab = lds;
-    uint8_t *slots = lds + JDA_LT_BYTES + wave * JDA_SEG_WAVE_LDS;
-    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab);
+    uint8_t *slots = lds + JDA_LT_BYTES + JDA_LT_LONG_BYTES + wave * JDA_SEG_WAVE_LDS;
+    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true);       // with the long halves of the AC LUTs (see jda_lds_layout)
     const bool in_range = seg < P.n_segs;
     // what this lane has to do
     uint32_t *e_cur = (round & 1u) ? P.entry_nxt : P.entry_cur, *e_nxt = (round & 1u) ? P.entry_cur : P.entry_nxt;
@@ -572,7 +572,7 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_LT_BYTES + 4 * JDA_SEG_WAVE_LDS;
+    const int lds_bytes = JDA_LT_BYTES + JDA_LT_LONG_BYTES + 4 * JDA_SEG_WAVE_LDS;          // 79,136 B: two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -406,6 +406,12 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         if (e == hipSuccess) e = jda_launch_segscan_sums(d_seg, ns, ctx->stream);      // first block ordinal, DC predictors, window lag per segment
         for (uint32_t p = 0; p < ns; p++) items[seg_owner[p]].dev_ok = settled;
         JDA_UP_MARK("sums");
+        // the write pass ORs its index entries into place (a block's truncation flag may come from the lane of a later segment
+        // than the one that holds the block's first bit): the index starts as zeros
+        for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
+            Item &it = items[seg_owner[p]];
+            e = hipMemsetAsync(it.d->base + it.d->off_index, 0, 4 * (it.n_blocks + 1), ctx->stream);
+        }
         if (e == hipSuccess) e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_WRITE, rounds, ctx->stream);
         for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
             Item &it = items[seg_owner[p]];

@@ -80,16 +80,16 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         // stream without restart markers (8f N2): what jda_upload_batch + jda_segscan do, lane by lane
         const jda_image_info *I = jda_image_get_info(img);
         const size_t nb = (size_t)I->mcus_x * I->mcus_y * I->blocks_per_mcu;
-        dev_index.assign(nb + 1, 0xdeadbeefu); dev_dc.assign(nb, 0x7777);
+        dev_index.assign(nb + 1, 0u); dev_dc.assign(nb, 0x7777);      // (the write pass ORs its entries into a zeroed index, as jda_upload_batch has it)
         uint32_t sl = 0, tb = 0;
         const uint8_t *scan = jda_image_scan(img, &sl);
         const uint8_t *tables = jda_image_tables(img, &tb);
         const uint32_t n_segs = sl / JDA_SEG_BYTES + 1u;
         std::vector<uint32_t> padded(((size_t)n_segs * JDA_SEG_BYTES + 16) / 4 + 1, 0);
         memcpy(padded.data(), scan, sl);
-        std::vector<uint64_t> lt_store((JDA_LT_BYTES + 7) / 8);
+        std::vector<uint64_t> lt_store((JDA_LT_BYTES + JDA_LT_LONG_BYTES + 7) / 8);
         uint8_t *lt = (uint8_t *)lt_store.data();
-        for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables_from(tables, tid, 256, lt);
+        for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables_from(tables, tid, 256, lt, true);
         std::vector<uint32_t> ea(n_segs + 1, 0), eb(n_segs + 1, 0), seg_sum((size_t)n_segs * 6), seg_start((size_t)n_segs * 5, 0);
         jda_segscan_params P;
         memset(&P, 0, sizeof(P));

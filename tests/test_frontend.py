@@ -34,10 +34,20 @@ def test_prepare_matches_oracle_stage_by_stage(name, oracle, product_lib):
     n, coefs, flags, state, dcp = oracle.entropy(jpeg, 0)
     idx, nok = p.block_index()
     assert nok == p.n_mcus and n == len(flags) == p.n_blocks
-    assert np.array_equal(idx[:-1] >> 7, oracle.blk_state[:, 0]) and np.array_equal(idx[:-1] & 127, oracle.blk_state[:, 1])
+    # (an entry holds the reader AFTER the block's opening refill, jpeg.inl:2110-2114: offsets above 47 are folded into the
+    # byte position; bit 6 flags a block with a truncated magnitude read)
+    def refilled(st):
+        pos, off = st[:, 0].astype(np.int64), st[:, 1].astype(np.int64)
+        big = off > 47
+        return np.where(big, pos + (off >> 3), pos), np.where(big, off & 7, off)
+    wpos, woff = refilled(oracle.blk_state)
+    assert np.array_equal(idx[:-1] >> 7, wpos) and np.array_equal(idx[:-1] & 63, woff)
     assert np.array_equal(p.block_dc().astype(np.int32), oracle.blk_pred)
     bpm = p.info.blocks_per_mcu                      # MCU starts are the first block of each MCU
-    assert np.array_equal(idx[:-1:bpm] >> 7, state[:, 0]) and np.array_equal(idx[:-1:bpm] & 127, state[:, 1])
+    mpos, moff = refilled(state)
+    assert np.array_equal(idx[:-1:bpm] >> 7, mpos) and np.array_equal(idx[:-1:bpm] & 63, moff)
+    n_flagged = int(np.count_nonzero(idx[:-1] & 64))
+    assert n_flagged <= p.truncation_events() and (n_flagged > 0) == (p.truncation_events() > 0)
     p.close()
 
 
