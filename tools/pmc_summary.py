@@ -31,8 +31,8 @@ def main():
     w_kb = sum(write) / len(write)
     out = {
         "command": "tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes, no trace domains) "
-                   "--output-format csv -- python bench.py --steps 10 --warmup 2 --no-parity --no-cpu-baseline",
-        "kernel": "jda_decode_tiles_persistent<2,true>",
+                   "--output-format csv -- python bench.py --steps 10 --warmup 2 --ramp-ms 0 --no-parity --no-cpu-baseline",
+        "kernel": "jda_decode_tiles_persistent<2,true,1>",
         "launches_sampled": len(fetch),
         "images_per_launch": batch,
         "workload": bench["config"]["workload"],
