@@ -191,8 +191,9 @@ uint32_t jda_dev_image_mcus_ok(const jda_dev_image *dimg);        /* MCUs the pr
 int jda_last_prescan_rounds(const jda_ctx *ctx);
 /* The marker / byte-stuffing filter (JPEGFilter, jpeg.inl:1431-1540) run on the GPU over a host buffer, result back on the
  * host: out must hold len bytes; *out_len = filtered length; restart_pos[0] = 0 and restart_pos[k] = filtered offset at
- * which the k-th RSTn marker stood (first restart_cap entries), *n_restarts = markers seen.  What jda_upload_batch uses for
- * images prepared with JDA_PREPARE_DEVICE_FILTER; exposed for callers that want the filtered scan, and for the tests. */
+ * which the k-th RSTn marker stood (first restart_cap entries), *n_restarts = markers seen.  A stand-alone entry point
+ * (jda_upload_batch still takes the scan filtered by jda_prepare on the host); exposed for callers that want the filtered
+ * scan made on the GPU, and for the tests. */
 int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t *out, int32_t *out_len,
                          uint32_t *restart_pos, int32_t restart_cap, int32_t *n_restarts);   /* speculative rounds of the last marker-less device pre-scan (diagnostics) */
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg);
