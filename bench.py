@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--subsampling", default="4:2:0", choices=["4:2:0", "4:4:4", "4:2:2", "gray"])
     ap.add_argument("--pixel-type", default="rgb8888", choices=["rgb8888", "rgb565", "gray8"])
     ap.add_argument("--options", type=int, default=0)
+    ap.add_argument("--quality", type=int, default=85, help="JPEG quality of the synthetic inputs (85 = the headline config, SURVEY 8d)")
     ap.add_argument("--restart-rows", type=int, default=0, help="encode the inputs with a restart marker every N MCU rows (0 = none, the headline config)")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed decode launches before the warm-up steps until the GPU clocks have ramped (0: none)")
     ap.add_argument("--device-prescan", action="store_true", help="JDA_PREPARE_DEVICE_PRESCAN: the block index is made on the GPU at upload (restart intervals, or the self-synchronising segment walk)")
@@ -113,7 +114,7 @@ def main():
         pt = J.GRAY8   # JPEGPutMCUGray never writes 32-bit pixels
 
     # ---- inputs: `distinct` synthetic JPEGs, prepared on the host, `batch` resident copies in HBM
-    jpegs = [cached_jpeg(args.width, args.height, args.subsampling, 1234 + i, restart_rows=args.restart_rows) for i in range(args.distinct)]
+    jpegs = [cached_jpeg(args.width, args.height, args.subsampling, 1234 + i, quality=args.quality, restart_rows=args.restart_rows) for i in range(args.distinct)]
     bits_px = 8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * args.width * args.height)
     n_dev = max(1, J.load_library().jda_device_count())
     ctx = J.Context(local_rank % n_dev)     # one process per GPU; raises without a GPU: there is no CPU fallback
