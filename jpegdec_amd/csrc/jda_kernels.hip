@@ -57,9 +57,10 @@ template <typename P> __device__ __forceinline__ P jda_uni_ptr(P p)
     const uint64_t v = (uint64_t)p;
     return (P)(((uint64_t)jda_uni32((uint32_t)(v >> 32)) << 32) | jda_uni32((uint32_t)v));
 }
-// VARIANT 1 (the plain case: full size, RGB8888, every block decoded, 24-bit multiplies -- the host puts only such images
-// in that launch list): these fields are constants, and everything that tests them folds away (1837 -> 1775 VALU per tile)
-template <int VARIANT = 0>
+// VARIANT 1 / 2 / 3 (the plain cases: full size, 24-bit multiplies, output RGB8888 / RGB565 little endian / 8-bit gray -- of a
+// colour file: luma only, its chroma blocks never decoded --; the host puts only such images in those launch lists): these
+// fields are constants, and everything that tests them folds away (1837 -> 1775 VALU per tile for RGB8888)
+template <int VARIANT = 0, int MODE = JDA_MODE_420>
 __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
 {
     const jda_dev_desc JDA_GLOBAL *g = JDA_G(const jda_dev_desc, p);
@@ -71,7 +72,11 @@ __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
     L.scan_len = jda_uni32(g->scan_len);
 #pragma unroll
     for (int i = 0; i < 4; i++) L.cfg[i] = jda_uni32(g->cfg[i]);      // mode .. pad_: sixteen byte fields in four SGPRs
-    if (VARIANT == 1) { L.scale_shift = 0; L.gray_from_color = 0; L.pad_[0] = 0; L.pixel_type = JDA_RGB8888; }
+    if (VARIANT >= 1) {
+        L.scale_shift = 0; L.pad_[0] = 0;
+        L.pixel_type = VARIANT == 1 ? JDA_RGB8888 : (VARIANT == 2 ? JDA_RGB565_LITTLE_ENDIAN : JDA_EIGHT_BIT_GRAYSCALE);
+        L.gray_from_color = (VARIANT == 3 && MODE != JDA_MODE_GRAY) ? 1 : 0;
+    }
     return L;
 }
 
@@ -206,6 +211,9 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
         staged++;                                                                                         \
     }
 
+#ifndef JDA_EXP_SKIP
+#define JDA_EXP_SKIP 0       // profiling builds (tools/gpu_phase_counts.sh): 1 no P4, 2 no P3, 4 no P2, 8 no lists, 16 no P1
+#endif
 template <int MODE, bool FAST, int VARIANT>
 __global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
 void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads)
@@ -231,7 +239,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     const jda_strip R0 = jda_load_record(tiles + t_begin);
     uint32_t staged = R0.ord;                                                            // image (ordinal) whose tables are in LDS
     const uint32_t last_ord = jda_load_record(tiles + (t_end - 1u)).ord;
-    jda_dev_desc Dc = jda_desc_uniform<VARIANT>(descs + R0.image);
+    jda_dev_desc Dc = jda_desc_uniform<VARIANT, MODE>(descs + R0.image);
     jda_p0_tables(Dc, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab, L::LONG_LDS != 0);
     __syncthreads();                                  // tables staged, counter set
 
@@ -243,7 +251,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     }
     uint32_t i_nxt = jda_draw_tile<MODE>(ctr, lane);
     jda_strip S = jda_load_record(tiles + i_cur);
-    if (S.image != R0.image) Dc = jda_desc_uniform<VARIANT>(descs + S.image);
+    if (S.image != R0.image) Dc = jda_desc_uniform<VARIANT, MODE>(descs + S.image);
     jda_p1_inputs in;
     jda_tile_ctx C;
     // everything a tile needs before its P1, fetched with nothing to overlap it (first tile of a wavefront, first
@@ -297,8 +305,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // wave priorities: the phase that is a dependent chain (P1) and the one that feeds the memory pipe (P4) go first,
         // the arithmetic-dense IDCT fills the issue slots they leave (measured: 0.6-1 % over "oldest wave first")
         __builtin_amdgcn_s_setprio(3);
-        const uint32_t p1flags = jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
-        if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
+        const uint32_t p1flags = (JDA_EXP_SKIP & 16) ? 0u : jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
+        if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 8)) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
         __builtin_amdgcn_s_setprio(1);
         JDA_WAVE_SYNC();
         JDA_PTRACE(2);
@@ -321,7 +329,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         }
 
         JDA_PTRACE(3);
-        if (D.scale_shift < 2) {
+        if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 4)) {
             jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
             JDA_WAVE_SYNC();
         }
@@ -334,7 +342,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         if (pipelined) jda_window_store(wl + L::WIN_OFF, Cn.win_len, lane, chunk);
 
         JDA_PTRACE(5);
-        if (D.scale_shift < 2) {
+        if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 2)) {
             jda_p3_rows<MODE>(D, lane, tab, wl);
             JDA_WAVE_SYNC();
         }
@@ -342,7 +350,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;      // list counters reset for the next tile
 
         __builtin_amdgcn_s_setprio(3);
-        jda_p4_output<MODE>(D, S, C, lane, wl, P4);
+        if (!(JDA_EXP_SKIP & 1)) jda_p4_output<MODE>(D, S, C, lane, wl, P4);
         JDA_PTRACE(7);
 #ifdef JDA_PHASE_TRACE
         iter++;
@@ -352,7 +360,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         Sn = jda_unpack_record(r0, r1, r2, r3);
         if (pipelined) { C = Cn; in = inn; }
         else {                                        // image boundary: every wavefront of the workgroup passes here once
-            Dc = jda_desc_uniform<VARIANT>(descs + S.image);
+            Dc = jda_desc_uniform<VARIANT, MODE>(descs + S.image);
             JDA_ADVANCE_TABLES(S.ord, true, S, Dc);
             JDA_WAVE_SYNC();
             JDA_TILE_COLD_START();
@@ -722,12 +730,16 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, con
         default: return hipErrorInvalidValue;
         }
     }
-    if (variant == 1 && fast_mul) {                   // the plain-case kernels (colour layouts; everything else runs the general one)
-        switch (mode) {
-        case JDA_MODE_444: return launch_persistent<JDA_MODE_444, true, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420: return launch_persistent<JDA_MODE_420, true, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_422: return launch_persistent<JDA_MODE_422, true, 1>(descs, tiles, n_tiles, stream);
-        default: break;
+    if (variant >= 1 && fast_mul) {                   // the plain-case kernels (jda_plain_variant decides who gets here)
+        switch (mode * 4 + variant) {
+        case JDA_MODE_444 * 4 + 1: return launch_persistent<JDA_MODE_444, true, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 1: return launch_persistent<JDA_MODE_420, true, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_422 * 4 + 1: return launch_persistent<JDA_MODE_422, true, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_444 * 4 + 2: return launch_persistent<JDA_MODE_444, true, 2>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 2: return launch_persistent<JDA_MODE_420, true, 2>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 3: return launch_persistent<JDA_MODE_420, true, 3>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_GRAY * 4 + 3: return launch_persistent<JDA_MODE_GRAY, true, 3>(descs, tiles, n_tiles, stream);
+        default: return hipErrorInvalidValue;
         }
     }
     switch (mode * 2 + (fast_mul ? 1 : 0)) {

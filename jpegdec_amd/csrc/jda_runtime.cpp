@@ -32,8 +32,19 @@ extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
-// launch lists of a batch: one per (mode, fast_mul, kernel variant); index = (mode * 2 + fast) * 2 + variant
-#define JDA_N_LISTS (4 * JDA_N_MODES)
+// launch lists of a batch: one per (mode, fast_mul, kernel variant); index = (mode * 2 + fast) * 4 + variant
+#define JDA_N_LISTS (8 * JDA_N_MODES)
+// The plain-case kernel variants (jda_desc_uniform in jda_kernels.hip): full size, every multiply in 24 bits, no stream flags,
+// and one of the (layout, output format) pairs a kernel was built for.  0 = the general kernel.
+static int jda_plain_variant(const jda_dev_desc &D)
+{
+    if (D.scale_shift != 0 || D.pad_[0] != 0 || !D.fast_mul) return 0;
+    const bool colour = D.mode != JDA_MODE_GRAY;
+    if (D.pixel_type == JDA_RGB8888 && !D.gray_from_color) return (D.mode == JDA_MODE_444 || D.mode == JDA_MODE_420 || D.mode == JDA_MODE_422) ? 1 : 0;
+    if (D.pixel_type == JDA_RGB565_LITTLE_ENDIAN && colour && !D.gray_from_color) return (D.mode == JDA_MODE_444 || D.mode == JDA_MODE_420) ? 2 : 0;
+    if (D.pixel_type == JDA_EIGHT_BIT_GRAYSCALE) return (D.mode == JDA_MODE_GRAY || (D.mode == JDA_MODE_420 && D.gray_from_color)) ? 3 : 0;
+    return 0;
+}
 
 struct jda_ctx {
     int device;
@@ -589,8 +600,8 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         }
         // kernel variant 1: the plain case -- full size, RGB8888, every block decoded -- runs a kernel in which these
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
-        const int variant = (D.scale_shift == 0 && D.pixel_type == JDA_RGB8888 && !D.gray_from_color && D.pad_[0] == 0 && D.fast_mul) ? 1 : 0;
-        jda_append_strips(strips[(D.mode * 2 + (D.fast_mul ? 1 : 0)) * 2 + variant], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode);
+        const int variant = jda_plain_variant(D);
+        jda_append_strips(strips[(D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode);
         st.source_pixels += (int64_t)I.width * I.height;
         st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
         st.scan_bytes += im->scan_len;
@@ -610,7 +621,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 4));
+        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 8));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -639,7 +650,7 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
     if (!b) return JDA_INVALID_PARAMETER;
     for (int m = 0; m < JDA_N_LISTS; m++) {
         if (!b->n_strips[m]) continue;
-        JDA_HIP(ctx, jda_launch_decode(m >> 2, (m >> 1) & 1, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
+        JDA_HIP(ctx, jda_launch_decode(m >> 3, (m >> 2) & 1, m & 3, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
     }
     return JDA_SUCCESS;
 }
