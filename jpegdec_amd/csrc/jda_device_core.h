@@ -2022,6 +2022,42 @@ JDA_HD void jda_p4_gray8_full(const jda_dev_desc &D, uint32_t t, const uint8_t *
     }
 }
 
+// half-size 8-bit gray output of any source layout (JPEGPutMCU8BitGray half-size bodies, jpeg.inl:2812-2827, :2857-2873,
+// :2907-2923, :2979-2999): a pixel = (the 2x2 luma samples' sum + 2) >> 2.  A work item is one output row of one luma block:
+// two source rows (16 bytes) -> 4 pixels, the sums two at a time in the halves of a word; items are dealt row-major so
+// that consecutive lanes store consecutive dwords.
+JDA_HD uint32_t jda_pair_sums(uint32_t v) { return (v & 0x00ff00ffu) + ((v >> 8) & 0x00ff00ffu); }       // [b0 + b1, b2 + b3] as 16-bit halves
+template <int MODE, bool CLIP>
+JDA_HD void jda_p4_gray8_half(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                              uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t nbx = (uint32_t)T::MCU_W / 8u;                 // luma blocks across an MCU: 1 or 2
+    const uint32_t chunks = tile_w >> 2;                          // 4-pixel chunks per output row of the tile (tile_w: output pixels)
+    const uint32_t inv = jda_recip22(chunks);
+    uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
+    const uint32_t pitch = D.out_pitch;
+    const uint32_t tile_off = y_base * pitch + x_base;
+    for (uint32_t i = t; i < chunks * ((uint32_t)T::MCU_H >> 1); i += JDA_TILE_THREADS) {
+        const uint32_t r = jda_umul24(i, inv) >> 22, c = i - jda_umul24(r, chunks);
+        const uint32_t m = nbx == 2 ? (c >> 1) : c, bxq = nbx == 2 ? (c & 1u) : 0u;
+        const uint32_t q = (r >> 2) * nbx + bxq;                  // luma block inside the MCU
+        const jda_u32_alias *src = (const jda_u32_alias *)(plane_base + jda_umul24(m, plane_stride) + q * JDA_COEF_STRIDE + (r & 3u) * 16);
+        const uint32_t s01 = jda_pair_sums(src[0]) + jda_pair_sums(src[2]) + 0x00020002u;       // pixels 0, 1: two rows' pair sums + 2
+        const uint32_t s23 = jda_pair_sums(src[1]) + jda_pair_sums(src[3]) + 0x00020002u;       // pixels 2, 3
+        const uint32_t v = jda_perm(s23 >> 2, s01 >> 2, 0x06040200u);                          // (sums <= 1022: the shifted halves are the bytes)
+        const uint32_t X = x_base + c * 4, Y = y_base + r;
+        if (!CLIP) *(jda_u32_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + c * 4) = v;
+        else {
+            if (Y >= D.out_rows || X >= D.out_w) continue;
+            uint8_t JDA_GLOBAL *row = out + (size_t)Y * pitch;
+            const uint32_t n = X + 4 <= D.out_w ? 4u : D.out_w - X;
+            if (n == 4) *(jda_u32_alias JDA_GLOBAL *)(row + X) = v;
+            else for (uint32_t j = 0; j < n; j++) row[X + j] = (uint8_t)(v >> (8 * j));
+        }
+    }
+}
+
 // pixel type and clipping are decided once per tile (uniform), so the item loops are branch-free
 template <int MODE, bool CLIP>
 JDA_HD void jda_p4_full_colour(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
@@ -2112,6 +2148,10 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;
         if (inside) jda_p4_gray8_full<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_gray8_full<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    } else if (shift == 1 && !colour_out) {                       // 8-bit gray, half size: 2x2 luma sums
+        const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows && (x_base & 3u) == 0;
+        if (inside) jda_p4_gray8_half<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        else jda_p4_gray8_half<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
     } else
         jda_p4_generic<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
