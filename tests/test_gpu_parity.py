@@ -62,9 +62,14 @@ def test_matches_real_reference_when_present(gpu_ctx, ref_scalar):
 
 def test_batch_of_mixed_images_resident(gpu_ctx, oracle):
     """One launch plan over several resident images of different shapes and output formats."""
-    names = ["c420_333x217", "c444_333x217", "gray_333x217", "c420_1100x48", "c420_640x368_rstrow"]
-    pts = [J.RGB8888, J.RGB565_LE, J.GRAY8, J.RGB8888, J.RGB565_BE]
-    opts = [0, J.SCALE_HALF, 0, J.SCALE_QUARTER, 0]
+    # (every kernel variant the runtime routes to gets at least one image: the general kernel and the plain-case ones for
+    # RGB8888 / RGB565 / 8-bit gray, several launch lists per decode)
+    names = ["c420_333x217", "c444_333x217", "gray_333x217", "c420_1100x48", "c420_640x368_rstrow",
+             "c420_333x217", "c420_1280x720", "c444_333x217", "gray_1100x24", "c444_600x16", "c422_333x217", "c420_1100x48", "c440_200x120"]
+    pts = [J.RGB8888, J.RGB565_LE, J.GRAY8, J.RGB8888, J.RGB565_BE,
+           J.RGB565_LE, J.GRAY8, J.RGB565_LE, J.GRAY8, J.RGB8888, J.RGB8888, J.GRAY8, J.GRAY8]
+    opts = [0, J.SCALE_HALF, 0, J.SCALE_QUARTER, 0,
+            0, 0, 0, 0, 0, 0, J.SCALE_HALF, J.SCALE_HALF]
     prepared = [J.PreparedImage(jpeg_for(n)) for n in names]
     dev = [J.DeviceImage(gpu_ctx, p) for p in prepared]
     outs, ptrs, geos = [], [], []
