@@ -1810,8 +1810,11 @@ JDA_HD uint32_t jda_565_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t 
 // pixels = exactly five passes of the wavefront): item i = lane + 64 * pass always lands on the same LDS offsets and
 // on the same offset from the tile's first output pixel, so the index arithmetic (a third of the stage's VALU work)
 // is done once per image and kept in registers.  Only the output offset depends on the image (pitch, pixel size).
+// The same for a FULL 4:4:4 tile (21 MCUs = 168 x 8 pixels = 336 items of 4 pixels of one row = five passes and a quarter):
+// yo = the luma bytes (Cb, Cr one and two block slots further), rel as above; co is not used.
 #define JDA_P4_PASSES 5
-struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES], co[JDA_P4_PASSES], rel[JDA_P4_PASSES]; };
+#define JDA_P4_PASSES_444 6
+struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES_444], co[JDA_P4_PASSES], rel[JDA_P4_PASSES_444]; };
 JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, uint32_t pitch, uint32_t bpp)
 {
 #pragma unroll
@@ -1822,6 +1825,18 @@ JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, 
         P.co[it] = po + 4 * JDA_COEF_STRIDE + rp * 8 + (g & 3u) * 2;
         P.rel[it] = rp * 2u * pitch + g * 4u * bpp;
     }
+}
+
+JDA_HD void jda_p4_precompute_444(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, uint32_t pitch, uint32_t bpp)
+{
+#pragma unroll
+    for (int it = 0; it < JDA_P4_PASSES_444; it++) {
+        const uint32_t i = t + 64u * (uint32_t)it, r = i / 42u, x4 = (i - r * 42u) * 4u;    // 42 groups of 4 pixels per row
+        P.yo[it] = (x4 >> 3) * plane_stride + r * 8u + (x4 & 7u);
+        P.rel[it] = r * pitch + x4 * bpp;
+    }
+#pragma unroll
+    for (int it = 0; it < JDA_P4_PASSES; it++) P.co[it] = 0;
 }
 
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
@@ -1948,6 +1963,36 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
                 v[j] = jda_rgb_pixel<PT>((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u));
         }
         jda_store4<PT, CLIP>(out + (size_t)Y * D.out_pitch, X, D.out_w, v);
+    }
+}
+
+// a full, unclipped 4:4:4 tile: six passes with the precomputed item addresses (the last one a quarter full)
+template <int PT>
+JDA_HD void jda_p4_444_full21(const jda_dev_desc &D, const jda_p4_pre &P, uint32_t t, const uint8_t *plane_base, uint32_t x_base, uint32_t y_base)
+{
+    const uint32_t bpp = PT == JDA_RGB8888 ? 4u : 2u;
+    uint8_t JDA_GLOBAL *tile = JDA_G(uint8_t, D.out) + (y_base * D.out_pitch + x_base * bpp);      // uniform
+#pragma unroll
+    for (int it = 0; it < JDA_P4_PASSES_444; it++) {
+        if (it == JDA_P4_PASSES_444 - 1 && t >= 336u - 64u * (JDA_P4_PASSES_444 - 1)) break;
+        const uint8_t *Pp = plane_base + P.yo[it];
+        const uint32_t y = *(const jda_u32_alias *)Pp, cb = *(const jda_u32_alias *)(Pp + JDA_COEF_STRIDE), cr = *(const jda_u32_alias *)(Pp + 2 * JDA_COEF_STRIDE);
+        uint32_t v[4];
+        if (PT == JDA_RGB8888) {
+            jda_chroma2 c[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms16((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
+            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
+            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
+            jda_chunk16_alias q;
+            q.w[0] = v[0]; q.w[1] = v[1]; q.w[2] = v[2]; q.w[3] = v[3];
+            *(jda_chunk16_alias JDA_GLOBAL *)(tile + P.rel[it]) = q;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                v[j] = jda_rgb_pixel<PT>((y >> (8 * j)) & 255u, jda_chroma_terms((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u));
+            *(jda_u64_alias JDA_GLOBAL *)(tile + P.rel[it]) = (uint64_t)(v[0] | (v[1] << 16)) | ((uint64_t)(v[2] | (v[3] << 16)) << 32);
+        }
     }
 }
 
@@ -2115,6 +2160,7 @@ JDA_HD void jda_p4_prepare(jda_p4_pre &P, const jda_dev_desc &D, uint32_t t)
 {
     typedef jda_lds_layout<MODE> L;
     if (MODE == JDA_MODE_420) jda_p4_precompute(P, t, L::PLANE_STRIDE, D.out_pitch, D.pixel_type == JDA_RGB8888 ? 4u : 2u);
+    else if (MODE == JDA_MODE_444) jda_p4_precompute_444(P, t, L::PLANE_STRIDE, D.out_pitch, D.pixel_type == JDA_RGB8888 ? 4u : 2u);
     else {
 #pragma unroll
         for (int it = 0; it < JDA_P4_PASSES; it++) P.yo[it] = P.co[it] = P.rel[it] = 0;
@@ -2140,6 +2186,13 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
             if (pt == JDA_RGB8888) jda_p4_420_full10<JDA_RGB8888>(D, P, plane_base, x_base, y_base);
             else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_420_full10<JDA_RGB565_LITTLE_ENDIAN>(D, P, plane_base, x_base, y_base);
             else jda_p4_420_full10<JDA_RGB565_BIG_ENDIAN>(D, P, plane_base, x_base, y_base);
+            return;
+        }
+        if (MODE == JDA_MODE_444 && inside && C.count == (uint32_t)L::MCUS) {          // a full 4:4:4 tile
+            const int pt = D.pixel_type;
+            if (pt == JDA_RGB8888) jda_p4_444_full21<JDA_RGB8888>(D, P, t, plane_base, x_base, y_base);
+            else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_444_full21<JDA_RGB565_LITTLE_ENDIAN>(D, P, t, plane_base, x_base, y_base);
+            else jda_p4_444_full21<JDA_RGB565_BIG_ENDIAN>(D, P, t, plane_base, x_base, y_base);
             return;
         }
         if (inside) jda_p4_full_colour<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
