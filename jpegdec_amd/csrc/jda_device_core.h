@@ -2047,6 +2047,14 @@ JDA_HD void jda_p4_gray8_full(const jda_dev_desc &D, uint32_t t, const uint8_t *
     uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
     const uint32_t pitch = D.out_pitch;
     const uint32_t tile_off = y_base * pitch + x_base;
+    if (MODE == JDA_MODE_GRAY && !CLIP && chunks == JDA_TILE_THREADS) {      // a full tile of a gray file: pass = row, lane = block
+        const jda_u32_alias *src = (const jda_u32_alias *)(plane_base + jda_umul24(t, plane_stride));
+        uint8_t JDA_GLOBAL *dst = out + tile_off + t * 8u;
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++)
+            *(jda_u64_alias JDA_GLOBAL *)(dst + jda_umul24(r, pitch)) = (uint64_t)src[2 * r] | ((uint64_t)src[2 * r + 1] << 32);
+        return;
+    }
     for (uint32_t i = t; i < chunks * (uint32_t)T::MCU_H; i += JDA_TILE_THREADS) {
         const uint32_t r = jda_umul24(i, inv) >> 22, c = i - jda_umul24(r, chunks);
         const uint32_t m = nbx == 2 ? (c >> 1) : c, bxq = nbx == 2 ? (c & 1u) : 0u;
@@ -2083,6 +2091,17 @@ JDA_HD void jda_p4_gray8_half(const jda_dev_desc &D, uint32_t t, const uint8_t *
     uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
     const uint32_t pitch = D.out_pitch;
     const uint32_t tile_off = y_base * pitch + x_base;
+    if (MODE == JDA_MODE_GRAY && !CLIP && chunks == JDA_TILE_THREADS) {      // a full tile of a gray file: pass = output row, lane = block
+        const jda_u32_alias *src = (const jda_u32_alias *)(plane_base + jda_umul24(t, plane_stride));
+        uint8_t JDA_GLOBAL *dst = out + tile_off + t * 4u;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint32_t s01 = jda_pair_sums(src[4 * r]) + jda_pair_sums(src[4 * r + 2]) + 0x00020002u;
+            const uint32_t s23 = jda_pair_sums(src[4 * r + 1]) + jda_pair_sums(src[4 * r + 3]) + 0x00020002u;
+            *(jda_u32_alias JDA_GLOBAL *)(dst + jda_umul24(r, pitch)) = jda_perm(s23 >> 2, s01 >> 2, 0x06040200u);
+        }
+        return;
+    }
     for (uint32_t i = t; i < chunks * ((uint32_t)T::MCU_H >> 1); i += JDA_TILE_THREADS) {
         const uint32_t r = jda_umul24(i, inv) >> 22, c = i - jda_umul24(r, chunks);
         const uint32_t m = nbx == 2 ? (c >> 1) : c, bxq = nbx == 2 ? (c & 1u) : 0u;
