@@ -212,7 +212,7 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
     }
 
 #ifndef JDA_EXP_SKIP
-#define JDA_EXP_SKIP 0       // profiling builds (tools/gpu_phase_counts.sh): 1 no P4, 2 no P3, 4 no P2, 8 no lists, 16 no P1
+#define JDA_EXP_SKIP 0       // profiling builds (tools/phase_count_libs.sh): 1 no P4, 2 no P3, 4 no P2, 8 no lists, 16 no P1
 #endif
 template <int MODE, bool FAST, int VARIANT>
 __global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
