@@ -2224,6 +2224,17 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows && (x_base & 3u) == 0;
         if (inside) jda_p4_gray8_half<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_gray8_half<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    } else if (MODE == JDA_MODE_GRAY && shift >= 2 && !colour_out && C.count == (uint32_t)L::MCUS &&
+               x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows) {
+        // 8-bit gray thumbnails of a gray file (1/4: the block's 2x2 samples, 1/8: its one), a full unclipped tile: lane = block,
+        // the 64 lanes of one store instruction cover one contiguous piece of an output row
+        const uint8_t *blk = plane_base + jda_umul24(t, (uint32_t)L::PLANE_STRIDE);
+        uint8_t JDA_GLOBAL *o = JDA_G(uint8_t, D.out) + (y_base * D.out_pitch + x_base);
+        if (shift == 3) o[t] = blk[0];
+        else {
+            *(uint16_t JDA_GLOBAL *)(o + 2u * t) = *(const uint16_t *)blk;
+            *(uint16_t JDA_GLOBAL *)(o + D.out_pitch + 2u * t) = *(const uint16_t *)(blk + 2);
+        }
     } else
         jda_p4_generic<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
