@@ -2122,6 +2122,73 @@ JDA_HD void jda_p4_gray8_half(const jda_dev_desc &D, uint32_t t, const uint8_t *
     }
 }
 
+// Half-size RGB8888 output of 4:2:0 (JPEGPutMCU22 half-size body, jpeg.inl:3577-3626): a pixel's luma is the SUM of its 2x2
+// samples, << 10, its chroma the one sample at its place (no averaging), and each channel clamp((k . c + (sum << 10)) >> 12)
+// = clamp((((k . c) >> 10) + sum) >> 2) -- two pixels per instruction in the halves of a word.  A work item is 4 pixels of
+// one output row: two rows of one luma block (16 bytes) and four Cb / Cr samples.
+// per 16-bit lane: arithmetic shift right by 2 (v_pk_ashrrev_i16)
+JDA_HD uint32_t jda_pk_ashr2(uint32_t a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short jda_s2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(jda_s2, a) >> 2);
+#else
+    const int32_t lo = (int16_t)(a & 0xffffu), hi = (int16_t)(a >> 16);
+    return ((uint32_t)(lo >> 2) & 0xffffu) | ((uint32_t)(hi >> 2) << 16);
+#endif
+}
+// the three chroma terms x 64 (the wanted (k . c) >> 10 sits in bits 31:16)
+JDA_HD jda_chroma2 jda_chroma_terms64(uint32_t cb8, uint32_t cr8)
+{
+    const int32_t cb = (int32_t)cb8, cr = (int32_t)cr8;
+    jda_chroma2 t;
+    t.r = (uint32_t)(64 * 5742 * cr - 64 * 5742 * 128);
+    t.g = (uint32_t)(-64 * 1409 * cb - 64 * 2925 * cr + 64 * (1409 + 2925) * 128);
+    t.b = (uint32_t)(64 * 7258 * cb - 64 * 7258 * 128);
+    return t;
+}
+JDA_HD void jda_rgba_pair_half(uint32_t ysum2, uint32_t tr, uint32_t tg, uint32_t tb, uint32_t &px0, uint32_t &px1)
+{
+    const uint32_t r2 = jda_sat_pk_u8(jda_pk_ashr2(jda_pk_add16(ysum2, tr)));
+    const uint32_t g2 = jda_sat_pk_u8(jda_pk_ashr2(jda_pk_add16(ysum2, tg)));
+    const uint32_t b2 = jda_sat_pk_u8(jda_pk_ashr2(jda_pk_add16(ysum2, tb)));
+    const uint32_t rg = jda_perm(g2, r2, 0x05010400u);
+    px0 = jda_perm(b2, rg, 0x0d040100u);
+    px1 = jda_perm(b2, rg, 0x0d050302u);
+}
+template <bool CLIP>
+JDA_HD void jda_p4_420_half_rgba(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                                 uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    const uint32_t groups = tile_w >> 2;                          // tile_w (output pixels) is a multiple of 8
+    const uint32_t inv = jda_recip22(groups);
+    uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
+    const uint32_t pitch = D.out_pitch;
+    const uint32_t tile_off = y_base * pitch + x_base * 4u;
+    for (uint32_t i = t; i < groups * 8; i += JDA_TILE_THREADS) {
+        const uint32_t r = jda_umul24(i, inv) >> 22, g = i - jda_umul24(r, groups);     // output row 0..7, group in the row
+        const uint32_t X = x_base + g * 4, Y = y_base + r;
+        if (CLIP && (Y >= D.out_rows || X >= D.out_w)) continue;
+        // MCU g >> 1, luma block (r >> 2) * 2 + (g & 1), its rows 2 (r & 3) and 2 (r & 3) + 1; chroma row r, columns (g & 1) * 4 ..
+        const uint32_t po = jda_umul24(g >> 1, plane_stride);
+        const jda_u32_alias *ys = (const jda_u32_alias *)(plane_base + po + ((r >> 2) * 2u + (g & 1u)) * JDA_COEF_STRIDE + (r & 3u) * 16);
+        const uint32_t co = po + 4 * JDA_COEF_STRIDE + r * 8 + (g & 1u) * 4;
+        const uint32_t s01 = jda_pair_sums(ys[0]) + jda_pair_sums(ys[2]), s23 = jda_pair_sums(ys[1]) + jda_pair_sums(ys[3]);
+        const uint32_t cb = *(const jda_u32_alias *)(plane_base + co), cr = *(const jda_u32_alias *)(plane_base + co + JDA_COEF_STRIDE);
+        jda_chroma2 c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms64((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
+        uint32_t v[4];
+        jda_rgba_pair_half(s01, jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
+        jda_rgba_pair_half(s23, jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
+        if (!CLIP) {
+            jda_chunk16_alias q;
+            q.w[0] = v[0]; q.w[1] = v[1]; q.w[2] = v[2]; q.w[3] = v[3];
+            *(jda_chunk16_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + g * 16u) = q;
+        } else jda_store4<JDA_RGB8888, true>(out + (size_t)Y * pitch, X, D.out_w, v);
+    }
+}
+
 // pixel type and clipping are decided once per tile (uniform), so the item loops are branch-free
 template <int MODE, bool CLIP>
 JDA_HD void jda_p4_full_colour(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
@@ -2220,6 +2287,10 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;
         if (inside) jda_p4_gray8_full<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_gray8_full<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    } else if (MODE == JDA_MODE_420 && shift == 1 && D.pixel_type == JDA_RGB8888) {      // the most used scaled colour output
+        const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;
+        if (inside) jda_p4_420_half_rgba<false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        else jda_p4_420_half_rgba<true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
     } else if (shift == 1 && !colour_out) {                       // 8-bit gray, half size: 2x2 luma sums
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows && (x_base & 3u) == 0;
         if (inside) jda_p4_gray8_half<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
