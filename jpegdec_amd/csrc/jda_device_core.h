@@ -2240,6 +2240,31 @@ JDA_HD void jda_p4_generic(const jda_dev_desc &D, uint32_t t, const uint8_t *pla
     }
 }
 
+// 1/4 and 1/8 outputs are a few pixels per MCU (a 4:2:0 tile at 1/8: 20 x 2): one pixel per lane instead of the generic
+// stage's four -- the wavefront runs a quarter of the per-pixel code --, consecutive lanes store consecutive pixels
+template <int MODE>
+JDA_HD void jda_p4_thumb(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                         uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    typedef jda_mode_traits<MODE> T;
+    const int shift = D.scale_shift;
+    const uint32_t mw_log2 = (uint32_t)T::MCU_W_LOG2 - (uint32_t)shift;       // MCU tile edge in output px = 1 << mw_log2
+    const uint32_t mh = (uint32_t)T::MCU_H >> shift;
+    const int pt = D.pixel_type;
+    const uint32_t inv = jda_recip22(tile_w);
+    for (uint32_t i = t; i < tile_w * mh; i += JDA_TILE_THREADS) {
+        const uint32_t row = jda_umul24(i, inv) >> 22, x = i - jda_umul24(row, tile_w);
+        const uint32_t Y = y_base + row, X = x_base + x;
+        if (Y >= D.out_rows || X >= D.out_w) continue;
+        const uint32_t m = x >> mw_log2;
+        const uint32_t v = jda_output_pixel<MODE>(plane_base + jda_umul24(m, plane_stride), x - (m << mw_log2), row, shift, pt);
+        uint8_t JDA_GLOBAL *rowp = JDA_G(uint8_t, D.out) + (size_t)Y * D.out_pitch;
+        if (pt == JDA_RGB8888) ((jda_u32_alias JDA_GLOBAL *)rowp)[X] = v;
+        else if (pt == JDA_EIGHT_BIT_GRAYSCALE) rowp[X] = (uint8_t)v;
+        else ((uint16_t JDA_GLOBAL *)rowp)[X] = (uint16_t)v;
+    }
+}
+
 // the precomputed item addresses belong to an image (pitch, pixel size): made when a wavefront meets a new image
 template <int MODE>
 JDA_HD void jda_p4_prepare(jda_p4_pre &P, const jda_dev_desc &D, uint32_t t)
@@ -2306,7 +2331,9 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
             *(uint16_t JDA_GLOBAL *)(o + 2u * t) = *(const uint16_t *)blk;
             *(uint16_t JDA_GLOBAL *)(o + D.out_pitch + 2u * t) = *(const uint16_t *)(blk + 2);
         }
-    } else
+    } else if (shift >= 2)
+        jda_p4_thumb<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+    else
         jda_p4_generic<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
 
