@@ -202,11 +202,15 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
 }
 
 // Bring the staged tables up to image `target` of the run (see above).  P / DP: the tile this wavefront is about
-// to decode and its image's descriptor (have == false: the wavefront has no tile left).
+// to decode and its image's descriptor (have == false: the wavefront has no tile left).  The wavefront that drew the new
+// image's first tile publishes where its tables are; then the WHOLE workgroup stages them (one wavefront doing it alone kept
+// the other fifteen at the barrier for eleven rounds of loads and entry conversions: 2-4 % of a batch of small images).
 #define JDA_ADVANCE_TABLES(target, have, P, DP)                                                         \
     while (staged < (target)) {                                                                           \
         __syncthreads();                              /* nobody reads the old tables any more */          \
-        if ((have) && (P).first && (P).ord == staged + 1u) jda_p0_tables((DP), lane, 64u, tab, L::LONG_LDS != 0);         \
+        if ((have) && (P).first && (P).ord == staged + 1u && lane == 0) *tab_src = (unsigned long long)(DP).tables;  \
+        __syncthreads();                                                                                  \
+        jda_p0_tables_from((const uint8_t *)*(volatile unsigned long long *)tab_src, threadIdx.x, 64 * L::WAVES, tab, L::LONG_LDS != 0); \
         __syncthreads();                                                                                  \
         staged++;                                                                                         \
     }
@@ -233,6 +237,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     uint8_t *tab = lds;
     uint8_t *wl = lds + L::TAB_BYTES + wave * L::WAVE_BYTES;
     uint32_t *ctr = (uint32_t *)(lds + L::TAB_BYTES + L::WAVES * L::WAVE_BYTES);            // the run's draw counter
+    unsigned long long *tab_src = (unsigned long long *)(ctr + 2);                          // where the next image's tables are (JDA_ADVANCE_TABLES)
 
     // ---- prologue: the tables of the run's first image, the counter
     if (threadIdx.x == 0) *ctr = t_begin;
