@@ -2156,15 +2156,27 @@ JDA_HD void jda_rgba_pair_half(uint32_t ysum2, uint32_t tr, uint32_t tg, uint32_
     px0 = jda_perm(b2, rg, 0x0d040100u);
     px1 = jda_perm(b2, rg, 0x0d050302u);
 }
-template <bool CLIP>
+// the same for RGB565 (JPEGPixelLE / BE through the 10-bit wrapping tables: the identity on this value range, as in jda_565_pair)
+template <int PT>
+JDA_HD uint32_t jda_565_pair_half(uint32_t ysum2, uint32_t tr, uint32_t tg, uint32_t tb)
+{
+    const uint32_t r2 = jda_pk_clamp255(jda_pk_ashr2(jda_pk_add16(ysum2, tr)));
+    const uint32_t g2 = jda_pk_clamp255(jda_pk_ashr2(jda_pk_add16(ysum2, tg)));
+    const uint32_t b2 = jda_pk_clamp255(jda_pk_ashr2(jda_pk_add16(ysum2, tb)));
+    uint32_t v = ((r2 & 0x00f800f8u) << 8) | ((g2 & 0x00fc00fcu) << 3) | ((b2 >> 3) & 0x001f001fu);
+    if (PT == JDA_RGB565_BIG_ENDIAN) v = jda_perm(0, v, 0x02030001u);
+    return v;
+}
+template <int PT, bool CLIP>
 JDA_HD void jda_p4_420_half_rgba(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
                                  uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
 {
+    const uint32_t bpp = PT == JDA_RGB8888 ? 4u : 2u;
     const uint32_t groups = tile_w >> 2;                          // tile_w (output pixels) is a multiple of 8
     const uint32_t inv = jda_recip22(groups);
     uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
     const uint32_t pitch = D.out_pitch;
-    const uint32_t tile_off = y_base * pitch + x_base * 4u;
+    const uint32_t tile_off = y_base * pitch + x_base * bpp;
     for (uint32_t i = t; i < groups * 8; i += JDA_TILE_THREADS) {
         const uint32_t r = jda_umul24(i, inv) >> 22, g = i - jda_umul24(r, groups);     // output row 0..7, group in the row
         const uint32_t X = x_base + g * 4, Y = y_base + r;
@@ -2179,13 +2191,23 @@ JDA_HD void jda_p4_420_half_rgba(const jda_dev_desc &D, uint32_t t, const uint8_
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms64((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
         uint32_t v[4];
-        jda_rgba_pair_half(s01, jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
-        jda_rgba_pair_half(s23, jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
-        if (!CLIP) {
-            jda_chunk16_alias q;
-            q.w[0] = v[0]; q.w[1] = v[1]; q.w[2] = v[2]; q.w[3] = v[3];
-            *(jda_chunk16_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + g * 16u) = q;
-        } else jda_store4<JDA_RGB8888, true>(out + (size_t)Y * pitch, X, D.out_w, v);
+        if (PT == JDA_RGB8888) {
+            jda_rgba_pair_half(s01, jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
+            jda_rgba_pair_half(s23, jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
+            if (!CLIP) {
+                jda_chunk16_alias q;
+                q.w[0] = v[0]; q.w[1] = v[1]; q.w[2] = v[2]; q.w[3] = v[3];
+                *(jda_chunk16_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + g * 16u) = q;
+            } else jda_store4<PT, true>(out + (size_t)Y * pitch, X, D.out_w, v);
+        } else {
+            const uint32_t a01 = jda_565_pair_half<PT>(s01, jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b));
+            const uint32_t a23 = jda_565_pair_half<PT>(s23, jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b));
+            if (!CLIP) *(jda_u64_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + g * 8u) = (uint64_t)a01 | ((uint64_t)a23 << 32);
+            else {
+                v[0] = a01 & 0xffffu; v[1] = a01 >> 16; v[2] = a23 & 0xffffu; v[3] = a23 >> 16;
+                jda_store4<PT, true>(out + (size_t)Y * pitch, X, D.out_w, v);
+            }
+        }
     }
 }
 
@@ -2312,10 +2334,19 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;
         if (inside) jda_p4_gray8_full<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         else jda_p4_gray8_full<MODE, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
-    } else if (MODE == JDA_MODE_420 && shift == 1 && D.pixel_type == JDA_RGB8888) {      // the most used scaled colour output
+    } else if (MODE == JDA_MODE_420 && shift == 1 && colour_out) {      // the most used scaled colour outputs
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;
-        if (inside) jda_p4_420_half_rgba<false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
-        else jda_p4_420_half_rgba<true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        const int pt = D.pixel_type;
+        if (pt == JDA_RGB8888) {
+            if (inside) jda_p4_420_half_rgba<JDA_RGB8888, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+            else jda_p4_420_half_rgba<JDA_RGB8888, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        } else if (pt == JDA_RGB565_LITTLE_ENDIAN) {
+            if (inside) jda_p4_420_half_rgba<JDA_RGB565_LITTLE_ENDIAN, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+            else jda_p4_420_half_rgba<JDA_RGB565_LITTLE_ENDIAN, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        } else {
+            if (inside) jda_p4_420_half_rgba<JDA_RGB565_BIG_ENDIAN, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+            else jda_p4_420_half_rgba<JDA_RGB565_BIG_ENDIAN, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        }
     } else if (shift == 1 && !colour_out) {                       // 8-bit gray, half size: 2x2 luma sums
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows && (x_base & 3u) == 0;
         if (inside) jda_p4_gray8_half<MODE, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
