@@ -215,6 +215,11 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
         staged++;                                                                                         \
     }
 
+#ifndef JDA_PRIO_P1
+#define JDA_PRIO_P1 3
+#define JDA_PRIO_IDCT 1
+#define JDA_PRIO_P4 3
+#endif
 #ifndef JDA_EXP_SKIP
 #define JDA_EXP_SKIP 0       // profiling builds (tools/phase_count_libs.sh): 1 no P4, 2 no P3, 4 no P2, 8 no lists, 16 no P1
 #endif
@@ -309,10 +314,10 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         JDA_PTRACE(1);
         // wave priorities: the phase that is a dependent chain (P1) and the one that feeds the memory pipe (P4) go first,
         // the arithmetic-dense IDCT fills the issue slots they leave (measured: 0.6-1 % over "oldest wave first")
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(JDA_PRIO_P1);
         const uint32_t p1flags = (JDA_EXP_SKIP & 16) ? 0u : jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
         if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 8)) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(JDA_PRIO_IDCT);
         JDA_WAVE_SYNC();
         JDA_PTRACE(2);
 
@@ -354,7 +359,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         JDA_PTRACE(6);
         if (lane < 8) ((uint32_t *)(wl + L::CNT_OFF))[lane] = 0;      // list counters reset for the next tile
 
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(JDA_PRIO_P4);
         if (!(JDA_EXP_SKIP & 1)) jda_p4_output<MODE>(D, S, C, lane, wl, P4);
         JDA_PTRACE(7);
 #ifdef JDA_PHASE_TRACE
