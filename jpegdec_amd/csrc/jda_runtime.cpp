@@ -46,6 +46,8 @@ static int jda_plain_variant(const jda_dev_desc &D)
     return 0;
 }
 
+#define JDA_POOL_SLOTS 192
+#define JDA_POOL_IDLE_MAX ((size_t)2 << 30)      // idle bytes kept at most
 struct jda_ctx {
     int device;
     hipStream_t stream;
@@ -54,6 +56,12 @@ struct jda_ctx {
     size_t pinned_cap;
     int last_segscan_rounds;  // speculative rounds the last marker-less device pre-scan needed (diagnostics)
     char last_error[256];
+    // Device blocks the runtime allocated for itself (resident images, launch plans, the one-call path's surface), kept when
+    // released and handed out again: hipFree costs ~0.23 ms and synchronises the device, which was most of a small image's
+    // time through jda_decode_to_host (the JPEGDEC class).  Everything of a context runs on its one stream, so a block
+    // released while work on it is still queued is safe to reuse: the next user's work queues behind it.
+    struct { void *p; size_t bytes; bool busy; } pool[JDA_POOL_SLOTS];
+    size_t pool_idle;
 };
 
 struct jda_dev_image {
@@ -85,6 +93,41 @@ static int set_err(jda_ctx *ctx, hipError_t e, const char *what)
 #define JDA_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err((ctx), e_, #call); } while (0)
 
 static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+static hipError_t pool_alloc(jda_ctx *ctx, void **out, size_t bytes)
+{
+    if (!bytes) bytes = 16;
+    int best = -1, empty = -1;
+    for (int i = 0; i < JDA_POOL_SLOTS; i++) {
+        if (!ctx->pool[i].p) { if (empty < 0) empty = i; continue; }
+        if (!ctx->pool[i].busy && ctx->pool[i].bytes >= bytes && ctx->pool[i].bytes <= 2 * bytes + 65536 &&
+            (best < 0 || ctx->pool[i].bytes < ctx->pool[best].bytes)) best = i;
+    }
+    if (best >= 0) { ctx->pool[best].busy = true; ctx->pool_idle -= ctx->pool[best].bytes; *out = ctx->pool[best].p; return hipSuccess; }
+    const hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess && empty >= 0) { ctx->pool[empty].p = *out; ctx->pool[empty].bytes = bytes; ctx->pool[empty].busy = true; }
+    return e;          // (no slot left: the block is not tracked and pool_free hands it to hipFree)
+}
+static void pool_free(jda_ctx *ctx, void *p)
+{
+    if (!p) return;
+    for (int i = 0; i < JDA_POOL_SLOTS; i++)
+        if (ctx->pool[i].p == p) {
+            ctx->pool[i].busy = false;
+            ctx->pool_idle += ctx->pool[i].bytes;
+            while (ctx->pool_idle > JDA_POOL_IDLE_MAX) {           // too much idle memory: give the largest idle blocks back
+                int big = -1;
+                for (int k = 0; k < JDA_POOL_SLOTS; k++)
+                    if (ctx->pool[k].p && !ctx->pool[k].busy && (big < 0 || ctx->pool[k].bytes > ctx->pool[big].bytes)) big = k;
+                if (big < 0) break;
+                (void)hipFree(ctx->pool[big].p);
+                ctx->pool_idle -= ctx->pool[big].bytes;
+                ctx->pool[big].p = NULL; ctx->pool[big].bytes = 0;
+            }
+            return;
+        }
+    (void)hipFree(p);
+}
 
 extern "C" {
 
@@ -125,6 +168,7 @@ void jda_destroy(jda_ctx *ctx)
     (void)hipEventDestroy(ctx->ev_stop);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int i = 0; i < JDA_POOL_SLOTS; i++) if (ctx->pool[i].p) (void)hipFree(ctx->pool[i].p);
     delete ctx;
 }
 
@@ -203,7 +247,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     hipError_t e = hipSuccess;
     for (int i = 0; i < n; i++) out[i] = NULL;
     auto fail_all = [&](int code) {
-        for (int i = 0; i < n; i++) { if (items[i].d) { if (items[i].d->base) (void)hipFree(items[i].d->base); delete items[i].d; items[i].d = NULL; } out[i] = NULL; }
+        for (int i = 0; i < n; i++) { if (items[i].d) { if (items[i].d->base) pool_free(ctx, items[i].d->base); delete items[i].d; items[i].d = NULL; } out[i] = NULL; }
         return code;
     };
     std::vector<jda_prescan_params> params;
@@ -298,7 +342,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.off_sstats = it.off_start + align16((size_t)it.n_segs * 20);
             it.alloc = it.off_sstats + 256;
         }
-        e = hipMalloc((void **)&d->base, it.alloc);
+        e = pool_alloc(ctx, (void **)&d->base, it.alloc);
         if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
         if (it.seg_mode) {
             // only the tables and the scan travel; everything behind the scan's last byte starts as zeros (padding, round-0
@@ -368,7 +412,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
 
     jda_prescan_params *d_params = NULL;
     if (!params.empty()) {
-        e = hipMalloc((void **)&d_params, params.size() * sizeof(jda_prescan_params));
+        e = pool_alloc(ctx, (void **)&d_params, params.size() * sizeof(jda_prescan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), params.size() * sizeof(jda_prescan_params), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = jda_launch_prescan(d_params, (uint32_t)params.size(), max_int, 0, ctx->stream);          // MAP
         for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
@@ -392,7 +436,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     jda_segscan_params *d_seg = NULL;
     if (!seg_params.empty() && e == hipSuccess) {
         const uint32_t ns = (uint32_t)seg_params.size();
-        e = hipMalloc((void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
+        e = pool_alloc(ctx, (void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg_params.data(), seg_params.size() * sizeof(jda_segscan_params), hipMemcpyHostToDevice, ctx->stream);
         const uint32_t kMaxRounds = 48;                     // (the result words hold a change counter per round: 8 + 48 <= 64)
         uint32_t rounds = 0;
@@ -431,8 +475,8 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     JDA_UP_MARK("write pass + D2H");
-    if (d_params) (void)hipFree(d_params);
-    if (d_seg) (void)hipFree(d_seg);
+    if (d_params) pool_free(ctx, d_params);
+    if (d_seg) pool_free(ctx, d_seg);
     if (e != hipSuccess) return fail_all(set_err(ctx, e, "jda_upload_batch"));
 
     // a marker that is not where the MCU count puts it, or a corrupt interval: the serial host pre-scan reproduces
@@ -543,7 +587,7 @@ void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg)
 {
     if (!dimg) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (dimg->base) (void)hipFree(dimg->base);
+    if (dimg->base) { if (ctx) pool_free(ctx, dimg->base); else (void)hipFree(dimg->base); }
     delete dimg;
 }
 
@@ -613,12 +657,12 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     memset(b, 0, sizeof(*b));
     b->n_images = n;
     (void)hipSetDevice(ctx->device);
-    hipError_t e = hipMalloc((void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
+    hipError_t e = pool_alloc(ctx, (void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
     if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
     for (int m = 0; m < JDA_N_LISTS && e == hipSuccess; m++) {
         b->n_strips[m] = (uint32_t)strips[m].size();
         if (!b->n_strips[m]) continue;
-        e = hipMalloc((void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
+        e = pool_alloc(ctx, (void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
         st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 8));
@@ -639,8 +683,8 @@ void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
 {
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (b->d_descs) (void)hipFree(b->d_descs);
-    for (int m = 0; m < JDA_N_LISTS; m++) if (b->d_strips[m]) (void)hipFree(b->d_strips[m]);
+    if (b->d_descs) { if (ctx) pool_free(ctx, b->d_descs); else (void)hipFree(b->d_descs); }
+    for (int m = 0; m < JDA_N_LISTS; m++) if (b->d_strips[m]) { if (ctx) pool_free(ctx, b->d_strips[m]); else (void)hipFree(b->d_strips[m]); }
     delete b;
 }
 
@@ -697,7 +741,14 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     int32_t err = JDA_SUCCESS;
-    jda_image *img = jda_prepare_ex(jpeg, len, JDA_PREPARE_DEVICE_PRESCAN, &err);   // restart markers: index made on the GPU
+    static const bool trace = getenv("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
+    double t_mark = trace ? now_ms() : 0.0;
+#define JDA_OC_MARK(what) do { if (trace) { const double t_ = now_ms(); fprintf(stderr, "jda_decode_to_host: %-24s %7.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
+    // One image at a time, the device pre-scan is a few latency-bound passes of ~0.5 ms each whatever the size (a 640x480 scan
+    // is four wavefronts' worth of segments): 1.85 ms where the serial host pre-scan of that image takes 0.29 ms.  It wins from
+    // about 2.5 Mpixel on (1080p: 1.7 ms on the host, 4096x4096: 13 ms against 5.5 ms) -- in batches it always does.
+    const int32_t prep_flags = len >= (300 << 10) ? JDA_PREPARE_DEVICE_PRESCAN : 0;
+    jda_image *img = jda_prepare_ex(jpeg, len, prep_flags, &err);
     if (!img) return err;
     const jda_image_info &I = *jda_image_get_info(img);
     int bpp, ow, oh, cw, ch;
@@ -705,18 +756,22 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
     if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
     const int dpitch = (int)align16((size_t)cw * bpp);
     const int drows = rows < ch ? rows : ch;
+    JDA_OC_MARK("prepare (host)");
     jda_dev_image *dimg = jda_upload(ctx, img, &err);
+    JDA_OC_MARK("upload + device pre-scan");
     uint32_t nok = 0;
     jda_image_block_index(img, &nok);                   // (after the upload: a deferred pre-scan has run by now)
     const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
     jda_image_free(img);
     if (!dimg) return err;
-    void *dout = jda_malloc(ctx, (size_t)dpitch * ch);
+    void *dout = NULL;
+    if (pool_alloc(ctx, &dout, (size_t)dpitch * ch) != hipSuccess) dout = NULL;
     if (!dout) { jda_dev_image_free(ctx, dimg); return JDA_ERROR_MEMORY; }
     jda_output O;
     O.pixels = dout; O.pitch_bytes = dpitch; O.width_px = cw; O.rows = drows;
     jda_batch *b = jda_batch_create(ctx, 1, &dimg, &O, &pixel_type, &options, &err);
     rc = err;
+    JDA_OC_MARK("surface + launch plan");
     if (b) {
         if (!complete) (void)hipMemsetAsync(dout, 0, (size_t)dpitch * ch, ctx->stream);
         rc = jda_batch_decode(ctx, b);
@@ -726,10 +781,13 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) rc = set_err(ctx, e, "copy back");
         }
+        JDA_OC_MARK("decode + copy back");
         jda_batch_destroy(ctx, b);
     }
-    jda_free(ctx, dout);
+    pool_free(ctx, dout);
     jda_dev_image_free(ctx, dimg);
+    JDA_OC_MARK("release");
+#undef JDA_OC_MARK
     if (rc == JDA_SUCCESS && !complete) rc = JDA_DECODE_ERROR;   // jpeg.inl:5354-5356
     return rc;
 }
