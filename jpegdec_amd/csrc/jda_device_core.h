@@ -2211,6 +2211,52 @@ JDA_HD void jda_p4_420_half_rgba(const jda_dev_desc &D, uint32_t t, const uint8_
     }
 }
 
+// Half-size colour output of 4:4:4 (JPEGPutMCU11 half-size body, jpeg.inl:3297-3322): luma = the 2x2 sum << 10 as above, each
+// chroma sample = (its 2x2 sum + 2) >> 2.  A work item is one output row of one MCU (4 pixels): rows 2r, 2r + 1 of its Y, Cb
+// and Cr blocks.
+template <int PT, bool CLIP>
+JDA_HD void jda_p4_444_half(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
+                            uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
+{
+    const uint32_t bpp = PT == JDA_RGB8888 ? 4u : 2u;
+    const uint32_t groups = tile_w >> 2;                          // = MCUs in the tile
+    const uint32_t inv = jda_recip22(groups);
+    uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, D.out);
+    const uint32_t pitch = D.out_pitch;
+    const uint32_t tile_off = y_base * pitch + x_base * bpp;
+    for (uint32_t i = t; i < groups * 4; i += JDA_TILE_THREADS) {
+        const uint32_t r = jda_umul24(i, inv) >> 22, g = i - jda_umul24(r, groups);     // output row 0..3, MCU
+        const uint32_t X = x_base + g * 4, Y = y_base + r;
+        if (CLIP && (Y >= D.out_rows || X >= D.out_w)) continue;
+        const jda_u32_alias *ys = (const jda_u32_alias *)(plane_base + jda_umul24(g, plane_stride) + r * 16);
+        const jda_u32_alias *bs = (const jda_u32_alias *)((const uint8_t *)ys + JDA_COEF_STRIDE), *rs = (const jda_u32_alias *)((const uint8_t *)ys + 2 * JDA_COEF_STRIDE);
+        const uint32_t s01 = jda_pair_sums(ys[0]) + jda_pair_sums(ys[2]), s23 = jda_pair_sums(ys[1]) + jda_pair_sums(ys[3]);
+        const uint32_t b01 = ((jda_pair_sums(bs[0]) + jda_pair_sums(bs[2]) + 0x00020002u) >> 2) & 0x00ff00ffu, b23 = ((jda_pair_sums(bs[1]) + jda_pair_sums(bs[3]) + 0x00020002u) >> 2) & 0x00ff00ffu;
+        const uint32_t r01 = ((jda_pair_sums(rs[0]) + jda_pair_sums(rs[2]) + 0x00020002u) >> 2) & 0x00ff00ffu, r23 = ((jda_pair_sums(rs[1]) + jda_pair_sums(rs[3]) + 0x00020002u) >> 2) & 0x00ff00ffu;
+        jda_chroma2 c[4];
+        c[0] = jda_chroma_terms64(b01 & 0xffffu, r01 & 0xffffu); c[1] = jda_chroma_terms64(b01 >> 16, r01 >> 16);
+        c[2] = jda_chroma_terms64(b23 & 0xffffu, r23 & 0xffffu); c[3] = jda_chroma_terms64(b23 >> 16, r23 >> 16);
+        uint32_t v[4];
+        if (PT == JDA_RGB8888) {
+            jda_rgba_pair_half(s01, jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
+            jda_rgba_pair_half(s23, jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
+            if (!CLIP) {
+                jda_chunk16_alias q;
+                q.w[0] = v[0]; q.w[1] = v[1]; q.w[2] = v[2]; q.w[3] = v[3];
+                *(jda_chunk16_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + g * 16u) = q;
+            } else jda_store4<PT, true>(out + (size_t)Y * pitch, X, D.out_w, v);
+        } else {
+            const uint32_t a01 = jda_565_pair_half<PT>(s01, jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b));
+            const uint32_t a23 = jda_565_pair_half<PT>(s23, jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b));
+            if (!CLIP) *(jda_u64_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + g * 8u) = (uint64_t)a01 | ((uint64_t)a23 << 32);
+            else {
+                v[0] = a01 & 0xffffu; v[1] = a01 >> 16; v[2] = a23 & 0xffffu; v[3] = a23 >> 16;
+                jda_store4<PT, true>(out + (size_t)Y * pitch, X, D.out_w, v);
+            }
+        }
+    }
+}
+
 // pixel type and clipping are decided once per tile (uniform), so the item loops are branch-free
 template <int MODE, bool CLIP>
 JDA_HD void jda_p4_full_colour(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
@@ -2346,6 +2392,19 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
         } else {
             if (inside) jda_p4_420_half_rgba<JDA_RGB565_BIG_ENDIAN, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
             else jda_p4_420_half_rgba<JDA_RGB565_BIG_ENDIAN, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        }
+    } else if (MODE == JDA_MODE_444 && shift == 1 && colour_out) {
+        const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;
+        const int pt = D.pixel_type;
+        if (pt == JDA_RGB8888) {
+            if (inside) jda_p4_444_half<JDA_RGB8888, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+            else jda_p4_444_half<JDA_RGB8888, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        } else if (pt == JDA_RGB565_LITTLE_ENDIAN) {
+            if (inside) jda_p4_444_half<JDA_RGB565_LITTLE_ENDIAN, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+            else jda_p4_444_half<JDA_RGB565_LITTLE_ENDIAN, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+        } else {
+            if (inside) jda_p4_444_half<JDA_RGB565_BIG_ENDIAN, false>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
+            else jda_p4_444_half<JDA_RGB565_BIG_ENDIAN, true>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
         }
     } else if (shift == 1 && !colour_out) {                       // 8-bit gray, half size: 2x2 luma sums
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows && (x_base & 3u) == 0;
