@@ -19,4 +19,10 @@ run "metric, RGB565 output" --pixel-type rgb565
 run "metric, restart marker per MCU row + device pre-scan" --restart-rows 1 --device-prescan
 run "4096x4096 4:2:2 -> RGB8888" --subsampling 4:2:2
 run "metric image -> GRAY8" --pixel-type gray8
+run "metric image, JPEG_SCALE_HALF -> RGB8888" --options 2
+run "metric image, JPEG_SCALE_HALF -> RGB565" --options 2 --pixel-type rgb565
+run "metric image, 1/4 -> RGB8888" --options 4
+run "metric image, 1/8 -> RGB8888 (thumbnail)" --options 8
+run "4096x4096 4:4:4, JPEG_SCALE_HALF -> RGB8888" --subsampling 4:4:4 --options 2
+run "batch 1024 x 640x480 4:2:0 -> RGB565 (the reference's own test image size)" --batch 1024 --width 640 --height 480 --distinct 4 --pixel-type rgb565
 cat $out
