@@ -36,8 +36,18 @@ cuser: tests/capi_c/c_user
 tests/capi_c/c_user: tests/capi_c/c_user.c include/JPEGDEC.h $(LIB)
 	$(CC) -std=c99 -O2 -Wall -Iinclude -o $@ tests/capi_c/c_user.c -Ljpegdec_amd -ljpegdec_amd -Wl,-rpath,'$$ORIGIN/../../jpegdec_amd'
 
+# the reference's own test program (MacOS/JPEGDEC_Test/JPEGDEC_Test/main.cpp) restated against the product's class
+jpegtest: tests/ref_main/jpegtest_amd
+tests/ref_main/jpegtest_amd: tests/ref_main/jpegtest_amd.cpp include/JPEGDEC.h $(LIB)
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude -o $@ tests/ref_main/jpegtest_amd.cpp -Ljpegdec_amd -ljpegdec_amd -Wl,-rpath,'$$ORIGIN/../../jpegdec_amd'
+
+# the host front end under ASan + UBSan with a mutation driver (no GPU code in jda_frontend.cpp)
+frontfuzz: tests/fuzz/frontend_fuzz
+tests/fuzz/frontend_fuzz: tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp $(CSRC)/jda_internal.h include/jpegdec_amd.h
+	$(CXX) -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Wall -Iinclude -pthread -o $@ tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp
+
 clean:
-	rm -f $(LIB) tests/hostsim/libjda_hostsim.so tests/capi_c/c_user
+	rm -f $(LIB) tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim classshim cuser clean
+.PHONY: all lib oracle hostsim classshim cuser jpegtest frontfuzz clean

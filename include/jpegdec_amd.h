@@ -239,6 +239,11 @@ double jda_timer_elapsed_ms(jda_ctx *ctx);
  * HOST canvas of canvas_w x canvas_h pixels (pitch_bytes per row). */
 int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
                        int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows);
+/* The same; *mcus_decoded (may be NULL) = MCUs decoded before the first invalid code, in scan order (all of them on
+ * JDA_SUCCESS; fewer with JDA_DECODE_ERROR: the reference stops at that MCU, jpeg.inl:2137, 2237, 5354-5356 -- the
+ * canvas holds the MCUs before it, zeros behind). */
+int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
+                          int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded);
 
 const char *jda_version(void);
 

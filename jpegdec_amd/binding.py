@@ -97,6 +97,7 @@ _PROTOTYPES = [
     ("jda_timer_stop", C.c_int, [_P]),
     ("jda_timer_elapsed_ms", C.c_double, [_P]),
     ("jda_decode_to_host", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32]),
+    ("jda_decode_to_host_ex", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_version", C.c_char_p, []),
 ]
 

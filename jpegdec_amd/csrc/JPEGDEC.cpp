@@ -203,10 +203,15 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     if (s->pixel_type > EIGHT_BIT_GRAYSCALE) { s->error = JPEG_UNSUPPORTED_FEATURE; return 0; }
     if (iOptions & JPEG_EXIF_THUMBNAIL) {              // jpeg.inl:4967-4976: decode the JPEG embedded in the EXIF block instead
         if (s->info.thumb_offset == 0 || s->info.thumb_w == 0) { s->error = JPEG_INVALID_PARAMETER; return 0; }
-        if (s->info.thumb_offset >= s->size) { s->error = JPEG_INVALID_FILE; return 0; }
+        if (s->info.thumb_offset < 0 || s->info.thumb_offset > s->size - 256) { s->error = JPEG_INVALID_FILE; return 0; }   // (JPEGParseInfo wants 256 bytes, :1598)
+        // jpeg.inl:4964-4966 runs BEFORE the thumbnail is parsed: it is the MAIN image's mode that ORs JPEG_SCALE_EIGHTH in
+        if (s->info.jpeg_type == 1) iOptions |= JPEG_SCALE_EIGHTH;
         jda_image_info ti;
         const int prc = jda_parse(s->data + s->info.thumb_offset, s->size - s->info.thumb_offset, &ti);   // JPEGParseInfo(pJPEG, 1)
         if (prc != JDA_SUCCESS) { s->error = prc; return 0; }
+        // a progressive thumbnail inside a baseline file would go through the reference's DC-only decode at whatever scale was
+        // asked for (no EIGHTH OR-ed in): not a case this path reproduces
+        if (ti.jpeg_type == 1 && s->info.jpeg_type == 0 && !(iOptions & (JPEG_SCALE_HALF | JPEG_SCALE_EIGHTH))) { s->error = JPEG_UNSUPPORTED_FEATURE; return 0; }
         // the reference parses the thumbnail over its own state: the object now describes the thumbnail
         ti.has_thumb = s->info.has_thumb; ti.thumb_w = s->info.thumb_w; ti.thumb_h = s->info.thumb_h; ti.thumb_offset = 0;
         s->data += s->info.thumb_offset; s->size -= s->info.thumb_offset;
@@ -214,6 +219,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         s->crop_w = ti.width; s->crop_h = ti.height;
         iOptions &= ~JPEG_EXIF_THUMBNAIL;
     }
+    if (s->crop_w <= 0 || s->crop_h <= 0) { s->error = JPEG_INVALID_PARAMETER; return 0; }   // image smaller than one MCU / overhanging request (jpeg.inl:713-719 leaves w <= 0): nothing sane to deliver
     const bool cropped = s->crop_x != 0 || s->crop_y != 0 || s->crop_w != s->info.width || s->crop_h != s->info.height;
     int pt = s->pixel_type;
     if ((iOptions & JPEG_LUMA_ONLY) && pt < EIGHT_BIT_GRAYSCALE) pt = s->pixel_type = EIGHT_BIT_GRAYSCALE;   // jpeg.inl:4991-4993
@@ -225,9 +231,10 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     if (!ctx) { s->error = cerr; return 0; }
 
     std::vector<uint8_t> canvas((size_t)cw * ch * bpp);
+    int32_t mcus_decoded = 0;
     {
         std::lock_guard<std::mutex> lk(g_ctx_mutex);
-        rc = jda_decode_to_host(ctx, s->data, s->size, pt, iOptions, canvas.data(), cw * bpp, ch);
+        rc = jda_decode_to_host_ex(ctx, s->data, s->size, pt, iOptions, canvas.data(), cw * bpp, ch, &mcus_decoded);
     }
     const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
     if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
@@ -300,6 +307,13 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         if (n > 65536) n = 65536;
         for (int i = 0; i < n; i++) {
             const int32_t *r = &rects[(size_t)8 * i];
+            if (partial) {
+                // the reference returns at the first bad MCU (jpeg.inl:5150-5297 "if (iErr) ... return 0" paths): only the strips it
+                // had completed before that MCU reach the callback
+                int x_last = (r[6] + r[2]) / mw - 1;
+                if (x_last > s->info.mcus_x - 1) x_last = s->info.mcus_x - 1;
+                if ((r[7] / mh) * s->info.mcus_x + x_last >= mcus_decoded) break;
+            }
             uint16_t *buf = s->strip + (dma ? half * (MAX_BUFFERED_PIXELS / 2) : 0);
             const int row_bytes = r[2] * bpp;
             for (int rr = 0; rr < mh; rr++) {

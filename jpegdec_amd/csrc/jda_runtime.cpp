@@ -739,6 +739,13 @@ double jda_timer_elapsed_ms(jda_ctx *ctx)
 int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
                        int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows)
 {
+    return jda_decode_to_host_ex(ctx, jpeg, len, pixel_type, options, host_pixels, pitch_bytes, rows, NULL);
+}
+
+int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
+                          int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded)
+{
+    if (mcus_decoded) *mcus_decoded = 0;
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     int32_t err = JDA_SUCCESS;
     static const bool trace = getenv("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
@@ -762,6 +769,7 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
     uint32_t nok = 0;
     jda_image_block_index(img, &nok);                   // (after the upload: a deferred pre-scan has run by now)
     const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
+    if (mcus_decoded) *mcus_decoded = (int32_t)nok;
     jda_image_free(img);
     if (!dimg) return err;
     void *dout = NULL;

@@ -70,6 +70,8 @@ class RefDecoder:
                                     C.POINTER(C.c_int), C.c_int, C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ref_decode_cb.restype = C.c_int
+        L.ref_decode_cb2.argtypes = L.ref_decode_cb.argtypes + [C.POINTER(C.c_int)]
+        L.ref_decode_cb2.restype = C.c_int
         L.ref_decode_fb.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.ref_decode_fb.restype = C.c_int
         L.ref_bench.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
@@ -117,16 +119,18 @@ class RefDecoder:
         dma = C.c_int(0)
         err = C.c_int(0)
         croparr = (C.c_int * 4)(*crop) if crop is not None else None
-        rc = self.lib.ref_decode_cb(data, len(data), pixel_type, options, max_mcus, xoff, yoff,
-                                    croparr, canvas.ctypes.data_as(C.c_void_p), cols * bpp, rows,
-                                    1 if used_only else 0, log, maxlog if want_log else 0, stop_after,
-                                    C.byref(n_calls), C.byref(dma), C.byref(err))
+        after = (C.c_int * 2)()
+        rc = self.lib.ref_decode_cb2(data, len(data), pixel_type, options, max_mcus, xoff, yoff,
+                                     croparr, canvas.ctypes.data_as(C.c_void_p), cols * bpp, rows,
+                                     1 if used_only else 0, log, maxlog if want_log else 0, stop_after,
+                                     C.byref(n_calls), C.byref(dma), C.byref(err), after)
         out_log = None
         if want_log:
             n = min(n_calls.value, maxlog)
             out_log = np.frombuffer(log, dtype=np.int32)[: 6 * n].reshape(n, 6).copy()
         return dict(rc=rc, canvas=canvas, n_calls=n_calls.value, dma_reuse=dma.value,
-                    last_error=err.value, log=out_log, info=inf, bpp=bpp, scale_shift=sh)
+                    last_error=err.value, log=out_log, info=inf, bpp=bpp, scale_shift=sh,
+                    size_after=(after[0], after[1]))
 
     def decode_frame(self, data: bytes, pixel_type=RGB8888, options=0):
         """Full frame (H>>s x W>>s pixels, tightly packed) assembled from the draw callbacks."""

@@ -112,11 +112,27 @@ int ref_get_info(const uint8_t *data, int len, int *info)
 
 // Callback-mode decode assembled into a caller canvas.  Returns decode()'s return value
 // (or -1 if open failed).  crop[4] may be NULL (x,y,w,h passed to setCropArea).
+// after[0..1] (may be NULL) = getWidth(), getHeight() AFTER decode(): with JPEG_EXIF_THUMBNAIL the object then describes
+// the embedded thumbnail (reference test 10, MacOS/JPEGDEC_Test/JPEGDEC_Test/main.cpp:236-260)
+int ref_decode_cb2(const uint8_t *data, int len, int pixel_type, int options, int max_mcus,
+                   int xoff, int yoff, const int *crop,
+                   uint8_t *canvas, int pitch_bytes, int rows, int used_only,
+                   int *log, int max_log, int stop_after,
+                   int *n_calls, int *dma_reuse, int *last_error, int *after);
 int ref_decode_cb(const uint8_t *data, int len, int pixel_type, int options, int max_mcus,
                   int xoff, int yoff, const int *crop,
                   uint8_t *canvas, int pitch_bytes, int rows, int used_only,
                   int *log, int max_log, int stop_after,
                   int *n_calls, int *dma_reuse, int *last_error)
+{
+    return ref_decode_cb2(data, len, pixel_type, options, max_mcus, xoff, yoff, crop, canvas, pitch_bytes, rows, used_only,
+                          log, max_log, stop_after, n_calls, dma_reuse, last_error, NULL);
+}
+int ref_decode_cb2(const uint8_t *data, int len, int pixel_type, int options, int max_mcus,
+                   int xoff, int yoff, const int *crop,
+                   uint8_t *canvas, int pitch_bytes, int rows, int used_only,
+                   int *log, int max_log, int stop_after,
+                   int *n_calls, int *dma_reuse, int *last_error, int *after)
 {
     JPEGDEC *j = new JPEGDEC();
     Canvas c;
@@ -137,6 +153,7 @@ int ref_decode_cb(const uint8_t *data, int len, int pixel_type, int options, int
     if (n_calls) *n_calls = c.n_calls;
     if (dma_reuse) *dma_reuse = c.dma_reuse;
     if (last_error) *last_error = j->getLastError();
+    if (after) { after[0] = j->getWidth(); after[1] = j->getHeight(); }
     j->close();
     delete j;
     return rc;

@@ -2,6 +2,7 @@
 parse, Huffman LUTs, scan filter, quant prescale, serial pre-scan index, draw plan -- each against
 the oracle's independent restatement of the same reference stage."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -163,3 +164,55 @@ def test_exif_thumbnail_metadata_matches_the_reference(ref_scalar):
                 assert j[info.thumb_offset:info.thumb_offset + 2] == b"\xff\xd8"
     plain = ImageInfo()
     assert load_library().jda_parse(main, len(main), C.byref(plain)) == 0 and plain.has_thumb == 0
+
+
+def _dht_segments(jpeg):
+    """offsets of the DHT table headers: (offset of the Tc/Th byte) for every table of every DHT segment"""
+    out, at = [], 2
+    while at + 4 <= len(jpeg):
+        marker, seglen = jpeg[at + 1], (jpeg[at + 2] << 8) | jpeg[at + 3]
+        if marker == 0xDA:
+            break
+        if marker == 0xC4:
+            q, end = at + 4, at + 2 + seglen
+            while q + 17 <= end:
+                out.append(q)
+                q += 17 + sum(jpeg[q + 1: q + 17])
+        at += 2 + seglen
+    return out
+
+
+def test_oversubscribed_dht_is_rejected():
+    """a DHT whose counts no prefix code can have (more codes of a length than there are bit patterns) made
+    build_ac_lut / build_dc_lut write far outside the LUT.  Such a table is refused (JDA_UNSUPPORTED_FEATURE, the code
+    JPEGMakeHuffTables failures map to, jpeg.inl:1771-1775) -- for every table of the file, DC and AC."""
+    base = jpeg_for("c420_333x217")
+    tabs = _dht_segments(base)
+    assert len(tabs) == 4
+    for q in tabs:
+        for length, count in ((1, 255), (1, 3), (2, 5), (3, 9)):
+            b = bytearray(base)
+            total = sum(b[q + 1: q + 17])
+            if count > total:
+                continue
+            # keep the total (the symbol bytes stay where they are): move `count` codes to `length`
+            counts = [0] * 16
+            counts[length - 1] = count
+            counts[15] = total - count
+            b[q + 1: q + 17] = bytes(counts)
+            with pytest.raises(J.JdaError) as e:
+                J.PreparedImage(bytes(b))
+            assert e.value.code in (2, 3), (q, length, count, e.value.code)
+
+
+def test_frontend_fuzz_under_asan_ubsan():
+    """Header mutations (DHT / DQT / SOF / SOS / APPn bytes, truncations) and scan corruptions through jda_parse, jda_prepare_ex,
+    the draw plan and the crop rounding, compiled with -fsanitize=address,undefined: any out-of-bounds access or UB aborts."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "frontfuzz"], cwd=root, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    exe = os.path.join(root, "tests", "fuzz", "frontend_fuzz")
+    for seed, rel in enumerate(("golden/ref/tulips.jpg", "golden/ref/thumb_test.jpg", "golden/c444_8x8_q30.jpg", "golden/c420_16x16.jpg",
+                                "golden/gray_64x64_rst3.jpg", "golden/c440_300x64_rst5.jpg", "golden/p420_200x120.jpg", "golden/ref/corrupt5.jpg")):
+        p = subprocess.run([exe, os.path.join(root, "tests", rel), "2500", str(seed + 1)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert p.returncode == 0, (rel, p.stdout[-3000:])
