@@ -152,6 +152,10 @@ int jda_draw_plan(const jda_image_info *info, int32_t pixel_type, int32_t option
 void jda_crop_round(const jda_image_info *info, int32_t *x, int32_t *y, int32_t *w, int32_t *h);
 int jda_draw_plan_ex(const jda_image_info *info, int32_t pixel_type, int32_t options, int32_t max_mcus,
                      int32_t uses_dma, const int32_t *crop, int32_t *rects, int32_t max_rects);
+/* The same for decode(xoff, ..): the reference's strip widths of a CROPPED decode depend on the x offset passed to decode()
+ * (jpeg.inl:5328 compares jd.x, offset included, with iCropX + iCropCX).  rects as above, x / y relative to the offset. */
+int jda_draw_plan_at(const jda_image_info *info, int32_t pixel_type, int32_t options, int32_t max_mcus,
+                     int32_t uses_dma, const int32_t *crop, int32_t xoff, int32_t *rects, int32_t max_rects);
 
 /* ------------------------------------------------------------------ device runtime */
 

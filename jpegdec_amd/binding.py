@@ -74,6 +74,7 @@ _PROTOTYPES = [
     ("jda_draw_plan", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     ("jda_crop_round", None, [C.POINTER(ImageInfo)] + [C.POINTER(C.c_int32)] * 4),
     ("jda_draw_plan_ex", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
+    ("jda_draw_plan_at", C.c_int, [C.POINTER(ImageInfo), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32]),
     ("jda_device_count", C.c_int, []),
     ("jda_create", _P, [C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_destroy", None, [_P]),

@@ -292,8 +292,8 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     } else if (s->draw) {
         std::vector<int32_t> rects(8 * 65536);
         const int32_t crop[4] = { s->crop_x, s->crop_y, s->crop_w, s->crop_h };
-        int n = jda_draw_plan_ex(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0,
-                                 cropped ? crop : NULL, rects.data(), 65536);
+        int n = jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0,
+                                 cropped ? crop : NULL, s->xoff, rects.data(), 65536);
         // with JPEG_USES_DMA (and no user cap on the MCU count) the strip ping-pongs between the two halves
         bool dma = (iOptions & JPEG_USES_DMA) != 0;
         {   // the halves only alternate when the user cap did not win (jpeg.inl:5071-5076)
@@ -315,7 +315,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
                 if ((r[7] / mh) * s->info.mcus_x + x_last >= mcus_decoded) break;
             }
             uint16_t *buf = s->strip + (dma ? half * (MAX_BUFFERED_PIXELS / 2) : 0);
-            const int row_bytes = r[2] * bpp;
+            const int row_bytes = r[2] > 0 ? r[2] * bpp : 0;
             for (int rr = 0; rr < mh; rr++) {
                 const int cy_ = r[7] + rr;                       // strip position in the decoded canvas
                 uint8_t *dst = (uint8_t *)buf + (size_t)rr * row_bytes;

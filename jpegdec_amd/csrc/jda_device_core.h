@@ -91,22 +91,25 @@ JDA_HD uint32_t jda_ac_entry(uint32_t raw)
 #ifndef JDA_LONG_LDS_MODES
 #define JDA_LONG_LDS_MODES 0x1fu     // bit per JDA_MODE_*: the layouts that stage the long AC halves
 #endif
-template <int MODE> struct jda_lds_layout {       // the per-WAVE region
+// The per-WAVE region.  BIG = 1: one wavefront less per workgroup, its LDS shared out as a larger scan window -- the kernel
+// variant for high-bitrate images (a tile whose slice of the scan does not fit the window takes the general reader, which
+// goes to HBM at every refill: 3-4x slower in P1).
+template <int MODE, int BIG = 0> struct jda_lds_layout {
     enum {
         MCUS = JDA_TILE_THREADS / jda_mode_traits<MODE>::NBLK,       // MCUs per tile: 10 / 21 / 64
         BLOCKS = MCUS * jda_mode_traits<MODE>::NBLK,                 // blocks per tile: 60 / 63 / 64
         // one 136-byte slot per block: int16[64] coefficients, later (first 64 bytes) its 8x8 samples --
         // the row stage stores its bytes over the block it has just read, as the reference does (:2682)
         COEF_OFF = 0,
-        COLLIST_OFF = COEF_OFF + BLOCKS * JDA_COEF_STRIDE,           // uint16 items
-        COLLIST_ENTRIES = BLOCKS * 8,                               // every column of every block
-        WIN_OFF = COLLIST_OFF,                                      // (shared with the column list, see above)
-        WIN_BYTES = (COLLIST_ENTRIES * 2) / 16 * 16 > 1024 ? 1024 : (COLLIST_ENTRIES * 2) / 16 * 16,   // one 16-byte chunk per lane at most
-        // the row list comes right after the column list: a block writes eight column items whatever it has (jda_p1_lists),
-        // up to seven past the list's end, i.e. into row list bytes that are only written afterwards
-        ROWLIST_OFF = COLLIST_OFF + COLLIST_ENTRIES * 2,            // 64 block ids (uint8), grouped by row class
+        ROWLIST_OFF = COEF_OFF + BLOCKS * JDA_COEF_STRIDE,          // 64 block ids (uint8), grouped by row class
         CNT_OFF = ROWLIST_OFF + JDA_TILE_THREADS,                   // 8 uint32 counters
-        WAVE_BYTES = CNT_OFF + 32,                                  // 9,216 B (4:2:0)
+        // the column list comes last, and the scan window lies over it and over everything that is left of the wavefront's
+        // share of the LDS behind it.  (A block writes eight column items whatever it has (jda_p1_lists), up to seven past
+        // the list's end: window bytes, dead by then.)
+        COLLIST_OFF = (CNT_OFF + 32 + 15) / 16 * 16,                // uint16 items
+        COLLIST_ENTRIES = BLOCKS * 8,                               // every column of every block
+        WIN_OFF = COLLIST_OFF,
+        BASE_BYTES = COLLIST_OFF + COLLIST_ENTRIES * 2 + 16,        // what a wavefront needs at least
         PLANE_OFF = COEF_OFF,
         PLANE_STRIDE = jda_mode_traits<MODE>::NBLK * JDA_COEF_STRIDE, // bytes between consecutive MCUs' samples
         // Codes that start 111111 -- every code of 10 bits and more of the Annex K tables -- are looked up in the long halves of
@@ -115,8 +118,14 @@ template <int MODE> struct jda_lds_layout {       // the per-WAVE region
         // tile's output stores.  So the long halves are staged too
         LONG_LDS = JDA_LONG_LDS_MODES >> MODE & 1,
         TAB_BYTES = JDA_LT_BYTES + (LONG_LDS ? JDA_LT_LONG_BYTES : 0),
-        // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy (and the 16-byte draw counter)
-        WAVES = (160 * 1024 - TAB_BYTES - 16) / WAVE_BYTES > 16 ? 16 : (160 * 1024 - TAB_BYTES - 16) / WAVE_BYTES
+        // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy (and the 16-byte draw
+        // counter), 16 at most; every wavefront gets an equal share of what is there, and what it does not need is window
+        LDS_FREE = 160 * 1024 - TAB_BYTES - 16,
+        WAVES_MAX = LDS_FREE / BASE_BYTES > 16 ? 16 : LDS_FREE / BASE_BYTES,
+        WAVES = WAVES_MAX - BIG,
+        WAVE_BYTES = LDS_FREE / WAVES / 16 * 16,                    // 9,568 B (4:2:0), 10,208 B with BIG
+        WIN_BYTES = WAVE_BYTES - WIN_OFF > 2048 ? 2048 : WAVE_BYTES - WIN_OFF,     // 1,312 B (4:2:0), 1,952 B with BIG
+        WIN_CHUNKS = (WIN_BYTES + 1023) / 1024                      // 16-byte chunks a lane copies when the window is staged
     };
 };
 
@@ -300,26 +309,34 @@ JDA_HD void jda_refill(jda_bitreader &br)
 struct jda_chunk16 { uint32_t w[4]; };
 typedef jda_chunk16 __attribute__((may_alias)) jda_chunk16_alias;
 // the same copy split in two so the HBM load can be issued early and the LDS store done late
-// (WIN_BYTES <= 64 lanes x 16 bytes: one chunk per lane)
-JDA_HD jda_chunk16 jda_window_load(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint32_t lane)
+// (the window is NCH x 64 lanes x 16 bytes at most: lane l copies chunks l, l + 64, ..)
+template <int NCH> struct jda_chunks { jda_chunk16 c[NCH]; };
+template <int NCH>
+JDA_HD jda_chunks<NCH> jda_window_load(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint32_t lane)
 {
-    jda_chunk16 c;
-    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
-    if (lane < (win_len >> 4)) {
-        const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
-        const jda_chunk16_alias v = src[lane];
-        c.w[0] = v.w[0]; c.w[1] = v.w[1]; c.w[2] = v.w[2]; c.w[3] = v.w[3];
+    jda_chunks<NCH> r;
+    const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        r.c[k].w[0] = r.c[k].w[1] = r.c[k].w[2] = r.c[k].w[3] = 0;
+        if (lane + 64u * (uint32_t)k < (win_len >> 4)) {
+            const jda_chunk16_alias v = src[lane + 64u * (uint32_t)k];
+            r.c[k].w[0] = v.w[0]; r.c[k].w[1] = v.w[1]; r.c[k].w[2] = v.w[2]; r.c[k].w[3] = v.w[3];
+        }
     }
-    return c;
+    return r;
 }
-JDA_HD void jda_window_store(uint8_t *win, uint32_t win_len, uint32_t lane, const jda_chunk16 &c)
+template <int NCH>
+JDA_HD void jda_window_store(uint8_t *win, uint32_t win_len, uint32_t lane, const jda_chunks<NCH> &r)
 {
-    if (lane < (win_len >> 4)) {
-        jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
-        jda_chunk16_alias v;                            // every dword with the stream's first byte on top: P1's bit buffer takes them as they are
-        v.w[0] = __builtin_bswap32(c.w[0]); v.w[1] = __builtin_bswap32(c.w[1]); v.w[2] = __builtin_bswap32(c.w[2]); v.w[3] = __builtin_bswap32(c.w[3]);
-        dst[lane] = v;
-    }
+    jda_chunk16_alias *dst = (jda_chunk16_alias *)win;
+#pragma unroll
+    for (int k = 0; k < NCH; k++)
+        if (lane + 64u * (uint32_t)k < (win_len >> 4)) {
+            jda_chunk16_alias v;                        // every dword with the stream's first byte on top: P1's bit buffer takes them as they are
+            v.w[0] = __builtin_bswap32(r.c[k].w[0]); v.w[1] = __builtin_bswap32(r.c[k].w[1]); v.w[2] = __builtin_bswap32(r.c[k].w[2]); v.w[3] = __builtin_bswap32(r.c[k].w[3]);
+            dst[lane + 64u * (uint32_t)k] = v;
+        }
 }
 
 JDA_HD void jda_window_fill(const uint8_t JDA_GLOBAL *scan, uint32_t win_lo, uint32_t win_len, uint8_t *win, uint32_t lane)
@@ -601,7 +618,12 @@ JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint
     // never looks at marker positions, so a stream whose markers sit elsewhere must take the serial path
     const uint32_t end_byte = br.pos + ((br.off + 7u) >> 3);
     if (k + 1 < P.n_intervals) { if (end_byte != rpos[k + 1]) R.mismatch = 1; }
-    else blk_index[(size_t)P.n_mcus * P.nblocks] = (br.pos << JDA_INDEX_OFF_BITS) | br.off;
+    else {
+        // the closing entry = the reader as the serial pre-scan leaves it: a restart interval that ends with the image is still
+        // rounded up to a byte (jpeg.inl:5339-5346 runs after the last MCU as well)
+        const uint32_t off_end = count == P.interval_mcus ? ((br.off + 7u) & ~7u) : br.off;
+        blk_index[(size_t)P.n_mcus * P.nblocks] = (br.pos << JDA_INDEX_OFF_BITS) | off_end;
+    }
     return R;
 }
 
@@ -1255,7 +1277,7 @@ struct jda_tile_ctx {                 // wave-uniform facts about the tile, comp
 // same, from index entries already in registers: ix_first = index[first block of the tile],
 // ix_end = index[first block after the tile]
 template <int MODE>
-JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &S, uint32_t ix_first, uint32_t ix_end)
+JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &S, uint32_t ix_first, uint32_t ix_end, uint32_t win_cap = (uint32_t)jda_lds_layout<MODE>::WIN_BYTES)
 {
     typedef jda_mode_traits<MODE> T;
     jda_tile_ctx C;
@@ -1272,7 +1294,7 @@ JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
         C.win_need = C.win_len;
-        if (C.win_len > (uint32_t)jda_lds_layout<MODE>::WIN_BYTES) C.win_len = (uint32_t)jda_lds_layout<MODE>::WIN_BYTES;
+        if (C.win_len > win_cap) C.win_len = win_cap;
     }
     return C;
 }

@@ -223,12 +223,13 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
 #ifndef JDA_EXP_SKIP
 #define JDA_EXP_SKIP 0       // profiling builds (tools/phase_count_libs.sh): 1 no P4, 2 no P3, 4 no P2, 8 no lists, 16 no P1
 #endif
-template <int MODE, bool FAST, int VARIANT>
-__global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
+template <int MODE, bool FAST, int VARIANT, int BIG>
+__global__ __launch_bounds__((64 * jda_lds_layout<MODE, BIG>::WAVES))
 void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    typedef jda_lds_layout<MODE> L;
+    typedef jda_lds_layout<MODE, BIG> L;
+    typedef jda_chunks<L::WIN_CHUNKS> chunks_t;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // runs of n_quads / grid groups of tiles, the remainder one more each for the first workgroups (rounding the run length up
     // instead left the last workgroups of a 64-image batch with half a run and none: 0.6 % of the kernel's time)
@@ -250,7 +251,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     uint32_t staged = R0.ord;                                                            // image (ordinal) whose tables are in LDS
     const uint32_t last_ord = jda_load_record(tiles + (t_end - 1u)).ord;
     jda_dev_desc Dc = jda_desc_uniform<VARIANT, MODE>(descs + R0.image);
-    jda_p0_tables(Dc, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab, L::LONG_LDS != 0);
+    jda_p0_tables(Dc, threadIdx.x, 64 * L::WAVES, tab, L::LONG_LDS != 0);
     __syncthreads();                                  // tables staged, counter set
 
     uint32_t i_cur = jda_draw_tile<MODE>(ctr, lane);
@@ -270,11 +271,11 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     do {                                                                                                          \
         uint32_t ixe_;                                                                                            \
         jda_issue_index_loads<MODE>(Dc, S, lane, in, ixe_);                                                       \
-        C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ixe_)); \
+        C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ixe_), (uint32_t)L::WIN_BYTES); \
         C.count = __builtin_amdgcn_readfirstlane(C.count);                                                        \
         C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);                                                      \
         C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);                                                    \
-        jda_window_store(wl + L::WIN_OFF, C.win_len, lane, jda_window_load(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane)); \
+        jda_window_store<L::WIN_CHUNKS>(wl + L::WIN_OFF, C.win_len, lane, jda_window_load<L::WIN_CHUNKS>(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane)); \
         asm volatile("" : "+v"(in.ix), "+v"(in.pred));   /* nothing in flight when the loop (re)starts */                                \
     } while (0)
     JDA_TILE_COLD_START();
@@ -324,18 +325,19 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // stage C: index entries are here -> window bounds -> the next tile's scan slice (HBM -> registers),
         // in flight during the column stage
         jda_tile_ctx Cn = C;
-        jda_chunk16 chunk;
-        chunk.w[0] = chunk.w[1] = chunk.w[2] = chunk.w[3] = 0;
+        chunks_t chunk;
+#pragma unroll
+        for (int k = 0; k < L::WIN_CHUNKS; k++) chunk.c[k].w[0] = chunk.c[k].w[1] = chunk.c[k].w[2] = chunk.c[k].w[3] = 0;
         // the index loads and the record have landed: settle their waits HERE.  Left to the compiler, the record's wait
         // lands after P4 (where it is consumed) as s_waitcnt vmcnt(0) -- the counter is shared with stores on gfx9, so the
         // wavefront would sit out the write acknowledgements of its own tile before starting the next one
         asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
         if (pipelined) {
-            Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end));
+            Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end), (uint32_t)L::WIN_BYTES);
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
             Cn.win_lo = __builtin_amdgcn_readfirstlane(Cn.win_lo);
             Cn.win_len = __builtin_amdgcn_readfirstlane(Cn.win_len);
-            chunk = jda_window_load(JDA_G(const uint8_t, D.scan), Cn.win_lo, Cn.win_len, lane);
+            chunk = jda_window_load<L::WIN_CHUNKS>(JDA_G(const uint8_t, D.scan), Cn.win_lo, Cn.win_len, lane);
         }
 
         JDA_PTRACE(3);
@@ -348,8 +350,9 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // stage D: scan slice -> the LDS window (this tile's P1, its only reader, is over).  The load is settled for every
         // lane, also those that store nothing: a load the compiler still counts as pending at the loop's back edge costs
         // an s_waitcnt vmcnt(0) at the top of the next tile, i.e. behind this tile's output stores
-        asm volatile("" : "+v"(chunk.w[0]), "+v"(chunk.w[1]), "+v"(chunk.w[2]), "+v"(chunk.w[3]));
-        if (pipelined) jda_window_store(wl + L::WIN_OFF, Cn.win_len, lane, chunk);
+#pragma unroll
+        for (int k = 0; k < L::WIN_CHUNKS; k++) asm volatile("" : "+v"(chunk.c[k].w[0]), "+v"(chunk.c[k].w[1]), "+v"(chunk.c[k].w[2]), "+v"(chunk.c[k].w[3]));
+        if (pipelined) jda_window_store<L::WIN_CHUNKS>(wl + L::WIN_OFF, Cn.win_len, lane, chunk);
 
         JDA_PTRACE(5);
         if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 2)) {
@@ -384,14 +387,16 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u + 1u] = wall_clock64();
 }
 
-template <int MODE, bool FAST, int VARIANT>
+template <int MODE, bool FAST, int VARIANT, int BIG = 0>
 static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    const int lds_bytes = jda_lds_layout<MODE>::TAB_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16;   // + the draw counter
-    static_assert(jda_lds_layout<MODE>::TAB_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
+    typedef jda_lds_layout<MODE, BIG> L;
+    const int lds_bytes = L::TAB_BYTES + L::WAVES * L::WAVE_BYTES + 16;   // + the draw counter
+    static_assert(L::TAB_BYTES + L::WAVES * L::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
+    static_assert(L::WIN_BYTES >= L::COLLIST_ENTRIES * 2 + 16 && L::WIN_BYTES % 16 == 0 && L::WIN_OFF % 16 == 0, "the window covers the column list and its overrun");
     static int grid_cap = 0;
     if (!grid_cap) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT>,
+        hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
@@ -399,9 +404,9 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
         const int per_cu = (160 * 1024) / lds_bytes;
         grid_cap = cus * (per_cu > 0 ? per_cu : 1);
     }
-    const uint32_t n_quads = n_tiles / jda_lds_layout<MODE>::WAVES;
+    const uint32_t n_quads = n_tiles / L::WAVES;
     const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
-    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST, VARIANT>), dim3(grid), dim3(64 * jda_lds_layout<MODE>::WAVES), lds_bytes, stream,
+    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG>), dim3(grid), dim3(64 * L::WAVES), lds_bytes, stream,
                        descs, tiles, n_quads);
     return hipGetLastError();
 }
@@ -719,7 +724,7 @@ extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)
 }
 
 // Launch entry used by jda_runtime.cpp.  n_tiles is a multiple of jda_lds_layout<MODE>::WAVES (padded per image).
-extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, const jda_dev_desc *descs, const jda_strip *tiles,
+extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, const jda_dev_desc *descs, const jda_strip *tiles,
                                         uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
@@ -737,6 +742,19 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, con
         case JDA_MODE_422 * 2 + 1: return launch<JDA_MODE_422, true>(descs, tiles, n_tiles, stream);
         case JDA_MODE_440 * 2 + 0: return launch<JDA_MODE_440, false>(descs, tiles, n_tiles, stream);
         case JDA_MODE_440 * 2 + 1: return launch<JDA_MODE_440, true>(descs, tiles, n_tiles, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (big) {                                        // the large-window kernels for high-bitrate images (jda_big_window in jda_runtime.cpp decides who gets here)
+        switch (mode * 4 + variant) {
+        case JDA_MODE_GRAY * 4 + 0: return launch_persistent<JDA_MODE_GRAY, true, 0, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_444 * 4 + 0: return launch_persistent<JDA_MODE_444, true, 0, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 0: return launch_persistent<JDA_MODE_420, true, 0, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_422 * 4 + 0: return launch_persistent<JDA_MODE_422, true, 0, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_440 * 4 + 0: return launch_persistent<JDA_MODE_440, true, 0, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_444 * 4 + 1: return launch_persistent<JDA_MODE_444, true, 1, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 1: return launch_persistent<JDA_MODE_420, true, 1, 1>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_422 * 4 + 1: return launch_persistent<JDA_MODE_422, true, 1, 1>(descs, tiles, n_tiles, stream);
         default: return hipErrorInvalidValue;
         }
     }

@@ -71,14 +71,25 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
 // 64 of gray); one wavefront decodes one tile, and a workgroup is as many wavefronts as fit in a CU's LDS
 // next to one copy of the tables (16 for 4:2:0, 15 otherwise).  The list is padded with empty tiles per
 // image so that a workgroup never spans two images (it stages one table set).
-inline uint32_t jda_tiles_per_wg(int mode)
+inline uint32_t jda_tiles_per_wg(int mode, int big = 0)
 {
     switch (mode) {
-    case JDA_MODE_420: return (uint32_t)jda_lds_layout<JDA_MODE_420>::WAVES;
-    case JDA_MODE_444: return (uint32_t)jda_lds_layout<JDA_MODE_444>::WAVES;
-    case JDA_MODE_422: return (uint32_t)jda_lds_layout<JDA_MODE_422>::WAVES;
-    case JDA_MODE_440: return (uint32_t)jda_lds_layout<JDA_MODE_440>::WAVES;
-    default: return (uint32_t)jda_lds_layout<JDA_MODE_GRAY>::WAVES;
+    case JDA_MODE_420: return (uint32_t)jda_lds_layout<JDA_MODE_420>::WAVES - (uint32_t)big;
+    case JDA_MODE_444: return (uint32_t)jda_lds_layout<JDA_MODE_444>::WAVES - (uint32_t)big;
+    case JDA_MODE_422: return (uint32_t)jda_lds_layout<JDA_MODE_422>::WAVES - (uint32_t)big;
+    case JDA_MODE_440: return (uint32_t)jda_lds_layout<JDA_MODE_440>::WAVES - (uint32_t)big;
+    default: return (uint32_t)jda_lds_layout<JDA_MODE_GRAY>::WAVES - (uint32_t)big;
+    }
+}
+// bytes of scan window a wavefront of the kernel has (BIG = 0 / 1)
+inline uint32_t jda_window_bytes(int mode, int big)
+{
+    switch (mode) {
+    case JDA_MODE_420: return big ? (uint32_t)jda_lds_layout<JDA_MODE_420, 1>::WIN_BYTES : (uint32_t)jda_lds_layout<JDA_MODE_420, 0>::WIN_BYTES;
+    case JDA_MODE_444: return big ? (uint32_t)jda_lds_layout<JDA_MODE_444, 1>::WIN_BYTES : (uint32_t)jda_lds_layout<JDA_MODE_444, 0>::WIN_BYTES;
+    case JDA_MODE_422: return big ? (uint32_t)jda_lds_layout<JDA_MODE_422, 1>::WIN_BYTES : (uint32_t)jda_lds_layout<JDA_MODE_422, 0>::WIN_BYTES;
+    case JDA_MODE_440: return big ? (uint32_t)jda_lds_layout<JDA_MODE_440, 1>::WIN_BYTES : (uint32_t)jda_lds_layout<JDA_MODE_440, 0>::WIN_BYTES;
+    default: return big ? (uint32_t)jda_lds_layout<JDA_MODE_GRAY, 1>::WIN_BYTES : (uint32_t)jda_lds_layout<JDA_MODE_GRAY, 0>::WIN_BYTES;
     }
 }
 inline uint32_t jda_mcus_per_tile(int mode)
@@ -86,7 +97,7 @@ inline uint32_t jda_mcus_per_tile(int mode)
     return mode == JDA_MODE_420 ? 10u : mode == JDA_MODE_444 ? 21u : (mode == JDA_MODE_422 || mode == JDA_MODE_440) ? 16u : 64u;
 }
 
-inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode)
+inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, int big = 0)
 {
     const uint32_t per = jda_mcus_per_tile(mode);
     const uint32_t ord = v.empty() ? 0u : v.back().ord + 1u;      // images are appended one after the other
@@ -101,7 +112,7 @@ inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_
             first = false;
             v.push_back(s);
         }
-    while (v.size() % jda_tiles_per_wg(mode)) {
+    while (v.size() % jda_tiles_per_wg(mode, big)) {
         jda_strip s;
         memset(&s, 0, sizeof(s));
         s.image = image; s.ord = ord;

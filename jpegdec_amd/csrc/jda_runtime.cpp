@@ -30,10 +30,10 @@ extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint3
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
 extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
-extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, const jda_dev_desc *descs, const jda_strip *strips,
+extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
-// launch lists of a batch: one per (mode, fast_mul, kernel variant); index = (mode * 2 + fast) * 4 + variant
-#define JDA_N_LISTS (8 * JDA_N_MODES)
+// launch lists of a batch: one per (mode, fast_mul, kernel variant, window size); index = ((mode * 2 + fast) * 4 + variant) * 2 + big
+#define JDA_N_LISTS (16 * JDA_N_MODES)
 // The plain-case kernel variants (jda_desc_uniform in jda_kernels.hip): full size, every multiply in 24 bits, no stream flags,
 // and one of the (layout, output format) pairs a kernel was built for.  0 = the general kernel.
 static int jda_plain_variant(const jda_dev_desc &D)
@@ -44,6 +44,26 @@ static int jda_plain_variant(const jda_dev_desc &D)
     if (D.pixel_type == JDA_RGB565_LITTLE_ENDIAN && colour && !D.gray_from_color) return (D.mode == JDA_MODE_444 || D.mode == JDA_MODE_420) ? 2 : 0;
     if (D.pixel_type == JDA_EIGHT_BIT_GRAYSCALE) return (D.mode == JDA_MODE_GRAY || (D.mode == JDA_MODE_420 && D.gray_from_color)) ? 3 : 0;
     return 0;
+}
+
+// High-bitrate images go to the kernel variant with one wavefront less per CU and a larger scan window (jda_lds_layout<MODE, 1>):
+// a tile whose slice of the scan does not fit the window takes the general bit reader, which goes to HBM at every refill.
+// Decided per image from its average bytes of scan per full tile (+ 50 % for the spread between tiles); the kernels exist for
+// the general variant and the RGB8888 plain case, 24-bit multiplies.  JDA_BIG_WINDOW=0 / 1 forces the choice (A/B runs).
+static int jda_big_window(const jda_dev_desc &D, int variant)
+{
+    static int forced = -2;
+    if (forced == -2) {
+        const char *e = getenv("JDA_BIG_WINDOW"), *k = getenv("JDA_KERNEL");
+        forced = (k && k[0] == 's') ? 0 : (e ? atoi(e) : -1);
+    }
+    if (!D.fast_mul || variant > 1) return 0;
+    if (variant == 1 && D.mode == JDA_MODE_GRAY) return 0;
+    if (forced >= 0) return forced ? 1 : 0;
+    const uint64_t n_mcus = (uint64_t)D.mcus_x * D.mcus_y;
+    if (!n_mcus) return 0;
+    const uint64_t avg = (uint64_t)D.scan_len * jda_mcus_per_tile(D.mode) / n_mcus;
+    return avg + avg / 2 + 48 > jda_window_bytes(D.mode, 0) ? 1 : 0;
 }
 
 #define JDA_POOL_SLOTS 192
@@ -645,7 +665,8 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         // kernel variant 1: the plain case -- full size, RGB8888, every block decoded -- runs a kernel in which these
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
-        jda_append_strips(strips[(D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode);
+        const int big = jda_big_window(D, variant);
+        jda_append_strips(strips[((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big);
         st.source_pixels += (int64_t)I.width * I.height;
         st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
         st.scan_bytes += im->scan_len;
@@ -665,7 +686,7 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         e = pool_alloc(ctx, (void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 8));
+        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 16, m & 1));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -694,7 +715,7 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
     if (!b) return JDA_INVALID_PARAMETER;
     for (int m = 0; m < JDA_N_LISTS; m++) {
         if (!b->n_strips[m]) continue;
-        JDA_HIP(ctx, jda_launch_decode(m >> 3, (m >> 2) & 1, m & 3, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
+        JDA_HIP(ctx, jda_launch_decode(m >> 4, (m >> 3) & 1, (m >> 1) & 3, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
     }
     return JDA_SUCCESS;
 }

@@ -245,7 +245,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             jda_image *ref = jda_prepare(jpeg, len, &e2);
             uint32_t nn = 0;
             const uint32_t *hi = ref ? jda_image_block_index(ref, &nn) : NULL;
-            g_index_equal = ref && memcmp(hi, dev_index.data(), nb * 4) == 0 && memcmp(jda_image_block_dc(ref), dev_dc.data(), nb * 2) == 0 &&
+            g_index_equal = ref && memcmp(hi, dev_index.data(), (nb + 1) * 4) == 0 && memcmp(jda_image_block_dc(ref), dev_dc.data(), nb * 2) == 0 &&
                             jda_image_truncation_events(ref) == trunc ? 1 : 0;
             if (ref && getenv("HOSTSIM_DEBUG")) { for (size_t i = 0; i < nb; i++) if (hi[i] != dev_index[i] || jda_image_block_dc(ref)[i] != dev_dc[i]) { fprintf(stderr, "first diff at block %zu: host %u/%u dc %d, dev %u/%u dc %d; trunc host %u dev %u\n", i, hi[i] >> 7, hi[i] & 127, jda_image_block_dc(ref)[i], dev_index[i] >> 7, dev_index[i] & 127, dev_dc[i], jda_image_truncation_events(ref), trunc); break; } fprintf(stderr, "trunc host %u dev %u\n", jda_image_truncation_events(ref), trunc); }
             if (ref) jda_image_free(ref);

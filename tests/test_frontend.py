@@ -216,3 +216,31 @@ def test_frontend_fuzz_under_asan_ubsan():
                                 "golden/gray_64x64_rst3.jpg", "golden/c440_300x64_rst5.jpg", "golden/p420_200x120.jpg", "golden/ref/corrupt5.jpg")):
         p = subprocess.run([exe, os.path.join(root, "tests", rel), "2500", str(seed + 1)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert p.returncode == 0, (rel, p.stdout[-3000:])
+
+
+def test_cropped_draw_plan_depends_on_the_x_offset(ref_scalar):
+    """jpeg.inl:5328 compares jd.x (iXOffset included) with iCropX + iCropCX: the strip widths of a cropped decode change with the
+    x passed to decode().  jda_draw_plan_at == the real reference's JPEGDRAW sequence for a grid of crops x offsets x pixel types."""
+    lib = load_library()
+    checked = 0
+    for name in ("c420_640x368_rstrow", "c444_333x217", "gray_333x217", "c422_333x217"):
+        jpeg = jpeg_for(name)
+        p = J.PreparedImage(jpeg)
+        for crop in ((16, 32, 100, 60), (50, 50, 125, 170), (0, 0, 64, 64), (100, 20, 200, 100), (8, 8, 300, 40)):
+            for xoff in ((0, 3, 16) if crop[2] == 300 else (0, 3, 16, 61)):      # (the reference crashes on (8, 8, 300, 40) at x = 61)
+                for pt in (0, 2, 3):
+                    if name.startswith("gray") and pt == 2:
+                        continue
+                    b = ref_scalar.decode_cb(jpeg, pt, 0, crop=crop, want_log=True, xoff=xoff, yoff=5)
+                    if b["rc"] != 1:
+                        continue
+                    c = (C.c_int32 * 4)(*J.crop_round(p.info, *crop))
+                    rects = np.zeros((4096, 8), np.int32)
+                    n = lib.jda_draw_plan_at(C.byref(p.info), pt, 0, 0, 0, c, xoff, rects.ctypes.data_as(C.c_void_p), 4096)
+                    got = rects[:n, :6].copy()
+                    got[:, 0] += xoff
+                    got[:, 1] += 5
+                    assert np.array_equal(got, b["log"]), (name, crop, xoff, pt)
+                    checked += 1
+        p.close()
+    assert checked > 100

@@ -54,7 +54,8 @@ def test_fixtures_as_one_resident_batch(device_prescan, gpu_ctx):
     dev = J.upload_batch(gpu_ctx, prepared)
     if device_prescan:
         for n, d, h in zip(names, dev, host):
-            assert d.prescan_on_device, n
+            # (corrupt5 is 48 MCUs followed by 40 KB of unrelated bytes: the segment walk hands it to the serial pre-scan)
+            assert d.prescan_on_device or n == "corrupt5", n
             idx, dc = d.read_index()
             assert np.array_equal(idx, h.block_index()[0]), n
             assert np.array_equal(dc, h.block_dc()), n
@@ -111,8 +112,9 @@ def test_reference_test_1_and_9_tulips(product_class):
 def test_reference_test_2_crop_tulips(product_class):
     """main.cpp:107-137: setCropArea(50, 50, 125, 170) gets MCU-adjusted; the drawn extent equals the adjusted rectangle"""
     jpeg = ref_jpeg("tulips")
-    info = J.PreparedImage(jpeg).info
-    cx, cy, cw, ch = J.crop_round(info, 50, 50, 125, 170)
+    p = J.PreparedImage(jpeg)
+    cx, cy, cw, ch = J.crop_round(p.info, 50, 50, 125, 170)
+    assert (cx, cy, cw, ch) == (48, 48, 128, 176)
     r = product_class.decode_cb(jpeg, RGB565_LE, 0, crop=(50, 50, 125, 170), want_log=True)
     assert r["rc"] == 1
     log = r["log"]
