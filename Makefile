@@ -10,8 +10,8 @@ CSRC  = jpegdec_amd/csrc
 EXTRA ?=
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fwrapv -pthread -Wall -Wno-unused-function -Iinclude $(EXTRA)
 LIB = jpegdec_amd/libjpegdec_amd.so
-LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
-LIB_DEPS = $(LIB_SRCS) $(CSRC)/jda_internal.h $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h include/jpegdec_amd.h include/JPEGDEC.h
+LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_pipeline.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
+LIB_DEPS = $(LIB_SRCS) $(CSRC)/jda_runtime_internal.h $(CSRC)/jda_internal.h $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h include/jpegdec_amd.h include/JPEGDEC.h
 
 all: lib oracle hostsim classshim
 

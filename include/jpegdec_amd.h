@@ -249,6 +249,35 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
 int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
                           int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded);
 
+/* ------------------------------------------------------------------ the streamed pipeline
+ * Files in, pixels resident in HBM out, batch after batch: the host parses headers and builds tables (microseconds per file);
+ * the unfiltered entropy-coded bytes go to the GPU, which filters them (JPEGFilter, jpeg.inl:1431-1540), makes the per-block
+ * index (equal to the serial pre-scan's, entry for entry) and decodes (jpeg.inl:5109-5353).  Upload + filter + pre-scan of
+ * batch n+1 run on a second stream under the decode of batch n.  Images the device walk cannot take or that fail its checks
+ * (progressive, corrupt, truncated, ...) are redone through the serial host pre-scan when the batch is waited for, so every
+ * image ends with the status -- and the pixels -- the one-image path (jda_decode_to_host) gives it.
+ *   jda_pipeline_create   max_images per batch; depth = batches in flight (1..4); host_threads <= 0: up to 8
+ *   jda_pipeline_submit   enqueue one batch; the JPEG buffers and the output surfaces (DEVICE pointers, as jda_output) must
+ *                         stay valid until the batch has been waited for.  *ticket identifies the batch.
+ *   jda_pipeline_wait     block until the batch is decoded; status[i] = JDA_SUCCESS or the image's error (may be NULL).
+ *                         A batch must be waited for before `depth` further batches are submitted.  Returns JDA_SUCCESS unless
+ *                         the pipeline itself failed (a bad image is reported in status[], it does not fail its batch). */
+typedef struct jda_pipeline jda_pipeline;
+typedef struct jda_pipeline_stats {
+    int64_t images, device_images, host_path_images, failed_images;
+    int64_t source_pixels, compressed_bytes, h2d_bytes;
+    int32_t launches, spec_rounds_max;
+} jda_pipeline_stats;
+jda_pipeline *jda_pipeline_create(jda_ctx *ctx, int32_t max_images, int32_t depth, int32_t host_threads, int32_t *err);
+void jda_pipeline_destroy(jda_pipeline *p);
+int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
+                        const int32_t *pixel_types, const int32_t *options, int32_t *ticket);
+int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status);
+int jda_pipeline_get_stats(const jda_pipeline *p, jda_pipeline_stats *out);   /* totals over the batches waited for */
+/* diagnostics: after jda_pipeline_wait(ticket), before `depth` more batches are submitted -- the per-block index (n_blocks + 1
+ * entries) and DC predictors (n_blocks) the device made for image i, and its filtered scan length (any pointer may be NULL) */
+int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t *index, int16_t *dc, uint32_t *filtered_len);
+
 const char *jda_version(void);
 
 #ifdef __cplusplus

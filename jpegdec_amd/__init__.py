@@ -19,6 +19,7 @@ from .binding import (  # noqa: F401
     Context,
     DeviceImage,
     JdaError,
+    Pipeline,
     PreparedImage,
     crop_round,
     decode_to_host,

@@ -34,6 +34,11 @@ class Output(C.Structure):
                 ("rows", C.c_int32)]
 
 
+class PipelineStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("images", "device_images", "host_path_images", "failed_images", "source_pixels",
+                                          "compressed_bytes", "h2d_bytes")] + [("launches", C.c_int32), ("spec_rounds_max", C.c_int32)]
+
+
 class BatchStats(C.Structure):
     _fields_ = [("source_pixels", C.c_int64), ("output_bytes", C.c_int64), ("scan_bytes", C.c_int64),
                 ("index_bytes", C.c_int64), ("table_bytes", C.c_int64), ("n_launches", C.c_int32),
@@ -99,6 +104,13 @@ _PROTOTYPES = [
     ("jda_timer_elapsed_ms", C.c_double, [_P]),
     ("jda_decode_to_host", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32]),
     ("jda_decode_to_host_ex", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_pipeline_create", _P, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_pipeline_destroy", None, [_P]),
+    ("jda_pipeline_submit", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(Output), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("jda_pipeline_wait", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_pipeline_get_stats", C.c_int, [_P, C.POINTER(PipelineStats)]),
+    ("jda_pipeline_read_index", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_uint32)]),
     ("jda_version", C.c_char_p, []),
 ]
 
@@ -364,6 +376,60 @@ class Batch:
     def close(self):
         if self.handle:
             self.ctx.lib.jda_batch_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+class Pipeline:
+    """The streamed pipeline (jda_pipeline_*): files in, pixels resident in HBM out; upload + filter + pre-scan of the next
+    batch run under the decode of the current one."""
+
+    def __init__(self, ctx: Context, max_images: int, depth: int = 2, host_threads: int = 0):
+        self.ctx = ctx
+        err = C.c_int32(0)
+        self.handle = ctx.lib.jda_pipeline_create(ctx.handle, max_images, depth, host_threads, C.byref(err))
+        if not self.handle:
+            raise JdaError(err.value, "jda_pipeline_create")
+        self._keep = {}
+
+    def submit(self, jpegs, outputs, pixel_types, options) -> int:
+        """outputs: list of (device_ptr, pitch_bytes, width_px, rows).  Returns the batch's ticket."""
+        n = len(jpegs)
+        arr = (C.c_char_p * n)(*jpegs)
+        lens = (C.c_int32 * n)(*[len(j) for j in jpegs])
+        outs = (Output * n)(*[Output(*o) for o in outputs])
+        pts = (C.c_int32 * n)(*pixel_types)
+        opts = (C.c_int32 * n)(*options)
+        t = C.c_int32(-1)
+        self.ctx.check(self.ctx.lib.jda_pipeline_submit(self.handle, n, arr, lens, outs, pts, opts, C.byref(t)), "jda_pipeline_submit")
+        self._keep[t.value] = (jpegs, arr, lens, outs, pts, opts, n)      # the buffers stay alive until the batch is waited for
+        return t.value
+
+    def wait(self, ticket: int):
+        """Blocks until the batch is decoded; returns the list of per-image status codes."""
+        n = self._keep[ticket][-1]
+        st = (C.c_int32 * n)()
+        self.ctx.check(self.ctx.lib.jda_pipeline_wait(self.handle, ticket, st), "jda_pipeline_wait")
+        del self._keep[ticket]
+        return list(st)
+
+    def read_index(self, ticket: int, i: int, n_blocks: int):
+        idx = np.zeros(n_blocks + 1, np.uint32)
+        dc = np.zeros(n_blocks, np.int16)
+        flen = C.c_uint32(0)
+        rc = self.ctx.lib.jda_pipeline_read_index(self.handle, ticket, i, idx.ctypes.data_as(_P), dc.ctypes.data_as(_P), C.byref(flen))
+        if rc != 0:
+            raise JdaError(rc, "jda_pipeline_read_index")
+        return idx, dc, flen.value
+
+    @property
+    def stats(self):
+        st = PipelineStats()
+        self.ctx.lib.jda_pipeline_get_stats(self.handle, C.byref(st))
+        return {k: getattr(st, k) for k, _ in PipelineStats._fields_}
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.jda_pipeline_destroy(self.handle)
             self.handle = None
 
 

@@ -501,6 +501,9 @@ struct jda_prescan_params {
     uint32_t *stats;                 // EXACT out: [0] first bad MCU (min), [1] marker mismatch, [2] max AC category, [3] max |DC|, [4] truncated reads
     uint32_t scan_len, n_intervals, n_mcus, interval_mcus;
     uint8_t nluma, nblocks, dc_id[3], ac_id[3];
+    // when the marker filter ran on the device too (jda_pipeline): [0] filtered length (replaces scan_len), [1] RSTn markers seen
+    // (must be n_intervals - 1, else the stream takes the serial host path); NULL otherwise
+    const uint32_t *filter_result;
 };
 struct jda_prescan_result { uint32_t first_bad, mismatch, max_ac_bits, max_abs_dc, trunc_events, phase_map; };
 
@@ -1072,7 +1075,7 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 #define JDA_SEG_SLOT  268u           // bytes a lane reads: its segment + 12 bytes of the next; 67 dwords per lane in LDS (odd: no bank conflicts)
 #define JDA_SEG_DEAD  0x7fffffffu    // state of a walk that met an invalid code (bit 31 is the rounds' "changed" mark)
 #define JDA_SEG_CHANGED 0x80000000u // entry-state word: "differs from the previous round's" (the walker's own bits are 14:0)
-enum { JDA_SEG_SPEC = 0, JDA_SEG_COUNT = 1, JDA_SEG_WRITE = 2 };
+enum { JDA_SEG_SPEC = 0, JDA_SEG_COUNT = 1, JDA_SEG_WRITE = 2, JDA_SEG_FUSED = 3 /* SPEC and COUNT in one walk: jda_segscan_fused */ };
 
 struct jda_segscan_params {          // one per image
     const uint8_t *scan;             // filtered scan (global), zero padded to n_segs * JDA_SEG_BYTES + 16
@@ -1085,7 +1088,17 @@ struct jda_segscan_params {          // one per image
     uint32_t *stats;                 // [0] bad, [1] terminal entry written, [2] max AC category, [3] max |DC|, [4] truncated reads, [5] states changed in this round
     uint32_t scan_len, n_segs, n_blocks_total, first_round;
     uint8_t nluma, nblocks, dc_id[3], ac_id[3];
+    const uint32_t *filter_result;   // device filter ran (jda_pipeline): [0] = the filtered length; scan_len / n_segs above are upper bounds then
+    uint32_t *worklist;              // jda_segscan_fused: two lists of n_segs (upper bound) segment numbers -- who walks in the next round
+    uint32_t worklist_cap;
 };
+// the parameters with what only the device knows filled in
+JDA_HD jda_segscan_params jda_segscan_resolve(const jda_segscan_params &in)
+{
+    jda_segscan_params P = in;
+    if (P.filter_result) { P.scan_len = JDA_G(const uint32_t, P.filter_result)[0]; P.n_segs = P.scan_len / 256u + 1u; }
+    return P;
+}
 struct jda_seg_sum { uint32_t nblk; int32_t dcsum[3]; uint32_t phase_map, bad; };
 struct jda_seg_stats { uint32_t bad, terminal, max_ac_bits, max_abs_dc, trunc_events; };
 
@@ -1097,148 +1110,174 @@ JDA_HD void jda_atomic_or_u32(uint32_t *p, uint32_t v)
     *p |= v;                                         // (the emulator steps the lanes one after another)
 #endif
 }
-// the next 32 bits of the stream at bit `bit` of the lane's slot (dword-aligned reads; big-endian bit order)
+// the next 32 bits of the stream at bit `bit` of the lane's slot.  The slot holds the segment as byte-swapped dwords (the
+// stream's first byte on top: jda_seg_stage_word), so two aligned reads and a funnel shift give the bits
+JDA_HD uint32_t jda_seg_stage_word(uint32_t v) { return __builtin_bswap32(v); }
 JDA_HD uint32_t jda_seg_fetch(const uint8_t *slot, uint32_t bit)
 {
     const jda_u32_alias *d = (const jda_u32_alias *)(slot + ((bit >> 5) << 2));
-    const uint64_t v = ((uint64_t)__builtin_bswap32(d[0]) << 32) | __builtin_bswap32(d[1]);
+    const uint64_t v = ((uint64_t)d[0] << 32) | d[1];
     return (uint32_t)((v << (bit & 31u)) >> 32);
 }
-// eight bit offsets, one per byte: the reference's refill (jpeg.inl:2110-2114) on each
-JDA_HD uint64_t jda_ph8_refill(uint64_t x)
+
+// The walk's own DC table (JDA_LT_DC16, built while the tables are staged): the reference's DC LUT (jpeg.inl:1098-1152) re-laid
+// out like the AC entries -- (code length - 1) << 12 | SSSS << 8 | folded -- so that one 16-bit lookup serves a DC and an AC
+// symbol alike.  "folded" (bit 0): the reference takes code and magnitude from the LUT in one step (:1132-1152) and does not
+// refill between them.
+#define JDA_LT_DC16 (JDA_LT_BYTES + JDA_LT_LONG_BYTES)      // 2 x 256 uint16
+#define JDA_LT_DC16_BYTES 1024
+#define JDA_LT_WALK_BYTES (JDA_LT_DC16 + JDA_LT_DC16_BYTES)
+JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
 {
-    const uint64_t K = 0x0101010101010101ull;
-    const uint64_t ge48 = ((x + (0x80u - 48u) * K) & (0x80u * K)) >> 7;   // offsets stay below 128: no carry between bytes
-    const uint64_t m = ge48 * 0xffu;
-    return (x & ~m) | (x & m & (0x07u * K));
+    if (e8 == 0u) return JDA_AC_NONE;
+    const uint32_t s = e8 & 15u, tot = e8 >> 4;
+    const bool fold = s != 0u && folded != 0;
+    const uint32_t len = fold ? tot - s : tot;                   // a folded entry holds code + magnitude length
+    return ((len - 1u) << 12) | (s << 8) | (fold ? 1u : 0u);
 }
 
-// lt: the tables in the kernels' LDS layout (JDA_LT_*, long AC halves included); slot: the segment's bytes (JDA_SEG_SLOT readable)
+// One walk of a segment.  lt: the tables in the kernels' LDS layout + the long AC halves + JDA_LT_DC16; slot: the segment's
+// bytes as jda_seg_stage_word leaves them (JDA_SEG_SLOT readable).
+//
+// A step decodes ONE symbol, DC or AC alike, without a branch on which it is: the lanes of a wavefront sit at unrelated places
+// of their blocks, so "if DC .. else AC .." ran both sides every step.  The reference's refills (jpeg.inl:2110-2114) happen at
+// fixed places -- before a block's first symbol, before a DC magnitude that is not folded into its LUT entry, at the top and
+// the bottom of the AC loop -- and two of them in a row at the same bit are one; so a step is: [refill before an unfolded DC
+// magnitude] .. refill at its end (bottom of the AC loop / top of it after the DC symbol / opening refill of the next block
+// after EOB: same position, same result).  State at a step boundary, hence at a segment boundary: after that refill.
+//   SPEC   exit state only.
+//   COUNT  + block starts, DC sums per component, and how the reference window's BYTE LAG u = (p >> 3) - pBuf propagates: the
+//          six lags a boundary state can have (a refill leaves off <= 47) ride in 5-bit fields of one word (4 value bits + a
+//          guard bit for the compare); bits consumed advance all of them by the same number of bytes, a refill resets those
+//          that reached 6 bytes.  phase_map: field j (3 bits) = exit lag for entry lag j.
+//   WRITE  the reader itself (pBuf, ulBitOff), block ordinals and DC predictors from seg_start: index entries (held back to the
+//          block's end so that a truncation flag joins its entry in the register: one plain store; only a block that crosses into
+//          the next segment is ORed in atomically), blk_dc, maxima, truncation count.
 template <int OP>
 JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint8_t *slot, const uint8_t *lt,
                              jda_seg_sum &S, jda_seg_stats &ST)
 {
+    const bool CNT = OP == JDA_SEG_COUNT || OP == JDA_SEG_FUSED;      // the segment's sums are wanted
+    const bool TOL = OP == JDA_SEG_SPEC || OP == JDA_SEG_FUSED;       // a speculative walk steps over an invalid code
     S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
     uint32_t p = entry & 63u, b = (entry >> 6) & 7u, k = (entry >> 9) & 63u;
-    const uint16_t *ac_long_lds = (const uint16_t *)(lt + JDA_LT_LONG);          // (lt holds the long halves too)
-    const uint64_t K8 = 0x0101010101010101ull;
+    // per component: LDS offsets of its DC16 / AC short / AC long table (ids are 0 or 1)
+    const uint32_t dcb0 = JDA_LT_DC16 + P.dc_id[0] * 512u, dcb1 = JDA_LT_DC16 + P.dc_id[1] * 512u, dcb2 = JDA_LT_DC16 + P.dc_id[2] * 512u;
+    const uint32_t acb0 = JDA_LT_AC + P.ac_id[0] * 2048u, acb1 = JDA_LT_AC + P.ac_id[1] * 2048u, acb2 = JDA_LT_AC + P.ac_id[2] * 2048u;
     // WRITE: the reference reader (pBuf, ulBitOff), the block ordinal and the DC predictors at the entry
-    uint32_t pos = 0, off = 0, g = 0;
-    int32_t pred[3] = { 0, 0, 0 };
+    uint32_t pos = 0, off = 0, g = 0, pos_pre = 0, off_pre = 0;
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0;
     const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 8;
-    uint64_t ph = 0;                                                // COUNT: offsets (p & 7) + 8 j, j = 0..7
+    uint32_t U = 0;                                                 // COUNT: the six byte lags
+    const uint32_t kOnes = 0x02108421u, kGuard = 0x21084210u;       // 1 / 16 in each 5-bit field
     if (OP == JDA_SEG_WRITE) {
         const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)seg * 5;
-        g = st[0]; pred[0] = (int32_t)st[1]; pred[1] = (int32_t)st[2]; pred[2] = (int32_t)st[3];
+        g = st[0]; pred0 = (int32_t)st[1]; pred1 = (int32_t)st[2]; pred2 = (int32_t)st[3];
         const uint32_t j = st[4], p_abs = seg * JDA_SEG_BITS + p;
         pos = (p_abs >> 3) - j; off = (p_abs & 7u) + 8u * j;
+        pos_pre = pos; off_pre = off;
     }
-    if (OP == JDA_SEG_COUNT) ph = 0x3830282018100800ull + (uint64_t)(p & 7u) * K8;
-#define JDA_SG_REFILL() do { if (OP == JDA_SEG_WRITE) { if (off > 47) { pos += off >> 3; off &= 7u; if (pos > limit_pos) bad = true; } } \
-                             else if (OP == JDA_SEG_COUNT) ph = jda_ph8_refill(ph); } while (0)
-#define JDA_SG_ADVANCE(n) do { if (OP == JDA_SEG_WRITE) off += (n); else if (OP == JDA_SEG_COUNT) ph += (uint64_t)(n) * K8; } while (0)
-    bool bad = false, done = false;
+    if (CNT) U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);
+    uint32_t pend = 0, pend_g = 0;                                  // WRITE: index entry of the block in progress (if it began here)
+    bool pending = false, bad = false;
     while (p < JDA_SEG_BITS) {
+        const bool isdc = k == 0;
         const uint32_t c = b < P.nluma ? 0u : b - P.nluma + 1u;
-        if (k == 0) {                                               // a block starts here (jpeg.inl:2129-2165)
-            if (OP == JDA_SEG_COUNT) S.nblk++;
-            if (OP == JDA_SEG_WRITE) {
-                if (g >= P.n_blocks_total) {                        // past the image: the state after the last block closes the index
-                    if (g == P.n_blocks_total) { JDA_G(uint32_t, P.blk_index)[g] = (pos << JDA_INDEX_OFF_BITS) | off; ST.terminal = 1; }
-                    done = true;
-                    break;
+        if (OP == JDA_SEG_WRITE && isdc) {                          // a block starts here (jpeg.inl:2129-2165)
+            if (g >= P.n_blocks_total) {                            // past the image: the reader as the last block left it closes the index
+                if (g == P.n_blocks_total) { JDA_G(uint32_t, P.blk_index)[g] = (pos_pre << JDA_INDEX_OFF_BITS) | off_pre; ST.terminal = 1; }
+                break;
+            }
+            const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+            if (pr < -32768 || pr > 32767) { bad = true; break; }
+#if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 1))
+            JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
+#endif
+            pend = (pos << JDA_INDEX_OFF_BITS) | off; pend_g = g; pending = true;       // the reader after the block's opening refill
+            g++;
+        }
+        if (CNT && isdc && !S.bad) S.nblk++;
+        const uint32_t w = jda_seg_fetch(slot, p);
+        // one 16-bit lookup: the DC16 table by the top 6 / 7 bits, or the short / long AC table by the top 10 / the next 10
+        const uint32_t dcb = c == 0 ? dcb0 : (c == 1 ? dcb1 : dcb2), acb = c == 0 ? acb0 : (c == 1 ? acb1 : acb2);
+        const uint32_t code12 = w >> 20;
+        const uint32_t a_dc = dcb + 2u * (code12 >= 0xf80u ? (code12 & 0xffu) : (w >> 26));
+        const uint32_t a_ac = w >= 0xfc000000u ? acb + (JDA_LT_LONG - JDA_LT_AC) + ((w >> 15) & 0x7feu) : acb + ((w >> 22) << 1);
+        const uint32_t e = *(const uint16_t *)(lt + (isdc ? a_dc : a_ac));
+        const uint32_t elow = e & 0xffu;
+        if (elow == JDA_AC_NONE) {                                  // no such code  (:2137-2138, :2237-2238)
+            // a speculative walk that is not on the decoder's path yet may meet anything: step on one bit and keep looking
+            // (a walk that gave up would hand "dead" down the chain of segments, one per round)
+            if (TOL) { p += 1; k = 0; if (CNT) S.bad = 1; continue; }
+            bad = true; break;
+        }
+        const bool eob = elow == JDA_AC_EOB;
+        const uint32_t len = (e >> 12) + 1u, sz = eob ? 0u : (e >> 8) & 15u;
+        const uint32_t kk = k + ((e >> 1) & 15u);                   // (DC: + 0)
+        const bool fold = isdc && (e & 1u);
+        // ---- the reader(s) over the code bits
+        const uint32_t by1 = ((p & 7u) + len) >> 3;                 // whole bytes the code bits advance the stream position by
+        const uint32_t p1 = p + len;
+        const uint32_t by2 = ((p1 & 7u) + sz) >> 3;
+        if (OP == JDA_SEG_WRITE) {
+            off += len;
+            if (isdc && sz && !fold && off > 47u) { pos += off >> 3; off &= 7u; if (pos > limit_pos) { bad = true; break; } }      // :2149-2154
+            if (!isdc && sz) {
+                if (kk < 64u && off + sz > 64u) {                   // the magnitude read runs out of the window
+                    ST.trunc_events++;
+                    if (pending) pend |= JDA_INDEX_TRUNC;           // the block began in this segment: its entry is still here
+                    else jda_atomic_or_u32(P.blk_index + (g - 1u), JDA_INDEX_TRUNC);
                 }
-                const int32_t pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
-                if (pr < -32768 || pr > 32767) { bad = true; break; }
-                JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
-                g++;
+                if (sz > ST.max_ac_bits && kk < 64u) ST.max_ac_bits = sz;
             }
-            JDA_SG_REFILL();
-            if (bad) break;
-            // the reader after the block's opening refill.  ORed into a zeroed index: the block's truncation flag may come from
-            // the lane of a later segment, before or after this
-            if (OP == JDA_SEG_WRITE) jda_atomic_or_u32(P.blk_index + (g - 1u), (pos << JDA_INDEX_OFF_BITS) | off);
-            const uint32_t w = jda_seg_fetch(slot, p);
-            uint32_t code = w >> 20;
-            code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
-            const uint32_t dci = c == 0 ? P.dc_id[0] : (c == 1 ? P.dc_id[1] : P.dc_id[2]);
-            const uint8_t *dc = lt + JDA_LT_DC + dci * 1024;
-            const uint32_t e = dc[code];
-            if (e == 0) {                                           // :2137-2138
-                // a speculative walk that is not on the decoder's path yet may meet anything: step on one bit and keep
-                // looking (a walk that gave up would hand "dead" down the chain of segments, one per round)
-                if (OP == JDA_SEG_SPEC) { p += 1; continue; }
-                bad = true; break;
+            off += sz;
+        }
+        if (CNT) {
+            U += by1 * kOnes;
+            if (isdc && sz && !fold) {                               // the refill before an unfolded DC magnitude
+                const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
+                U &= ~(f - (f >> 4));
             }
-            const uint32_t len = e >> 4, s = e & 0xfu;
-            const int32_t folded = (int8_t)dc[code + 512];
-            int32_t diff = 0;
-            JDA_SG_ADVANCE(len);
-            p += len;
-            if (s) {
-                if (folded) diff = folded;                          // code and magnitude in one LUT step (:1132-1152)
-                else {
-                    JDA_SG_REFILL();                                // :2149-2154
-                    if (bad) break;
-                    diff = jda_extend_top(w << len, s);
-                    JDA_SG_ADVANCE(s);
-                    p += s;
-                }
-            }
-            if (OP == JDA_SEG_COUNT) { if (c == 0) S.dcsum[0] += diff; else if (c == 1) S.dcsum[1] += diff; else S.dcsum[2] += diff; }
+            U += by2 * kOnes;
+        }
+        if (isdc && (CNT || OP == JDA_SEG_WRITE)) {                 // the DC difference (:2155-2165; a folded entry holds the same value)
+            const int32_t diff = sz ? jda_extend_top(w << len, sz) : 0;
+            if (CNT && !S.bad) { if (c == 0) S.dcsum[0] += diff; else if (c == 1) S.dcsum[1] += diff; else S.dcsum[2] += diff; }
             if (OP == JDA_SEG_WRITE) {
-                int32_t &pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
-                pr += diff;
+                int32_t pr;
+                if (c == 0) pr = pred0 += diff; else if (c == 1) pr = pred1 += diff; else pr = pred2 += diff;
                 const uint32_t a = (uint32_t)(pr < 0 ? -pr : pr);
                 if (a > ST.max_abs_dc) ST.max_abs_dc = a;
             }
-            k = 1;
-        } else {                                                    // an AC symbol (:2223-2265)
-            JDA_SG_REFILL();
-            if (bad) break;
-            const uint32_t w = jda_seg_fetch(slot, p);
-            const uint32_t aci = c == 0 ? P.ac_id[0] : (c == 1 ? P.ac_id[1] : P.ac_id[2]);
-            uint32_t e;
-            {
-                const uint16_t *ps = (const uint16_t *)(lt + JDA_LT_AC) + aci * 1024 + (w >> 22), *pl = ac_long_lds + aci * 1024 + ((w >> 16) & 0x3ffu);
-                e = *(w >= 0xfc000000u ? pl : ps);                      // one lookup, no branch (codes starting 111111: the long half)
-            }
-            if (e == JDA_AC_NONE) {                                 // no such code  :2237-2238
-                if (OP == JDA_SEG_SPEC) { p += 1; k = 0; continue; }
-                bad = true; break;
-            }
-            const uint32_t len = (e >> 12) + 1u;
-            JDA_SG_ADVANCE(len);
-            p += len;
-            if ((e & 0xffu) == JDA_AC_EOB) { k = 0; b = b + 1u == P.nblocks ? 0u : b + 1u; }       // EOB: no refill follows
-            else {
-                const uint32_t ms = (e >> 8) & 0xfu, kk = k + ((e >> 1) & 0xfu);
-                if (OP == JDA_SEG_WRITE) {
-                    if (ms && kk < 64 && off + ms > 64) {                        // flag the block (g - 1: it may have begun in an earlier segment)
-                        ST.trunc_events++;
-                        jda_atomic_or_u32(P.blk_index + (g - 1u), JDA_INDEX_TRUNC);
-                    }
-                    if (ms > ST.max_ac_bits && kk < 64) ST.max_ac_bits = ms;
-                }
-                JDA_SG_ADVANCE(ms);
-                p += ms;
-                k = kk + 1u;
-                JDA_SG_REFILL();                                    // :2259-2264 (bottom of the loop)
-                if (bad) break;
-                if (k >= 64) { k = 0; b = b + 1u == P.nblocks ? 0u : b + 1u; }
-            }
+        }
+        p = p1 + sz;
+        // ---- the refill at the end of the step (not after EOB in the reference -- there it is the next block's opening one)
+        if (OP == JDA_SEG_WRITE) {
+            pos_pre = pos; off_pre = off;                           // (what closes the index if this was the image's last symbol and an EOB)
+            if (off > 47u) { pos += off >> 3; off &= 7u; if (pos > limit_pos) { bad = true; break; } }
+            if (!eob) { pos_pre = pos; off_pre = off; }             // a block that ends on its 63rd coefficient has had its bottom refill
+        }
+        if (CNT) {
+            const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
+            U &= ~(f - (f >> 4));
+        }
+        const bool ends = eob || kk + 1u >= 64u;
+        k = ends ? 0u : kk + 1u;
+        if (ends) {
+            b = b + 1u == P.nblocks ? 0u : b + 1u;
+#if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 2))
+            if (OP == JDA_SEG_WRITE && pending) { JDA_G(uint32_t, P.blk_index)[pend_g] = pend; pending = false; }
+#endif
         }
     }
-#undef JDA_SG_REFILL
-#undef JDA_SG_ADVANCE
+    if (OP == JDA_SEG_WRITE && pending && !bad) jda_atomic_or_u32(P.blk_index + pend_g, pend);      // the block goes on in the next segment
     if (bad) { S.bad = 1; ST.bad = 1; return JDA_SEG_DEAD; }
-    if (OP == JDA_SEG_COUNT) {
+    if (CNT) {
         uint32_t map = 0;
-        for (int j = 0; j < 8; j++) map |= (((uint32_t)(ph >> (8 * j)) & 0xffu) >> 3) << (3 * j);
+        for (int j = 0; j < 6; j++) map |= ((U >> (5 * j)) & 7u) << (3 * j);
         S.phase_map = map;
     }
-    (void)done;
     return (p - JDA_SEG_BITS) | (b << 6) | (k << 9);
 }
 
@@ -1334,10 +1373,17 @@ JDA_HD uint32_t jda_nibble_list(uint32_t m)
 }
 // tables: once per workgroup (tid = thread in workgroup, nthreads = workgroup size)
 // with_long: also the long halves of the AC LUTs (JDA_LT_LONG; tab_lds then holds JDA_LT_BYTES + JDA_LT_LONG_BYTES)
-JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false);
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false, bool with_walk = false);
 JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false) { jda_p0_tables_from(D.tables, tid, nthreads, tab_lds, with_long); }
-JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long)
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long, bool with_walk)
 {
+    if (with_walk) {                                                // the segment walk's DC table (JDA_LT_DC16; tab_lds then holds JDA_LT_WALK_BYTES)
+        for (uint32_t j = tid; j < 512u; j += nthreads) {
+            const uint32_t t = j >> 8, idx = j & 255u;
+            const uint8_t JDA_GLOBAL *dc = JDA_G(const uint8_t, tables) + JDA_TB_DC + t * 1024u;
+            ((uint16_t *)(tab_lds + JDA_LT_DC16))[j] = (uint16_t)jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]);
+        }
+    }
     const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, tables);
     jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;

@@ -90,4 +90,16 @@ struct jda_filter_params {
 };
 
 
+// What the host makes of one file when the GPU does everything else (jda_pipeline): see jda_front_prepare in jda_frontend.cpp
+struct jda_front {
+    jda_image_info info;
+    uint8_t dc_id[3], ac_id[3], q_id[3];
+    uint8_t general_p1;          // JDA_DESC_GENERAL_P1
+    uint8_t progressive;
+    uint8_t device_ok;           // filter + pre-scan can run on the device (else: the serial host path)
+    uint8_t fast_provable;       // the 24-bit-multiply bound holds for every legal stream with these quantisers
+    uint32_t raw_off, raw_len;   // the entropy-coded segment inside the file (unfiltered)
+    uint32_t n_intervals;        // restart intervals (0: no DRI)
+};
+
 #endif

@@ -423,7 +423,12 @@ __global__ __launch_bounds__(64)
 void jda_prescan_intervals(const jda_prescan_params *__restrict__ params)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tab[JDA_TABLE_BYTES];   // the LUTs: two dependent lookups per symbol
-    const jda_prescan_params P = params[blockIdx.y];            // one image per grid row
+    jda_prescan_params P = params[blockIdx.y];                  // one image per grid row
+    bool marker_count_off = false;
+    if (P.filter_result) {                                      // the filter ran on the device: its results are in memory only
+        P.scan_len = JDA_G(const uint32_t, P.filter_result)[0];
+        marker_count_off = JDA_G(const uint32_t, P.filter_result)[1] + 1u != P.n_intervals;
+    }
     {
         const jda_chunk16_alias JDA_GLOBAL *src = JDA_G(const jda_chunk16_alias, P.tables);
         jda_chunk16_alias *dst = (jda_chunk16_alias *)tab;
@@ -432,6 +437,10 @@ void jda_prescan_intervals(const jda_prescan_params *__restrict__ params)
     __syncthreads();
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= P.n_intervals) return;
+    if (marker_count_off) {                                     // the restart positions are not what the MCU count says: nothing to walk
+        if (EXACT && k == 0) atomicOr(&P.stats[1], 1u);
+        return;
+    }
     const jda_prescan_result R = jda_prescan_interval<EXACT>(P, k, tab);
     if (!EXACT) { P.phase_map[k] = R.phase_map; return; }
     uint32_t *st = P.stats;
@@ -440,6 +449,30 @@ void jda_prescan_intervals(const jda_prescan_params *__restrict__ params)
     atomicMax(&st[2], R.max_ac_bits);
     atomicMax(&st[3], R.max_abs_dc);
     if (R.trunc_events) atomicAdd(&st[4], R.trunc_events);
+}
+
+// Between MAP and EXACT: the window phase every interval starts with = the maps composed from interval 0 (whose phase is 0:
+// the scan starts with pBuf at its first byte and ulBitOff 0, jpeg.inl:4996-4998).  One thread per image walks its intervals --
+// a few hundred table lookups; doing it here keeps the host out of the middle of the pre-scan (jda_pipeline).
+__global__ __launch_bounds__(64)
+void jda_prescan_compose(const jda_prescan_params *__restrict__ params, uint32_t n_images)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n_images) return;
+    const jda_prescan_params P = params[i];
+    uint8_t *phase = const_cast<uint8_t *>(P.start_phase);
+    P.stats[0] = 0xffffffffu;                         // "first bad MCU": a minimum is taken over the intervals (the other words start as zeros)
+    uint32_t j = 0;
+    for (uint32_t k = 0; k < P.n_intervals; k++) {
+        phase[k] = (uint8_t)(8u * j);
+        j = (P.phase_map[k] >> (4u * (j > 5u ? 0u : j))) & 15u;
+    }
+}
+extern "C" hipError_t jda_launch_prescan_compose(const jda_prescan_params *params, uint32_t n_images, hipStream_t stream)
+{
+    if (n_images == 0) return hipSuccess;
+    hipLaunchKernelGGL(jda_prescan_compose, dim3((n_images + 63u) / 64u), dim3(64), 0, stream, params, n_images);
+    return hipGetLastError();
 }
 
 // params: device array of n_images descriptors; max_intervals: the largest n_intervals among them
@@ -464,13 +497,16 @@ __global__ __launch_bounds__(256)
 void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const jda_segscan_params P = params[blockIdx.y];
+    const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t seg0 = (blockIdx.x * 4u + wave) * 64u, seg = seg0 + lane;
     if (blockIdx.x * 256u >= P.n_segs) return;                       // (uniform per workgroup: images of a batch differ in size)
+    // a speculative round after one that changed nothing has nothing to do (the host launches a fixed number of rounds when it
+    // does not want to look at the counters in between: jda_pipeline)
+    if (OP == JDA_SEG_SPEC && round >= 1 && JDA_G(const uint32_t, P.stats)[8u + round - 1u] == 0u) return;
     uint8_t *tab = lds;
-    uint8_t *slots = lds + JDA_LT_BYTES + JDA_LT_LONG_BYTES + wave * JDA_SEG_WAVE_LDS;
-    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true);       // with the long halves of the AC LUTs (see jda_lds_layout)
+    uint8_t *slots = lds + JDA_LT_WALK_BYTES + wave * JDA_SEG_WAVE_LDS;
+    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true, true);       // with the long halves of the AC LUTs (see jda_lds_layout) and the walk's DC table
     const bool in_range = seg < P.n_segs;
     // what this lane has to do
     uint32_t *e_cur = (round & 1u) ? P.entry_nxt : P.entry_cur, *e_nxt = (round & 1u) ? P.entry_cur : P.entry_nxt;
@@ -487,7 +523,7 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
             const uint32_t sl = t / (JDA_SEG_SLOT / 4u), w = t - sl * (JDA_SEG_SLOT / 4u);
             uint32_t v = 0;
             if (seg0 + sl < P.n_segs) v = src[(size_t)(seg0 + sl) * (JDA_SEG_BYTES / 4u) + w];
-            *(jda_u32_alias *)(slots + sl * JDA_SEG_SLOT + w * 4u) = v;
+            *(jda_u32_alias *)(slots + sl * JDA_SEG_SLOT + w * 4u) = jda_seg_stage_word(v);
         }
     }
     __syncthreads();                                                 // tables and slots are in LDS
@@ -520,6 +556,91 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
     }
 }
 
+// The speculative rounds and the count pass in one (jda_pipeline).  Round 0 walks every segment; a walk whose exit state differs
+// from what the next segment was entered with stores the new state and puts that segment on the work list of the next round, so
+// round r + 1 only walks the segments whose entry state round r changed (7 % after round 0, then a handful) -- packed into
+// full wavefronts instead of spread one or two per wavefront over all of them.  The entry states are updated in place: a lane
+// may read its entry while the lane of the segment before it replaces it, but then it is on the next round's list and walks
+// again from the final value; when a round leaves its list empty every segment's last walk started from its final entry
+// state (= the serial decoder's, by induction from segment 0) and its sums (block starts, DC sums, window phase map) are the
+// count pass's.  A round whose list is empty returns at once, so the host launches a fixed number of rounds and looks at the
+// last list's length when the batch is waited for.  stats[8 + r] = length of round r's list (r >= 2).  Round 0 walks every
+// segment from the guess "a block starts here" for the exit states alone (most guesses are wrong, so its sums would be thrown
+// away); round 1 walks every segment again, now with the sums, and starts the lists.
+template <int OP>       // JDA_SEG_SPEC: round 0 (every segment from the guess "a block starts here": exit states only); JDA_SEG_FUSED: the rest
+__global__ __launch_bounds__(256)
+void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t round)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t JDA_GLOBAL *stats = JDA_G(uint32_t, P.stats);
+    const bool all = round <= 1u;                                    // rounds 0 and 1 walk every segment (round 1 to make everybody's sums)
+    const uint32_t count = all ? P.n_segs : stats[8u + round];
+    if (blockIdx.x * 256u >= count) return;                          // (uniform per workgroup)
+    const uint32_t JDA_GLOBAL *wl_in = JDA_G(const uint32_t, P.worklist) + ((round & 1u) ? P.worklist_cap : 0u);
+    uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
+    uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
+    uint8_t *tab = lds;
+    uint8_t *slots = lds + JDA_LT_WALK_BYTES + wave * JDA_SEG_WAVE_LDS;
+    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true, true);
+    __syncthreads();                                                 // the tables; the slots below are a wavefront's own
+    const uint32_t JDA_GLOBAL *src = JDA_G(const uint32_t, P.scan);
+    for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < count; base += gridDim.x * 256u) {
+        const uint32_t item = base + lane;
+        const bool have = item < count;
+        const uint32_t seg = !have ? 0xffffffffu : (all ? item : wl_in[item]);
+        // the wavefront's 64 segments -> its LDS slots (slot sl = the segment of lane sl)
+        for (uint32_t t = lane; t < 64u * (JDA_SEG_SLOT / 4u); t += 64u) {
+            const uint32_t sl = t / (JDA_SEG_SLOT / 4u), w = t - sl * (JDA_SEG_SLOT / 4u);
+            const uint32_t sg = all ? base + sl : (uint32_t)__shfl((int)seg, (int)sl);
+            uint32_t v = 0;
+            if (sg < P.n_segs) v = src[(size_t)sg * (JDA_SEG_BYTES / 4u) + w];
+            *(jda_u32_alias *)(slots + sl * JDA_SEG_SLOT + w * 4u) = jda_seg_stage_word(v);
+        }
+        JDA_WAVE_SYNC();
+        if (have) {
+            jda_seg_sum S;
+            jda_seg_stats ST;
+            ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0;
+            const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];   // the scan starts at a block start (jpeg.inl:4996-4998)
+            const uint32_t x = jda_seg_walk<OP>(P, seg, entry, slots + lane * JDA_SEG_SLOT, tab, S, ST);
+            if (OP == JDA_SEG_FUSED) {
+                uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
+                o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
+            }
+            if (seg + 1u < P.n_segs) {
+                if (round == 0) E[seg + 1u] = x;                     // (nobody reads the entry states in round 0)
+                else if (x != E[seg + 1u]) {
+                    E[seg + 1u] = x;
+                    const uint32_t at = atomicAdd(&P.stats[8u + round + 1u], 1u);
+                    if (at < P.worklist_cap) wl_out[at] = seg + 1u;
+                }
+            }
+        }
+        JDA_WAVE_SYNC();                                             // the slots are rewritten by the next step
+    }
+}
+
+extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream)
+{
+    if (n_images == 0 || max_segs == 0) return hipSuccess;
+    const int lds_bytes = JDA_LT_WALK_BYTES + 4 * JDA_SEG_WAVE_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t full = (max_segs + 255u) / 256u;
+    // later rounds walk a few percent of the segments: a few workgroups per image, each stepping through the list
+    const dim3 grid(round <= 1 ? full : (full < 8u ? full : 8u), n_images), block(256);
+    if (round == 0) hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
+    else hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_FUSED>, grid, block, lds_bytes, stream, params, round);
+    return hipGetLastError();
+}
+
 // Exclusive sums over the segments of one image (one wavefront per image, 64 segments per step): first block ordinal and
 // DC predictors at every segment's entry (wave prefix sums + a carry), and the reference window's byte lag (composition of
 // the segments' phase maps: eight values wide, so it is walked lane by lane with readlane -- 64 scalar steps per 64
@@ -540,7 +661,7 @@ __device__ __forceinline__ uint32_t jda_wave_incl_sum_u32(uint32_t v)
 __global__ __launch_bounds__(64)
 void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
 {
-    const jda_segscan_params P = params[blockIdx.x];
+    const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.x]);
     const uint32_t lane = threadIdx.x;
     uint32_t *seg_start = const_cast<uint32_t *>(P.seg_start);
     uint32_t g_carry = 0, p0 = 0, p1 = 0, p2 = 0, j = 0;          // wave-uniform running values
@@ -595,7 +716,7 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_LT_BYTES + JDA_LT_LONG_BYTES + 4 * JDA_SEG_WAVE_LDS;          // 79,136 B: two workgroups per CU
+    const int lds_bytes = JDA_LT_WALK_BYTES + 4 * JDA_SEG_WAVE_LDS;          // 80,160 B: two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -1,0 +1,597 @@
+// jda_pipeline.cpp -- the whole path as one streamed pipeline: files in, pixels resident in HBM out.
+//
+//   host   parse + Huffman LUTs + prescaled quantisers per file (a few microseconds each, on a small thread pool)
+//   H2D    the UNFILTERED entropy-coded bytes of every file + one control blob (tables, kernel parameters, launch plan)
+//   GPU    marker / stuffing filter (JPEGFilter, jpeg.inl:1431-1540)            jda_filter_scan
+//          per-block index = the serial pre-scan's, entry for entry              jda_segscan / jda_prescan_intervals
+//          the MCU loops of DecodeJPEG (jpeg.inl:5109-5353)                      jda_decode_tiles_persistent
+// The host never touches a compressed byte.  Upload + filter + pre-scan of batch n+1 run on their own stream under the
+// decode of batch n; every batch lives in one device arena per pipeline slot (no allocation per image, no host
+// synchronisation inside a batch).  The decode is launched OPTIMISTICALLY -- every MCU valid, 24-bit multiplies where the
+// quantisers allow them for every legal stream -- and the pre-scan's own verdict (bad code, marker out of place, states not
+// settled, a magnitude beyond the legal categories) is read when the batch is waited for: an image that fails it, or that
+// the device walk cannot take (progressive, one restart interval, odd table ids), is redone through the serial host
+// pre-scan (jda_prepare), which reproduces what the reference does with such streams.  A bad image never poisons its
+// batch: every image has its own status.
+//
+// There is NO CPU decode fallback here either: the slow path is the same kernels behind the host pre-scan.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "jda_runtime_internal.h"
+
+extern "C" int jda_front_prepare(const uint8_t *jpeg, int32_t len, uint8_t *tables, jda_front *out);
+extern "C" uint32_t jda_front_fast_mul(const uint8_t *tables, const jda_front *f, uint32_t max_ac_bits, int32_t max_abs_dc);
+
+namespace {
+
+inline size_t a16(size_t v) { return (v + 15) & ~(size_t)15; }
+inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// a few persistent worker threads: run(n, fn) calls fn(0..n-1) across them and the caller.  Items are handed out under the
+// mutex (an item is tens of microseconds of work: no contention to speak of), tagged with the run's generation so that a
+// worker that is late leaving one run cannot take an item of the next one twice.
+class Workers {
+public:
+    explicit Workers(int n_threads) : stop_(false), gen_(0), fn_(nullptr), n_(0), next_(0), done_(0)
+    {
+        for (int t = 1; t < n_threads; t++) th_.emplace_back([this]() { loop(); });
+    }
+    ~Workers()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int threads() const { return (int)th_.size() + 1; }
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+        uint64_t g;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_ = n; next_ = 0; done_ = 0; g = ++gen_;
+        }
+        cv_.notify_all();
+        work(g);
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [this]() { return done_ >= n_; });
+        fn_ = nullptr; n_ = 0;
+    }
+
+private:
+    void work(uint64_t g)
+    {
+        for (;;) {
+            int i;
+            const std::function<void(int)> *f;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (gen_ != g || next_ >= n_) return;
+                i = next_++; f = fn_;
+            }
+            (*f)(i);
+            std::lock_guard<std::mutex> lk(m_);
+            if (gen_ == g && ++done_ >= n_) cv_done_.notify_all();
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t g;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return gen_ != seen; });
+                seen = g = gen_;
+                if (stop_) return;
+            }
+            work(g);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    bool stop_;
+    uint64_t gen_;
+    const std::function<void(int)> *fn_;
+    int n_, next_, done_;
+};
+
+struct Img {
+    jda_front f;
+    int32_t err;                 // front-end verdict
+    bool device;                 // filter + pre-scan + decode were enqueued for it
+    bool seg_mode;               // marker-less segment walk (else: restart intervals)
+    bool fast;                   // launched with 24-bit multiplies
+    uint32_t n_segs_ub, n_blocks;
+    size_t off_raw, off_scan, scan_bytes, off_index, off_dc, off_work, off_zero, off_stats;   // arena offsets
+    size_t work_bytes, zero_bytes;
+    size_t ctl_tables;           // offset of its tables inside the control blob
+    uint32_t list, n_tiles;      // launch list it is in, tiles (padded)
+    size_t strip_off;            // its first strip inside the list
+    uint32_t ord;
+};
+
+} // namespace
+
+#define JDA_PIPE_MAX_DEPTH 4
+#define JDA_PIPE_SPEC_ROUNDS 24      // rounds launched (a round with an empty work list returns at once); stats[8 + r], r <= 24 < 56
+#define JDA_PIPE_STATS_BYTES 288      // per image: filter result (2 words, 16 bytes) | 64 result words of the pre-scan + 16 bytes
+
+struct jda_pipeline {
+    jda_ctx *ctx;
+    int depth, max_images;
+    hipStream_t s_up, s_copy;            // filter + pre-scan | memset + H2D (its own stream: a copy must not queue behind the previous batch's pre-scan)
+    Workers *workers;
+    struct Slot {
+        int ticket;
+        bool in_flight;
+        uint8_t *dev; size_t dev_cap;
+        uint8_t *pin; size_t pin_cap;          // control blob (H2D) followed by the statistics read back (D2H)
+        hipEvent_t ev_copy, ev_up, ev_dec;
+        std::vector<Img> imgs;
+        std::vector<const uint8_t *> jpegs; std::vector<int32_t> lens, pts, opts; std::vector<jda_output> outs;
+        size_t ctl_bytes, off_stats_dev, stats_bytes;
+        size_t list_off[JDA_N_LISTS]; uint32_t list_n[JDA_N_LISTS];
+        size_t off_descs;
+        jda_pipeline_stats st;
+    } slots[JDA_PIPE_MAX_DEPTH];
+    int next_ticket;
+    jda_pipeline_stats total;
+};
+
+static void slot_free(jda_pipeline::Slot &s)
+{
+    if (s.dev) (void)hipFree(s.dev);
+    if (s.pin) (void)hipHostFree(s.pin);
+    s.dev = NULL; s.pin = NULL; s.dev_cap = s.pin_cap = 0;
+}
+
+// tiles of one image, padded to whole workgroups (the same list jda_append_strips makes)
+static uint32_t count_tiles(uint32_t mcus_x, uint32_t mcus_y, int mode, int big)
+{
+    const uint32_t per = jda_mcus_per_tile(mode), wg = jda_tiles_per_wg(mode, big);
+    const uint32_t n = mcus_y * ((mcus_x + per - 1) / per);
+    return (n + wg - 1) / wg * wg;
+}
+static void fill_strips(jda_strip *dst, uint32_t n_padded, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, uint32_t ord)
+{
+    const uint32_t per = jda_mcus_per_tile(mode);
+    uint32_t k = 0;
+    for (uint32_t y = 0; y < mcus_y; y++)
+        for (uint32_t x = 0; x < mcus_x; x += per, k++) {
+            jda_strip s;
+            memset(&s, 0, sizeof(s));
+            s.image = image; s.mcu_y = (uint16_t)y; s.mcu_x0 = (uint16_t)x;
+            s.count = (uint8_t)(mcus_x - x < per ? mcus_x - x : per);
+            s.first = k == 0 ? 1 : 0; s.ord = ord;
+            dst[k] = s;
+        }
+    for (; k < n_padded; k++) { jda_strip s; memset(&s, 0, sizeof(s)); s.image = image; s.ord = ord; dst[k] = s; }
+}
+
+extern "C" {
+
+jda_pipeline *jda_pipeline_create(jda_ctx *ctx, int32_t max_images, int32_t depth, int32_t host_threads, int32_t *err)
+{
+    int32_t dummy;
+    if (!err) err = &dummy;
+    if (!ctx) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
+    if (max_images <= 0 || depth < 1 || depth > JDA_PIPE_MAX_DEPTH) { *err = JDA_INVALID_PARAMETER; return NULL; }
+    jda_pipeline *p = new (std::nothrow) jda_pipeline;
+    if (!p) { *err = JDA_ERROR_MEMORY; return NULL; }
+    p->ctx = ctx; p->depth = depth; p->max_images = max_images; p->next_ticket = 0; p->workers = NULL; p->s_up = NULL; p->s_copy = NULL;
+    memset(&p->total, 0, sizeof(p->total));
+    (void)hipSetDevice(ctx->device);
+    bool ok = hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < JDA_PIPE_MAX_DEPTH; i++) {
+        jda_pipeline::Slot &s = p->slots[i];
+        s.ticket = -1; s.in_flight = false; s.dev = NULL; s.pin = NULL; s.dev_cap = s.pin_cap = 0; s.ev_copy = s.ev_up = s.ev_dec = NULL;
+        if (i < depth && ok) ok = hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.ev_dec, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { jda_pipeline_destroy(p); *err = JDA_ERROR_HIP; return NULL; }
+    unsigned nt = host_threads > 0 ? (unsigned)host_threads : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    p->workers = new (std::nothrow) Workers((int)nt);
+    if (!p->workers) { jda_pipeline_destroy(p); *err = JDA_ERROR_MEMORY; return NULL; }
+    *err = JDA_SUCCESS;
+    return p;
+}
+
+void jda_pipeline_destroy(jda_pipeline *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    if (p->s_copy) (void)hipStreamSynchronize(p->s_copy);
+    if (p->s_up) (void)hipStreamSynchronize(p->s_up);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (int i = 0; i < JDA_PIPE_MAX_DEPTH; i++) {
+        jda_pipeline::Slot &s = p->slots[i];
+        slot_free(s);
+        if (s.ev_copy) (void)hipEventDestroy(s.ev_copy);
+        if (s.ev_up) (void)hipEventDestroy(s.ev_up);
+        if (s.ev_dec) (void)hipEventDestroy(s.ev_dec);
+    }
+    if (p->s_up) (void)hipStreamDestroy(p->s_up);
+    if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
+    delete p->workers;
+    delete p;
+}
+
+int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
+                        const int32_t *pixel_types, const int32_t *options, int32_t *ticket)
+{
+    if (!p) return JDA_ERROR_NO_DEVICE;
+    if (n <= 0 || n > p->max_images || !jpegs || !lens || !outputs || !ticket) return JDA_INVALID_PARAMETER;
+    jda_ctx *ctx = p->ctx;
+    (void)hipSetDevice(ctx->device);
+    const int t = p->next_ticket;
+    jda_pipeline::Slot &S = p->slots[t % p->depth];
+    if (S.in_flight) return JDA_INVALID_PARAMETER;          // the batch that used this slot has not been waited for
+    S.imgs.assign((size_t)n, Img());
+    S.jpegs.assign(jpegs, jpegs + n); S.lens.assign(lens, lens + n); S.outs.assign(outputs, outputs + n);
+    S.pts.resize((size_t)n); S.opts.resize((size_t)n);
+    for (int i = 0; i < n; i++) { S.pts[(size_t)i] = pixel_types ? pixel_types[i] : JDA_RGB8888; S.opts[(size_t)i] = options ? options[i] : 0; }
+    memset(&S.st, 0, sizeof(S.st));
+    S.st.images = n;
+
+    // ---- control blob layout, part 1: the tables (the workers write them straight into the page-locked buffer)
+    const size_t tab_stride = a16(JDA_TABLE_BYTES);
+    size_t ctl = 0;
+    for (int i = 0; i < n; i++) { S.imgs[(size_t)i].ctl_tables = ctl; ctl += tab_stride; }
+    const size_t off_fparams = a16(ctl); ctl = off_fparams + a16((size_t)n * sizeof(jda_filter_params));
+    const size_t off_sparams = ctl; ctl += a16((size_t)n * sizeof(jda_segscan_params));
+    const size_t off_pparams = ctl; ctl += a16((size_t)n * sizeof(jda_prescan_params));
+    S.off_descs = ctl; ctl += a16((size_t)n * sizeof(jda_dev_desc));
+    const size_t strips_base = ctl;
+    // the page-locked buffer must hold the tables before the strips are counted: size it generously for them now
+    size_t pin_need_min = ctl + (size_t)n * JDA_PIPE_STATS_BYTES + 4096;
+    if (S.pin_cap < pin_need_min) {
+        if (S.pin) (void)hipHostFree(S.pin);
+        S.pin = NULL; S.pin_cap = 0;
+        const size_t want = a256(pin_need_min * 2 + ((size_t)8 << 20));
+        if (hipHostMalloc((void **)&S.pin, want, hipHostMallocDefault) != hipSuccess) { S.pin = NULL; return JDA_ERROR_MEMORY; }
+        S.pin_cap = want;
+    }
+
+    // ---- host: parse + tables, in parallel
+    p->workers->run(n, [&](int i) {
+        Img &im = S.imgs[(size_t)i];
+        im.err = (jpegs[i] && lens[i] > 0) ? jda_front_prepare(jpegs[i], lens[i], S.pin + im.ctl_tables, &im.f) : JDA_INVALID_PARAMETER;
+    });
+
+    // ---- launch plan and arena layout
+    std::vector<jda_dev_desc> descs((size_t)n);
+    uint32_t list_tiles[JDA_N_LISTS], list_ord[JDA_N_LISTS];
+    memset(list_tiles, 0, sizeof(list_tiles)); memset(list_ord, 0, sizeof(list_ord));
+    size_t arena = 0;
+    auto take = [&](size_t bytes) { const size_t o = arena; arena += a256(bytes); return o; };
+    // regions: [control blob][raw][dc][work][ ZERO: scan | index | zero ][stats]; laid out by region so that one memset and
+    // one read-back cover all images
+    std::vector<size_t> raw_sz((size_t)n, 0);
+    int n_dev = 0;
+    for (int i = 0; i < n; i++) {
+        Img &im = S.imgs[(size_t)i];
+        im.device = false;
+        if (im.err != JDA_SUCCESS) continue;
+        const jda_image_info &I = im.f.info;
+        jda_dev_desc &D = descs[(size_t)i];
+        int bpp = 0;
+        im.n_blocks = (uint32_t)((size_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu);
+        im.fast = im.f.fast_provable != 0;
+        const int rc = jda_fill_launch_desc(D, I, im.f.dc_id, im.f.ac_id, im.f.q_id, im.fast ? 1 : 0, im.f.general_p1, (uint32_t)(I.mcus_x * I.mcus_y), 0,
+                                            outputs[i], S.pts[(size_t)i], S.opts[(size_t)i], &bpp);
+        if (rc != JDA_SUCCESS) { im.err = rc; continue; }
+        if (!im.f.device_ok) continue;                       // valid, but the serial host pre-scan has to make its index (jda_pipeline_wait)
+        im.device = true; n_dev++;
+        im.seg_mode = im.f.n_intervals == 0;
+        const int variant = jda_plain_variant(D);
+        // (window size: the filtered length is not known yet; the unfiltered one is at most a few percent larger)
+        D.scan_len = im.f.raw_len;
+        const int big = jda_big_window(D, variant);
+        im.list = (uint32_t)(((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big);
+        im.n_tiles = count_tiles(D.mcus_x, D.mcus_y, D.mode, big);
+        im.strip_off = list_tiles[im.list]; list_tiles[im.list] += im.n_tiles;
+        im.ord = list_ord[im.list]++;
+        S.st.source_pixels += (int64_t)I.width * I.height;
+        S.st.compressed_bytes += lens[i];
+    }
+    for (int m = 0; m < JDA_N_LISTS; m++) { S.list_off[m] = ctl; S.list_n[m] = list_tiles[m]; ctl += a16((size_t)list_tiles[m] * sizeof(jda_strip)); }
+    (void)strips_base;
+    S.ctl_bytes = a256(ctl);
+    arena = S.ctl_bytes;
+    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_raw = take(a16(im.f.raw_len) + 16); }
+    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_dc = take((size_t)im.n_blocks * 2); }
+    for (int i = 0; i < n; i++) {
+        Img &im = S.imgs[(size_t)i];
+        if (!im.device) continue;
+        if (im.seg_mode) {
+            im.n_segs_ub = im.f.raw_len / JDA_SEG_BYTES + 1u;
+            im.work_bytes = a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);   // seg_sum | seg_start | two work lists
+        } else {
+            const size_t ni = im.f.n_intervals;
+            im.n_segs_ub = 0;
+            im.work_bytes = a16((ni + 1) * 4) + a16(ni * 4) + a16(ni);                                             // restart_pos | phase_map | start_phase
+        }
+        im.off_work = take(im.work_bytes);
+    }
+    const size_t zero_begin = arena;
+    for (int i = 0; i < n; i++) {
+        Img &im = S.imgs[(size_t)i];
+        if (!im.device) continue;
+        im.scan_bytes = a16(std::max((size_t)im.f.raw_len + JDA_SCAN_PAD, (size_t)im.n_segs_ub * JDA_SEG_BYTES + 16));
+        im.off_scan = take(im.scan_bytes);
+    }
+    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_index = take(((size_t)im.n_blocks + 1) * 4); }
+    for (int i = 0; i < n; i++) {
+        Img &im = S.imgs[(size_t)i];
+        if (!im.device) continue;
+        im.zero_bytes = im.seg_mode ? a16(((size_t)im.n_segs_ub + 1) * 4) : 0;                                     // entry states
+        im.off_zero = take(im.zero_bytes);
+    }
+    S.off_stats_dev = arena;
+    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; im.off_stats = arena; arena += JDA_PIPE_STATS_BYTES; }
+    S.stats_bytes = arena - S.off_stats_dev;
+    arena = a256(arena);
+    const size_t zero_end = arena;
+    arena += 8192;                                            // slack: readers run a few hundred bytes past a (corrupt) scan
+
+    if (S.pin_cap < S.ctl_bytes + S.stats_bytes + 256) {     // (the strips did not fit: grow, keeping the tables)
+        uint8_t *np = NULL;
+        const size_t want = a256((S.ctl_bytes + S.stats_bytes) * 3 / 2 + ((size_t)1 << 20));
+        if (hipHostMalloc((void **)&np, want, hipHostMallocDefault) != hipSuccess) return JDA_ERROR_MEMORY;
+        memcpy(np, S.pin, off_fparams);
+        (void)hipHostFree(S.pin);
+        S.pin = np; S.pin_cap = want;
+    }
+    if (S.dev_cap < arena) {
+        if (S.dev) (void)hipFree(S.dev);
+        S.dev = NULL; S.dev_cap = 0;
+        const size_t want = a256(arena + arena / 4);
+        hipError_t e = hipMalloc((void **)&S.dev, want);
+        if (e != hipSuccess) { S.dev = NULL; return jda_set_err(ctx, e, "hipMalloc(pipeline arena)"), JDA_ERROR_MEMORY; }
+        S.dev_cap = want;
+    }
+
+    // ---- control blob, part 2: parameters, descriptors, strips (in parallel: the strip lists are the bulk)
+    jda_filter_params *fp = (jda_filter_params *)(S.pin + off_fparams);
+    jda_segscan_params *sp = (jda_segscan_params *)(S.pin + off_sparams);
+    jda_prescan_params *pp = (jda_prescan_params *)(S.pin + off_pparams);
+    jda_dev_desc *dd = (jda_dev_desc *)(S.pin + S.off_descs);
+    std::vector<int> seg_ix, int_ix, dev_ix;
+    for (int i = 0; i < n; i++) { const Img &im = S.imgs[(size_t)i]; if (!im.device) continue; dev_ix.push_back(i); (im.seg_mode ? seg_ix : int_ix).push_back(i); }
+    uint32_t max_segs = 0, max_int = 0;
+    for (size_t k = 0; k < dev_ix.size(); k++) {
+        const int i = dev_ix[k];
+        Img &im = S.imgs[(size_t)i];
+        const jda_image_info &I = im.f.info;
+        uint8_t *B = S.dev;
+        uint32_t *fres = (uint32_t *)(B + im.off_stats);
+        uint32_t *pstats = (uint32_t *)(B + im.off_stats + 16);
+        jda_filter_params &F = fp[k];
+        F.raw = B + im.off_raw; F.out = B + im.off_scan; F.result = fres; F.raw_len = im.f.raw_len;
+        F.restart_pos = im.seg_mode ? (uint32_t *)(B + im.off_work) /* unused */ : (uint32_t *)(B + im.off_work);
+        F.restart_cap = im.seg_mode ? 0u : im.f.n_intervals + 1u;
+        jda_dev_desc &D = descs[(size_t)i];
+        D.tables = B + im.ctl_tables;
+        D.blk_index = (const uint32_t *)(B + im.off_index);
+        D.blk_dc = (const int16_t *)(B + im.off_dc);
+        D.scan = B + im.off_scan;
+        D.scan_len = (uint32_t)(im.scan_bytes - JDA_SCAN_PAD);          // upper bound of the filtered length; the bytes behind it are zero
+        dd[i] = D;
+        if (im.seg_mode) {
+            jda_segscan_params P;
+            memset(&P, 0, sizeof(P));
+            P.scan = B + im.off_scan; P.tables = B + im.ctl_tables;
+            P.entry_cur = (uint32_t *)(B + im.off_zero); P.entry_nxt = P.entry_cur;
+            P.worklist = (uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20)); P.worklist_cap = im.n_segs_ub;
+            P.seg_sum = (uint32_t *)(B + im.off_work); P.seg_start = (const uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24));
+            P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
+            P.stats = pstats;
+            P.scan_len = im.f.raw_len; P.n_segs = im.n_segs_ub; P.n_blocks_total = im.n_blocks;
+            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
+            for (int c = 0; c < 3; c++) { P.dc_id[c] = im.f.dc_id[c]; P.ac_id[c] = im.f.ac_id[c]; }
+            P.filter_result = fres;
+            sp[std::find(seg_ix.begin(), seg_ix.end(), i) - seg_ix.begin()] = P;
+            max_segs = std::max(max_segs, im.n_segs_ub);
+        } else {
+            const size_t ni = im.f.n_intervals;
+            jda_prescan_params P;
+            memset(&P, 0, sizeof(P));
+            P.scan = B + im.off_scan; P.tables = B + im.ctl_tables;
+            P.restart_pos = (const uint32_t *)(B + im.off_work);
+            P.phase_map = (uint32_t *)(B + im.off_work + a16((ni + 1) * 4));
+            P.start_phase = B + im.off_work + a16((ni + 1) * 4) + a16(ni * 4);
+            P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
+            P.stats = pstats;
+            P.scan_len = im.f.raw_len; P.n_intervals = im.f.n_intervals; P.n_mcus = (uint32_t)(I.mcus_x * I.mcus_y);
+            P.interval_mcus = (uint32_t)I.restart_interval;
+            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
+            for (int c = 0; c < 3; c++) { P.dc_id[c] = im.f.dc_id[c]; P.ac_id[c] = im.f.ac_id[c]; }
+            P.filter_result = fres;
+            pp[std::find(int_ix.begin(), int_ix.end(), i) - int_ix.begin()] = P;
+            max_int = std::max(max_int, im.f.n_intervals);
+        }
+    }
+    p->workers->run((int)dev_ix.size(), [&](int k) {
+        const int i = dev_ix[(size_t)k];
+        const Img &im = S.imgs[(size_t)i];
+        const jda_dev_desc &D = descs[(size_t)i];
+        fill_strips((jda_strip *)(S.pin + S.list_off[im.list]) + im.strip_off, im.n_tiles, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, im.ord);
+    });
+
+    // ---- enqueue: upload stream
+    hipError_t e = hipSuccess;
+    uint8_t *B = S.dev;
+    if (n_dev) {
+        e = hipMemsetAsync(B + zero_begin, 0, zero_end - zero_begin, p->s_copy);
+        if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, S.ctl_bytes, hipMemcpyHostToDevice, p->s_copy);
+        for (size_t k = 0; k < dev_ix.size() && e == hipSuccess; k++) {
+            const int i = dev_ix[k];
+            const Img &im = S.imgs[(size_t)i];
+            e = hipMemcpyAsync(B + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len, hipMemcpyHostToDevice, p->s_copy);
+            S.st.h2d_bytes += im.f.raw_len;
+        }
+        S.st.h2d_bytes += (int64_t)S.ctl_bytes;
+        if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->s_up, S.ev_copy, 0);
+        if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), p->s_up);
+        if (e == hipSuccess && !int_ix.empty()) {
+            const jda_prescan_params *dp = (const jda_prescan_params *)(B + off_pparams);
+            e = jda_launch_prescan(dp, (uint32_t)int_ix.size(), max_int, 0, p->s_up);                                  // MAP
+            if (e == hipSuccess) e = jda_launch_prescan_compose(dp, (uint32_t)int_ix.size(), p->s_up);                 // phases + result words
+            if (e == hipSuccess) e = jda_launch_prescan(dp, (uint32_t)int_ix.size(), max_int, 1, p->s_up);             // EXACT
+        }
+        if (e == hipSuccess && !seg_ix.empty()) {
+            const jda_segscan_params *dp = (const jda_segscan_params *)(B + off_sparams);
+            const uint32_t ns = (uint32_t)seg_ix.size();
+            // speculative rounds with the count pass folded in (work lists: a round after the first walks what the one before changed)
+            for (uint32_t r = 0; r < JDA_PIPE_SPEC_ROUNDS && e == hipSuccess; r++) e = jda_launch_segscan_fused(dp, ns, max_segs, r, p->s_up);
+            if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, p->s_up);
+            if (e == hipSuccess) e = jda_launch_segscan(dp, ns, max_segs, JDA_SEG_WRITE, 0, p->s_up);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.ctl_bytes, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, p->s_up);
+    }
+    if (e == hipSuccess) e = hipEventRecord(S.ev_up, p->s_up);
+    // ---- enqueue: decode stream
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, S.ev_up, 0);
+    for (int m = 0; m < JDA_N_LISTS && e == hipSuccess && n_dev; m++) {
+        if (!S.list_n[m]) continue;
+        e = jda_launch_decode(m >> 4, (m >> 3) & 1, (m >> 1) & 3, m & 1, (const jda_dev_desc *)(B + S.off_descs), (const jda_strip *)(B + S.list_off[m]), S.list_n[m], ctx->stream);
+        S.st.launches++;
+    }
+    if (e == hipSuccess) e = hipEventRecord(S.ev_dec, ctx->stream);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(p->s_copy); (void)hipStreamSynchronize(p->s_up); (void)hipStreamSynchronize(ctx->stream); return jda_set_err(ctx, e, "jda_pipeline_submit"); }
+    S.ticket = t; S.in_flight = true;
+    p->next_ticket++;
+    *ticket = t;
+    return JDA_SUCCESS;
+}
+
+// the serial path for one image: host pre-scan, upload, decode into the caller's surface; returns the image's status
+static int slow_path(jda_pipeline *p, const uint8_t *jpeg, int32_t len, const jda_output &O, int32_t pt, int32_t opt)
+{
+    jda_ctx *ctx = p->ctx;
+    int32_t err = JDA_SUCCESS;
+    jda_image *img = jda_prepare_ex(jpeg, len, 0, &err);
+    if (!img) return err;
+    jda_dev_image *d = jda_upload(ctx, img, &err);
+    uint32_t nok = 0;
+    (void)jda_image_block_index(img, &nok);
+    const jda_image_info I = *jda_image_get_info(img);
+    jda_image_free(img);
+    if (!d) return err;
+    int rc = JDA_SUCCESS;
+    jda_batch *b = jda_batch_create(ctx, 1, &d, &O, &pt, &opt, &err);
+    if (!b) rc = err;
+    else {
+        const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
+        if (!complete) {                                      // the reference leaves the MCUs behind the bad one undrawn: zeros here
+            int bpp, ow, oh, cw, ch;
+            if (jda_output_geometry(&I, pt, opt, &bpp, &ow, &oh, &cw, &ch) == JDA_SUCCESS) {
+                const size_t wbytes = (size_t)std::min(O.width_px, cw) * bpp;
+                (void)hipMemset2DAsync(O.pixels, (size_t)O.pitch_bytes, 0, wbytes, (size_t)std::min(O.rows, ch), ctx->stream);
+            }
+        }
+        rc = jda_batch_decode(ctx, b);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == JDA_SUCCESS) rc = JDA_ERROR_HIP;
+        jda_batch_destroy(ctx, b);
+        if (rc == JDA_SUCCESS && !complete) rc = JDA_DECODE_ERROR;      // jpeg.inl:5354-5356
+    }
+    jda_dev_image_free(ctx, d);
+    return rc;
+}
+
+int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status)
+{
+    if (!p) return JDA_ERROR_NO_DEVICE;
+    if (ticket < 0 || ticket >= p->next_ticket) return JDA_INVALID_PARAMETER;
+    jda_pipeline::Slot &S = p->slots[ticket % p->depth];
+    if (!S.in_flight || S.ticket != ticket) return JDA_INVALID_PARAMETER;
+    jda_ctx *ctx = p->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipError_t e = hipEventSynchronize(S.ev_dec);
+    S.in_flight = false;
+    if (e != hipSuccess) return jda_set_err(ctx, e, "jda_pipeline_wait");
+    const int n = (int)S.imgs.size();
+    int first_err = JDA_SUCCESS;
+    for (int i = 0; i < n; i++) {
+        Img &im = S.imgs[(size_t)i];
+        int st = im.err;
+        if (st == JDA_SUCCESS) {
+            bool redo = !im.device;
+            if (im.device) {
+                const uint32_t *rb = (const uint32_t *)(S.pin + S.ctl_bytes + (im.off_stats - S.off_stats_dev));
+                const uint32_t *ps = rb + 4;
+                uint32_t max_ac = 0, max_dc = 0;
+                bool ok;
+                if (im.seg_mode) {
+                    ok = ps[8 + JDA_PIPE_SPEC_ROUNDS] == 0 && ps[6] == 1 && ps[0] == 0 && ps[1] == 1;   // the last round left nothing to walk; enough blocks; no bad code; closing entry once
+                    max_ac = ps[2]; max_dc = ps[3];
+                    S.st.spec_rounds_max = std::max<int32_t>(S.st.spec_rounds_max, [&]() { int r = 1; while (r <= JDA_PIPE_SPEC_ROUNDS && ps[8 + r]) r++; return r; }());
+                } else {
+                    ok = ps[0] == 0xffffffffu && ps[1] == 0;
+                    max_ac = ps[2]; max_dc = ps[3];
+                }
+                if (ok && im.fast && !jda_front_fast_mul(S.pin + im.ctl_tables, &im.f, max_ac, (int32_t)max_dc)) ok = false;   // a magnitude no legal stream has
+                redo = !ok;
+                if (ok) S.st.device_images++;
+                else {
+                    static const bool trace = getenv("JDA_PIPE_TRACE") != NULL;
+                    if (trace) fprintf(stderr, "jda_pipeline: image %d (%dx%d, %s) of ticket %d goes to the host path: filter %u bytes / %u markers, result words %u %u %u %u %u, [6] %u, last round %u, fast %d\n",
+                                       i, im.f.info.width, im.f.info.height, im.seg_mode ? "segments" : "intervals", ticket, rb[0], rb[1], ps[0], ps[1], ps[2], ps[3], ps[4], ps[6],
+                                       ps[8 + JDA_PIPE_SPEC_ROUNDS], (int)im.fast);
+                }
+            }
+            if (redo) { st = slow_path(p, S.jpegs[(size_t)i], S.lens[(size_t)i], S.outs[(size_t)i], S.pts[(size_t)i], S.opts[(size_t)i]); S.st.host_path_images++; }
+        }
+        if (status) status[i] = st;
+        if (st != JDA_SUCCESS && first_err == JDA_SUCCESS) first_err = st;
+        if (st != JDA_SUCCESS) S.st.failed_images++;
+    }
+    p->total.images += S.st.images; p->total.device_images += S.st.device_images; p->total.host_path_images += S.st.host_path_images;
+    p->total.failed_images += S.st.failed_images; p->total.source_pixels += S.st.source_pixels; p->total.compressed_bytes += S.st.compressed_bytes;
+    p->total.h2d_bytes += S.st.h2d_bytes; p->total.launches += S.st.launches;
+    p->total.spec_rounds_max = std::max(p->total.spec_rounds_max, S.st.spec_rounds_max);
+    (void)first_err;
+    return JDA_SUCCESS;
+}
+
+// After jda_pipeline_wait(ticket) and before the slot is used again: the per-block index and DC predictors the device made for
+// image i of that batch (tests: they must equal the serial pre-scan's).  JDA_INVALID_PARAMETER if the image did not take the
+// device path.
+int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t *index, int16_t *dc, uint32_t *filtered_len)
+{
+    if (!p) return JDA_ERROR_NO_DEVICE;
+    if (ticket < 0 || ticket >= p->next_ticket) return JDA_INVALID_PARAMETER;
+    jda_pipeline::Slot &S = p->slots[ticket % p->depth];
+    if (S.in_flight || S.ticket != ticket || i < 0 || i >= (int)S.imgs.size() || !S.imgs[(size_t)i].device) return JDA_INVALID_PARAMETER;
+    const Img &im = S.imgs[(size_t)i];
+    (void)hipSetDevice(p->ctx->device);
+    hipError_t e = hipSuccess;
+    if (index) e = hipMemcpy(index, S.dev + im.off_index, ((size_t)im.n_blocks + 1) * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && dc) e = hipMemcpy(dc, S.dev + im.off_dc, (size_t)im.n_blocks * 2, hipMemcpyDeviceToHost);
+    if (filtered_len) *filtered_len = ((const uint32_t *)(S.pin + S.ctl_bytes + (im.off_stats - S.off_stats_dev)))[0];
+    return e == hipSuccess ? JDA_SUCCESS : jda_set_err(p->ctx, e, "jda_pipeline_read_index");
+}
+
+int jda_pipeline_get_stats(const jda_pipeline *p, jda_pipeline_stats *out)
+{
+    if (!p || !out) return JDA_INVALID_PARAMETER;
+    *out = p->total;
+    return JDA_SUCCESS;
+}
+
+} // extern "C"

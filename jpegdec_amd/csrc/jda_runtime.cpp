@@ -17,8 +17,7 @@
 #include <thread>
 #include <vector>
 
-#include "jda_internal.h"
-#include "jda_plan.h"
+#include "jda_runtime_internal.h"
 
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
 extern "C" uint32_t jda_image_general_p1(const jda_image *img);
@@ -26,17 +25,9 @@ extern "C" const uint32_t *jda_image_restart_positions(const jda_image *img, uin
 extern "C" void jda_image_run_host_prescan(jda_image *img);
 extern "C" int jda_image_index_on_device(const jda_image *img);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
-extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
-extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
-extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, hipStream_t stream);
-extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
-extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, const jda_dev_desc *descs, const jda_strip *strips,
-                                        uint32_t n_strips, hipStream_t stream);
-// launch lists of a batch: one per (mode, fast_mul, kernel variant, window size); index = ((mode * 2 + fast) * 4 + variant) * 2 + big
-#define JDA_N_LISTS (16 * JDA_N_MODES)
 // The plain-case kernel variants (jda_desc_uniform in jda_kernels.hip): full size, every multiply in 24 bits, no stream flags,
 // and one of the (layout, output format) pairs a kernel was built for.  0 = the general kernel.
-static int jda_plain_variant(const jda_dev_desc &D)
+int jda_plain_variant(const jda_dev_desc &D)
 {
     if (D.scale_shift != 0 || D.pad_[0] != 0 || !D.fast_mul) return 0;
     const bool colour = D.mode != JDA_MODE_GRAY;
@@ -50,7 +41,7 @@ static int jda_plain_variant(const jda_dev_desc &D)
 // a tile whose slice of the scan does not fit the window takes the general bit reader, which goes to HBM at every refill.
 // Decided per image from its average bytes of scan per full tile (+ 50 % for the spread between tiles); the kernels exist for
 // the general variant and the RGB8888 plain case, 24-bit multiplies.  JDA_BIG_WINDOW=0 / 1 forces the choice (A/B runs).
-static int jda_big_window(const jda_dev_desc &D, int variant)
+int jda_big_window(const jda_dev_desc &D, int variant)
 {
     static int forced = -2;
     if (forced == -2) {
@@ -66,55 +57,17 @@ static int jda_big_window(const jda_dev_desc &D, int variant)
     return avg + avg / 2 + 48 > jda_window_bytes(D.mode, 0) ? 1 : 0;
 }
 
-#define JDA_POOL_SLOTS 192
-#define JDA_POOL_IDLE_MAX ((size_t)2 << 30)      // idle bytes kept at most
-struct jda_ctx {
-    int device;
-    hipStream_t stream;
-    hipEvent_t ev_start, ev_stop;
-    uint8_t *pinned;          // page-locked staging for uploads (grow-only, reused)
-    size_t pinned_cap;
-    int last_segscan_rounds;  // speculative rounds the last marker-less device pre-scan needed (diagnostics)
-    char last_error[256];
-    // Device blocks the runtime allocated for itself (resident images, launch plans, the one-call path's surface), kept when
-    // released and handed out again: hipFree costs ~0.23 ms and synchronises the device, which was most of a small image's
-    // time through jda_decode_to_host (the JPEGDEC class).  Everything of a context runs on its one stream, so a block
-    // released while work on it is still queued is safe to reuse: the next user's work queues behind it.
-    struct { void *p; size_t bytes; bool busy; } pool[JDA_POOL_SLOTS];
-    size_t pool_idle;
-};
-
-struct jda_dev_image {
-    uint8_t *base;            // one allocation: tables | index | dc | scan
-    size_t bytes;
-    size_t off_tables, off_index, off_dc, off_scan;
-    jda_image_info info;
-    uint32_t scan_len, n_mcus_ok;
-    uint8_t dc_id[3], ac_id[3], q_id[3];
-    uint8_t fast_mul;
-    uint8_t general_p1;          // JDA_DESC_GENERAL_P1
-    uint8_t prescan_on_device;   // the block index was made by jda_prescan_intervals (restart-marker fast path)
-};
-
-struct jda_batch {
-    int32_t n_images;
-    jda_dev_desc *d_descs;
-    jda_strip *d_strips[JDA_N_LISTS];
-    uint32_t n_strips[JDA_N_LISTS];
-    jda_batch_stats stats;
-};
-
-static int set_err(jda_ctx *ctx, hipError_t e, const char *what)
+int jda_set_err(jda_ctx *ctx, hipError_t e, const char *what)
 {
     if (ctx) snprintf(ctx->last_error, sizeof(ctx->last_error), "%s: %s", what, hipGetErrorString(e));
     return JDA_ERROR_HIP;
 }
 
-#define JDA_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err((ctx), e_, #call); } while (0)
+#define JDA_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return jda_set_err((ctx), e_, #call); } while (0)
 
 static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-static hipError_t pool_alloc(jda_ctx *ctx, void **out, size_t bytes)
+hipError_t jda_pool_alloc(jda_ctx *ctx, void **out, size_t bytes)
 {
     if (!bytes) bytes = 16;
     int best = -1, empty = -1;
@@ -128,7 +81,7 @@ static hipError_t pool_alloc(jda_ctx *ctx, void **out, size_t bytes)
     if (e == hipSuccess && empty >= 0) { ctx->pool[empty].p = *out; ctx->pool[empty].bytes = bytes; ctx->pool[empty].busy = true; }
     return e;          // (no slot left: the block is not tracked and pool_free hands it to hipFree)
 }
-static void pool_free(jda_ctx *ctx, void *p)
+void jda_pool_free(jda_ctx *ctx, void *p)
 {
     if (!p) return;
     for (int i = 0; i < JDA_POOL_SLOTS; i++)
@@ -201,7 +154,7 @@ void *jda_malloc(jda_ctx *ctx, size_t bytes)
     void *p = NULL;
     (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-    if (e != hipSuccess) { set_err(ctx, e, "hipMalloc"); return NULL; }
+    if (e != hipSuccess) { jda_set_err(ctx, e, "hipMalloc"); return NULL; }
     return p;
 }
 
@@ -267,7 +220,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     hipError_t e = hipSuccess;
     for (int i = 0; i < n; i++) out[i] = NULL;
     auto fail_all = [&](int code) {
-        for (int i = 0; i < n; i++) { if (items[i].d) { if (items[i].d->base) pool_free(ctx, items[i].d->base); delete items[i].d; items[i].d = NULL; } out[i] = NULL; }
+        for (int i = 0; i < n; i++) { if (items[i].d) { if (items[i].d->base) jda_pool_free(ctx, items[i].d->base); delete items[i].d; items[i].d = NULL; } out[i] = NULL; }
         return code;
     };
     std::vector<jda_prescan_params> params;
@@ -362,8 +315,8 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.off_sstats = it.off_start + align16((size_t)it.n_segs * 20);
             it.alloc = it.off_sstats + 256;
         }
-        e = pool_alloc(ctx, (void **)&d->base, it.alloc);
-        if (e != hipSuccess) { set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
+        e = jda_pool_alloc(ctx, (void **)&d->base, it.alloc);
+        if (e != hipSuccess) { jda_set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
         if (it.seg_mode) {
             // only the tables and the scan travel; everything behind the scan's last byte starts as zeros (padding, round-0
             // entry states, counters).  The index is written by the WRITE pass.
@@ -379,7 +332,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
                 if (e == hipSuccess) e = hipMemcpyAsync(d->base + d->off_scan, it.stage + align16(it.tbytes), scan_len, hipMemcpyHostToDevice, ctx->stream);
             }
             if (e == hipSuccess) e = hipMemsetAsync(d->base + d->off_scan + scan_len, 0, it.alloc - (d->off_scan + scan_len), ctx->stream);
-            if (e != hipSuccess) { rc = set_err(ctx, e, "hipMemcpy(image)"); break; }
+            if (e != hipSuccess) { rc = jda_set_err(ctx, e, "hipMemcpy(image)"); break; }
             jda_segscan_params SP;
             memset(&SP, 0, sizeof(SP));
             SP.scan = d->base + d->off_scan; SP.tables = d->base + d->off_tables;
@@ -423,16 +376,16 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             memcpy(it.stage + d->off_dc, jda_image_block_dc(img), it.n_blocks * sizeof(int16_t));
         }
         e = hipMemcpyAsync(d->base, it.stage, it.alloc, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { rc = set_err(ctx, e, "hipMemcpy(image)"); break; }
+        if (e != hipSuccess) { rc = jda_set_err(ctx, e, "hipMemcpy(image)"); break; }
     }
     flush_stage_jobs();
-    if (rc == JDA_SUCCESS && stage_err != hipSuccess) rc = set_err(ctx, stage_err, "hipMemcpy(image)");
+    if (rc == JDA_SUCCESS && stage_err != hipSuccess) rc = jda_set_err(ctx, stage_err, "hipMemcpy(image)");
     if (rc != JDA_SUCCESS) { (void)hipStreamSynchronize(ctx->stream); return fail_all(rc); }
     JDA_UP_MARK("alloc + stage + H2D");
 
     jda_prescan_params *d_params = NULL;
     if (!params.empty()) {
-        e = pool_alloc(ctx, (void **)&d_params, params.size() * sizeof(jda_prescan_params));
+        e = jda_pool_alloc(ctx, (void **)&d_params, params.size() * sizeof(jda_prescan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), params.size() * sizeof(jda_prescan_params), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = jda_launch_prescan(d_params, (uint32_t)params.size(), max_int, 0, ctx->stream);          // MAP
         for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
@@ -456,7 +409,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     jda_segscan_params *d_seg = NULL;
     if (!seg_params.empty() && e == hipSuccess) {
         const uint32_t ns = (uint32_t)seg_params.size();
-        e = pool_alloc(ctx, (void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
+        e = jda_pool_alloc(ctx, (void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg_params.data(), seg_params.size() * sizeof(jda_segscan_params), hipMemcpyHostToDevice, ctx->stream);
         const uint32_t kMaxRounds = 48;                     // (the result words hold a change counter per round: 8 + 48 <= 64)
         uint32_t rounds = 0;
@@ -495,9 +448,9 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     JDA_UP_MARK("write pass + D2H");
-    if (d_params) pool_free(ctx, d_params);
-    if (d_seg) pool_free(ctx, d_seg);
-    if (e != hipSuccess) return fail_all(set_err(ctx, e, "jda_upload_batch"));
+    if (d_params) jda_pool_free(ctx, d_params);
+    if (d_seg) jda_pool_free(ctx, d_seg);
+    if (e != hipSuccess) return fail_all(jda_set_err(ctx, e, "jda_upload_batch"));
 
     // a marker that is not where the MCU count puts it, or a corrupt interval: the serial host pre-scan reproduces
     // what the reference does with such a stream
@@ -536,7 +489,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         }
     }
     if (reupload && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return fail_all(set_err(ctx, e, "jda_upload_batch(re-upload)"));
+    if (e != hipSuccess) return fail_all(jda_set_err(ctx, e, "jda_upload_batch(re-upload)"));
     for (int i = 0; i < n; i++) {
         uint32_t nok = 0;
         (void)jda_image_block_index(imgs[i], &nok);
@@ -571,7 +524,7 @@ int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t 
     const size_t off_out = raw_cap, off_rpos = off_out + align16((size_t)len + 16), off_res = off_rpos + align16(rcap * 4), off_par = off_res + 16;
     uint8_t *d = NULL;
     hipError_t e = hipMalloc((void **)&d, off_par + sizeof(jda_filter_params));
-    if (e != hipSuccess) return set_err(ctx, e, "hipMalloc(filter)");
+    if (e != hipSuccess) return jda_set_err(ctx, e, "hipMalloc(filter)");
     jda_filter_params P;
     P.raw = d; P.out = d + off_out; P.restart_pos = (uint32_t *)(d + off_rpos); P.result = (uint32_t *)(d + off_res);
     P.raw_len = (uint32_t)len; P.restart_cap = (uint32_t)rcap;
@@ -586,7 +539,7 @@ int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t 
     if (e == hipSuccess && restart_pos && restart_cap > 0)
         e = hipMemcpy(restart_pos, d + off_rpos, (size_t)std::min<uint32_t>(res[1] + 1, (uint32_t)restart_cap) * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d);
-    if (e != hipSuccess) return set_err(ctx, e, "jda_filter_on_device");
+    if (e != hipSuccess) return jda_set_err(ctx, e, "jda_filter_on_device");
     *out_len = (int32_t)res[0];
     if (n_restarts) *n_restarts = (int32_t)res[1];
     return JDA_SUCCESS;
@@ -600,18 +553,54 @@ int jda_dev_image_read_index(jda_ctx *ctx, const jda_dev_image *dimg, uint32_t *
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && index) e = hipMemcpy(index, dimg->base + dimg->off_index, (nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess && dc) e = hipMemcpy(dc, dimg->base + dimg->off_dc, nb * sizeof(int16_t), hipMemcpyDeviceToHost);
-    return e == hipSuccess ? JDA_SUCCESS : set_err(ctx, e, "jda_dev_image_read_index");
+    return e == hipSuccess ? JDA_SUCCESS : jda_set_err(ctx, e, "jda_dev_image_read_index");
 }
 
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg)
 {
     if (!dimg) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (dimg->base) { if (ctx) pool_free(ctx, dimg->base); else (void)hipFree(dimg->base); }
+    if (dimg->base) { if (ctx) jda_pool_free(ctx, dimg->base); else (void)hipFree(dimg->base); }
     delete dimg;
 }
 
 size_t jda_dev_image_bytes(const jda_dev_image *dimg) { return dimg ? dimg->bytes : 0; }
+
+} // extern "C"
+
+int jda_fill_launch_desc(jda_dev_desc &D, const jda_image_info &I, const uint8_t dc_id[3], const uint8_t ac_id[3], const uint8_t q_id[3],
+                         int fast_mul, int general_p1, uint32_t n_mcus_ok, uint32_t scan_len, const jda_output &O, int pt_req, int options,
+                         int *bpp_out)
+{
+    const int opt = jda_effective_options(&I, options);      // progressive: 1/8 thumbnail from the DC scan
+    memset(&D, 0, sizeof(D));
+    if (pt_req < 0 || pt_req > JDA_EIGHT_BIT_GRAYSCALE) return JDA_INVALID_PARAMETER;
+    int pt = pt_req;
+    if ((opt & JDA_LUMA_ONLY) && pt < JDA_EIGHT_BIT_GRAYSCALE) pt = JDA_EIGHT_BIT_GRAYSCALE;   // jpeg.inl:4991-4993
+    int bpp, ow, oh, cw, ch;
+    { const int grc = jda_output_geometry(&I, pt, opt, &bpp, &ow, &oh, &cw, &ch); if (grc != JDA_SUCCESS) return grc; }
+    D.mode = (uint8_t)jda_mode_of(I);
+    D.ncomp = (uint8_t)I.ncomp;
+    D.pixel_type = (uint8_t)((D.mode == JDA_MODE_GRAY && pt == JDA_RGB8888) ? JDA_RGB565_BIG_ENDIAN : pt);
+    D.scale_shift = (uint8_t)((opt & JDA_SCALE_HALF) ? 1 : (opt & JDA_SCALE_QUARTER) ? 2 : (opt & JDA_SCALE_EIGHTH) ? 3 : 0);
+    D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE);
+    memcpy(D.dc_id, dc_id, 3); memcpy(D.ac_id, ac_id, 3); memcpy(D.q_id, q_id, 3);
+    D.fast_mul = (uint8_t)(fast_mul ? 1 : 0);
+    { static const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = (uint8_t)((dbg ? (atoi(dbg) & 3) : 0) | jda_desc_stream_bits(I) | (general_p1 ? JDA_DESC_GENERAL_P1 : 0u)); }   // profiling aid: 1 = no P4, 2 = no IDCT
+    D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
+    D.n_mcus_ok = n_mcus_ok; D.scan_len = scan_len;
+    D.out = (uint8_t *)O.pixels;
+    D.out_pitch = (uint32_t)O.pitch_bytes;
+    D.out_w = (uint32_t)(O.width_px < cw ? O.width_px : cw);
+    D.out_rows = (uint32_t)(O.rows < ch ? O.rows : ch);
+    // the kernels address a surface with 32-bit byte offsets: MCU-padded rows x pitch must stay below 4 GiB
+    if (!O.pixels || ((uintptr_t)O.pixels & 15) || (O.pitch_bytes & 15) || O.width_px < 0 || O.rows < 0 || O.pitch_bytes < (int)D.out_w * bpp ||
+        (uint64_t)(ch + 16) * (uint64_t)O.pitch_bytes >= (1ull << 32) || O.pitch_bytes >= (1 << 23)) return JDA_INVALID_PARAMETER;
+    if (bpp_out) *bpp_out = bpp;
+    return JDA_SUCCESS;
+}
+
+extern "C" {
 
 jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *images,
                             const jda_output *outputs, const int32_t *pixel_types,
@@ -629,39 +618,15 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         const jda_dev_image *im = images[i];
         if (!im) { *err = JDA_INVALID_PARAMETER; return NULL; }
         const jda_image_info &I = im->info;
-        const int pt_req = pixel_types ? pixel_types[i] : JDA_RGB8888;
-        const int opt = jda_effective_options(&I, options ? options[i] : 0);      // progressive: 1/8 thumbnail from the DC scan
         jda_dev_desc &D = descs[(size_t)i];
-        memset(&D, 0, sizeof(D));
-        if (pt_req < 0 || pt_req > JDA_EIGHT_BIT_GRAYSCALE) { *err = JDA_INVALID_PARAMETER; return NULL; }
-        int pt = pt_req;
-        if ((opt & JDA_LUMA_ONLY) && pt < JDA_EIGHT_BIT_GRAYSCALE) pt = JDA_EIGHT_BIT_GRAYSCALE;   // jpeg.inl:4991-4993
-        int bpp, ow, oh, cw, ch;
-        { const int grc = jda_output_geometry(&I, pt, opt, &bpp, &ow, &oh, &cw, &ch); if (grc != JDA_SUCCESS) { *err = grc; return NULL; } }
-        const jda_output &O = outputs[i];
-        D.mode = (uint8_t)jda_mode_of(I);
-        D.ncomp = (uint8_t)I.ncomp;
-        D.pixel_type = (uint8_t)((D.mode == JDA_MODE_GRAY && pt == JDA_RGB8888) ? JDA_RGB565_BIG_ENDIAN : pt);
-        D.scale_shift = (uint8_t)((opt & JDA_SCALE_HALF) ? 1 : (opt & JDA_SCALE_QUARTER) ? 2 : (opt & JDA_SCALE_EIGHTH) ? 3 : 0);
-        D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE);
-        memcpy(D.dc_id, im->dc_id, 3); memcpy(D.ac_id, im->ac_id, 3); memcpy(D.q_id, im->q_id, 3);
-        D.fast_mul = im->fast_mul;
-        { const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = (uint8_t)((dbg ? (atoi(dbg) & 3) : 0) | jda_desc_stream_bits(I) | (im->general_p1 ? JDA_DESC_GENERAL_P1 : 0u)); }   // profiling aid: 1 = no P4, 2 = no IDCT
-        D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
-        D.n_mcus_ok = im->n_mcus_ok; D.scan_len = im->scan_len;
+        int bpp = 0;
+        const int rc = jda_fill_launch_desc(D, I, im->dc_id, im->ac_id, im->q_id, im->fast_mul, im->general_p1, im->n_mcus_ok, im->scan_len,
+                                            outputs[i], pixel_types ? pixel_types[i] : JDA_RGB8888, options ? options[i] : 0, &bpp);
+        if (rc != JDA_SUCCESS) { *err = rc; return NULL; }
         D.tables = im->base + im->off_tables;
         D.blk_index = (const uint32_t *)(im->base + im->off_index);
         D.blk_dc = (const int16_t *)(im->base + im->off_dc);
         D.scan = im->base + im->off_scan;
-        D.out = (uint8_t *)O.pixels;
-        D.out_pitch = (uint32_t)O.pitch_bytes;
-        D.out_w = (uint32_t)(O.width_px < cw ? O.width_px : cw);
-        D.out_rows = (uint32_t)(O.rows < ch ? O.rows : ch);
-        // the kernels address a surface with 32-bit byte offsets: MCU-padded rows x pitch must stay below 4 GiB
-        if (!O.pixels || ((uintptr_t)O.pixels & 15) || (O.pitch_bytes & 15) || O.pitch_bytes < (int)D.out_w * bpp ||
-            (uint64_t)(ch + 16) * (uint64_t)O.pitch_bytes >= (1ull << 32) || O.pitch_bytes >= (1 << 23)) {
-            *err = JDA_INVALID_PARAMETER; return NULL;
-        }
         // kernel variant 1: the plain case -- full size, RGB8888, every block decoded -- runs a kernel in which these
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
@@ -678,19 +643,19 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     memset(b, 0, sizeof(*b));
     b->n_images = n;
     (void)hipSetDevice(ctx->device);
-    hipError_t e = pool_alloc(ctx, (void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
+    hipError_t e = jda_pool_alloc(ctx, (void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
     if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
     for (int m = 0; m < JDA_N_LISTS && e == hipSuccess; m++) {
         b->n_strips[m] = (uint32_t)strips[m].size();
         if (!b->n_strips[m]) continue;
-        e = pool_alloc(ctx, (void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
+        e = jda_pool_alloc(ctx, (void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
         st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 16, m & 1));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        set_err(ctx, e, "jda_batch_create");
+        jda_set_err(ctx, e, "jda_batch_create");
         jda_batch_destroy(ctx, b);
         *err = JDA_ERROR_HIP;
         return NULL;
@@ -704,8 +669,8 @@ void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
 {
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (b->d_descs) { if (ctx) pool_free(ctx, b->d_descs); else (void)hipFree(b->d_descs); }
-    for (int m = 0; m < JDA_N_LISTS; m++) if (b->d_strips[m]) { if (ctx) pool_free(ctx, b->d_strips[m]); else (void)hipFree(b->d_strips[m]); }
+    if (b->d_descs) { if (ctx) jda_pool_free(ctx, b->d_descs); else (void)hipFree(b->d_descs); }
+    for (int m = 0; m < JDA_N_LISTS; m++) if (b->d_strips[m]) { if (ctx) jda_pool_free(ctx, b->d_strips[m]); else (void)hipFree(b->d_strips[m]); }
     delete b;
 }
 
@@ -794,7 +759,7 @@ int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_
     jda_image_free(img);
     if (!dimg) return err;
     void *dout = NULL;
-    if (pool_alloc(ctx, &dout, (size_t)dpitch * ch) != hipSuccess) dout = NULL;
+    if (jda_pool_alloc(ctx, &dout, (size_t)dpitch * ch) != hipSuccess) dout = NULL;
     if (!dout) { jda_dev_image_free(ctx, dimg); return JDA_ERROR_MEMORY; }
     jda_output O;
     O.pixels = dout; O.pitch_bytes = dpitch; O.width_px = cw; O.rows = drows;
@@ -808,12 +773,12 @@ int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_
             const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
             hipError_t e = hipMemcpy2DAsync(host_pixels, (size_t)pitch_bytes, dout, (size_t)dpitch, row_bytes, (size_t)drows, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) rc = set_err(ctx, e, "copy back");
+            if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
         }
         JDA_OC_MARK("decode + copy back");
         jda_batch_destroy(ctx, b);
     }
-    pool_free(ctx, dout);
+    jda_pool_free(ctx, dout);
     jda_dev_image_free(ctx, dimg);
     JDA_OC_MARK("release");
 #undef JDA_OC_MARK

@@ -1,0 +1,72 @@
+// jda_runtime_internal.h -- what the pieces of the device runtime (jda_runtime.cpp, jda_pipeline.cpp) share.
+#ifndef JDA_RUNTIME_INTERNAL_H
+#define JDA_RUNTIME_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include "jda_internal.h"
+#include "jda_plan.h"
+
+// launch lists of a batch: one per (mode, fast_mul, kernel variant, window size); index = ((mode * 2 + fast) * 4 + variant) * 2 + big
+#define JDA_N_LISTS (16 * JDA_N_MODES)
+
+#define JDA_POOL_SLOTS 192
+#define JDA_POOL_IDLE_MAX ((size_t)2 << 30)      // idle bytes kept at most
+struct jda_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev_start, ev_stop;
+    uint8_t *pinned;          // page-locked staging for uploads (grow-only, reused)
+    size_t pinned_cap;
+    int last_segscan_rounds;  // speculative rounds the last marker-less device pre-scan needed (diagnostics)
+    char last_error[256];
+    // Device blocks the runtime allocated for itself (resident images, launch plans, the one-call path's surface), kept when
+    // released and handed out again: hipFree costs ~0.23 ms and synchronises the device, which was most of a small image's
+    // time through jda_decode_to_host (the JPEGDEC class).  Everything of a context runs on its one stream, so a block
+    // released while work on it is still queued is safe to reuse: the next user's work queues behind it.
+    struct { void *p; size_t bytes; bool busy; } pool[JDA_POOL_SLOTS];
+    size_t pool_idle;
+};
+
+struct jda_dev_image {
+    uint8_t *base;            // one allocation: tables | index | dc | scan
+    size_t bytes;
+    size_t off_tables, off_index, off_dc, off_scan;
+    jda_image_info info;
+    uint32_t scan_len, n_mcus_ok;
+    uint8_t dc_id[3], ac_id[3], q_id[3];
+    uint8_t fast_mul;
+    uint8_t general_p1;          // JDA_DESC_GENERAL_P1
+    uint8_t prescan_on_device;   // the block index was made by jda_prescan_intervals (restart-marker fast path)
+};
+
+struct jda_batch {
+    int32_t n_images;
+    jda_dev_desc *d_descs;
+    jda_strip *d_strips[JDA_N_LISTS];
+    uint32_t n_strips[JDA_N_LISTS];
+    jda_batch_stats stats;
+};
+
+
+int jda_set_err(jda_ctx *ctx, hipError_t e, const char *what);
+hipError_t jda_pool_alloc(jda_ctx *ctx, void **out, size_t bytes);
+void jda_pool_free(jda_ctx *ctx, void *p);
+int jda_plain_variant(const jda_dev_desc &D);
+int jda_big_window(const jda_dev_desc &D, int variant);
+// Fill the descriptor of one image of a launch plan (everything but the pointers into the image's HBM block, which the
+// caller sets) and validate the output surface.  Returns JDA_SUCCESS or the error jda_batch_create reports.
+int jda_fill_launch_desc(jda_dev_desc &D, const jda_image_info &I, const uint8_t dc_id[3], const uint8_t ac_id[3], const uint8_t q_id[3],
+                         int fast_mul, int general_p1, uint32_t n_mcus_ok, uint32_t scan_len, const jda_output &O, int pixel_type, int options,
+                         int *bpp_out);
+
+extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
+extern "C" hipError_t jda_launch_prescan_compose(const jda_prescan_params *params, uint32_t n_images, hipStream_t stream);
+extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
+extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream);
+extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, hipStream_t stream);
+extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
+extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, const jda_dev_desc *descs, const jda_strip *strips,
+                                        uint32_t n_strips, hipStream_t stream);
+
+#endif

@@ -1,0 +1,165 @@
+"""The streamed pipeline (jda_pipeline_*): unfiltered scans to the GPU, marker filter + per-block index + decode on the device,
+batches overlapped on two streams, per-image status.  Parity: every image's pixels == the oracle's, the device-made index ==
+the serial host pre-scan's entry for entry (the filtered length too), a bad image does not poison its batch."""
+import numpy as np
+import pytest
+
+import jpegdec_amd as J
+from oracle.loader import digest
+from tests.cases import PROGRESSIVE_CASES, SYNTH_CASES, jpeg_for
+from tests.ref_fixtures import FAIL_IN_DECODE, GOOD, REJECTED_AT_OPEN, ref_golden, ref_jpeg
+
+pytestmark = pytest.mark.gpu
+
+
+def _surfaces(ctx, jpegs, pts, opts):
+    outs, metas = [], []
+    for j, pt, opt in zip(jpegs, pts, opts):
+        info = J.parse(j)
+        if info["status"] != 0 or info["mcu_w"] == 0:
+            ptr = ctx.malloc(4096)
+            outs.append((ptr, 64, 16, 16)); metas.append(None)
+            continue
+        ii = J.binding.ImageInfo(**{k: v for k, v in info.items() if k != "status"})
+        try:
+            g = J.output_geometry(ii, pt, opt)
+        except J.JdaError:
+            ptr = ctx.malloc(4096)
+            outs.append((ptr, 64, 16, 16)); metas.append(None)
+            continue
+        pitch = (g["canvas_w"] * g["bpp"] + 15) & ~15
+        ptr = ctx.malloc(pitch * g["canvas_h"])
+        ctx.memset(ptr, 0x5a, pitch * g["canvas_h"])
+        outs.append((ptr, pitch, g["canvas_w"], g["canvas_h"])); metas.append((g, pitch))
+    return outs, metas
+
+
+def _check(ctx, oracle, jpegs, pts, opts, outs, metas, status, names):
+    for j, pt, opt, o, m, st, nm in zip(jpegs, pts, opts, outs, metas, status, names):
+        try:
+            orc, want, err = oracle.decode_canvas(j, pt, opt)
+        except Exception:
+            orc, want, err = -1, None, 2
+        if orc == 1:
+            assert st == 0, (nm, pt, opt, st)
+            g, pitch = m
+            got = ctx.to_host(o[0], pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[:, : g["canvas_w"] * g["bpp"]]
+            assert np.array_equal(got, want), (nm, pt, opt, int(np.count_nonzero(got != want)))
+        else:
+            assert st != 0, (nm, pt, opt)
+
+
+def test_pipeline_mixed_batches_bit_exact(gpu_ctx, oracle):
+    """three batches in flight over every synthetic case (all layouts, restart intervals, progressive = host path) and mixed
+    output formats; all the reference's fixtures incl. the corrupt ones in a fourth"""
+    names = sorted(SYNTH_CASES) + sorted(PROGRESSIVE_CASES)
+    jp = [jpeg_for(n) for n in names]
+    modes = [(J.RGB8888, 0), (J.RGB565_LE, 0), (J.GRAY8, 0), (J.RGB565_BE, J.SCALE_HALF), (J.RGB8888, J.SCALE_QUARTER), (J.RGB565_LE, J.SCALE_EIGHTH)]
+    pipe = J.Pipeline(gpu_ctx, max_images=64, depth=3, host_threads=4)
+    batches = []
+    for b in range(3):
+        pts, opts = [], []
+        for i, n in enumerate(names):
+            pt, opt = modes[(i + b) % len(modes)]
+            if n.startswith("gray") and pt == J.RGB8888:
+                pt = J.RGB565_LE
+            if n.startswith("c440") and pt == J.RGB8888 and (opt & 4):
+                opt = 0
+            if n.startswith("p"):                          # progressive: what the reference itself can do (tests/cases.py)
+                pt, opt = (J.RGB565_LE, 0) if not n.startswith("pgray") else (J.GRAY8, 0)
+            pts.append(pt); opts.append(opt)
+        outs, metas = _surfaces(gpu_ctx, jp, pts, opts)
+        t = pipe.submit(jp, outs, pts, opts)
+        batches.append((t, pts, opts, outs, metas))
+    for t, pts, opts, outs, metas in batches:
+        st = pipe.wait(t)
+        _check(gpu_ctx, oracle, jp, pts, opts, outs, metas, st, names)
+        for o in outs:
+            gpu_ctx.free(o[0])
+    s = pipe.stats
+    assert s["images"] == 3 * len(names) and s["failed_images"] == 0
+    assert s["host_path_images"] == 3 * len(PROGRESSIVE_CASES), s      # everything else took the device path
+    pipe.close()
+
+
+def test_pipeline_reference_fixtures_and_bad_images(gpu_ctx, oracle):
+    """tulips .. perf + corrupt1-5 + the truncated thumb_test in ONE batch: 9 decode with the real reference's hashes, the
+    corrupt ones get their own status (JPEG_DECODE_ERROR), nobody else notices.  The device-made index of every good fixture
+    equals the serial pre-scan's entry for entry, the filtered length too."""
+    names = list(GOOD) + list(REJECTED_AT_OPEN) + list(FAIL_IN_DECODE)
+    jp = [ref_jpeg(n) for n in names]
+    pipe = J.Pipeline(gpu_ctx, max_images=32, depth=2)
+    for pt, opt in ((J.RGB8888, 0), (J.RGB565_LE, J.SCALE_HALF), (J.GRAY8, 0)):
+        outs, metas = _surfaces(gpu_ctx, jp, [pt] * len(jp), [opt] * len(jp))
+        t = pipe.submit(jp, outs, [pt] * len(jp), [opt] * len(jp))
+        st = pipe.wait(t)
+        for n, s_, o, m in zip(names, st, outs, metas):
+            if n in GOOD:
+                fr = ref_golden()[n]["frames"]["%d:%d" % (pt, opt)]
+                g, pitch = m
+                got = gpu_ctx.to_host(o[0], pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)
+                assert s_ == 0 and digest(got[: fr["h"], : fr["w"] * fr["bpp"]]) == fr["sha"], (n, pt, opt, s_)
+            else:
+                assert s_ == 2, (n, s_)                       # JPEG_DECODE_ERROR: rejected header or bad MCU
+        if pt == J.RGB8888:
+            for i, n in enumerate(names):
+                if n not in GOOD or n == "corrupt5":
+                    continue
+                h = J.PreparedImage(jp[i])
+                idx, dc, flen = pipe.read_index(t, i, h.n_blocks)
+                assert flen == len(h.scan()), n
+                assert np.array_equal(idx, h.block_index()[0]) and np.array_equal(dc, h.block_dc()), n
+                h.close()
+        for o in outs:
+            gpu_ctx.free(o[0])
+    s = pipe.stats
+    assert s["failed_images"] == 3 * 5 and s["device_images"] >= 3 * 7
+    pipe.close()
+
+
+def test_pipeline_one_corrupt_image_in_sixteen(gpu_ctx, oracle):
+    """VERDICT r1 task 7: one corrupt image in a 16-image upload -- 15 decode, 1 flagged"""
+    good = jpeg_for("c420_333x217")
+    bad = bytearray(good)
+    sos = bytes(bad).index(b"\xff\xda")
+    for k in range(40, 48):
+        bad[sos + 14 + 700 + k] = 0xFF if k & 1 else 0x00      # stuffing bytes and stray markers in the middle of the scan
+    bad = bytes(bad[: sos + 14 + 1500])                        # ... and the stream ends early
+    jp = [good] * 16
+    jp[5] = bad
+    pipe = J.Pipeline(gpu_ctx, max_images=16, depth=1)
+    outs, metas = _surfaces(gpu_ctx, jp, [J.RGB8888] * 16, [0] * 16)
+    st = pipe.wait(pipe.submit(jp, outs, [J.RGB8888] * 16, [0] * 16))
+    assert [s == 0 for s in st] == [i != 5 for i in range(16)], st
+    assert st[5] == 2
+    orc, want, _ = oracle.decode_canvas(good, J.RGB8888, 0)
+    for i in range(16):
+        if i == 5:
+            continue
+        g, pitch = metas[i]
+        got = gpu_ctx.to_host(outs[i][0], pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[:, : g["canvas_w"] * g["bpp"]]
+        assert np.array_equal(got, want), i
+    for o in outs:
+        gpu_ctx.free(o[0])
+    pipe.close()
+
+
+def test_pipeline_at_bench_size(gpu_ctx, ref_scalar):
+    """two 4096x4096 images of the bench workload through the pipeline: frames == the real reference's"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = [os.path.join(root, "bench_cache", "synth_4096x4096_420_q85_s%d.jpg" % s) for s in (1234, 1235)]
+    if not all(os.path.exists(p) for p in paths):
+        pytest.skip("bench_cache inputs absent")
+    jp = [open(p, "rb").read() for p in paths]
+    pipe = J.Pipeline(gpu_ctx, max_images=8, depth=2)
+    outs, metas = _surfaces(gpu_ctx, jp, [J.RGB8888] * 2, [0] * 2)
+    st = pipe.wait(pipe.submit(jp, outs, [J.RGB8888] * 2, [0] * 2))
+    assert st == [0, 0]
+    for j, o, (g, pitch) in zip(jp, outs, metas):
+        got = gpu_ctx.to_host(o[0], pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[: g["out_h"], : g["out_w"] * 4]
+        want = ref_scalar.decode_cb(j, J.RGB8888, 0)["canvas"][: g["out_h"], : g["out_w"] * 4]
+        assert np.array_equal(got, want)
+        gpu_ctx.free(o[0])
+    assert pipe.stats["device_images"] == 2
+    pipe.close()
