@@ -3,16 +3,21 @@
 
 A "step" is one pass of the hot path (the MCU loops of DecodeJPEG, reference jpeg.inl:5109-5353,
 here one kernel launch) over one batch of synthetic baseline JPEGs whose inputs (filtered scan,
-per-MCU index, tables) are already resident in HBM.  Default workload = the metric's own
+per-block index, tables) are already resident in HBM.  Default workload = the metric's own
 configuration: 4096x4096 baseline 4:2:0 -> RGB8888.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; images are independent so each rank decodes its own batch (weak scaling, no
-data-path collective); RCCL is used only for the barrier that brackets the timed region and for
-the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+One process per GPU.  ONE image list (N x batch images; --workload c4: BASELINE config 4's 8192 x 1920x1080) is
+sharded into contiguous blocks over the ranks (jpegdec_amd/sharding.py); a rank prepares its shard on its share of
+the host cores (pinned to its GPU's NUMA node), keeps it resident and decodes it -- no data-path collective, the
+pixels stay where they were decoded.  RCCL carries the barrier that brackets the timed region, the max-over-ranks
+of the elapsed time, the work counters, and the all-reduce of the per-image checksum / decode-count vectors that
+proves every image of the list was decoded exactly once and equal to its single-GPU decode.  Rank 0 prints ONE
+JSON line.  Besides the kernel-only `value` it carries `end_to_end` -- the same images streamed from host memory
+through jda_pipeline (device filter + pre-scan + decode, batches overlapped), host work included.
 """
 import argparse
 import json
@@ -38,9 +43,10 @@ def cached_jpeg(width, height, subsampling, seed, quality=85, restart_rows=0):
     os.makedirs(d, exist_ok=True)
     name = "synth_%dx%d_%s_q%d_s%d%s.jpg" % (width, height, subsampling.replace(":", ""), quality, seed,
                                              "_rst%d" % restart_rows if restart_rows else "")
+    for dd in (d, os.path.join(ROOT, "bench_cold")):
+        if os.path.exists(os.path.join(dd, name)):
+            return open(os.path.join(dd, name), "rb").read()
     path = os.path.join(d, name)
-    if os.path.exists(path):
-        return open(path, "rb").read()
     data = synth_jpeg(width, height, subsampling, seed=seed, quality=quality, restart_rows=restart_rows)
     with open(path + ".tmp%d" % os.getpid(), "wb") as f:
         f.write(data)
@@ -48,39 +54,57 @@ def cached_jpeg(width, height, subsampling, seed, quality=85, restart_rows=0):
     return data
 
 
-def cpu_baseline(jpegs, pixel_type, threads, target_cpu_seconds=16.0):
-    """The reference's own default (SSE2) build from oracle/_ref timed on this host's cores.
+def cpu_baseline(jpegs, pixel_type, cores, detail, model, wall_target=5.0):
+    """The reference itself (oracle/_ref, built from /root/reference) timed on this host's cores: its default x86-64
+    build (SSE2) on one thread and on all usable cores, and its scalar integer build (-DNO_SIMD, the parity target)
+    on one thread -- linux/examples/jpeg_perf_test's convention (one JPEGDEC object per thread, no-op draw callback).
     Test-infrastructure use of oracle/: a reported baseline, never the measured product."""
     from oracle.loader import RefDecoder, ref_available
 
     if not ref_available(simd=True):
         return None
     ref = RefDecoder(simd=True)
-    r0 = ref.bench(jpegs[:1], pixel_type, 0, 1, 1)                  # calibrate: one decode, one thread
-    per_image = max(r0["seconds"], 1e-4)
-    # every thread walks the image list with stride `threads`: give each thread >= 1 image
-    imgs = list(jpegs) * max(1, (threads + len(jpegs) - 1) // len(jpegs))
-    reps = max(1, int(round(target_cpu_seconds / per_image / len(imgs))))
-    r = ref.bench(imgs, pixel_type, 0, reps, threads)
-    return {
-        "value": r["pixels"] / r["seconds"] / 1e6,
+
+    def timed(dec, threads, wall):
+        r0 = dec.bench(jpegs[:1], pixel_type, 0, 1, 1)              # calibrate: one decode, one thread
+        per_image = max(r0["seconds"], 1e-4)
+        per_thread = max(8, int(round(wall / per_image)))           # >= 8 decodes per thread, >= `wall` seconds
+        imgs = [jpegs[i % len(jpegs)] for i in range(threads)]      # one image per thread and repetition
+        r = dec.bench(imgs, pixel_type, 0, per_thread, threads)
+        return {"mpix_s": r["pixels"] / r["seconds"] / 1e6, "threads": threads, "decodes_per_thread": per_thread,
+                "wall_s": round(r["seconds"], 2), "failures": r["failures"]}
+
+    one = timed(ref, 1, 3.0)
+    allc = timed(ref, cores, wall_target)
+    scalar = timed(RefDecoder(simd=False), 1, 3.0) if ref_available(simd=False) else None
+    out = {
+        "value": allc["mpix_s"],
         "unit": "Mpixels/s",
-        "cores": threads,
+        "cores": cores,
         "kind": "reference",
-        "sample": "%d decodes of the workload images (%d distinct), JPEGDEC default x86-64 build (SSE2), "
-                  "one JPEGDEC object per thread, no-op draw callback, %.1f s wall"
-                  % (reps * len(imgs), len(jpegs), r["seconds"]),
-        "single_thread_mpix_s": r0["pixels"] / r0["seconds"] / 1e6,
+        "sample": "%d threads x %d decodes of the workload images (%d distinct), JPEGDEC default x86-64 build (SSE2), one JPEGDEC "
+                  "object per thread, no-op draw callback, %.1f s wall" % (cores, allc["decodes_per_thread"], len(jpegs), allc["wall_s"]),
+        "cpu_model": model,
+        "cores_detail": detail,
+        "sse2_1_thread_mpix_s": one["mpix_s"],
+        "sse2_all_cores_mpix_s": allc["mpix_s"],
+        "scaling_all_over_1": allc["mpix_s"] / one["mpix_s"],
+        "scalar_no_simd_1_thread_mpix_s": scalar["mpix_s"] if scalar else None,
+        "runs": {"sse2_1": one, "sse2_all": allc, "scalar_1": scalar},
     }
+    return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic images cycled through the batch")
+    ap.add_argument("--workload", default="metric", choices=["metric", "c4"],
+                    help="metric: batch x N images of --width x --height (weak scaling); c4: BASELINE config 4, 8192 x 1920x1080 4:2:0 split over the ranks (strong scaling)")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (metric workload)")
+    ap.add_argument("--total-images", type=int, default=8192, help="size of the list of the c4 workload")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images cycled through the list (0: 2 for metric, 8 for c4)")
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--subsampling", default="4:2:0", choices=["4:2:0", "4:4:4", "4:2:2", "gray"])
@@ -89,72 +113,83 @@ def main():
     ap.add_argument("--quality", type=int, default=85, help="JPEG quality of the synthetic inputs (85 = the headline config, SURVEY 8d)")
     ap.add_argument("--restart-rows", type=int, default=0, help="encode the inputs with a restart marker every N MCU rows (0 = none, the headline config)")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed decode launches before the warm-up steps until the GPU clocks have ramped (0: none)")
-    ap.add_argument("--device-prescan", action="store_true", help="JDA_PREPARE_DEVICE_PRESCAN: the block index is made on the GPU at upload (restart intervals, or the self-synchronising segment walk)")
+    ap.add_argument("--device-prescan", action="store_true", help="resident inputs: the block index is made on the GPU at upload (default: serial host pre-scan; the streamed pipeline always uses the device)")
+    ap.add_argument("--e2e-batches", type=int, default=10, help="batches streamed through jda_pipeline for the end-to-end figure (0: skip)")
+    ap.add_argument("--e2e-depth", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the control collectives (nccl = RCCL)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    from jpegdec_amd.sharding import Group, env_rank_world
+
+def run(args, J, out=sys.stdout):
+    """The benchmark proper.  J: the jpegdec_amd module (tests pass a stub of its device half to run this control flow
+    under gloo without a GPU)."""
+    from jpegdec_amd.sharding import Group, cpu_model, env_rank_world, place_rank, shard_range, verify_exactly_once
 
     rank, world, local_rank = env_rank_world()
     if world != args.gpus and rank == 0:
         print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     on_gpu_backend = args.dist_backend == "nccl"
-    if world > 1 and on_gpu_backend:
+    dist_on = world > 1 or bool(os.environ.get("JDA_FORCE_DIST"))
+    if dist_on and on_gpu_backend:
         import torch
 
         torch.cuda.set_device(local_rank)
-    group = Group(backend=args.dist_backend, device="cuda" if (world > 1 and on_gpu_backend) else None)   # RCCL over xGMI; control traffic only
-
-    import jpegdec_amd as J
+    group = Group(backend=args.dist_backend, device="cuda" if (dist_on and on_gpu_backend) else None)   # RCCL over xGMI; control traffic only
 
     pt = {"rgb8888": J.RGB8888, "rgb565": J.RGB565_LE, "gray8": J.GRAY8}[args.pixel_type]
     if args.subsampling == "gray" and pt == J.RGB8888:
         pt = J.GRAY8   # JPEGPutMCUGray never writes 32-bit pixels (SURVEY 8d)
 
-    # ---- inputs: `distinct` synthetic JPEGs, prepared on the host, `batch` resident copies in HBM
-    jpegs = [cached_jpeg(args.width, args.height, args.subsampling, 1234 + i, quality=args.quality, restart_rows=args.restart_rows) for i in range(args.distinct)]
-    bits_px = 8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * args.width * args.height)
     n_dev = max(1, J.load_library().jda_device_count())
     ctx = J.Context(local_rank % n_dev)     # one process per GPU; raises without a GPU: there is no CPU fallback
+    threads, placement = place_rank(group, ctx.pci_bus_id())   # this rank's share of the host cores, on its GPU's NUMA node
+
+    # ---- ONE list of images for the whole job; this rank's contiguous shard of it
+    if args.workload == "c4":
+        width, height, sub = 1920, 1080, "4:2:0"
+        n_total = args.total_images
+        n_distinct = args.distinct or 8
+    else:
+        width, height, sub = args.width, args.height, args.subsampling
+        n_total = args.batch * world
+        n_distinct = args.distinct or 2
+    jpegs = [cached_jpeg(width, height, sub, 1234 + i, quality=args.quality, restart_rows=args.restart_rows) for i in range(n_distinct)]
+    bits_px = 8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * width * height)
+    lo, hi = shard_range(n_total, rank, world)
+    my_files = [jpegs[i % n_distinct] for i in range(lo, hi)]
+    n_mine = hi - lo
+
+    # ---- host prepare of the shard on this rank's threads, upload, launch plan
     t_prep0 = time.perf_counter()
-    prepared = [J.PreparedImage(j, device_prescan=args.device_prescan) for j in jpegs]
-    t_prep = (time.perf_counter() - t_prep0) / len(jpegs)
-    # the same on all host threads (jda_prepare_batch): what the host stage sustains for a batch
-    t_par = float("nan")
-    if world == 1:                                       # (N > 1: the ranks would only fight over the same host cores)
-        n_par = max(len(jpegs), min(4 * args.batch, 4 * (os.cpu_count() or 1)))
-        t_par0 = time.perf_counter()
-        par = J.prepare_batch([jpegs[i % len(jpegs)] for i in range(n_par)], device_prescan=args.device_prescan, threads=0)
-        t_par = (time.perf_counter() - t_par0) / n_par
-        for p_ in par:
-            p_.close()
-        del par
+    one = J.PreparedImage(jpegs[0], device_prescan=args.device_prescan)
+    t_prep1 = time.perf_counter() - t_prep0                                    # one image, one thread
+    one.close()
+    t_par0 = time.perf_counter()
+    prepared = J.prepare_batch(my_files, device_prescan=args.device_prescan, threads=threads)
+    t_par = (time.perf_counter() - t_par0) / max(n_mine, 1)
     geo = prepared[0].geometry(pt, args.options)
     pitch = (geo["canvas_w"] * geo["bpp"] + 15) & ~15
     img_bytes = pitch * geo["canvas_h"]
-    dev_images, outputs = [], []
-    out_base = ctx.malloc(img_bytes * args.batch)
+    out_base = ctx.malloc(img_bytes * n_mine)
     t_up0 = time.perf_counter()
-    dev_images = J.upload_batch(ctx, [prepared[i % len(prepared)] for i in range(args.batch)])
-    for i in range(args.batch):
-        outputs.append((out_base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]))
-    t_up = (time.perf_counter() - t_up0) / args.batch      # H2D (+ the device pre-scan when it is used), the whole batch at once
-    prescan_rounds = int(ctx.lib.jda_last_prescan_rounds(ctx.handle)) if args.device_prescan else 0
-    batch = J.Batch(ctx, dev_images, outputs, [pt] * args.batch, [args.options] * args.batch)
+    dev_images = J.upload_batch(ctx, prepared)
+    t_up = (time.perf_counter() - t_up0) / max(n_mine, 1)
+    outputs = [(out_base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(n_mine)]
+    batch = J.Batch(ctx, dev_images, outputs, [pt] * n_mine, [args.options] * n_mine)
     st = batch.stats
 
     def barrier():
         ctx.sync()                       # our launches go to the context's own HIP stream
-        if world > 1:
+        if dist_on:
             group.barrier()
             if on_gpu_backend:
                 import torch
 
                 torch.cuda.synchronize()
 
-    # Clock ramp, untimed and outside the W warm-up steps: a step is ~1.3 ms of GPU work, so W = 3 steps end long before the
+    # Clock ramp, untimed and outside the W warm-up steps: a step is ~1.2 ms of GPU work, so W = 3 steps end long before the
     # GPU's power management has raised the clocks to their level under load (measured: a 5-step run straight after the
     # upload is 15 % slower per launch than a 20-step one).  The same launches, kept going for --ramp-ms.
     t_ramp = time.perf_counter()
@@ -176,6 +211,38 @@ def main():
     kernel_ms = ctx.timer_elapsed_ms() / args.steps
     total_pixels = group.sum(st["source_pixels"])       # whole job, all ranks
 
+    # ---- the sharding, proved: per-image checksums made where the pixels are, all-reduced; every image exactly once and
+    # equal to the single-GPU decode of its file (rank 0's own decode of the distinct files, broadcast with the same reduce)
+    row_bytes = geo["canvas_w"] * geo["bpp"]
+    sums = ctx.checksums(outputs, [row_bytes] * n_mine)
+    ref_sums = np.zeros(n_distinct, dtype=np.uint64)
+    if rank == 0:
+        have = {}
+        for i in range(lo, hi):
+            have.setdefault(i % n_distinct, sums[i - lo])
+        missing = [d for d in range(n_distinct) if d not in have]
+        if missing:                      # (a shard smaller than the set of distinct files: decode the rest once, here)
+            extra_prep = [J.PreparedImage(jpegs[d]) for d in missing]
+            extra_dev = J.upload_batch(ctx, extra_prep)
+            ex_base = ctx.malloc(img_bytes * len(missing))
+            ex_out = [(ex_base + k * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for k in range(len(missing))]
+            eb = J.Batch(ctx, extra_dev, ex_out, [pt] * len(missing), [args.options] * len(missing))
+            eb.decode(); ctx.sync()
+            for d, v in zip(missing, ctx.checksums(ex_out, [row_bytes] * len(missing))):
+                have[d] = v
+            eb.close()
+            for d_ in extra_dev:
+                d_.close()
+            for p_ in extra_prep:
+                p_.close()
+            ctx.free(ex_base)
+        for d in range(n_distinct):
+            ref_sums[d] = have[d]
+    ref_sums = group.sum_int64_vector(ref_sums.view(np.int64)).view(np.uint64)      # = a broadcast from rank 0
+    sharding = verify_exactly_once(group, n_total, lo, sums, expected_of=lambda i: int(ref_sums[i % n_distinct]))
+    sharding.update({"list": "%d images (%d distinct files), rank r owns the contiguous block shard_range(n, r, %d)" % (n_total, n_distinct, world),
+                     "images_this_rank": n_mine, "host_placement": placement})
+
     # ---- parity spot check outside the timed region: first image of this rank vs the oracle
     parity = None
     if not args.no_parity and rank == 0:
@@ -183,20 +250,65 @@ def main():
             from oracle.loader import OracleDecoder, RefDecoder, ref_available
             got = ctx.to_host(out_base, img_bytes).reshape(geo["canvas_h"], pitch)[:, : geo["canvas_w"] * geo["bpp"]]
             if ref_available(False):
-                want = RefDecoder(False).decode_cb(jpegs[0], pt, args.options)["canvas"][: geo["canvas_h"], : geo["canvas_w"] * geo["bpp"]]
-                got = got[: geo["out_h"]]
-                want = want[: geo["out_h"]]
-                parity = {"checker": "oracle/_ref scalar reference", "bit_exact": bool(np.array_equal(got, want))}
+                want = RefDecoder(False).decode_cb(jpegs[lo % n_distinct], pt, args.options)["canvas"][: geo["canvas_h"], : geo["canvas_w"] * geo["bpp"]]
+                parity = {"checker": "oracle/_ref scalar reference", "bit_exact": bool(np.array_equal(got[: geo["out_h"]], want[: geo["out_h"]]))}
             else:
-                rc, want, _ = OracleDecoder().decode_canvas(jpegs[0], pt, args.options)
+                rc, want, _ = OracleDecoder().decode_canvas(jpegs[lo % n_distinct], pt, args.options)
                 parity = {"checker": "oracle restatement", "bit_exact": bool(rc == 1 and np.array_equal(got, want))}
+            parity["device_checksum_equals_host_checksum"] = bool(J.surface_checksum_host(got) == sums[0])
         except Exception as e:  # checker missing: report, do not fail the measurement
             parity = {"checker": "unavailable: %s" % e, "bit_exact": None}
+
+    # ---- end to end: the same files streamed from host memory through jda_pipeline (host parse + tables, H2D of the unfiltered
+    # scans, device filter + pre-scan + decode; batches overlapped on three streams), host work included, pixels stay in HBM
+    e2e = None
+    if args.e2e_batches > 0:
+        eb = min(n_mine, args.batch) if args.workload == "metric" else min(n_mine, 256)
+        depth = max(1, min(args.e2e_depth, 4))
+        files = my_files[:eb]
+        pipe = J.Pipeline(ctx, max_images=eb, depth=depth, host_threads=min(threads, 8))
+        surf = [out_base] if eb * depth > n_mine else [out_base + k * eb * img_bytes for k in range(depth)]
+        extra = [ctx.malloc(img_bytes * eb) for _ in range(depth - len(surf))]
+        surf += extra
+
+        def submit(k):
+            base = surf[k % depth]
+            return pipe.submit(files, [(base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(eb)], [pt] * eb, [args.options] * eb)
+
+        inflight, t_submit, warm = [], 0.0, 2
+        tb0 = 0.0
+        for k in range(warm + args.e2e_batches):
+            if k == warm:
+                while inflight:
+                    pipe.wait(inflight.pop(0))
+                barrier()
+                tb0 = time.perf_counter()
+            if len(inflight) == depth:
+                assert all(s == 0 for s in pipe.wait(inflight.pop(0)))
+            ts = time.perf_counter()
+            inflight.append(submit(k))
+            if k >= warm:
+                t_submit += time.perf_counter() - ts
+        while inflight:
+            assert all(s == 0 for s in pipe.wait(inflight.pop(0)))
+        barrier()
+        dt = group.max(time.perf_counter() - tb0)
+        n_img = eb * args.e2e_batches
+        px_all = group.sum(float(geo["out_w"] * geo["out_h"] * n_img))
+        pst = pipe.stats
+        pipe.close()
+        for p_ in extra:
+            ctx.free(p_)
+        e2e = {"mpix_s": px_all / dt / 1e6, "ms_per_image": dt / n_img * 1e3, "host_submit_ms_per_image": t_submit / n_img * 1e3,
+               "batches": args.e2e_batches, "images_per_batch": eb, "depth": depth, "host_threads": min(threads, 8),
+               "device_path_images": pst["device_images"], "host_path_images": pst["host_path_images"],
+               "what": "files in host memory -> pixels resident in HBM through jda_pipeline: host parse + tables, H2D of the unfiltered scans, "
+                       "device marker filter + per-block index + decode, batches overlapped; whole job, all ranks"}
 
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         try:
-            cpu = cpu_baseline(jpegs, pt, threads=os.cpu_count() or 1)
+            cpu = cpu_baseline(jpegs, pt, placement["cores_usable"], {k: placement[k] for k in ("affinity_cpus", "cgroup_cpu_quota", "os_cpu_count")}, cpu_model())
         except Exception as e:
             cpu = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "reference", "sample": "failed: %s" % e}
 
@@ -204,19 +316,20 @@ def main():
         px_per_step = st["source_pixels"]
         value = total_pixels * args.steps / elapsed / 1e6
         # algorithmic bytes per launch: output + filtered scan + 4 B/MCU index
-        n_mcus = sum(p.n_mcus for p in prepared) * (args.batch // len(prepared)) + sum(
-            p.n_mcus for p in prepared[: args.batch % len(prepared)])
+        n_mcus = sum(p.n_mcus for p in prepared)
         algo_bytes = st["output_bytes"] + st["scan_bytes"] + 4 * n_mcus
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM traffic per launch: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 --pmc passes of the same workload (profiles/), scaled to
         # this batch; null for any other workload
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
-        if (os.path.exists(tp) and (args.width, args.height, args.subsampling, args.pixel_type, args.options)
-                == (4096, 4096, "4:2:0", "rgb8888", 0)):
-            traffic = json.load(open(tp))["hbm_bytes_per_image"] * args.batch
-            traffic_src = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
+        for tag in ("r02", "r01_final"):
+            tp = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+            if (os.path.exists(tp) and args.workload == "metric" and (args.width, args.height, args.subsampling, args.pixel_type, args.options, args.quality)
+                    == (4096, 4096, "4:2:0", "rgb8888", 0, 85)):
+                traffic = json.load(open(tp))["hbm_bytes_per_image"] * n_mine
+                traffic_src = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)" % tag
+                break
         line = {
             "metric": "Mpixels/s decoded",
             "value": value,
@@ -226,18 +339,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.workload == "metric" else "strong",
             "vs_baseline": None,
             "dtype": "i32",
             "data": "synthetic",
             "config": {
-                "workload": "batch of %d %dx%d baseline %s JPEGs per GPU -> %s, inputs resident in HBM"
-                            % (args.batch, args.width, args.height, args.subsampling, args.pixel_type),
-                "images_per_gpu_per_step": args.batch,
+                "workload": "list of %d %dx%d baseline %s JPEGs (%d per GPU) -> %s, inputs resident in HBM"
+                            % (n_total, width, height, sub, n_mine, args.pixel_type),
+                "images_per_gpu_per_step": n_mine,
                 "distinct_images": len(jpegs),
                 "bits_per_pixel": round(bits_px, 3),
                 "options": args.options,
-                "parallelism": "images sharded, %d GPU(s), no data-path collective" % world,
+                "parallelism": "one image list sharded in contiguous blocks over %d GPU(s), no data-path collective" % world,
             },
             "roofline": {
                 "bound": "hbm",
@@ -247,31 +360,42 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "jda_decode_tiles_persistent<MODE,FAST>",
+                "kernel": "jda_decode_tiles_persistent<MODE,FAST,VARIANT,BIG>",
                 "kernel_ms_per_launch": kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
             "cpu_baseline": cpu,
             "parity": parity,
-            "host_prepare_ms_per_image": t_prep * 1e3,
-            "host_prepare_all_threads_ms_per_image": (t_par * 1e3) if t_par == t_par else None,
-            "host_threads": os.cpu_count(),
+            "sharding": sharding,
+            "end_to_end": e2e,
+            "end_to_end_mpix_s": e2e["mpix_s"] if e2e else None,
+            "host_prepare_ms_per_image": t_prep1 * 1e3,
+            "host_prepare_threads_ms_per_image": t_par * 1e3,
+            "host_threads": threads,
             "upload_ms_per_image": t_up * 1e3,
             "device_prescan": bool(dev_images[0].prescan_on_device),
-            "device_prescan_rounds": prescan_rounds,      # speculative rounds of the marker-less segment walk (0: not used)
             "clock_ramp_ms": args.ramp_ms,                # untimed launches before the W warm-up steps (see above)
             "kernel_only_mpix_s": px_per_step / (kernel_ms * 1e-3) / 1e6,
-            # host prepare (all threads) + upload + kernel, one after the other (no overlap between the stages)
-            "end_to_end_mpix_s_no_overlap": (args.width * args.height / 1e6) / ((t_par if t_par == t_par else t_prep) + t_up + kernel_ms * 1e-3 / args.batch),
+            "dist": {"backend": (args.dist_backend if dist_on else "none"), "ranks": world},
         }
-        print(json.dumps(line))
+        print(json.dumps(line), file=out)
+        out.flush()
 
     batch.close()
     for d in dev_images:
         d.close()
+    for p_ in prepared:
+        p_.close()
     ctx.free(out_base)
     ctx.close()
     group.close()
+
+
+def main():
+    args = parse_args()
+    import jpegdec_amd as J
+
+    run(args, J)
 
 
 if __name__ == "__main__":

@@ -233,6 +233,14 @@ int jda_batch_get_stats(const jda_batch *batch, jda_batch_stats *stats);
 
 int jda_sync(jda_ctx *ctx);
 
+/* A position-dependent 64-bit checksum of each of n decoded surfaces (DEVICE pointers; rows x row_bytes[i] at pitch), computed
+ * on the GPU: sum over the dwords d at linear index i of (uint64)((d ^ (i * 0x9E3779B1)) * 0x85EBCA6B mod 2^32) * (2 i + 1), mod 2^64,
+ * a row's tail bytes zero-extended.  Lets a multi-GPU driver prove "every image decoded exactly once, identically" without moving
+ * pixels (the reference has no such notion: its pixels go to a display as they are made).  Synchronous. */
+int jda_checksum_surfaces(jda_ctx *ctx, int32_t n, const jda_output *surfaces, const int32_t *row_bytes, uint64_t *checksums);
+/* PCI bus id ("0000:8e:00.0") of the context's GPU, for NUMA placement of the host threads that feed it; buf >= 16 bytes */
+int jda_device_pci_bus_id(jda_ctx *ctx, char *buf, int32_t len);
+
 /* HIP-event timing on the ctx stream: start/stop record events on that stream; elapsed blocks
  * until stop has happened and returns milliseconds (<0 on error). */
 int jda_timer_start(jda_ctx *ctx);

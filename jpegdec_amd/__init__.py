@@ -31,5 +31,6 @@ from .binding import (  # noqa: F401
     output_geometry,
     parse,
     prepare_batch,
+    surface_checksum_host,
     upload_batch,
 )

@@ -111,6 +111,8 @@ _PROTOTYPES = [
     ("jda_pipeline_wait", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_pipeline_get_stats", C.c_int, [_P, C.POINTER(PipelineStats)]),
     ("jda_pipeline_read_index", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_uint32)]),
+    ("jda_checksum_surfaces", C.c_int, [_P, C.c_int32, C.POINTER(Output), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    ("jda_device_pci_bus_id", C.c_int, [_P, C.c_char_p, C.c_int32]),
     ("jda_version", C.c_char_p, []),
 ]
 
@@ -282,6 +284,20 @@ class Context:
     def sync(self):
         self.check(self.lib.jda_sync(self.handle), "jda_sync")
 
+    def checksums(self, surfaces, row_bytes):
+        """jda_checksum_surfaces: surfaces = list of (device_ptr, pitch_bytes, width_px, rows); one uint64 per surface."""
+        n = len(surfaces)
+        outs = (Output * n)(*[Output(*o) for o in surfaces])
+        rb = (C.c_int32 * n)(*row_bytes)
+        res = (C.c_uint64 * n)()
+        self.check(self.lib.jda_checksum_surfaces(self.handle, n, outs, rb, res), "jda_checksum_surfaces")
+        return [int(v) for v in res]
+
+    def pci_bus_id(self) -> str:
+        buf = C.create_string_buffer(32)
+        self.check(self.lib.jda_device_pci_bus_id(self.handle, buf, 32), "jda_device_pci_bus_id")
+        return buf.value.decode()
+
     def timer_start(self):
         self.check(self.lib.jda_timer_start(self.handle), "jda_timer_start")
 
@@ -431,6 +447,19 @@ class Pipeline:
         if self.handle:
             self.ctx.lib.jda_pipeline_destroy(self.handle)
             self.handle = None
+
+
+def surface_checksum_host(canvas: np.ndarray) -> int:
+    """The same checksum as Context.checksums, of a host array (rows x row_bytes uint8): the reference value in tests."""
+    rows, row_bytes = canvas.shape
+    dpr = (row_bytes + 3) // 4
+    pad = np.zeros((rows, dpr * 4), np.uint8)
+    pad[:, :row_bytes] = canvas
+    d = pad.view("<u4").reshape(-1).astype(np.uint64)
+    i = np.arange(d.size, dtype=np.uint64)
+    m = ((d ^ ((i * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF))) * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        return int(np.sum(m * (np.uint64(2) * i + np.uint64(1)), dtype=np.uint64))
 
 
 def decode_to_host(ctx: Context, jpeg: bytes, pixel_type=RGB8888, options=0):

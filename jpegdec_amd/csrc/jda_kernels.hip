@@ -834,6 +834,41 @@ extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// A position-dependent 64-bit checksum of a decoded surface (rows x row_bytes at pitch), made where the pixels are: the
+// multi-GPU driver all-reduces one of these per image to prove that every image was decoded exactly once and identically on
+// whichever GPU took it (bench.py, jpegdec_amd/sharding.py); tests use it for surfaces too large to copy back.
+//   sum over the surface's dwords d at linear index i (row * dwords_per_row + column; a row's tail bytes zero-extended) of
+//   (uint64)((d ^ (i * 0x9E3779B1)) * 0x85EBCA6B mod 2^32) * (2 i + 1)        mod 2^64
+__global__ __launch_bounds__(256)
+void jda_surface_checksum(const uint8_t *__restrict__ base, uint32_t pitch, uint32_t row_bytes, uint32_t rows, unsigned long long *out)
+{
+    const uint32_t dpr = (row_bytes + 3u) / 4u;
+    const uint64_t total = (uint64_t)dpr * rows;
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t r = (uint32_t)(i / dpr), c = (uint32_t)(i - (uint64_t)r * dpr);
+        const uint8_t JDA_GLOBAL *p = JDA_G(const uint8_t, base) + (size_t)r * pitch + (size_t)c * 4u;
+        uint32_t d;
+        if (c * 4u + 4u <= row_bytes) d = *(const jda_u32_alias JDA_GLOBAL *)p;      // (pitch and base are 16-byte aligned)
+        else { d = 0; for (uint32_t k = 0; c * 4u + k < row_bytes; k++) d |= (uint32_t)p[k] << (8u * k); }
+        const uint32_t m = (d ^ ((uint32_t)i * 0x9E3779B1u)) * 0x85EBCA6Bu;
+        acc += (unsigned long long)m * (2ull * i + 1ull);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(out, acc);
+}
+extern "C" hipError_t jda_launch_checksum(const void *base, uint32_t pitch, uint32_t row_bytes, uint32_t rows, unsigned long long *out, hipStream_t stream)
+{
+    if (rows == 0 || row_bytes == 0) return hipSuccess;
+    const uint64_t total = (uint64_t)((row_bytes + 3u) / 4u) * rows;
+    uint64_t g = (total + 256u * 8u - 1u) / (256u * 8u);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(jda_surface_checksum, dim3((uint32_t)g), dim3(256), 0, stream, (const uint8_t *)base, pitch, row_bytes, rows, out);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t jda_internal_set_wgtrace(unsigned long long *dev_buf)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_jda_wgtrace), &dev_buf, sizeof(dev_buf));

@@ -692,6 +692,34 @@ int jda_batch_get_stats(const jda_batch *b, jda_batch_stats *stats)
     return JDA_SUCCESS;
 }
 
+// checksums[i] of n surfaces (device pointers): see jda_surface_checksum in jda_kernels.hip.  Synchronous.
+int jda_checksum_surfaces(jda_ctx *ctx, int32_t n, const jda_output *surfaces, const int32_t *row_bytes, uint64_t *checksums)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (n <= 0 || !surfaces || !row_bytes || !checksums) return JDA_INVALID_PARAMETER;
+    (void)hipSetDevice(ctx->device);
+    unsigned long long *d = NULL;
+    hipError_t e = jda_pool_alloc(ctx, (void **)&d, (size_t)n * 8);
+    if (e != hipSuccess) return jda_set_err(ctx, e, "hipMalloc(checksums)");
+    e = hipMemsetAsync(d, 0, (size_t)n * 8, ctx->stream);
+    for (int i = 0; i < n && e == hipSuccess; i++) {
+        if (!surfaces[i].pixels || surfaces[i].pitch_bytes < row_bytes[i] || row_bytes[i] < 0 || surfaces[i].rows < 0) { jda_pool_free(ctx, d); return JDA_INVALID_PARAMETER; }
+        e = jda_launch_checksum(surfaces[i].pixels, (uint32_t)surfaces[i].pitch_bytes, (uint32_t)row_bytes[i], (uint32_t)surfaces[i].rows, d + i, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(checksums, d, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    jda_pool_free(ctx, d);
+    return e == hipSuccess ? JDA_SUCCESS : jda_set_err(ctx, e, "jda_checksum_surfaces");
+}
+
+// "0000:8e:00.0" of the context's GPU (for NUMA placement of the host threads that feed it); buf >= 16 bytes
+int jda_device_pci_bus_id(jda_ctx *ctx, char *buf, int32_t len)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (!buf || len < 16) return JDA_INVALID_PARAMETER;
+    return hipDeviceGetPCIBusId(buf, len, ctx->device) == hipSuccess ? JDA_SUCCESS : JDA_ERROR_HIP;
+}
+
 int jda_sync(jda_ctx *ctx)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
