@@ -90,6 +90,7 @@ class JPEGDEC {
     int open(void *fHandle, int iDataSize, JPEG_CLOSE_CALLBACK *pfnClose, JPEG_READ_CALLBACK *pfnRead,
              JPEG_SEEK_CALLBACK *pfnSeek, JPEG_DRAW_CALLBACK *pfnDraw);
     void setFramebuffer(void *pFramebuffer);
+    void setDevice(int iDevice);       /* not in the reference: the GPU this object decodes on (default $JPEGDEC_AMD_DEVICE, else 0) */
     void setCropArea(int x, int y, int w, int h);
     void getCropArea(int *x, int *y, int *w, int *h);
     void close();
@@ -121,6 +122,9 @@ class JPEGDEC {
 // offers it to C translation units that include jpeg.inl; here the functions live in libjpegdec_amd.so and are
 // callable from C and C++ alike.  JPEGIMAGE is caller-allocated as in the reference (there: the 18 KB decoder
 // state; here: a small handle -- the state lives behind it and is released by JPEG_close or the next open).
+// Two rules the reference does not have: (1) zero-initialise a JPEGIMAGE before its first JPEG_open* (`JPEGIMAGE j = {0};` --
+// an open tells a live handle from stack garbage by the magic word); (2) ALWAYS call JPEG_close when done, also for RAM /
+// FLASH sources (upstream that is a no-op for them; here it frees the state behind the handle).
 typedef struct jpeg_image_tag {
     uint32_t magic;          /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
     void *impl;
@@ -132,6 +136,7 @@ extern "C" {
 int JPEG_openRAM(JPEGIMAGE *pJPEG, uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw);
 int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *pfnDraw);
 void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer);
+void JPEG_setDevice(JPEGIMAGE *pJPEG, int iDevice);   /* not in the reference: see JPEGDEC::setDevice */
 void JPEG_setCropArea(JPEGIMAGE *pJPEG, int x, int y, int w, int h);
 void JPEG_getCropArea(JPEGIMAGE *pJPEG, int *x, int *y, int *w, int *h);
 int JPEG_getWidth(JPEGIMAGE *pJPEG);

@@ -187,6 +187,10 @@ jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err);
  * latency-bound, so throughput comes from the number of restart intervals in flight).  out[i] = device image.
  * Returns JDA_SUCCESS or the first error (then every out[i] is NULL). */
 int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out);
+/* The same, tolerant of holes: imgs[i] == NULL (a file jda_prepare_batch rejected) gives out[i] = NULL and status[i] =
+ * JDA_INVALID_PARAMETER; every other image is uploaded (status[i] = JDA_SUCCESS, or the batch's HIP error).  The arrays stay
+ * index-aligned with the caller's file list; jda_batch_create accepts the holes and launches nothing for them. */
+int jda_upload_batch_ex(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out, int32_t *status);
 int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: a device pre-scan produced the index */
 /* copy the per-block index (n_blocks + 1 entries) and DC predictors (n_blocks) of a resident image back to the host
  * (either pointer may be NULL); n_blocks = mcus_x * mcus_y * blocks_per_mcu.  Synchronous. */
@@ -230,6 +234,9 @@ typedef struct jda_batch_stats {
     int32_t n_workgroups;
 } jda_batch_stats;
 int jda_batch_get_stats(const jda_batch *batch, jda_batch_stats *stats);
+/* status[i] for every image of the plan: JDA_SUCCESS; JDA_DECODE_ERROR = the stream has a bad MCU (the MCUs before it are decoded,
+ * what the reference delivers before it returns the error, jpeg.inl:5354-5356); JDA_INVALID_PARAMETER = a hole (images[i] == NULL) */
+int jda_batch_get_status(const jda_batch *batch, int32_t *status);
 
 int jda_sync(jda_ctx *ctx);
 

@@ -113,6 +113,8 @@ _PROTOTYPES = [
     ("jda_pipeline_read_index", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_uint32)]),
     ("jda_checksum_surfaces", C.c_int, [_P, C.c_int32, C.POINTER(Output), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     ("jda_device_pci_bus_id", C.c_int, [_P, C.c_char_p, C.c_int32]),
+    ("jda_upload_batch_ex", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int32)]),
+    ("jda_batch_get_status", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("jda_version", C.c_char_p, []),
 ]
 
@@ -338,8 +340,9 @@ class DeviceImage:
             self.handle = None
 
 
-def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0):
-    """jda_prepare_batch: the images are prepared on `threads` host threads (0 = all)."""
+def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0, strict: bool = True):
+    """jda_prepare_batch: the images are prepared on `threads` host threads (0 = all).  strict=False: a rejected file leaves a
+    None in the list (and its error code in the second return value) instead of failing the whole batch."""
     lib = load_library()
     n = len(jpegs)
     arr = (C.c_char_p * n)(*jpegs)
@@ -348,6 +351,8 @@ def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0):
     errs = (C.c_int32 * n)()
     rc = lib.jda_prepare_batch(n, arr, lens, PREPARE_DEVICE_PRESCAN if device_prescan else 0, threads, outs, errs)
     res = [PreparedImage(jpegs[i], _handle=outs[i]) if outs[i] else None for i in range(n)]
+    if not strict:
+        return res, list(errs)
     if rc != 0:
         for r in res:
             if r is not None:
@@ -359,12 +364,13 @@ def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0):
 def upload_batch(ctx: Context, prepared_list):
     """jda_upload_batch: all images in one go (pending block indexes are made on the GPU in two launches)."""
     n = len(prepared_list)
-    himgs = (_P * n)(*[p.handle for p in prepared_list])
+    himgs = (_P * n)(*[(p.handle if p is not None else None) for p in prepared_list])
     outs = (_P * n)()
-    rc = ctx.lib.jda_upload_batch(ctx.handle, n, himgs, outs)
+    st = (C.c_int32 * n)()
+    rc = ctx.lib.jda_upload_batch_ex(ctx.handle, n, himgs, outs, st)      # holes (None) stay holes
     if rc != 0:
         raise JdaError(rc, "jda_upload_batch")
-    return [DeviceImage(ctx, prepared_list[i], _handle=outs[i]) for i in range(n)]
+    return [DeviceImage(ctx, prepared_list[i], _handle=outs[i]) if outs[i] else None for i in range(n)]
 
 
 class Batch:
@@ -374,7 +380,8 @@ class Batch:
         """outputs: list of (device_ptr, pitch_bytes, width_px, rows)."""
         n = len(images)
         self.ctx = ctx
-        himgs = (_P * n)(*[im.handle for im in images])
+        self.n = n
+        himgs = (_P * n)(*[(im.handle if im is not None else None) for im in images])
         outs = (Output * n)(*[Output(*o) for o in outputs])
         pts = (C.c_int32 * n)(*pixel_types)
         opts = (C.c_int32 * n)(*options)
@@ -388,6 +395,12 @@ class Batch:
 
     def decode(self):
         self.ctx.check(self.ctx.lib.jda_batch_decode(self.ctx.handle, self.handle), "jda_batch_decode")
+
+    def status(self):
+        """per image: 0, 2 (JDA_DECODE_ERROR: bad MCU, the MCUs before it are decoded) or 1 (a hole in the image list)"""
+        st = (C.c_int32 * self.n)()
+        self.ctx.check(self.ctx.lib.jda_batch_get_status(self.handle, st), "jda_batch_get_status")
+        return list(st)
 
     def close(self):
         if self.handle:

@@ -12,7 +12,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
 #include <vector>
 
 #include "../../include/jpegdec_amd.h"
@@ -28,6 +27,7 @@ struct jpegdec_amd_state {
     int options;
     int xoff, yoff;
     int crop_x, crop_y, crop_w, crop_h;
+    int device;                       // -1: $JPEGDEC_AMD_DEVICE / 0
     void *user;
     void *framebuffer;
     JPEG_DRAW_CALLBACK *draw;
@@ -40,22 +40,37 @@ struct jpegdec_amd_state {
 
 namespace {
 
-std::mutex g_ctx_mutex;
-jda_ctx *g_ctx = NULL;
-int g_ctx_err = JDA_SUCCESS;
+// One device context per THREAD and device, created on the thread's first decode there and destroyed when the thread ends:
+// objects used from different threads ("one JPEGDEC object per thread" is the reference's threading model) decode
+// concurrently -- each context has its own HIP stream, staging buffer and block pool, so nothing is shared and nothing is
+// locked.  Device of an object: setDevice() / JPEG_setDevice(), else $JPEGDEC_AMD_DEVICE, else 0.
+struct ThreadContexts {
+    enum { kMax = 16 };
+    jda_ctx *ctx[kMax];
+    int err[kMax];
+    ThreadContexts() { for (int i = 0; i < kMax; i++) { ctx[i] = NULL; err[i] = JDA_SUCCESS; } }
+    ~ThreadContexts() { for (int i = 0; i < kMax; i++) if (ctx[i]) jda_destroy(ctx[i]); }
+};
+thread_local ThreadContexts t_contexts;
 
-// one device context per process, created on first decode (device = $JPEGDEC_AMD_DEVICE or 0)
-jda_ctx *shared_ctx(int *err)
+int default_device()
 {
-    std::lock_guard<std::mutex> lk(g_ctx_mutex);
-    if (!g_ctx && g_ctx_err == JDA_SUCCESS) {
-        const char *e = getenv("JPEGDEC_AMD_DEVICE");
+    static const int dev = []() { const char *e = getenv("JPEGDEC_AMD_DEVICE"); return e ? atoi(e) : 0; }();
+    return dev;
+}
+
+jda_ctx *thread_ctx(int device, int *err)
+{
+    if (device < 0) device = default_device();
+    if (device < 0 || device >= ThreadContexts::kMax) { if (err) *err = JDA_INVALID_PARAMETER; return NULL; }
+    ThreadContexts &T = t_contexts;
+    if (!T.ctx[device] && T.err[device] == JDA_SUCCESS) {
         int32_t rc = JDA_SUCCESS;
-        g_ctx = jda_create(e ? atoi(e) : 0, &rc);
-        g_ctx_err = g_ctx ? JDA_SUCCESS : rc;
+        T.ctx[device] = jda_create(device, &rc);
+        T.err[device] = T.ctx[device] ? JDA_SUCCESS : rc;
     }
-    if (err) *err = g_ctx_err;
-    return g_ctx;
+    if (err) *err = T.err[device];
+    return T.ctx[device];
 }
 
 void reset(jpegdec_amd_state *s)
@@ -73,6 +88,7 @@ void reset(jpegdec_amd_state *s)
     s->opened = false;
 }
 
+
 int finish_open(jpegdec_amd_state *s, JPEG_DRAW_CALLBACK *draw)
 {
     s->draw = draw;
@@ -86,7 +102,7 @@ int finish_open(jpegdec_amd_state *s, JPEG_DRAW_CALLBACK *draw)
 
 } // namespace
 
-JPEGDEC::JPEGDEC() : _jpeg(new jpegdec_amd_state) { reset(_jpeg); }
+JPEGDEC::JPEGDEC() : _jpeg(new jpegdec_amd_state) { _jpeg->device = -1; reset(_jpeg); }
 JPEGDEC::~JPEGDEC() { delete _jpeg; }
 
 int JPEGDEC::openRAM(uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw)
@@ -158,6 +174,7 @@ void JPEGDEC::close()
 }
 
 void JPEGDEC::setFramebuffer(void *p) { _jpeg->framebuffer = p; }
+void JPEGDEC::setDevice(int iDevice) { _jpeg->device = iDevice; }      // (not in the reference: which GPU this object decodes on)
 void JPEGDEC::setUserPointer(void *p) { _jpeg->user = p; }
 int JPEGDEC::getOrientation() { return _jpeg->info.orientation; }
 int JPEGDEC::getLastError() { return _jpeg->error; }
@@ -227,15 +244,23 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     int rc = jda_output_geometry(&s->info, pt, iOptions, &bpp, &ow, &oh, &cw, &ch);
     if (rc != JDA_SUCCESS) { s->error = s->info.mcu_w ? rc : JPEG_UNSUPPORTED_FEATURE; return 0; }
     int cerr = JDA_SUCCESS;
-    jda_ctx *ctx = shared_ctx(&cerr);
+    jda_ctx *ctx = thread_ctx(s->device, &cerr);
     if (!ctx) { s->error = cerr; return 0; }
 
-    std::vector<uint8_t> canvas((size_t)cw * ch * bpp);
+    const int eff0 = jda_effective_options(&s->info, iOptions);
+    const int shift0 = (eff0 & JPEG_SCALE_HALF) ? 1 : (eff0 & JPEG_SCALE_QUARTER) ? 2 : (eff0 & JPEG_SCALE_EIGHTH) ? 3 : 0;
     int32_t mcus_decoded = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_ctx_mutex);
-        rc = jda_decode_to_host_ex(ctx, s->data, s->size, pt, iOptions, canvas.data(), cw * bpp, ch, &mcus_decoded);
+    // Framebuffer mode, full size, no crop, a width that is a whole number of MCUs: the caller's buffer has the layout of the
+    // decoded canvas (pitch = width, MCU-padded rows: what the reference writes, jpeg.inl:5114-5124), so the copy back from the
+    // GPU lands in it directly -- no intermediate canvas, no second copy
+    if (s->framebuffer && !cropped && shift0 == 0 && cw == s->info.width && s->crop_w == s->info.width) {
+        rc = jda_decode_to_host_ex(ctx, s->data, s->size, pt, iOptions, s->framebuffer, cw * bpp, ch, &mcus_decoded);
+        if (rc != JDA_SUCCESS && rc != JDA_DECODE_ERROR) { s->error = rc; return 0; }
+        if (rc == JDA_DECODE_ERROR) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
+        return 1;
     }
+    std::vector<uint8_t> canvas((size_t)cw * ch * bpp);
+    rc = jda_decode_to_host_ex(ctx, s->data, s->size, pt, iOptions, canvas.data(), cw * bpp, ch, &mcus_decoded);
     const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
     if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
 
@@ -363,6 +388,7 @@ int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *
     return j ? j->open(szFilename, pfnDraw) : 0;
 }
 void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer) { if (JPEGDEC *j = c_obj(pJPEG)) j->setFramebuffer(pFramebuffer); }
+void JPEG_setDevice(JPEGIMAGE *pJPEG, int iDevice) { if (JPEGDEC *j = c_obj(pJPEG)) j->setDevice(iDevice); }
 void JPEG_setCropArea(JPEGIMAGE *pJPEG, int x, int y, int w, int h) { if (JPEGDEC *j = c_obj(pJPEG)) j->setCropArea(x, y, w, h); }
 void JPEG_getCropArea(JPEGIMAGE *pJPEG, int *x, int *y, int *w, int *h) { if (JPEGDEC *j = c_obj(pJPEG)) j->getCropArea(x, y, w, h); }
 int JPEG_getWidth(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getWidth() : 0; }

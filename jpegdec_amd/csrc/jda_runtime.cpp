@@ -500,6 +500,26 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     return JDA_SUCCESS;
 }
 
+// The same, tolerant of holes: imgs[i] == NULL (a file jda_prepare_batch rejected) gets out[i] = NULL and
+// status[i] = JDA_INVALID_PARAMETER, everybody else is uploaded -- a bad image does not cost the batch its place in the arrays.
+int jda_upload_batch_ex(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out, int32_t *status)
+{
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (n <= 0 || !imgs || !out) return JDA_INVALID_PARAMETER;
+    std::vector<jda_image *> v;
+    std::vector<int> ix;
+    for (int i = 0; i < n; i++) {
+        out[i] = NULL;
+        if (status) status[i] = imgs[i] ? JDA_SUCCESS : JDA_INVALID_PARAMETER;
+        if (imgs[i]) { v.push_back(imgs[i]); ix.push_back(i); }
+    }
+    if (v.empty()) return JDA_SUCCESS;
+    std::vector<jda_dev_image *> o(v.size(), NULL);
+    const int rc = jda_upload_batch(ctx, (int32_t)v.size(), v.data(), o.data());
+    for (size_t k = 0; k < v.size(); k++) { out[ix[k]] = o[k]; if (status && rc != JDA_SUCCESS) status[ix[k]] = rc; }
+    return rc;
+}
+
 jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err)
 {
     int32_t dummy;
@@ -612,13 +632,15 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     if (n <= 0 || !images || !outputs) { *err = JDA_INVALID_PARAMETER; return NULL; }
     std::vector<jda_dev_desc> descs((size_t)n);
     std::vector<jda_strip> strips[JDA_N_LISTS];
+    std::vector<int32_t> image_status;
     jda_batch_stats st;
     memset(&st, 0, sizeof(st));
     for (int i = 0; i < n; i++) {
         const jda_dev_image *im = images[i];
-        if (!im) { *err = JDA_INVALID_PARAMETER; return NULL; }
-        const jda_image_info &I = im->info;
         jda_dev_desc &D = descs[(size_t)i];
+        if (!im) { memset(&D, 0, sizeof(D)); image_status.push_back(JDA_INVALID_PARAMETER); continue; }   // a hole (rejected file): nothing is launched for it
+        const jda_image_info &I = im->info;
+        image_status.push_back(im->n_mcus_ok < (uint32_t)(I.mcus_x * I.mcus_y) ? JDA_DECODE_ERROR : JDA_SUCCESS);   // jpeg.inl:5354-5356
         int bpp = 0;
         const int rc = jda_fill_launch_desc(D, I, im->dc_id, im->ac_id, im->q_id, im->fast_mul, im->general_p1, im->n_mcus_ok, im->scan_len,
                                             outputs[i], pixel_types ? pixel_types[i] : JDA_RGB8888, options ? options[i] : 0, &bpp);
@@ -642,6 +664,8 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
     if (!b) { *err = JDA_ERROR_MEMORY; return NULL; }
     memset(b, 0, sizeof(*b));
     b->n_images = n;
+    b->status = new (std::nothrow) int32_t[(size_t)n];
+    if (b->status) memcpy(b->status, image_status.data(), (size_t)n * sizeof(int32_t));
     (void)hipSetDevice(ctx->device);
     hipError_t e = jda_pool_alloc(ctx, (void **)&b->d_descs, descs.size() * sizeof(jda_dev_desc));
     if (e == hipSuccess) e = hipMemcpyAsync(b->d_descs, descs.data(), descs.size() * sizeof(jda_dev_desc), hipMemcpyHostToDevice, ctx->stream);
@@ -671,6 +695,7 @@ void jda_batch_destroy(jda_ctx *ctx, jda_batch *b)
     if (ctx) (void)hipSetDevice(ctx->device);
     if (b->d_descs) { if (ctx) jda_pool_free(ctx, b->d_descs); else (void)hipFree(b->d_descs); }
     for (int m = 0; m < JDA_N_LISTS; m++) if (b->d_strips[m]) { if (ctx) jda_pool_free(ctx, b->d_strips[m]); else (void)hipFree(b->d_strips[m]); }
+    delete[] b->status;
     delete b;
 }
 
@@ -682,6 +707,15 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
         if (!b->n_strips[m]) continue;
         JDA_HIP(ctx, jda_launch_decode(m >> 4, (m >> 3) & 1, (m >> 1) & 3, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
     }
+    return JDA_SUCCESS;
+}
+
+// status[i] of every image of the plan: JDA_SUCCESS, JDA_DECODE_ERROR (the stream has a bad MCU: the MCUs before it are decoded,
+// as the reference leaves them, jpeg.inl:5354-5356) or JDA_INVALID_PARAMETER (a hole in the image array)
+int jda_batch_get_status(const jda_batch *b, int32_t *status)
+{
+    if (!b || !status || !b->status) return JDA_INVALID_PARAMETER;
+    memcpy(status, b->status, (size_t)b->n_images * sizeof(int32_t));
     return JDA_SUCCESS;
 }
 

@@ -46,6 +46,7 @@ struct jda_batch {
     jda_strip *d_strips[JDA_N_LISTS];
     uint32_t n_strips[JDA_N_LISTS];
     jda_batch_stats stats;
+    int32_t *status;            // per image: JDA_SUCCESS / JDA_DECODE_ERROR (bad MCU) / JDA_INVALID_PARAMETER (hole)
 };
 
 

@@ -177,3 +177,50 @@ def test_exif_thumbnail(product_class, ref_scalar):
     # the main image still decodes as before
     ra, rb = product_class.decode_cb(j, RGB8888, 0), ref_scalar.decode_cb(j, RGB8888, 0)
     assert ra["rc"] == rb["rc"] == 1 and np.array_equal(ra["canvas"][:240], rb["canvas"][:240])
+
+
+def test_objects_on_four_threads_decode_concurrently(product_class):
+    """One JPEGDEC object per thread is the reference's threading model; every thread gets its own device context
+    (stream, staging buffer, block pool), so four threads must beat one -- and deliver the same pixels."""
+    import threading
+    import time
+    from oracle.loader import digest
+    from tests.ref_fixtures import ref_golden, ref_jpeg
+
+    jpeg = ref_jpeg("tulips")
+    want = ref_golden()["tulips"]["frames"]["0:0"]["sha"]
+    n_each = 60
+
+    def work(out):
+        ok = 0
+        for _ in range(n_each):
+            r = product_class.decode_cb(jpeg, RGB565_LE, 0)
+            ok += int(r["rc"] == 1 and digest(r["canvas"][:480, : 640 * 2]) == want)
+        out.append(ok)
+
+    warm = []
+    work(warm)                                            # (first use: context creation, code objects)
+    t0 = time.perf_counter(); one = []; work(one); t1 = time.perf_counter() - t0
+    res = []
+    th = [threading.Thread(target=work, args=(res,)) for _ in range(4)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    t4 = time.perf_counter() - t0
+    assert one == [n_each] and res == [n_each] * 4        # every decode right, on every thread
+    speedup = (4 * n_each / t4) / (n_each / t1)
+    print("class decode: 1 thread %.2f ms / image, 4 threads %.2fx the throughput" % (t1 / n_each * 1e3, speedup))
+    assert speedup > 1.15, speedup
+
+
+def test_framebuffer_direct_copy_and_device_selection(product_class, ref_scalar):
+    """Framebuffer mode with an MCU-multiple width takes the direct D2H path (no intermediate canvas): same bytes as the
+    real reference, for every pixel type."""
+    from tests.ref_fixtures import ref_jpeg
+    for name, w, h in (("tulips", 640, 480), ("zebra", 320, 240)):
+        for pt, bpp in ((RGB565_LE, 2), (RGB8888, 4), (GRAY8, 1)):
+            rc_a, fa = product_class.decode_fb(ref_jpeg(name), pt, 0)
+            rc_b, fb = ref_scalar.decode_fb(ref_jpeg(name), pt, 0)
+            assert rc_a == rc_b == 1 and np.array_equal(fa[: w * h * bpp], fb[: w * h * bpp]), (name, pt)

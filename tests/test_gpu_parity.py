@@ -361,3 +361,43 @@ def test_duplicate_eob_code_general_reader(luma_hv, gpu_ctx, oracle):
     dimg = J.DeviceImage(gpu_ctx, dev)
     assert np.array_equal(dimg.read_index()[0], host.block_index()[0])
     dimg.close(); dev.close(); host.close()
+
+
+def test_one_bad_file_does_not_poison_a_resident_batch(gpu_ctx, oracle):
+    """VERDICT r1 task 7 on the resident path: jda_prepare_batch -> jda_upload_batch_ex -> jda_batch_create over 16 files of
+    which one is rejected by the parser and one has a corrupt scan: 14 decode bit-exact, the hole and the partial decode are
+    flagged per image (jda_batch_get_status), nobody else notices."""
+    good = jpeg_for("c420_333x217")
+    broken_scan = bytearray(good)
+    sos = bytes(broken_scan).index(b"\xff\xda")
+    broken_scan = bytes(broken_scan[: sos + 14 + 900])            # the stream ends early: bad MCU somewhere in the middle
+    files = [good] * 16
+    files[3] = good[:100]                                          # not a JPEG any more (JPEG_INVALID_FILE)
+    files[9] = broken_scan
+    prepared, errs = J.prepare_batch(files, threads=4, strict=False)
+    assert [p is None for p in prepared] == [i == 3 for i in range(16)] and errs[3] == 4
+    dev = J.upload_batch(gpu_ctx, prepared)
+    assert [d is None for d in dev] == [i == 3 for i in range(16)]
+    g = prepared[0].geometry(J.RGB8888, 0)
+    pitch = (g["canvas_w"] * 4 + 15) & ~15
+    base = gpu_ctx.malloc(pitch * g["canvas_h"] * 16)
+    gpu_ctx.memset(base, 0, pitch * g["canvas_h"] * 16)
+    outs = [(base + i * pitch * g["canvas_h"], pitch, g["canvas_w"], g["canvas_h"]) for i in range(16)]
+    batch = J.Batch(gpu_ctx, dev, outs, [J.RGB8888] * 16, [0] * 16)
+    batch.decode(); gpu_ctx.sync()
+    assert batch.status() == [1 if i == 3 else (2 if i == 9 else 0) for i in range(16)]
+    rc, want, _ = oracle.decode_canvas(good, J.RGB8888, 0)
+    for i in range(16):
+        got = gpu_ctx.to_host(outs[i][0], pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[:, : g["canvas_w"] * 4]
+        if i not in (3, 9):
+            assert np.array_equal(got, want), i
+    nok = prepared[9].block_index()[1]
+    assert 0 < nok < prepared[9].n_mcus
+    got = gpu_ctx.to_host(outs[9][0], pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[:, : g["canvas_w"] * 4]
+    rows = (nok // prepared[9].info.mcus_x) * 16
+    assert np.array_equal(got[:rows], want[:rows])                 # the MCU rows in front of the bad one are the good image's
+    batch.close()
+    for d in dev:
+        if d is not None:
+            d.close()
+    gpu_ctx.free(base)
