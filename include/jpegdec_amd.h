@@ -219,6 +219,13 @@ typedef struct jda_output {
 jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *images,
                             const jda_output *outputs, const int32_t *pixel_types,
                             const int32_t *options, int32_t *err);
+/* The same with a rectangle of MCUs per image: mcu_rects[4 i ..] = {mx0, my0, mx1, my1} (half open, MCU units), or NULL for whole
+ * images.  Only the tiles of the rectangle are launched -- the crop-aware decode (the reference skips the MCU rows above the crop
+ * and the MCUs left and right of it, jpeg.inl:5111, 5134-5137; here they are not even visited: the per-block index lets a tile start
+ * at any MCU).  The surface keeps the whole image's geometry; pixels outside the rectangle are not written. */
+jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *images,
+                                 const jda_output *outputs, const int32_t *pixel_types,
+                                 const int32_t *options, const int32_t *mcu_rects, int32_t *err);
 void jda_batch_destroy(jda_ctx *ctx, jda_batch *batch);
 
 /* Enqueue the decode kernels for the whole batch on the ctx stream (asynchronous). */
@@ -232,6 +239,8 @@ typedef struct jda_batch_stats {
     int64_t table_bytes;
     int32_t n_launches;         /* kernel launches per jda_batch_decode */
     int32_t n_workgroups;
+    int64_t tiles;              /* wavefront tiles with work in the plan */
+    int64_t tiles_whole_images; /* ... and what the whole images would have taken (crop-aware plans launch fewer) */
 } jda_batch_stats;
 int jda_batch_get_stats(const jda_batch *batch, jda_batch_stats *stats);
 /* status[i] for every image of the plan: JDA_SUCCESS; JDA_DECODE_ERROR = the stream has a bad MCU (the MCUs before it are decoded,
@@ -263,6 +272,11 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
  * canvas holds the MCUs before it, zeros behind). */
 int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
                           int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded);
+/* The same, decoding only the MCUs of mcu_rect = {mx0, my0, mx1, my1} (half open; NULL: everything): the canvas keeps its
+ * geometry, the rows of the rectangle are written (zeros left and right of it), the others are not touched.  tiles (may be NULL):
+ * [0] wavefront tiles launched, [1] tiles of the whole image. */
+int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                            void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles);
 
 /* ------------------------------------------------------------------ the streamed pipeline
  * Files in, pixels resident in HBM out, batch after batch: the host parses headers and builds tables (microseconds per file);

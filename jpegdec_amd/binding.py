@@ -42,7 +42,7 @@ class PipelineStats(C.Structure):
 class BatchStats(C.Structure):
     _fields_ = [("source_pixels", C.c_int64), ("output_bytes", C.c_int64), ("scan_bytes", C.c_int64),
                 ("index_bytes", C.c_int64), ("table_bytes", C.c_int64), ("n_launches", C.c_int32),
-                ("n_workgroups", C.c_int32)]
+                ("n_workgroups", C.c_int32), ("tiles", C.c_int64), ("tiles_whole_images", C.c_int64)]
 
 
 def library_path() -> str:
@@ -115,6 +115,10 @@ _PROTOTYPES = [
     ("jda_device_pci_bus_id", C.c_int, [_P, C.c_char_p, C.c_int32]),
     ("jda_upload_batch_ex", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("jda_batch_get_status", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("jda_decode_to_host_rect", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P, C.c_int32, C.c_int32,
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("jda_batch_create_rect", _P, [_P, C.c_int32, C.POINTER(_P), C.POINTER(Output), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("jda_version", C.c_char_p, []),
 ]
 
@@ -486,6 +490,22 @@ def decode_to_host(ctx: Context, jpeg: bytes, pixel_type=RGB8888, options=0):
     rc = ctx.lib.jda_decode_to_host(ctx.handle, jpeg, len(jpeg), pixel_type, options,
                                     canvas.ctypes.data_as(_P), canvas.shape[1], canvas.shape[0])
     return rc, canvas, g
+
+
+def decode_to_host_rect(ctx: Context, jpeg: bytes, pixel_type, options, mcu_rect):
+    """jda_decode_to_host_rect: (rc, canvas, geometry, (tiles launched, tiles of the whole image))"""
+    info = ImageInfo()
+    rc = ctx.lib.jda_parse(jpeg, len(jpeg), C.byref(info))
+    if rc != 0:
+        raise JdaError(rc, "jda_parse")
+    g = output_geometry(info, pixel_type, options)
+    canvas = np.zeros((g["canvas_h"], g["canvas_w"] * g["bpp"]), dtype=np.uint8)
+    rect = (C.c_int32 * 4)(*mcu_rect) if mcu_rect is not None else None
+    tiles = (C.c_int32 * 2)()
+    nok = C.c_int32(0)
+    rc = ctx.lib.jda_decode_to_host_rect(ctx.handle, jpeg, len(jpeg), pixel_type, options, rect, canvas.ctypes.data_as(_P), canvas.shape[1],
+                                         canvas.shape[0], C.byref(nok), tiles)
+    return rc, canvas, g, (tiles[0], tiles[1])
 
 
 def filter_on_device(ctx: Context, raw: bytes, restart_cap: int = 1 << 16):

@@ -260,7 +260,22 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         return 1;
     }
     std::vector<uint8_t> canvas((size_t)cw * ch * bpp);
-    rc = jda_decode_to_host_ex(ctx, s->data, s->size, pt, iOptions, canvas.data(), cw * bpp, ch, &mcus_decoded);
+    // A cropped decode only launches the tiles of the MCUs the reference keeps (jpeg.inl:5111, :5134-5137: MCU rows from the crop's
+    // first row on, MCU columns from iCropX up to and including the one AT iCropX + iCropCX -- the '>' there).  The reference
+    // still entropy-decodes what it skips (it has to, to find the next MCU); the per-block index makes that unnecessary here.
+    int32_t rect[4] = { 0, 0, s->info.mcus_x, s->info.mcus_y };
+    if (cropped) {
+        const int mw0 = s->info.mcu_w >> shift0, mh0 = s->info.mcu_h >> shift0;
+        int x0 = s->info.mcus_x, x1 = 0;
+        for (int x = 0; x < s->info.mcus_x; x++)
+            if (!(x * mw0 < s->crop_x || x * mw0 > s->crop_x + s->crop_w)) { if (x < x0) x0 = x; x1 = x + 1; }
+        int y0 = 0;
+        while (y0 < s->info.mcus_y && y0 * mh0 < s->crop_y) y0++;
+        int y1 = (s->crop_y + s->crop_h + s->info.mcu_h - 1) / s->info.mcu_h;
+        if (y1 > s->info.mcus_y) y1 = s->info.mcus_y;
+        rect[0] = x0 < x1 ? x0 : 0; rect[1] = y0; rect[2] = x0 < x1 ? x1 : 0; rect[3] = y1 > y0 ? y1 : y0;
+    }
+    rc = jda_decode_to_host_rect(ctx, s->data, s->size, pt, iOptions, cropped ? rect : NULL, canvas.data(), cw * bpp, ch, &mcus_decoded, NULL);
     const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
     if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
 

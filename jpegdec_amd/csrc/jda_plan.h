@@ -97,21 +97,35 @@ inline uint32_t jda_mcus_per_tile(int mode)
     return mode == JDA_MODE_420 ? 10u : mode == JDA_MODE_444 ? 21u : (mode == JDA_MODE_422 || mode == JDA_MODE_440) ? 16u : 64u;
 }
 
-inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, int big = 0)
+// rect = {mx0, my0, mx1, my1} in MCUs (half open) restricts the list to the tiles of that rectangle (crop-aware decode:
+// the per-block index lets a tile start at any MCU); NULL = the whole image
+inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, int big = 0, const int32_t *rect = nullptr)
 {
     const uint32_t per = jda_mcus_per_tile(mode);
     const uint32_t ord = v.empty() ? 0u : v.back().ord + 1u;      // images are appended one after the other
+    uint32_t x0 = 0, y0 = 0, x1 = mcus_x, y1 = mcus_y;
+    if (rect) {
+        x0 = rect[0] < 0 ? 0u : (uint32_t)rect[0]; y0 = rect[1] < 0 ? 0u : (uint32_t)rect[1];
+        x1 = rect[2] < 0 ? 0u : ((uint32_t)rect[2] < mcus_x ? (uint32_t)rect[2] : mcus_x);
+        y1 = rect[3] < 0 ? 0u : ((uint32_t)rect[3] < mcus_y ? (uint32_t)rect[3] : mcus_y);
+    }
     bool first = true;
-    for (uint32_t y = 0; y < mcus_y; y++)
-        for (uint32_t x = 0; x < mcus_x; x += per) {
+    for (uint32_t y = y0; y < y1; y++)
+        for (uint32_t x = x0; x < x1; x += per) {
             jda_strip s;
             memset(&s, 0, sizeof(s));
             s.image = image; s.mcu_y = (uint16_t)y; s.mcu_x0 = (uint16_t)x;
-            s.count = (uint8_t)(mcus_x - x < per ? mcus_x - x : per);
+            s.count = (uint8_t)(x1 - x < per ? x1 - x : per);
             s.first = first ? 1 : 0; s.ord = ord;
             first = false;
             v.push_back(s);
         }
+    if (first) {                                                   // an empty rectangle: one padding tile keeps the image's place (ord) in the list
+        jda_strip s;
+        memset(&s, 0, sizeof(s));
+        s.image = image; s.first = 1; s.ord = ord;
+        v.push_back(s);
+    }
     while (v.size() % jda_tiles_per_wg(mode, big)) {
         jda_strip s;
         memset(&s, 0, sizeof(s));

@@ -626,6 +626,13 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
                             const jda_output *outputs, const int32_t *pixel_types,
                             const int32_t *options, int32_t *err)
 {
+    return jda_batch_create_rect(ctx, n, images, outputs, pixel_types, options, NULL, err);
+}
+
+jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *images,
+                                 const jda_output *outputs, const int32_t *pixel_types,
+                                 const int32_t *options, const int32_t *mcu_rects, int32_t *err)
+{
     int32_t dummy;
     if (!err) err = &dummy;
     if (!ctx) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
@@ -653,7 +660,14 @@ jda_batch *jda_batch_create(jda_ctx *ctx, int32_t n, jda_dev_image *const *image
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
         const int big = jda_big_window(D, variant);
-        jda_append_strips(strips[((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big], (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big);
+        {
+            std::vector<jda_strip> &lst = strips[((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big];
+            const size_t before = lst.size();
+            jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL);
+            for (size_t k = before; k < lst.size(); k++) if (lst[k].count) st.tiles++;
+            const uint32_t per = jda_mcus_per_tile(D.mode);
+            st.tiles_whole_images += (int64_t)D.mcus_y * ((D.mcus_x + per - 1) / per);
+        }
         st.source_pixels += (int64_t)I.width * I.height;
         st.output_bytes += (int64_t)D.out_w * D.out_rows * bpp;
         st.scan_bytes += im->scan_len;
@@ -793,7 +807,14 @@ int jda_decode_to_host(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t p
 int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type,
                           int32_t options, void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded)
 {
+    return jda_decode_to_host_rect(ctx, jpeg, len, pixel_type, options, NULL, host_pixels, pitch_bytes, rows, mcus_decoded, NULL);
+}
+
+int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                            void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles)
+{
     if (mcus_decoded) *mcus_decoded = 0;
+    if (tiles) tiles[0] = tiles[1] = 0;
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     int32_t err = JDA_SUCCESS;
     static const bool trace = getenv("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
@@ -825,15 +846,22 @@ int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_
     if (!dout) { jda_dev_image_free(ctx, dimg); return JDA_ERROR_MEMORY; }
     jda_output O;
     O.pixels = dout; O.pitch_bytes = dpitch; O.width_px = cw; O.rows = drows;
-    jda_batch *b = jda_batch_create(ctx, 1, &dimg, &O, &pixel_type, &options, &err);
+    jda_batch *b = jda_batch_create_rect(ctx, 1, &dimg, &O, &pixel_type, &options, mcu_rect, &err);
     rc = err;
     JDA_OC_MARK("surface + launch plan");
     if (b) {
-        if (!complete) (void)hipMemsetAsync(dout, 0, (size_t)dpitch * ch, ctx->stream);
+        if (tiles) { tiles[0] = (int32_t)b->stats.tiles; tiles[1] = (int32_t)b->stats.tiles_whole_images; }
+        // only the MCU rows of the rectangle are decoded, zeroed where nothing is written, and copied back
+        int r0 = 0, r1 = drows;
+        if (mcu_rect) {
+            const int mh_out = ch / (I.mcus_y ? I.mcus_y : 1);
+            r0 = std::max(0, std::min(drows, mcu_rect[1] * mh_out)); r1 = std::max(r0, std::min(drows, mcu_rect[3] * mh_out));
+        }
+        if ((!complete || mcu_rect) && r1 > r0) (void)hipMemsetAsync((uint8_t *)dout + (size_t)r0 * dpitch, 0, (size_t)dpitch * (r1 - r0), ctx->stream);
         rc = jda_batch_decode(ctx, b);
-        if (rc == JDA_SUCCESS) {
+        if (rc == JDA_SUCCESS && r1 > r0) {
             const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
-            hipError_t e = hipMemcpy2DAsync(host_pixels, (size_t)pitch_bytes, dout, (size_t)dpitch, row_bytes, (size_t)drows, hipMemcpyDeviceToHost, ctx->stream);
+            hipError_t e = hipMemcpy2DAsync((uint8_t *)host_pixels + (size_t)r0 * pitch_bytes, (size_t)pitch_bytes, (uint8_t *)dout + (size_t)r0 * dpitch, (size_t)dpitch, row_bytes, (size_t)(r1 - r0), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
         }

@@ -217,3 +217,26 @@ def test_reference_test_program(gpu_ctx):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
     assert "Total tests: 11, 11 passed, 0 failed" in p.stdout, p.stdout[-3000:]
+
+
+def test_crop_aware_decode_launches_only_the_crop(gpu_ctx):
+    """VERDICT r1 task 8: crop_area.ino's rectangle on croptest -- the launch plan holds the tiles of the kept MCUs only
+    (<= 40 % of the image's), the pixels of the rectangle are those of the full decode, nothing outside it is written."""
+    jpeg = ref_jpeg("croptest")
+    p = J.PreparedImage(jpeg)
+    cx, cy, cw, ch = J.crop_round(p.info, *CROP_INO)
+    assert (cx, cy, cw, ch) == (112, 64, 128, 112)
+    mw, mh = p.info.mcu_w, p.info.mcu_h
+    xs = [x for x in range(p.info.mcus_x) if not (x * mw < cx or x * mw > cx + cw)]
+    rect = (xs[0], (cy + mh - 1) // mh, xs[-1] + 1, min(p.info.mcus_y, (cy + ch + mh - 1) // mh))
+    for pt in (RGB8888, RGB565_LE, GRAY8):
+        rc0, full, g = J.decode_to_host(gpu_ctx, jpeg, pt, 0)
+        rc1, part, g1, tiles = J.binding.decode_to_host_rect(gpu_ctx, jpeg, pt, 0, rect)
+        assert rc0 == rc1 == 0 and tiles[1] == 30 and tiles[0] <= 0.4 * tiles[1], tiles
+        bpp = g["bpp"]
+        ys, xb = slice(rect[1] * mh, rect[3] * mh), slice(rect[0] * mw * bpp, rect[2] * mw * bpp)
+        assert np.array_equal(part[ys, xb], full[ys, xb])
+        outside = part.copy()
+        outside[ys, xb] = 0
+        assert not outside.any()
+    p.close()
