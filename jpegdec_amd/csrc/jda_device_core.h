@@ -54,21 +54,22 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
 // that do not start with six 1 bits; the long halves are rare and stay in global memory),
 // quantisers, zigzag.
 #define JDA_LT_DC      0         // 2 x 1024
-#define JDA_LT_AC      2048      // 2 x 1024 uint16, re-laid out while staging (jda_ac_entry)
+#define JDA_LT_AC      2048      // 2 tables x (1024 short + 1024 long) uint16, re-laid out while staging (jda_ac_entry): the long half
+                                 // (codes starting 111111, the reference's usHuffAC[1024 + ..]) right behind the short one, so that ONE
+                                 // 11-bit key finds an entry: (w >> 22) for a short code, (w >> 16) & 0x7ff = 1024 + the next 10 bits for a long one
 // The prescaled quantiser tables (4 x 64 int16) sit in the DC LUTs' unused bytes: a DC LUT (the reference's layout, jpeg.inl:1098-1152)
 // is indexed 0..61 and 128..255 (+ 512 for the folded values), so bytes 256..511 of each 1024-byte LUT are never read --
 // room for two 128-byte tables each.  512 bytes less per workgroup is what lets 16 wavefronts of the 64-block tile layouts fit.
 #define JDA_LT_QUANT_OFF(q) ((((q) >> 1) * 1024u) + 256u + (((q) & 1u) * 128u))
 #define JDA_LT_NIB     96        // 16 x uint16: the set bits of a nibble, lowest first, as 3-bit fields (jda_p1_lists); same DC LUT bytes
 #define JDA_LT_EOB     64        // 2 x uint32: JDA_TB_EOB, in never-read bytes of DC LUT 0
-#define JDA_LT_ZZ      6144      // 144 x uint16, built while staging: where the coefficient at zigzag position j goes
+#define JDA_LT_ZZ      10240     // 144 x uint16, built while staging: where the coefficient at zigzag position j goes
 #define JDA_ZZ_ENTRIES 144       //   j < 64: (column bit 1 << (n & 7)) << 8 | 2 n (n = natural index: the byte offset in the
                                  //   block); j >= 64 (past the block, or 64 + j for a symbol that stores nothing): 128 = the
                                  //   block's padding, no flags.  j <= 63 + 15 + 64.
 #define JDA_ZZ_DUMP    128u
-#define JDA_LT_BYTES   6432
-#define JDA_LT_LONG    JDA_LT_BYTES   // 2 x 1024 uint16: the long halves of the AC LUTs (codes starting 111111), same entry layout -- staged
-#define JDA_LT_LONG_BYTES 4096        // only by the layouts that have the room (jda_lds_layout<MODE>::LONG_LDS); the others read the blob
+#define JDA_LT_BYTES   10528
+#define JDA_LT_LONG_BYTES 0           // (the long halves are part of JDA_LT_AC now)
 
 // AC LUT entry as the kernels keep it in LDS, made from the reference's (length << 8) | RS:
 //   (length - 1) << 12 | S << 8 | Z,   Z = 2 (R + 64 nostore)  -- or 0xff for EOB, 0xfe for "no such code" (raw 0)
@@ -116,8 +117,8 @@ template <int MODE, int BIG = 0> struct jda_lds_layout {
         // the AC LUTs.  They are some percent of the symbols, i.e. SOME lane of a wavefront meets one in most trips of the
         // entropy loop: from the table blob in HBM that was a global load per trip, behind a wait that also drains the
         // tile's output stores.  So the long halves are staged too
-        LONG_LDS = JDA_LONG_LDS_MODES >> MODE & 1,
-        TAB_BYTES = JDA_LT_BYTES + (LONG_LDS ? JDA_LT_LONG_BYTES : 0),
+        LONG_LDS = 1,
+        TAB_BYTES = JDA_LT_BYTES,
         // wavefronts per workgroup = per CU: as many as fit in the 160 KB of LDS next to one table copy (and the 16-byte draw
         // counter), 16 at most; every wavefront gets an equal share of what is there, and what it does not need is window
         LDS_FREE = 160 * 1024 - TAB_BYTES - 16,
@@ -457,7 +458,7 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
     jda_refill(br);
     while (k < LIMIT) {
         code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
-        if (code >= 0xfc00u) e = jda_ac_entry(T.ac_long[code & 0x3ffu]);   // usHuffAC[1024 + ...]  :2232-2233
+        if (code >= 0xfc00u) e = T.ac_long_lds[code & 0x3ffu];               // usHuffAC[1024 + ...]  :2232-2233
         else e = T.ac_short[code >> 6];
         if (JDA_AC_STOPS(e)) break;                     // EOB (no refill follows; the block's reader state is not needed any more)
         br.off += (e >> 12) + 1u;
@@ -661,6 +662,25 @@ struct jda_wreader {
     uint32_t left;           // bits of hi still to come
     const uint8_t *wp;       // LDS address nxt came from
 };
+// a + (b & 0xff) in one instruction (the byte select rides on the add: SDWA)
+JDA_HD uint32_t jda_add_byte0(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a + (b & 0xffu);
+#endif
+}
+JDA_HD uint32_t jda_bfe(uint32_t v, uint32_t off, uint32_t width)          // v_bfe_u32: (v >> off) & ((1 << width) - 1), off + width <= 32
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    return (v >> off) & ((1u << width) - 1u);
+#endif
+}
 JDA_HD uint32_t jda_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)      // low 32 bits of {hi, lo} >> sh, sh = 0..31
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -691,6 +711,17 @@ JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n)
 // the reference's refill (jpeg.inl:2110-2114) as far as its ulBitOff is concerned
 JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) : roff; }
 
+// LDS accesses by 32-bit address in the entropy loop (GPU): the zigzag lookup and the deferred coefficient store take their
+// address from an SDWA add (a + byte 0 of b), which the compiler can only keep in the LDS address space if it is told so
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JDA_LDS_A32(p) ((uint32_t)(uintptr_t)(p))
+#define JDA_LDS_LOAD_U16(base_ptr, a32) ((uint32_t)*(const uint16_t __attribute__((address_space(3))) *)(a32))
+#define JDA_COEF_STORE(coef, t, v) (*(int16_t __attribute__((address_space(3))) *)jda_add_byte0(JDA_LDS_A32(coef), (t)) = (int16_t)(v))
+#else
+#define JDA_LDS_A32(p) 0u
+#define JDA_LDS_LOAD_U16(base_ptr, a32) ((uint32_t)*(const uint16_t *)((const uint8_t *)(base_ptr) + (a32)))
+#define JDA_COEF_STORE(coef, t, v) (*(int16_t *)((uint8_t *)(coef) + ((t) & 0xffu)) = (int16_t)(v))
+#endif
 // EXACT = false leaves the reference's ulBitOff out (five instructions and a branch less per symbol): only right for a block
 // in which the reference truncates no magnitude read, i.e. one whose index entry lacks JDA_INDEX_TRUNC.
 // zero_fill: clear the block first.
@@ -730,7 +761,8 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     if (LIMIT == 1) return 0;
     coef[0] = (int16_t)pred;
     if (dc_only) return 0;                               // no AC symbol in this scan: a DC-only block (flags 0)
-    uint32_t k2 = 2;                                     // twice the zigzag position: the byte offset into the zigzag table
+    const uint32_t zzb = JDA_LDS_A32(T.zz);              // (GPU: the zigzag table's LDS address rides in k2, so a lookup's address is one add)
+    uint32_t k2 = zzb + 2;                               // twice the zigzag position: the byte offset into the zigzag table
     if (EXACT) roff = jda_ref_refill(roff);
     // EOB is recognised on the stream bits themselves -- one code per table, checked by the host (JDA_DESC_GENERAL_P1) --
     // before the symbol is looked up: a block costs one trip per coefficient symbol, none for its EOB, and the wavefront
@@ -739,25 +771,20 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     // A symbol's value is stored one trip later, while the next symbol's lookup is under way: the zigzag entry it needs was
     // asked for a trip earlier and LDS answers in order, so the trip waits for LDS once, not twice.  (The first trip stores a
     // zero to the block's padding.)
-    uint16_t t_prev = JDA_ZZ_DUMP;
+    uint32_t t_prev = JDA_ZZ_DUMP;
     int32_t v_prev = 0;
     w = jda_wr_peek(R);
     if ((w >> T.eob_sh) != T.eob_code) for (;;) {
-        uint32_t li = w >> 22;
-        JDA_OPAQUE(li);                                  // (keeps it a shift + a shift-add: the compiler's own form is shift, mask, add)
-        if (LONG_LDS) {
-            // codes starting 111111 (usHuffAC[1024 + ...], :2232-2233) sit in the second LDS table: one lookup, no branch
-            const uint16_t *ps = T.ac_short + li, *pl = T.ac_long_lds + ((w >> 16) & 0x3ffu);
-            e = *(w >= 0xfc000000u ? pl : ps);
-        } else e = T.ac_short[li];
+        // codes starting 111111 (usHuffAC[1024 + ...], :2232-2233) sit right behind the short half: one 11-bit key, one lookup,
+        // no branch -- the key is a bit field whose position depends on the code's class
+        e = T.ac_short[jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u)];
         fl |= t_prev;
-        *(int16_t *)((uint8_t *)coef + (t_prev & 0xffu)) = (int16_t)v_prev;
-        if (!LONG_LDS) { if (__builtin_expect(w >= 0xfc000000u, 0)) e = jda_ac_entry(T.ac_long[(w >> 16) & 0x3ffu]); }
+        JDA_COEF_STORE(coef, t_prev, v_prev);
         // the zigzag lookup decides where the value goes: position k + R of the block, or the padding when that is past
         // the block or the symbol carries no value (ZRL: the entry's low byte reads 2 (R + 64))
-        const uint32_t kk2 = k2 + (e & 0xffu);
-        uint32_t t = *(const uint16_t *)((const uint8_t *)T.zz + kk2);
-        if (LIMIT != 64 && kk2 >= 2u * (uint32_t)LIMIT) t = JDA_ZZ_DUMP;     // 1/4 scale keeps zigzag 1..4 only (:2117-2119)
+        const uint32_t kk2 = jda_add_byte0(k2, e);
+        uint32_t t = JDA_LDS_LOAD_U16(T.zz, kk2);
+        if (LIMIT != 64 && kk2 >= zzb + 2u * (uint32_t)LIMIT) t = JDA_ZZ_DUMP;     // 1/4 scale keeps zigzag 1..4 only (:2117-2119)
         const uint32_t len = (e >> 12) + 1u, ms = (e >> 8) & 0xfu;
         uint32_t m = w << len;
         const uint32_t n = len + ms;
@@ -767,14 +794,14 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
             roff = jda_ref_refill(roff);
         }
         v_prev = jda_extend_top(m, ms);
-        t_prev = (uint16_t)t;
+        t_prev = t;
         jda_wr_consume(R, n);
         k2 += (e & 0x1eu) + 2u;
         w = jda_wr_peek(R);
-        if (k2 >= 2u * (uint32_t)LIMIT || (w >> T.eob_sh) == T.eob_code) break;
+        if (k2 >= zzb + 2u * (uint32_t)LIMIT || (w >> T.eob_sh) == T.eob_code) break;
     }
     fl |= t_prev;
-    *(int16_t *)((uint8_t *)coef + (t_prev & 0xffu)) = (int16_t)v_prev;
+    JDA_COEF_STORE(coef, t_prev, v_prev);
     // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested; fl holds 2n in 7:0
     return (fl >> 8) | ((fl & 0x40u) << 7);
 }
@@ -1124,7 +1151,7 @@ JDA_HD uint32_t jda_seg_fetch(const uint8_t *slot, uint32_t bit)
 // out like the AC entries -- (code length - 1) << 12 | SSSS << 8 | folded -- so that one 16-bit lookup serves a DC and an AC
 // symbol alike.  "folded" (bit 0): the reference takes code and magnitude from the LUT in one step (:1132-1152) and does not
 // refill between them.
-#define JDA_LT_DC16 (JDA_LT_BYTES + JDA_LT_LONG_BYTES)      // 2 x 256 uint16
+#define JDA_LT_DC16 JDA_LT_BYTES      // 2 x 256 uint16
 #define JDA_LT_DC16_BYTES 1024
 #define JDA_LT_WALK_BYTES (JDA_LT_DC16 + JDA_LT_DC16_BYTES)
 JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
@@ -1164,7 +1191,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     uint32_t p = entry & 63u, b = (entry >> 6) & 7u, k = (entry >> 9) & 63u;
     // per component: LDS offsets of its DC16 / AC short / AC long table (ids are 0 or 1)
     const uint32_t dcb0 = JDA_LT_DC16 + P.dc_id[0] * 512u, dcb1 = JDA_LT_DC16 + P.dc_id[1] * 512u, dcb2 = JDA_LT_DC16 + P.dc_id[2] * 512u;
-    const uint32_t acb0 = JDA_LT_AC + P.ac_id[0] * 2048u, acb1 = JDA_LT_AC + P.ac_id[1] * 2048u, acb2 = JDA_LT_AC + P.ac_id[2] * 2048u;
+    const uint32_t acb0 = JDA_LT_AC + P.ac_id[0] * 4096u, acb1 = JDA_LT_AC + P.ac_id[1] * 4096u, acb2 = JDA_LT_AC + P.ac_id[2] * 4096u;
     // WRITE: the reference reader (pBuf, ulBitOff), the block ordinal and the DC predictors at the entry
     uint32_t pos = 0, off = 0, g = 0, pos_pre = 0, off_pre = 0;
     int32_t pred0 = 0, pred1 = 0, pred2 = 0;
@@ -1203,7 +1230,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         const uint32_t dcb = c == 0 ? dcb0 : (c == 1 ? dcb1 : dcb2), acb = c == 0 ? acb0 : (c == 1 ? acb1 : acb2);
         const uint32_t code12 = w >> 20;
         const uint32_t a_dc = dcb + 2u * (code12 >= 0xf80u ? (code12 & 0xffu) : (w >> 26));
-        const uint32_t a_ac = w >= 0xfc000000u ? acb + (JDA_LT_LONG - JDA_LT_AC) + ((w >> 15) & 0x7feu) : acb + ((w >> 22) << 1);
+        const uint32_t a_ac = acb + 2u * jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
         const uint32_t e = *(const uint16_t *)(lt + (isdc ? a_dc : a_ac));
         const uint32_t elow = e & 0xffu;
         if (elow == JDA_AC_NONE) {                                  // no such code  (:2137-2138, :2237-2238)
@@ -1396,14 +1423,7 @@ JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nth
         }
         ((uint16_t *)(tab_lds + JDA_LT_ZZ))[j] = (uint16_t)v;
     }
-    if (with_long) {
-        for (uint32_t i = tid; i < JDA_LT_LONG_BYTES / 16; i += nthreads) {         // table i / 128, chunk i % 128 of its long half
-            jda_chunk16_alias c = blob[(JDA_TB_AC >> 4) + (i >> 7) * 256u + 128u + (i & 127u)];
-#pragma unroll
-            for (int k = 0; k < 4; k++) c.w[k] = jda_ac_entry(c.w[k] & 0xffffu) | (jda_ac_entry(c.w[k] >> 16) << 16);
-            tab[(JDA_LT_LONG >> 4) + i] = c;
-        }
-    }
+    (void)with_long;
     for (uint32_t i = tid; i < JDA_LT_ZZ / 16; i += nthreads) {
         uint32_t src;
         if (i < 128) {                                          // DC LUTs; chunks 16..31 of each (bytes 256..511) take two quantiser tables
@@ -1418,10 +1438,9 @@ JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nth
                 continue;
             }
         }
-        else if (i < 256) src = (JDA_TB_AC >> 4) + (i - 128);   // AC table 0, short half
-        else src = (JDA_TB_AC >> 4) + 256 + (i - 256);          // AC table 1, short half
+        else src = (JDA_TB_AC >> 4) + (i - 128);                // the AC LUTs, both halves of both tables, in the blob's order
         jda_chunk16_alias c = blob[src];
-        if (i >= 128 && i < 384) {                              // AC entries -> the kernels' layout
+        if (i >= 128) {                                         // AC entries -> the kernels' layout
 #pragma unroll
             for (int k = 0; k < 4; k++) c.w[k] = jda_ac_entry(c.w[k] & 0xffffu) | (jda_ac_entry(c.w[k] >> 16) << 16);
         }
@@ -1464,7 +1483,7 @@ JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t l
     const uint32_t eob = *(const jda_u32_alias *)(tab + JDA_LT_EOB + 4u * ac_id);   // (the image's tables must be staged)
     LP.eob_sh = eob >> 16; LP.eob_code = eob & 0xffffu;
     LP.dc_off = JDA_LT_DC + dc_id * 1024;
-    LP.ac_off = JDA_LT_AC + ac_id * 2048;
+    LP.ac_off = JDA_LT_AC + ac_id * 4096;
     LP.ac_long_off = JDA_TB_AC + (ac_id * 2048 + 1024) * 2;
     LP.quant_off = JDA_LT_QUANT_OFF(q_id);
     LP.qsel = (JDA_LT_QUANT_OFF(q_id) >> 7) << 9;                 // (the table's offset in units of 128 bytes)
@@ -1510,7 +1529,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     TB.dc = tab + LP.dc_off;
     TB.ac_short = (const uint16_t *)(tab + LP.ac_off);
     TB.ac_long = (const uint16_t JDA_GLOBAL *)(JDA_G(const uint8_t, D.tables) + LP.ac_long_off);
-    TB.ac_long_lds = (const uint16_t *)(tab + JDA_LT_LONG + (LP.ac_off - JDA_LT_AC));      // (AC table id x 2048 bytes in both)
+    TB.ac_long_lds = TB.ac_short + 1024;
     TB.zz = (const uint16_t *)(tab + JDA_LT_ZZ);
     TB.eob_sh = LP.eob_sh; TB.eob_code = LP.eob_code;
     const int16_t *quant = (const int16_t *)(tab + LP.quant_off);

@@ -25,7 +25,7 @@ template <int MODE, bool FAST>
 static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles)
 {
     typedef jda_lds_layout<MODE> L;
-    std::vector<uint64_t> tab_store((JDA_LT_BYTES + JDA_LT_LONG_BYTES + 7) / 8), lds_store((L::WAVE_BYTES + 7) / 8);
+    std::vector<uint64_t> tab_store((JDA_LT_BYTES + 7) / 8), lds_store((L::WAVE_BYTES + 7) / 8);
     uint8_t *tab = (uint8_t *)tab_store.data(), *wl = (uint8_t *)lds_store.data();
     for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables(D, tid, 256, tab, L::LONG_LDS != 0);
     for (size_t ii = 0; ii < tiles.size(); ii++) {
