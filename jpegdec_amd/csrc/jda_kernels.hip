@@ -220,6 +220,9 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
 #define JDA_PRIO_IDCT 1
 #define JDA_PRIO_P4 3
 #endif
+#ifndef JDA_GRID_MULT_DEFAULT
+#define JDA_GRID_MULT_DEFAULT 1
+#endif
 #ifndef JDA_EXP_SKIP
 #define JDA_EXP_SKIP 0       // profiling builds (tools/phase_count_libs.sh): 1 no P4, 2 no P3, 4 no P2, 8 no lists, 16 no P1
 #endif
@@ -402,7 +405,10 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int per_cu = (160 * 1024) / lds_bytes;
-        grid_cap = cus * (per_cu > 0 ? per_cu : 1);
+        // more workgroups than CUs: the ones that do not fit start as others finish, so the hardware deals the second half of the
+        // work out by who is done first (the static split left the CUs finishing up to 4 % apart: profiles/r01_final_wg_balance.txt)
+        static const int mult = []() { const char *e = getenv("JDA_GRID_MULT"); const int m = e ? atoi(e) : JDA_GRID_MULT_DEFAULT; return m < 1 ? 1 : (m > 16 ? 16 : m); }();
+        grid_cap = cus * (per_cu > 0 ? per_cu : 1) * mult;
     }
     const uint32_t n_quads = n_tiles / L::WAVES;
     const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
