@@ -1137,15 +1137,35 @@ JDA_HD void jda_atomic_or_u32(uint32_t *p, uint32_t v)
     *p |= v;                                         // (the emulator steps the lanes one after another)
 #endif
 }
-// the next 32 bits of the stream at bit `bit` of the lane's slot.  The slot holds the segment as byte-swapped dwords (the
-// stream's first byte on top: jda_seg_stage_word), so two aligned reads and a funnel shift give the bits
-JDA_HD uint32_t jda_seg_stage_word(uint32_t v) { return __builtin_bswap32(v); }
-JDA_HD uint32_t jda_seg_fetch(const uint8_t *slot, uint32_t bit)
+// The walk's view of its segment: 64 stream bits in two registers and the two dwords after them on their way from memory (the
+// segment is read where it lies -- global memory, L2 -- one dword per 32 bits consumed, two dwords ahead of the bits in use, so
+// no load sits between two symbols and nothing of the scan is staged in LDS: the tables are all a workgroup keeps there, and
+// the wavefronts a CU holds are bounded by registers, not by 17 KB of slots each).  A symbol is at most 31 bits (code <= 16,
+// magnitude <= 15), so a step advances the window by at most one dword.
+struct jda_seg_reader {
+    const uint32_t JDA_GLOBAL *d;   // the segment's first dword (readable: JDA_SEG_SLOT bytes)
+    uint32_t idx;                   // dword index of hi
+    uint32_t hi, lo;                // stream bits, first byte on top
+    uint32_t n1, n2;                // dwords idx + 2, idx + 3 as loaded (little endian)
+};
+JDA_HD void jda_seg_reader_init(jda_seg_reader &R, const uint32_t JDA_GLOBAL *d, uint32_t p)
 {
-    const jda_u32_alias *d = (const jda_u32_alias *)(slot + ((bit >> 5) << 2));
-    const uint64_t v = ((uint64_t)d[0] << 32) | d[1];
-    return (uint32_t)((v << (bit & 31u)) >> 32);
+    R.d = d; R.idx = p >> 5;
+    R.hi = __builtin_bswap32(d[R.idx]); R.lo = __builtin_bswap32(d[R.idx + 1u]);
+    R.n1 = d[R.idx + 2u]; R.n2 = d[R.idx + 3u];
 }
+// the next 32 bits of the stream at bit p of the segment (p moves forward by at most 31 bits between calls)
+JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
+{
+    const uint32_t wi = p >> 5;
+    if (wi != R.idx) {                                              // (one dword further)
+        R.hi = R.lo; R.lo = __builtin_bswap32(R.n1); R.n1 = R.n2; R.idx = wi;
+        R.n2 = R.d[wi + 3u];
+    }
+    const uint64_t v = ((uint64_t)R.hi << 32) | R.lo;
+    return (uint32_t)((v << (p & 31u)) >> 32);
+}
+#define JDA_SEG_READ_DWORDS 68u     // dwords of the scan a walk may touch from its segment's start (64 + the window's reach)
 
 // The walk's own DC table (JDA_LT_DC16, built while the tables are staged): the reference's DC LUT (jpeg.inl:1098-1152) re-laid
 // out like the AC entries -- (code length - 1) << 12 | SSSS << 8 | folded -- so that one 16-bit lookup serves a DC and an AC
@@ -1163,15 +1183,18 @@ JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
     return ((len - 1u) << 12) | (s << 8) | (fold ? 1u : 0u);
 }
 
-// One walk of a segment.  lt: the tables in the kernels' LDS layout + the long AC halves + JDA_LT_DC16; slot: the segment's
-// bytes as jda_seg_stage_word leaves them (JDA_SEG_SLOT readable).
+// One walk of a segment.  lt: the tables in the kernels' LDS layout + JDA_LT_DC16; segw: the segment's first dword in the
+// (zero-padded) filtered scan.
 //
 // A step decodes ONE symbol, DC or AC alike, without a branch on which it is: the lanes of a wavefront sit at unrelated places
-// of their blocks, so "if DC .. else AC .." ran both sides every step.  The reference's refills (jpeg.inl:2110-2114) happen at
-// fixed places -- before a block's first symbol, before a DC magnitude that is not folded into its LUT entry, at the top and
-// the bottom of the AC loop -- and two of them in a row at the same bit are one; so a step is: [refill before an unfolded DC
-// magnitude] .. refill at its end (bottom of the AC loop / top of it after the DC symbol / opening refill of the next block
-// after EOB: same position, same result).  State at a step boundary, hence at a segment boundary: after that refill.
+// of their blocks, so "if DC .. else AC .." ran both sides every step -- and every small `if` in the body costs an exec-mask
+// region (s_and_saveexec / s_cbranch / s_or), so the body is written with selects; what stays a branch is what is rare (a
+// truncated magnitude, an invalid code) or has to store (a block's start and end in the WRITE pass).  The reference's refills
+// (jpeg.inl:2110-2114) happen at fixed places -- before a block's first symbol, before a DC magnitude that is not folded into
+// its LUT entry, at the top and the bottom of the AC loop -- and two of them in a row at the same bit are one; so a step is:
+// [refill before an unfolded DC magnitude] .. refill at its end (bottom of the AC loop / top of it after the DC symbol / opening
+// refill of the next block after EOB: same position, same result).  State at a step boundary, hence at a segment boundary:
+// after that refill.
 //   SPEC   exit state only.
 //   COUNT  + block starts, DC sums per component, and how the reference window's BYTE LAG u = (p >> 3) - pBuf propagates: the
 //          six lags a boundary state can have (a refill leaves off <= 47) ride in 5-bit fields of one word (4 value bits + a
@@ -1181,7 +1204,7 @@ JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
 //          block's end so that a truncation flag joins its entry in the register: one plain store; only a block that crosses into
 //          the next segment is ORed in atomically), blk_dc, maxima, truncation count.
 template <int OP>
-JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint8_t *slot, const uint8_t *lt,
+JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *lt,
                              jda_seg_sum &S, jda_seg_stats &ST)
 {
     const bool CNT = OP == JDA_SEG_COUNT || OP == JDA_SEG_FUSED;      // the segment's sums are wanted
@@ -1189,15 +1212,19 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
     uint32_t p = entry & 63u, b = (entry >> 6) & 7u, k = (entry >> 9) & 63u;
-    // per component: LDS offsets of its DC16 / AC short / AC long table (ids are 0 or 1)
+    // per component: LDS offsets of its DC16 / AC table (ids are 0 or 1)
     const uint32_t dcb0 = JDA_LT_DC16 + P.dc_id[0] * 512u, dcb1 = JDA_LT_DC16 + P.dc_id[1] * 512u, dcb2 = JDA_LT_DC16 + P.dc_id[2] * 512u;
     const uint32_t acb0 = JDA_LT_AC + P.ac_id[0] * 4096u, acb1 = JDA_LT_AC + P.ac_id[1] * 4096u, acb2 = JDA_LT_AC + P.ac_id[2] * 4096u;
+    const uint32_t nluma = P.nluma, nblocks = P.nblocks;
     // WRITE: the reference reader (pBuf, ulBitOff), the block ordinal and the DC predictors at the entry
     uint32_t pos = 0, off = 0, g = 0, pos_pre = 0, off_pre = 0;
     int32_t pred0 = 0, pred1 = 0, pred2 = 0;
     const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 8;
     uint32_t U = 0;                                                 // COUNT: the six byte lags
     const uint32_t kOnes = 0x02108421u, kGuard = 0x21084210u;       // 1 / 16 in each 5-bit field
+    uint32_t nblk = 0, sbad = 0;
+    int32_t ds0 = 0, ds1 = 0, ds2 = 0;
+    uint32_t max_ac = 0, max_dc = 0;
     if (OP == JDA_SEG_WRITE) {
         const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)seg * 5;
         g = st[0]; pred0 = (int32_t)st[1]; pred1 = (int32_t)st[2]; pred2 = (int32_t)st[3];
@@ -1207,98 +1234,108 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     }
     if (CNT) U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);
     uint32_t pend = 0, pend_g = 0;                                  // WRITE: index entry of the block in progress (if it began here)
-    bool pending = false, bad = false;
-    while (p < JDA_SEG_BITS) {
-        const bool isdc = k == 0;
-        const uint32_t c = b < P.nluma ? 0u : b - P.nluma + 1u;
-        if (OP == JDA_SEG_WRITE && isdc) {                          // a block starts here (jpeg.inl:2129-2165)
-            if (g >= P.n_blocks_total) {                            // past the image: the reader as the last block left it closes the index
+    bool pending = false, bad = false, stop = false;                // stop: leave the loop after this step (one exit test per step)
+    jda_seg_reader R;
+    jda_seg_reader_init(R, segw, p);
+    while ((p < JDA_SEG_BITS) & !stop) {
+        const bool isdc0 = k == 0;
+        const uint32_t c = b < nluma ? 0u : b - nluma + 1u;
+        if (OP == JDA_SEG_WRITE) {                                  // a block starts here (jpeg.inl:2129-2165): by selects, but for the two stores
+            const bool term = isdc0 & (g >= P.n_blocks_total);      // past the image: the reader as the last block left it closes the index
+            const bool begin = isdc0 & !term;
+            if (term) {
                 if (g == P.n_blocks_total) { JDA_G(uint32_t, P.blk_index)[g] = (pos_pre << JDA_INDEX_OFF_BITS) | off_pre; ST.terminal = 1; }
-                break;
             }
             const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-            if (pr < -32768 || pr > 32767) { bad = true; break; }
+            const bool out_of_range = begin & ((pr < -32768) | (pr > 32767));
+            bad |= out_of_range; stop |= out_of_range | term;
 #if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 1))
-            JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
+            if (begin) JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
 #endif
-            pend = (pos << JDA_INDEX_OFF_BITS) | off; pend_g = g; pending = true;       // the reader after the block's opening refill
-            g++;
+            pend = begin ? (pos << JDA_INDEX_OFF_BITS) | off : pend;       // the reader after the block's opening refill
+            pend_g = begin ? g : pend_g;
+            pending = pending | begin;
+            g += begin ? 1u : 0u;
         }
-        if (CNT && isdc && !S.bad) S.nblk++;
-        const uint32_t w = jda_seg_fetch(slot, p);
-        // one 16-bit lookup: the DC16 table by the top 6 / 7 bits, or the short / long AC table by the top 10 / the next 10
+        const uint32_t w = jda_seg_reader_peek(R, p);
+        // one 16-bit lookup: the DC16 table by the top 6 / 7 bits, or the AC table by an 11-bit key (short / long half)
         const uint32_t dcb = c == 0 ? dcb0 : (c == 1 ? dcb1 : dcb2), acb = c == 0 ? acb0 : (c == 1 ? acb1 : acb2);
         const uint32_t code12 = w >> 20;
         const uint32_t a_dc = dcb + 2u * (code12 >= 0xf80u ? (code12 & 0xffu) : (w >> 26));
         const uint32_t a_ac = acb + 2u * jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
-        const uint32_t e = *(const uint16_t *)(lt + (isdc ? a_dc : a_ac));
+        const uint32_t e = *(const uint16_t *)(lt + (isdc0 ? a_dc : a_ac));
         const uint32_t elow = e & 0xffu;
-        if (elow == JDA_AC_NONE) {                                  // no such code  (:2137-2138, :2237-2238)
-            // a speculative walk that is not on the decoder's path yet may meet anything: step on one bit and keep looking
-            // (a walk that gave up would hand "dead" down the chain of segments, one per round)
-            if (TOL) { p += 1; k = 0; if (CNT) S.bad = 1; continue; }
-            bad = true; break;
-        }
-        const bool eob = elow == JDA_AC_EOB;
-        const uint32_t len = (e >> 12) + 1u, sz = eob ? 0u : (e >> 8) & 15u;
+        // no such code (:2137-2138, :2237-2238).  A speculative walk that is not on the decoder's path yet may meet anything: it steps
+        // on one bit and keeps looking (a walk that gave up would hand "dead" down the chain of segments, one per round) -- a
+        // one-bit symbol without effects, by selects; the other passes stop.
+        const bool inval = elow == JDA_AC_NONE;
+        if (TOL) sbad |= inval ? 1u : 0u; else { bad |= inval; stop |= inval; }
+        const bool live = !inval & !stop;                           // the step's effects count
+        const bool isdc = isdc0 & live;
+        const bool eob = (elow == JDA_AC_EOB) & !inval;
+        const uint32_t len = inval ? 1u : (e >> 12) + 1u, sz = (eob | inval) ? 0u : (e >> 8) & 15u;
         const uint32_t kk = k + ((e >> 1) & 15u);                   // (DC: + 0)
-        const bool fold = isdc && (e & 1u);
-        // ---- the reader(s) over the code bits
-        const uint32_t by1 = ((p & 7u) + len) >> 3;                 // whole bytes the code bits advance the stream position by
+        const bool dcmag = isdc & (sz != 0u) & ((e & 1u) == 0u);    // a DC magnitude the reference refills for (not folded into the LUT entry)
+        const bool acmag = !isdc0 & live & (sz != 0u) & (kk < 64u); // an AC magnitude that is stored
         const uint32_t p1 = p + len;
-        const uint32_t by2 = ((p1 & 7u) + sz) >> 3;
         if (OP == JDA_SEG_WRITE) {
             off += len;
-            if (isdc && sz && !fold && off > 47u) { pos += off >> 3; off &= 7u; if (pos > limit_pos) { bad = true; break; } }      // :2149-2154
-            if (!isdc && sz) {
-                if (kk < 64u && off + sz > 64u) {                   // the magnitude read runs out of the window
-                    ST.trunc_events++;
-                    if (pending) pend |= JDA_INDEX_TRUNC;           // the block began in this segment: its entry is still here
-                    else jda_atomic_or_u32(P.blk_index + (g - 1u), JDA_INDEX_TRUNC);
-                }
-                if (sz > ST.max_ac_bits && kk < 64u) ST.max_ac_bits = sz;
+            const bool r1 = dcmag & (off > 47u);                    // :2149-2154
+            pos += r1 ? off >> 3 : 0u; off = r1 ? off & 7u : off;
+            if (acmag && off + sz > 64u) {                          // the magnitude read runs out of the window (rare)
+                ST.trunc_events++;
+                if (pending) pend |= JDA_INDEX_TRUNC;               // the block began in this segment: its entry is still here
+                else jda_atomic_or_u32(P.blk_index + (g - 1u), JDA_INDEX_TRUNC);
             }
+            const uint32_t m = acmag ? sz : 0u;
+            max_ac = m > max_ac ? m : max_ac;
             off += sz;
         }
         if (CNT) {
-            U += by1 * kOnes;
-            if (isdc && sz && !fold) {                               // the refill before an unfolded DC magnitude
-                const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
-                U &= ~(f - (f >> 4));
-            }
-            U += by2 * kOnes;
+            nblk += (isdc & (sbad == 0u)) ? 1u : 0u;
+            U += (((p & 7u) + len) >> 3) * kOnes;                   // whole bytes the code bits advance the stream position by
+            const uint32_t f1 = ((U | kGuard) - 6u * kOnes) & kGuard;
+            U &= dcmag ? ~(f1 - (f1 >> 4)) : 0xffffffffu;           // the refill before an unfolded DC magnitude
+            U += (((p1 & 7u) + sz) >> 3) * kOnes;
         }
-        if (isdc && (CNT || OP == JDA_SEG_WRITE)) {                 // the DC difference (:2155-2165; a folded entry holds the same value)
-            const int32_t diff = sz ? jda_extend_top(w << len, sz) : 0;
-            if (CNT && !S.bad) { if (c == 0) S.dcsum[0] += diff; else if (c == 1) S.dcsum[1] += diff; else S.dcsum[2] += diff; }
+        if (CNT || OP == JDA_SEG_WRITE) {                           // the DC difference (:2155-2165; a folded entry holds the same value)
+            const int32_t diff = (isdc & (sz != 0u)) ? jda_extend_top(w << len, sz) : 0;
+            const int32_t d0 = c == 0 ? diff : 0, d1 = c == 1 ? diff : 0, d2 = c >= 2 ? diff : 0;
+            if (CNT) { const int32_t gate = sbad ? 0 : -1; ds0 += d0 & gate; ds1 += d1 & gate; ds2 += d2 & gate; }
             if (OP == JDA_SEG_WRITE) {
-                int32_t pr;
-                if (c == 0) pr = pred0 += diff; else if (c == 1) pr = pred1 += diff; else pr = pred2 += diff;
-                const uint32_t a = (uint32_t)(pr < 0 ? -pr : pr);
-                if (a > ST.max_abs_dc) ST.max_abs_dc = a;
+                pred0 += d0; pred1 += d1; pred2 += d2;
+                const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+                const uint32_t a = isdc ? (uint32_t)(pr < 0 ? -pr : pr) : 0u;
+                max_dc = a > max_dc ? a : max_dc;
             }
         }
         p = p1 + sz;
         // ---- the refill at the end of the step (not after EOB in the reference -- there it is the next block's opening one)
         if (OP == JDA_SEG_WRITE) {
-            pos_pre = pos; off_pre = off;                           // (what closes the index if this was the image's last symbol and an EOB)
-            if (off > 47u) { pos += off >> 3; off &= 7u; if (pos > limit_pos) { bad = true; break; } }
-            if (!eob) { pos_pre = pos; off_pre = off; }             // a block that ends on its 63rd coefficient has had its bottom refill
+            const bool r2 = off > 47u;
+            const uint32_t npos = pos + (r2 ? off >> 3 : 0u), noff = r2 ? off & 7u : off;
+            // what closes the index if this was the image's last symbol: the reader before the refill after an EOB (the reference has
+            // not refilled yet), after it otherwise (a block that ends on its 63rd coefficient has had its bottom refill)
+            pos_pre = eob ? pos : npos; off_pre = eob ? off : noff;
+            pos = npos; off = noff;
+            const bool over = pos > limit_pos;                      // the stream ran out: the serial pre-scan knows what the reference does then
+            bad |= over; stop |= over;
         }
         if (CNT) {
             const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
             U &= ~(f - (f >> 4));
         }
-        const bool ends = eob || kk + 1u >= 64u;
-        k = ends ? 0u : kk + 1u;
-        if (ends) {
-            b = b + 1u == P.nblocks ? 0u : b + 1u;
+        const bool ends = (eob | (kk + 1u >= 64u)) & !inval;
+        k = (ends | inval) ? 0u : kk + 1u;
+        const uint32_t bn = b + 1u == nblocks ? 0u : b + 1u;
+        b = ends ? bn : b;
 #if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 2))
-            if (OP == JDA_SEG_WRITE && pending) { JDA_G(uint32_t, P.blk_index)[pend_g] = pend; pending = false; }
+        if (OP == JDA_SEG_WRITE && ends && pending) { JDA_G(uint32_t, P.blk_index)[pend_g] = pend; pending = false; }
 #endif
-        }
     }
     if (OP == JDA_SEG_WRITE && pending && !bad) jda_atomic_or_u32(P.blk_index + pend_g, pend);      // the block goes on in the next segment
+    if (OP == JDA_SEG_WRITE) { ST.max_ac_bits = max_ac; ST.max_abs_dc = max_dc; }
+    S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2; S.bad = sbad;
     if (bad) { S.bad = 1; ST.bad = 1; return JDA_SEG_DEAD; }
     if (CNT) {
         uint32_t map = 0;

@@ -496,23 +496,19 @@ extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint3
 // lane per 256-byte segment of the filtered scan, a wavefront's 64 consecutive segments staged in LDS with one
 // coalesced copy (268-byte slots: a lane's reads run a few bytes into the next segment; the odd dword stride keeps
 // the lanes on different banks), four wavefronts per workgroup around one copy of the tables.
-#define JDA_SEG_WAVE_LDS (64u * JDA_SEG_SLOT)
-
 template <int OP>
 __global__ __launch_bounds__(256)
 void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t seg0 = (blockIdx.x * 4u + wave) * 64u, seg = seg0 + lane;
+    const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
     if (blockIdx.x * 256u >= P.n_segs) return;                       // (uniform per workgroup: images of a batch differ in size)
     // a speculative round after one that changed nothing has nothing to do (the host launches a fixed number of rounds when it
-    // does not want to look at the counters in between: jda_pipeline)
+    // does not want to look at the counters in between)
     if (OP == JDA_SEG_SPEC && round >= 1 && JDA_G(const uint32_t, P.stats)[8u + round - 1u] == 0u) return;
     uint8_t *tab = lds;
-    uint8_t *slots = lds + JDA_LT_WALK_BYTES + wave * JDA_SEG_WAVE_LDS;
-    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true, true);       // with the long halves of the AC LUTs (see jda_lds_layout) and the walk's DC table
+    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true, true);       // the tables (with the walk's DC table) are all that is staged
     const bool in_range = seg < P.n_segs;
     // what this lane has to do
     uint32_t *e_cur = (round & 1u) ? P.entry_nxt : P.entry_cur, *e_nxt = (round & 1u) ? P.entry_cur : P.entry_nxt;
@@ -522,19 +518,9 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
         if (in_range) { entry = e_cur[seg]; need = round == 0 || (entry & JDA_SEG_CHANGED) != 0; }
     } else if (in_range) entry = ((round & 1u) ? P.entry_nxt : P.entry_cur)[seg];
     if (OP == JDA_SEG_WRITE && in_range && P.seg_start[(size_t)seg * 5] > P.n_blocks_total) need = false;   // past the image
-    const bool wave_works = __builtin_amdgcn_ballot_w64(need) != 0;
-    if (wave_works) {                                                // the wavefront's 64 segments -> LDS
-        const uint32_t JDA_GLOBAL *src = JDA_G(const uint32_t, P.scan);
-        for (uint32_t t = lane; t < 64u * (JDA_SEG_SLOT / 4u); t += 64u) {
-            const uint32_t sl = t / (JDA_SEG_SLOT / 4u), w = t - sl * (JDA_SEG_SLOT / 4u);
-            uint32_t v = 0;
-            if (seg0 + sl < P.n_segs) v = src[(size_t)(seg0 + sl) * (JDA_SEG_BYTES / 4u) + w];
-            *(jda_u32_alias *)(slots + sl * JDA_SEG_SLOT + w * 4u) = jda_seg_stage_word(v);
-        }
-    }
-    __syncthreads();                                                 // tables and slots are in LDS
+    __syncthreads();                                                 // the tables are in LDS
     if (!in_range) return;
-    const uint8_t *slot = slots + lane * JDA_SEG_SLOT;
+    const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
     jda_seg_sum S;
     jda_seg_stats ST;
     ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0;
@@ -542,18 +528,18 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
         const uint32_t old = e_cur[seg + 1] & ~JDA_SEG_CHANGED;
         uint32_t out = old;
         if (need) {
-            const uint32_t x = jda_seg_walk<JDA_SEG_SPEC>(P, seg, entry & ~JDA_SEG_CHANGED, slot, tab, S, ST) & ~JDA_SEG_CHANGED;
+            const uint32_t x = jda_seg_walk<JDA_SEG_SPEC>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST) & ~JDA_SEG_CHANGED;
             out = x;
             if (x != old) { out |= JDA_SEG_CHANGED; atomicAdd(&P.stats[8 + round], 1u); }
         }
         e_nxt[seg + 1] = out;
         if (seg == 0) e_nxt[0] = 0;                                  // the scan starts at a block start (jpeg.inl:4996-4998)
     } else if (OP == JDA_SEG_COUNT) {
-        (void)jda_seg_walk<JDA_SEG_COUNT>(P, seg, entry & ~JDA_SEG_CHANGED, slot, tab, S, ST);
+        (void)jda_seg_walk<JDA_SEG_COUNT>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
         uint32_t *o = P.seg_sum + (size_t)seg * 6;
         o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
     } else if (need) {
-        (void)jda_seg_walk<JDA_SEG_WRITE>(P, seg, entry & ~JDA_SEG_CHANGED, slot, tab, S, ST);
+        (void)jda_seg_walk<JDA_SEG_WRITE>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
         if (ST.bad) atomicOr(&P.stats[0], 1u);
         if (ST.terminal) atomicAdd(&P.stats[1], 1u);
         if (ST.max_ac_bits) atomicMax(&P.stats[2], ST.max_ac_bits);
@@ -588,50 +574,36 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
     uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
     uint8_t *tab = lds;
-    uint8_t *slots = lds + JDA_LT_WALK_BYTES + wave * JDA_SEG_WAVE_LDS;
     jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true, true);
-    __syncthreads();                                                 // the tables; the slots below are a wavefront's own
-    const uint32_t JDA_GLOBAL *src = JDA_G(const uint32_t, P.scan);
+    __syncthreads();                                                 // the tables: all that is staged (a walk reads its segment from memory)
     for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < count; base += gridDim.x * 256u) {
         const uint32_t item = base + lane;
-        const bool have = item < count;
-        const uint32_t seg = !have ? 0xffffffffu : (all ? item : wl_in[item]);
-        // the wavefront's 64 segments -> its LDS slots (slot sl = the segment of lane sl)
-        for (uint32_t t = lane; t < 64u * (JDA_SEG_SLOT / 4u); t += 64u) {
-            const uint32_t sl = t / (JDA_SEG_SLOT / 4u), w = t - sl * (JDA_SEG_SLOT / 4u);
-            const uint32_t sg = all ? base + sl : (uint32_t)__shfl((int)seg, (int)sl);
-            uint32_t v = 0;
-            if (sg < P.n_segs) v = src[(size_t)sg * (JDA_SEG_BYTES / 4u) + w];
-            *(jda_u32_alias *)(slots + sl * JDA_SEG_SLOT + w * 4u) = jda_seg_stage_word(v);
+        if (item >= count) continue;
+        const uint32_t seg = all ? item : wl_in[item];
+        jda_seg_sum S;
+        jda_seg_stats ST;
+        ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0;
+        const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];   // the scan starts at a block start (jpeg.inl:4996-4998)
+        const uint32_t x = jda_seg_walk<OP>(P, seg, entry, JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u), tab, S, ST);
+        if (OP == JDA_SEG_FUSED) {
+            uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
+            o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
         }
-        JDA_WAVE_SYNC();
-        if (have) {
-            jda_seg_sum S;
-            jda_seg_stats ST;
-            ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0;
-            const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];   // the scan starts at a block start (jpeg.inl:4996-4998)
-            const uint32_t x = jda_seg_walk<OP>(P, seg, entry, slots + lane * JDA_SEG_SLOT, tab, S, ST);
-            if (OP == JDA_SEG_FUSED) {
-                uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
-                o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
-            }
-            if (seg + 1u < P.n_segs) {
-                if (round == 0) E[seg + 1u] = x;                     // (nobody reads the entry states in round 0)
-                else if (x != E[seg + 1u]) {
-                    E[seg + 1u] = x;
-                    const uint32_t at = atomicAdd(&P.stats[8u + round + 1u], 1u);
-                    if (at < P.worklist_cap) wl_out[at] = seg + 1u;
-                }
+        if (seg + 1u < P.n_segs) {
+            if (round == 0) E[seg + 1u] = x;                         // (nobody reads the entry states in round 0)
+            else if (x != E[seg + 1u]) {
+                E[seg + 1u] = x;
+                const uint32_t at = atomicAdd(&P.stats[8u + round + 1u], 1u);
+                if (at < P.worklist_cap) wl_out[at] = seg + 1u;
             }
         }
-        JDA_WAVE_SYNC();                                             // the slots are rewritten by the next step
     }
 }
 
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_LT_WALK_BYTES + 4 * JDA_SEG_WAVE_LDS;
+    const int lds_bytes = JDA_LT_WALK_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -722,7 +694,7 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_LT_WALK_BYTES + 4 * JDA_SEG_WAVE_LDS;          // 80,160 B: two workgroups per CU
+    const int lds_bytes = JDA_LT_WALK_BYTES;          // the tables only: 11.5 KB per workgroup
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -445,9 +445,11 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
             S.st.h2d_bytes += im.f.raw_len;
         }
         S.st.h2d_bytes += (int64_t)S.ctl_bytes;
+        // the marker filter rides on the copy stream: one workgroup per image keeps a quarter of the CUs busy for a millisecond, which
+        // the previous batch's pre-scan (11.5 KB of LDS per workgroup) leaves room for
+        if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), p->s_copy);
         if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->s_up, S.ev_copy, 0);
-        if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), p->s_up);
         if (e == hipSuccess && !int_ix.empty()) {
             const jda_prescan_params *dp = (const jda_prescan_params *)(B + off_pparams);
             e = jda_launch_prescan(dp, (uint32_t)int_ix.size(), max_int, 0, p->s_up);                                  // MAP

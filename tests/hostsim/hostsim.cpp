@@ -90,9 +90,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         std::vector<uint64_t> lt_store((JDA_LT_WALK_BYTES + 7) / 8);
         uint8_t *lt = (uint8_t *)lt_store.data();
         for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables_from(tables, tid, 256, lt, true, true);
-        // the kernels stage a segment as byte-swapped dwords (jda_seg_stage_word)
-        std::vector<uint32_t> staged(padded.size());
-        for (size_t q = 0; q < padded.size(); q++) staged[q] = jda_seg_stage_word(padded[q]);
+
         std::vector<uint32_t> ea(n_segs + 1, 0), eb(n_segs + 1, 0), seg_sum((size_t)n_segs * 6), seg_start((size_t)n_segs * 5, 0);
         jda_segscan_params P;
         memset(&P, 0, sizeof(P));
@@ -117,7 +115,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 const uint32_t old = cur[seg + 1] & ~JDA_SEG_CHANGED;
                 uint32_t out = old;
                 if (need) {
-                    const uint8_t *slot = (const uint8_t *)staged.data() + (size_t)seg * JDA_SEG_BYTES;
+                    const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
                     const uint32_t x = jda_seg_walk<JDA_SEG_SPEC>(P, seg, entry & ~JDA_SEG_CHANGED, slot, lt, S, ST) & ~JDA_SEG_CHANGED;
                     out = x;
                     if (x != old) { out |= JDA_SEG_CHANGED; changed++; }
@@ -136,7 +134,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             uint32_t *c2 = a.data(), *n2 = b2.data();
             for (uint32_t r = 0; r < 12; r++) {
                 for (uint32_t seg = 0; seg < n_segs; seg++) {
-                    const uint8_t *slot = (const uint8_t *)staged.data() + (size_t)seg * JDA_SEG_BYTES;
+                    const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
                     n2[seg + 1] = jda_seg_walk<JDA_SEG_SPEC>(P, seg, c2[seg], slot, lt, S, ST);
                 }
                 n2[0] = 0;
@@ -148,7 +146,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         }
         memset(&ST, 0, sizeof(ST));
         for (uint32_t seg = 0; seg < n_segs; seg++) {           // COUNT
-            const uint8_t *slot = (const uint8_t *)staged.data() + (size_t)seg * JDA_SEG_BYTES;
+            const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
             (void)jda_seg_walk<JDA_SEG_COUNT>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST);
             uint32_t *o = &seg_sum[(size_t)seg * 6];
             o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
@@ -177,7 +175,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         uint32_t terminal = 0;
         for (uint32_t seg = 0; seg < n_segs; seg++) {           // WRITE
             if (seg_start[(size_t)seg * 5] > P.n_blocks_total) continue;
-            const uint8_t *slot = (const uint8_t *)staged.data() + (size_t)seg * JDA_SEG_BYTES;
+            const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
             jda_seg_stats T1;
             memset(&T1, 0, sizeof(T1));
             (void)jda_seg_walk<JDA_SEG_WRITE>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1);
