@@ -275,7 +275,7 @@ def run(args, J, out=sys.stdout):
             base = surf[k % depth]
             return pipe.submit(files, [(base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(eb)], [pt] * eb, [args.options] * eb)
 
-        inflight, t_submit, warm = [], 0.0, 2
+        inflight, t_submit, warm = [], 0.0, max(2, depth)
         tb0 = 0.0
         for k in range(warm + args.e2e_batches):
             if k == warm:

@@ -144,7 +144,7 @@ struct jda_pipeline {
         hipEvent_t ev_copy, ev_up, ev_dec;
         std::vector<Img> imgs;
         std::vector<const uint8_t *> jpegs; std::vector<int32_t> lens, pts, opts; std::vector<jda_output> outs;
-        size_t ctl_bytes, off_stats_dev, stats_bytes;
+        size_t ctl_bytes, off_stats_dev, stats_bytes, pin_stats;
         size_t list_off[JDA_N_LISTS]; uint32_t list_n[JDA_N_LISTS];
         size_t off_descs;
         jda_pipeline_stats st;
@@ -313,6 +313,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     S.ctl_bytes = a256(ctl);
     arena = S.ctl_bytes;
     for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_raw = take(a16(im.f.raw_len) + 16); }
+    const size_t raw_end = arena;                             // [0, raw_end) = control blob + unfiltered scans: one H2D copy from the page-locked mirror
     for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_dc = take((size_t)im.n_blocks * 2); }
     for (int i = 0; i < n; i++) {
         Img &im = S.imgs[(size_t)i];
@@ -348,9 +349,11 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     const size_t zero_end = arena;
     arena += 8192;                                            // slack: readers run a few hundred bytes past a (corrupt) scan
 
-    if (S.pin_cap < S.ctl_bytes + S.stats_bytes + 256) {     // (the strips did not fit: grow, keeping the tables)
+    S.pin_stats = a256(raw_end);                              // the read-back of the result words sits behind the mirror
+    const size_t pin_stats = S.pin_stats;
+    if (S.pin_cap < pin_stats + S.stats_bytes + 256) {        // (strips and scans did not fit: grow, keeping the tables)
         uint8_t *np = NULL;
-        const size_t want = a256((S.ctl_bytes + S.stats_bytes) * 3 / 2 + ((size_t)1 << 20));
+        const size_t want = a256((pin_stats + S.stats_bytes) * 5 / 4 + ((size_t)1 << 20));
         if (hipHostMalloc((void **)&np, want, hipHostMallocDefault) != hipSuccess) return JDA_ERROR_MEMORY;
         memcpy(np, S.pin, off_fparams);
         (void)hipHostFree(S.pin);
@@ -430,6 +433,9 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         const Img &im = S.imgs[(size_t)i];
         const jda_dev_desc &D = descs[(size_t)i];
         fill_strips((jda_strip *)(S.pin + S.list_off[im.list]) + im.strip_off, im.n_tiles, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, im.ord);
+        // the file's entropy-coded bytes into the page-locked mirror (the workers' memcpy is the only time the host touches them):
+        // the whole batch then travels as ONE asynchronous copy instead of a blocking pageable copy per file
+        memcpy(S.pin + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len);
     });
 
     // ---- enqueue: upload stream
@@ -437,14 +443,8 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     uint8_t *B = S.dev;
     if (n_dev) {
         e = hipMemsetAsync(B + zero_begin, 0, zero_end - zero_begin, p->s_copy);
-        if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, S.ctl_bytes, hipMemcpyHostToDevice, p->s_copy);
-        for (size_t k = 0; k < dev_ix.size() && e == hipSuccess; k++) {
-            const int i = dev_ix[k];
-            const Img &im = S.imgs[(size_t)i];
-            e = hipMemcpyAsync(B + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len, hipMemcpyHostToDevice, p->s_copy);
-            S.st.h2d_bytes += im.f.raw_len;
-        }
-        S.st.h2d_bytes += (int64_t)S.ctl_bytes;
+        if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, raw_end, hipMemcpyHostToDevice, p->s_copy);      // control blob + every file's scan
+        S.st.h2d_bytes += (int64_t)raw_end;
         // the marker filter rides on the copy stream: one workgroup per image keeps a quarter of the CUs busy for a millisecond, which
         // the previous batch's pre-scan (11.5 KB of LDS per workgroup) leaves room for
         if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), p->s_copy);
@@ -464,7 +464,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
             if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, p->s_up);
             if (e == hipSuccess) e = jda_launch_segscan(dp, ns, max_segs, JDA_SEG_WRITE, 0, p->s_up);
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.ctl_bytes, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, p->s_up);
+        if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.pin_stats, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, p->s_up);
     }
     if (e == hipSuccess) e = hipEventRecord(S.ev_up, p->s_up);
     // ---- enqueue: decode stream
@@ -535,7 +535,7 @@ int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status)
         if (st == JDA_SUCCESS) {
             bool redo = !im.device;
             if (im.device) {
-                const uint32_t *rb = (const uint32_t *)(S.pin + S.ctl_bytes + (im.off_stats - S.off_stats_dev));
+                const uint32_t *rb = (const uint32_t *)(S.pin + S.pin_stats + (im.off_stats - S.off_stats_dev));
                 const uint32_t *ps = rb + 4;
                 uint32_t max_ac = 0, max_dc = 0;
                 bool ok;
@@ -585,7 +585,7 @@ int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t
     hipError_t e = hipSuccess;
     if (index) e = hipMemcpy(index, S.dev + im.off_index, ((size_t)im.n_blocks + 1) * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && dc) e = hipMemcpy(dc, S.dev + im.off_dc, (size_t)im.n_blocks * 2, hipMemcpyDeviceToHost);
-    if (filtered_len) *filtered_len = ((const uint32_t *)(S.pin + S.ctl_bytes + (im.off_stats - S.off_stats_dev)))[0];
+    if (filtered_len) *filtered_len = ((const uint32_t *)(S.pin + S.pin_stats + (im.off_stats - S.off_stats_dev)))[0];
     return e == hipSuccess ? JDA_SUCCESS : jda_set_err(p->ctx, e, "jda_pipeline_read_index");
 }
 

@@ -13,7 +13,8 @@ import jpegdec_amd as J  # noqa: E402
 from bench import cached_jpeg  # noqa: E402
 
 
-def run(ctx, jpegs, batch, batches, depth, threads, pt=J.RGB8888, opt=0, warm=2):
+def run(ctx, jpegs, batch, batches, depth, threads, pt=J.RGB8888, opt=0, warm=0):
+    warm = max(warm, depth, 2)          # every slot has grown its arena and page-locked buffer before the clock starts
     info = J.PreparedImage(jpegs[0])
     g = info.geometry(pt, opt)
     info.close()
