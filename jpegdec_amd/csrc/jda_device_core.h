@@ -508,128 +508,12 @@ struct jda_prescan_params {
 };
 struct jda_prescan_result { uint32_t first_bad, mismatch, max_ac_bits, max_abs_dc, trunc_events, phase_map; };
 
-// six bit offsets, one per byte: refill (jpeg.inl:2110-2114) and advance
-JDA_HD uint64_t jda_ph_refill(uint64_t x)
-{
-    const uint64_t K = 0x010101010101ull;
-    const uint64_t ge48 = ((x + (0x80u - 48u) * K) & (0x80u * K)) >> 7;   // offsets stay below 128: no carry between bytes
-    const uint64_t m = ge48 * 0xffu;
-    return (x & ~m) | (x & m & (0x07u * K));
-}
-
-// lds_tables: the table blob staged in LDS by the caller's workgroup (GPU), or NULL to read P.tables from memory
+// lt: the tables in the kernels' LDS layout + JDA_LT_DC16 (jda_p0_tables_from(.., true, true)), staged by the caller's workgroup.
+// The walk is jda_seg_walk's unified step (one symbol, DC or AC alike, by selects; see there) over a whole interval, bounded by
+// its MCU count instead of a bit length, from a known decoder state; the interval's LAST symbol is not followed by a refill (the
+// reference rounds ulBitOff up without one, :5339-5346), every other step ends with one.
 template <bool EXACT>
-JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k, const uint8_t *lds_tables = nullptr)
-{
-    jda_prescan_result R;
-    R.first_bad = 0xffffffffu; R.mismatch = 0; R.max_ac_bits = 0; R.max_abs_dc = 0; R.trunc_events = 0; R.phase_map = 0;
-    const uint8_t JDA_GLOBAL *tables = JDA_G(const uint8_t, P.tables);
-    const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
-    uint32_t JDA_GLOBAL *blk_index = JDA_G(uint32_t, P.blk_index);
-    int16_t JDA_GLOBAL *blk_dc = JDA_G(int16_t, P.blk_dc);
-    const uint32_t start_off = EXACT ? (uint32_t)JDA_G(const uint8_t, P.start_phase)[k] : 0u;
-    jda_bitreader br;
-    br.base = JDA_G(const uint8_t, P.scan);
-    br.win = nullptr; br.win_lo = 0; br.win_len = 0;            // no LDS window: every load goes to memory
-    br.pos = rpos[k] - (start_off >> 3);
-    br.off = start_off;
-    br.bits = jda_load_be64(br, br.pos);
-    const uint64_t K = 0x010101010101ull;
-    uint64_t ph = 0x282018100800ull;                             // MAP: the offsets 0, 8, .., 40
-    const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 8;
-    const uint32_t first_mcu = k * P.interval_mcus;
-    const uint32_t count = P.n_mcus - first_mcu < P.interval_mcus ? P.n_mcus - first_mcu : P.interval_mcus;
-    int32_t pred[3] = { 0, 0, 0 };
-    bool bad = false;
-    uint32_t m = 0;
-#define JDA_PS_REFILL() do { jda_refill(br); if (!EXACT) ph = jda_ph_refill(ph); if (br.pos > limit_pos) bad = true; } while (0)
-#define JDA_PS_ADVANCE(n) do { br.off += (n); if (!EXACT) ph += (uint64_t)(n) * K; } while (0)
-    for (; m < count && !bad; m++) {
-        for (uint32_t b = 0; b < P.nblocks && !bad; b++) {
-            const uint32_t c = b < P.nluma ? 0u : b - P.nluma + 1u;
-            int32_t &pr = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
-            if (pr < -32768 || pr > 32767) { bad = true; break; }
-            const size_t gb = (size_t)(first_mcu + m) * P.nblocks + b;
-            const uint32_t dci = c == 0 ? P.dc_id[0] : (c == 1 ? P.dc_id[1] : P.dc_id[2]);
-            const uint32_t aci = c == 0 ? P.ac_id[0] : (c == 1 ? P.ac_id[1] : P.ac_id[2]);
-            const uint32_t dc_off = JDA_TB_DC + dci * 1024, ac_off = JDA_TB_AC + aci * 4096;
-#define JDA_PS_TAB8(o) (lds_tables ? (uint32_t)lds_tables[o] : (uint32_t)tables[o])
-#define JDA_PS_TAB16(o) (lds_tables ? (uint32_t)*(const uint16_t *)(lds_tables + (o)) : (uint32_t)*(const uint16_t JDA_GLOBAL *)(tables + (o)))
-            JDA_PS_REFILL();
-            if (bad) break;
-            uint32_t entry = (br.pos << JDA_INDEX_OFF_BITS) | br.off;      // the reader after the block's opening refill
-            if (EXACT) { blk_index[gb] = entry; blk_dc[gb] = (int16_t)pr; }
-            uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
-            code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
-            uint32_t e = JDA_PS_TAB8(dc_off + code);
-            if (e == 0) { bad = true; break; }                   // :2137-2138
-            JDA_PS_ADVANCE(e >> 4);
-            const uint32_t s = e & 0xfu;
-            if (s) {
-                const int32_t folded = (int8_t)JDA_PS_TAB8(dc_off + code + 512);
-                if (folded) pr += folded;
-                else {
-                    JDA_PS_REFILL();
-                    if (bad) break;
-                    pr += jda_take_extend(br.bits, br.off, s);
-                    JDA_PS_ADVANCE(s);
-                }
-            }
-            { const uint32_t a = (uint32_t)(pr < 0 ? -pr : pr); if (a > R.max_abs_dc) R.max_abs_dc = a; }
-            int kk = 1;
-            while (kk < 64) {
-                JDA_PS_REFILL();
-                if (bad) break;
-                code = (uint32_t)(br.bits >> (48 - br.off)) & 0xffffu;
-                code = code >= 0xfc00u ? ((code & 0x3ffu) + 1024u) : (code >> 6);
-                e = JDA_PS_TAB16(ac_off + code * 2);
-                if (e == 0) { bad = true; break; }               // :2237-2238
-                JDA_PS_ADVANCE(e >> 8);
-                e &= 0xffu;
-                if (e == 0) break;                               // EOB (no refill follows)
-                kk += (int)(e >> 4);
-                const uint32_t ms = e & 0xfu;
-                if (ms && kk < 64 && br.off + ms > 64) {
-                    R.trunc_events++;
-                    if (EXACT && !(entry & JDA_INDEX_TRUNC)) { entry |= JDA_INDEX_TRUNC; blk_index[gb] = entry; }
-                }
-                if (ms > R.max_ac_bits && kk < 64) R.max_ac_bits = ms;
-                JDA_PS_ADVANCE(ms);
-                kk++;
-                JDA_PS_REFILL();                                 // :2259-2264 (bottom of the loop; matters before a restart)
-            }
-        }
-        if (bad) break;
-    }
-#undef JDA_PS_REFILL
-#undef JDA_PS_ADVANCE
-#undef JDA_PS_TAB8
-#undef JDA_PS_TAB16
-    if (bad) { R.first_bad = first_mcu + m; return R; }
-    if (!EXACT) {
-        // :5339-5346: round each offset up to a byte: 0, 8, .., 64 (48 and up behave like 0 from the next block's
-        // first refill on, but the recorded phase keeps the reference's own value)
-        uint32_t map = 0;
-        for (int j = 0; j < 6; j++) {
-            uint32_t o = (uint32_t)(ph >> (8 * j)) & 0xffu;
-            o = (o + 7u) & ~7u;
-            map |= (o >> 3) << (4 * j);
-        }
-        R.phase_map = map;
-        return R;
-    }
-    // the interval must end (rounded up to a byte) where the next one starts: the reference counts MCUs and
-    // never looks at marker positions, so a stream whose markers sit elsewhere must take the serial path
-    const uint32_t end_byte = br.pos + ((br.off + 7u) >> 3);
-    if (k + 1 < P.n_intervals) { if (end_byte != rpos[k + 1]) R.mismatch = 1; }
-    else {
-        // the closing entry = the reader as the serial pre-scan leaves it: a restart interval that ends with the image is still
-        // rounded up to a byte (jpeg.inl:5339-5346 runs after the last MCU as well)
-        const uint32_t off_end = count == P.interval_mcus ? ((br.off + 7u) & ~7u) : br.off;
-        blk_index[(size_t)P.n_mcus * P.nblocks] = (br.pos << JDA_INDEX_OFF_BITS) | off_end;
-    }
-    return R;
-}
+JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k, const uint8_t *lt);
 
 // ---- the same, for a tile whose whole scan slice is in the LDS window (the normal case) ----------
 // No lane can leave the window, so the reader needs no bounds check and no HBM path, and the block
@@ -1343,6 +1227,120 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         S.phase_map = map;
     }
     return (p - JDA_SEG_BITS) | (b << 6) | (k << 9);
+}
+
+template <bool EXACT>
+JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k, const uint8_t *lt)
+{
+    jda_prescan_result Rs;
+    Rs.first_bad = 0xffffffffu; Rs.mismatch = 0; Rs.max_ac_bits = 0; Rs.max_abs_dc = 0; Rs.trunc_events = 0; Rs.phase_map = 0;
+    const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
+    const uint32_t first_mcu = k * P.interval_mcus;
+    const uint32_t count = P.n_mcus - first_mcu < P.interval_mcus ? P.n_mcus - first_mcu : P.interval_mcus;
+    const uint32_t nluma = P.nluma, nblocks = P.nblocks, total_blocks = count * nblocks;
+    const uint32_t dcb0 = JDA_LT_DC16 + P.dc_id[0] * 512u, dcb1 = JDA_LT_DC16 + P.dc_id[1] * 512u, dcb2 = JDA_LT_DC16 + P.dc_id[2] * 512u;
+    const uint32_t acb0 = JDA_LT_AC + P.ac_id[0] * 4096u, acb1 = JDA_LT_AC + P.ac_id[1] * 4096u, acb2 = JDA_LT_AC + P.ac_id[2] * 4096u;
+    const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 24;     // (the register window reads up to 16 bytes ahead of the bits in use)
+    const uint32_t kOnes = 0x02108421u, kGuard = 0x21084210u;
+    const uint32_t start = rpos[k];
+    uint32_t p = start << 3;                                        // absolute bit position in the filtered scan (< 2^28)
+    // EXACT: the reference reader; the interval starts with (pBuf, ulBitOff) = (start - j, 8 j)
+    uint32_t pos = 0, off = 0;
+    uint32_t U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);     // MAP: the byte lags of the six start phases
+    if (EXACT) { const uint32_t so = (uint32_t)JDA_G(const uint8_t, P.start_phase)[k]; pos = start - (so >> 3); off = so; }
+    // the interval's first block opens with a refill like any other (the lags 6, 7, 8 of a rounded-up offset join lag 0 here)
+    if (EXACT) { if (off > 47u) { pos += off >> 3; off &= 7u; } }
+    else { const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard; U &= ~(f - (f >> 4)); }
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0;
+    uint32_t b = 0, kz = 0, done = 0, g = first_mcu * nblocks;
+    uint32_t max_ac = 0, max_dc = 0, trunc = 0, pend = 0;
+    bool bad = false, stop = total_blocks == 0;
+    jda_seg_reader R;
+    jda_seg_reader_init(R, JDA_G(const uint32_t, P.scan), p);
+    while (!stop) {
+        const bool isdc = kz == 0;
+        const uint32_t c = b < nluma ? 0u : b - nluma + 1u;
+        if (EXACT && isdc) {                                        // a block starts: its DC predictor, and the reader after its opening refill
+            const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+            const bool oor = (pr < -32768) | (pr > 32767);
+            bad |= oor; stop |= oor;
+            JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
+            pend = (pos << JDA_INDEX_OFF_BITS) | off;
+        }
+        const uint32_t w = jda_seg_reader_peek(R, p);
+        const uint32_t dcb = c == 0 ? dcb0 : (c == 1 ? dcb1 : dcb2), acb = c == 0 ? acb0 : (c == 1 ? acb1 : acb2);
+        const uint32_t code12 = w >> 20;
+        const uint32_t a_dc = dcb + 2u * (code12 >= 0xf80u ? (code12 & 0xffu) : (w >> 26));
+        const uint32_t a_ac = acb + 2u * jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
+        const uint32_t e = *(const uint16_t *)(lt + (isdc ? a_dc : a_ac));
+        const uint32_t elow = e & 0xffu;
+        const bool inval = elow == JDA_AC_NONE;                     // :2137-2138, :2237-2238
+        bad |= inval; stop |= inval;
+        const bool live = !stop;
+        const bool eob = (elow == JDA_AC_EOB) & !inval;
+        const uint32_t len = inval ? 1u : (e >> 12) + 1u, sz = (eob | inval) ? 0u : (e >> 8) & 15u;
+        const uint32_t kk = kz + ((e >> 1) & 15u);
+        const bool dcmag = isdc & live & (sz != 0u) & ((e & 1u) == 0u);
+        const bool acmag = !isdc & live & (sz != 0u) & (kk < 64u);
+        const bool ends = (eob | (kk + 1u >= 64u)) & live;
+        const bool last = eob & live & (done + 1u == total_blocks);  // the interval's last symbol, an EOB: no refill behind it (a block that ends
+                                                                     // on its 63rd coefficient has had the AC loop's bottom refill)
+        const uint32_t p1 = p + len;
+        if (EXACT) {
+            off += len;
+            const bool r1 = dcmag & (off > 47u);                    // :2149-2154
+            pos += r1 ? off >> 3 : 0u; off = r1 ? off & 7u : off;
+            if (acmag && off + sz > 64u) { trunc++; pend |= JDA_INDEX_TRUNC; }
+            const uint32_t m = acmag ? sz : 0u;
+            max_ac = m > max_ac ? m : max_ac;
+            off += sz;
+            const int32_t diff = (isdc & live & (sz != 0u)) ? jda_extend_top(w << len, sz) : 0;
+            pred0 += c == 0 ? diff : 0; pred1 += c == 1 ? diff : 0; pred2 += c >= 2 ? diff : 0;
+            const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+            const uint32_t a = (isdc & live) ? (uint32_t)(pr < 0 ? -pr : pr) : 0u;
+            max_dc = a > max_dc ? a : max_dc;
+            const bool r2 = (off > 47u) & !last;
+            pos += r2 ? off >> 3 : 0u; off = r2 ? off & 7u : off;
+            const bool over = pos > limit_pos;
+            bad |= over; stop |= over;
+            if (ends) JDA_G(uint32_t, P.blk_index)[g] = pend;
+        } else {
+            U += (((p & 7u) + len) >> 3) * kOnes;
+            const uint32_t f1 = ((U | kGuard) - 6u * kOnes) & kGuard;
+            U &= dcmag ? ~(f1 - (f1 >> 4)) : 0xffffffffu;
+            U += (((p1 & 7u) + sz) >> 3) * kOnes;
+            const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
+            U &= last ? 0xffffffffu : ~(f - (f >> 4));
+            if ((p1 >> 3) > limit_pos) { bad = true; stop = true; }
+        }
+        p = p1 + sz;
+        kz = ends ? 0u : kk + 1u;
+        b = ends ? (b + 1u == nblocks ? 0u : b + 1u) : b;
+        g += ends ? 1u : 0u;
+        done += ends ? 1u : 0u;
+        stop |= done == total_blocks;
+    }
+    if (bad) { Rs.first_bad = first_mcu + done / (nblocks ? nblocks : 1u); return Rs; }
+    if (!EXACT) {
+        // :5339-5346: every start phase's offset at the interval's end, rounded up to a byte: 0, 8, .., 64
+        const uint32_t frac = (p & 7u) ? 1u : 0u;
+        uint32_t map = 0;
+        for (int j = 0; j < 6; j++) map |= (((U >> (5 * j)) & 15u) + frac) << (4 * j);
+        Rs.phase_map = map;
+        return Rs;
+    }
+    Rs.max_ac_bits = max_ac; Rs.max_abs_dc = max_dc; Rs.trunc_events = trunc;
+    // the interval must end (rounded up to a byte) where the next one starts: the reference counts MCUs and
+    // never looks at marker positions, so a stream whose markers sit elsewhere must take the serial path
+    const uint32_t end_byte = pos + ((off + 7u) >> 3);
+    if (k + 1 < P.n_intervals) { if (end_byte != rpos[k + 1]) Rs.mismatch = 1; }
+    else {
+        // the closing entry = the reader as the serial pre-scan leaves it: a restart interval that ends with the image is still
+        // rounded up to a byte (jpeg.inl:5339-5346 runs after the last MCU as well)
+        const uint32_t off_end = count == P.interval_mcus ? ((off + 7u) & ~7u) : off;
+        JDA_G(uint32_t, P.blk_index)[(size_t)P.n_mcus * nblocks] = (pos << JDA_INDEX_OFF_BITS) | off_end;
+    }
+    return Rs;
 }
 
 // ================================================================================================

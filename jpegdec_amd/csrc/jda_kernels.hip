@@ -428,18 +428,14 @@ template <bool EXACT>
 __global__ __launch_bounds__(64)
 void jda_prescan_intervals(const jda_prescan_params *__restrict__ params)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tab[JDA_TABLE_BYTES];   // the LUTs: two dependent lookups per symbol
+    __shared__ __attribute__((aligned(16))) uint8_t tab[JDA_LT_WALK_BYTES];   // the tables in the kernels' layout + the walk's DC table
     jda_prescan_params P = params[blockIdx.y];                  // one image per grid row
     bool marker_count_off = false;
     if (P.filter_result) {                                      // the filter ran on the device: its results are in memory only
         P.scan_len = JDA_G(const uint32_t, P.filter_result)[0];
         marker_count_off = JDA_G(const uint32_t, P.filter_result)[1] + 1u != P.n_intervals;
     }
-    {
-        const jda_chunk16_alias JDA_GLOBAL *src = JDA_G(const jda_chunk16_alias, P.tables);
-        jda_chunk16_alias *dst = (jda_chunk16_alias *)tab;
-        for (uint32_t i = threadIdx.x; i < JDA_TABLE_BYTES / 16; i += 64u) dst[i] = src[i];
-    }
+    jda_p0_tables_from(P.tables, threadIdx.x, 64u, tab, true, true);
     __syncthreads();
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= P.n_intervals) return;

@@ -41,7 +41,7 @@ int jda_plain_variant(const jda_dev_desc &D)
 // a tile whose slice of the scan does not fit the window takes the general bit reader, which goes to HBM at every refill.
 // Decided per image from its average bytes of scan per full tile (+ 50 % for the spread between tiles); the kernels exist for
 // the general variant and the RGB8888 plain case, 24-bit multiplies.  JDA_BIG_WINDOW=0 / 1 forces the choice (A/B runs).
-int jda_big_window(const jda_dev_desc &D, int variant)
+int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uint32_t tiles_over_small)
 {
     static int forced = -2;
     if (forced == -2) {
@@ -51,6 +51,9 @@ int jda_big_window(const jda_dev_desc &D, int variant)
     if (!D.fast_mul || variant > 1) return 0;
     if (variant == 1 && D.mode == JDA_MODE_GRAY) return 0;
     if (forced >= 0) return forced ? 1 : 0;
+    // the index was made on the host: the tiles' slices are known exactly -- the larger window (and the wavefront it costs) only
+    // when more than one tile in a hundred does not fit the smaller one
+    if (tiles_total) return (uint64_t)tiles_over_small * 100u > tiles_total ? 1 : 0;
     const uint64_t n_mcus = (uint64_t)D.mcus_x * D.mcus_y;
     if (!n_mcus) return 0;
     const uint64_t avg = (uint64_t)D.scan_len * jda_mcus_per_tile(D.mode) / n_mcus;
@@ -374,6 +377,20 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             const uint32_t *index = jda_image_block_index(img, &nok);
             memcpy(it.stage + d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
             memcpy(it.stage + d->off_dc, jda_image_block_dc(img), it.n_blocks * sizeof(int16_t));
+            {   // the scan slice of every tile, as jda_tile_setup_from computes it: how many exceed the 16-wave kernel's window
+                const int mode = jda_mode_of(I);
+                const uint32_t per = jda_mcus_per_tile(mode), win = jda_window_bytes(mode, 0), nb = (uint32_t)I.blocks_per_mcu;
+                uint32_t total = 0, over = 0;
+                for (uint32_t y = 0; y < (uint32_t)I.mcus_y; y++)
+                    for (uint32_t x = 0; x < (uint32_t)I.mcus_x; x += per) {
+                        const uint32_t cnt = (uint32_t)I.mcus_x - x < per ? (uint32_t)I.mcus_x - x : per;
+                        const size_t b0 = ((size_t)y * I.mcus_x + x) * nb, b1 = b0 + (size_t)cnt * nb;
+                        const uint32_t lo = (index[b0] >> JDA_INDEX_OFF_BITS) & ~15u, hi = ((index[b1] >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
+                        total++;
+                        if (hi - lo > win) over++;
+                    }
+                d->tiles_total = total; d->tiles_over_small = over;
+            }
         }
         e = hipMemcpyAsync(d->base, it.stage, it.alloc, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { rc = jda_set_err(ctx, e, "hipMemcpy(image)"); break; }
@@ -659,7 +676,7 @@ jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *
         // kernel variant 1: the plain case -- full size, RGB8888, every block decoded -- runs a kernel in which these
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
-        const int big = jda_big_window(D, variant);
+        const int big = jda_big_window(D, variant, im->tiles_total, im->tiles_over_small);
         {
             std::vector<jda_strip> &lst = strips[((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big];
             const size_t before = lst.size();

@@ -38,6 +38,7 @@ struct jda_dev_image {
     uint8_t fast_mul;
     uint8_t general_p1;          // JDA_DESC_GENERAL_P1
     uint8_t prescan_on_device;   // the block index was made by jda_prescan_intervals (restart-marker fast path)
+    uint32_t tiles_total, tiles_over_small;   // host index known: tiles, and those whose scan slice exceeds the 16-wave kernel's window (0 / 0: unknown)
 };
 
 struct jda_batch {
@@ -54,7 +55,7 @@ int jda_set_err(jda_ctx *ctx, hipError_t e, const char *what);
 hipError_t jda_pool_alloc(jda_ctx *ctx, void **out, size_t bytes);
 void jda_pool_free(jda_ctx *ctx, void *p);
 int jda_plain_variant(const jda_dev_desc &D);
-int jda_big_window(const jda_dev_desc &D, int variant);
+int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total = 0, uint32_t tiles_over_small = 0);
 // Fill the descriptor of one image of a launch plan (everything but the pointers into the image's HBM block, which the
 // caller sets) and validate the output surface.  Returns JDA_SUCCESS or the error jda_batch_create reports.
 int jda_fill_launch_desc(jda_dev_desc &D, const jda_image_info &I, const uint8_t dc_id[3], const uint8_t ac_id[3], const uint8_t q_id[3],

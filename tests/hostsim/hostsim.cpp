@@ -217,18 +217,21 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         P.nblocks = (uint8_t)I->blocks_per_mcu; P.nluma = (uint8_t)(I->blocks_per_mcu - (I->ncomp == 3 ? 2 : 0));
         uint8_t q_id[3];
         jda_image_component_ids(img, P.dc_id, P.ac_id, q_id);
+        std::vector<uint64_t> lt_store((JDA_LT_WALK_BYTES + 7) / 8);      // the tables as the kernel stages them
+        uint8_t *lt = (uint8_t *)lt_store.data();
+        for (uint32_t tid = 0; tid < 64; tid++) jda_p0_tables_from(P.tables, tid, 64, lt, true, true);
         // MAP pass -> compose the phases -> EXACT pass, as jda_upload does
         std::vector<uint8_t> phase(n_int);
         uint32_t j = 0;
         for (uint32_t k = 0; k < n_int; k++) {
             phase[k] = (uint8_t)(8u * j);
-            const jda_prescan_result R = jda_prescan_interval<false>(P, k);
+            const jda_prescan_result R = jda_prescan_interval<false>(P, k, lt);
             j = (R.phase_map >> (4u * (j > 5u ? 0u : j))) & 15u;
         }
         P.start_phase = phase.data();
         uint32_t first_bad = 0xffffffffu, mismatch = 0, max_ac = 0, max_dc = 0, trunc = 0;
         for (uint32_t k = 0; k < n_int; k++) {
-            const jda_prescan_result R = jda_prescan_interval<true>(P, k);
+            const jda_prescan_result R = jda_prescan_interval<true>(P, k, lt);
             if (R.first_bad < first_bad) first_bad = R.first_bad;
             mismatch |= R.mismatch; trunc += R.trunc_events;
             if (R.max_ac_bits > max_ac) max_ac = R.max_ac_bits;
