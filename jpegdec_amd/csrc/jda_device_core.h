@@ -996,22 +996,35 @@ struct jda_segscan_params {          // one per image
     const uint32_t *seg_start;       // WRITE in, 5 words per segment: first block ordinal, DC predictors [3], byte lag j of the reference window
     uint32_t *blk_index;             // WRITE out: n_blocks_total + 1
     int16_t *blk_dc;                 // WRITE out: n_blocks_total
-    uint32_t *stats;                 // [0] bad, [1] terminal entry written, [2] max AC category, [3] max |DC|, [4] truncated reads, [5] states changed in this round
+    uint32_t *stats;                 // [0] bad, [1] terminal entry written, [2] max AC category, [3] max |DC|, [4] truncated reads, [5] a restart marker is not where the MCU count puts it
     uint32_t scan_len, n_segs, n_blocks_total, first_round;
     uint8_t nluma, nblocks, dc_id[3], ac_id[3];
     const uint32_t *filter_result;   // device filter ran (jda_pipeline): [0] = the filtered length; scan_len / n_segs above are upper bounds then
     uint32_t *worklist;              // jda_segscan_fused: two lists of n_segs (upper bound) segment numbers -- who walks in the next round
     uint32_t worklist_cap;
+    // streams with restart intervals (0 / NULL otherwise): where in the FILTERED scan every interval starts -- restart_pos[0] = 0,
+    // restart_pos[1 .. n_intervals - 1] = the positions the RSTn markers stood at, restart_pos[n_intervals] = JDA_RST_SENTINEL --,
+    // blocks per interval (DRI x blocks per MCU), and whether the last interval is a whole one (the closing index entry is then
+    // rounded up to a byte like every interval end, jpeg.inl:5339-5346)
+    const uint32_t *restart_pos;
+    uint32_t n_intervals, interval_blocks, round_last;
 };
+#define JDA_RST_SENTINEL 0x1fffffffu      // (a byte position no scan reaches: the index packs positions in 25 bits)
+#define JDA_SEG_HAS_RESTART 2u           // seg_sum word 5, bit 1: an interval ends inside the segment (its DC sums count from there)
 // the parameters with what only the device knows filled in
 JDA_HD jda_segscan_params jda_segscan_resolve(const jda_segscan_params &in)
 {
     jda_segscan_params P = in;
-    if (P.filter_result) { P.scan_len = JDA_G(const uint32_t, P.filter_result)[0]; P.n_segs = P.scan_len / 256u + 1u; }
+    if (P.filter_result) {
+        P.scan_len = JDA_G(const uint32_t, P.filter_result)[0]; P.n_segs = P.scan_len / 256u + 1u;
+        // as many RSTn markers as the MCU count asks for?  If not, nothing walks (restart_pos is not what the walk takes it for) and
+        // the result words stay "no index": the serial pre-scan does what the reference does with such a file
+        if (P.restart_pos && JDA_G(const uint32_t, P.filter_result)[1] + 1u != P.n_intervals) P.n_segs = 0;
+    }
     return P;
 }
 struct jda_seg_sum { uint32_t nblk; int32_t dcsum[3]; uint32_t phase_map, bad; };
-struct jda_seg_stats { uint32_t bad, terminal, max_ac_bits, max_abs_dc, trunc_events; };
+struct jda_seg_stats { uint32_t bad, terminal, max_ac_bits, max_abs_dc, trunc_events, mismatch; };
 
 JDA_HD void jda_atomic_or_u32(uint32_t *p, uint32_t v)
 {
@@ -1087,7 +1100,13 @@ JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
 //   WRITE  the reader itself (pBuf, ulBitOff), block ordinals and DC predictors from seg_start: index entries (held back to the
 //          block's end so that a truncation flag joins its entry in the register: one plain store; only a block that crosses into
 //          the next segment is ORed in atomically), blk_dc, maxima, truncation count.
-template <int OP>
+// RST: the stream has restart intervals.  The filter recorded where every interval starts (byte aligned: the rest of the byte in
+// front is padding); a walk that finishes an MCU within 7 bits of the next start has finished the interval: it steps over the
+// padding, the reference rounds ulBitOff up WITHOUT a refill (jpeg.inl:5339-5346; so the refill after an interval's closing EOB
+// waits for the next block's opening one), the DC predictors restart at zero.  The reference itself counts MCUs and never
+// looks at marker positions: the WRITE pass checks that the two agree (every interval end at a multiple of interval_blocks,
+// every such multiple an interval end) and sends the image to the serial pre-scan when they do not.
+template <int OP, bool RST = false>
 JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *lt,
                              jda_seg_sum &S, jda_seg_stats &ST)
 {
@@ -1119,16 +1138,35 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     if (CNT) U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);
     uint32_t pend = 0, pend_g = 0;                                  // WRITE: index entry of the block in progress (if it began here)
     bool pending = false, bad = false, stop = false;                // stop: leave the loop after this step (one exit test per step)
+    // RST: the next interval start ahead of the walk (as a bit position relative to the segment), blocks left in the interval
+    const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
+    const uint32_t seg_bit0 = seg * JDA_SEG_BITS;
+    uint32_t nr = 0, next_bit = 0xffffffffu, left_blocks = 0, has_rst = 0;
+    if (RST) {
+        const uint32_t byte0 = (seg_bit0 + p) >> 3;                 // smallest nr >= 1 with restart_pos[nr] * 8 > the entry position
+        uint32_t lo = 1, hi = P.n_intervals;                        // (restart_pos[n_intervals] is the sentinel)
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rpos[mid] > byte0) hi = mid; else lo = mid + 1; }
+        nr = lo;
+        next_bit = (rpos[nr] << 3) - seg_bit0;
+        if (OP == JDA_SEG_WRITE) left_blocks = P.interval_blocks - (g - (k != 0u ? 1u : 0u)) % P.interval_blocks;   // (k != 0: block g - 1 is still open)
+    }
     jda_seg_reader R;
     jda_seg_reader_init(R, segw, p);
     while ((p < JDA_SEG_BITS) & !stop) {
+        if (RST && p >= next_bit) {                                 // (a walk off the decoder's path ran over an interval start: catch up)
+            nr++; next_bit = (rpos[nr] << 3) - seg_bit0;
+            if (nr > P.n_intervals) { nr = P.n_intervals; next_bit = 0xffffffffu; }
+        }
         const bool isdc0 = k == 0;
         const uint32_t c = b < nluma ? 0u : b - nluma + 1u;
         if (OP == JDA_SEG_WRITE) {                                  // a block starts here (jpeg.inl:2129-2165): by selects, but for the two stores
             const bool term = isdc0 & (g >= P.n_blocks_total);      // past the image: the reader as the last block left it closes the index
             const bool begin = isdc0 & !term;
             if (term) {
-                if (g == P.n_blocks_total) { JDA_G(uint32_t, P.blk_index)[g] = (pos_pre << JDA_INDEX_OFF_BITS) | off_pre; ST.terminal = 1; }
+                if (g == P.n_blocks_total) {
+                    const uint32_t off_end = (RST && P.round_last) ? ((off_pre + 7u) & ~7u) : off_pre;    // (a whole last interval is rounded up like the others)
+                    JDA_G(uint32_t, P.blk_index)[g] = (pos_pre << JDA_INDEX_OFF_BITS) | off_end; ST.terminal = 1;
+                }
             }
             const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
             const bool out_of_range = begin & ((pr < -32768) | (pr > 32767));
@@ -1194,9 +1232,14 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             }
         }
         p = p1 + sz;
+        const bool ends = (eob | (kk + 1u >= 64u)) & !inval;
+        const uint32_t bn = b + 1u == nblocks ? 0u : b + 1u;
+        // RST: this symbol completes an MCU within 7 bits of the next interval's start = it completes the interval
+        const bool iend = RST & ends & live & (bn == 0u) & (next_bit - p < 8u);
+        const bool hold = iend & eob;                               // the refill after an interval's closing EOB waits for the rounding
         // ---- the refill at the end of the step (not after EOB in the reference -- there it is the next block's opening one)
         if (OP == JDA_SEG_WRITE) {
-            const bool r2 = off > 47u;
+            const bool r2 = (off > 47u) & !hold;
             const uint32_t npos = pos + (r2 ? off >> 3 : 0u), noff = r2 ? off & 7u : off;
             // what closes the index if this was the image's last symbol: the reader before the refill after an EOB (the reference has
             // not refilled yet), after it otherwise (a block that ends on its 63rd coefficient has had its bottom refill)
@@ -1207,19 +1250,44 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         }
         if (CNT) {
             const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
-            U &= ~(f - (f >> 4));
+            U &= hold ? 0xffffffffu : ~(f - (f >> 4));
         }
-        const bool ends = (eob | (kk + 1u >= 64u)) & !inval;
         k = (ends | inval) ? 0u : kk + 1u;
-        const uint32_t bn = b + 1u == nblocks ? 0u : b + 1u;
         b = ends ? bn : b;
 #if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 2))
         if (OP == JDA_SEG_WRITE && ends && pending) { JDA_G(uint32_t, P.blk_index)[pend_g] = pend; pending = false; }
 #endif
+        if (RST) {
+            if (OP == JDA_SEG_WRITE) {
+                // the reference restarts by MCU count, the filter found the markers: they must agree
+                left_blocks -= ends ? 1u : 0u;
+                const bool expect = ends & live & (left_blocks == 0u);
+                if ((expect != iend) & (g < P.n_blocks_total)) ST.mismatch = 1;
+                left_blocks = left_blocks == 0u ? P.interval_blocks : left_blocks;
+            }
+            if (iend) {                                             // over the padding to the next interval's first byte
+                const uint32_t frac = (p & 7u) ? 1u : 0u;           // (interval starts are byte aligned, so are segment starts)
+                if (OP == JDA_SEG_WRITE) {
+                    off = (off + 7u) & ~7u;                         // :5339-5346, no refill ..
+                    pos_pre = pos; off_pre = off;
+                    if (off > 47u) { pos += off >> 3; off &= 7u; }  // .. then the next block's opening one
+                    pred0 = pred1 = pred2 = 0;
+                }
+                if (CNT) {
+                    U += frac * kOnes;
+                    const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
+                    U &= ~(f - (f >> 4));
+                    ds0 = ds1 = ds2 = 0; has_rst = JDA_SEG_HAS_RESTART;
+                }
+                p = next_bit;
+                nr++; next_bit = nr <= P.n_intervals ? (rpos[nr] << 3) - seg_bit0 : 0xffffffffu;
+                if (p < JDA_SEG_BITS) jda_seg_reader_init(R, segw, p);     // (a long symbol + the padding may step over a whole dword)
+            }
+        }
     }
     if (OP == JDA_SEG_WRITE && pending && !bad) jda_atomic_or_u32(P.blk_index + pend_g, pend);      // the block goes on in the next segment
     if (OP == JDA_SEG_WRITE) { ST.max_ac_bits = max_ac; ST.max_abs_dc = max_dc; }
-    S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2; S.bad = sbad;
+    S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2; S.bad = sbad | has_rst;
     if (bad) { S.bad = 1; ST.bad = 1; return JDA_SEG_DEAD; }
     if (CNT) {
         uint32_t map = 0;

@@ -519,24 +519,28 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
     const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
     jda_seg_sum S;
     jda_seg_stats ST;
-    ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0;
+    ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
     if (OP == JDA_SEG_SPEC) {
         const uint32_t old = e_cur[seg + 1] & ~JDA_SEG_CHANGED;
         uint32_t out = old;
         if (need) {
-            const uint32_t x = jda_seg_walk<JDA_SEG_SPEC>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST) & ~JDA_SEG_CHANGED;
+            const uint32_t x = (P.restart_pos ? jda_seg_walk<JDA_SEG_SPEC, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST)
+                                              : jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST)) & ~JDA_SEG_CHANGED;
             out = x;
             if (x != old) { out |= JDA_SEG_CHANGED; atomicAdd(&P.stats[8 + round], 1u); }
         }
         e_nxt[seg + 1] = out;
         if (seg == 0) e_nxt[0] = 0;                                  // the scan starts at a block start (jpeg.inl:4996-4998)
     } else if (OP == JDA_SEG_COUNT) {
-        (void)jda_seg_walk<JDA_SEG_COUNT>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
+        if (P.restart_pos) (void)jda_seg_walk<JDA_SEG_COUNT, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
+        else (void)jda_seg_walk<JDA_SEG_COUNT, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
         uint32_t *o = P.seg_sum + (size_t)seg * 6;
         o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
     } else if (need) {
-        (void)jda_seg_walk<JDA_SEG_WRITE>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
+        if (P.restart_pos) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
+        else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
         if (ST.bad) atomicOr(&P.stats[0], 1u);
+        if (ST.mismatch) atomicOr(&P.stats[5], 1u);
         if (ST.terminal) atomicAdd(&P.stats[1], 1u);
         if (ST.max_ac_bits) atomicMax(&P.stats[2], ST.max_ac_bits);
         if (ST.max_abs_dc) atomicMax(&P.stats[3], ST.max_abs_dc);
@@ -578,9 +582,10 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
         const uint32_t seg = all ? item : wl_in[item];
         jda_seg_sum S;
         jda_seg_stats ST;
-        ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0;
+        ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
         const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];   // the scan starts at a block start (jpeg.inl:4996-4998)
-        const uint32_t x = jda_seg_walk<OP>(P, seg, entry, JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u), tab, S, ST);
+        const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
+        const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST) : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST);
         if (OP == JDA_SEG_FUSED) {
             uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
             o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
@@ -643,34 +648,36 @@ void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
     for (uint32_t base = 0; base < P.n_segs; base += 64u) {
         const uint32_t seg = base + lane;
         const bool in = seg < P.n_segs;
-        uint32_t nblk = 0, d0 = 0, d1 = 0, d2 = 0, map = 0x00fac688u /* identity: j -> j */, bad = 0;
+        uint32_t nblk = 0, d0 = 0, d1 = 0, d2 = 0, map = 0x00fac688u /* identity: j -> j */, bad = 0, rst = 0;
         if (in && !ended) {
             const uint32_t *su = P.seg_sum + (size_t)seg * 6;
-            nblk = su[0]; d0 = su[1]; d1 = su[2]; d2 = su[3]; map = su[4]; bad = su[5];
+            nblk = su[0]; d0 = su[1]; d1 = su[2]; d2 = su[3]; map = su[4]; bad = su[5] & 1u; rst = su[5] & JDA_SEG_HAS_RESTART;
         }
         // the first bad segment of this step (its own block count still counts; nothing behind it does)
         const uint64_t badmask = __builtin_amdgcn_ballot_w64(bad != 0);
         const uint32_t first_bad = badmask ? (uint32_t)__builtin_ctzll(badmask) : 64u;
-        if (lane > first_bad) { nblk = 0; d0 = d1 = d2 = 0; }
-        const uint32_t in_g = jda_wave_incl_sum_u32(nblk), in0 = jda_wave_incl_sum_u32(d0), in1 = jda_wave_incl_sum_u32(d1), in2 = jda_wave_incl_sum_u32(d2);
-        // window lag at every lane's entry: serial composition over the 64 maps of this step
-        uint32_t my_j = 0, jj = j;
+        if (lane > first_bad) { nblk = 0; d0 = d1 = d2 = 0; rst = 0; }
+        const uint32_t in_g = jda_wave_incl_sum_u32(nblk);
+        // window lag and DC predictors at every lane's entry: serial over the 64 segments of this step -- the lag is a composition of
+        // maps, the predictors are sums that start over where an interval ended inside a segment (its sums count from there)
+        uint32_t my_j = 0, jj = j, my0 = 0, my1 = 0, my2 = 0, r0 = p0, r1 = p1, r2 = p2;
         for (uint32_t l = 0; l < 64u; l++) {
-            if (lane == l) my_j = jj;
+            if (lane == l) { my_j = jj; my0 = r0; my1 = r1; my2 = r2; }
             const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)map, (int)l);
             jj = (m >> (3u * jj)) & 7u;
+            const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)rst, (int)l);
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)l), e1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)l), e2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)l);
+            r0 = fl ? e0 : r0 + e0; r1 = fl ? e1 : r1 + e1; r2 = fl ? e2 : r2 + e2;
         }
         if (in) {
             uint32_t *st = seg_start + (size_t)seg * 5;
             const bool dead = ended || lane > first_bad;            // behind a bad code: the write pass skips these
             const uint32_t gs = g_carry + in_g - nblk;
             st[0] = dead ? 0xfffffff0u : (gs > 0xfffffff0u ? 0xfffffff0u : gs);
-            st[1] = p0 + in0 - d0; st[2] = p1 + in1 - d1; st[3] = p2 + in2 - d2; st[4] = my_j;
+            st[1] = my0; st[2] = my1; st[3] = my2; st[4] = my_j;
         }
         g_carry += (uint32_t)__builtin_amdgcn_readlane((int)in_g, 63);
-        p0 += (uint32_t)__builtin_amdgcn_readlane((int)in0, 63);
-        p1 += (uint32_t)__builtin_amdgcn_readlane((int)in1, 63);
-        p2 += (uint32_t)__builtin_amdgcn_readlane((int)in2, 63);
+        p0 = r0; p1 = r1; p2 = r2;
         j = jj;
         if (!ended && badmask) { ended = true; if (g_carry < P.n_blocks_total + 1u) ok = false; }
     }
@@ -798,7 +805,10 @@ void jda_filter_scan(const jda_filter_params *__restrict__ params)
         rst_base += (T.w1 >> (16 * old)) & 0xffffu;
         __syncthreads();
     }
-    if (tid == 0) { P.result[0] = out_base; P.result[1] = rst_base; }
+    if (tid == 0) {
+        P.result[0] = out_base; P.result[1] = rst_base;
+        if (rst_base + 1u < P.restart_cap) P.restart_pos[rst_base + 1u] = JDA_RST_SENTINEL;      // behind the last interval start (the segment walk's search ends there)
+    }
 }
 
 extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, hipStream_t stream)

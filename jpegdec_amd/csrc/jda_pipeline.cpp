@@ -114,11 +114,10 @@ struct Img {
     jda_front f;
     int32_t err;                 // front-end verdict
     bool device;                 // filter + pre-scan + decode were enqueued for it
-    bool seg_mode;               // marker-less segment walk (else: restart intervals)
     bool fast;                   // launched with 24-bit multiplies
     uint32_t n_segs_ub, n_blocks;
     size_t off_raw, off_scan, scan_bytes, off_index, off_dc, off_work, off_zero, off_stats;   // arena offsets
-    size_t work_bytes, zero_bytes;
+    size_t work_bytes, zero_bytes, off_rpos;     // off_rpos: restart positions inside the work region
     size_t ctl_tables;           // offset of its tables inside the control blob
     uint32_t list, n_tiles;      // launch list it is in, tiles (padded)
     size_t strip_off;            // its first strip inside the list
@@ -253,7 +252,6 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     for (int i = 0; i < n; i++) { S.imgs[(size_t)i].ctl_tables = ctl; ctl += tab_stride; }
     const size_t off_fparams = a16(ctl); ctl = off_fparams + a16((size_t)n * sizeof(jda_filter_params));
     const size_t off_sparams = ctl; ctl += a16((size_t)n * sizeof(jda_segscan_params));
-    const size_t off_pparams = ctl; ctl += a16((size_t)n * sizeof(jda_prescan_params));
     S.off_descs = ctl; ctl += a16((size_t)n * sizeof(jda_dev_desc));
     const size_t strips_base = ctl;
     // the page-locked buffer must hold the tables before the strips are counted: size it generously for them now
@@ -296,7 +294,6 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         if (rc != JDA_SUCCESS) { im.err = rc; continue; }
         if (!im.f.device_ok) continue;                       // valid, but the serial host pre-scan has to make its index (jda_pipeline_wait)
         im.device = true; n_dev++;
-        im.seg_mode = im.f.n_intervals == 0;
         const int variant = jda_plain_variant(D);
         // (window size: the filtered length is not known yet; the unfiltered one is at most a few percent larger)
         D.scan_len = im.f.raw_len;
@@ -318,14 +315,10 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     for (int i = 0; i < n; i++) {
         Img &im = S.imgs[(size_t)i];
         if (!im.device) continue;
-        if (im.seg_mode) {
-            im.n_segs_ub = im.f.raw_len / JDA_SEG_BYTES + 1u;
-            im.work_bytes = a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);   // seg_sum | seg_start | two work lists
-        } else {
-            const size_t ni = im.f.n_intervals;
-            im.n_segs_ub = 0;
-            im.work_bytes = a16((ni + 1) * 4) + a16(ni * 4) + a16(ni);                                             // restart_pos | phase_map | start_phase
-        }
+        // seg_sum | seg_start | two work lists | where the restart intervals start (+ the sentinel)
+        im.n_segs_ub = im.f.raw_len / JDA_SEG_BYTES + 1u;
+        im.off_rpos = a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);
+        im.work_bytes = im.off_rpos + (im.f.n_intervals ? a16(((size_t)im.f.n_intervals + 1) * 4) : 0);
         im.off_work = take(im.work_bytes);
     }
     const size_t zero_begin = arena;
@@ -339,7 +332,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     for (int i = 0; i < n; i++) {
         Img &im = S.imgs[(size_t)i];
         if (!im.device) continue;
-        im.zero_bytes = im.seg_mode ? a16(((size_t)im.n_segs_ub + 1) * 4) : 0;                                     // entry states
+        im.zero_bytes = a16(((size_t)im.n_segs_ub + 1) * 4);                                                       // entry states
         im.off_zero = take(im.zero_bytes);
     }
     S.off_stats_dev = arena;
@@ -371,11 +364,10 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     // ---- control blob, part 2: parameters, descriptors, strips (in parallel: the strip lists are the bulk)
     jda_filter_params *fp = (jda_filter_params *)(S.pin + off_fparams);
     jda_segscan_params *sp = (jda_segscan_params *)(S.pin + off_sparams);
-    jda_prescan_params *pp = (jda_prescan_params *)(S.pin + off_pparams);
     jda_dev_desc *dd = (jda_dev_desc *)(S.pin + S.off_descs);
-    std::vector<int> seg_ix, int_ix, dev_ix;
-    for (int i = 0; i < n; i++) { const Img &im = S.imgs[(size_t)i]; if (!im.device) continue; dev_ix.push_back(i); (im.seg_mode ? seg_ix : int_ix).push_back(i); }
-    uint32_t max_segs = 0, max_int = 0;
+    std::vector<int> dev_ix;
+    for (int i = 0; i < n; i++) if (S.imgs[(size_t)i].device) dev_ix.push_back(i);
+    uint32_t max_segs = 0;
     for (size_t k = 0; k < dev_ix.size(); k++) {
         const int i = dev_ix[k];
         Img &im = S.imgs[(size_t)i];
@@ -385,8 +377,9 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         uint32_t *pstats = (uint32_t *)(B + im.off_stats + 16);
         jda_filter_params &F = fp[k];
         F.raw = B + im.off_raw; F.out = B + im.off_scan; F.result = fres; F.raw_len = im.f.raw_len;
-        F.restart_pos = im.seg_mode ? (uint32_t *)(B + im.off_work) /* unused */ : (uint32_t *)(B + im.off_work);
-        F.restart_cap = im.seg_mode ? 0u : im.f.n_intervals + 1u;
+        const uint32_t n_int = im.f.n_intervals;                       // 0: no restart intervals
+        F.restart_pos = (uint32_t *)(B + im.off_work + im.off_rpos);
+        F.restart_cap = n_int ? n_int + 1u : 0u;
         jda_dev_desc &D = descs[(size_t)i];
         D.tables = B + im.ctl_tables;
         D.blk_index = (const uint32_t *)(B + im.off_index);
@@ -394,39 +387,25 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         D.scan = B + im.off_scan;
         D.scan_len = (uint32_t)(im.scan_bytes - JDA_SCAN_PAD);          // upper bound of the filtered length; the bytes behind it are zero
         dd[i] = D;
-        if (im.seg_mode) {
-            jda_segscan_params P;
-            memset(&P, 0, sizeof(P));
-            P.scan = B + im.off_scan; P.tables = B + im.ctl_tables;
-            P.entry_cur = (uint32_t *)(B + im.off_zero); P.entry_nxt = P.entry_cur;
-            P.worklist = (uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20)); P.worklist_cap = im.n_segs_ub;
-            P.seg_sum = (uint32_t *)(B + im.off_work); P.seg_start = (const uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24));
-            P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
-            P.stats = pstats;
-            P.scan_len = im.f.raw_len; P.n_segs = im.n_segs_ub; P.n_blocks_total = im.n_blocks;
-            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
-            for (int c = 0; c < 3; c++) { P.dc_id[c] = im.f.dc_id[c]; P.ac_id[c] = im.f.ac_id[c]; }
-            P.filter_result = fres;
-            sp[std::find(seg_ix.begin(), seg_ix.end(), i) - seg_ix.begin()] = P;
-            max_segs = std::max(max_segs, im.n_segs_ub);
-        } else {
-            const size_t ni = im.f.n_intervals;
-            jda_prescan_params P;
-            memset(&P, 0, sizeof(P));
-            P.scan = B + im.off_scan; P.tables = B + im.ctl_tables;
-            P.restart_pos = (const uint32_t *)(B + im.off_work);
-            P.phase_map = (uint32_t *)(B + im.off_work + a16((ni + 1) * 4));
-            P.start_phase = B + im.off_work + a16((ni + 1) * 4) + a16(ni * 4);
-            P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
-            P.stats = pstats;
-            P.scan_len = im.f.raw_len; P.n_intervals = im.f.n_intervals; P.n_mcus = (uint32_t)(I.mcus_x * I.mcus_y);
-            P.interval_mcus = (uint32_t)I.restart_interval;
-            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
-            for (int c = 0; c < 3; c++) { P.dc_id[c] = im.f.dc_id[c]; P.ac_id[c] = im.f.ac_id[c]; }
-            P.filter_result = fres;
-            pp[std::find(int_ix.begin(), int_ix.end(), i) - int_ix.begin()] = P;
-            max_int = std::max(max_int, im.f.n_intervals);
+        jda_segscan_params P;
+        memset(&P, 0, sizeof(P));
+        P.scan = B + im.off_scan; P.tables = B + im.ctl_tables;
+        P.entry_cur = (uint32_t *)(B + im.off_zero); P.entry_nxt = P.entry_cur;
+        P.worklist = (uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20)); P.worklist_cap = im.n_segs_ub;
+        P.seg_sum = (uint32_t *)(B + im.off_work); P.seg_start = (const uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24));
+        P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
+        P.stats = pstats;
+        P.scan_len = im.f.raw_len; P.n_segs = im.n_segs_ub; P.n_blocks_total = im.n_blocks;
+        P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
+        for (int c = 0; c < 3; c++) { P.dc_id[c] = im.f.dc_id[c]; P.ac_id[c] = im.f.ac_id[c]; }
+        P.filter_result = fres;
+        if (n_int) {                                                    // the walk ends intervals where the filter found the markers
+            P.restart_pos = F.restart_pos; P.n_intervals = n_int;
+            P.interval_blocks = (uint32_t)I.restart_interval * (uint32_t)I.blocks_per_mcu;
+            P.round_last = ((uint32_t)(I.mcus_x * I.mcus_y) % (uint32_t)I.restart_interval) == 0 ? 1u : 0u;
         }
+        sp[k] = P;
+        max_segs = std::max(max_segs, im.n_segs_ub);
     }
     p->workers->run((int)dev_ix.size(), [&](int k) {
         const int i = dev_ix[(size_t)k];
@@ -450,15 +429,9 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), p->s_copy);
         if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->s_up, S.ev_copy, 0);
-        if (e == hipSuccess && !int_ix.empty()) {
-            const jda_prescan_params *dp = (const jda_prescan_params *)(B + off_pparams);
-            e = jda_launch_prescan(dp, (uint32_t)int_ix.size(), max_int, 0, p->s_up);                                  // MAP
-            if (e == hipSuccess) e = jda_launch_prescan_compose(dp, (uint32_t)int_ix.size(), p->s_up);                 // phases + result words
-            if (e == hipSuccess) e = jda_launch_prescan(dp, (uint32_t)int_ix.size(), max_int, 1, p->s_up);             // EXACT
-        }
-        if (e == hipSuccess && !seg_ix.empty()) {
+        if (e == hipSuccess) {
             const jda_segscan_params *dp = (const jda_segscan_params *)(B + off_sparams);
-            const uint32_t ns = (uint32_t)seg_ix.size();
+            const uint32_t ns = (uint32_t)dev_ix.size();
             // speculative rounds with the count pass folded in (work lists: a round after the first walks what the one before changed)
             for (uint32_t r = 0; r < JDA_PIPE_SPEC_ROUNDS && e == hipSuccess; r++) e = jda_launch_segscan_fused(dp, ns, max_segs, r, p->s_up);
             if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, p->s_up);
@@ -538,22 +511,19 @@ int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status)
                 const uint32_t *rb = (const uint32_t *)(S.pin + S.pin_stats + (im.off_stats - S.off_stats_dev));
                 const uint32_t *ps = rb + 4;
                 uint32_t max_ac = 0, max_dc = 0;
-                bool ok;
-                if (im.seg_mode) {
-                    ok = ps[8 + JDA_PIPE_SPEC_ROUNDS] == 0 && ps[6] == 1 && ps[0] == 0 && ps[1] == 1;   // the last round left nothing to walk; enough blocks; no bad code; closing entry once
-                    max_ac = ps[2]; max_dc = ps[3];
-                    S.st.spec_rounds_max = std::max<int32_t>(S.st.spec_rounds_max, [&]() { int r = 1; while (r <= JDA_PIPE_SPEC_ROUNDS && ps[8 + r]) r++; return r; }());
-                } else {
-                    ok = ps[0] == 0xffffffffu && ps[1] == 0;
-                    max_ac = ps[2]; max_dc = ps[3];
-                }
+                // the last round left nothing to walk; enough blocks; no bad code; the closing entry written once; and, with restart
+                // intervals, as many markers as the MCU count asks for, each where the count puts it
+                bool ok = ps[8 + JDA_PIPE_SPEC_ROUNDS] == 0 && ps[6] == 1 && ps[0] == 0 && ps[1] == 1;
+                if (im.f.n_intervals && (rb[1] + 1u != im.f.n_intervals || ps[5] != 0)) ok = false;
+                max_ac = ps[2]; max_dc = ps[3];
+                S.st.spec_rounds_max = std::max<int32_t>(S.st.spec_rounds_max, [&]() { int r = 1; while (r <= JDA_PIPE_SPEC_ROUNDS && ps[8 + r]) r++; return r; }());
                 if (ok && im.fast && !jda_front_fast_mul(S.pin + im.ctl_tables, &im.f, max_ac, (int32_t)max_dc)) ok = false;   // a magnitude no legal stream has
                 redo = !ok;
                 if (ok) S.st.device_images++;
                 else {
                     static const bool trace = getenv("JDA_PIPE_TRACE") != NULL;
-                    if (trace) fprintf(stderr, "jda_pipeline: image %d (%dx%d, %s) of ticket %d goes to the host path: filter %u bytes / %u markers, result words %u %u %u %u %u, [6] %u, last round %u, fast %d\n",
-                                       i, im.f.info.width, im.f.info.height, im.seg_mode ? "segments" : "intervals", ticket, rb[0], rb[1], ps[0], ps[1], ps[2], ps[3], ps[4], ps[6],
+                    if (trace) fprintf(stderr, "jda_pipeline: image %d (%dx%d, %u restart intervals) of ticket %d goes to the host path: filter %u bytes / %u markers, result words %u %u %u %u %u, [5] %u [6] %u, last round %u, fast %d\n",
+                                       i, im.f.info.width, im.f.info.height, im.f.n_intervals, ticket, rb[0], rb[1], ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6],
                                        ps[8 + JDA_PIPE_SPEC_ROUNDS], (int)im.fast);
                 }
             }

@@ -76,8 +76,9 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     std::vector<uint32_t> dev_index;
     std::vector<int16_t> dev_dc;
     g_prescan_used = 0;
-    if (jda_image_prescan_pending(img) && jda_image_get_info(img)->restart_interval == 0) {
-        // stream without restart markers (8f N2): what jda_upload_batch + jda_segscan do, lane by lane
+    if (jda_image_prescan_pending(img) && (jda_image_get_info(img)->restart_interval == 0 || g_device_prescan == 2)) {
+        // the segment walk (8f N2): what jda_upload_batch / jda_pipeline + jda_segscan do, lane by lane -- streams without restart
+        // markers, and (hostsim_set_device_prescan(2), as jda_pipeline does it) streams with them
         const jda_image_info *I = jda_image_get_info(img);
         const size_t nb = (size_t)I->mcus_x * I->mcus_y * I->blocks_per_mcu;
         dev_index.assign(nb + 1, 0u); dev_dc.assign(nb, 0x7777);      // (the write pass ORs its entries into a zeroed index, as jda_upload_batch has it)
@@ -101,6 +102,15 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         P.nblocks = (uint8_t)I->blocks_per_mcu; P.nluma = (uint8_t)(I->blocks_per_mcu - (I->ncomp == 3 ? 2 : 0));
         uint8_t q_id[3];
         jda_image_component_ids(img, P.dc_id, P.ac_id, q_id);
+        std::vector<uint32_t> rp;                               // restart intervals: where they start in the filtered scan + the sentinel
+        if (I->restart_interval) {
+            uint32_t n_int = 0;
+            const uint32_t *r0 = jda_image_restart_positions(img, &n_int);
+            rp.assign(r0, r0 + n_int); rp.push_back(JDA_RST_SENTINEL);
+            P.restart_pos = rp.data(); P.n_intervals = n_int; P.interval_blocks = (uint32_t)I->restart_interval * P.nblocks;
+            P.round_last = ((uint32_t)(I->mcus_x * I->mcus_y) % (uint32_t)I->restart_interval) == 0 ? 1u : 0u;
+        }
+        const bool rst = P.restart_pos != nullptr;
         jda_seg_sum S;
         jda_seg_stats ST;
         memset(&ST, 0, sizeof(ST));
@@ -116,7 +126,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 uint32_t out = old;
                 if (need) {
                     const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-                    const uint32_t x = jda_seg_walk<JDA_SEG_SPEC>(P, seg, entry & ~JDA_SEG_CHANGED, slot, lt, S, ST) & ~JDA_SEG_CHANGED;
+                    const uint32_t x = (rst ? jda_seg_walk<JDA_SEG_SPEC, true>(P, seg, entry & ~JDA_SEG_CHANGED, slot, lt, S, ST) : jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, entry & ~JDA_SEG_CHANGED, slot, lt, S, ST)) & ~JDA_SEG_CHANGED;
                     out = x;
                     if (x != old) { out |= JDA_SEG_CHANGED; changed++; }
                 }
@@ -135,7 +145,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             for (uint32_t r = 0; r < 12; r++) {
                 for (uint32_t seg = 0; seg < n_segs; seg++) {
                     const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-                    n2[seg + 1] = jda_seg_walk<JDA_SEG_SPEC>(P, seg, c2[seg], slot, lt, S, ST);
+                    n2[seg + 1] = rst ? jda_seg_walk<JDA_SEG_SPEC, true>(P, seg, c2[seg], slot, lt, S, ST) : jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, c2[seg], slot, lt, S, ST);
                 }
                 n2[0] = 0;
                 std::swap(c2, n2);
@@ -147,7 +157,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         memset(&ST, 0, sizeof(ST));
         for (uint32_t seg = 0; seg < n_segs; seg++) {           // COUNT
             const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-            (void)jda_seg_walk<JDA_SEG_COUNT>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST);
+            if (rst) (void)jda_seg_walk<JDA_SEG_COUNT, true>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST); else (void)jda_seg_walk<JDA_SEG_COUNT, false>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST);
             uint32_t *o = &seg_sum[(size_t)seg * 6];
             o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
         }
@@ -161,12 +171,13 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 const uint32_t *su = &seg_sum[(size_t)i * 6];
                 st[0] = g > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)g; st[1] = (uint32_t)pred[0]; st[2] = (uint32_t)pred[1]; st[3] = (uint32_t)pred[2]; st[4] = j;
                 g += su[0];
-                if (su[5]) {
+                if (su[5] & 1u) {
                     if (g < (uint64_t)nb + 1) ok = false;
                     for (uint32_t r = i + 1; r < n_segs; r++) seg_start[(size_t)r * 5] = 0xfffffff0u;
                     break;
                 }
-                pred[0] += (int32_t)su[1]; pred[1] += (int32_t)su[2]; pred[2] += (int32_t)su[3];
+                if (su[5] & JDA_SEG_HAS_RESTART) { pred[0] = (int32_t)su[1]; pred[1] = (int32_t)su[2]; pred[2] = (int32_t)su[3]; }   // an interval ended inside: its sums count from there
+                else { pred[0] += (int32_t)su[1]; pred[1] += (int32_t)su[2]; pred[2] += (int32_t)su[3]; }
                 j = (su[4] >> (3u * j)) & 7u;
             }
             if (g < (uint64_t)nb + 1) ok = false;
@@ -178,8 +189,8 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
             jda_seg_stats T1;
             memset(&T1, 0, sizeof(T1));
-            (void)jda_seg_walk<JDA_SEG_WRITE>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1);
-            ST.bad |= T1.bad; terminal += T1.terminal; ST.trunc_events += T1.trunc_events;
+            if (rst) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1); else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1);
+            ST.bad |= T1.bad | T1.mismatch; terminal += T1.terminal; ST.trunc_events += T1.trunc_events;
             if (T1.max_ac_bits > ST.max_ac_bits) ST.max_ac_bits = T1.max_ac_bits;
             if (T1.max_abs_dc > ST.max_abs_dc) ST.max_abs_dc = T1.max_abs_dc;
         }
@@ -199,6 +210,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             }
             if (ref) jda_image_free(ref);
         } else {                                                // corrupt / truncated: the serial pre-scan, as jda_upload_batch does
+            if (getenv("HOSTSIM_DEBUG")) fprintf(stderr, "segment path rejected: ok %d settled %d rounds %u bad %u terminal %u\n", (int)ok, (int)settled, rounds, ST.bad, terminal);
             jda_image_run_host_prescan(img);
             dev_index.clear(); dev_dc.clear();
         }

@@ -163,3 +163,43 @@ def test_pipeline_at_bench_size(gpu_ctx, ref_scalar):
         gpu_ctx.free(o[0])
     assert pipe.stats["device_images"] == 2
     pipe.close()
+
+
+def _with_dri(jpeg: bytes, f):
+    i = jpeg.index(b"\xff\xdd\x00\x04")
+    v = (jpeg[i + 4] << 8) | jpeg[i + 5]
+    nv = f(v)
+    return jpeg[: i + 4] + bytes([nv >> 8, nv & 255]) + jpeg[i + 6:]
+
+
+def test_pipeline_restart_streams_take_the_segment_walk(gpu_ctx, oracle):
+    """Streams with restart intervals go through the same speculative segment walk as those without (one lane per 256 bytes, not
+    one per interval): index and DC predictors == the serial pre-scan's entry for entry, pixels == the oracle's; a file whose
+    DRI does not match where its markers are (same number of intervals, other places -- or another number) is noticed on the
+    device and decoded through the serial pre-scan, like the reference (which counts MCUs) would."""
+    names = [n for n in sorted(SYNTH_CASES) if "rst" in n]
+    assert len(names) >= 6
+    jp = [jpeg_for(n) for n in names]
+    odd = [_with_dri(jpeg_for("c420_640x368_rstrow"), lambda v: v + 1), _with_dri(jpeg_for("c420_512x256_q98_rstrow"), lambda v: v + 1),
+           _with_dri(jpeg_for("c420_640x368_rstrow"), lambda v: v * 2), _with_dri(jpeg_for("c444_384x192_q100_rst7"), lambda v: v - 1)]
+    allj = jp + odd
+    nm = names + ["odd%d" % i for i in range(len(odd))]
+    pts = [J.GRAY8 if n.startswith("gray") else J.RGB8888 for n in nm]
+    opts = [0] * len(allj)
+    pipe = J.Pipeline(gpu_ctx, max_images=32, depth=2, host_threads=2)
+    outs, metas = _surfaces(gpu_ctx, allj, pts, opts)
+    t = pipe.submit(allj, outs, pts, opts)
+    st = pipe.wait(t)
+    _check(gpu_ctx, oracle, allj, pts, opts, outs, metas, st, nm)
+    for i, n in enumerate(names):
+        h = J.PreparedImage(jp[i])
+        idx, dc, flen = pipe.read_index(t, i, h.n_blocks)
+        assert flen == len(h.scan()), n
+        assert np.array_equal(idx, h.block_index()[0]) and np.array_equal(dc, h.block_dc()), n
+        h.close()
+    s = pipe.stats
+    assert s["device_images"] == len(names), s                 # every well-formed restart stream stayed on the device
+    assert s["host_path_images"] == len(odd), s
+    for o in outs:
+        gpu_ctx.free(o[0])
+    pipe.close()

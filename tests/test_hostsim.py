@@ -149,3 +149,80 @@ def test_duplicate_eob_code_takes_the_general_reader(luma_hv, hostsim, oracle):
         inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
         assert hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
         assert np.array_equal(got, want), (luma_hv, pt, opt)
+
+
+@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow",
+                                  "c422_1100x24_rstrow", "c440_300x64_rst5"])
+def test_restart_streams_through_the_segment_walk(name, hostsim, oracle):
+    """Round 2: in the streamed pipeline a stream WITH restart intervals goes through the same segment walk as one without (one
+    lane per 256 bytes instead of one per interval): an interval's end is found by position (the filter recorded where every
+    interval starts), the reference's rounding of ulBitOff without a refill and the predictor reset happen there, and the WRITE
+    pass checks that the marker positions agree with the MCU count.  Index == the serial pre-scan's entry for entry (reader
+    phase, truncation flags, DC predictors, closing entry), decode == the oracle's."""
+    jpeg = jpeg_for(name)
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        for pt, opt in ((2, 0), (0, 2), (3, 8)):
+            if name.startswith("gray") and pt == 2:
+                continue
+            rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+            hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert hrc == 0 and hostsim.hostsim_prescan_used() == 2, (name, hostsim.hostsim_prescan_used())
+            assert hostsim.hostsim_index_equal() == 1
+            assert np.array_equal(got, want), (name, pt, opt)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+
+
+def test_reference_fixtures_with_restart_intervals_through_the_segment_walk(hostsim):
+    """tulips (DRI) and the other fixtures with restart intervals: the segment walk's index == the serial pre-scan's"""
+    from tests.ref_fixtures import GOOD, ref_jpeg
+    hostsim.hostsim_set_device_prescan(2)
+    n = 0
+    try:
+        for name in GOOD:
+            jpeg = ref_jpeg(name)
+            if J.parse(jpeg)["restart_interval"] == 0 or name == "corrupt5":
+                continue
+            p = J.PreparedImage(jpeg)
+            geo = p.geometry(2, 0)
+            got = np.zeros((geo["canvas_h"], geo["canvas_w"] * geo["bpp"]), np.uint8)
+            assert hostsim.hostsim_decode(jpeg, len(jpeg), 2, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], p.info.mcus_x * p.info.mcu_w, p.info.mcus_y * p.info.mcu_h) == 0
+            assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1, name
+            p.close()
+            n += 1
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+    assert n >= 1
+
+
+def _with_dri(jpeg: bytes, f):
+    i = jpeg.index(b"\xff\xdd\x00\x04")
+    v = (jpeg[i + 4] << 8) | jpeg[i + 5]
+    nv = f(v)
+    return jpeg[: i + 4] + bytes([nv >> 8, nv & 255]) + jpeg[i + 6:]
+
+
+@pytest.mark.parametrize("name,f", [("c420_640x368_rstrow", lambda v: v * 2), ("c420_640x368_rstrow", lambda v: v - 1),
+                                    ("c420_640x368_rstrow", lambda v: v + 1),          # same NUMBER of intervals (23), other places
+                                    ("c420_512x256_q98_rstrow", lambda v: v + 1),
+                                    ("c444_384x192_q100_rst7", lambda v: v + 1), ("gray_64x64_rst3", lambda v: 2)])
+def test_restart_markers_that_disagree_with_the_mcu_count(name, f, hostsim, oracle):
+    """The reference restarts by MCU COUNT (jpeg.inl:5339) and never looks where the markers were; the segment walk ends intervals
+    where the filter found markers.  A DRI that does not match the markers makes the two disagree: the WRITE pass notices and the
+    image takes the serial pre-scan -- pixels stay the reference's (garbage, but the same garbage)."""
+    jpeg = _with_dri(jpeg_for(name), f)
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        pt = 0 if name.startswith("gray") else 2
+        rc, want, err = oracle.decode_canvas(jpeg, pt, 0)
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, 0)
+        hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+        assert hostsim.hostsim_prescan_used() == 0            # rejected by the device path
+        if rc == 1:
+            assert hrc == 0 and np.array_equal(got, want)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
