@@ -1034,43 +1034,54 @@ JDA_HD void jda_atomic_or_u32(uint32_t *p, uint32_t v)
     *p |= v;                                         // (the emulator steps the lanes one after another)
 #endif
 }
-// The walk's view of its segment: 64 stream bits in two registers and the two dwords after them on their way from memory (the
-// segment is read where it lies -- global memory, L2 -- one dword per 32 bits consumed, two dwords ahead of the bits in use, so
-// no load sits between two symbols and nothing of the scan is staged in LDS: the tables are all a workgroup keeps there, and
-// the wavefronts a CU holds are bounded by registers, not by 17 KB of slots each).  A symbol is at most 31 bits (code <= 16,
-// magnitude <= 15), so a step advances the window by at most one dword.
+// The walk's view of its segment: 64 stream bits in two registers and the three dwords after them (the segment is read where it
+// lies -- global memory, L2 -- and nothing of the scan is staged in LDS: the tables are all a workgroup keeps there, and the
+// wavefronts a CU holds are bounded by registers, not by 17 KB of slots each).  A symbol is at most 31 bits (code <= 16, magnitude
+// <= 15), so a step advances the window by at most one dword -- a register shuffle, no load: the five dwords are (re)loaded for
+// ALL lanes of the wavefront at once, from wherever each lane stands, every JDA_SEG_REFILL_STEPS steps (jda_seg_walk).  A load
+// inside the step ("the lane that crosses a dword boundary fetches the next one") was a load + its wait in EVERY step of the
+// wavefront: one of 64 unsynchronised lanes crosses every time.  Five dwords are at least 97 bits ahead of the lane: 12 bits per
+// symbol over eight steps; the lane that runs out anyway (or, at an interval end, steps over a dword) reloads on its own (rare).
 struct jda_seg_reader {
     const uint32_t JDA_GLOBAL *d;   // the segment's first dword (readable: JDA_SEG_SLOT bytes)
-    uint32_t idx;                   // dword index of hi
+    uint32_t idx, base;             // dword index of hi now / when the registers were loaded
     uint32_t hi, lo;                // stream bits, first byte on top
-    uint32_t n1, n2;                // dwords idx + 2, idx + 3 as loaded (little endian)
+    uint32_t n1, n2, n3;            // the dwords behind lo, as loaded (little endian); valid while idx - base <= 3
 };
+#define JDA_SEG_REFILL_STEPS 8u
 JDA_HD void jda_seg_reader_init(jda_seg_reader &R, const uint32_t JDA_GLOBAL *d, uint32_t p)
 {
-    R.d = d; R.idx = p >> 5;
+    R.d = d; R.idx = R.base = p >> 5;
     R.hi = __builtin_bswap32(d[R.idx]); R.lo = __builtin_bswap32(d[R.idx + 1u]);
-    R.n1 = d[R.idx + 2u]; R.n2 = d[R.idx + 3u];
+    R.n1 = d[R.idx + 2u]; R.n2 = d[R.idx + 3u]; R.n3 = d[R.idx + 4u];
 }
-// the next 32 bits of the stream at bit p of the segment (p moves forward by at most 31 bits between calls)
+// the next 32 bits of the stream at bit p of the segment
 JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
 {
     const uint32_t wi = p >> 5;
-    if (wi != R.idx) {                                              // (one dword further)
-        R.hi = R.lo; R.lo = __builtin_bswap32(R.n1); R.n1 = R.n2; R.idx = wi;
-        R.n2 = R.d[wi + 3u];
+    if (wi != R.idx) {
+        if ((wi - R.idx != 1u) | (wi - R.base > 3u)) jda_seg_reader_init(R, R.d, p);      // (rare: see above)
+        else { R.hi = R.lo; R.lo = __builtin_bswap32(R.n1); R.n1 = R.n2; R.n2 = R.n3; R.idx = wi; }
     }
     const uint64_t v = ((uint64_t)R.hi << 32) | R.lo;
     return (uint32_t)((v << (p & 31u)) >> 32);
 }
 #define JDA_SEG_READ_DWORDS 68u     // dwords of the scan a walk may touch from its segment's start (64 + the window's reach)
 
-// The walk's own DC table (JDA_LT_DC16, built while the tables are staged): the reference's DC LUT (jpeg.inl:1098-1152) re-laid
-// out like the AC entries -- (code length - 1) << 12 | SSSS << 8 | folded -- so that one 16-bit lookup serves a DC and an AC
-// symbol alike.  "folded" (bit 0): the reference takes code and magnitude from the LUT in one step (:1132-1152) and does not
-// refill between them.
+// The walks' DC entries: the reference's DC LUT (jpeg.inl:1098-1152) re-laid out like the AC entries -- (code length - 1) << 12 |
+// SSSS << 8 | folded -- so that one 16-bit lookup serves a DC and an AC symbol alike.  "folded" (bit 0): the reference takes code
+// and magnitude from the LUT in one step (:1132-1152) and does not refill between them.
+//   JDA_LT_DC16 (the interval walk, behind the decode kernels' tables): 2 x 256 entries under the reference's own index.
+//   JDA_WT_* (the segment walk's own LDS layout): FOUR tables of 2048 entries -- AC 0, AC 1, DC 0, DC 1 -- under the AC tables'
+//   11-bit key (the stream's top 10 bits, or 1024 + the 10 bits behind six leading ones), so that a step computes ONE address:
+//   table number from the block's place in the MCU, key from the stream.  A DC entry under that key is the reference's for every
+//   stream that has those bits, provided no DC code 111110.. is longer than 10 bits (jda_dc_lut_walkable: the front end keeps
+//   such a file -- none seen -- on the serial pre-scan).
 #define JDA_LT_DC16 JDA_LT_BYTES      // 2 x 256 uint16
 #define JDA_LT_DC16_BYTES 1024
 #define JDA_LT_WALK_BYTES (JDA_LT_DC16 + JDA_LT_DC16_BYTES)
+#define JDA_WT_TABLE_BYTES 4096u
+#define JDA_WT_BYTES (4u * JDA_WT_TABLE_BYTES)
 JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
 {
     if (e8 == 0u) return JDA_AC_NONE;
@@ -1080,8 +1091,25 @@ JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
     return ((len - 1u) << 12) | (s << 8) | (fold ? 1u : 0u);
 }
 
-// One walk of a segment.  lt: the tables in the kernels' LDS layout + JDA_LT_DC16; segw: the segment's first dword in the
-// (zero-padded) filtered scan.
+// the segment walk's tables, staged by its workgroup (tid = thread in workgroup): wt holds JDA_WT_BYTES
+JDA_HD void jda_walk_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *wt)
+{
+    const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, tables);
+    jda_chunk16_alias *out = (jda_chunk16_alias *)wt;
+    for (uint32_t i = tid; i < 2u * JDA_WT_TABLE_BYTES / 16u; i += nthreads) {      // both halves of both AC tables -> the kernels' entries
+        jda_chunk16_alias c = blob[(JDA_TB_AC >> 4) + i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c.w[k] = jda_ac_entry(c.w[k] & 0xffffu) | (jda_ac_entry(c.w[k] >> 16) << 16);
+        out[i] = c;
+    }
+    for (uint32_t j = tid; j < 4096u; j += nthreads) {                              // the DC tables under the same key
+        const uint32_t t = j >> 11, idx = jda_dc_lut_index(jda_walk_key_code12(j & 2047u, 0u));
+        const uint8_t JDA_GLOBAL *dc = JDA_G(const uint8_t, tables) + JDA_TB_DC + t * 1024u;
+        ((uint16_t *)(wt + 2u * JDA_WT_TABLE_BYTES))[j] = (uint16_t)jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]);
+    }
+}
+// One walk of a segment.  wt: the walk's tables (jda_walk_tables_from); segw: the segment's first dword in the (zero-padded)
+// filtered scan.
 //
 // A step decodes ONE symbol, DC or AC alike, without a branch on which it is: the lanes of a wavefront sit at unrelated places
 // of their blocks, so "if DC .. else AC .." ran both sides every step -- and every small `if` in the body costs an exec-mask
@@ -1107,18 +1135,25 @@ JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
 // looks at marker positions: the WRITE pass checks that the two agree (every interval end at a multiple of interval_blocks,
 // every such multiple an interval end) and sends the image to the serial pre-scan when they do not.
 template <int OP, bool RST = false>
-JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *lt,
+JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *wt,
                              jda_seg_sum &S, jda_seg_stats &ST)
 {
     const bool CNT = OP == JDA_SEG_COUNT || OP == JDA_SEG_FUSED;      // the segment's sums are wanted
     const bool TOL = OP == JDA_SEG_SPEC || OP == JDA_SEG_FUSED;       // a speculative walk steps over an invalid code
     S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
-    uint32_t p = entry & 63u, b = (entry >> 6) & 7u, k = (entry >> 9) & 63u;
-    // per component: LDS offsets of its DC16 / AC table (ids are 0 or 1)
-    const uint32_t dcb0 = JDA_LT_DC16 + P.dc_id[0] * 512u, dcb1 = JDA_LT_DC16 + P.dc_id[1] * 512u, dcb2 = JDA_LT_DC16 + P.dc_id[2] * 512u;
-    const uint32_t acb0 = JDA_LT_AC + P.ac_id[0] * 4096u, acb1 = JDA_LT_AC + P.ac_id[1] * 4096u, acb2 = JDA_LT_AC + P.ac_id[2] * 4096u;
-    const uint32_t nluma = P.nluma, nblocks = P.nblocks;
+    uint32_t p = entry & 63u, b2 = ((entry >> 6) & 7u) * 2u, k = (entry >> 9) & 63u;      // b2: twice the block's place in the MCU
+    // per place in the MCU, in 2-bit fields (uniform): the block's component, and which of the walk's four tables decodes its
+    // AC symbols (0 / 1) and its DC symbol (2 / 3)
+    uint32_t csel = 0, acsel = 0, dcsel = 0;
+    const uint32_t nluma = P.nluma, nblocks2 = 2u * P.nblocks;
+    const uint32_t aid0 = P.ac_id[0] & 1u, aid1 = P.ac_id[1] & 1u, aid2 = P.ac_id[2] & 1u, did0 = P.dc_id[0] & 1u, did1 = P.dc_id[1] & 1u, did2 = P.dc_id[2] & 1u;
+#pragma unroll
+    for (uint32_t i = 0; i < 6u; i++) {                             // (constant indices only: a dynamic one would move P to scratch memory)
+        const uint32_t ci = i < nluma ? 0u : i - nluma + 1u;
+        const uint32_t a = ci == 0u ? aid0 : (ci == 1u ? aid1 : aid2), d = ci == 0u ? did0 : (ci == 1u ? did1 : did2);
+        if (i < P.nblocks && ci < 3u) { csel |= ci << (2u * i); acsel |= a << (2u * i); dcsel |= (2u + d) << (2u * i); }
+    }
     // WRITE: the reference reader (pBuf, ulBitOff), the block ordinal and the DC predictors at the entry
     uint32_t pos = 0, off = 0, g = 0, pos_pre = 0, off_pre = 0;
     int32_t pred0 = 0, pred1 = 0, pred2 = 0;
@@ -1151,14 +1186,20 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         if (OP == JDA_SEG_WRITE) left_blocks = P.interval_blocks - (g - (k != 0u ? 1u : 0u)) % P.interval_blocks;   // (k != 0: block g - 1 is still open)
     }
     jda_seg_reader R;
-    jda_seg_reader_init(R, segw, p);
-    while ((p < JDA_SEG_BITS) & !stop) {
+    bool go = p < JDA_SEG_BITS;
+    while (go) {
+    jda_seg_reader_init(R, segw, p);                                // every lane of the wavefront from where it stands: one wait for all of them
+    uint32_t since = 0;
+    do {
+#ifdef JDA_SEG_STEP_HOOK
+        JDA_SEG_STEP_HOOK();                                        // (host simulator: counts the steps of a walk)
+#endif
         if (RST && p >= next_bit) {                                 // (a walk off the decoder's path ran over an interval start: catch up)
             nr++; next_bit = (rpos[nr] << 3) - seg_bit0;
             if (nr > P.n_intervals) { nr = P.n_intervals; next_bit = 0xffffffffu; }
         }
         const bool isdc0 = k == 0;
-        const uint32_t c = b < nluma ? 0u : b - nluma + 1u;
+        const uint32_t c = jda_bfe(csel, b2, 2u);
         if (OP == JDA_SEG_WRITE) {                                  // a block starts here (jpeg.inl:2129-2165): by selects, but for the two stores
             const bool term = isdc0 & (g >= P.n_blocks_total);      // past the image: the reader as the last block left it closes the index
             const bool begin = isdc0 & !term;
@@ -1180,12 +1221,11 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             g += begin ? 1u : 0u;
         }
         const uint32_t w = jda_seg_reader_peek(R, p);
-        // one 16-bit lookup: the DC16 table by the top 6 / 7 bits, or the AC table by an 11-bit key (short / long half)
-        const uint32_t dcb = c == 0 ? dcb0 : (c == 1 ? dcb1 : dcb2), acb = c == 0 ? acb0 : (c == 1 ? acb1 : acb2);
-        const uint32_t code12 = w >> 20;
-        const uint32_t a_dc = dcb + 2u * (code12 >= 0xf80u ? (code12 & 0xffu) : (w >> 26));
-        const uint32_t a_ac = acb + 2u * jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
-        const uint32_t e = *(const uint16_t *)(lt + (isdc0 ? a_dc : a_ac));
+        // one 16-bit lookup, one address: the table by the block's place in the MCU and DC / AC, the entry by the 11-bit key (the
+        // stream's top 10 bits, or 1024 + the 10 bits behind six leading ones)
+        const uint32_t tsel = jda_bfe(isdc0 ? dcsel : acsel, b2, 2u);
+        const uint32_t key = jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
+        const uint32_t e = *(const uint16_t *)(wt + ((tsel << 12) | (key << 1)));
         const uint32_t elow = e & 0xffu;
         // no such code (:2137-2138, :2237-2238).  A speculative walk that is not on the decoder's path yet may meet anything: it steps
         // on one bit and keeps looking (a walk that gave up would hand "dead" down the chain of segments, one per round) -- a
@@ -1233,7 +1273,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         }
         p = p1 + sz;
         const bool ends = (eob | (kk + 1u >= 64u)) & !inval;
-        const uint32_t bn = b + 1u == nblocks ? 0u : b + 1u;
+        const uint32_t bn = b2 + 2u == nblocks2 ? 0u : b2 + 2u;
         // RST: this symbol completes an MCU within 7 bits of the next interval's start = it completes the interval
         const bool iend = RST & ends & live & (bn == 0u) & (next_bit - p < 8u);
         const bool hold = iend & eob;                               // the refill after an interval's closing EOB waits for the rounding
@@ -1253,7 +1293,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             U &= hold ? 0xffffffffu : ~(f - (f >> 4));
         }
         k = (ends | inval) ? 0u : kk + 1u;
-        b = ends ? bn : b;
+        b2 = ends ? bn : b2;
 #if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 2))
         if (OP == JDA_SEG_WRITE && ends && pending) { JDA_G(uint32_t, P.blk_index)[pend_g] = pend; pending = false; }
 #endif
@@ -1281,9 +1321,11 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                 }
                 p = next_bit;
                 nr++; next_bit = nr <= P.n_intervals ? (rpos[nr] << 3) - seg_bit0 : 0xffffffffu;
-                if (p < JDA_SEG_BITS) jda_seg_reader_init(R, segw, p);     // (a long symbol + the padding may step over a whole dword)
             }
         }
+        go = (p < JDA_SEG_BITS) & !stop;
+        since++;
+    } while (go & (since < JDA_SEG_REFILL_STEPS));
     }
     if (OP == JDA_SEG_WRITE && pending && !bad) jda_atomic_or_u32(P.blk_index + pend_g, pend);      // the block goes on in the next segment
     if (OP == JDA_SEG_WRITE) { ST.max_ac_bits = max_ac; ST.max_abs_dc = max_dc; }
@@ -1294,7 +1336,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         for (int j = 0; j < 6; j++) map |= ((U >> (5 * j)) & 7u) << (3 * j);
         S.phase_map = map;
     }
-    return (p - JDA_SEG_BITS) | (b << 6) | (k << 9);
+    return (p - JDA_SEG_BITS) | (b2 << 5) | (k << 9);
 }
 
 template <bool EXACT>

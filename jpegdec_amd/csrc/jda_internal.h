@@ -24,6 +24,31 @@
                                   // entry behind the last block is the reader as the last block left it: offset 0..64, no flag.)
 #define JDA_INDEX_TRUNC 0x40u     // the reference truncates a magnitude read of this block: P1 must follow its ulBitOff
 
+// ---- the segment walk's 11-bit table key (jda_device_core.h, JDA_WT_*) and the reference's DC LUT index, shared with the front end
+#if defined(__HIPCC__)
+#define JDA_HD_INLINE __host__ __device__ static inline
+#else
+#define JDA_HD_INLINE static inline
+#endif
+// the reference's DC LUT index for the 12 stream bits code12 (jpeg.inl:2129-2136: short half by the top 6 bits; codes 11111..: 128 + the low 7 bits)
+JDA_HD_INLINE uint32_t jda_dc_lut_index(uint32_t code12) { return code12 >= 0xf80u ? (code12 & 0xffu) : (code12 >> 6); }
+// the 12 stream bits an 11-bit walk key stands for (low: the two bits a short key does not have)
+JDA_HD_INLINE uint32_t jda_walk_key_code12(uint32_t key, uint32_t low) { return key < 1024u ? ((key << 2) | low) : (0xfc0u | ((key - 1024u) >> 4)); }
+// Can the walk's DC tables stand for DC LUT t of the blob?  Only a short key of the form 111110xxxx leaves bits the reference
+// looks at (it takes 12) undetermined: it must not matter what they are.
+static inline int jda_dc_lut_walkable(const uint8_t *tables, uint32_t t)
+{
+    const uint8_t *dc = tables + JDA_TB_DC + t * 1024u;
+    for (uint32_t key = 992u; key < 1008u; key++) {
+        const uint32_t i0 = jda_dc_lut_index(jda_walk_key_code12(key, 0u));
+        for (uint32_t low = 1; low < 4u; low++) {
+            const uint32_t i = jda_dc_lut_index(jda_walk_key_code12(key, low));
+            if (dc[i] != dc[i0] || dc[i + 512u] != dc[i0 + 512u]) return 0;
+        }
+    }
+    return 1;
+}
+
 // kinds of MCU the kernels are specialised for
 enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2, JDA_MODE_422 = 3 /* h2v1, MCU 16x8 */, JDA_MODE_440 = 4 /* h1v2, MCU 8x16 */, JDA_N_MODES = 5 };
 

@@ -487,6 +487,22 @@ extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint3
     return hipGetLastError();
 }
 
+// wave-wide maximum / sum of a value of every ACTIVE lane (inactive lanes contribute nothing), the same in every lane
+__device__ __forceinline__ uint32_t jda_wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t jda_wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
 // ------------------------------------------------------------------------------------------------
 // Device pre-scan for streams WITHOUT restart markers (the algorithm is described at jda_seg_walk): one
 // lane per 256-byte segment of the filtered scan, a wavefront's 64 consecutive segments staged in LDS with one
@@ -504,7 +520,7 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
     // does not want to look at the counters in between)
     if (OP == JDA_SEG_SPEC && round >= 1 && JDA_G(const uint32_t, P.stats)[8u + round - 1u] == 0u) return;
     uint8_t *tab = lds;
-    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true, true);       // the tables (with the walk's DC table) are all that is staged
+    jda_walk_tables_from(P.tables, threadIdx.x, 256u, tab);                 // the walk's four tables are all that is staged
     const bool in_range = seg < P.n_segs;
     // what this lane has to do
     uint32_t *e_cur = (round & 1u) ? P.entry_nxt : P.entry_cur, *e_nxt = (round & 1u) ? P.entry_cur : P.entry_nxt;
@@ -515,7 +531,8 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
     } else if (in_range) entry = ((round & 1u) ? P.entry_nxt : P.entry_cur)[seg];
     if (OP == JDA_SEG_WRITE && in_range && P.seg_start[(size_t)seg * 5] > P.n_blocks_total) need = false;   // past the image
     __syncthreads();                                                 // the tables are in LDS
-    if (!in_range) return;
+    if (!in_range && OP != JDA_SEG_WRITE) return;                    // (the write pass keeps its wavefronts whole for the reduction of their results)
+    if (!in_range) need = false;
     const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
     jda_seg_sum S;
     jda_seg_stats ST;
@@ -539,12 +556,22 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
     } else if (need) {
         if (P.restart_pos) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
         else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
-        if (ST.bad) atomicOr(&P.stats[0], 1u);
-        if (ST.mismatch) atomicOr(&P.stats[5], 1u);
-        if (ST.terminal) atomicAdd(&P.stats[1], 1u);
-        if (ST.max_ac_bits) atomicMax(&P.stats[2], ST.max_ac_bits);
-        if (ST.max_abs_dc) atomicMax(&P.stats[3], ST.max_abs_dc);
-        if (ST.trunc_events) atomicAdd(&P.stats[4], ST.trunc_events);
+    }
+    if (OP == JDA_SEG_WRITE) {
+        // the image's result words, ONE atomic per wavefront and word: every lane has maxima to report, and 6,500 lanes of an image
+        // finishing together on the same two addresses cost a quarter of the pass (1.54 -> 1.13 ms per 64-image batch)
+        if (!need) { ST.bad = 0; ST.mismatch = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; }
+        const uint32_t m_ac = jda_wave_max_u32(ST.max_ac_bits), m_dc = jda_wave_max_u32(ST.max_abs_dc), n_tr = jda_wave_sum_u32(ST.trunc_events);
+        const bool any_bad = __builtin_amdgcn_ballot_w64(ST.bad != 0) != 0, any_mis = __builtin_amdgcn_ballot_w64(ST.mismatch != 0) != 0;
+        const uint32_t n_term = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ST.terminal != 0));
+        if ((threadIdx.x & 63u) == 0u) {
+            if (any_bad) atomicOr(&P.stats[0], 1u);
+            if (any_mis) atomicOr(&P.stats[5], 1u);
+            if (n_term) atomicAdd(&P.stats[1], n_term);
+            if (m_ac) atomicMax(&P.stats[2], m_ac);
+            if (m_dc) atomicMax(&P.stats[3], m_dc);
+            if (n_tr) atomicAdd(&P.stats[4], n_tr);
+        }
     }
 }
 
@@ -574,7 +601,7 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
     uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
     uint8_t *tab = lds;
-    jda_p0_tables_from(P.tables, threadIdx.x, 256u, tab, true, true);
+    jda_walk_tables_from(P.tables, threadIdx.x, 256u, tab);
     __syncthreads();                                                 // the tables: all that is staged (a walk reads its segment from memory)
     for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < count; base += gridDim.x * 256u) {
         const uint32_t item = base + lane;
@@ -590,12 +617,20 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
             uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
             o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
         }
-        if (seg + 1u < P.n_segs) {
-            if (round == 0) E[seg + 1u] = x;                         // (nobody reads the entry states in round 0)
-            else if (x != E[seg + 1u]) {
-                E[seg + 1u] = x;
-                const uint32_t at = atomicAdd(&P.stats[8u + round + 1u], 1u);
-                if (at < P.worklist_cap) wl_out[at] = seg + 1u;
+        if (round == 0) { if (seg + 1u < P.n_segs) E[seg + 1u] = x; }   // (nobody reads the entry states in round 0)
+        else {
+            const bool changed = seg + 1u < P.n_segs && x != E[seg + 1u];
+            const uint64_t who = __builtin_amdgcn_ballot_w64(changed);     // one atomic per wavefront for its places on the next list
+            if (who) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(who);
+                uint32_t at0 = 0;
+                if (lane == first) at0 = atomicAdd(&P.stats[8u + round + 1u], (uint32_t)__builtin_popcountll(who));
+                at0 = (uint32_t)__builtin_amdgcn_readlane((int)at0, (int)first);
+                if (changed) {
+                    E[seg + 1u] = x;
+                    const uint32_t at = at0 + (uint32_t)__builtin_popcountll(who & ((1ull << lane) - 1ull));
+                    if (at < P.worklist_cap) wl_out[at] = seg + 1u;
+                }
             }
         }
     }
@@ -604,11 +639,17 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_LT_WALK_BYTES;
+    // Round 0 (exit states only: the lightest walk) runs FASTER with four workgroups per CU than with the eight its 16 KB of tables
+    // allow (455 -> 365 us per 64-image batch; five: 407, two: 506): it is launched with 16 KB more than it uses (32 KB per workgroup: four fit).  The
+    // counting rounds do not care (540 -> 585 at four).  JDA_WALK_LDS_R0 / JDA_WALK_LDS_R1: extra bytes, for measuring.
+    static const int lds_extra0 = []() { const char *e = getenv("JDA_WALK_LDS_R0"); return e ? atoi(e) : 16384; }();
+    static const int lds_extra1 = []() { const char *e = getenv("JDA_WALK_LDS_R1"); return e ? atoi(e) : 0; }();
+    const int lds_max = JDA_WT_BYTES + (lds_extra0 > lds_extra1 ? lds_extra0 : lds_extra1);
+    const int lds_bytes = JDA_WT_BYTES + (round == 0 ? lds_extra0 : lds_extra1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -620,75 +661,130 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     return hipGetLastError();
 }
 
-// Exclusive sums over the segments of one image (one wavefront per image, 64 segments per step): first block ordinal and
-// DC predictors at every segment's entry (wave prefix sums + a carry), and the reference window's byte lag (composition of
-// the segments' phase maps: eight values wide, so it is walked lane by lane with readlane -- 64 scalar steps per 64
-// segments).  A segment that met an invalid code ends the sums: harmless only behind the image's last block.
-// Result words: stats[6] = 1 when the index can be written (enough blocks, no bad code before the end).
-__device__ __forceinline__ uint32_t jda_wave_incl_sum_u32(uint32_t v)
+// One element of the scan over an image's segments, and its (associative) combination "A, then B": block starts add up; the
+// window's byte lag is a map (field j = exit lag for entry lag j) and maps compose; the DC sums add up, but start over where an
+// interval ended inside a segment (flag bit 0: B's sums count from its last restart).
+struct jda_sum_el { uint32_t nblk, map, flag; uint32_t d0, d1, d2; };
+#define JDA_MAP_IDENTITY 0x2c688u                                   // 3-bit fields: j -> j, j = 0..5
+__device__ __forceinline__ uint32_t jda_map_compose(uint32_t a, uint32_t b)
 {
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
-    return (uint32_t)x;
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 6u; j++) r |= ((b >> (3u * ((a >> (3u * j)) & 7u))) & 7u) << (3u * j);
+    return r;
+}
+__device__ __forceinline__ jda_sum_el jda_sum_identity() { jda_sum_el e; e.nblk = 0; e.map = JDA_MAP_IDENTITY; e.flag = 0; e.d0 = e.d1 = e.d2 = 0; return e; }
+__device__ __forceinline__ jda_sum_el jda_sum_combine(const jda_sum_el &A, const jda_sum_el &B)
+{
+    jda_sum_el R;
+    const bool rst = (B.flag & 1u) != 0;
+    R.nblk = A.nblk + B.nblk; R.map = jda_map_compose(A.map, B.map); R.flag = A.flag | B.flag;
+    R.d0 = rst ? B.d0 : A.d0 + B.d0; R.d1 = rst ? B.d1 : A.d1 + B.d1; R.d2 = rst ? B.d2 : A.d2 + B.d2;
+    return R;
+}
+__device__ __forceinline__ jda_sum_el jda_sum_shfl_up(const jda_sum_el &v, int d)
+{
+    jda_sum_el r;
+    r.nblk = (uint32_t)__shfl_up((int)v.nblk, d, 64); r.map = (uint32_t)__shfl_up((int)v.map, d, 64); r.flag = (uint32_t)__shfl_up((int)v.flag, d, 64);
+    r.d0 = (uint32_t)__shfl_up((int)v.d0, d, 64); r.d1 = (uint32_t)__shfl_up((int)v.d1, d, 64); r.d2 = (uint32_t)__shfl_up((int)v.d2, d, 64);
+    return r;
+}
+__device__ __forceinline__ jda_sum_el jda_sum_wave_scan(jda_sum_el v, uint32_t lane)      // inclusive, all 64 lanes active
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const jda_sum_el o = jda_sum_shfl_up(v, d);
+        if (lane >= (uint32_t)d) v = jda_sum_combine(o, v);
+    }
+    return v;
+}
+// a chunk = the 64 segments of one wavefront step: every lane's element (what is behind the chunk's first bad segment is dead:
+// identity) and the chunk-local verdict
+__device__ __forceinline__ jda_sum_el jda_sum_load_chunk(const jda_segscan_params &P, uint32_t chunk, uint32_t lane, uint32_t &first_bad)
+{
+    const uint32_t seg = chunk * 64u + lane;
+    jda_sum_el e = jda_sum_identity();
+    uint32_t bad = 0;
+    if (seg < P.n_segs) {
+        const uint32_t JDA_GLOBAL *su = JDA_G(const uint32_t, P.seg_sum) + (size_t)seg * 6;
+        e.nblk = su[0]; e.d0 = su[1]; e.d1 = su[2]; e.d2 = su[3]; e.map = su[4]; bad = su[5] & 1u; e.flag = (su[5] & JDA_SEG_HAS_RESTART) ? 1u : 0u;
+    }
+    const uint64_t badmask = __builtin_amdgcn_ballot_w64(bad != 0);
+    first_bad = badmask ? (uint32_t)__builtin_ctzll(badmask) : 64u;
+    if (lane > first_bad) e = jda_sum_identity();                   // (the bad segment's own block count still counts; nothing behind it does)
+    return e;
 }
 
-__global__ __launch_bounds__(64)
+// Exclusive scan over the segments of one image: first block ordinal, DC predictors and the reference window's byte lag at every
+// segment's entry.  One workgroup of 16 wavefronts per image: every wavefront scans chunks of 64 segments (chunk, chunk + 16, ..)
+// for their aggregates, wavefront 0 scans the aggregates (<= 2,048 of them: 32 MB of scan), every wavefront scans its chunks again
+// with the chunk's carry-in and writes seg_start.  (One wavefront walking the segments in order -- 64 serial steps per chunk for
+// the lag, then also for the predictors -- took 0.23-0.49 ms per 64-image batch with nothing beside it on the GPU.)
+// A segment that met an invalid code ends the sums: harmless only behind the image's last block.
+// Result word: stats[6] = 1 when the index can be written (enough blocks, no bad code before the end).
+#define JDA_SUMS_WAVES 16u
+#define JDA_SUMS_MAX_CHUNKS 2048u
+__global__ __launch_bounds__(64 * JDA_SUMS_WAVES)
 void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
 {
+    __shared__ jda_sum_el agg[JDA_SUMS_MAX_CHUNKS];                 // a chunk's aggregate, then its carry-in; flag bit 1: the chunk has a bad segment, bit 2: dead
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.x]);
-    const uint32_t lane = threadIdx.x;
-    uint32_t *seg_start = const_cast<uint32_t *>(P.seg_start);
-    uint32_t g_carry = 0, p0 = 0, p1 = 0, p2 = 0, j = 0;          // wave-uniform running values
-    bool ended = false, ok = true;
-    for (uint32_t base = 0; base < P.n_segs; base += 64u) {
-        const uint32_t seg = base + lane;
-        const bool in = seg < P.n_segs;
-        uint32_t nblk = 0, d0 = 0, d1 = 0, d2 = 0, map = 0x00fac688u /* identity: j -> j */, bad = 0, rst = 0;
-        if (in && !ended) {
-            const uint32_t *su = P.seg_sum + (size_t)seg * 6;
-            nblk = su[0]; d0 = su[1]; d1 = su[2]; d2 = su[3]; map = su[4]; bad = su[5] & 1u; rst = su[5] & JDA_SEG_HAS_RESTART;
-        }
-        // the first bad segment of this step (its own block count still counts; nothing behind it does)
-        const uint64_t badmask = __builtin_amdgcn_ballot_w64(bad != 0);
-        const uint32_t first_bad = badmask ? (uint32_t)__builtin_ctzll(badmask) : 64u;
-        if (lane > first_bad) { nblk = 0; d0 = d1 = d2 = 0; rst = 0; }
-        const uint32_t in_g = jda_wave_incl_sum_u32(nblk);
-        // window lag and DC predictors at every lane's entry: serial over the 64 segments of this step -- the lag is a composition of
-        // maps, the predictors are sums that start over where an interval ended inside a segment (its sums count from there)
-        uint32_t my_j = 0, jj = j, my0 = 0, my1 = 0, my2 = 0, r0 = p0, r1 = p1, r2 = p2;
-        for (uint32_t l = 0; l < 64u; l++) {
-            if (lane == l) { my_j = jj; my0 = r0; my1 = r1; my2 = r2; }
-            const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)map, (int)l);
-            jj = (m >> (3u * jj)) & 7u;
-            const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)rst, (int)l);
-            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)l), e1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)l), e2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)l);
-            r0 = fl ? e0 : r0 + e0; r1 = fl ? e1 : r1 + e1; r2 = fl ? e2 : r2 + e2;
-        }
-        if (in) {
-            uint32_t *st = seg_start + (size_t)seg * 5;
-            const bool dead = ended || lane > first_bad;            // behind a bad code: the write pass skips these
-            const uint32_t gs = g_carry + in_g - nblk;
-            st[0] = dead ? 0xfffffff0u : (gs > 0xfffffff0u ? 0xfffffff0u : gs);
-            st[1] = my0; st[2] = my1; st[3] = my2; st[4] = my_j;
-        }
-        g_carry += (uint32_t)__builtin_amdgcn_readlane((int)in_g, 63);
-        p0 = r0; p1 = r1; p2 = r2;
-        j = jj;
-        if (!ended && badmask) { ended = true; if (g_carry < P.n_blocks_total + 1u) ok = false; }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_chunks = (P.n_segs + 63u) / 64u;
+    if (n_chunks > JDA_SUMS_MAX_CHUNKS) { if (threadIdx.x == 0) P.stats[6] = 0; return; }    // (the front end admits no scan that long)
+    for (uint32_t c = wave; c < n_chunks; c += JDA_SUMS_WAVES) {    // ---- chunk aggregates
+        uint32_t first_bad;
+        const jda_sum_el incl = jda_sum_wave_scan(jda_sum_load_chunk(P, c, lane, first_bad), lane);
+        if (lane == 63u) { agg[c] = incl; agg[c].flag = (incl.flag & 1u) | (first_bad < 64u ? 2u : 0u); }
     }
-    if (g_carry < P.n_blocks_total + 1u) ok = false;               // the scan ends before the image does
-    if (lane == 0) P.stats[6] = ok ? 1u : 0u;
+    __syncthreads();
+    if (wave == 0) {                                                // ---- every chunk's carry-in
+        jda_sum_el carry = jda_sum_identity();
+        bool ended = false;
+        for (uint32_t base = 0; base < n_chunks; base += 64u) {
+            const uint32_t c = base + lane;
+            jda_sum_el e = (c < n_chunks && !ended) ? agg[c] : jda_sum_identity();
+            const uint64_t bm = __builtin_amdgcn_ballot_w64((e.flag & 2u) != 0);
+            const uint32_t fb = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+            if (lane > fb) e = jda_sum_identity();                  // chunks behind the first bad one are dead
+            e.flag &= 1u;
+            const jda_sum_el incl = jda_sum_wave_scan(e, lane);
+            jda_sum_el excl = jda_sum_shfl_up(incl, 1);
+            if (lane == 0) excl = jda_sum_identity();
+            jda_sum_el pre = jda_sum_combine(carry, excl);
+            pre.flag = (ended || lane > fb) ? 4u : 0u;
+            if (c < n_chunks) agg[c] = pre;
+            jda_sum_el last;                                        // the whole step, from lane 63
+            last.nblk = (uint32_t)__shfl((int)incl.nblk, 63, 64); last.map = (uint32_t)__shfl((int)incl.map, 63, 64); last.flag = (uint32_t)__shfl((int)incl.flag, 63, 64);
+            last.d0 = (uint32_t)__shfl((int)incl.d0, 63, 64); last.d1 = (uint32_t)__shfl((int)incl.d1, 63, 64); last.d2 = (uint32_t)__shfl((int)incl.d2, 63, 64);
+            carry = jda_sum_combine(carry, last);
+            if (bm) ended = true;
+        }
+        if (lane == 0) P.stats[6] = carry.nblk >= P.n_blocks_total + 1u ? 1u : 0u;     // else: the scan ends before the image does
+    }
+    __syncthreads();
+    uint32_t *seg_start = const_cast<uint32_t *>(P.seg_start);
+    for (uint32_t c = wave; c < n_chunks; c += JDA_SUMS_WAVES) {    // ---- every segment's entry values
+        uint32_t first_bad;
+        const jda_sum_el incl = jda_sum_wave_scan(jda_sum_load_chunk(P, c, lane, first_bad), lane);
+        jda_sum_el excl = jda_sum_shfl_up(incl, 1);
+        if (lane == 0) excl = jda_sum_identity();
+        const jda_sum_el in = agg[c];
+        const jda_sum_el pre = jda_sum_combine(in, excl);
+        const uint32_t seg = c * 64u + lane;
+        if (seg < P.n_segs) {
+            uint32_t *st = seg_start + (size_t)seg * 5;
+            const bool dead = (in.flag & 4u) != 0 || lane > first_bad;       // behind a bad code: the write pass skips these
+            st[0] = dead ? 0xfffffff0u : (pre.nblk > 0xfffffff0u ? 0xfffffff0u : pre.nblk);
+            st[1] = pre.d0; st[2] = pre.d1; st[3] = pre.d2; st[4] = pre.map & 7u;      // (the lag the scan starts with is 0: field 0 of the composed map)
+        }
+    }
 }
 
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream)
 {
     if (n_images == 0) return hipSuccess;
-    hipLaunchKernelGGL(jda_segscan_sums, dim3(n_images), dim3(64), 0, stream, params);
+    hipLaunchKernelGGL(jda_segscan_sums, dim3(n_images), dim3(64 * JDA_SUMS_WAVES), 0, stream, params);
     return hipGetLastError();
 }
 
@@ -697,7 +793,7 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
 extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_LT_WALK_BYTES;          // the tables only: 11.5 KB per workgroup
+    const int lds_bytes = JDA_WT_BYTES;               // the tables only: 16 KB per workgroup
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -11,6 +11,8 @@
 
 #include <vector>
 
+static unsigned g_seg_steps = 0;
+#define JDA_SEG_STEP_HOOK() (g_seg_steps++)
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
 
@@ -88,9 +90,9 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         const uint32_t n_segs = sl / JDA_SEG_BYTES + 1u;
         std::vector<uint32_t> padded(((size_t)n_segs * JDA_SEG_BYTES + 16) / 4 + 1, 0);
         memcpy(padded.data(), scan, sl);
-        std::vector<uint64_t> lt_store((JDA_LT_WALK_BYTES + 7) / 8);
+        std::vector<uint64_t> lt_store((JDA_WT_BYTES + 7) / 8);
         uint8_t *lt = (uint8_t *)lt_store.data();
-        for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables_from(tables, tid, 256, lt, true, true);
+        for (uint32_t tid = 0; tid < 256; tid++) jda_walk_tables_from(tables, tid, 256, lt);
 
         std::vector<uint32_t> ea(n_segs + 1, 0), eb(n_segs + 1, 0), seg_sum((size_t)n_segs * 6), seg_start((size_t)n_segs * 5, 0);
         jda_segscan_params P;
@@ -184,15 +186,23 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         }
         memset(&ST, 0, sizeof(ST));
         uint32_t terminal = 0;
+        std::vector<unsigned> steps_of(n_segs, 0);
         for (uint32_t seg = 0; seg < n_segs; seg++) {           // WRITE
+            g_seg_steps = 0;
             if (seg_start[(size_t)seg * 5] > P.n_blocks_total) continue;
             const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
             jda_seg_stats T1;
             memset(&T1, 0, sizeof(T1));
             if (rst) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1); else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1);
+            steps_of[seg] = g_seg_steps;
             ST.bad |= T1.bad | T1.mismatch; terminal += T1.terminal; ST.trunc_events += T1.trunc_events;
             if (T1.max_ac_bits > ST.max_ac_bits) ST.max_ac_bits = T1.max_ac_bits;
             if (T1.max_abs_dc > ST.max_abs_dc) ST.max_abs_dc = T1.max_abs_dc;
+        }
+        if (getenv("HOSTSIM_SEGDEBUG")) {       // how uneven are the walks of the 64 lanes of a wavefront?
+            double sum = 0, summax = 0; unsigned mx = 0;
+            for (uint32_t b0 = 0; b0 < n_segs; b0 += 64) { unsigned m = 0; for (uint32_t i = b0; i < n_segs && i < b0 + 64; i++) { sum += steps_of[i]; if (steps_of[i] > m) m = steps_of[i]; } summax += 64.0 * m; if (m > mx) mx = m; }
+            fprintf(stderr, "steps per segment: mean %.1f, mean of the wavefronts' maxima %.1f, max %u (lane efficiency %.2f)\n", sum / n_segs, summax / 64.0 / ((n_segs + 63) / 64), mx, sum / summax);
         }
         if (ok && !ST.bad && terminal == 1) {
             g_prescan_trunc = ST.trunc_events;
