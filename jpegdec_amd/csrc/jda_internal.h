@@ -112,7 +112,9 @@ struct jda_filter_params {
     uint32_t *restart_pos;       // [0] = 0, then the filtered offset at which each RSTn marker stood (first restart_cap entries)
     uint32_t *result;            // [0] filtered length, [1] number of RSTn markers
     uint32_t raw_len, restart_cap;
+    uint32_t *work;              // JDA_FILTER_WORK_BYTES(raw_len): the chunks' transition functions and entry values
 };
+#define JDA_FILTER_WORK_BYTES(raw_len) (((size_t)(raw_len) / 16384u + 1u) * 20u)
 
 
 // What the host makes of one file when the GPU does everything else (jda_pipeline): see jda_front_prepare in jda_frontend.cpp

@@ -814,8 +814,16 @@ extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint3
 // (xx != 0, also FF FF) -> both bytes dropped, a trailing FF dropped; the offsets at which RSTn markers stood are kept).
 // It is a two-state machine over the bytes -- "normal" / "the previous byte was an unpaired FF" -- so it parallelises as a
 // scan of state-transition functions: every thread runs its 16 bytes from both possible incoming states (end state,
-// bytes emitted, markers seen), a workgroup-wide scan composes them, and a second walk from the now known state writes.
-// One workgroup per image walks the scan in 16 KB steps, carrying state and output offset.
+// bytes emitted, markers seen) and the functions compose.  Three launches over 16 KB chunks of every image of a batch:
+//   jda_filter_count   one workgroup per chunk: the chunk's function
+//   jda_filter_carry   one wavefront per image: scan of its chunks' functions -> state / output offset / marker count at every
+//                      chunk's entry, the image's totals, the sentinel behind the restart positions
+//   jda_filter_write   one workgroup per chunk: the scan inside the chunk, output bytes staged in LDS at the alignment they
+//                      will have in memory and copied out 16 bytes per thread
+// (Round 1's filter was one workgroup per image walking its chunks in order, a byte store per output byte: 1.0-1.6 ms per batch
+// of 64 on 64 CUs -- which a decode kernel launched meanwhile could not use: its workgroups need a CU's whole LDS, and the ones
+// that had to wait started a millisecond late with a full share of the tiles.)
+#define JDA_FILTER_CHUNK 16384u
 struct jda_fsm { uint32_t w0, w1; };   // w0: end state for incoming 0 | for incoming 1 << 1 | emitted (in 0) << 2 | emitted (in 1) << 17; w1: markers (in 0) | (in 1) << 16
 __device__ __forceinline__ jda_fsm jda_fsm_compose(jda_fsm A, jda_fsm B)     // A first, then B
 {
@@ -830,87 +838,180 @@ __device__ __forceinline__ jda_fsm jda_fsm_compose(jda_fsm A, jda_fsm B)     // 
     R.w1 = r0 | (r1 << 16);
     return R;
 }
+#define JDA_FSM_IDENTITY_W0 2u          // state 0 -> 0, 1 -> 1, nothing emitted
+// this thread's 16 bytes of the chunk (valid: how many of them exist) and their function
+__device__ __forceinline__ jda_fsm jda_filter_thread(const jda_filter_params &P, uint32_t chunk, uint32_t tid, uint32_t b[4], uint32_t &valid)
+{
+    const uint32_t off = chunk * JDA_FILTER_CHUNK + tid * 16u;
+    valid = off >= P.raw_len ? 0u : (P.raw_len - off < 16u ? P.raw_len - off : 16u);
+    b[0] = b[1] = b[2] = b[3] = 0;
+    if (valid) {                                                  // (the raw buffer is padded to a multiple of 16 bytes)
+        const jda_chunk16_alias v = *(const jda_chunk16_alias JDA_GLOBAL *)(JDA_G(const uint8_t, P.raw) + off);
+        b[0] = v.w[0]; b[1] = v.w[1]; b[2] = v.w[2]; b[3] = v.w[3];
+    }
+    uint32_t s0 = 0, s1 = 1, n0 = 0, n1 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        const bool live = k < valid, ff = c == 0xffu, zero = c == 0u, rst = (c & 0xf8u) == 0xd0u;
+        if (live) {
+            n0 += s0 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r0 += (s0 && rst) ? 1u : 0u; s0 = s0 ? 0u : (ff ? 1u : 0u);
+            n1 += s1 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r1 += (s1 && rst) ? 1u : 0u; s1 = s1 ? 0u : (ff ? 1u : 0u);
+        }
+    }
+    jda_fsm X;
+    X.w0 = s0 | (s1 << 1) | (n0 << 2) | (n1 << 17);
+    X.w1 = r0 | (r1 << 16);
+    return X;
+}
+// inclusive scan of the functions of a workgroup's 1024 threads (wt: 16 entries of LDS); total: the whole chunk's
+__device__ __forceinline__ jda_fsm jda_fsm_block_scan(jda_fsm v, uint32_t tid, jda_fsm *wt, jda_fsm &total)
+{
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        jda_fsm o;
+        o.w0 = (uint32_t)__shfl_up((int)v.w0, d, 64); o.w1 = (uint32_t)__shfl_up((int)v.w1, d, 64);
+        if (lane >= (uint32_t)d) v = jda_fsm_compose(o, v);
+    }
+    if (lane == 63u) wt[wave] = v;
+    __syncthreads();
+    jda_fsm pre; pre.w0 = JDA_FSM_IDENTITY_W0; pre.w1 = 0;
+    total = pre;
+    for (uint32_t w = 0; w < 16u; w++) {                          // (uniform: sixteen wavefront totals)
+        const jda_fsm t = wt[w];
+        if (w < wave) pre = jda_fsm_compose(pre, t);
+        total = jda_fsm_compose(total, t);
+    }
+    return jda_fsm_compose(pre, v);
+}
+// work, per image: [chunk] function (2 words) | [chunk] entry state, output offset, marker count (3 words)
+__device__ __forceinline__ uint32_t jda_filter_chunks(uint32_t raw_len) { return (raw_len + JDA_FILTER_CHUNK - 1u) / JDA_FILTER_CHUNK; }
 
 __global__ __launch_bounds__(1024)
-void jda_filter_scan(const jda_filter_params *__restrict__ params)
+void jda_filter_count(const jda_filter_params *__restrict__ params)
 {
-    __shared__ jda_fsm sc[2][1024];
+    __shared__ jda_fsm wt[16];
+    const jda_filter_params P = params[blockIdx.y];
+    const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len);
+    if (chunk >= n_chunks) return;
+    uint32_t b[4], valid;
+    jda_fsm total;
+    (void)jda_fsm_block_scan(jda_filter_thread(P, chunk, threadIdx.x, b, valid), threadIdx.x, wt, total);
+    if (threadIdx.x == 0) { P.work[2u * chunk] = total.w0; P.work[2u * chunk + 1u] = total.w1; }
+}
+
+struct jda_fsm_wide { uint32_t s, n0, n1, r0, r1; };                // s: end state for incoming 0 | for incoming 1 << 1; counts unpacked (sums over chunks)
+__device__ __forceinline__ jda_fsm_wide jda_fsm_wide_compose(const jda_fsm_wide &A, const jda_fsm_wide &B)
+{
+    const uint32_t m0 = A.s & 1u, m1 = (A.s >> 1) & 1u;
+    jda_fsm_wide R;
+    R.s = ((B.s >> m0) & 1u) | (((B.s >> m1) & 1u) << 1);
+    R.n0 = A.n0 + (m0 ? B.n1 : B.n0); R.n1 = A.n1 + (m1 ? B.n1 : B.n0);
+    R.r0 = A.r0 + (m0 ? B.r1 : B.r0); R.r1 = A.r1 + (m1 ? B.r1 : B.r0);
+    return R;
+}
+__device__ __forceinline__ jda_fsm_wide jda_fsm_wide_shfl(const jda_fsm_wide &v, int src, bool up)
+{
+    jda_fsm_wide r;
+    if (up) { r.s = (uint32_t)__shfl_up((int)v.s, src, 64); r.n0 = (uint32_t)__shfl_up((int)v.n0, src, 64); r.n1 = (uint32_t)__shfl_up((int)v.n1, src, 64); r.r0 = (uint32_t)__shfl_up((int)v.r0, src, 64); r.r1 = (uint32_t)__shfl_up((int)v.r1, src, 64); }
+    else { r.s = (uint32_t)__shfl((int)v.s, src, 64); r.n0 = (uint32_t)__shfl((int)v.n0, src, 64); r.n1 = (uint32_t)__shfl((int)v.n1, src, 64); r.r0 = (uint32_t)__shfl((int)v.r0, src, 64); r.r1 = (uint32_t)__shfl((int)v.r1, src, 64); }
+    return r;
+}
+__global__ __launch_bounds__(64)
+void jda_filter_carry(const jda_filter_params *__restrict__ params)
+{
     const jda_filter_params P = params[blockIdx.x];
-    const uint32_t tid = threadIdx.x;
-    uint32_t state = 0, out_base = 0, rst_base = 0;                 // carried from step to step (uniform)
-    if (tid == 0 && P.restart_cap) P.restart_pos[0] = 0;
-    for (uint32_t base = 0; base < P.raw_len; base += 16384u) {
-        const uint32_t off = base + tid * 16u;
-        const uint32_t valid = off >= P.raw_len ? 0u : (P.raw_len - off < 16u ? P.raw_len - off : 16u);
-        uint32_t b[4] = { 0, 0, 0, 0 };
-        if (valid) {                                              // (the raw buffer is padded to a multiple of 16 bytes)
-            const jda_chunk16_alias v = *(const jda_chunk16_alias JDA_GLOBAL *)(JDA_G(const uint8_t, P.raw) + off);
-            b[0] = v.w[0]; b[1] = v.w[1]; b[2] = v.w[2]; b[3] = v.w[3];
+    const uint32_t lane = threadIdx.x, n_chunks = jda_filter_chunks(P.raw_len);
+    uint32_t state = 0, out_base = 0, rst_base = 0;               // the scan starts in state 0 at output offset 0 (uniform)
+    uint32_t *carry = P.work + 2u * n_chunks;
+    for (uint32_t base = 0; base < n_chunks; base += 64u) {
+        const uint32_t c = base + lane;
+        jda_fsm_wide v; v.s = 2u; v.n0 = v.n1 = v.r0 = v.r1 = 0;     // identity
+        if (c < n_chunks) {
+            const uint32_t w0 = P.work[2u * c], w1 = P.work[2u * c + 1u];
+            v.s = w0 & 3u; v.n0 = (w0 >> 2) & 0x7fffu; v.n1 = (w0 >> 17) & 0x7fffu; v.r0 = w1 & 0xffffu; v.r1 = w1 >> 16;
         }
-        // this thread's bytes from both incoming states
-        uint32_t s0 = 0, s1 = 1, n0 = 0, n1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) {
-            const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            const bool live = k < valid, ff = c == 0xffu, zero = c == 0u, rst = (c & 0xf8u) == 0xd0u;
-            if (live) {
-                n0 += s0 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r0 += (s0 && rst) ? 1u : 0u; s0 = s0 ? 0u : (ff ? 1u : 0u);
-                n1 += s1 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r1 += (s1 && rst) ? 1u : 0u; s1 = s1 ? 0u : (ff ? 1u : 0u);
-            }
+        for (int d = 1; d < 64; d <<= 1) {
+            const jda_fsm_wide o = jda_fsm_wide_shfl(v, d, true);
+            if (lane >= (uint32_t)d) v = jda_fsm_wide_compose(o, v);
         }
-        jda_fsm X;
-        X.w0 = s0 | (s1 << 1) | (n0 << 2) | (n1 << 17);
-        X.w1 = r0 | (r1 << 16);
-        // inclusive scan of the transition functions over the 1024 threads
-        uint32_t cur = 0;
-        sc[0][tid] = X;
-        __syncthreads();
-        for (uint32_t d = 1; d < 1024u; d <<= 1) {
-            jda_fsm v = sc[cur][tid];
-            if (tid >= d) v = jda_fsm_compose(sc[cur][tid - d], v);
-            sc[cur ^ 1][tid] = v;
-            cur ^= 1;
-            __syncthreads();
+        jda_fsm_wide ex = jda_fsm_wide_shfl(v, 1, true);
+        if (lane == 0) { ex.s = 2u; ex.n0 = ex.n1 = ex.r0 = ex.r1 = 0; }
+        if (c < n_chunks) {                                       // the functions of the chunks before this one, applied to the step's entry
+            carry[3u * c] = (ex.s >> state) & 1u;
+            carry[3u * c + 1u] = out_base + (state ? ex.n1 : ex.n0);
+            carry[3u * c + 2u] = rst_base + (state ? ex.r1 : ex.r0);
         }
-        // this thread's incoming state and offsets: the functions of all threads before it, applied to the step's state
-        uint32_t st = state, o = out_base, rp = rst_base;
-        if (tid) {
-            const jda_fsm E = sc[cur][tid - 1];
-            st = (E.w0 >> state) & 1u;
-            o += (E.w0 >> (2 + 15 * state)) & 0x7fffu;
-            rp += (E.w1 >> (16 * state)) & 0xffffu;
-        }
-        const jda_fsm T = sc[cur][1023];
-        uint8_t JDA_GLOBAL *out = JDA_G(uint8_t, P.out);
-        uint32_t JDA_GLOBAL *rpos = JDA_G(uint32_t, P.restart_pos);
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) {
-            const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            if (k < valid) {
-                if (st) {                                         // c follows an unpaired FF
-                    if (c == 0u) out[o++] = 0xffu;                // FF 00 -> FF
-                    else if ((c & 0xf8u) == 0xd0u) { rp++; if (rp < P.restart_cap) rpos[rp] = o; }     // RSTn: the next interval starts here
-                    st = 0;
-                } else if (c == 0xffu) st = 1;
-                else out[o++] = (uint8_t)c;
-            }
-        }
-        const uint32_t old = state;                                // the whole step, applied to the state it started in
-        state = (T.w0 >> old) & 1u;
-        out_base += (T.w0 >> (2 + 15 * old)) & 0x7fffu;
-        rst_base += (T.w1 >> (16 * old)) & 0xffffu;
-        __syncthreads();
+        const jda_fsm_wide T = jda_fsm_wide_shfl(v, 63, false);   // the whole step
+        out_base += state ? T.n1 : T.n0; rst_base += state ? T.r1 : T.r0; state = (T.s >> state) & 1u;
     }
-    if (tid == 0) {
+    if (lane == 0) {
         P.result[0] = out_base; P.result[1] = rst_base;
-        if (rst_base + 1u < P.restart_cap) P.restart_pos[rst_base + 1u] = JDA_RST_SENTINEL;      // behind the last interval start (the segment walk's search ends there)
+        if (P.restart_cap) {
+            P.restart_pos[0] = 0;
+            if (rst_base + 1u < P.restart_cap) P.restart_pos[rst_base + 1u] = JDA_RST_SENTINEL;      // behind the last interval start (the segment walk's search ends there)
+        }
     }
 }
 
-extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, hipStream_t stream)
+__global__ __launch_bounds__(1024)
+void jda_filter_write(const jda_filter_params *__restrict__ params)
+{
+    __shared__ jda_fsm wt[16];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[JDA_FILTER_CHUNK + 32];
+    const jda_filter_params P = params[blockIdx.y];
+    const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len), tid = threadIdx.x;
+    if (chunk >= n_chunks) return;
+    const uint32_t *carry = P.work + 2u * n_chunks + 3u * chunk;
+    const uint32_t state = carry[0], out_base = carry[1], rst_base = carry[2];
+    uint32_t b[4], valid;
+    jda_fsm total;
+    const jda_fsm X = jda_filter_thread(P, chunk, tid, b, valid);
+    const jda_fsm incl = jda_fsm_block_scan(X, tid, wt, total);
+    // this thread's entry: the functions of all threads before it, applied to the chunk's entry
+    jda_fsm E;
+    E.w0 = (uint32_t)__shfl_up((int)incl.w0, 1, 64); E.w1 = (uint32_t)__shfl_up((int)incl.w1, 1, 64);
+    if ((tid & 63u) == 0u) {                                      // (lane 0: the wavefronts before this one)
+        E.w0 = JDA_FSM_IDENTITY_W0; E.w1 = 0;
+        for (uint32_t w = 0; w < (tid >> 6); w++) E = jda_fsm_compose(E, wt[w]);
+    }
+    uint32_t st = (E.w0 >> state) & 1u;
+    const uint32_t mis = out_base & 15u;                          // the staged bytes sit at the alignment they will have in memory
+    uint32_t o = mis + ((E.w0 >> (2 + 15 * state)) & 0x7fffu);
+    uint32_t rp = rst_base + ((E.w1 >> (16 * state)) & 0xffffu);
+    uint32_t JDA_GLOBAL *rpos = JDA_G(uint32_t, P.restart_pos);
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        if (k < valid) {
+            if (st) {                                             // c follows an unpaired FF
+                if (c == 0u) stage[o++] = 0xffu;                  // FF 00 -> FF
+                else if ((c & 0xf8u) == 0xd0u) { rp++; if (rp < P.restart_cap) rpos[rp] = out_base + (o - mis); }     // RSTn: the next interval starts here
+                st = 0;
+            } else if (c == 0xffu) st = 1;
+            else stage[o++] = (uint8_t)c;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_out = (total.w0 >> (2 + 15 * state)) & 0x7fffu, end = mis + n_out;
+    uint8_t JDA_GLOBAL *gout = JDA_G(uint8_t, P.out) + (out_base - mis);                   // 16-byte aligned (P.out is)
+    for (uint32_t piece = tid; piece * 16u < end; piece += 1024u) {
+        const uint32_t lo = piece * 16u, hi = lo + 16u;
+        if (lo >= mis && hi <= end) *(jda_chunk16_alias JDA_GLOBAL *)(gout + lo) = *(const jda_chunk16_alias *)(stage + lo);
+        else for (uint32_t i = lo < mis ? mis : lo; i < (hi < end ? hi : end); i++) gout[i] = stage[i];        // (the chunk's first and last 16 bytes: a neighbour writes the rest)
+    }
+}
+
+// max_raw_len: the longest raw_len among the images (the grid's width)
+extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, uint32_t max_raw_len, hipStream_t stream)
 {
     if (n_images == 0) return hipSuccess;
-    hipLaunchKernelGGL(jda_filter_scan, dim3(n_images), dim3(1024), 0, stream, params);
+    const uint32_t chunks = (max_raw_len + JDA_FILTER_CHUNK - 1u) / JDA_FILTER_CHUNK;
+    if (chunks) hipLaunchKernelGGL(jda_filter_count, dim3(chunks, n_images), dim3(1024), 0, stream, params);
+    hipLaunchKernelGGL(jda_filter_carry, dim3(n_images), dim3(64), 0, stream, params);
+    if (chunks) hipLaunchKernelGGL(jda_filter_write, dim3(chunks, n_images), dim3(1024), 0, stream, params);
     return hipGetLastError();
 }
 

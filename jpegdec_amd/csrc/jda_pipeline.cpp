@@ -117,7 +117,7 @@ struct Img {
     bool fast;                   // launched with 24-bit multiplies
     uint32_t n_segs_ub, n_blocks;
     size_t off_raw, off_scan, scan_bytes, off_index, off_dc, off_work, off_zero, off_stats;   // arena offsets
-    size_t work_bytes, zero_bytes, off_rpos;     // off_rpos: restart positions inside the work region
+    size_t work_bytes, zero_bytes, off_rpos, off_fwork;     // off_rpos / off_fwork: restart positions / the filter's work words inside the work region
     size_t ctl_tables;           // offset of its tables inside the control blob
     uint32_t list, n_tiles;      // launch list it is in, tiles (padded)
     size_t strip_off;            // its first strip inside the list
@@ -318,7 +318,8 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         // seg_sum | seg_start | two work lists | where the restart intervals start (+ the sentinel)
         im.n_segs_ub = im.f.raw_len / JDA_SEG_BYTES + 1u;
         im.off_rpos = a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);
-        im.work_bytes = im.off_rpos + (im.f.n_intervals ? a16(((size_t)im.f.n_intervals + 1) * 4) : 0);
+        im.off_fwork = im.off_rpos + (im.f.n_intervals ? a16(((size_t)im.f.n_intervals + 1) * 4) : 0);          // .. | the filter's chunk functions
+        im.work_bytes = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len));
         im.off_work = take(im.work_bytes);
     }
     const size_t zero_begin = arena;
@@ -367,7 +368,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     jda_dev_desc *dd = (jda_dev_desc *)(S.pin + S.off_descs);
     std::vector<int> dev_ix;
     for (int i = 0; i < n; i++) if (S.imgs[(size_t)i].device) dev_ix.push_back(i);
-    uint32_t max_segs = 0;
+    uint32_t max_segs = 0, max_raw = 0;
     for (size_t k = 0; k < dev_ix.size(); k++) {
         const int i = dev_ix[k];
         Img &im = S.imgs[(size_t)i];
@@ -380,6 +381,8 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         const uint32_t n_int = im.f.n_intervals;                       // 0: no restart intervals
         F.restart_pos = (uint32_t *)(B + im.off_work + im.off_rpos);
         F.restart_cap = n_int ? n_int + 1u : 0u;
+        F.work = (uint32_t *)(B + im.off_work + im.off_fwork);
+        max_raw = std::max(max_raw, im.f.raw_len);
         jda_dev_desc &D = descs[(size_t)i];
         D.tables = B + im.ctl_tables;
         D.blk_index = (const uint32_t *)(B + im.off_index);
@@ -424,9 +427,9 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         e = hipMemsetAsync(B + zero_begin, 0, zero_end - zero_begin, p->s_copy);
         if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, raw_end, hipMemcpyHostToDevice, p->s_copy);      // control blob + every file's scan
         S.st.h2d_bytes += (int64_t)raw_end;
-        // the marker filter rides on the copy stream: one workgroup per image keeps a quarter of the CUs busy for a millisecond, which
-        // the previous batch's pre-scan (11.5 KB of LDS per workgroup) leaves room for
-        if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), p->s_copy);
+        // the marker filter rides on the copy stream, behind the batch's copy (three short launches over 16 KB chunks: it shares the GPU
+        // with whatever the other two streams have running)
+        if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), max_raw, p->s_copy);
         if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->s_up, S.ev_copy, 0);
         if (e == hipSuccess) {

@@ -558,17 +558,18 @@ int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t 
     if (!raw || len < 0 || !out || !out_len) return JDA_INVALID_PARAMETER;
     (void)hipSetDevice(ctx->device);
     const size_t raw_cap = align16((size_t)len) + 16, rcap = restart_cap > 0 ? (size_t)restart_cap : 1;
-    const size_t off_out = raw_cap, off_rpos = off_out + align16((size_t)len + 16), off_res = off_rpos + align16(rcap * 4), off_par = off_res + 16;
+    const size_t off_out = raw_cap, off_rpos = off_out + align16((size_t)len + 16), off_res = off_rpos + align16(rcap * 4), off_work = off_res + 16;
+    const size_t off_par = off_work + align16(JDA_FILTER_WORK_BYTES(len));
     uint8_t *d = NULL;
     hipError_t e = hipMalloc((void **)&d, off_par + sizeof(jda_filter_params));
     if (e != hipSuccess) return jda_set_err(ctx, e, "hipMalloc(filter)");
     jda_filter_params P;
     P.raw = d; P.out = d + off_out; P.restart_pos = (uint32_t *)(d + off_rpos); P.result = (uint32_t *)(d + off_res);
-    P.raw_len = (uint32_t)len; P.restart_cap = (uint32_t)rcap;
+    P.raw_len = (uint32_t)len; P.restart_cap = (uint32_t)rcap; P.work = (uint32_t *)(d + off_work);
     e = hipMemsetAsync(d, 0, off_par, ctx->stream);
     if (e == hipSuccess && len) e = hipMemcpyAsync(d, raw, (size_t)len, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + off_par, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(d + off_par), 1, ctx->stream);
+    if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(d + off_par), 1, (uint32_t)len, ctx->stream);
     uint32_t res[2] = { 0, 0 };
     if (e == hipSuccess) e = hipMemcpyAsync(res, d + off_res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
