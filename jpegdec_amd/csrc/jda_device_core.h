@@ -1215,6 +1215,9 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
 #if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 1))
             if (begin) JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
 #endif
+#ifdef JDA_SEG_BLOCK_HOOK
+            if (begin) JDA_SEG_BLOCK_HOOK();                        // (host simulator: where blocks start among the steps)
+#endif
             pend = begin ? (pos << JDA_INDEX_OFF_BITS) | off : pend;       // the reader after the block's opening refill
             pend_g = begin ? g : pend_g;
             pending = pending | begin;

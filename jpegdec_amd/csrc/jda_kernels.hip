@@ -586,6 +586,40 @@ void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
 // last list's length when the batch is waited for.  stats[8 + r] = length of round r's list (r >= 2).  Round 0 walks every
 // segment from the guess "a block starts here" for the exit states alone (most guesses are wrong, so its sums would be thrown
 // away); round 1 walks every segment again, now with the sums, and starts the lists.
+// one segment of a round: walk it, store its sums, and if its exit state is not what the next segment was entered with, replace that
+// and put the next segment on the next round's list (one atomic per wavefront for the places on it)
+template <int OP>
+__device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, const uint8_t *tab, uint32_t seg, uint32_t round, uint32_t lane,
+                                               uint32_t JDA_GLOBAL *E, uint32_t JDA_GLOBAL *wl_out)
+{
+    jda_seg_sum S;
+    jda_seg_stats ST;
+    ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
+    const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];       // the scan starts at a block start (jpeg.inl:4996-4998)
+    const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
+    const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST) : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST);
+    if (OP == JDA_SEG_FUSED) {
+        uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
+        o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
+    }
+    if (round == 0) { if (seg + 1u < P.n_segs) E[seg + 1u] = x; }       // (nobody reads the entry states in round 0)
+    else {
+        const bool changed = seg + 1u < P.n_segs && x != E[seg + 1u];
+        const uint64_t who = __builtin_amdgcn_ballot_w64(changed);
+        if (who) {
+            const uint32_t first = (uint32_t)__builtin_ctzll(who);
+            uint32_t at0 = 0;
+            if (lane == first) at0 = atomicAdd(&P.stats[8u + round + 1u], (uint32_t)__builtin_popcountll(who));
+            at0 = (uint32_t)__builtin_amdgcn_readlane((int)at0, (int)first);
+            if (changed) {
+                E[seg + 1u] = x;
+                const uint32_t at = at0 + (uint32_t)__builtin_popcountll(who & ((1ull << lane) - 1ull));
+                if (at < P.worklist_cap) wl_out[at] = seg + 1u;
+            }
+        }
+    }
+}
+
 template <int OP>       // JDA_SEG_SPEC: round 0 (every segment from the guess "a block starts here": exit states only); JDA_SEG_FUSED: the rest
 __global__ __launch_bounds__(256)
 void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t round)
@@ -606,34 +640,42 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
     for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < count; base += gridDim.x * 256u) {
         const uint32_t item = base + lane;
         if (item >= count) continue;
-        const uint32_t seg = all ? item : wl_in[item];
-        jda_seg_sum S;
-        jda_seg_stats ST;
-        ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
-        const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];   // the scan starts at a block start (jpeg.inl:4996-4998)
-        const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
-        const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST) : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST);
-        if (OP == JDA_SEG_FUSED) {
-            uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
-            o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
-        }
-        if (round == 0) { if (seg + 1u < P.n_segs) E[seg + 1u] = x; }   // (nobody reads the entry states in round 0)
-        else {
-            const bool changed = seg + 1u < P.n_segs && x != E[seg + 1u];
-            const uint64_t who = __builtin_amdgcn_ballot_w64(changed);     // one atomic per wavefront for its places on the next list
-            if (who) {
-                const uint32_t first = (uint32_t)__builtin_ctzll(who);
-                uint32_t at0 = 0;
-                if (lane == first) at0 = atomicAdd(&P.stats[8u + round + 1u], (uint32_t)__builtin_popcountll(who));
-                at0 = (uint32_t)__builtin_amdgcn_readlane((int)at0, (int)first);
-                if (changed) {
-                    E[seg + 1u] = x;
-                    const uint32_t at = at0 + (uint32_t)__builtin_popcountll(who & ((1ull << lane) - 1ull));
-                    if (at < P.worklist_cap) wl_out[at] = seg + 1u;
-                }
-            }
-        }
+        jda_fused_item<OP>(P, tab, all ? item : wl_in[item], round, lane, E, wl_out);
     }
+}
+
+// The rounds behind the first few, in ONE launch: one workgroup of 16 wavefronts per image goes round after round (a barrier and a
+// fence between two) until a round leaves its list empty -- lists of a handful of segments by then; a launch per round cost more
+// than its walk, and a fixed number of launches was a limit on the rounds.  stats[7] = 1: settled (0: max_round reached).
+__global__ __launch_bounds__(1024)
+void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t first_round, uint32_t max_round)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.x]);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t *stats = P.stats;
+    uint32_t round = first_round;
+    uint32_t count = __hip_atomic_load(&stats[8u + round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (count == 0) { if (threadIdx.x == 0) stats[7] = 1; return; }       // (the usual case: nothing is staged)
+    uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
+    uint8_t *tab = lds;
+    jda_walk_tables_from(P.tables, threadIdx.x, 1024u, tab);
+    __syncthreads();
+    while (count != 0 && round < max_round) {
+        const uint32_t JDA_GLOBAL *wl_in = JDA_G(const uint32_t, P.worklist) + ((round & 1u) ? P.worklist_cap : 0u);
+        uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
+        if (count > P.worklist_cap) count = P.worklist_cap;
+        for (uint32_t base = wave * 64u; base < count; base += 1024u) {
+            const uint32_t item = base + lane;
+            if (item >= count) continue;
+            jda_fused_item<JDA_SEG_FUSED>(P, tab, wl_in[item], round, lane, E, wl_out);
+        }
+        __threadfence();                                             // this round's entry states, sums and list, for every wavefront of the next
+        __syncthreads();
+        round++;
+        count = __hip_atomic_load(&stats[8u + round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) stats[7] = count == 0 ? 1u : 0u;
 }
 
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream)
@@ -658,6 +700,13 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     const dim3 grid(round <= 1 ? full : (full < 8u ? full : 8u), n_images), block(256);
     if (round == 0) hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
     else hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_FUSED>, grid, block, lds_bytes, stream, params, round);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t first_round, uint32_t max_round, hipStream_t stream)
+{
+    if (n_images == 0) return hipSuccess;
+    hipLaunchKernelGGL(jda_segscan_tail, dim3(n_images), dim3(1024), JDA_WT_BYTES, stream, params, first_round, max_round);
     return hipGetLastError();
 }
 
@@ -982,17 +1031,17 @@ void jda_filter_write(const jda_filter_params *__restrict__ params)
     uint32_t o = mis + ((E.w0 >> (2 + 15 * state)) & 0x7fffu);
     uint32_t rp = rst_base + ((E.w1 >> (16 * state)) & 0xffffu);
     uint32_t JDA_GLOBAL *rpos = JDA_G(uint32_t, P.restart_pos);
+    // every byte is stored -- to its place, or to a dump byte behind the buffer -- so that the sixteen steps are straight-line code
+    // (a branch per byte was sixteen exec-mask regions per thread); a restart marker is rare and keeps its branch
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
         const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        if (k < valid) {
-            if (st) {                                             // c follows an unpaired FF
-                if (c == 0u) stage[o++] = 0xffu;                  // FF 00 -> FF
-                else if ((c & 0xf8u) == 0xd0u) { rp++; if (rp < P.restart_cap) rpos[rp] = out_base + (o - mis); }     // RSTn: the next interval starts here
-                st = 0;
-            } else if (c == 0xffu) st = 1;
-            else stage[o++] = (uint8_t)c;
-        }
+        const bool live = k < valid, ff = c == 0xffu;
+        const bool emit = live & (st ? c == 0u : !ff);            // FF 00 -> FF; a byte behind an unpaired FF is dropped with it; FF waits for its partner
+        if (live & (st != 0u) & ((c & 0xf8u) == 0xd0u)) { rp++; if (rp < P.restart_cap) rpos[rp] = out_base + (o - mis); }     // RSTn: the next interval starts here
+        stage[emit ? o : (uint32_t)(JDA_FILTER_CHUNK + 31u)] = st ? (uint8_t)0xffu : (uint8_t)c;
+        o += emit ? 1u : 0u;
+        st = live ? ((st == 0u) & ff ? 1u : 0u) : st;
     }
     __syncthreads();
     const uint32_t n_out = (total.w0 >> (2 + 15 * state)) & 0x7fffu, end = mis + n_out;

@@ -127,7 +127,8 @@ struct Img {
 } // namespace
 
 #define JDA_PIPE_MAX_DEPTH 4
-#define JDA_PIPE_SPEC_ROUNDS 24      // rounds launched (a round with an empty work list returns at once); stats[8 + r], r <= 24 < 56
+#define JDA_PIPE_SPEC_ROUNDS 4       // rounds launched one by one (a round with an empty work list returns at once); the rest in one launch (jda_segscan_tail)
+#define JDA_PIPE_MAX_ROUNDS 56       // stats[8 + r] = length of round r's list, r <= 57 < 60
 #define JDA_PIPE_STATS_BYTES 288      // per image: filter result (2 words, 16 bytes) | 64 result words of the pre-scan + 16 bytes
 
 struct jda_pipeline {
@@ -437,6 +438,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
             const uint32_t ns = (uint32_t)dev_ix.size();
             // speculative rounds with the count pass folded in (work lists: a round after the first walks what the one before changed)
             for (uint32_t r = 0; r < JDA_PIPE_SPEC_ROUNDS && e == hipSuccess; r++) e = jda_launch_segscan_fused(dp, ns, max_segs, r, p->s_up);
+            if (e == hipSuccess) e = jda_launch_segscan_tail(dp, ns, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, p->s_up);
             if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, p->s_up);
             if (e == hipSuccess) e = jda_launch_segscan(dp, ns, max_segs, JDA_SEG_WRITE, 0, p->s_up);
         }
@@ -516,18 +518,18 @@ int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status)
                 uint32_t max_ac = 0, max_dc = 0;
                 // the last round left nothing to walk; enough blocks; no bad code; the closing entry written once; and, with restart
                 // intervals, as many markers as the MCU count asks for, each where the count puts it
-                bool ok = ps[8 + JDA_PIPE_SPEC_ROUNDS] == 0 && ps[6] == 1 && ps[0] == 0 && ps[1] == 1;
+                bool ok = ps[7] == 1 && ps[6] == 1 && ps[0] == 0 && ps[1] == 1;
                 if (im.f.n_intervals && (rb[1] + 1u != im.f.n_intervals || ps[5] != 0)) ok = false;
                 max_ac = ps[2]; max_dc = ps[3];
-                S.st.spec_rounds_max = std::max<int32_t>(S.st.spec_rounds_max, [&]() { int r = 1; while (r <= JDA_PIPE_SPEC_ROUNDS && ps[8 + r]) r++; return r; }());
+                S.st.spec_rounds_max = std::max<int32_t>(S.st.spec_rounds_max, [&]() { int r = 2; while (r <= JDA_PIPE_MAX_ROUNDS + 1 && ps[8 + r]) r++; return r; }());   // rounds that had something to walk
                 if (ok && im.fast && !jda_front_fast_mul(S.pin + im.ctl_tables, &im.f, max_ac, (int32_t)max_dc)) ok = false;   // a magnitude no legal stream has
                 redo = !ok;
                 if (ok) S.st.device_images++;
                 else {
                     static const bool trace = getenv("JDA_PIPE_TRACE") != NULL;
-                    if (trace) fprintf(stderr, "jda_pipeline: image %d (%dx%d, %u restart intervals) of ticket %d goes to the host path: filter %u bytes / %u markers, result words %u %u %u %u %u, [5] %u [6] %u, last round %u, fast %d\n",
+                    if (trace) fprintf(stderr, "jda_pipeline: image %d (%dx%d, %u restart intervals) of ticket %d goes to the host path: filter %u bytes / %u markers, result words %u %u %u %u %u, [5] %u [6] %u, settled %u, fast %d\n",
                                        i, im.f.info.width, im.f.info.height, im.f.n_intervals, ticket, rb[0], rb[1], ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6],
-                                       ps[8 + JDA_PIPE_SPEC_ROUNDS], (int)im.fast);
+                                       ps[7], (int)im.fast);
                 }
             }
             if (redo) { st = slow_path(p, S.jpegs[(size_t)i], S.lens[(size_t)i], S.outs[(size_t)i], S.pts[(size_t)i], S.opts[(size_t)i]); S.st.host_path_images++; }

@@ -11,8 +11,11 @@
 
 #include <vector>
 
+#include <vector>
 static unsigned g_seg_steps = 0;
+static std::vector<unsigned> g_blk_at;
 #define JDA_SEG_STEP_HOOK() (g_seg_steps++)
+#define JDA_SEG_BLOCK_HOOK() (g_blk_at.push_back(g_seg_steps))
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
 
@@ -187,14 +190,21 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         memset(&ST, 0, sizeof(ST));
         uint32_t terminal = 0;
         std::vector<unsigned> steps_of(n_segs, 0);
+        std::vector<std::vector<unsigned> > syms_of(n_segs);
         for (uint32_t seg = 0; seg < n_segs; seg++) {           // WRITE
-            g_seg_steps = 0;
+            g_seg_steps = 0; g_blk_at.clear();
             if (seg_start[(size_t)seg * 5] > P.n_blocks_total) continue;
             const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
             jda_seg_stats T1;
             memset(&T1, 0, sizeof(T1));
             if (rst) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1); else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1);
             steps_of[seg] = g_seg_steps;
+            {   // symbols per block of this walk: the part of a block that began earlier, then whole blocks, then the part of the last one
+                std::vector<unsigned> &v = syms_of[seg];
+                unsigned prev = 0;
+                for (size_t i = 0; i < g_blk_at.size(); i++) { if (i || g_blk_at[i]) v.push_back(g_blk_at[i] - 1 - prev + (i ? 0 : 1)); prev = g_blk_at[i] - 1; }
+                v.push_back(g_seg_steps - prev);
+            }
             ST.bad |= T1.bad | T1.mismatch; terminal += T1.terminal; ST.trunc_events += T1.trunc_events;
             if (T1.max_ac_bits > ST.max_ac_bits) ST.max_ac_bits = T1.max_ac_bits;
             if (T1.max_abs_dc > ST.max_abs_dc) ST.max_abs_dc = T1.max_abs_dc;
@@ -203,6 +213,15 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             double sum = 0, summax = 0; unsigned mx = 0;
             for (uint32_t b0 = 0; b0 < n_segs; b0 += 64) { unsigned m = 0; for (uint32_t i = b0; i < n_segs && i < b0 + 64; i++) { sum += steps_of[i]; if (steps_of[i] > m) m = steps_of[i]; } summax += 64.0 * m; if (m > mx) mx = m; }
             fprintf(stderr, "steps per segment: mean %.1f, mean of the wavefronts' maxima %.1f, max %u (lane efficiency %.2f)\n", sum / n_segs, summax / 64.0 / ((n_segs + 63) / 64), mx, sum / summax);
+            // what a block-synchronous walk would cost: per wavefront, sum over block iterations of the longest block of the 64 lanes
+            double outer = 0, inner = 0, waves = 0;
+            for (uint32_t b0 = 0; b0 < n_segs; b0 += 64) {
+                size_t nb_max = 0;
+                for (uint32_t i = b0; i < n_segs && i < b0 + 64; i++) nb_max = std::max(nb_max, syms_of[i].size());
+                for (size_t k = 0; k < nb_max; k++) { unsigned m = 0; for (uint32_t i = b0; i < n_segs && i < b0 + 64; i++) if (k < syms_of[i].size()) m = std::max(m, syms_of[i][k]); inner += m; }
+                outer += nb_max; waves++;
+            }
+            fprintf(stderr, "block-synchronous: %.1f block iterations and %.1f symbol iterations per wavefront (now: %.1f steps)\n", outer / waves, inner / waves, summax / 64.0 / waves);
         }
         if (ok && !ST.bad && terminal == 1) {
             g_prescan_trunc = ST.trunc_events;

@@ -203,3 +203,41 @@ def test_pipeline_restart_streams_take_the_segment_walk(gpu_ctx, oracle):
     for o in outs:
         gpu_ctx.free(o[0])
     pipe.close()
+
+
+def test_pipeline_corrupted_scans_decode_like_the_oracle(gpu_ctx, oracle):
+    """Random byte corruptions inside the entropy-coded data (the reference's fuzz idea, MacOS/JPEGDEC_Test/main.cpp:262-300), a whole
+    batch of them through the device filter, segment walk and decode: the oracle's garbage bit for bit, failure on the same
+    streams -- whether the device's index stood or the image went back to the serial pre-scan."""
+    rng = np.random.default_rng(5)
+    jp, nm = [], []
+    for name in ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217"):
+        base = bytearray(jpeg_for(name))
+        sos = bytes(base).index(b"\xff\xda")
+        made = 0
+        while made < 14:
+            b = bytearray(base)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+            jb = bytes(b)
+            try:
+                p = J.PreparedImage(jb)
+            except J.JdaError:
+                continue
+            idx, nok = p.block_index()
+            out_of_contract = (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan())      # (DESIGN 3: ran out of data)
+            p.close()
+            if out_of_contract:
+                continue
+            jp.append(jb); nm.append("%s#%d" % (name, made)); made += 1
+    pts = [J.RGB8888] * len(jp)
+    opts = [0] * len(jp)
+    pipe = J.Pipeline(gpu_ctx, max_images=64, depth=2, host_threads=4)
+    outs, metas = _surfaces(gpu_ctx, jp, pts, opts)
+    st = pipe.wait(pipe.submit(jp, outs, pts, opts))
+    _check(gpu_ctx, oracle, jp, pts, opts, outs, metas, st, nm)
+    s = pipe.stats
+    assert s["device_images"] >= len(jp) // 4, s               # many corruptions leave a stream the device can still index
+    for o in outs:
+        gpu_ctx.free(o[0])
+    pipe.close()

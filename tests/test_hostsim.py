@@ -91,7 +91,7 @@ def test_markerless_prescan_equals_serial(name, hostsim, oracle):
         hostsim.hostsim_set_device_prescan(0)
 
 
-@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "c422_333x217", "c420_640x368_rstrow"])
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "c422_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c440_300x64_rst5"])
 def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
     """The reference's fuzz idea (MacOS/JPEGDEC_Test/main.cpp:262-300) turned into a parity test: random byte
     corruptions inside the entropy-coded data.  A corrupted scan usually still "decodes" -- to garbage that
@@ -103,10 +103,11 @@ def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
     sos = bytes(base).index(b"\xff\xda")
     rng = np.random.default_rng(11)
     agree = 0
-    for it in range(80):
-        # every other stream goes through the device pre-scans (segment walk / restart intervals): a stream they cannot
-        # reproduce exactly must send them back to the serial pre-scan
-        hostsim.hostsim_set_device_prescan(it & 1)
+    for it in range(120):
+        # two of three streams go through the device pre-scans (1: segment walk, restart streams one lane per interval; 2: restart
+        # streams through the segment walk too, as the pipeline has it): a stream they cannot reproduce exactly must send them
+        # back to the serial pre-scan, and an index they do make must be the serial one
+        hostsim.hostsim_set_device_prescan(it % 3)
         b = bytearray(base)
         for _ in range(int(rng.integers(1, 4))):
             b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
@@ -124,6 +125,8 @@ def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
             inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jb, pt, opt)
             hrc = hostsim.hostsim_decode(jb, len(jb), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
             assert (rc == 1) == (hrc == 0), (name, it, pt, opt, rc, err, hrc)
+            if hostsim.hostsim_prescan_used():
+                assert hostsim.hostsim_index_equal() == 1, (name, it)
             if rc == 1:
                 assert np.array_equal(got, want), (name, it, pt, opt)
                 agree += 1
