@@ -981,7 +981,9 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 // State at a symbol boundary (after the reference's bottom-of-loop refill, before its next top-of-loop refill):
 //   bits 5:0 bit offset from the segment's first bit (entry: how far the previous segment's last symbol reached in),
 //   bits 8:6 block within the MCU, bits 14:9 zigzag position k (0 = the next symbol is a DC code).
+#ifndef JDA_SEG_BYTES
 #define JDA_SEG_BYTES 256u
+#endif
 #define JDA_SEG_BITS  (JDA_SEG_BYTES * 8u)
 #define JDA_SEG_SLOT  268u           // bytes a lane reads: its segment + 12 bytes of the next; 67 dwords per lane in LDS (odd: no bank conflicts)
 #define JDA_SEG_DEAD  0x7fffffffu    // state of a walk that met an invalid code (bit 31 is the rounds' "changed" mark)
@@ -1016,7 +1018,7 @@ JDA_HD jda_segscan_params jda_segscan_resolve(const jda_segscan_params &in)
 {
     jda_segscan_params P = in;
     if (P.filter_result) {
-        P.scan_len = JDA_G(const uint32_t, P.filter_result)[0]; P.n_segs = P.scan_len / 256u + 1u;
+        P.scan_len = JDA_G(const uint32_t, P.filter_result)[0]; P.n_segs = P.scan_len / JDA_SEG_BYTES + 1u;
         // as many RSTn markers as the MCU count asks for?  If not, nothing walks (restart_pos is not what the walk takes it for) and
         // the result words stay "no index": the serial pre-scan does what the reference does with such a file
         if (P.restart_pos && JDA_G(const uint32_t, P.filter_result)[1] + 1u != P.n_intervals) P.n_segs = 0;

@@ -772,11 +772,12 @@ __device__ __forceinline__ jda_sum_el jda_sum_load_chunk(const jda_segscan_param
 // A segment that met an invalid code ends the sums: harmless only behind the image's last block.
 // Result word: stats[6] = 1 when the index can be written (enough blocks, no bad code before the end).
 #define JDA_SUMS_WAVES 16u
-#define JDA_SUMS_MAX_CHUNKS 2048u
+#define JDA_SUMS_MAX_CHUNKS ((1u << 25) / (64u * JDA_SEG_BYTES))      // 32 MB of scan (the index packs byte positions in 25 bits)
 __global__ __launch_bounds__(64 * JDA_SUMS_WAVES)
 void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
 {
-    __shared__ jda_sum_el agg[JDA_SUMS_MAX_CHUNKS];                 // a chunk's aggregate, then its carry-in; flag bit 1: the chunk has a bad segment, bit 2: dead
+    extern __shared__ __attribute__((aligned(16))) uint8_t sums_lds[];
+    jda_sum_el *agg = (jda_sum_el *)sums_lds;                       // JDA_SUMS_MAX_CHUNKS x: a chunk's aggregate, then its carry-in; flag bit 1: the chunk has a bad segment, bit 2: dead
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.x]);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_chunks = (P.n_segs + 63u) / 64u;
@@ -833,7 +834,14 @@ void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream)
 {
     if (n_images == 0) return hipSuccess;
-    hipLaunchKernelGGL(jda_segscan_sums, dim3(n_images), dim3(64 * JDA_SUMS_WAVES), 0, stream, params);
+    const int lds_bytes = (int)(JDA_SUMS_MAX_CHUNKS * sizeof(jda_sum_el));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_sums, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(jda_segscan_sums, dim3(n_images), dim3(64 * JDA_SUMS_WAVES), lds_bytes, stream, params);
     return hipGetLastError();
 }
 
