@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Random walks over the reference's public API (pixel type x option bits x crop x decode offsets x max output size), each run through
+the UNMODIFIED reference (oracle/_ref, scalar build) in a process of its own -- some combinations crash it -- and recorded:
+return code, last error, number of draw calls, hashes of the JPEGDRAW sequence and of the assembled canvas.
+
+    python tests/golden/make_api_walk_golden.py        (needs /root/reference; writes tests/golden/api_walks.json)
+
+tests/test_gpu_api_walks.py replays the walks through the product's JPEGDEC class on the GPU box (where the reference does not exist).
+"""
+import hashlib
+import json
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+IMAGES = ["c420_333x217", "c444_333x217", "gray_333x217", "c422_333x217", "c440_200x120", "c420_640x368_rstrow", "c444_384x192_q100_rst7",
+          "c420_250x250_q10", "c420_16x16", "gray_64x64_rst3", "p420_200x120", "p444_333x217", "pgray_100x100", "c420_1100x48"]
+N_WALKS = 420
+SCALES = (0, 0, 0, 2, 4, 8)            # full size as often as the three reduced ones together
+OUT = os.path.join(ROOT, "tests", "golden", "api_walks.json")
+
+
+def make_walks():
+    rng = np.random.default_rng(20260925)
+    from tests.cases import jpeg_for
+    import jpegdec_amd as J
+
+    walks = []
+    for i in range(N_WALKS):
+        name = IMAGES[int(rng.integers(0, len(IMAGES)))]
+        info = J.parse(jpeg_for(name))
+        opt = int(SCALES[int(rng.integers(0, len(SCALES)))])
+        if rng.random() < 0.06:
+            opt |= int(SCALES[int(rng.integers(3, len(SCALES)))])          # now and then a second scale bit
+        if rng.random() < 0.2:
+            opt |= 64                                                        # JPEG_LUMA_ONLY
+        if rng.random() < 0.2:
+            opt |= 128                                                       # JPEG_USES_DMA
+        w = dict(i=i, image=name, pixel_type=int(rng.integers(0, 4)), options=opt, max_mcus=0, xoff=0, yoff=0, crop=None)
+        if info["ncomp"] == 1 and w["pixel_type"] == 2:
+            w["pixel_type"] = 0        # (a gray JPEG to RGB8888: the reference reports 32 bpp and writes 16-bit pixels, SURVEY C.5 -- the other half of each strip is whatever the buffer held)
+        if rng.random() < 0.3:
+            w["max_mcus"] = int(rng.integers(1, 40))
+        if rng.random() < 0.3:
+            w["xoff"], w["yoff"] = int(rng.integers(0, 70)), int(rng.integers(0, 40))
+        if rng.random() < 0.35 and info["width"] > 48 and info["height"] > 48:
+            cx, cy = int(rng.integers(0, info["width"] - 32)), int(rng.integers(0, info["height"] - 32))
+            w["crop"] = [cx, cy, int(rng.integers(8, info["width"] - cx + 16)), int(rng.integers(8, info["height"] - cy + 16))]
+        walks.append(w)
+    return walks
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()[:20]
+
+
+def run_one(w, q):
+    from oracle.loader import RefDecoder
+    from tests.cases import jpeg_for
+
+    ref = RefDecoder(False)
+    r = ref.decode_cb(jpeg_for(w["image"]), w["pixel_type"], w["options"], max_mcus=w["max_mcus"], xoff=w["xoff"], yoff=w["yoff"],
+                      crop=w["crop"], want_log=True, used_only=w["crop"] is not None)     # (a cropped strip is wider than what the reference writes into it: only iWidthUsed pixels are defined)
+    q.put(dict(rc=int(r["rc"]), last_error=int(r["last_error"]), n_calls=int(r["n_calls"]), dma_reuse=int(r["dma_reuse"]),
+               log=sha(r["log"]) if r["log"] is not None else None, canvas=sha(r["canvas"]) if r["canvas"] is not None else None,
+               canvas_shape=list(r["canvas"].shape) if r["canvas"] is not None else None))
+
+
+def main():
+    ctx = mp.get_context("spawn")
+    out = []
+    for w in make_walks():
+        q = ctx.Queue()
+        p = ctx.Process(target=run_one, args=(w, q))
+        p.start()
+        p.join(120)
+        res = None
+        if p.is_alive():
+            p.kill()
+            res = dict(crashed="timeout")
+        elif p.exitcode != 0:
+            res = dict(crashed="exit %d" % p.exitcode)                      # the reference died (segmentation fault, SIGFPE)
+        else:
+            res = q.get()
+        out.append(dict(walk=w, ref=res))
+        print(w["i"], w["image"], w["pixel_type"], w["options"], res.get("crashed") or (res["rc"], res["last_error"], res["n_calls"]), flush=True)
+    json.dump(dict(generator="tests/golden/make_api_walk_golden.py", reference="oracle/_ref scalar build (-DNO_SIMD) of /root/reference", walks=out),
+              open(OUT, "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()
