@@ -233,7 +233,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         ti.has_thumb = s->info.has_thumb; ti.thumb_w = s->info.thumb_w; ti.thumb_h = s->info.thumb_h; ti.thumb_offset = 0;
         s->data += s->info.thumb_offset; s->size -= s->info.thumb_offset;
         s->info = ti;
-        s->crop_w = ti.width; s->crop_h = ti.height;
+        s->crop_x = s->crop_y = 0; s->crop_w = ti.width; s->crop_h = ti.height;      // the SOF handler resets the whole crop rectangle (jpeg.inl:1683-1685)
         iOptions &= ~JPEG_EXIF_THUMBNAIL;
     }
     if (s->crop_w <= 0 || s->crop_h <= 0) { s->error = JPEG_INVALID_PARAMETER; return 0; }   // image smaller than one MCU / overhanging request (jpeg.inl:713-719 leaves w <= 0): nothing sane to deliver
@@ -276,6 +276,8 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         rect[0] = x0 < x1 ? x0 : 0; rect[1] = y0; rect[2] = x0 < x1 ? x1 : 0; rect[3] = y1 > y0 ? y1 : y0;
     }
     rc = jda_decode_to_host_rect(ctx, s->data, s->size, pt, iOptions, cropped ? rect : NULL, canvas.data(), cw * bpp, ch, &mcus_decoded, NULL);
+    // the reference walks the MCU rows down to the crop's bottom only (jpeg.inl:5014-5037): a bad MCU below it is never met
+    if (rc == JDA_DECODE_ERROR && cropped && mcus_decoded >= rect[3] * s->info.mcus_x && rect[3] < s->info.mcus_y) rc = JDA_SUCCESS;
     const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
     if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
 

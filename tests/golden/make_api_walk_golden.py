@@ -20,7 +20,9 @@ sys.path.insert(0, ROOT)
 
 IMAGES = ["c420_333x217", "c444_333x217", "gray_333x217", "c422_333x217", "c440_200x120", "c420_640x368_rstrow", "c444_384x192_q100_rst7",
           "c420_250x250_q10", "c420_16x16", "gray_64x64_rst3", "p420_200x120", "p444_333x217", "pgray_100x100", "c420_1100x48"]
+REF_IMAGES = ["tulips", "zebra", "sciopero", "croptest", "thumb_test", "corrupt2", "corrupt3", "corrupt5", "demo"]      # the reference's own fixtures (tests/golden/ref/)
 N_WALKS = 420
+N_REF_WALKS = 160
 SCALES = (0, 0, 0, 2, 4, 8)            # full size as often as the three reduced ones together
 OUT = os.path.join(ROOT, "tests", "golden", "api_walks.json")
 
@@ -31,9 +33,9 @@ def make_walks():
     import jpegdec_amd as J
 
     walks = []
-    for i in range(N_WALKS):
-        name = IMAGES[int(rng.integers(0, len(IMAGES)))]
-        info = J.parse(jpeg_for(name))
+    for i in range(N_WALKS + N_REF_WALKS):
+        name = IMAGES[int(rng.integers(0, len(IMAGES)))] if i < N_WALKS else "ref:" + REF_IMAGES[int(rng.integers(0, len(REF_IMAGES)))]
+        info = J.parse(jpeg_of(name))
         opt = int(SCALES[int(rng.integers(0, len(SCALES)))])
         if rng.random() < 0.06:
             opt |= int(SCALES[int(rng.integers(3, len(SCALES)))])          # now and then a second scale bit
@@ -41,6 +43,8 @@ def make_walks():
             opt |= 64                                                        # JPEG_LUMA_ONLY
         if rng.random() < 0.2:
             opt |= 128                                                       # JPEG_USES_DMA
+        if name == "ref:thumb_test" and rng.random() < 0.6:
+            opt |= 32                                                        # JPEG_EXIF_THUMBNAIL
         w = dict(i=i, image=name, pixel_type=int(rng.integers(0, 4)), options=opt, max_mcus=0, xoff=0, yoff=0, crop=None)
         if info["ncomp"] == 1 and w["pixel_type"] == 2:
             w["pixel_type"] = 0        # (a gray JPEG to RGB8888: the reference reports 32 bpp and writes 16-bit pixels, SURVEY C.5 -- the other half of each strip is whatever the buffer held)
@@ -55,6 +59,12 @@ def make_walks():
     return walks
 
 
+def jpeg_of(name):
+    from tests.cases import jpeg_for
+    from tests.ref_fixtures import ref_jpeg
+    return ref_jpeg(name[4:]) if name.startswith("ref:") else jpeg_for(name)
+
+
 def sha(a):
     return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()[:20]
 
@@ -64,8 +74,8 @@ def run_one(w, q):
     from tests.cases import jpeg_for
 
     ref = RefDecoder(False)
-    r = ref.decode_cb(jpeg_for(w["image"]), w["pixel_type"], w["options"], max_mcus=w["max_mcus"], xoff=w["xoff"], yoff=w["yoff"],
-                      crop=w["crop"], want_log=True, used_only=w["crop"] is not None)     # (a cropped strip is wider than what the reference writes into it: only iWidthUsed pixels are defined)
+    r = ref.decode_cb(jpeg_of(w["image"]), w["pixel_type"], w["options"], max_mcus=w["max_mcus"], xoff=w["xoff"], yoff=w["yoff"],
+                      crop=w["crop"], want_log=True, used_only=True)     # (a strip can be wider than what the reference writes into it -- crops, decode offsets at reduced scale: only iWidthUsed pixels are defined)
     q.put(dict(rc=int(r["rc"]), last_error=int(r["last_error"]), n_calls=int(r["n_calls"]), dma_reuse=int(r["dma_reuse"]),
                log=sha(r["log"]) if r["log"] is not None else None, canvas=sha(r["canvas"]) if r["canvas"] is not None else None,
                canvas_shape=list(r["canvas"].shape) if r["canvas"] is not None else None))

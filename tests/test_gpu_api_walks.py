@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from tests.cases import jpeg_for
+from tests.ref_fixtures import ref_jpeg
 
 from oracle.loader import RefDecoder
 
@@ -37,6 +38,18 @@ def _documented_refusal(w, info):
         return bool(scale & (scale - 1))                            # two scale bits on a baseline image
     gray_out = w["pixel_type"] == 3 or (opt & 64)
     return (info["subsample"] != 0 and gray_out) or bool((opt & 4) and not (opt & 2))
+
+
+def _crop_reaches_below_the_image(w, jpeg):
+    import jpegdec_amd as J
+    if w["crop"] is None or (w["options"] & 32):
+        return False
+    p = J.PreparedImage(jpeg)
+    try:
+        x, y, cw, ch = J.crop_round(p.info, *w["crop"])
+        return y + ch > p.info.mcus_y * p.info.mcu_h
+    finally:
+        p.close()
 
 
 def _pixels_undefined_in_the_reference(w, jpeg):
@@ -69,18 +82,20 @@ def test_api_walks_match_the_reference(product_class):
         if "crashed" in ref:
             crashed += 1
             continue
-        jpeg = jpeg_for(w["image"])
+        jpeg = ref_jpeg(w["image"][4:]) if w["image"].startswith("ref:") else jpeg_for(w["image"])
         info = product_class.info(jpeg)
         r = product_class.decode_cb(jpeg, w["pixel_type"], w["options"], max_mcus=w["max_mcus"], xoff=w["xoff"], yoff=w["yoff"],
-                                    crop=w["crop"], want_log=True, used_only=w["crop"] is not None)
+                                    crop=w["crop"], want_log=True, used_only=True)
         if r["rc"] == 0 and r["last_error"] == 3 and _documented_refusal(w, info):
             refused += 1
+            continue
+        if _crop_reaches_below_the_image(w, jpeg):                   # the reference decodes the bytes behind the scan as extra rows
             continue
         got = dict(rc=int(r["rc"]), last_error=int(r["last_error"]), n_calls=int(r["n_calls"]), dma_reuse=int(r["dma_reuse"]),
                    log=_sha(r["log"]) if r["log"] is not None else None, canvas=_sha(r["canvas"]) if r["canvas"] is not None else None)
         want = {k: ref[k] for k in got}
-        if ref["rc"] != 1:                                           # a failed decode: the verdict and how far the callbacks got
-            got = {k: got[k] for k in ("rc", "last_error", "n_calls")}
+        if ref["rc"] != 1:                                           # a failed decode: the verdict (how many strips the reference still delivers
+            got = {k: got[k] for k in ("rc", "last_error")}          # depends on what its 2 KB file buffer holds behind the data: DESIGN.md 3)
             want = {k: want[k] for k in got}
         elif _pixels_undefined_in_the_reference(w, jpeg):
             got.pop("canvas"); want.pop("canvas")
@@ -91,4 +106,4 @@ def test_api_walks_match_the_reference(product_class):
     if wrong and os.environ.get("JDA_API_WALK_DUMP"):
         json.dump(wrong, open(os.environ["JDA_API_WALK_DUMP"], "w"))
     assert not wrong, (len(wrong), wrong[:12])
-    assert compared >= 300 and refused <= 40 and loose <= 40, (compared, refused, crashed, loose)
+    assert compared >= 450 and refused <= 30 and loose <= 80, (compared, refused, crashed, loose)      # (loose: draw sequence compared, pixels undefined in the reference)
