@@ -298,11 +298,12 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         //  - the scaled paths and JPEGPutMCU8BitGray for 8x8 MCUs (:2799-2840) do not clip: the overhang lands at
         //    the start of the next buffer row, after that row's own pixels were written ("wrap", replayed in the
         //    same order here; only the overhang of the very last row is dropped instead of overrunning the buffer);
-        //  - the full-size colour paths and 4:2:0 clip at the pitch (:3017-3030, :3079-3095, :3520-3524, :4318-4330).
+        //  - the full-size paths of 4:4:4, gray -> RGB565 and 4:2:0 clip at the pitch (:3017-3030, :3079-3095, :3520-3524, :4318-4330).
         // Known divergence: a 4:4:4 image whose width is not a multiple of 8, full size, RGB565/RGB8888: the
         // reference's clipped last MCU advances pCb/pCr but not pY per row (:3521-3557), so its last partial MCU
         // column mixes luma of the wrong pixels; this path delivers the correct pixels there.
-        const bool wrap = shift != 0 || (pt == EIGHT_BIT_GRAYSCALE && s->info.mcu_w == 8);
+        //  - neither do JPEGPutMCU21 / JPEGPutMCU12 (4:2:2, 4:4:0) at any size or pixel type (:4546-4868, :2842-2943: fixed 8- / 16-pixel loops).
+        const bool wrap = shift != 0 || (pt == EIGHT_BIT_GRAYSCALE && s->info.mcu_w == 8) || s->info.subsample == 0x21 || s->info.subsample == 0x12;
         const int pitch_px = s->crop_w;
         int x0 = 0, x1 = -1;
         for (int x = 0; x < s->info.mcus_x; x++) {

@@ -23,6 +23,7 @@ IMAGES = ["c420_333x217", "c444_333x217", "gray_333x217", "c422_333x217", "c440_
 REF_IMAGES = ["tulips", "zebra", "sciopero", "croptest", "thumb_test", "corrupt2", "corrupt3", "corrupt5", "demo"]      # the reference's own fixtures (tests/golden/ref/)
 N_WALKS = 420
 N_REF_WALKS = 160
+N_FB_WALKS = 160                      # setFramebuffer() instead of a draw callback
 SCALES = (0, 0, 0, 2, 4, 8)            # full size as often as the three reduced ones together
 OUT = os.path.join(ROOT, "tests", "golden", "api_walks.json")
 
@@ -33,8 +34,9 @@ def make_walks():
     import jpegdec_amd as J
 
     walks = []
-    for i in range(N_WALKS + N_REF_WALKS):
-        name = IMAGES[int(rng.integers(0, len(IMAGES)))] if i < N_WALKS else "ref:" + REF_IMAGES[int(rng.integers(0, len(REF_IMAGES)))]
+    for i in range(N_WALKS + N_REF_WALKS + N_FB_WALKS):
+        fb = i >= N_WALKS + N_REF_WALKS
+        name = IMAGES[int(rng.integers(0, len(IMAGES)))] if (i < N_WALKS or (fb and rng.random() < 0.7)) else "ref:" + REF_IMAGES[int(rng.integers(0, len(REF_IMAGES)))]
         info = J.parse(jpeg_of(name))
         opt = int(SCALES[int(rng.integers(0, len(SCALES)))])
         if rng.random() < 0.06:
@@ -55,6 +57,12 @@ def make_walks():
         if rng.random() < 0.35 and info["width"] > 48 and info["height"] > 48:
             cx, cy = int(rng.integers(0, info["width"] - 32)), int(rng.integers(0, info["height"] - 32))
             w["crop"] = [cx, cy, int(rng.integers(8, info["width"] - cx + 16)), int(rng.integers(8, info["height"] - cy + 16))]
+        if fb:
+            w["fb"] = True
+            w["max_mcus"] = 0; w["xoff"] = w["yoff"] = 0; w["options"] &= ~(128 | 32)
+            if w["crop"] is not None:                                        # (inside the image: an overhanging request is undefined, see the test)
+                cx, cy = w["crop"][0], w["crop"][1]
+                w["crop"][2] = min(w["crop"][2], info["width"] - cx); w["crop"][3] = min(w["crop"][3], info["height"] - cy)
         walks.append(w)
     return walks
 
@@ -74,6 +82,15 @@ def run_one(w, q):
     from tests.cases import jpeg_for
 
     ref = RefDecoder(False)
+    if w.get("fb"):
+        import jpegdec_amd as J
+        from tests.fb_region import fb_defined_bytes
+        jpeg = jpeg_of(w["image"])
+        rc, fb = ref.decode_fb(jpeg, w["pixel_type"], w["options"], crop=w["crop"])
+        p = J.PreparedImage(jpeg)
+        n = fb_defined_bytes(J, p.info, w["pixel_type"], w["options"], w["crop"])      # (behind them the reference overruns the image)
+        q.put(dict(rc=int(rc), last_error=int(ref.last_error), fb=sha(fb[:n]) if fb is not None else None, fb_bytes=int(n)))
+        return
     r = ref.decode_cb(jpeg_of(w["image"]), w["pixel_type"], w["options"], max_mcus=w["max_mcus"], xoff=w["xoff"], yoff=w["yoff"],
                       crop=w["crop"], want_log=True, used_only=True)     # (a strip can be wider than what the reference writes into it -- crops, decode offsets at reduced scale: only iWidthUsed pixels are defined)
     q.put(dict(rc=int(r["rc"]), last_error=int(r["last_error"]), n_calls=int(r["n_calls"]), dma_reuse=int(r["dma_reuse"]),
@@ -98,7 +115,7 @@ def main():
         else:
             res = q.get()
         out.append(dict(walk=w, ref=res))
-        print(w["i"], w["image"], w["pixel_type"], w["options"], res.get("crashed") or (res["rc"], res["last_error"], res["n_calls"]), flush=True)
+        print(w["i"], w["image"], w["pixel_type"], w["options"], res.get("crashed") or (res["rc"], res["last_error"], res.get("n_calls")), flush=True)
     json.dump(dict(generator="tests/golden/make_api_walk_golden.py", reference="oracle/_ref scalar build (-DNO_SIMD) of /root/reference", walks=out),
               open(OUT, "w"), indent=0)
 

@@ -52,6 +52,25 @@ def _crop_reaches_below_the_image(w, jpeg):
         p.close()
 
 
+def _fb_undefined_in_the_reference(w, jpeg):
+    """framebuffer mode: DESIGN.md 3's known divergences"""
+    import jpegdec_amd as J
+    p = J.PreparedImage(jpeg)
+    try:
+        info = p.info
+        if info.subsample == 0x12 and w["pixel_type"] == 2 and (w["options"] & 14) == 4 and not (w["options"] & 64):
+            return True                                              # JPEGPutMCU12's pointer bug (see below)
+        # a 4:4:4 image whose width is not a multiple of 8, full size, colour output: the reference's clipped last MCU advances
+        # pCb / pCr but not pY (jpeg.inl:3521-3557); the product delivers the correct pixels there
+        if info.subsample == 0x11 and info.ncomp == 3 and (info.width & 7) and not (w["options"] & 14) and w["pixel_type"] != 3 and not (w["options"] & 64):
+            return True
+        if w["crop"] is not None and (w["options"] & 14):
+            return True
+    finally:
+        p.close()
+    return False
+
+
 def _pixels_undefined_in_the_reference(w, jpeg):
     """where the reference's strips hold bytes it never wrote (or wrote somewhere else): only the draw sequence is compared"""
     import jpegdec_amd as J
@@ -84,6 +103,24 @@ def test_api_walks_match_the_reference(product_class):
             continue
         jpeg = ref_jpeg(w["image"][4:]) if w["image"].startswith("ref:") else jpeg_for(w["image"])
         info = product_class.info(jpeg)
+        if w.get("fb"):
+            rc, fb = product_class.decode_fb(jpeg, w["pixel_type"], w["options"], crop=w["crop"])
+            if rc == 0 and product_class.last_error == 3 and _documented_refusal(w, info):
+                refused += 1
+                continue
+            if _crop_reaches_below_the_image(w, jpeg):
+                continue
+            got = dict(rc=int(rc), last_error=int(product_class.last_error), fb=_sha(fb[: ref["fb_bytes"]]) if fb is not None else None)
+            want = {k: ref[k] for k in got}
+            if ref["rc"] != 1:
+                got.pop("fb"); want.pop("fb")
+            elif _fb_undefined_in_the_reference(w, jpeg):
+                got.pop("fb"); want.pop("fb")
+                loose += 1
+            if got != want:
+                wrong.append((w, {k: (got[k], want[k]) for k in got if got[k] != want[k]}))
+            compared += 1
+            continue
         r = product_class.decode_cb(jpeg, w["pixel_type"], w["options"], max_mcus=w["max_mcus"], xoff=w["xoff"], yoff=w["yoff"],
                                     crop=w["crop"], want_log=True, used_only=True)
         if r["rc"] == 0 and r["last_error"] == 3 and _documented_refusal(w, info):
@@ -106,4 +143,4 @@ def test_api_walks_match_the_reference(product_class):
     if wrong and os.environ.get("JDA_API_WALK_DUMP"):
         json.dump(wrong, open(os.environ["JDA_API_WALK_DUMP"], "w"))
     assert not wrong, (len(wrong), wrong[:12])
-    assert compared >= 450 and refused <= 30 and loose <= 80, (compared, refused, crashed, loose)      # (loose: draw sequence compared, pixels undefined in the reference)
+    assert compared >= 600 and refused <= 30 and loose <= 100, (compared, refused, crashed, loose)      # (loose: draw sequence compared, pixels undefined in the reference)
