@@ -231,6 +231,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         if (ti.jpeg_type == 1 && s->info.jpeg_type == 0 && !(iOptions & (JPEG_SCALE_HALF | JPEG_SCALE_EIGHTH))) { s->error = JPEG_UNSUPPORTED_FEATURE; return 0; }
         // the reference parses the thumbnail over its own state: the object now describes the thumbnail
         ti.has_thumb = s->info.has_thumb; ti.thumb_w = s->info.thumb_w; ti.thumb_h = s->info.thumb_h; ti.thumb_offset = 0;
+        if (!ti.orientation) ti.orientation = s->info.orientation;       // (ucOrientation is only written when an orientation tag is met: the main image's stays)
         s->data += s->info.thumb_offset; s->size -= s->info.thumb_offset;
         s->info = ti;
         s->crop_x = s->crop_y = 0; s->crop_w = ti.width; s->crop_h = ti.height;      // the SOF handler resets the whole crop rectangle (jpeg.inl:1683-1685)
@@ -348,6 +349,23 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         }
         int half = 0;
         if (n > 65536) n = 65536;
+        // The reference's strip buffer is usPixels[2048] inside its state; a plan can ask for more (a decode x offset on an image whose
+        // width is not a whole number of MCUs widens the row's last strip, jpeg.inl:5328-5335 -- the reference then writes over the
+        // tables behind usPixels).  Here such a strip gets a buffer of its own size: the callback sees the strip the plan describes.
+        size_t need = 0;
+        for (int i = 0; i < n; i++) {
+            const int32_t *r = &rects[(size_t)8 * i];
+            const size_t bytes = (size_t)(r[2] > 0 ? r[2] : 0) * bpp * (size_t)mh;
+            if (bytes > need) need = bytes;
+        }
+        std::vector<uint16_t> big;
+        uint16_t *strip0 = s->strip;
+        size_t half_words = MAX_BUFFERED_PIXELS / 2;
+        if (need > (dma ? sizeof(s->strip) / 2 : sizeof(s->strip)) - 16) {
+            half_words = (need + 31) / 2 & ~(size_t)7;
+            big.assign(half_words * 2 + 16, 0);
+            strip0 = big.data();
+        }
         for (int i = 0; i < n; i++) {
             const int32_t *r = &rects[(size_t)8 * i];
             if (partial) {
@@ -357,7 +375,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
                 if (x_last > s->info.mcus_x - 1) x_last = s->info.mcus_x - 1;
                 if ((r[7] / mh) * s->info.mcus_x + x_last >= mcus_decoded) break;
             }
-            uint16_t *buf = s->strip + (dma ? half * (MAX_BUFFERED_PIXELS / 2) : 0);
+            uint16_t *buf = strip0 + (dma ? half * half_words : 0);
             const int row_bytes = r[2] > 0 ? r[2] * bpp : 0;
             for (int rr = 0; rr < mh; rr++) {
                 const int cy_ = r[7] + rr;                       // strip position in the decoded canvas

@@ -162,6 +162,16 @@ class RefDecoder:
         self.last_error = err.value
         return rc, fb
 
+    def run_script(self, data: bytes, ops, canvas_rows=1200, canvas_pitch=8192):
+        """A sequence of calls on ONE object (ref_run_script in ref_shim.cpp: op, a, b, c, d per row); returns the recorded values."""
+        arr = np.ascontiguousarray(np.asarray(ops, dtype=np.int32).reshape(-1, 5))
+        canvas = np.zeros((canvas_rows, canvas_pitch), dtype=np.uint8)
+        out = np.zeros(4096, dtype=np.int32)
+        self.lib.ref_run_script.restype = C.c_int
+        n = self.lib.ref_run_script(data, len(data), arr.ctypes.data_as(C.c_void_p), arr.shape[0], canvas.ctypes.data_as(C.c_void_p),
+                                    canvas_pitch, canvas_rows, out.ctypes.data_as(C.c_void_p), out.size)
+        return out[: min(n, out.size)].tolist()
+
     def bench(self, datas, pixel_type=RGB8888, options=0, reps=1, threads=1):
         n = len(datas)
         arr = (C.c_char_p * n)(*datas)

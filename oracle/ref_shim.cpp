@@ -159,6 +159,70 @@ int ref_decode_cb2(const uint8_t *data, int len, int pixel_type, int options, in
     return rc;
 }
 
+// A SEQUENCE of calls on ONE object (what state does a decode leave behind for the next one?).  ops: op code + 4 arguments each;
+// out: the values every op records, in order; returns how many were written.
+//   1 setPixelType(a)            -> rc? (void in the class: nothing recorded), then getLastError is NOT touched
+//   2 setMaxOutputSize(a)
+//   3 setCropArea(a, b, c, d)    -> getCropArea's x, y, w, h
+//   4 decode(a, b, options = c)  -> rc, getLastError, draw calls, FNV-1a of the draw log, FNV-1a of the canvas (iWidthUsed pixels of
+//                                   every strip; the canvas is cleared first).  ONE decode per open: the reference does not rewind its
+//                                   file position, a second decode() fails or decodes from the wrong place
+//   5 getters                    -> width, height, bpp, subsample, jpegtype, orientation, hasThumb, thumb w, thumb h, lastError
+//   6 close + openFLASH again    -> open's rc
+static uint32_t fnv1a(const void *p, size_t n, uint32_t h = 2166136261u)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 16777619u; }
+    return h;
+}
+int ref_run_script(const uint8_t *data, int len, const int *ops, int n_ops, uint8_t *canvas, int pitch_bytes, int rows, int *out, int max_out)
+{
+    JPEGDEC *j = new JPEGDEC();
+    Canvas c;
+    static int log[6 * 65536];
+    int n = 0;
+#define PUT(v) do { if (n < max_out) out[n] = (int)(v); n++; } while (0)
+    memset(&c, 0, sizeof(c));
+    c.pix = canvas; c.pitch_bytes = pitch_bytes; c.rows = rows; c.cols_bytes = pitch_bytes; c.used_only = 1; c.log = log; c.max_log = 65536;
+    int opened = j->openFLASH(data, len, draw_to_canvas);
+    PUT(opened);
+    if (opened) j->setUserPointer(&c);
+    for (int i = 0; i < n_ops && opened; i++) {
+        const int *o = ops + 5 * i;
+        switch (o[0]) {
+        case 1: j->setPixelType(o[1]); break;
+        case 2: j->setMaxOutputSize(o[1]); break;
+        case 3: { j->setCropArea(o[1], o[2], o[3], o[4]); int x, y, w, h; j->getCropArea(&x, &y, &w, &h); PUT(x); PUT(y); PUT(w); PUT(h); break; }
+        case 4: {
+            memset(canvas, 0, (size_t)pitch_bytes * rows);
+            c.n_calls = 0; c.dma_reuse = 0; c.last_ptr = NULL;
+            const int rc = j->decode(o[1], o[2], o[3]);
+            PUT(rc); PUT(j->getLastError());
+            // (a failed decode: how far the reference got before it noticed is not pinned)
+            PUT(rc ? c.n_calls : 0);
+            PUT(rc ? fnv1a(log, sizeof(int) * 6 * (size_t)(c.n_calls < 65536 ? c.n_calls : 65536)) : 0);
+            PUT(rc ? fnv1a(canvas, (size_t)pitch_bytes * rows) : 0);
+            break;
+        }
+        case 5:
+            PUT(j->getWidth()); PUT(j->getHeight()); PUT(j->getBpp()); PUT(j->getSubSample()); PUT(j->getJPEGType()); PUT(j->getOrientation());
+            PUT(j->hasThumb()); PUT(j->getThumbWidth()); PUT(j->getThumbHeight()); PUT(j->getLastError());
+            break;
+        case 6:
+            j->close();
+            opened = j->openFLASH(data, len, draw_to_canvas);
+            PUT(opened);
+            if (opened) j->setUserPointer(&c);
+            break;
+        default: break;
+        }
+    }
+#undef PUT
+    if (opened) j->close();
+    delete j;
+    return n;
+}
+
 // Framebuffer-mode decode (jpeg.inl:5114-5124): caller buffer, pitch = image width,
 // rows rounded up to an MCU multiple by the caller.
 int ref_decode_fb_crop(const uint8_t *data, int len, int pixel_type, int options, const int *crop,
