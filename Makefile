@@ -31,6 +31,18 @@ classshim: tests/libjpegdec_class_shim.so
 tests/libjpegdec_class_shim.so: oracle/ref_shim.cpp include/JPEGDEC.h $(LIB)
 	$(CXX) -O2 -std=c++17 -fPIC -shared -w -DSHIM_PRODUCT -Iinclude -o $@ oracle/ref_shim.cpp -Ljpegdec_amd -ljpegdec_amd -lpthread -Wl,-rpath,'$$ORIGIN/../jpegdec_amd'
 
+# the same driver over the class's HOST logic alone: JPEGDEC.cpp + the host front end + a CPU stand-in for the device entry points
+# (tests/class_cpu/stub_runtime.cpp: pixels from the oracle) -- test infrastructure: the recorded reference walks run on it without a
+# GPU (tests/test_class_walks_cpu.py), the second build under AddressSanitizer
+classcpu: tests/class_cpu/libjpegdec_class_cpu.so tests/class_cpu/walks_asan
+CLASS_CPU_SRCS = oracle/ref_shim.cpp $(CSRC)/JPEGDEC.cpp $(CSRC)/jda_frontend.cpp tests/class_cpu/stub_runtime.cpp
+tests/class_cpu/libjpegdec_class_cpu.so: $(CLASS_CPU_SRCS) oracle/jpegdec_oracle.c include/JPEGDEC.h include/jpegdec_amd.h
+	$(CC) -O2 -std=c11 -fPIC -c -o tests/class_cpu/oracle.o oracle/jpegdec_oracle.c
+	$(CXX) -O2 -std=c++17 -fPIC -shared -w -DSHIM_PRODUCT -Iinclude -o $@ $(CLASS_CPU_SRCS) tests/class_cpu/oracle.o -lpthread
+tests/class_cpu/walks_asan: $(CLASS_CPU_SRCS) tests/class_cpu/walks_main.cpp oracle/jpegdec_oracle.c include/JPEGDEC.h include/jpegdec_amd.h
+	$(CC) -O1 -g -std=c11 -fsanitize=address,undefined -fno-omit-frame-pointer -c -o tests/class_cpu/oracle_asan.o oracle/jpegdec_oracle.c
+	$(CXX) -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -w -DSHIM_PRODUCT -Iinclude -o $@ $(CLASS_CPU_SRCS) tests/class_cpu/walks_main.cpp tests/class_cpu/oracle_asan.o -lpthread
+
 # a plain C program on the C flavour of the API (JPEG_openFile / JPEG_decode / ...), compiled with the C compiler
 cuser: tests/capi_c/c_user
 tests/capi_c/c_user: tests/capi_c/c_user.c include/JPEGDEC.h $(LIB)
@@ -47,7 +59,7 @@ tests/fuzz/frontend_fuzz: tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp 
 	$(CXX) -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Wall -Iinclude -pthread -o $@ tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp
 
 clean:
-	rm -f $(LIB) tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user
+	rm -f $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim classshim cuser jpegtest frontfuzz clean
+.PHONY: all lib oracle hostsim classshim classcpu cuser jpegtest frontfuzz clean

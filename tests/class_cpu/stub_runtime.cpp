@@ -1,0 +1,78 @@
+// tests/class_cpu/stub_runtime.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// A CPU stand-in for the four device entry points the drop-in class (jpegdec_amd/csrc/JPEGDEC.cpp) calls, so that the class's HOST
+// logic -- option handling, crop rounding, the JPEGDRAW replay, framebuffer wrap / clip, EXIF thumbnails, error codes, what one call
+// leaves behind for the next -- can be run here, without a GPU, against the walks recorded from the unmodified reference
+// (tests/golden/api_walks.json, script_walks.json), and under AddressSanitizer.  The pixels come from the oracle's CPU restatement
+// (oracle/jpegdec_oracle.c), the number of MCUs in front of a bad one from the product's own serial pre-scan (jda_frontend.cpp, host
+// code): exactly what the device runtime reports.  Nothing here is measured or shipped; the GPU tests run the same walks through
+// the real runtime.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/jpegdec_amd.h"
+extern "C" {
+#include "../../oracle/jpegdec_oracle.h"
+}
+
+struct jda_ctx { int device; };
+
+extern "C" {
+
+jda_ctx *jda_create(int32_t device, int32_t *err) { if (err) *err = JDA_SUCCESS; jda_ctx *c = new jda_ctx; c->device = device; return c; }
+void jda_destroy(jda_ctx *ctx) { delete ctx; }
+
+int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                            void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles)
+{
+    if (mcus_decoded) *mcus_decoded = 0;
+    if (tiles) tiles[0] = tiles[1] = 0;
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    int32_t err = JDA_SUCCESS;
+    jda_image *img = jda_prepare(jpeg, len, &err);
+    if (!img) return err;
+    const jda_image_info I = *jda_image_get_info(img);
+    uint32_t nok = 0;
+    (void)jda_image_block_index(img, &nok);
+    jda_image_free(img);
+    if (mcus_decoded) *mcus_decoded = (int32_t)nok;
+    int bpp, ow, oh, cw, ch;
+    const int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
+    if (rc != JDA_SUCCESS) return rc;
+    std::vector<uint8_t> canvas((size_t)cw * bpp * ch, 0);
+    int oerr = 0;
+    (void)orc_decode(jpeg, len, pixel_type, options, canvas.data(), cw * bpp, ch, &oerr);
+    const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
+    // MCUs from the bad one on are zeros in the product (the oracle may have left a partly written one)
+    const int mw = cw / I.mcus_x, mh = ch / I.mcus_y;
+    if (!complete)
+        for (uint32_t m = nok; m < (uint32_t)(I.mcus_x * I.mcus_y); m++) {
+            const int mx = (int)(m % (uint32_t)I.mcus_x), my = (int)(m / (uint32_t)I.mcus_x);
+            for (int r = 0; r < mh; r++) memset(canvas.data() + ((size_t)(my * mh + r) * cw + (size_t)mx * mw) * bpp, 0, (size_t)mw * bpp);
+        }
+    int r0 = 0, r1 = rows < ch ? rows : ch, x0 = 0, x1 = cw;
+    if (mcu_rect) {                                                  // only the rectangle's rows are written, zeros left and right of it
+        r0 = mcu_rect[1] * mh; r1 = mcu_rect[3] * mh < r1 ? mcu_rect[3] * mh : r1;
+        x0 = mcu_rect[0] * mw; x1 = mcu_rect[2] * mw < cw ? mcu_rect[2] * mw : cw;
+        if (x1 < x0) x1 = x0;
+    }
+    const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
+    for (int r = r0; r < r1; r++) {
+        uint8_t *dst = (uint8_t *)host_pixels + (size_t)r * pitch_bytes;
+        memset(dst, 0, row_bytes);
+        const size_t a = (size_t)x0 * bpp, b = (size_t)x1 * bpp < row_bytes ? (size_t)x1 * bpp : row_bytes;
+        if (b > a) memcpy(dst + a, canvas.data() + (size_t)r * cw * bpp + a, b - a);
+    }
+    return complete ? JDA_SUCCESS : JDA_DECODE_ERROR;
+}
+
+int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, void *host_pixels,
+                          int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded)
+{
+    return jda_decode_to_host_rect(ctx, jpeg, len, pixel_type, options, NULL, host_pixels, pitch_bytes, rows, mcus_decoded, NULL);
+}
+
+} // extern "C"

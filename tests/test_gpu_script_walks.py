@@ -24,22 +24,8 @@ def product_class(gpu_ctx):
 
 
 def test_call_sequences_leave_the_state_the_reference_leaves(product_class):
-    G = json.load(open(os.path.join(HERE, "golden", "script_walks.json")))
-    compared, wrong = 0, []
-    for item in G["scripts"]:
-        sc, ref = item["script"], item["ref"]
-        if "crashed" in ref:
-            continue
-        jpeg = ref_jpeg(sc["image"][4:]) if sc["image"].startswith("ref:") else jpeg_for(sc["image"])
-        got = product_class.run_script(jpeg, sc["ops"])
-        if got != ref["values"]:
-            first = next((k for k in range(min(len(got), len(ref["values"]))) if got[k] != ref["values"][k]), min(len(got), len(ref["values"])))
-            wrong.append(dict(i=sc["i"], image=sc["image"], ops=sc["ops"], first_difference=first, got=got[max(0, first - 3): first + 6], want=ref["values"][max(0, first - 3): first + 6]))
-        compared += 1
-    if wrong and os.environ.get("JDA_API_WALK_DUMP"):
-        json.dump(wrong, open(os.environ["JDA_API_WALK_DUMP"], "w"))
-    assert not wrong, (len(wrong), wrong[:6])
-    assert compared >= 240
+    from tests.walks import check_script_walks
+    check_script_walks(product_class)
 
 
 def test_a_second_decode_equals_a_first_one(product_class):
