@@ -178,13 +178,12 @@ int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes)
 
 /* H2D: tables + index + filtered scan of one prepared image into one HBM allocation.  For an image prepared
  * with JDA_PREPARE_DEVICE_PRESCAN whose index is still pending, the index is made here on the GPU, equal to
- * the serial pre-scan's entry for entry: with restart markers one lane per restart interval; without, one
- * lane per 256 bytes of the scan, whose decoder states settle by self-synchronisation in a few speculative
- * rounds.  A marker that is not where the MCU count puts it, a corrupt or truncated stream, or states that do
+ * the serial pre-scan's entry for entry: one lane per 256 bytes of the scan, whose decoder states settle by
+ * self-synchronisation in a few speculative rounds (restart intervals end where the filter found the markers).  A marker that is not where the MCU count puts it, a corrupt or truncated stream, or states that do
  * not settle send the image to the serial host pre-scan instead (the image object is completed in place). */
 jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err);
-/* The same for n images at once: all pending block indexes are made in two launches (the per-interval walk is
- * latency-bound, so throughput comes from the number of restart intervals in flight).  out[i] = device image.
+/* The same for n images at once: all pending block indexes are made by the same launches (the walk is latency-bound
+ * per lane, so throughput comes from the number of segments in flight).  out[i] = device image.
  * Returns JDA_SUCCESS or the first error (then every out[i] is NULL). */
 int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out);
 /* The same, tolerant of holes: imgs[i] == NULL (a file jda_prepare_batch rejected) gives out[i] = NULL and status[i] =

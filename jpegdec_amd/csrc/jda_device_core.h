@@ -13,7 +13,7 @@
 //                                                                                  DC-only bypass jpeg.inl:5146-5154
 //   P4  lanes tile the output rows: YCbCr -> RGB565/RGB8888/gray, chroma        <- JPEGPutMCU*    jpeg.inl:2799-4868
 //       upsample, 1/2-1/4-1/8, coalesced stores                                    JPEGPixel*     jpeg.inl:3101-3278
-// plus the per-restart-interval symbol walk of the device pre-scan (jda_prescan_interval).
+// plus the segment walk of the device pre-scan (jda_seg_walk) and the tables it stages (jda_walk_tables_from).
 // The bit reader reproduces the reference's 64-bit window and refill rule exactly, so that the
 // low-bit truncation of SURVEY.md fact 6 is reproduced by construction.
 #ifndef JDA_DEVICE_CORE_H
@@ -476,45 +476,6 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
     return flags;
 }
 
-// ---- walk of one restart interval in skip mode (the GPU side of the pre-scan) -------
-// One lane per restart interval: the interval starts on a byte boundary (right after an RSTn marker the
-// host's filter removed) with zero DC predictors (jpeg.inl:5337-5348), so its symbols can be walked
-// without the intervals before it.  The lane follows JPEGDecodeMCU with iMCU < 0 (:2115-2116: decode
-// symbols, store nothing) and records for every block the reader phase and DC predictor on entry -- the
-// per-block index the host pre-scan makes, entry for entry.
-// What an interval cannot know locally is the reference's window phase: at a restart the reference only
-// rounds ulBitOff up to a byte (no refill), so (pBuf, ulBitOff) at the interval's first bit is
-// (start - j, 8j) with j decided by the previous interval, and the phase decides which magnitude reads get
-// truncated.  Two passes settle it exactly:
-//   MAP   walk with all six possible phases in flight (8j for j = 0..5; 48/56/64 refill at once and join 0): only
-//         symbol lengths matter, the six bit offsets live in the bytes of one 64-bit word.  Result: for
-//         each start phase the phase the NEXT interval starts with.
-//   (host: compose the maps from interval 0, whose phase is 0 -- n_intervals table lookups)
-//   EXACT walk from the now known phase: identical to the serial host pre-scan.
-struct jda_prescan_params {
-    const uint8_t *scan;             // filtered scan (global), padded
-    const uint8_t *tables;           // table blob (global)
-    const uint32_t *restart_pos;     // n_intervals entries
-    const uint8_t *start_phase;      // EXACT: n_intervals entries (bit offset 8j the interval starts with)
-    uint32_t *phase_map;             // MAP out: n_intervals words, 4 bits per start phase j = 0..5: (bit offset the next interval starts with) / 8
-    uint32_t *blk_index;             // EXACT out: n_blocks + 1
-    int16_t *blk_dc;                 // EXACT out: n_blocks
-    uint32_t *stats;                 // EXACT out: [0] first bad MCU (min), [1] marker mismatch, [2] max AC category, [3] max |DC|, [4] truncated reads
-    uint32_t scan_len, n_intervals, n_mcus, interval_mcus;
-    uint8_t nluma, nblocks, dc_id[3], ac_id[3];
-    // when the marker filter ran on the device too (jda_pipeline): [0] filtered length (replaces scan_len), [1] RSTn markers seen
-    // (must be n_intervals - 1, else the stream takes the serial host path); NULL otherwise
-    const uint32_t *filter_result;
-};
-struct jda_prescan_result { uint32_t first_bad, mismatch, max_ac_bits, max_abs_dc, trunc_events, phase_map; };
-
-// lt: the tables in the kernels' LDS layout + JDA_LT_DC16 (jda_p0_tables_from(.., true, true)), staged by the caller's workgroup.
-// The walk is jda_seg_walk's unified step (one symbol, DC or AC alike, by selects; see there) over a whole interval, bounded by
-// its MCU count instead of a bit length, from a known decoder state; the interval's LAST symbol is not followed by a refill (the
-// reference rounds ulBitOff up without one, :5339-5346), every other step ends with one.
-template <bool EXACT>
-JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k, const uint8_t *lt);
-
 // ---- the same, for a tile whose whole scan slice is in the LDS window (the normal case) ----------
 // No lane can leave the window, so the reader needs no bounds check and no HBM path, and the block
 // decode below is written without divergent branches: P1 is bound by the latency of its dependent
@@ -965,19 +926,18 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 }
 
 
-// ---- device pre-scan WITHOUT restart markers ------------------------------------------
+// ---- device pre-scan ----------------------------------------------------------------
 // The filtered scan is cut into segments of JDA_SEG_BYTES; one lane walks one segment's Huffman symbols in skip mode.
 // A lane does not know the decoder state at its segment's first bit -- (bit offset of the next symbol, block within the
 // MCU, zigzag position) -- so it guesses "a block starts here" and walks: Huffman streams re-synchronise by themselves
-// after a few symbols, and an EOB re-synchronises the zigzag position.  The passes:
-//   SPEC   lane i walks segment i from its current idea of the entry state and hands the state at the segment's end to
-//          segment i + 1.  Segment 0's entry state is known, so round r makes segments 0..r exact at the latest; with
-//          self-synchronisation everything is exact after a few rounds.  A round that changes nothing is the fixed point
-//          E[i+1] = walk(i, E[i]) with E[0] true, i.e. the serial decoder's states (induction over i).
-//   COUNT  from the exact entry states: block starts and per-component DC sums of every segment, and how the reference's
-//          window phase propagates across it (all eight byte lags in flight, as jda_prescan_interval's MAP pass)
-//   (exclusive sums / composition over the segments: first block ordinal, DC predictors, window phase at every entry)
-//   WRITE  the walk again, now writing the per-block index and DC predictors exactly as the serial host pre-scan does.
+// after a few symbols, and an EOB re-synchronises the zigzag position.  The passes (jda_kernels.hip):
+//   round 0   every lane walks its segment from the guess and hands the state at the segment's end to the next segment
+//   round 1.. walk again from the entry state the segment before handed over, now counting (block starts, per-component DC sums, how
+//             the reference's window phase propagates: six byte lags in flight); a walk whose exit differs from what the next segment
+//             was entered with puts that segment on the next round's list.  Segment 0's entry state is known, so a round that
+//             leaves its list empty is the fixed point E[i+1] = walk(i, E[i]) with E[0] true: the serial decoder's states
+//   sums      exclusive scan over the segments: first block ordinal, DC predictors, window phase at every entry
+//   WRITE     the walk once more, now writing the per-block index and DC predictors exactly as the serial host pre-scan does.
 // State at a symbol boundary (after the reference's bottom-of-loop refill, before its next top-of-loop refill):
 //   bits 5:0 bit offset from the segment's first bit (entry: how far the previous segment's last symbol reached in),
 //   bits 8:6 block within the MCU, bits 14:9 zigzag position k (0 = the next symbol is a DC code).
@@ -1073,15 +1033,11 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
 // The walks' DC entries: the reference's DC LUT (jpeg.inl:1098-1152) re-laid out like the AC entries -- (code length - 1) << 12 |
 // SSSS << 8 | folded -- so that one 16-bit lookup serves a DC and an AC symbol alike.  "folded" (bit 0): the reference takes code
 // and magnitude from the LUT in one step (:1132-1152) and does not refill between them.
-//   JDA_LT_DC16 (the interval walk, behind the decode kernels' tables): 2 x 256 entries under the reference's own index.
 //   JDA_WT_* (the segment walk's own LDS layout): FOUR tables of 2048 entries -- AC 0, AC 1, DC 0, DC 1 -- under the AC tables'
 //   11-bit key (the stream's top 10 bits, or 1024 + the 10 bits behind six leading ones), so that a step computes ONE address:
 //   table number from the block's place in the MCU, key from the stream.  A DC entry under that key is the reference's for every
 //   stream that has those bits, provided no DC code 111110.. is longer than 10 bits (jda_dc_lut_walkable: the front end keeps
 //   such a file -- none seen -- on the serial pre-scan).
-#define JDA_LT_DC16 JDA_LT_BYTES      // 2 x 256 uint16
-#define JDA_LT_DC16_BYTES 1024
-#define JDA_LT_WALK_BYTES (JDA_LT_DC16 + JDA_LT_DC16_BYTES)
 #define JDA_WT_TABLE_BYTES 4096u
 #define JDA_WT_BYTES (4u * JDA_WT_TABLE_BYTES)
 JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
@@ -1344,120 +1300,6 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     return (p - JDA_SEG_BITS) | (b2 << 5) | (k << 9);
 }
 
-template <bool EXACT>
-JDA_HD jda_prescan_result jda_prescan_interval(const jda_prescan_params &P, uint32_t k, const uint8_t *lt)
-{
-    jda_prescan_result Rs;
-    Rs.first_bad = 0xffffffffu; Rs.mismatch = 0; Rs.max_ac_bits = 0; Rs.max_abs_dc = 0; Rs.trunc_events = 0; Rs.phase_map = 0;
-    const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
-    const uint32_t first_mcu = k * P.interval_mcus;
-    const uint32_t count = P.n_mcus - first_mcu < P.interval_mcus ? P.n_mcus - first_mcu : P.interval_mcus;
-    const uint32_t nluma = P.nluma, nblocks = P.nblocks, total_blocks = count * nblocks;
-    const uint32_t dcb0 = JDA_LT_DC16 + P.dc_id[0] * 512u, dcb1 = JDA_LT_DC16 + P.dc_id[1] * 512u, dcb2 = JDA_LT_DC16 + P.dc_id[2] * 512u;
-    const uint32_t acb0 = JDA_LT_AC + P.ac_id[0] * 4096u, acb1 = JDA_LT_AC + P.ac_id[1] * 4096u, acb2 = JDA_LT_AC + P.ac_id[2] * 4096u;
-    const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 24;     // (the register window reads up to 16 bytes ahead of the bits in use)
-    const uint32_t kOnes = 0x02108421u, kGuard = 0x21084210u;
-    const uint32_t start = rpos[k];
-    uint32_t p = start << 3;                                        // absolute bit position in the filtered scan (< 2^28)
-    // EXACT: the reference reader; the interval starts with (pBuf, ulBitOff) = (start - j, 8 j)
-    uint32_t pos = 0, off = 0;
-    uint32_t U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);     // MAP: the byte lags of the six start phases
-    if (EXACT) { const uint32_t so = (uint32_t)JDA_G(const uint8_t, P.start_phase)[k]; pos = start - (so >> 3); off = so; }
-    // the interval's first block opens with a refill like any other (the lags 6, 7, 8 of a rounded-up offset join lag 0 here)
-    if (EXACT) { if (off > 47u) { pos += off >> 3; off &= 7u; } }
-    else { const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard; U &= ~(f - (f >> 4)); }
-    int32_t pred0 = 0, pred1 = 0, pred2 = 0;
-    uint32_t b = 0, kz = 0, done = 0, g = first_mcu * nblocks;
-    uint32_t max_ac = 0, max_dc = 0, trunc = 0, pend = 0;
-    bool bad = false, stop = total_blocks == 0;
-    jda_seg_reader R;
-    jda_seg_reader_init(R, JDA_G(const uint32_t, P.scan), p);
-    while (!stop) {
-        const bool isdc = kz == 0;
-        const uint32_t c = b < nluma ? 0u : b - nluma + 1u;
-        if (EXACT && isdc) {                                        // a block starts: its DC predictor, and the reader after its opening refill
-            const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-            const bool oor = (pr < -32768) | (pr > 32767);
-            bad |= oor; stop |= oor;
-            JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
-            pend = (pos << JDA_INDEX_OFF_BITS) | off;
-        }
-        const uint32_t w = jda_seg_reader_peek(R, p);
-        const uint32_t dcb = c == 0 ? dcb0 : (c == 1 ? dcb1 : dcb2), acb = c == 0 ? acb0 : (c == 1 ? acb1 : acb2);
-        const uint32_t code12 = w >> 20;
-        const uint32_t a_dc = dcb + 2u * (code12 >= 0xf80u ? (code12 & 0xffu) : (w >> 26));
-        const uint32_t a_ac = acb + 2u * jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
-        const uint32_t e = *(const uint16_t *)(lt + (isdc ? a_dc : a_ac));
-        const uint32_t elow = e & 0xffu;
-        const bool inval = elow == JDA_AC_NONE;                     // :2137-2138, :2237-2238
-        bad |= inval; stop |= inval;
-        const bool live = !stop;
-        const bool eob = (elow == JDA_AC_EOB) & !inval;
-        const uint32_t len = inval ? 1u : (e >> 12) + 1u, sz = (eob | inval) ? 0u : (e >> 8) & 15u;
-        const uint32_t kk = kz + ((e >> 1) & 15u);
-        const bool dcmag = isdc & live & (sz != 0u) & ((e & 1u) == 0u);
-        const bool acmag = !isdc & live & (sz != 0u) & (kk < 64u);
-        const bool ends = (eob | (kk + 1u >= 64u)) & live;
-        const bool last = eob & live & (done + 1u == total_blocks);  // the interval's last symbol, an EOB: no refill behind it (a block that ends
-                                                                     // on its 63rd coefficient has had the AC loop's bottom refill)
-        const uint32_t p1 = p + len;
-        if (EXACT) {
-            off += len;
-            const bool r1 = dcmag & (off > 47u);                    // :2149-2154
-            pos += r1 ? off >> 3 : 0u; off = r1 ? off & 7u : off;
-            if (acmag && off + sz > 64u) { trunc++; pend |= JDA_INDEX_TRUNC; }
-            const uint32_t m = acmag ? sz : 0u;
-            max_ac = m > max_ac ? m : max_ac;
-            off += sz;
-            const int32_t diff = (isdc & live & (sz != 0u)) ? jda_extend_top(w << len, sz) : 0;
-            pred0 += c == 0 ? diff : 0; pred1 += c == 1 ? diff : 0; pred2 += c >= 2 ? diff : 0;
-            const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-            const uint32_t a = (isdc & live) ? (uint32_t)(pr < 0 ? -pr : pr) : 0u;
-            max_dc = a > max_dc ? a : max_dc;
-            const bool r2 = (off > 47u) & !last;
-            pos += r2 ? off >> 3 : 0u; off = r2 ? off & 7u : off;
-            const bool over = pos > limit_pos;
-            bad |= over; stop |= over;
-            if (ends) JDA_G(uint32_t, P.blk_index)[g] = pend;
-        } else {
-            U += (((p & 7u) + len) >> 3) * kOnes;
-            const uint32_t f1 = ((U | kGuard) - 6u * kOnes) & kGuard;
-            U &= dcmag ? ~(f1 - (f1 >> 4)) : 0xffffffffu;
-            U += (((p1 & 7u) + sz) >> 3) * kOnes;
-            const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
-            U &= last ? 0xffffffffu : ~(f - (f >> 4));
-            if ((p1 >> 3) > limit_pos) { bad = true; stop = true; }
-        }
-        p = p1 + sz;
-        kz = ends ? 0u : kk + 1u;
-        b = ends ? (b + 1u == nblocks ? 0u : b + 1u) : b;
-        g += ends ? 1u : 0u;
-        done += ends ? 1u : 0u;
-        stop |= done == total_blocks;
-    }
-    if (bad) { Rs.first_bad = first_mcu + done / (nblocks ? nblocks : 1u); return Rs; }
-    if (!EXACT) {
-        // :5339-5346: every start phase's offset at the interval's end, rounded up to a byte: 0, 8, .., 64
-        const uint32_t frac = (p & 7u) ? 1u : 0u;
-        uint32_t map = 0;
-        for (int j = 0; j < 6; j++) map |= (((U >> (5 * j)) & 15u) + frac) << (4 * j);
-        Rs.phase_map = map;
-        return Rs;
-    }
-    Rs.max_ac_bits = max_ac; Rs.max_abs_dc = max_dc; Rs.trunc_events = trunc;
-    // the interval must end (rounded up to a byte) where the next one starts: the reference counts MCUs and
-    // never looks at marker positions, so a stream whose markers sit elsewhere must take the serial path
-    const uint32_t end_byte = pos + ((off + 7u) >> 3);
-    if (k + 1 < P.n_intervals) { if (end_byte != rpos[k + 1]) Rs.mismatch = 1; }
-    else {
-        // the closing entry = the reader as the serial pre-scan leaves it: a restart interval that ends with the image is still
-        // rounded up to a byte (jpeg.inl:5339-5346 runs after the last MCU as well)
-        const uint32_t off_end = count == P.interval_mcus ? ((off + 7u) & ~7u) : off;
-        JDA_G(uint32_t, P.blk_index)[(size_t)P.n_mcus * nblocks] = (pos << JDA_INDEX_OFF_BITS) | off_end;
-    }
-    return Rs;
-}
-
 // ================================================================================================
 // Tile phases.  Every lane of the tile's wavefront runs each phase; a wave-local fence separates
 // consecutive phases (the host emulator runs all 64 lanes of a phase, then the next).
@@ -1550,17 +1392,10 @@ JDA_HD uint32_t jda_nibble_list(uint32_t m)
 }
 // tables: once per workgroup (tid = thread in workgroup, nthreads = workgroup size)
 // with_long: also the long halves of the AC LUTs (JDA_LT_LONG; tab_lds then holds JDA_LT_BYTES + JDA_LT_LONG_BYTES)
-JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false, bool with_walk = false);
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false);
 JDA_HD void jda_p0_tables(const jda_dev_desc &D, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long = false) { jda_p0_tables_from(D.tables, tid, nthreads, tab_lds, with_long); }
-JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long, bool with_walk)
+JDA_HD void jda_p0_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *tab_lds, bool with_long)
 {
-    if (with_walk) {                                                // the segment walk's DC table (JDA_LT_DC16; tab_lds then holds JDA_LT_WALK_BYTES)
-        for (uint32_t j = tid; j < 512u; j += nthreads) {
-            const uint32_t t = j >> 8, idx = j & 255u;
-            const uint8_t JDA_GLOBAL *dc = JDA_G(const uint8_t, tables) + JDA_TB_DC + t * 1024u;
-            ((uint16_t *)(tab_lds + JDA_LT_DC16))[j] = (uint16_t)jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]);
-        }
-    }
     const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, tables);
     jda_chunk16_alias *tab = (jda_chunk16_alias *)tab_lds;
     // DC LUTs: blob[0, 2048) -> LT_DC ; AC short halves: blob[2048 + k*4096, +2048) -> LT_AC + k*2048 ;

@@ -13,7 +13,7 @@
 //   P4  lanes tile the tile's output rows: YCbCr -> RGB and 16-byte stores to consecutive addresses.
 // While a wavefront decodes tile n it prefetches tile n+1's index entries and scan slice (HBM -> registers
 // -> LDS) and tile n+2's record.
-// jda_prescan_intervals<EXACT>: the device half of the pre-scan for streams with restart markers.
+// jda_filter_*, jda_segscan_* : the marker filter and the per-block index on the device.
 // No MFMA: the IDCT is shift/add integer work; the decode kernel is bound by VALU issue.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -417,76 +417,6 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Device half of the pre-scan for streams with restart markers: one lane per restart
-// interval walks its Huffman symbols in skip mode -- first to find how the reference's window phase
-// propagates across the interval (MAP), then, with every interval's phase known, to write the per-block
-// index exactly as the serial host pre-scan would (EXACT).  Latency-bound scalar work (a lane owns a whole
-// interval), so it pays when many intervals / images are in flight; it replaces ~15 ms of serial host work
-// per 4096x4096 image.
-template <bool EXACT>
-__global__ __launch_bounds__(64)
-void jda_prescan_intervals(const jda_prescan_params *__restrict__ params)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t tab[JDA_LT_WALK_BYTES];   // the tables in the kernels' layout + the walk's DC table
-    jda_prescan_params P = params[blockIdx.y];                  // one image per grid row
-    bool marker_count_off = false;
-    if (P.filter_result) {                                      // the filter ran on the device: its results are in memory only
-        P.scan_len = JDA_G(const uint32_t, P.filter_result)[0];
-        marker_count_off = JDA_G(const uint32_t, P.filter_result)[1] + 1u != P.n_intervals;
-    }
-    jda_p0_tables_from(P.tables, threadIdx.x, 64u, tab, true, true);
-    __syncthreads();
-    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
-    if (k >= P.n_intervals) return;
-    if (marker_count_off) {                                     // the restart positions are not what the MCU count says: nothing to walk
-        if (EXACT && k == 0) atomicOr(&P.stats[1], 1u);
-        return;
-    }
-    const jda_prescan_result R = jda_prescan_interval<EXACT>(P, k, tab);
-    if (!EXACT) { P.phase_map[k] = R.phase_map; return; }
-    uint32_t *st = P.stats;
-    if (R.first_bad != 0xffffffffu) atomicMin(&st[0], R.first_bad);
-    if (R.mismatch) atomicOr(&st[1], 1u);
-    atomicMax(&st[2], R.max_ac_bits);
-    atomicMax(&st[3], R.max_abs_dc);
-    if (R.trunc_events) atomicAdd(&st[4], R.trunc_events);
-}
-
-// Between MAP and EXACT: the window phase every interval starts with = the maps composed from interval 0 (whose phase is 0:
-// the scan starts with pBuf at its first byte and ulBitOff 0, jpeg.inl:4996-4998).  One thread per image walks its intervals --
-// a few hundred table lookups; doing it here keeps the host out of the middle of the pre-scan (jda_pipeline).
-__global__ __launch_bounds__(64)
-void jda_prescan_compose(const jda_prescan_params *__restrict__ params, uint32_t n_images)
-{
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n_images) return;
-    const jda_prescan_params P = params[i];
-    uint8_t *phase = const_cast<uint8_t *>(P.start_phase);
-    P.stats[0] = 0xffffffffu;                         // "first bad MCU": a minimum is taken over the intervals (the other words start as zeros)
-    uint32_t j = 0;
-    for (uint32_t k = 0; k < P.n_intervals; k++) {
-        phase[k] = (uint8_t)(8u * j);
-        j = (P.phase_map[k] >> (4u * (j > 5u ? 0u : j))) & 15u;
-    }
-}
-extern "C" hipError_t jda_launch_prescan_compose(const jda_prescan_params *params, uint32_t n_images, hipStream_t stream)
-{
-    if (n_images == 0) return hipSuccess;
-    hipLaunchKernelGGL(jda_prescan_compose, dim3((n_images + 63u) / 64u), dim3(64), 0, stream, params, n_images);
-    return hipGetLastError();
-}
-
-// params: device array of n_images descriptors; max_intervals: the largest n_intervals among them
-extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream)
-{
-    if (n_images == 0 || max_intervals == 0) return hipSuccess;
-    const dim3 grid((max_intervals + 63u) / 64u, n_images), block(64);
-    if (exact) hipLaunchKernelGGL(jda_prescan_intervals<true>, grid, block, 0, stream, params);
-    else hipLaunchKernelGGL(jda_prescan_intervals<false>, grid, block, 0, stream, params);
-    return hipGetLastError();
-}
-
 // wave-wide maximum / sum of a value of every ACTIVE lane (inactive lanes contribute nothing), the same in every lane
 __device__ __forceinline__ uint32_t jda_wave_max_u32(uint32_t v)
 {
@@ -504,88 +434,48 @@ __device__ __forceinline__ uint32_t jda_wave_sum_u32(uint32_t v)
     return v;
 }
 // ------------------------------------------------------------------------------------------------
-// Device pre-scan for streams WITHOUT restart markers (the algorithm is described at jda_seg_walk): one
-// lane per 256-byte segment of the filtered scan, a wavefront's 64 consecutive segments staged in LDS with one
-// coalesced copy (268-byte slots: a lane's reads run a few bytes into the next segment; the odd dword stride keeps
-// the lanes on different banks), four wavefronts per workgroup around one copy of the tables.
-template <int OP>
+// The per-block index on the device (the algorithm is described at jda_seg_walk): one lane per 256-byte segment
+// of the filtered scan, read where it lies; a workgroup of four wavefronts around one copy of the walk's tables.  This kernel is the
+// WRITE pass (entry states settled, every segment's first block ordinal / DC predictors / window lag known): it stores the index
+// entries and DC predictors, exactly the serial pre-scan's.
 __global__ __launch_bounds__(256)
-void jda_segscan(const jda_segscan_params *__restrict__ params, uint32_t round)
+void jda_segscan_write(const jda_segscan_params *__restrict__ params)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
     const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
     if (blockIdx.x * 256u >= P.n_segs) return;                       // (uniform per workgroup: images of a batch differ in size)
-    // a speculative round after one that changed nothing has nothing to do (the host launches a fixed number of rounds when it
-    // does not want to look at the counters in between)
-    if (OP == JDA_SEG_SPEC && round >= 1 && JDA_G(const uint32_t, P.stats)[8u + round - 1u] == 0u) return;
     uint8_t *tab = lds;
-    jda_walk_tables_from(P.tables, threadIdx.x, 256u, tab);                 // the walk's four tables are all that is staged
+    jda_walk_tables_from(P.tables, threadIdx.x, 256u, tab);          // the walk's four tables are all that is staged
     const bool in_range = seg < P.n_segs;
-    // what this lane has to do
-    uint32_t *e_cur = (round & 1u) ? P.entry_nxt : P.entry_cur, *e_nxt = (round & 1u) ? P.entry_cur : P.entry_nxt;
     uint32_t entry = 0;
-    bool need = in_range;
-    if (OP == JDA_SEG_SPEC) {
-        if (in_range) { entry = e_cur[seg]; need = round == 0 || (entry & JDA_SEG_CHANGED) != 0; }
-    } else if (in_range) entry = ((round & 1u) ? P.entry_nxt : P.entry_cur)[seg];
-    if (OP == JDA_SEG_WRITE && in_range && P.seg_start[(size_t)seg * 5] > P.n_blocks_total) need = false;   // past the image
+    bool need = in_range;                                            // (the wavefronts stay whole for the reduction of their results)
+    if (in_range) entry = P.entry_cur[seg];
+    if (in_range && P.seg_start[(size_t)seg * 5] > P.n_blocks_total) need = false;   // past the image
     __syncthreads();                                                 // the tables are in LDS
-    if (!in_range && OP != JDA_SEG_WRITE) return;                    // (the write pass keeps its wavefronts whole for the reduction of their results)
-    if (!in_range) need = false;
     const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
     jda_seg_sum S;
     jda_seg_stats ST;
     ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
-    if (OP == JDA_SEG_SPEC) {
-        const uint32_t old = e_cur[seg + 1] & ~JDA_SEG_CHANGED;
-        uint32_t out = old;
-        if (need) {
-            const uint32_t x = (P.restart_pos ? jda_seg_walk<JDA_SEG_SPEC, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST)
-                                              : jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST)) & ~JDA_SEG_CHANGED;
-            out = x;
-            if (x != old) { out |= JDA_SEG_CHANGED; atomicAdd(&P.stats[8 + round], 1u); }
-        }
-        e_nxt[seg + 1] = out;
-        if (seg == 0) e_nxt[0] = 0;                                  // the scan starts at a block start (jpeg.inl:4996-4998)
-    } else if (OP == JDA_SEG_COUNT) {
-        if (P.restart_pos) (void)jda_seg_walk<JDA_SEG_COUNT, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
-        else (void)jda_seg_walk<JDA_SEG_COUNT, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
-        uint32_t *o = P.seg_sum + (size_t)seg * 6;
-        o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
-    } else if (need) {
+    if (need) {
         if (P.restart_pos) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
         else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
     }
-    if (OP == JDA_SEG_WRITE) {
-        // the image's result words, ONE atomic per wavefront and word: every lane has maxima to report, and 6,500 lanes of an image
-        // finishing together on the same two addresses cost a quarter of the pass (1.54 -> 1.13 ms per 64-image batch)
-        if (!need) { ST.bad = 0; ST.mismatch = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; }
-        const uint32_t m_ac = jda_wave_max_u32(ST.max_ac_bits), m_dc = jda_wave_max_u32(ST.max_abs_dc), n_tr = jda_wave_sum_u32(ST.trunc_events);
-        const bool any_bad = __builtin_amdgcn_ballot_w64(ST.bad != 0) != 0, any_mis = __builtin_amdgcn_ballot_w64(ST.mismatch != 0) != 0;
-        const uint32_t n_term = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ST.terminal != 0));
-        if ((threadIdx.x & 63u) == 0u) {
-            if (any_bad) atomicOr(&P.stats[0], 1u);
-            if (any_mis) atomicOr(&P.stats[5], 1u);
-            if (n_term) atomicAdd(&P.stats[1], n_term);
-            if (m_ac) atomicMax(&P.stats[2], m_ac);
-            if (m_dc) atomicMax(&P.stats[3], m_dc);
-            if (n_tr) atomicAdd(&P.stats[4], n_tr);
-        }
+    // the image's result words, ONE atomic per wavefront and word: every lane has maxima to report, and 6,500 lanes of an image
+    // finishing together on the same two addresses cost a quarter of the pass (1.54 -> 1.13 ms per 64-image batch)
+    const uint32_t m_ac = jda_wave_max_u32(ST.max_ac_bits), m_dc = jda_wave_max_u32(ST.max_abs_dc), n_tr = jda_wave_sum_u32(ST.trunc_events);
+    const bool any_bad = __builtin_amdgcn_ballot_w64(ST.bad != 0) != 0, any_mis = __builtin_amdgcn_ballot_w64(ST.mismatch != 0) != 0;
+    const uint32_t n_term = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ST.terminal != 0));
+    if ((threadIdx.x & 63u) == 0u) {
+        if (any_bad) atomicOr(&P.stats[0], 1u);
+        if (any_mis) atomicOr(&P.stats[5], 1u);
+        if (n_term) atomicAdd(&P.stats[1], n_term);
+        if (m_ac) atomicMax(&P.stats[2], m_ac);
+        if (m_dc) atomicMax(&P.stats[3], m_dc);
+        if (n_tr) atomicAdd(&P.stats[4], n_tr);
     }
 }
 
-// The speculative rounds and the count pass in one (jda_pipeline).  Round 0 walks every segment; a walk whose exit state differs
-// from what the next segment was entered with stores the new state and puts that segment on the work list of the next round, so
-// round r + 1 only walks the segments whose entry state round r changed (7 % after round 0, then a handful) -- packed into
-// full wavefronts instead of spread one or two per wavefront over all of them.  The entry states are updated in place: a lane
-// may read its entry while the lane of the segment before it replaces it, but then it is on the next round's list and walks
-// again from the final value; when a round leaves its list empty every segment's last walk started from its final entry
-// state (= the serial decoder's, by induction from segment 0) and its sums (block starts, DC sums, window phase map) are the
-// count pass's.  A round whose list is empty returns at once, so the host launches a fixed number of rounds and looks at the
-// last list's length when the batch is waited for.  stats[8 + r] = length of round r's list (r >= 2).  Round 0 walks every
-// segment from the guess "a block starts here" for the exit states alone (most guesses are wrong, so its sums would be thrown
-// away); round 1 walks every segment again, now with the sums, and starts the lists.
 // one segment of a round: walk it, store its sums, and if its exit state is not what the next segment was entered with, replace that
 // and put the next segment on the next round's list (one atomic per wavefront for the places on it)
 template <int OP>
@@ -845,24 +735,17 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
     return hipGetLastError();
 }
 
-// op: JDA_SEG_SPEC (round = 0, 1, ..: the entry-state buffers swap roles every round), JDA_SEG_COUNT / JDA_SEG_WRITE (round = the
-// number of SPEC rounds that ran: tells which buffer holds the final states)
-extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream)
+extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
     const int lds_bytes = JDA_WT_BYTES;               // the tables only: 16 KB per workgroup
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_COUNT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan<JDA_SEG_WRITE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_write, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const dim3 grid((max_segs + 255u) / 256u, n_images), block(256);
-    if (op == JDA_SEG_SPEC) hipLaunchKernelGGL(jda_segscan<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
-    else if (op == JDA_SEG_COUNT) hipLaunchKernelGGL(jda_segscan<JDA_SEG_COUNT>, grid, block, lds_bytes, stream, params, round);
-    else hipLaunchKernelGGL(jda_segscan<JDA_SEG_WRITE>, grid, block, lds_bytes, stream, params, round);
+    hipLaunchKernelGGL(jda_segscan_write, dim3((max_segs + 255u) / 256u, n_images), dim3(256), lds_bytes, stream, params);
     return hipGetLastError();
 }
 

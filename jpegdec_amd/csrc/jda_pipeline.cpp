@@ -2,8 +2,8 @@
 //
 //   host   parse + Huffman LUTs + prescaled quantisers per file (a few microseconds each, on a small thread pool)
 //   H2D    the UNFILTERED entropy-coded bytes of every file + one control blob (tables, kernel parameters, launch plan)
-//   GPU    marker / stuffing filter (JPEGFilter, jpeg.inl:1431-1540)            jda_filter_scan
-//          per-block index = the serial pre-scan's, entry for entry              jda_segscan / jda_prescan_intervals
+//   GPU    marker / stuffing filter (JPEGFilter, jpeg.inl:1431-1540)            jda_filter_count / _carry / _write
+//          per-block index = the serial pre-scan's, entry for entry              jda_segscan_fused / _tail / _sums / _write
 //          the MCU loops of DecodeJPEG (jpeg.inl:5109-5353)                      jda_decode_tiles_persistent
 // The host never touches a compressed byte.  Upload + filter + pre-scan of batch n+1 run on their own stream under the
 // decode of batch n; every batch lives in one device arena per pipeline slot (no allocation per image, no host
@@ -440,7 +440,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
             for (uint32_t r = 0; r < JDA_PIPE_SPEC_ROUNDS && e == hipSuccess; r++) e = jda_launch_segscan_fused(dp, ns, max_segs, r, p->s_up);
             if (e == hipSuccess) e = jda_launch_segscan_tail(dp, ns, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, p->s_up);
             if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, p->s_up);
-            if (e == hipSuccess) e = jda_launch_segscan(dp, ns, max_segs, JDA_SEG_WRITE, 0, p->s_up);
+            if (e == hipSuccess) e = jda_launch_segscan_write(dp, ns, max_segs, p->s_up);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.pin_stats, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, p->s_up);
     }

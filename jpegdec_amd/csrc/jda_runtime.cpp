@@ -190,10 +190,9 @@ int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes)
     return JDA_SUCCESS;
 }
 
-// Upload n prepared images.  Images whose block index is still pending (JDA_PREPARE_DEVICE_PRESCAN + restart
-// markers) get it made on the GPU, all of them in two launches (phase-map pass, exact pass: one lane per
-// restart interval, one grid row per image) -- the walk is latency-bound per lane, so it is the number of
-// intervals in flight that makes it fast.  out[i] receives the device image (NULL on failure).
+// Upload n prepared images.  Images whose block index is still pending (JDA_PREPARE_DEVICE_PRESCAN) get it made on the
+// GPU, all of them by the same launches (one grid row per image; the passes of DESIGN.md 5.3) -- the walk is latency-bound per
+// lane, so it is the number of segments in flight that makes it fast.  out[i] receives the device image (NULL on failure).
 static double now_ms()
 {
     struct timespec ts;
@@ -212,11 +211,11 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     (void)hipSetDevice(ctx->device);
     struct Item {
         jda_dev_image *d; uint8_t *stage; std::vector<uint8_t> heap; bool on_device; uint32_t n_int;
-        size_t off_rpos, off_map, off_phase, off_stats, alloc, n_blocks; uint32_t tbytes;
-        std::vector<uint32_t> map; std::vector<uint8_t> phase; uint32_t st[5];
-        // streams without restart markers (8f N2): segments of the scan, see jda_seg_walk
-        bool seg_mode; uint32_t n_segs; size_t off_ea, off_eb, off_sum, off_start, off_sstats; bool dev_ok;
-        uint32_t sst[64];
+        size_t alloc, n_blocks; uint32_t tbytes;
+        // the index is made on the device (8f N1 / N2): segments of the scan, see jda_seg_walk
+        bool seg_mode; uint32_t n_segs; size_t off_ea, off_sum, off_start, off_wl, off_rp, off_sstats;
+        std::vector<uint32_t> rp;            // restart positions + the sentinel, until their copy has been made
+        uint32_t sst[68];
     };
     std::vector<Item> items((size_t)n);
     int rc = JDA_SUCCESS;
@@ -226,9 +225,6 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         for (int i = 0; i < n; i++) { if (items[i].d) { if (items[i].d->base) jda_pool_free(ctx, items[i].d->base); delete items[i].d; items[i].d = NULL; } out[i] = NULL; }
         return code;
     };
-    std::vector<jda_prescan_params> params;
-    std::vector<int> params_owner;
-    uint32_t max_int = 0;
     std::vector<jda_segscan_params> seg_params;
     std::vector<int> seg_owner;
     uint32_t max_segs = 0;
@@ -287,7 +283,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         const uint8_t *scan = jda_image_scan(img, &scan_len);
         const uint8_t *tables = jda_image_tables(img, &it.tbytes);
         it.n_blocks = (size_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu;
-        it.on_device = jda_image_index_on_device(img) != 0;      // index to be made by jda_prescan_intervals
+        it.on_device = jda_image_index_on_device(img) != 0;      // index to be made on the device
         const uint32_t *rpos = jda_image_restart_positions(img, &it.n_int);
         jda_dev_image *d = new (std::nothrow) jda_dev_image;
         if (!d) { rc = JDA_ERROR_MEMORY; break; }
@@ -302,21 +298,20 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         d->off_dc = d->off_index + align16((it.n_blocks + 1) * sizeof(uint32_t));
         d->off_scan = d->off_dc + align16(it.n_blocks * sizeof(int16_t));
         d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
-        // the device pre-scan's extras ride along behind the image: restart positions, phase map, start phases, results
-        it.off_rpos = d->bytes; it.off_map = it.off_rpos + align16((size_t)it.n_int * 4);
-        it.off_phase = it.off_map + align16((size_t)it.n_int * 4); it.off_stats = it.off_phase + align16((size_t)it.n_int);
-        it.alloc = it.on_device ? it.off_stats + 32 : d->bytes;
-        it.seg_mode = it.on_device && I.restart_interval == 0;
-        it.dev_ok = false; it.n_segs = 0;
+        it.alloc = d->bytes;
+        it.seg_mode = it.on_device;
+        it.n_segs = 0;
         if (it.seg_mode) {
-            // the scan is read in whole 256-byte segments (+ a few bytes): zero padded behind its last byte; then the
-            // entry states (two buffers), the per-segment sums and start values, the result words
+            // the scan is read in whole 256-byte segments (+ a few bytes): zero padded behind its last byte; then the entry
+            // states, the per-segment sums and start values, the two work lists, the restart positions, the result words
             it.n_segs = scan_len / JDA_SEG_BYTES + 1u;
             d->bytes = d->off_scan + align16(std::max((size_t)scan_len + JDA_SCAN_PAD, (size_t)it.n_segs * JDA_SEG_BYTES + 16));
-            it.off_ea = d->bytes; it.off_eb = it.off_ea + align16(((size_t)it.n_segs + 1) * 4);
-            it.off_sum = it.off_eb + align16(((size_t)it.n_segs + 1) * 4); it.off_start = it.off_sum + align16((size_t)it.n_segs * 24);
-            it.off_sstats = it.off_start + align16((size_t)it.n_segs * 20);
-            it.alloc = it.off_sstats + 256;
+            it.off_ea = d->bytes;
+            it.off_sum = it.off_ea + align16(((size_t)it.n_segs + 1) * 4); it.off_start = it.off_sum + align16((size_t)it.n_segs * 24);
+            it.off_wl = it.off_start + align16((size_t)it.n_segs * 20);
+            it.off_rp = it.off_wl + align16((size_t)it.n_segs * 8);
+            it.off_sstats = it.off_rp + (I.restart_interval ? align16(((size_t)it.n_int + 1) * 4) : 0);
+            it.alloc = it.off_sstats + 512;
         }
         e = jda_pool_alloc(ctx, (void **)&d->base, it.alloc);
         if (e != hipSuccess) { jda_set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
@@ -339,8 +334,17 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             jda_segscan_params SP;
             memset(&SP, 0, sizeof(SP));
             SP.scan = d->base + d->off_scan; SP.tables = d->base + d->off_tables;
-            SP.entry_cur = (uint32_t *)(d->base + it.off_ea); SP.entry_nxt = (uint32_t *)(d->base + it.off_eb);
+            SP.entry_cur = (uint32_t *)(d->base + it.off_ea); SP.entry_nxt = SP.entry_cur;
             SP.seg_sum = (uint32_t *)(d->base + it.off_sum); SP.seg_start = (const uint32_t *)(d->base + it.off_start);
+            SP.worklist = (uint32_t *)(d->base + it.off_wl); SP.worklist_cap = it.n_segs;
+            if (I.restart_interval) {                        // the walk ends intervals where the (host) filter found the markers
+                it.rp.assign(rpos, rpos + it.n_int); it.rp.push_back(JDA_RST_SENTINEL);
+                e = hipMemcpyAsync(d->base + it.off_rp, it.rp.data(), it.rp.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+                if (e != hipSuccess) { rc = jda_set_err(ctx, e, "hipMemcpy(restart positions)"); break; }
+                SP.restart_pos = (const uint32_t *)(d->base + it.off_rp); SP.n_intervals = it.n_int;
+                SP.interval_blocks = (uint32_t)I.restart_interval * (uint32_t)I.blocks_per_mcu;
+                SP.round_last = ((uint32_t)(I.mcus_x * I.mcus_y) % (uint32_t)I.restart_interval) == 0 ? 1u : 0u;
+            }
             SP.blk_index = (uint32_t *)(d->base + d->off_index); SP.blk_dc = (int16_t *)(d->base + d->off_dc);
             SP.stats = (uint32_t *)(d->base + it.off_sstats);
             SP.scan_len = scan_len; SP.n_segs = it.n_segs; SP.n_blocks_total = (uint32_t)it.n_blocks;
@@ -355,25 +359,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         if (!it.stage) { it.heap.assign(it.alloc, 0); it.stage = it.heap.data(); }
         memcpy(it.stage + d->off_tables, tables, it.tbytes);
         memcpy(it.stage + d->off_scan, scan, (size_t)scan_len + JDA_SCAN_PAD);
-        if (it.on_device) {
-            memcpy(it.stage + it.off_rpos, rpos, (size_t)it.n_int * 4);
-            const uint32_t init[5] = { 0xffffffffu, 0, 0, 0, 0 };
-            memcpy(it.stage + it.off_stats, init, sizeof(init));
-            jda_prescan_params P;
-            memset(&P, 0, sizeof(P));
-            P.scan = d->base + d->off_scan; P.tables = d->base + d->off_tables;
-            P.restart_pos = (const uint32_t *)(d->base + it.off_rpos);
-            P.phase_map = (uint32_t *)(d->base + it.off_map); P.start_phase = d->base + it.off_phase;
-            P.blk_index = (uint32_t *)(d->base + d->off_index); P.blk_dc = (int16_t *)(d->base + d->off_dc);
-            P.stats = (uint32_t *)(d->base + it.off_stats);
-            P.scan_len = scan_len; P.n_intervals = it.n_int; P.n_mcus = (uint32_t)(I.mcus_x * I.mcus_y);
-            P.interval_mcus = (uint32_t)I.restart_interval;
-            P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
-            for (int c = 0; c < 3; c++) { P.dc_id[c] = d->dc_id[c]; P.ac_id[c] = d->ac_id[c]; }
-            params.push_back(P); params_owner.push_back(i);
-            if (it.n_int > max_int) max_int = it.n_int;
-            it.map.resize(it.n_int); it.phase.resize(it.n_int);
-        } else {
+        {
             const uint32_t *index = jda_image_block_index(img, &nok);
             memcpy(it.stage + d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
             memcpy(it.stage + d->off_dc, jda_image_block_dc(img), it.n_blocks * sizeof(int16_t));
@@ -400,56 +386,17 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     if (rc != JDA_SUCCESS) { (void)hipStreamSynchronize(ctx->stream); return fail_all(rc); }
     JDA_UP_MARK("alloc + stage + H2D");
 
-    jda_prescan_params *d_params = NULL;
-    if (!params.empty()) {
-        e = jda_pool_alloc(ctx, (void **)&d_params, params.size() * sizeof(jda_prescan_params));
-        if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), params.size() * sizeof(jda_prescan_params), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = jda_launch_prescan(d_params, (uint32_t)params.size(), max_int, 0, ctx->stream);          // MAP
-        for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
-            Item &it = items[params_owner[p]];
-            e = hipMemcpyAsync(it.map.data(), it.d->base + it.off_map, (size_t)it.n_int * 4, hipMemcpyDeviceToHost, ctx->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
-            Item &it = items[params_owner[p]];
-            uint32_t j = 0;                                   // the scan starts with pBuf at its first byte, ulBitOff 0 (:4996-4998)
-            for (uint32_t k = 0; k < it.n_int; k++) { it.phase[k] = (uint8_t)(8u * j); j = (it.map[k] >> (4u * (j > 5u ? 0u : j))) & 15u; }
-            e = hipMemcpyAsync(it.d->base + it.off_phase, it.phase.data(), it.n_int, hipMemcpyHostToDevice, ctx->stream);
-        }
-        if (e == hipSuccess) e = jda_launch_prescan(d_params, (uint32_t)params.size(), max_int, 1, ctx->stream);          // EXACT
-        for (size_t p = 0; p < params.size() && e == hipSuccess; p++) {
-            Item &it = items[params_owner[p]];
-            e = hipMemcpyAsync(it.st, it.d->base + it.off_stats, sizeof(it.st), hipMemcpyDeviceToHost, ctx->stream);
-        }
-    }
-    // ---- streams without restart markers: speculative rounds until nothing changes, COUNT, sums on the host, WRITE
+    // ---- the index on the device (with or without restart intervals): round 0 and round 1 over every segment, two rounds over the
+    // work lists, every further round in one launch, sums, WRITE -- the passes of jda_pipeline, on this context's stream
     jda_segscan_params *d_seg = NULL;
     if (!seg_params.empty() && e == hipSuccess) {
         const uint32_t ns = (uint32_t)seg_params.size();
         e = jda_pool_alloc(ctx, (void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg_params.data(), seg_params.size() * sizeof(jda_segscan_params), hipMemcpyHostToDevice, ctx->stream);
-        const uint32_t kMaxRounds = 48;                     // (the result words hold a change counter per round: 8 + 48 <= 64)
-        uint32_t rounds = 0;
-        bool settled = false;
-        while (e == hipSuccess && rounds < kMaxRounds && !settled) {
-            e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_SPEC, rounds, ctx->stream);
-            rounds++;
-            if (e == hipSuccess && rounds >= 3 && (rounds & 1u)) {      // look at the change counters every other round
-                for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
-                    Item &it = items[seg_owner[p]];
-                    e = hipMemcpyAsync(it.sst, it.d->base + it.off_sstats, sizeof(it.sst), hipMemcpyDeviceToHost, ctx->stream);
-                }
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                settled = true;
-                for (uint32_t p = 0; p < ns; p++) if (items[seg_owner[p]].sst[8 + rounds - 1] != 0) settled = false;
-            }
-        }
-        ctx->last_segscan_rounds = (int)rounds;
-        JDA_UP_MARK("speculative rounds");
-        if (e == hipSuccess) e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_COUNT, rounds, ctx->stream);
-        JDA_UP_MARK("count pass");
+        for (uint32_t r = 0; r < 4 && e == hipSuccess; r++) e = jda_launch_segscan_fused(d_seg, ns, max_segs, r, ctx->stream);
+        if (e == hipSuccess) e = jda_launch_segscan_tail(d_seg, ns, 4, 56, ctx->stream);
+        JDA_UP_MARK("speculative + counting rounds");
         if (e == hipSuccess) e = jda_launch_segscan_sums(d_seg, ns, ctx->stream);      // first block ordinal, DC predictors, window lag per segment
-        for (uint32_t p = 0; p < ns; p++) items[seg_owner[p]].dev_ok = settled;
         JDA_UP_MARK("sums");
         // the write pass ORs its index entries into place (a block's truncation flag may come from the lane of a later segment
         // than the one that holds the block's first bit): the index starts as zeros
@@ -457,7 +404,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             Item &it = items[seg_owner[p]];
             e = hipMemsetAsync(it.d->base + it.d->off_index, 0, 4 * (it.n_blocks + 1), ctx->stream);
         }
-        if (e == hipSuccess) e = jda_launch_segscan(d_seg, ns, max_segs, JDA_SEG_WRITE, rounds, ctx->stream);
+        if (e == hipSuccess) e = jda_launch_segscan_write(d_seg, ns, max_segs, ctx->stream);
         for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
             Item &it = items[seg_owner[p]];
             e = hipMemcpyAsync(it.sst, it.d->base + it.off_sstats, sizeof(it.sst), hipMemcpyDeviceToHost, ctx->stream);
@@ -465,35 +412,19 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     JDA_UP_MARK("write pass + D2H");
-    if (d_params) jda_pool_free(ctx, d_params);
     if (d_seg) jda_pool_free(ctx, d_seg);
     if (e != hipSuccess) return fail_all(jda_set_err(ctx, e, "jda_upload_batch"));
 
-    // a marker that is not where the MCU count puts it, or a corrupt interval: the serial host pre-scan reproduces
-    // what the reference does with such a stream
+    // a marker that is not where the MCU count puts it, a corrupt or truncated stream, states that did not settle: the serial host
+    // pre-scan reproduces what the reference does with such a stream
     bool reupload = false;
-    for (size_t p = 0; p < params.size(); p++) {
-        const int i = params_owner[p];
-        Item &it = items[i];
-        const jda_image_info &I = *jda_image_get_info(imgs[i]);
-        if (it.st[0] == 0xffffffffu && it.st[1] == 0) {
-            jda_image_adopt_prescan(imgs[i], (uint32_t)(I.mcus_x * I.mcus_y), it.st[2], (int32_t)it.st[3], it.st[4]);
-            it.d->prescan_on_device = 1;
-        } else {
-            jda_image_run_host_prescan(imgs[i]);
-            uint32_t nok = 0;
-            const uint32_t *index = jda_image_block_index(imgs[i], &nok);
-            e = hipMemcpyAsync(it.d->base + it.d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(it.d->base + it.d->off_dc, jda_image_block_dc(imgs[i]), it.n_blocks * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream);
-            reupload = true;
-            if (e != hipSuccess) break;
-        }
-    }
+    int rounds_max = 0;
     for (size_t p = 0; p < seg_owner.size() && e == hipSuccess; p++) {
         const int i = seg_owner[p];
         Item &it = items[i];
         const jda_image_info &I = *jda_image_get_info(imgs[i]);
-        if (it.dev_ok && it.sst[6] == 1 && it.sst[0] == 0 && it.sst[1] == 1) {   // states settled, enough blocks, no bad code before the end, the closing index entry written once
+        { int r = 2; while (r <= 57 && it.sst[8 + r]) r++; if (r > rounds_max) rounds_max = r; }
+        if (it.sst[7] == 1 && it.sst[6] == 1 && it.sst[0] == 0 && it.sst[1] == 1 && it.sst[5] == 0) {   // states settled, enough blocks, no bad code before the end, the closing index entry written once, every marker where the MCU count puts it
             jda_image_adopt_prescan(imgs[i], (uint32_t)(I.mcus_x * I.mcus_y), it.sst[2], (int32_t)it.sst[3], it.sst[4]);
             it.d->prescan_on_device = 1;
         } else {                                                         // corrupt or truncated stream: the serial pre-scan knows what the reference does
@@ -505,6 +436,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             reupload = true;
         }
     }
+    if (!seg_owner.empty()) ctx->last_segscan_rounds = rounds_max;           // rounds that had something to walk
     if (reupload && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail_all(jda_set_err(ctx, e, "jda_upload_batch(re-upload)"));
     for (int i = 0; i < n; i++) {

@@ -37,7 +37,7 @@ struct jda_dev_image {
     uint8_t dc_id[3], ac_id[3], q_id[3];
     uint8_t fast_mul;
     uint8_t general_p1;          // JDA_DESC_GENERAL_P1
-    uint8_t prescan_on_device;   // the block index was made by jda_prescan_intervals (restart-marker fast path)
+    uint8_t prescan_on_device;   // the block index was made on the device (jda_segscan_*)
     uint32_t tiles_total, tiles_over_small;   // host index known: tiles, and those whose scan slice exceeds the 16-wave kernel's window (0 / 0: unknown)
 };
 
@@ -62,9 +62,7 @@ int jda_fill_launch_desc(jda_dev_desc &D, const jda_image_info &I, const uint8_t
                          int fast_mul, int general_p1, uint32_t n_mcus_ok, uint32_t scan_len, const jda_output &O, int pixel_type, int options,
                          int *bpp_out);
 
-extern "C" hipError_t jda_launch_prescan(const jda_prescan_params *params, uint32_t n_images, uint32_t max_intervals, int exact, hipStream_t stream);
-extern "C" hipError_t jda_launch_prescan_compose(const jda_prescan_params *params, uint32_t n_images, hipStream_t stream);
-extern "C" hipError_t jda_launch_segscan(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, int op, uint32_t round, hipStream_t stream);
+extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream);
 extern "C" hipError_t jda_launch_checksum(const void *base, uint32_t pitch, uint32_t row_bytes, uint32_t rows, unsigned long long *out, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t first_round, uint32_t max_round, hipStream_t stream);

@@ -61,7 +61,7 @@ static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles
 extern "C" const uint32_t *jda_image_restart_positions(const jda_image *img, uint32_t *n);
 extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
-static int g_device_prescan = 0;     // 1: make the block index with the device-side interval walk (restart markers)
+static int g_device_prescan = 0;     // != 0: make the block index with the device's segment walk (jda_seg_walk), as jda_upload_batch / jda_pipeline do
 static int g_prescan_used = 0;
 static uint32_t g_prescan_trunc = 0;
 extern "C" void hostsim_set_device_prescan(int on) { g_device_prescan = on; }
@@ -81,7 +81,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     std::vector<uint32_t> dev_index;
     std::vector<int16_t> dev_dc;
     g_prescan_used = 0;
-    if (jda_image_prescan_pending(img) && (jda_image_get_info(img)->restart_interval == 0 || g_device_prescan == 2)) {
+    if (jda_image_prescan_pending(img)) {
         // the segment walk (8f N2): what jda_upload_batch / jda_pipeline + jda_segscan do, lane by lane -- streams without restart
         // markers, and (hostsim_set_device_prescan(2), as jda_pipeline does it) streams with them
         const jda_image_info *I = jda_image_get_info(img);
@@ -242,58 +242,6 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             if (getenv("HOSTSIM_DEBUG")) fprintf(stderr, "segment path rejected: ok %d settled %d rounds %u bad %u terminal %u\n", (int)ok, (int)settled, rounds, ST.bad, terminal);
             jda_image_run_host_prescan(img);
             dev_index.clear(); dev_dc.clear();
-        }
-    } else if (jda_image_prescan_pending(img)) {          // what jda_upload does, lane by lane
-        const jda_image_info *I = jda_image_get_info(img);
-        const size_t nb = (size_t)I->mcus_x * I->mcus_y * I->blocks_per_mcu;
-        dev_index.assign(nb + 1, 0xdeadbeefu); dev_dc.assign(nb, 0x7777);
-        uint32_t n_int = 0, sl = 0, tb = 0;
-        jda_prescan_params P;
-        memset(&P, 0, sizeof(P));
-        P.restart_pos = jda_image_restart_positions(img, &n_int);
-        P.scan = jda_image_scan(img, &sl); P.tables = jda_image_tables(img, &tb);
-        P.blk_index = dev_index.data(); P.blk_dc = dev_dc.data(); P.stats = NULL;
-        P.scan_len = sl; P.n_intervals = n_int; P.n_mcus = (uint32_t)(I->mcus_x * I->mcus_y);
-        P.interval_mcus = (uint32_t)I->restart_interval;
-        P.nblocks = (uint8_t)I->blocks_per_mcu; P.nluma = (uint8_t)(I->blocks_per_mcu - (I->ncomp == 3 ? 2 : 0));
-        uint8_t q_id[3];
-        jda_image_component_ids(img, P.dc_id, P.ac_id, q_id);
-        std::vector<uint64_t> lt_store((JDA_LT_WALK_BYTES + 7) / 8);      // the tables as the kernel stages them
-        uint8_t *lt = (uint8_t *)lt_store.data();
-        for (uint32_t tid = 0; tid < 64; tid++) jda_p0_tables_from(P.tables, tid, 64, lt, true, true);
-        // MAP pass -> compose the phases -> EXACT pass, as jda_upload does
-        std::vector<uint8_t> phase(n_int);
-        uint32_t j = 0;
-        for (uint32_t k = 0; k < n_int; k++) {
-            phase[k] = (uint8_t)(8u * j);
-            const jda_prescan_result R = jda_prescan_interval<false>(P, k, lt);
-            j = (R.phase_map >> (4u * (j > 5u ? 0u : j))) & 15u;
-        }
-        P.start_phase = phase.data();
-        uint32_t first_bad = 0xffffffffu, mismatch = 0, max_ac = 0, max_dc = 0, trunc = 0;
-        for (uint32_t k = 0; k < n_int; k++) {
-            const jda_prescan_result R = jda_prescan_interval<true>(P, k, lt);
-            if (R.first_bad < first_bad) first_bad = R.first_bad;
-            mismatch |= R.mismatch; trunc += R.trunc_events;
-            if (R.max_ac_bits > max_ac) max_ac = R.max_ac_bits;
-            if (R.max_abs_dc > max_dc) max_dc = R.max_abs_dc;
-        }
-        if (first_bad != 0xffffffffu || mismatch) {        // as jda_upload_batch: the serial pre-scan knows what the reference does
-            jda_image_run_host_prescan(img);
-            dev_index.clear(); dev_dc.clear();
-        } else {
-        g_prescan_trunc = trunc;
-        jda_image_adopt_prescan(img, P.n_mcus, max_ac, (int32_t)max_dc, trunc);
-        g_prescan_used = 1;
-        // the EXACT pass must reproduce the serial pre-scan entry for entry
-            int32_t e2 = 0;
-            jda_image *ref = jda_prepare(jpeg, len, &e2);
-            uint32_t nn = 0;
-            const uint32_t *hi = ref ? jda_image_block_index(ref, &nn) : NULL;
-            g_index_equal = ref && memcmp(hi, dev_index.data(), (nb + 1) * 4) == 0 && memcmp(jda_image_block_dc(ref), dev_dc.data(), nb * 2) == 0 &&
-                            jda_image_truncation_events(ref) == trunc ? 1 : 0;
-            if (ref && getenv("HOSTSIM_DEBUG")) { for (size_t i = 0; i < nb; i++) if (hi[i] != dev_index[i] || jda_image_block_dc(ref)[i] != dev_dc[i]) { fprintf(stderr, "first diff at block %zu: host %u/%u dc %d, dev %u/%u dc %d; trunc host %u dev %u\n", i, hi[i] >> 7, hi[i] & 127, jda_image_block_dc(ref)[i], dev_index[i] >> 7, dev_index[i] & 127, dev_dc[i], jda_image_truncation_events(ref), trunc); break; } fprintf(stderr, "trunc host %u dev %u\n", jda_image_truncation_events(ref), trunc); }
-            if (ref) jda_image_free(ref);
         }
     }
     jda_dev_desc D;

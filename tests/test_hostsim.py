@@ -48,9 +48,11 @@ def test_wave_emulation_equals_oracle(name, hostsim, oracle):
 @pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow",
                                   "c422_1100x24_rstrow", "c440_300x64_rst5"])
 def test_restart_interval_prescan_equals_oracle(name, hostsim, oracle):
-    """with restart markers the per-block index is made by the device-side interval walk
-    (jda_prescan_interval, one lane per restart interval) instead of the serial host pre-scan (two passes: window-phase map, then the exact walk).  The
-    index must equal the serial one entry for entry and the decode must be the oracle's, byte for byte."""
+    """a stream WITH restart intervals goes through the same segment walk as one without (one lane per 256 bytes, not one per
+    interval): an interval's end is found by position (the filter recorded where every interval starts), the reference's rounding of
+    ulBitOff without a refill and the predictor reset happen there, and the WRITE pass checks that the marker positions agree with the
+    MCU count.  The index must equal the serial one entry for entry (reader phase, truncation flags, DC predictors, closing entry) and
+    the decode must be the oracle's, byte for byte, in every pixel type and scale."""
     jpeg = jpeg_for(name)
     hostsim.hostsim_set_device_prescan(1)
     try:
@@ -59,7 +61,7 @@ def test_restart_interval_prescan_equals_oracle(name, hostsim, oracle):
             got = np.full_like(want, 0x33)
             inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
             hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
-            assert hrc == 0 and hostsim.hostsim_prescan_used() == 1
+            assert hrc == 0 and hostsim.hostsim_prescan_used() == 2
             assert hostsim.hostsim_index_equal() == 1          # phase, DC predictor and truncation count of every block
             assert np.array_equal(got, want), (name, pt, opt)
     finally:
@@ -152,31 +154,6 @@ def test_duplicate_eob_code_takes_the_general_reader(luma_hv, hostsim, oracle):
         inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
         assert hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
         assert np.array_equal(got, want), (luma_hv, pt, opt)
-
-
-@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "gray_64x64_rst3", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow",
-                                  "c422_1100x24_rstrow", "c440_300x64_rst5"])
-def test_restart_streams_through_the_segment_walk(name, hostsim, oracle):
-    """Round 2: in the streamed pipeline a stream WITH restart intervals goes through the same segment walk as one without (one
-    lane per 256 bytes instead of one per interval): an interval's end is found by position (the filter recorded where every
-    interval starts), the reference's rounding of ulBitOff without a refill and the predictor reset happen there, and the WRITE
-    pass checks that the marker positions agree with the MCU count.  Index == the serial pre-scan's entry for entry (reader
-    phase, truncation flags, DC predictors, closing entry), decode == the oracle's."""
-    jpeg = jpeg_for(name)
-    hostsim.hostsim_set_device_prescan(2)
-    try:
-        for pt, opt in ((2, 0), (0, 2), (3, 8)):
-            if name.startswith("gray") and pt == 2:
-                continue
-            rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
-            got = np.full_like(want, 0x33)
-            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
-            hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
-            assert hrc == 0 and hostsim.hostsim_prescan_used() == 2, (name, hostsim.hostsim_prescan_used())
-            assert hostsim.hostsim_index_equal() == 1
-            assert np.array_equal(got, want), (name, pt, opt)
-    finally:
-        hostsim.hostsim_set_device_prescan(0)
 
 
 def test_reference_fixtures_with_restart_intervals_through_the_segment_walk(hostsim):
