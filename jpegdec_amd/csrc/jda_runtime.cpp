@@ -772,7 +772,7 @@ int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int3
 #define JDA_OC_MARK(what) do { if (trace) { const double t_ = now_ms(); fprintf(stderr, "jda_decode_to_host: %-24s %7.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
     // One image at a time, the device pre-scan is a few latency-bound passes of ~0.5 ms each whatever the size (a 640x480 scan
     // is four wavefronts' worth of segments): 1.85 ms where the serial host pre-scan of that image takes 0.29 ms.  It wins from
-    // about 2.5 Mpixel on (1080p: 1.7 ms on the host, 4096x4096: 13 ms against 5.5 ms) -- in batches it always does.
+    // about 2.5 Mpixel on (1080p: 1.7 ms on the host, 4096x4096: 13 ms against 4.2 ms all in) -- in batches it always does.
     const int32_t prep_flags = len >= (300 << 10) ? JDA_PREPARE_DEVICE_PRESCAN : 0;
     jda_image *img = jda_prepare_ex(jpeg, len, prep_flags, &err);
     if (!img) return err;
