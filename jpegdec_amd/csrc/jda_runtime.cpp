@@ -770,10 +770,12 @@ int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int3
     static const bool trace = getenv("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
     double t_mark = trace ? now_ms() : 0.0;
 #define JDA_OC_MARK(what) do { if (trace) { const double t_ = now_ms(); fprintf(stderr, "jda_decode_to_host: %-24s %7.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
-    // One image at a time, the device pre-scan is a few latency-bound passes of ~0.5 ms each whatever the size (a 640x480 scan
-    // is four wavefronts' worth of segments): 1.85 ms where the serial host pre-scan of that image takes 0.29 ms.  It wins from
-    // about 2.5 Mpixel on (1080p: 1.7 ms on the host, 4096x4096: 13 ms against 4.2 ms all in) -- in batches it always does.
-    const int32_t prep_flags = len >= (300 << 10) ? JDA_PREPARE_DEVICE_PRESCAN : 0;
+    // One image at a time, the device pre-scan is seven latency-bound launches of ~0.1-0.25 ms each whatever the size (a 640x480 scan
+    // is four wavefronts' worth of segments): 0.88 ms all in where the serial host pre-scan of that image makes it 0.37 ms.  The host
+    // costs 6.8 us per KB of file, so the device wins from about 120 KB on (1920x1080, 250 KB: 1.24 ms against 1.95; 4096x4096: 4.2 ms
+    // against 13 for the host pre-scan alone) -- in batches it always does.
+    static const int32_t dev_from = []() { const char *e = getenv("JDA_ONECALL_DEVICE_PRESCAN_BYTES"); return e ? atoi(e) : (128 << 10); }();   // (for measuring the crossover)
+    const int32_t prep_flags = len >= dev_from ? JDA_PREPARE_DEVICE_PRESCAN : 0;
     jda_image *img = jda_prepare_ex(jpeg, len, prep_flags, &err);
     if (!img) return err;
     const jda_image_info &I = *jda_image_get_info(img);
