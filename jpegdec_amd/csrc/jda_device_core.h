@@ -1092,6 +1092,35 @@ JDA_HD void jda_walk_tables_from(const uint8_t *tables, uint32_t tid, uint32_t n
 // waits for the next block's opening one), the DC predictors restart at zero.  The reference itself counts MCUs and never
 // looks at marker positions: the WRITE pass checks that the two agree (every interval end at a multiple of interval_blocks,
 // every such multiple an interval end) and sends the image to the serial pre-scan when they do not.
+JDA_HD void jda_store_u32x4(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)      // one 16-byte store (p: global memory, 16-byte aligned)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    *JDA_G(uint4, p) = make_uint4(a, b, c, d);
+#else
+    uint32_t *o = (uint32_t *)p; o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+#endif
+}
+// WRITE's entry-by-entry stores (a lane's first and last group): the n newest of the buffered entries, the newest at ordinal g_new
+JDA_HD void jda_seg_flush_index(uint32_t *blk_index, uint32_t g_new, uint32_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, blk_index) + g_new;
+    o[0] = b3;
+    if (n > 1u) o[-1] = b2;
+    if (n > 2u) o[-2] = b1;
+    if (n > 3u) o[-3] = b0;
+}
+JDA_HD void jda_seg_flush_dc(int16_t *blk_dc, uint32_t g_new, uint32_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    int16_t JDA_GLOBAL *o = JDA_G(int16_t, blk_dc) + g_new;
+    o[0] = (int16_t)(b3 >> 16);
+    if (n > 1u) o[-1] = (int16_t)b3;
+    if (n > 2u) o[-2] = (int16_t)(b2 >> 16);
+    if (n > 3u) o[-3] = (int16_t)b2;
+    if (n > 4u) o[-4] = (int16_t)(b1 >> 16);
+    if (n > 5u) o[-5] = (int16_t)b1;
+    if (n > 6u) o[-6] = (int16_t)(b0 >> 16);
+    if (n > 7u) o[-7] = (int16_t)b0;
+}
 template <int OP, bool RST = false>
 JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *wt,
                              jda_seg_sum &S, jda_seg_stats &ST)
@@ -1130,6 +1159,11 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     }
     if (CNT) U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);
     uint32_t pend = 0, pend_g = 0;                                  // WRITE: index entry of the block in progress (if it began here)
+    // WRITE: a lane's entries go to consecutive ordinals, one every few steps, each lane in a cache line of its own: the lane
+    // keeps the last four index entries / eight predictors in registers (shifted in, newest last) and stores an aligned group of
+    // 16 bytes when it completes one; the groups it shares with its neighbours (its first and last) go out entry by entry.
+    uint32_t ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0, ibn = 0, ib_g = 0;  // ibn: entries not stored yet, ib_g: ordinal of the newest
+    uint32_t db0 = 0, db1 = 0, db2 = 0, db3 = 0, dbn = 0;            // (the newest predictor's ordinal is g - 1)
     bool pending = false, bad = false, stop = false;                // stop: leave the loop after this step (one exit test per step)
     // RST: the next interval start ahead of the walk (as a bit position relative to the segment), blocks left in the interval
     const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
@@ -1170,9 +1204,16 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
             const bool out_of_range = begin & ((pr < -32768) | (pr > 32767));
             bad |= out_of_range; stop |= out_of_range | term;
-#if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 1))
-            if (begin) JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pr;
-#endif
+            if (begin) {
+                db0 = jda_alignbit(db1, db0, 16); db1 = jda_alignbit(db2, db1, 16);
+                db2 = jda_alignbit(db3, db2, 16); db3 = jda_alignbit((uint32_t)pr, db3, 16);
+                dbn++;
+                if ((g & 7u) == 7u) {
+                    if (dbn == 8u) jda_store_u32x4(P.blk_dc + (g - 7u), db0, db1, db2, db3);
+                    else jda_seg_flush_dc(P.blk_dc, g, dbn, db0, db1, db2, db3);
+                    dbn = 0;
+                }
+            }
 #ifdef JDA_SEG_BLOCK_HOOK
             if (begin) JDA_SEG_BLOCK_HOOK();                        // (host simulator: where blocks start among the steps)
 #endif
@@ -1255,9 +1296,15 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         }
         k = (ends | inval) ? 0u : kk + 1u;
         b2 = ends ? bn : b2;
-#if !(defined(JDA_EXP_SEG) && (JDA_EXP_SEG & 2))
-        if (OP == JDA_SEG_WRITE && ends && pending) { JDA_G(uint32_t, P.blk_index)[pend_g] = pend; pending = false; }
-#endif
+        if (OP == JDA_SEG_WRITE && ends && pending) {
+            ib0 = ib1; ib1 = ib2; ib2 = ib3; ib3 = pend; ib_g = pend_g; ibn++;
+            if ((pend_g & 3u) == 3u) {
+                if (ibn == 4u) jda_store_u32x4(P.blk_index + (pend_g - 3u), ib0, ib1, ib2, ib3);
+                else jda_seg_flush_index(P.blk_index, pend_g, ibn, ib0, ib1, ib2, ib3);
+                ibn = 0;
+            }
+            pending = false;
+        }
         if (RST) {
             if (OP == JDA_SEG_WRITE) {
                 // the reference restarts by MCU count, the filter found the markers: they must agree
@@ -1287,6 +1334,10 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         go = (p < JDA_SEG_BITS) & !stop;
         since++;
     } while (go & (since < JDA_SEG_REFILL_STEPS));
+    }
+    if (OP == JDA_SEG_WRITE) {                                      // what is left of the lane's last groups
+        if (ibn) jda_seg_flush_index(P.blk_index, ib_g, ibn, ib0, ib1, ib2, ib3);
+        if (dbn) jda_seg_flush_dc(P.blk_dc, g - 1u, dbn, db0, db1, db2, db3);
     }
     if (OP == JDA_SEG_WRITE && pending && !bad) jda_atomic_or_u32(P.blk_index + pend_g, pend);      // the block goes on in the next segment
     if (OP == JDA_SEG_WRITE) { ST.max_ac_bits = max_ac; ST.max_abs_dc = max_dc; }
