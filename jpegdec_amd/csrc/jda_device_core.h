@@ -970,6 +970,9 @@ struct jda_segscan_params {          // one per image
     // rounded up to a byte like every interval end, jpeg.inl:5339-5346)
     const uint32_t *restart_pos;
     uint32_t n_intervals, interval_blocks, round_last;
+    // the walk's four tables (JDA_WT_BYTES) as jda_walk_tables_build makes them from the blob, once per image: a walker's workgroup
+    // copies them (one wait) instead of converting the blob itself
+    uint8_t *walk_tables;
 };
 #define JDA_RST_SENTINEL 0x1fffffffu      // (a byte position no scan reaches: the index packs positions in 25 bits)
 #define JDA_SEG_HAS_RESTART 2u           // seg_sum word 5, bit 1: an interval ends inside the segment (its DC sums count from there)
@@ -1065,6 +1068,13 @@ JDA_HD void jda_walk_tables_from(const uint8_t *tables, uint32_t tid, uint32_t n
         const uint8_t JDA_GLOBAL *dc = JDA_G(const uint8_t, tables) + JDA_TB_DC + t * 1024u;
         ((uint16_t *)(wt + 2u * JDA_WT_TABLE_BYTES))[j] = (uint16_t)jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]);
     }
+}
+// what a walker's workgroup does: a copy of the image's prepared tables (jda_walk_tables_build; 16 KB, one wait)
+JDA_HD void jda_walk_tables_stage(const uint8_t *prepared, uint32_t tid, uint32_t nthreads, uint8_t *wt)
+{
+    const jda_chunk16_alias JDA_GLOBAL *src = JDA_G(const jda_chunk16_alias, prepared);
+    jda_chunk16_alias *out = (jda_chunk16_alias *)wt;
+    for (uint32_t i = tid; i < JDA_WT_BYTES / 16u; i += nthreads) out[i] = src[i];
 }
 // One walk of a segment.  wt: the walk's tables (jda_walk_tables_from); segw: the segment's first dword in the (zero-padded)
 // filtered scan.

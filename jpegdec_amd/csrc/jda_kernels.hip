@@ -446,7 +446,7 @@ void jda_segscan_write(const jda_segscan_params *__restrict__ params)
     const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
     if (blockIdx.x * 256u >= P.n_segs) return;                       // (uniform per workgroup: images of a batch differ in size)
     uint8_t *tab = lds;
-    jda_walk_tables_from(P.tables, threadIdx.x, 256u, tab);          // the walk's four tables are all that is staged
+    jda_walk_tables_stage(P.walk_tables, threadIdx.x, 256u, tab);      // the walk's four tables are all that is staged
     const bool in_range = seg < P.n_segs;
     uint32_t entry = 0;
     bool need = in_range;                                            // (the wavefronts stay whole for the reduction of their results)
@@ -474,6 +474,21 @@ void jda_segscan_write(const jda_segscan_params *__restrict__ params)
         if (m_dc) atomicMax(&P.stats[3], m_dc);
         if (n_tr) atomicAdd(&P.stats[4], n_tr);
     }
+}
+
+// The walk's tables, once per image (every walker's workgroup converted the blob itself before: 16 dependent rounds of byte
+// loads in front of each of them -- a fifth of the latency-bound rounds)
+__global__ __launch_bounds__(1024)
+void jda_walk_tables_build(const jda_segscan_params *__restrict__ params)
+{
+    const jda_segscan_params &P = params[blockIdx.x];
+    jda_walk_tables_from(P.tables, threadIdx.x, 1024u, P.walk_tables);
+}
+extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream)
+{
+    if (n_images == 0) return hipSuccess;
+    hipLaunchKernelGGL(jda_walk_tables_build, dim3(n_images), dim3(1024), 0, stream, params);
+    return hipGetLastError();
 }
 
 // one segment of a round: walk it, store its sums, and if its exit state is not what the next segment was entered with, replace that
@@ -525,7 +540,7 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
     uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
     uint8_t *tab = lds;
-    jda_walk_tables_from(P.tables, threadIdx.x, 256u, tab);
+    jda_walk_tables_stage(P.walk_tables, threadIdx.x, 256u, tab);
     __syncthreads();                                                 // the tables: all that is staged (a walk reads its segment from memory)
     for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < count; base += gridDim.x * 256u) {
         const uint32_t item = base + lane;
@@ -549,7 +564,7 @@ void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t fi
     if (count == 0) { if (threadIdx.x == 0) stats[7] = 1; return; }       // (the usual case: nothing is staged)
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
     uint8_t *tab = lds;
-    jda_walk_tables_from(P.tables, threadIdx.x, 1024u, tab);
+    jda_walk_tables_stage(P.walk_tables, threadIdx.x, 1024u, tab);
     __syncthreads();
     while (count != 0 && round < max_round) {
         const uint32_t JDA_GLOBAL *wl_in = JDA_G(const uint32_t, P.worklist) + ((round & 1u) ? P.worklist_cap : 0u);

@@ -117,7 +117,7 @@ struct Img {
     bool fast;                   // launched with 24-bit multiplies
     uint32_t n_segs_ub, n_blocks;
     size_t off_raw, off_scan, scan_bytes, off_index, off_dc, off_work, off_zero, off_stats;   // arena offsets
-    size_t work_bytes, zero_bytes, off_rpos, off_fwork;     // off_rpos / off_fwork: restart positions / the filter's work words inside the work region
+    size_t work_bytes, zero_bytes, off_rpos, off_fwork, off_wt;     // off_rpos / off_fwork: restart positions / the filter's work words inside the work region
     size_t ctl_tables;           // offset of its tables inside the control blob
     uint32_t list, n_tiles;      // launch list it is in, tiles (padded)
     size_t strip_off;            // its first strip inside the list
@@ -320,7 +320,8 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         im.n_segs_ub = im.f.raw_len / JDA_SEG_BYTES + 1u;
         im.off_rpos = a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);
         im.off_fwork = im.off_rpos + (im.f.n_intervals ? a16(((size_t)im.f.n_intervals + 1) * 4) : 0);          // .. | the filter's chunk functions
-        im.work_bytes = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len));
+        im.off_wt = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len));                                       // .. | the walk's tables
+        im.work_bytes = im.off_wt + JDA_WT_BYTES;
         im.off_work = take(im.work_bytes);
     }
     const size_t zero_begin = arena;
@@ -399,6 +400,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         P.seg_sum = (uint32_t *)(B + im.off_work); P.seg_start = (const uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24));
         P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
         P.stats = pstats;
+        P.walk_tables = B + im.off_work + im.off_wt;
         P.scan_len = im.f.raw_len; P.n_segs = im.n_segs_ub; P.n_blocks_total = im.n_blocks;
         P.nblocks = (uint8_t)I.blocks_per_mcu; P.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
         for (int c = 0; c < 3; c++) { P.dc_id[c] = im.f.dc_id[c]; P.ac_id[c] = im.f.ac_id[c]; }
@@ -430,6 +432,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         S.st.h2d_bytes += (int64_t)raw_end;
         // the marker filter rides on the copy stream, behind the batch's copy (three short launches over 16 KB chunks: it shares the GPU
         // with whatever the other two streams have running)
+        if (e == hipSuccess) e = jda_launch_walk_tables((const jda_segscan_params *)(B + off_sparams), (uint32_t)dev_ix.size(), p->s_copy);
         if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), max_raw, p->s_copy);
         if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->s_up, S.ev_copy, 0);
@@ -522,6 +525,10 @@ int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status)
                 if (im.f.n_intervals && (rb[1] + 1u != im.f.n_intervals || ps[5] != 0)) ok = false;
                 max_ac = ps[2]; max_dc = ps[3];
                 S.st.spec_rounds_max = std::max<int32_t>(S.st.spec_rounds_max, [&]() { int r = 2; while (r <= JDA_PIPE_MAX_ROUNDS + 1 && ps[8 + r]) r++; return r; }());   // rounds that had something to walk
+                {
+                    static const bool trace_lists = getenv("JDA_PIPE_TRACE_LISTS") != NULL;      // (what the rounds behind round 1 had to walk)
+                    if (trace_lists && i == 0) fprintf(stderr, "jda_pipeline: ticket %d image 0: %u segments, work lists of rounds 2.. : %u %u %u %u %u\n", ticket, rb[0] / JDA_SEG_BYTES + 1u, ps[10], ps[11], ps[12], ps[13], ps[14]);
+                }
                 if (ok && im.fast && !jda_front_fast_mul(S.pin + im.ctl_tables, &im.f, max_ac, (int32_t)max_dc)) ok = false;   // a magnitude no legal stream has
                 redo = !ok;
                 if (ok) S.st.device_images++;

@@ -213,7 +213,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         jda_dev_image *d; uint8_t *stage; std::vector<uint8_t> heap; bool on_device; uint32_t n_int;
         size_t alloc, n_blocks; uint32_t tbytes;
         // the index is made on the device (8f N1 / N2): segments of the scan, see jda_seg_walk
-        bool seg_mode; uint32_t n_segs; size_t off_ea, off_sum, off_start, off_wl, off_rp, off_sstats;
+        bool seg_mode; uint32_t n_segs; size_t off_ea, off_sum, off_start, off_wl, off_rp, off_wt, off_sstats;
         std::vector<uint32_t> rp;            // restart positions + the sentinel, until their copy has been made
         uint32_t sst[68];
     };
@@ -310,7 +310,8 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.off_sum = it.off_ea + align16(((size_t)it.n_segs + 1) * 4); it.off_start = it.off_sum + align16((size_t)it.n_segs * 24);
             it.off_wl = it.off_start + align16((size_t)it.n_segs * 20);
             it.off_rp = it.off_wl + align16((size_t)it.n_segs * 8);
-            it.off_sstats = it.off_rp + (I.restart_interval ? align16(((size_t)it.n_int + 1) * 4) : 0);
+            it.off_wt = it.off_rp + (I.restart_interval ? align16(((size_t)it.n_int + 1) * 4) : 0);
+            it.off_sstats = it.off_wt + JDA_WT_BYTES;
             it.alloc = it.off_sstats + 512;
         }
         e = jda_pool_alloc(ctx, (void **)&d->base, it.alloc);
@@ -347,6 +348,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             }
             SP.blk_index = (uint32_t *)(d->base + d->off_index); SP.blk_dc = (int16_t *)(d->base + d->off_dc);
             SP.stats = (uint32_t *)(d->base + it.off_sstats);
+            SP.walk_tables = d->base + it.off_wt;
             SP.scan_len = scan_len; SP.n_segs = it.n_segs; SP.n_blocks_total = (uint32_t)it.n_blocks;
             SP.nblocks = (uint8_t)I.blocks_per_mcu; SP.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
             for (int c = 0; c < 3; c++) { SP.dc_id[c] = d->dc_id[c]; SP.ac_id[c] = d->ac_id[c]; }
@@ -393,6 +395,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         const uint32_t ns = (uint32_t)seg_params.size();
         e = jda_pool_alloc(ctx, (void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg_params.data(), seg_params.size() * sizeof(jda_segscan_params), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = jda_launch_walk_tables(d_seg, ns, ctx->stream);
         for (uint32_t r = 0; r < 4 && e == hipSuccess; r++) e = jda_launch_segscan_fused(d_seg, ns, max_segs, r, ctx->stream);
         if (e == hipSuccess) e = jda_launch_segscan_tail(d_seg, ns, 4, 56, ctx->stream);
         JDA_UP_MARK("speculative + counting rounds");
