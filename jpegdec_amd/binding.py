@@ -424,18 +424,28 @@ class Pipeline:
             raise JdaError(err.value, "jda_pipeline_create")
         self._keep = {}
 
-    def submit(self, jpegs, outputs, pixel_types, options) -> int:
-        """outputs: list of (device_ptr, pitch_bytes, width_px, rows).  Returns the batch's ticket."""
+    @staticmethod
+    def pack(jpegs, outputs, pixel_types, options):
+        """The C arrays of one submit (a caller that streams the same list again and again builds them once: a C caller has them
+        anyway, and per image they cost Python as much as the GPU takes for a 1280x720 file)."""
         n = len(jpegs)
         arr = (C.c_char_p * n)(*jpegs)
         lens = (C.c_int32 * n)(*[len(j) for j in jpegs])
         outs = (Output * n)(*[Output(*o) for o in outputs])
         pts = (C.c_int32 * n)(*pixel_types)
         opts = (C.c_int32 * n)(*options)
+        return (jpegs, arr, lens, outs, pts, opts, n)
+
+    def submit_packed(self, packed) -> int:
+        jpegs, arr, lens, outs, pts, opts, n = packed
         t = C.c_int32(-1)
         self.ctx.check(self.ctx.lib.jda_pipeline_submit(self.handle, n, arr, lens, outs, pts, opts, C.byref(t)), "jda_pipeline_submit")
-        self._keep[t.value] = (jpegs, arr, lens, outs, pts, opts, n)      # the buffers stay alive until the batch is waited for
+        self._keep[t.value] = packed                                      # the buffers stay alive until the batch is waited for
         return t.value
+
+    def submit(self, jpegs, outputs, pixel_types, options) -> int:
+        """outputs: list of (device_ptr, pitch_bytes, width_px, rows).  Returns the batch's ticket."""
+        return self.submit_packed(self.pack(jpegs, outputs, pixel_types, options))
 
     def wait(self, ticket: int):
         """Blocks until the batch is decoded; returns the list of per-image status codes."""

@@ -100,10 +100,17 @@ class Pipeline:
     def __init__(self, ctx, max_images, depth=2, host_threads=0):
         self.ctx, self.n, self.batches = ctx, {}, 0
 
-    def submit(self, jpegs, outputs, pixel_types, options):
+    @staticmethod
+    def pack(jpegs, outputs, pixel_types, options):
+        return (jpegs, outputs, pixel_types, options)
+
+    def submit_packed(self, packed):
         self.batches += 1
-        self.n[self.batches] = len(jpegs)
+        self.n[self.batches] = len(packed[0])
         return self.batches
+
+    def submit(self, jpegs, outputs, pixel_types, options):
+        return self.submit_packed(self.pack(jpegs, outputs, pixel_types, options))
 
     def wait(self, ticket):
         return [0] * self.n.pop(ticket)

@@ -24,9 +24,11 @@ def run(ctx, jpegs, batch, batches, depth, threads, pt=J.RGB8888, opt=0, warm=0)
     pipe = J.Pipeline(ctx, max_images=batch, depth=depth, host_threads=threads)
     files = [jpegs[i % len(jpegs)] for i in range(batch)]
 
+    # one set of C arrays per surface (what a C caller holds anyway: building them is Python's time, not the pipeline's)
+    packed = [pipe.pack(files, [(base + i * img_bytes, pitch, g["canvas_w"], g["canvas_h"]) for i in range(batch)], [pt] * batch, [opt] * batch) for base in surfaces]
+
     def submit(k):
-        base = surfaces[k % depth]
-        return pipe.submit(files, [(base + i * img_bytes, pitch, g["canvas_w"], g["canvas_h"]) for i in range(batch)], [pt] * batch, [opt] * batch)
+        return pipe.submit_packed(packed[k % depth])
 
     inflight = []
     t_submit = 0.0
