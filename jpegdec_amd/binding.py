@@ -489,14 +489,16 @@ def surface_checksum_host(canvas: np.ndarray) -> int:
         return int(np.sum(m * (np.uint64(2) * i + np.uint64(1)), dtype=np.uint64))
 
 
-def decode_to_host(ctx: Context, jpeg: bytes, pixel_type=RGB8888, options=0):
-    """Decode one image through the GPU path into an MCU-padded host canvas (rows x pitch bytes)."""
+def decode_to_host(ctx: Context, jpeg: bytes, pixel_type=RGB8888, options=0, out=None):
+    """Decode one image through the GPU path into an MCU-padded host canvas (rows x pitch bytes).
+    out: a canvas of that shape from an earlier call, to decode into (a fresh 4096x4096 canvas costs a millisecond of page faults)."""
     info = ImageInfo()
     rc = ctx.lib.jda_parse(jpeg, len(jpeg), C.byref(info))
     if rc != 0:
         raise JdaError(rc, "jda_parse")
     g = output_geometry(info, pixel_type, options)
-    canvas = np.zeros((g["canvas_h"], g["canvas_w"] * g["bpp"]), dtype=np.uint8)
+    shape = (g["canvas_h"], g["canvas_w"] * g["bpp"])
+    canvas = out if out is not None and out.shape == shape and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] else np.zeros(shape, dtype=np.uint8)
     rc = ctx.lib.jda_decode_to_host(ctx.handle, jpeg, len(jpeg), pixel_type, options,
                                     canvas.ctypes.data_as(_P), canvas.shape[1], canvas.shape[0])
     return rc, canvas, g
