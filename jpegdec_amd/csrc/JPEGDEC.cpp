@@ -18,6 +18,11 @@
 
 struct jpegdec_amd_state {
     std::vector<uint8_t> owned;       // file-sourced data (open(filename) / callbacks)
+    // the decoded canvas the draw callbacks / the framebuffer copy are replayed from, and the replay's strip plan: kept from one
+    // decode to the next (they grow to the largest image the object has decoded and go with it) -- a fresh canvas per decode was
+    // a memset and a page fault per 4 KB of it: 0.2 ms of a 640x480 decode, 5 ms of a 4096x4096 one
+    std::vector<uint8_t> canvas;
+    std::vector<int32_t> rects;
     const uint8_t *data;
     int size;
     jda_image_info info;
@@ -260,7 +265,10 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         if (rc == JDA_DECODE_ERROR) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
         return 1;
     }
-    std::vector<uint8_t> canvas((size_t)cw * ch * bpp);
+    if (s->canvas.size() < (size_t)cw * ch * bpp) s->canvas.resize((size_t)cw * ch * bpp);
+    uint8_t *const canvas = s->canvas.data();    // (every row the replay reads is copied back by this decode: the MCU rows it keeps)
+    static const bool poison = getenv("JPEGDEC_AMD_POISON_CANVAS") != NULL;     // (tests: what the last decode left must never show)
+    if (poison) memset(canvas, 0xA5, (size_t)cw * ch * bpp);
     // A cropped decode only launches the tiles of the MCUs the reference keeps (jpeg.inl:5111, :5134-5137: MCU rows from the crop's
     // first row on, MCU columns from iCropX up to and including the one AT iCropX + iCropCX -- the '>' there).  The reference
     // still entropy-decodes what it skips (it has to, to find the next MCU); the per-block index makes that unnecessary here.
@@ -276,7 +284,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         if (y1 > s->info.mcus_y) y1 = s->info.mcus_y;
         rect[0] = x0 < x1 ? x0 : 0; rect[1] = y0; rect[2] = x0 < x1 ? x1 : 0; rect[3] = y1 > y0 ? y1 : y0;
     }
-    rc = jda_decode_to_host_rect(ctx, s->data, s->size, pt, iOptions, cropped ? rect : NULL, canvas.data(), cw * bpp, ch, &mcus_decoded, NULL);
+    rc = jda_decode_to_host_rect(ctx, s->data, s->size, pt, iOptions, cropped ? rect : NULL, canvas, cw * bpp, ch, &mcus_decoded, NULL);
     // the reference walks the MCU rows down to the crop's bottom only (jpeg.inl:5014-5037): a bad MCU below it is never met
     if (rc == JDA_DECODE_ERROR && cropped && mcus_decoded >= rect[3] * s->info.mcus_x && rect[3] < s->info.mcus_y) rc = JDA_SUCCESS;
     const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
@@ -327,17 +335,19 @@ int JPEGDEC::decode(int x, int y, int iOptions)
             uint8_t *fb = fb0 - ((bpp == 1) ? ((ty * pitch_px) & 1) : 0);
             for (int pass = 0; pass < 2; pass++)
                 for (int rr = 0; rr < mh; rr++) {
-                    const uint8_t *src = canvas.data() + ((size_t)(y * mh + rr) * cw + (size_t)x0 * mw) * bpp;
+                    const uint8_t *src = canvas + ((size_t)(y * mh + rr) * cw + (size_t)x0 * mw) * bpp;
                     if (pass == 0) memcpy(fb + (size_t)(ty + rr) * pitch_px * bpp, src, (size_t)main_px * bpp);
                     else if (over_px > 0 && ty + rr + 1 <= last_row)
                         memcpy(fb + (size_t)(ty + rr + 1) * pitch_px * bpp, src + (size_t)main_px * bpp, (size_t)over_px * bpp);
                 }
         }
     } else if (s->draw) {
-        std::vector<int32_t> rects(8 * 65536);
         const int32_t crop[4] = { s->crop_x, s->crop_y, s->crop_w, s->crop_h };
-        int n = jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0,
-                                 cropped ? crop : NULL, s->xoff, rects.data(), 65536);
+        int n = jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0, cropped ? crop : NULL, s->xoff, NULL, 0);   // how many strips
+        if (n > 65536) n = 65536;
+        if (n > 0 && s->rects.size() < (size_t)8 * n) s->rects.resize((size_t)8 * n);
+        std::vector<int32_t> &rects = s->rects;
+        if (n > 0) (void)jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0, cropped ? crop : NULL, s->xoff, rects.data(), n);
         // with JPEG_USES_DMA (and no user cap on the MCU count) the strip ping-pongs between the two halves
         bool dma = (iOptions & JPEG_USES_DMA) != 0;
         {   // the halves only alternate when the user cap did not win (jpeg.inl:5071-5076)
@@ -384,7 +394,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
                 int avail = (cw - r[6]) * bpp;
                 if (avail > row_bytes) avail = row_bytes;
                 if (avail < 0) avail = 0;
-                memcpy(dst, canvas.data() + ((size_t)cy_ * cw + r[6]) * bpp, (size_t)avail);
+                memcpy(dst, canvas + ((size_t)cy_ * cw + r[6]) * bpp, (size_t)avail);
                 if (avail < row_bytes) memset(dst + avail, 0, (size_t)(row_bytes - avail));
             }
             JPEGDRAW jd;
