@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""A longer run of tests/test_gpu_pipeline.py's corruption test (test infrastructure: the oracle is the checker): random byte corruptions
+inside the entropy-coded data of a few files, batches of them through the device filter, segment walk and decode, every surface and status
+against the oracle's.  Usage (GPU box): python tools/gpu_fuzz_pipeline.py [rounds] [seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import jpegdec_amd as J  # noqa: E402
+from oracle.loader import OracleDecoder  # noqa: E402
+from tests.cases import jpeg_for  # noqa: E402
+from tests.test_gpu_pipeline import _check, _surfaces  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
+ctx = J.Context(0)
+oracle = OracleDecoder()
+pipe = J.Pipeline(ctx, max_images=64, depth=2, host_threads=4)
+bases = ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217", "c420_1280x720", "gray_333x217", "c420_256x256_q98", "c440_200x120")
+total = on_device = failed = 0
+for r in range(rounds):
+    jp, nm = [], []
+    for name in bases:
+        base = bytearray(jpeg_for(name))
+        sos = bytes(base).index(b"\xff\xda")
+        made = 0
+        while made < 8:
+            b = bytearray(base)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+            jb = bytes(b)
+            try:
+                p = J.PreparedImage(jb)
+            except J.JdaError:
+                continue
+            idx, nok = p.block_index()
+            out_of_contract = (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan())      # (ran out of data)
+            p.close()
+            if out_of_contract:
+                continue
+            jp.append(jb); nm.append("%s#%d.%d" % (name, r, made)); made += 1
+    pts = [J.RGB8888] * len(jp)
+    opts = [0] * len(jp)
+    outs, metas = _surfaces(ctx, jp, pts, opts)
+    before = pipe.stats
+    st = pipe.wait(pipe.submit(jp, outs, pts, opts))
+    _check(ctx, oracle, jp, pts, opts, outs, metas, st, nm)
+    after = pipe.stats
+    total += len(jp); on_device += after["device_images"] - before["device_images"]; failed += sum(1 for s in st if s != 0)
+    for o in outs:
+        ctx.free(o[0])
+print("corrupted streams %d, indexed on the device %d, decode errors %d (as the oracle's): all surfaces and statuses equal" % (total, on_device, failed))
+pipe.close(); ctx.close()
