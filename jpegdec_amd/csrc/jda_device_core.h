@@ -1094,8 +1094,9 @@ JDA_HD void jda_walk_tables_stage(const uint8_t *prepared, uint32_t tid, uint32_
 //          guard bit for the compare); bits consumed advance all of them by the same number of bytes, a refill resets those
 //          that reached 6 bytes.  phase_map: field j (3 bits) = exit lag for entry lag j.
 //   WRITE  the reader itself (pBuf, ulBitOff), block ordinals and DC predictors from seg_start: index entries (held back to the
-//          block's end so that a truncation flag joins its entry in the register: one plain store; only a block that crosses into
-//          the next segment is ORed in atomically), blk_dc, maxima, truncation count.
+//          block's end so that a truncation flag joins its entry in the register; only a block that crosses into the next segment
+//          is ORed in atomically), blk_dc -- both collected in registers and stored as aligned 16-byte groups (below) --,
+//          maxima, truncation count.
 // RST: the stream has restart intervals.  The filter recorded where every interval starts (byte aligned: the rest of the byte in
 // front is padding); a walk that finishes an MCU within 7 bits of the next start has finished the interval: it steps over the
 // padding, the reference rounds ulBitOff up WITHOUT a refill (jpeg.inl:5339-5346; so the refill after an interval's closing EOB
