@@ -134,7 +134,9 @@ struct Img {
 struct jda_pipeline {
     jda_ctx *ctx;
     int depth, max_images;
-    hipStream_t s_up, s_copy;            // filter + pre-scan | memset + H2D (its own stream: a copy must not queue behind the previous batch's pre-scan)
+    hipStream_t s_up, s_copy;            // pre-scan | memset + H2D + filter (its own stream: a copy must not queue behind the previous batch's pre-scan)
+    hipStream_t s_upx[2];                // more pre-scan streams, taken in turn with s_up: a batch's late rounds (a handful of wavefronts, the
+    int n_upx;                           // latency of a walk each) must not hold back the next batch's round 0 ($JDA_PIPE_UP_STREAMS: 1 .. 3 in all)
     Workers *workers;
     struct Slot {
         int ticket;
@@ -193,10 +195,16 @@ jda_pipeline *jda_pipeline_create(jda_ctx *ctx, int32_t max_images, int32_t dept
     if (max_images <= 0 || depth < 1 || depth > JDA_PIPE_MAX_DEPTH) { *err = JDA_INVALID_PARAMETER; return NULL; }
     jda_pipeline *p = new (std::nothrow) jda_pipeline;
     if (!p) { *err = JDA_ERROR_MEMORY; return NULL; }
-    p->ctx = ctx; p->depth = depth; p->max_images = max_images; p->next_ticket = 0; p->workers = NULL; p->s_up = NULL; p->s_copy = NULL;
+    p->ctx = ctx; p->depth = depth; p->max_images = max_images; p->next_ticket = 0; p->workers = NULL; p->s_up = NULL; p->s_upx[0] = p->s_upx[1] = NULL; p->n_upx = 0; p->s_copy = NULL;
     memset(&p->total, 0, sizeof(p->total));
     (void)hipSetDevice(ctx->device);
     bool ok = hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking) == hipSuccess;
+    {
+        const char *e = getenv("JDA_PIPE_UP_STREAMS");
+        int want = e ? atoi(e) : 2;
+        if (want > depth) want = depth;
+        for (int i = 1; i < want && i < 3 && ok; i++) { ok = hipStreamCreateWithFlags(&p->s_upx[i - 1], hipStreamNonBlocking) == hipSuccess; if (ok) p->n_upx = i; }
+    }
     for (int i = 0; i < JDA_PIPE_MAX_DEPTH; i++) {
         jda_pipeline::Slot &s = p->slots[i];
         s.ticket = -1; s.in_flight = false; s.dev = NULL; s.pin = NULL; s.dev_cap = s.pin_cap = 0; s.ev_copy = s.ev_up = s.ev_dec = NULL;
@@ -216,6 +224,7 @@ void jda_pipeline_destroy(jda_pipeline *p)
     (void)hipSetDevice(p->ctx->device);
     if (p->s_copy) (void)hipStreamSynchronize(p->s_copy);
     if (p->s_up) (void)hipStreamSynchronize(p->s_up);
+    for (int i = 0; i < 2; i++) if (p->s_upx[i]) (void)hipStreamSynchronize(p->s_upx[i]);
     (void)hipStreamSynchronize(p->ctx->stream);
     for (int i = 0; i < JDA_PIPE_MAX_DEPTH; i++) {
         jda_pipeline::Slot &s = p->slots[i];
@@ -225,6 +234,7 @@ void jda_pipeline_destroy(jda_pipeline *p)
         if (s.ev_dec) (void)hipEventDestroy(s.ev_dec);
     }
     if (p->s_up) (void)hipStreamDestroy(p->s_up);
+    for (int i = 0; i < 2; i++) if (p->s_upx[i]) (void)hipStreamDestroy(p->s_upx[i]);
     if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
     delete p->workers;
     delete p;
@@ -424,6 +434,8 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     });
 
     // ---- enqueue: upload stream
+    const int up_ix = t % (p->n_upx + 1);
+    hipStream_t s_up = up_ix ? p->s_upx[up_ix - 1] : p->s_up;           // batches take the pre-scan streams in turn
     hipError_t e = hipSuccess;
     uint8_t *B = S.dev;
     if (n_dev) {
@@ -435,19 +447,19 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         if (e == hipSuccess) e = jda_launch_walk_tables((const jda_segscan_params *)(B + off_sparams), (uint32_t)dev_ix.size(), p->s_copy);
         if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), max_raw, p->s_copy);
         if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->s_up, S.ev_copy, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_up, S.ev_copy, 0);
         if (e == hipSuccess) {
             const jda_segscan_params *dp = (const jda_segscan_params *)(B + off_sparams);
             const uint32_t ns = (uint32_t)dev_ix.size();
             // speculative rounds with the count pass folded in (work lists: a round after the first walks what the one before changed)
-            for (uint32_t r = 0; r < JDA_PIPE_SPEC_ROUNDS && e == hipSuccess; r++) e = jda_launch_segscan_fused(dp, ns, max_segs, r, p->s_up);
-            if (e == hipSuccess) e = jda_launch_segscan_tail(dp, ns, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, p->s_up);
-            if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, p->s_up);
-            if (e == hipSuccess) e = jda_launch_segscan_write(dp, ns, max_segs, p->s_up);
+            for (uint32_t r = 0; r < JDA_PIPE_SPEC_ROUNDS && e == hipSuccess; r++) e = jda_launch_segscan_fused(dp, ns, max_segs, r, s_up);
+            if (e == hipSuccess) e = jda_launch_segscan_tail(dp, ns, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, s_up);
+            if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, s_up);
+            if (e == hipSuccess) e = jda_launch_segscan_write(dp, ns, max_segs, s_up);
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.pin_stats, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, p->s_up);
+        if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.pin_stats, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, s_up);
     }
-    if (e == hipSuccess) e = hipEventRecord(S.ev_up, p->s_up);
+    if (e == hipSuccess) e = hipEventRecord(S.ev_up, s_up);
     // ---- enqueue: decode stream
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, S.ev_up, 0);
     for (int m = 0; m < JDA_N_LISTS && e == hipSuccess && n_dev; m++) {
@@ -456,7 +468,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         S.st.launches++;
     }
     if (e == hipSuccess) e = hipEventRecord(S.ev_dec, ctx->stream);
-    if (e != hipSuccess) { (void)hipStreamSynchronize(p->s_copy); (void)hipStreamSynchronize(p->s_up); (void)hipStreamSynchronize(ctx->stream); return jda_set_err(ctx, e, "jda_pipeline_submit"); }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(p->s_copy); (void)hipStreamSynchronize(s_up); (void)hipStreamSynchronize(ctx->stream); return jda_set_err(ctx, e, "jda_pipeline_submit"); }
     S.ticket = t; S.in_flight = true;
     p->next_ticket++;
     *ticket = t;

@@ -7,10 +7,11 @@ python bench.py > $out/bench_default.json 2> $out/bench_default.err
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out -o kt -- python $R/bench.py --no-parity --no-cpu-baseline --e2e-batches 0 > /dev/null 2>&1)
 : > $out/pipe.jsonl
 P="python tools/pipeline_bench.py --threads 8"
-for c in "--depth 1" "--depth 2" "--depth 3" "--depth 3 --batch 128 --batches 8" "--depth 3 --batch 256 --batches 6" "--depth 3 --restart-rows 1" "--depth 3 --restart-rows 4" \
+for c in "--depth 1" "--depth 2" "--depth 3" "--depth 4" "--depth 3 --distinct 16" "--depth 4 --distinct 16" "--depth 3 --batch 128 --batches 8" "--depth 3 --batch 256 --batches 6" "--depth 4 --batch 256 --batches 6 --distinct 16" "--depth 3 --restart-rows 1" "--depth 3 --restart-rows 4" \
          "--depth 3 --subsampling 4:4:4" "--depth 3 --quality 98 --batches 6" \
          "--depth 3 --width 1920 --height 1080 --batch 256 --batches 8" "--depth 3 --width 1920 --height 1080 --batch 1024 --batches 6" \
-         "--depth 3 --width 1280 --height 720 --batch 512 --batches 8" "--depth 3 --width 1280 --height 720 --batch 1024 --batches 8" "--depth 3 --width 1280 --height 720 --batch 2048 --batches 6"; do
+         "--depth 3 --width 1280 --height 720 --batch 512 --batches 8" "--depth 3 --width 1280 --height 720 --batch 1024 --batches 8" "--depth 3 --width 1280 --height 720 --batch 2048 --batches 6" \
+         "--depth 4 --width 1280 --height 720 --batch 1024 --batches 8 --distinct 64" "--depth 4 --width 1920 --height 1080 --batch 256 --batches 8 --distinct 16"; do
   timeout 300 $P $c 2>/dev/null | tail -1 >> $out/pipe.jsonl
 done
 kt() { name=$1; shift
@@ -29,6 +30,6 @@ import json
 for l in open("$out/pipe.jsonl"):
     try: d=json.loads(l)
     except Exception: print(l[:200]); continue
-    print("%8.0f Mpix/s  %.4f ms/img  host %.4f ms/img  batch %d depth %d rounds %d devimgs %d/%d" % (d["mpix_s"], d["ms_per_image"], d["host_submit_ms_per_image"], d["batch"], d["depth"], d["stats"]["spec_rounds_max"], d["stats"]["device_images"], d["stats"]["images"]))
+    print("%8.0f Mpix/s  %.4f ms/img  host %.4f ms/img  batch %d depth %d distinct %d rounds %d devimgs %d/%d" % (d["mpix_s"], d["ms_per_image"], d["host_submit_ms_per_image"], d["batch"], d["depth"], d.get("distinct", 2), d["stats"]["spec_rounds_max"], d["stats"]["device_images"], d["stats"]["images"]))
 PY
 tail -3 $out/soak.txt; tail -8 $out/single_image.txt

@@ -73,10 +73,12 @@ def main():
     ap.add_argument("--subsampling", default="4:2:0")
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--restart-rows", type=int, default=0)
+    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic files the batch cycles through (more: more segments that need a late round)")
     a = ap.parse_args()
-    jpegs = [cached_jpeg(a.width, a.height, a.subsampling, 1234 + i, quality=a.quality, restart_rows=a.restart_rows) for i in range(2)]
+    jpegs = [cached_jpeg(a.width, a.height, a.subsampling, 1234 + i, quality=a.quality, restart_rows=a.restart_rows) for i in range(a.distinct)]
     ctx = J.Context(0)
     r = run(ctx, jpegs, a.batch, a.batches, a.depth, a.threads)
+    r["distinct"] = a.distinct
     print(json.dumps(r))
     ctx.close()
 
