@@ -303,6 +303,7 @@ def run(args, J, out=sys.stdout):
             ctx.free(p_)
         e2e = {"mpix_s": px_all / dt / 1e6, "ms_per_image": dt / n_img * 1e3, "host_submit_ms_per_image": t_submit / n_img * 1e3,
                "batches": args.e2e_batches, "images_per_batch": eb, "depth": depth, "host_threads": min(threads, 8),
+               "distinct_images": min(n_distinct, eb),      # (more distinct files per batch: a few more latency-bound pre-scan rounds)
                "device_path_images": pst["device_images"], "host_path_images": pst["host_path_images"],
                "what": "files in host memory -> pixels resident in HBM through jda_pipeline: host parse + tables, H2D of the unfiltered scans, "
                        "device marker filter + per-block index + decode, batches overlapped; whole job, all ranks"}
