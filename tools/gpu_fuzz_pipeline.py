@@ -17,9 +17,10 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
 ctx = J.Context(0)
 oracle = OracleDecoder()
-pipe = J.Pipeline(ctx, max_images=64, depth=2, host_threads=4)
+pipe = J.Pipeline(ctx, max_images=64, depth=3, host_threads=4)
 bases = ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217", "c420_1280x720", "gray_333x217", "c420_256x256_q98", "c440_200x120")
 total = on_device = failed = 0
+inflight = []
 for r in range(rounds):
     jp, nm = [], []
     for name in bases:
@@ -44,12 +45,15 @@ for r in range(rounds):
     pts = [J.RGB8888] * len(jp)
     opts = [0] * len(jp)
     outs, metas = _surfaces(ctx, jp, pts, opts)
-    before = pipe.stats
-    st = pipe.wait(pipe.submit(jp, outs, pts, opts))
-    _check(ctx, oracle, jp, pts, opts, outs, metas, st, nm)
-    after = pipe.stats
-    total += len(jp); on_device += after["device_images"] - before["device_images"]; failed += sum(1 for s in st if s != 0)
-    for o in outs:
-        ctx.free(o[0])
+    inflight.append((pipe.submit(jp, outs, pts, opts), jp, pts, opts, outs, metas, nm))
+    if len(inflight) == 3 or r == rounds - 1:                 # three batches in flight: the pre-scan streams really run side by side
+        while inflight:
+            t, jp_, pts_, opts_, outs_, metas_, nm_ = inflight.pop(0)
+            st = pipe.wait(t)
+            _check(ctx, oracle, jp_, pts_, opts_, outs_, metas_, st, nm_)
+            total += len(jp_); failed += sum(1 for s in st if s != 0)
+            for o in outs_:
+                ctx.free(o[0])
+on_device = pipe.stats["device_images"]
 print("corrupted streams %d, indexed on the device %d, decode errors %d (as the oracle's): all surfaces and statuses equal" % (total, on_device, failed))
 pipe.close(); ctx.close()
