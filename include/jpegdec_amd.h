@@ -281,7 +281,7 @@ int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int3
  * Files in, pixels resident in HBM out, batch after batch: the host parses headers and builds tables (microseconds per file);
  * the unfiltered entropy-coded bytes go to the GPU, which filters them (JPEGFilter, jpeg.inl:1431-1540), makes the per-block
  * index (equal to the serial pre-scan's, entry for entry) and decodes (jpeg.inl:5109-5353).  Upload + filter + pre-scan of
- * batch n+1 run on a second stream under the decode of batch n.  Images the device walk cannot take or that fail its checks
+ * batch n+1 run on streams of their own under the decode of batch n (three batches in flight keep the GPU busy).  Images the device walk cannot take or that fail its checks
  * (progressive, corrupt, truncated, ...) are redone through the serial host pre-scan when the batch is waited for, so every
  * image ends with the status -- and the pixels -- the one-image path (jda_decode_to_host) gives it.
  *   jda_pipeline_create   max_images per batch; depth = batches in flight (1..4); host_threads <= 0: up to 8
