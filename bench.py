@@ -115,7 +115,7 @@ def parse_args(argv=None):
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed decode launches before the warm-up steps until the GPU clocks have ramped (0: none)")
     ap.add_argument("--device-prescan", action="store_true", help="resident inputs: the block index is made on the GPU at upload (default: serial host pre-scan; the streamed pipeline always uses the device)")
     ap.add_argument("--e2e-batches", type=int, default=10, help="batches streamed through jda_pipeline for the end-to-end figure (0: skip)")
-    ap.add_argument("--e2e-depth", type=int, default=3)
+    ap.add_argument("--e2e-depth", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the control collectives (nccl = RCCL)")
