@@ -99,11 +99,13 @@ typedef struct jda_image jda_image;
  * Returns NULL on failure with *err set.  The JPEG buffer is not referenced after return. */
 jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
 
-/* The same with options.  JDA_PREPARE_DEVICE_PRESCAN: when the stream carries restart markers (DRI,
- * jpeg.inl:1715-1718, 5337-5348) skip the serial Huffman pre-scan on the host; the per-block index is then
- * made on the GPU, one lane per restart interval, when the image is uploaded (jda_upload), which falls back
- * to the host pre-scan by itself if the device walk cannot guarantee bit-exact results.  Without restart
- * markers the flag has no effect. */
+/* The same with options.  JDA_PREPARE_DEVICE_PRESCAN: skip the serial Huffman pre-scan on the host; the per-block
+ * index is then made on the GPU when the image is uploaded (jda_upload / jda_upload_batch) by the segment walk --
+ * one lane per 256-byte segment of the filtered scan, with or without restart markers (DRI, jpeg.inl:1715-1718,
+ * 5337-5348) -- entry for entry what the serial pre-scan makes.  The upload falls back to the host pre-scan by itself
+ * when the walk cannot guarantee that (an invalid code, a marker out of place, states that do not settle); files the
+ * walk cannot take at all (progressive, one restart interval, table ids 2-3, DC codes its table key cannot tell
+ * apart) are pre-scanned here whatever the flag says: jda_image_prescan_pending tells. */
 #define JDA_PREPARE_DEVICE_PRESCAN 1
 jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
 /* jda_prepare_ex for n images on `threads` host threads (<= 0: all hardware threads); out[i] / errs[i] per image
@@ -195,14 +197,14 @@ int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: a device
  * (either pointer may be NULL); n_blocks = mcus_x * mcus_y * blocks_per_mcu.  Synchronous. */
 int jda_dev_image_read_index(jda_ctx *ctx, const jda_dev_image *dimg, uint32_t *index, int16_t *dc);
 uint32_t jda_dev_image_mcus_ok(const jda_dev_image *dimg);        /* MCUs the pre-scan validated */
-int jda_last_prescan_rounds(const jda_ctx *ctx);
+int jda_last_prescan_rounds(const jda_ctx *ctx);                 /* rounds the last device pre-scan on this context took (diagnostics) */
 /* The marker / byte-stuffing filter (JPEGFilter, jpeg.inl:1431-1540) run on the GPU over a host buffer, result back on the
  * host: out must hold len bytes; *out_len = filtered length; restart_pos[0] = 0 and restart_pos[k] = filtered offset at
  * which the k-th RSTn marker stood (first restart_cap entries), *n_restarts = markers seen.  A stand-alone entry point
  * (jda_upload_batch still takes the scan filtered by jda_prepare on the host); exposed for callers that want the filtered
  * scan made on the GPU, and for the tests. */
 int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t *out, int32_t *out_len,
-                         uint32_t *restart_pos, int32_t restart_cap, int32_t *n_restarts);   /* speculative rounds of the last marker-less device pre-scan (diagnostics) */
+                         uint32_t *restart_pos, int32_t restart_cap, int32_t *n_restarts);
 void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg);
 size_t jda_dev_image_bytes(const jda_dev_image *dimg);
 

@@ -143,11 +143,14 @@ def _codes(bits, vals):
 
 
 def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), restart_interval: int = 0,
-                       dup_eob: bool = False) -> bytes:
+                       dup_eob: bool = False, long_dc: bool = False) -> bytes:
     """Baseline JPEG of an HxWx3 RGB image with luma sampling factors luma_hv = (H, V) and 1x1 chroma:
     (1,1) 4:4:4, (2,1) 4:2:2, (1,2) 4:4:0, (2,2) 4:2:0.
     dup_eob: both AC tables code the end-of-block symbol twice (a second, 16-bit code) and every other block ends with
-    the second one -- a malformed but decodable DHT (decoders with per-code LUTs do not notice)."""
+    the second one -- a malformed but decodable DHT (decoders with per-code LUTs do not notice).
+    long_dc: both DC tables give categories 0-4 codes of 1-5 bits and categories 5-11 codes of ELEVEN bits, 11111000000 ..
+    11111000110 -- legal, and codes that start 111110 and are longer than 10 bits are what the device pre-scan's 11-bit table
+    key cannot tell apart (jda_dc_lut_walkable): such a file must stay on the serial pre-scan."""
     hs, vs = luma_hv
     h, w = pixels.shape[:2]
     rgb = pixels.astype(np.float64)
@@ -180,6 +183,9 @@ def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), re
         return np.rint(coef / q).astype(np.int32)
 
     cb = [blocks(planes[0], nat_q[0]), blocks(planes[1], nat_q[1]), blocks(planes[2], nat_q[1])]
+    if long_dc:
+        for th in (0, 1):
+            huff[(0, th)] = ([1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 7, 0, 0, 0, 0, 0], list(range(12)))
     dc_t = [_codes(*huff[(0, 0)]), _codes(*huff[(0, 1)])]
     eob2 = [None, None]
     if dup_eob:

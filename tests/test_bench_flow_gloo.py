@@ -93,3 +93,31 @@ def test_cpu_quota_and_placement_helpers():
     assert 1 <= cores <= detail["affinity_cpus"]
     assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert isinstance(cpu_model(), str)
+
+
+def test_bench_py_gpus_2_starts_its_own_ranks(tmp_path, product_lib):
+    """`python bench.py --gpus 2` as the driver runs it -- no torch.distributed.run around it, no WORLD_SIZE -- must start two
+    ranks itself and print ONE line with n_gpus == 2 (round 2's bench silently ran world = 1)."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--ramp-ms", "0",
+           "--dist-backend", "gloo", "--device-module", "tests.stub_device", "--no-parity", "--no-cpu-baseline", "--no-configs", "--e2e-batches", "2",
+           "--width", "333", "--height", "217", "--batch", "5", "--distinct", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dist"] == {"backend": "gloo", "ranks": 2}
+    assert line["sharding"]["decoded_exactly_once"] and line["sharding"]["images"] == 10
+
+
+def test_bench_py_refuses_a_launcher_world_that_is_not_gpus(tmp_path, product_lib):
+    import subprocess
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device-module", "tests.stub_device", "--dist-backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

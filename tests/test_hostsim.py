@@ -156,6 +156,31 @@ def test_duplicate_eob_code_takes_the_general_reader(luma_hv, hostsim, oracle):
         assert np.array_equal(got, want), (luma_hv, pt, opt)
 
 
+@pytest.mark.parametrize("restart_interval", [0, 3])
+def test_long_dc_codes_stay_on_the_serial_prescan(restart_interval, hostsim, oracle):
+    """DC codes 111110.. of 11 bits: the segment walk's 11-bit key cannot stand for them (jda_dc_lut_walkable), so the front end
+    must not defer such a file to the device pre-scan -- with or without restart intervals (round 2 checked the marker-less
+    branch only) -- and the serial path decodes it to the oracle's bytes."""
+    from jpegdec_amd.synth import encode_jpeg_custom, value_noise_image
+    img = value_noise_image(200, 120, 3, 91)
+    jpeg = encode_jpeg_custom(img, 85, (2, 2), restart_interval=restart_interval, long_dc=True)
+    plain = encode_jpeg_custom(img, 85, (2, 2), restart_interval=restart_interval)
+    p, q = J.PreparedImage(jpeg, device_prescan=True), J.PreparedImage(plain, device_prescan=True)
+    assert not p.prescan_pending and q.prescan_pending
+    p.close(); q.close()
+    rc, want, err = oracle.decode_canvas(jpeg, J.RGB8888, 0)
+    assert rc == 1
+    got = np.full_like(want, 0x33)
+    inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, J.RGB8888, 0)
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        assert hostsim.hostsim_decode(jpeg, len(jpeg), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert hostsim.hostsim_prescan_used() == 0          # the walk was not taken
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+    assert np.array_equal(got, want)
+
+
 def test_reference_fixtures_with_restart_intervals_through_the_segment_walk(hostsim):
     """tulips (DRI) and the other fixtures with restart intervals: the segment walk's index == the serial pre-scan's"""
     from tests.ref_fixtures import GOOD, ref_jpeg
