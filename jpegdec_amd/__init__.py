@@ -26,6 +26,7 @@ from .binding import (  # noqa: F401
     draw_plan,
     draw_plan_ex,
     filter_on_device,
+    index_equivalent,
     library_path,
     load_library,
     output_geometry,

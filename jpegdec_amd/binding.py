@@ -344,6 +344,21 @@ class DeviceImage:
             self.handle = None
 
 
+def index_equivalent(a, b) -> bool:
+    """Do two per-block indexes name the same decode?  An entry is (byte position << 7) | flag << 6 | bit offset: the bit position
+    pos * 8 + off of the block's first bit is what P1 starts from; the split into (pos, off) -- the reference reader's phase after
+    the block's opening refill -- only matters for a block flagged JDA_INDEX_TRUNC (its truncated magnitude reads are emulated
+    from that phase).  The serial pre-scan writes the true phase everywhere, the device pre-scan's RECORD mode a canonical one
+    ((p >> 3) << 7 | p & 7) into unflagged entries: equivalent = same bit position and flag everywhere, same entry where flagged."""
+    a = np.asarray(a, dtype=np.uint32)
+    b = np.asarray(b, dtype=np.uint32)
+    if a.shape != b.shape:
+        return False
+    pa, pb = (a >> 7) * 8 + (a & 63), (b >> 7) * 8 + (b & 63)
+    fa, fb = a & 64, b & 64
+    return bool(np.array_equal(pa, pb) and np.array_equal(fa, fb) and np.array_equal(a[fa != 0], b[fb != 0]))
+
+
 def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0, strict: bool = True):
     """jda_prepare_batch: the images are prepared on `threads` host threads (0 = all).  strict=False: a rejected file leaves a
     None in the list (and its error code in the second return value) instead of failing the whole batch."""

@@ -422,8 +422,11 @@ struct jda_tables {
 
 // dc_only / al: the scan holds DC symbols only (first scan of a progressive file, JPEGDecodeMCU_P jpeg.inl:1819-2084 with
 // Ss = Se = 0) and their differences are shifted left by Al (:1884); a baseline scan has dc_only = false, al = 0.
+// exact: the block is flagged JDA_INDEX_TRUNC -- its index entry is the reference reader's true phase, and magnitude reads lose the
+// bits the reference's window does not hold.  An unflagged block's entry may be canonical (the device pre-scan's: same bit
+// position, another phase), and the reference truncates nothing in it: the reader refills instead of reading short.
 template <int LIMIT>
-JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred, bool dc_only = false, uint32_t al = 0)
+JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred, bool dc_only = false, uint32_t al = 0, bool exact = true)
 {
     uint32_t flags = 0;
     jda_refill(br);
@@ -464,6 +467,7 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
         br.off += (e >> 12) + 1u;
         k += (int)((e >> 1) & 0xfu);
         const uint32_t ms = (e >> 8) & 0xfu;
+        if (!exact && br.off + ms > 64u) { br.pos += br.off >> 3; br.off &= 7u; br.bits = jda_load_be64(br, br.pos); }
         if (k < LIMIT && ms) {
             const uint32_t n = (T.zz[k] & 0xffu) >> 1;
             flags |= (1u << (n & 7u)) | (n << 8);
@@ -570,9 +574,10 @@ JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) 
 // EXACT = false leaves the reference's ulBitOff out (five instructions and a branch less per symbol): only right for a block
 // in which the reference truncates no magnitude read, i.e. one whose index entry lacks JDA_INDEX_TRUNC.
 // zero_fill: clear the block first.
+// trunc: this lane's block is the flagged one (EXACT runs for the whole wavefront when any lane's is).
 template <int LIMIT, bool EXACT, bool LONG_LDS>
 JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill,
-                                     bool dc_only, uint32_t al)
+                                     bool dc_only, uint32_t al, bool trunc = true)
 {
     jda_wreader R;
     jda_wr_init(R, wbase, pos, off);
@@ -635,7 +640,7 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
         const uint32_t n = len + ms;
         if (EXACT) {
             roff += n;                                   // the reference's ulBitOff after its magnitude read (:2249-2252)
-            if (__builtin_expect(roff > 64u, 0)) m &= ~(0xffffffffu >> (64u + ms - roff));      // its window ended inside the magnitude
+            if (__builtin_expect(roff > 64u && trunc, 0)) m &= ~(0xffffffffu >> (64u + ms - roff));      // its window ended inside the magnitude
             roff = jda_ref_refill(roff);
         }
         v_prev = jda_extend_top(m, ms);
@@ -948,7 +953,11 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 #define JDA_SEG_SLOT  268u           // bytes a lane reads: its segment + 12 bytes of the next; 67 dwords per lane in LDS (odd: no bank conflicts)
 #define JDA_SEG_DEAD  0x7fffffffu    // state of a walk that met an invalid code (bit 31 is the rounds' "changed" mark)
 #define JDA_SEG_CHANGED 0x80000000u // entry-state word: "differs from the previous round's" (the walker's own bits are 14:0)
-enum { JDA_SEG_SPEC = 0, JDA_SEG_COUNT = 1, JDA_SEG_WRITE = 2, JDA_SEG_FUSED = 3 /* SPEC and COUNT in one walk: jda_segscan_fused */ };
+enum { JDA_SEG_SPEC = 0, JDA_SEG_COUNT = 1, JDA_SEG_WRITE = 2, JDA_SEG_FUSED = 3 /* SPEC and COUNT in one walk: jda_segscan_fused */,
+       JDA_SEG_RECORD = 4 /* FUSED + one record per block start + truncation candidates: no WRITE walk follows (jda_segscan_finalize) */ };
+#define JDA_SEG_SUM_WORDS 8u         // per segment: block starts, DC sums [3], phase map, bad | has-restart | max AC category << 4, lag word at the last block start, round
+#define JDA_ST_NCAND 66u             // result word: truncation candidates appended (RECORD)
+#define JDA_REC_POS_BITS 12u         // a record: bit position of the block's first bit in its segment (11 bits) | spare | running DC sum of its component << 12
 
 struct jda_segscan_params {          // one per image
     const uint8_t *scan;             // filtered scan (global), zero padded to n_segs * JDA_SEG_BYTES + 16
@@ -973,6 +982,15 @@ struct jda_segscan_params {          // one per image
     // the walk's four tables (JDA_WT_BYTES) as jda_walk_tables_build makes them from the blob, once per image: a walker's workgroup
     // copies them (one wait) instead of converting the blob itself
     uint8_t *walk_tables;
+    // RECORD mode (NULL / 0: the counting walk + WRITE walk of round 2): the counting walk leaves one record per block start --
+    // rec_cap slots per segment (more than its 2,048 bits can start blocks: jda_record_cap), 16-byte groups -- and the rare
+    // magnitude read that SOME entry lag would truncate as a candidate (16 bytes: segment, ordinal + 1 | round << 16, lag word at
+    // the block's start, the lags that truncate); jda_segscan_finalize turns records into index entries and predictors,
+    // jda_segscan_resolve the candidates of the true lag into flagged entries
+    uint32_t *records;
+    uint32_t rec_cap;
+    uint32_t *cands;
+    uint32_t cand_cap;
 };
 #define JDA_RST_SENTINEL 0x1fffffffu      // (a byte position no scan reaches: the index packs positions in 25 bits)
 #define JDA_SEG_HAS_RESTART 2u           // seg_sum word 5, bit 1: an interval ends inside the segment (its DC sums count from there)
@@ -988,9 +1006,17 @@ JDA_HD jda_segscan_params jda_segscan_resolve(const jda_segscan_params &in)
     }
     return P;
 }
-struct jda_seg_sum { uint32_t nblk; int32_t dcsum[3]; uint32_t phase_map, bad; };
+struct jda_seg_sum { uint32_t nblk; int32_t dcsum[3]; uint32_t phase_map, bad, lag_last, max_ac; };
 struct jda_seg_stats { uint32_t bad, terminal, max_ac_bits, max_abs_dc, trunc_events, mismatch; };
 
+JDA_HD uint32_t jda_atomic_inc_u32(uint32_t *p)                   // the value before
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return (*p)++;                                   // (the emulator steps the lanes one after another)
+#endif
+}
 JDA_HD void jda_atomic_or_u32(uint32_t *p, uint32_t v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1134,11 +1160,12 @@ JDA_HD void jda_seg_flush_dc(int16_t *blk_dc, uint32_t g_new, uint32_t n, uint32
 }
 template <int OP, bool RST = false>
 JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *wt,
-                             jda_seg_sum &S, jda_seg_stats &ST)
+                             jda_seg_sum &S, jda_seg_stats &ST, uint32_t round = 0)
 {
-    const bool CNT = OP == JDA_SEG_COUNT || OP == JDA_SEG_FUSED;      // the segment's sums are wanted
-    const bool TOL = OP == JDA_SEG_SPEC || OP == JDA_SEG_FUSED;       // a speculative walk steps over an invalid code
-    S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0;
+    const bool REC = OP == JDA_SEG_RECORD;                            // FUSED + records + truncation candidates
+    const bool CNT = OP == JDA_SEG_COUNT || OP == JDA_SEG_FUSED || REC;      // the segment's sums are wanted
+    const bool TOL = OP == JDA_SEG_SPEC || OP == JDA_SEG_FUSED || REC;       // a speculative walk steps over an invalid code
+    S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0; S.lag_last = 0; S.max_ac = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
     uint32_t p = entry & 63u, b2 = ((entry >> 6) & 7u) * 2u, k = (entry >> 9) & 63u;      // b2: twice the block's place in the MCU
     // per place in the MCU, in 2-bit fields (uniform): the block's component, and which of the walk's four tables decodes its
@@ -1175,6 +1202,10 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     // 16 bytes when it completes one; the groups it shares with its neighbours (its first and last) go out entry by entry.
     uint32_t ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0, ibn = 0, ib_g = 0;  // ibn: entries not stored yet, ib_g: ordinal of the newest
     uint32_t db0 = 0, db1 = 0, db2 = 0, db3 = 0, dbn = 0;            // (the newest predictor's ordinal is g - 1)
+    // RECORD: the last four records (newest last; a group of four is stored when it is complete: the segment's slots are its own),
+    // the lag word at the start of the block in progress
+    uint32_t rb0 = 0, rb1 = 0, rb2 = 0, rb3 = 0, Ublk = 0;
+    uint32_t JDA_GLOBAL *recs = REC ? JDA_G(uint32_t, P.records) + (size_t)seg * P.rec_cap : (uint32_t JDA_GLOBAL *)0;
     bool pending = false, bad = false, stop = false;                // stop: leave the loop after this step (one exit test per step)
     // RST: the next interval start ahead of the walk (as a bit position relative to the segment), blocks left in the interval
     const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
@@ -1266,10 +1297,37 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             max_ac = m > max_ac ? m : max_ac;
             off += sz;
         }
+        if (REC) {                                                  // a counted block starts here: its record (before its own difference joins the sum)
+            const bool counted = isdc & (sbad == 0u);
+            const int32_t run = c == 0 ? ds0 : (c == 1 ? ds1 : ds2);
+            const uint32_t rec = p | ((uint32_t)run << JDA_REC_POS_BITS);
+            rb0 = counted ? rb1 : rb0; rb1 = counted ? rb2 : rb1; rb2 = counted ? rb3 : rb2; rb3 = counted ? rec : rb3;
+            Ublk = counted ? U : Ublk;
+            if (counted && (nblk & 3u) == 3u) {
+                if (nblk < P.rec_cap) jda_store_u32x4(recs + (nblk - 3u), rb0, rb1, rb2, rb3);
+                else sbad |= 1u;                                    // (jda_record_cap leaves no room for this; memory stays ours anyway)
+            }
+            // a DC category no 8-bit baseline stream has does not fit the record's 20-bit sum: such a file keeps to the serial pre-scan
+            sbad |= (isdc & (sz > 11u)) ? 1u : 0u;
+        }
         if (CNT) {
             nblk += (isdc & (sbad == 0u)) ? 1u : 0u;
             U += (((p & 7u) + len) >> 3) * kOnes;                   // whole bytes the code bits advance the stream position by
             const uint32_t f1 = ((U | kGuard) - 6u * kOnes) & kGuard;
+            if (REC) {
+                // SURVEY fact 6 without knowing the entry lag: the reference reads the magnitude at ulBitOff = 8 u + (p1 & 7) and loses
+                // bits when that + sz > 64 -- u >= 7 for (p1 & 7) + sz in 9..16, u >= 6 above 16 (u <= 7 here) -- so the six candidate
+                // lags are tested at once; the rare hit is kept with the lag word at the block's start (jda_segscan_resolve)
+                const uint32_t t = (p1 & 7u) + sz;
+                const uint32_t f7 = ((U | kGuard) - 7u * kOnes) & kGuard;
+                const uint32_t hit = t > 16u ? f1 : (t > 8u ? f7 : 0u);
+                const uint32_t m = acmag ? sz : 0u;
+                max_ac = m > max_ac ? m : max_ac;
+                if (__builtin_expect(acmag && hit != 0u && sbad == 0u, 0)) {
+                    const uint32_t at = jda_atomic_inc_u32(P.stats + JDA_ST_NCAND);
+                    if (at < P.cand_cap) jda_store_u32x4(P.cands + (size_t)at * 4u, seg, nblk | (round << 16), Ublk, hit);
+                }
+            }
             U &= dcmag ? ~(f1 - (f1 >> 4)) : 0xffffffffu;           // the refill before an unfolded DC magnitude
             U += (((p1 & 7u) + sz) >> 3) * kOnes;
         }
@@ -1352,6 +1410,15 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     }
     if (OP == JDA_SEG_WRITE && pending && !bad) jda_atomic_or_u32(P.blk_index + pend_g, pend);      // the block goes on in the next segment
     if (OP == JDA_SEG_WRITE) { ST.max_ac_bits = max_ac; ST.max_abs_dc = max_dc; }
+    if (REC) {                                                      // what is left of the last group, slot by slot
+        const uint32_t r = nblk & 3u, n4 = nblk & ~3u;
+        if (nblk <= P.rec_cap) {
+            if (r > 0u) recs[n4 + r - 1u] = rb3;
+            if (r > 1u) recs[n4 + r - 2u] = rb2;
+            if (r > 2u) recs[n4 + r - 3u] = rb1;
+        }
+        S.lag_last = Ublk; S.max_ac = max_ac;
+    }
     S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2; S.bad = sbad | has_rst;
     if (bad) { S.bad = 1; ST.bad = 1; return JDA_SEG_DEAD; }
     if (CNT) {
@@ -1362,6 +1429,62 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     return (p - JDA_SEG_BITS) | (b2 << 5) | (k << 9);
 }
 
+// ---- RECORD mode: from records to the index (block-parallel) ----------------------------------------
+// The index entry of a block the reference reads without truncation is CANONICAL here: (p >> 3) << 7 | (p & 7) for the bit
+// position p of the block's first bit -- P1 needs p alone (pos * 8 + off, whatever the split); only a block flagged
+// JDA_INDEX_TRUNC carries the reference reader's true (pBuf, ulBitOff), which its emulation starts from.  The serial pre-scan
+// writes the true phase everywhere: the two indexes agree on p and on the flag of every block and on the whole entry of a flagged one.
+JDA_HD uint32_t jda_index_canonical(uint32_t p_abs) { return ((p_abs >> 3) << JDA_INDEX_OFF_BITS) | (p_abs & 7u); }
+struct jda_fin_acc { uint32_t bad, terminal, max_abs_dc; };
+// record i of segment seg (first block ordinal g0, predictors pr0..2 at its entry: jda_segscan_sums) -> index entry, predictor
+JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t g0, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
+{
+    const uint32_t g = g0 + i;
+    if (g > P.n_blocks_total) return;                               // behind the image: padding decoded as blocks
+    const uint32_t rec = JDA_G(const uint32_t, P.records)[(size_t)seg * P.rec_cap + i];
+    const uint32_t p_abs = seg * JDA_SEG_BITS + (rec & (JDA_SEG_BITS - 1u));
+    // a stream that ends early has been read on into its zero padding: the serial pre-scan knows what the reference does with it
+    // (its test is on the reference's pBuf, at most five bytes behind: the margin makes this one the stricter)
+    if ((p_abs >> 3) + 8u > P.scan_len + JDA_SCAN_PAD - 8u) A.bad = 1;
+    if (g == P.n_blocks_total) {                                    // the reader as the last block left it closes the index
+        JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical(p_abs);
+        A.terminal++;
+        return;
+    }
+    const uint32_t b = g % P.nblocks, c = b < P.nluma ? 0u : b - P.nluma + 1u;
+    const int32_t pred = (c == 0u ? pr0 : (c == 1u ? pr1 : pr2)) + ((int32_t)rec >> JDA_REC_POS_BITS);
+    if (pred < -32768 || pred > 32767) A.bad = 1;
+    const uint32_t a = (uint32_t)(pred < 0 ? -pred : pred);
+    A.max_abs_dc = a > A.max_abs_dc ? a : A.max_abs_dc;
+    JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical(p_abs);
+    JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pred;
+}
+// candidate ci: a magnitude read that some entry lag of its segment truncates.  With the segment's true lag known: does it?  Then
+// the block's entry becomes the reference reader's true phase + the flag.  Returns 1 for a truncated read (the serial pre-scan's count).
+JDA_HD uint32_t jda_resolve_item(const jda_segscan_params &P, uint32_t ci)
+{
+    const uint32_t JDA_GLOBAL *cd = JDA_G(const uint32_t, P.cands) + (size_t)ci * 4u;
+    const uint32_t seg = cd[0], ord = cd[1] & 0xffffu, round = cd[1] >> 16, hit = cd[3];
+    const uint32_t JDA_GLOBAL *sum = JDA_G(const uint32_t, P.seg_sum);
+    const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start);
+    if (seg >= P.n_segs || sum[(size_t)seg * JDA_SEG_SUM_WORDS + 7u] != round) return 0;      // the segment was walked again: not its last walk's candidate
+    const uint32_t g0 = st[(size_t)seg * 5u], j = st[(size_t)seg * 5u + 4u];
+    if (g0 >= 0xfffffff0u || !((hit >> (4u + 5u * j)) & 1u)) return 0;
+    uint32_t t = seg, i = ord - 1u, lagw = cd[2], jt = j, g = g0 + i;
+    if (ord == 0u) {                                                // the block was open at the segment's entry: it started in ..
+        if (seg == 0u) return 0;
+        do { t--; } while (t > 0u && sum[(size_t)t * JDA_SEG_SUM_WORDS] == 0u);              // .. the last segment before that starts a block
+        const uint32_t nb = sum[(size_t)t * JDA_SEG_SUM_WORDS];
+        if (nb == 0u) return 0;
+        i = nb - 1u; lagw = sum[(size_t)t * JDA_SEG_SUM_WORDS + 6u]; jt = st[(size_t)t * 5u + 4u]; g = g0 - 1u;
+    }
+    if (g >= P.n_blocks_total || i >= P.rec_cap) return 0;
+    const uint32_t rec = JDA_G(const uint32_t, P.records)[(size_t)t * P.rec_cap + i];
+    const uint32_t p_abs = t * JDA_SEG_BITS + (rec & (JDA_SEG_BITS - 1u));
+    const uint32_t u0 = (lagw >> (5u * jt)) & 15u;                  // the window's byte lag at the block's opening refill
+    JDA_G(uint32_t, P.blk_index)[g] = (((p_abs >> 3) - u0) << JDA_INDEX_OFF_BITS) | JDA_INDEX_TRUNC | (8u * u0 + (p_abs & 7u));
+    return 1;
+}
 // ================================================================================================
 // Tile phases.  Every lane of the tile's wavefront runs each phase; a wave-local fence separates
 // consecutive phases (the host emulator runs all 64 lanes of a phase, then the next).
@@ -1589,6 +1712,7 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     br.win_lo = C.win_lo;
     br.win_len = C.win_len < win_cap ? C.win_len : win_cap;
     const uint32_t ix = in.ix;
+    const bool trunc = (ix & JDA_INDEX_TRUNC) != 0u;             // the entry holds the reference reader's true phase (else maybe a canonical one)
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & (JDA_INDEX_TRUNC - 1u);
     const uint8_t *wbase = br.win - br.win_lo;
@@ -1601,14 +1725,14 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     // wave-uniform: the whole slice is in LDS (and the tables allow the window-only reader's EOB test)
     const bool win_only = C.win_need <= br.win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
-        if (win_only) jda_decode_block_win<1, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al); }
+        if (win_only) jda_decode_block_win<1, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al, trunc); }
         *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
         return JDA_NO_LIST;
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
         uint32_t flags;
-        if (win_only) flags = jda_decode_block_win<5, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
-        else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred, dc_only, al); }
+        if (win_only) flags = jda_decode_block_win<5, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc);
+        else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred, dc_only, al, trunc); }
         const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
                                        : jda_idct_2x2(coef, quant);
         *(jda_u32_alias *)plane = px;
@@ -1618,10 +1742,10 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     if (win_only) {
         // the reference's ulBitOff is followed only in a tile that holds a block with a truncated magnitude read (the
         // pre-scan flags those: a fraction of a percent of the blocks of a photograph, none of most synthetic images)
-        if (jda_wave_any((ix & JDA_INDEX_TRUNC) != 0u)) flags = jda_decode_block_win<64, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+        if (jda_wave_any(trunc)) flags = jda_decode_block_win<64, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc);
         else flags = jda_decode_block_win<64, false, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
     }
-    else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred, dc_only, al); }
+    else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred, dc_only, al, trunc); }
     JDA_P1_TRACE(9);
     return flags;
 }

@@ -117,6 +117,16 @@ struct jda_filter_params {
 #define JDA_FILTER_WORK_BYTES(raw_len) (((size_t)(raw_len) / 16384u + 1u) * 20u)
 
 
+// Slots a 256-byte segment's block records need (RECORD mode of the device pre-scan, jda_device_core.h): more than its 2,048 bits
+// can start blocks.  mcu_min_bits: the fewest bits an MCU of the image can take -- per block the shortest DC code + the shorter of
+// the EOB code and four of the shortest AC codes (63 coefficients take at least four symbols) -- from the DHT segments
+// (jda_frontend.cpp).  A multiple of four (records are stored in 16-byte groups).
+static inline uint32_t jda_record_cap(uint32_t mcu_min_bits, uint32_t nblocks)
+{
+    if (mcu_min_bits < 2u * nblocks) mcu_min_bits = 2u * nblocks;
+    return ((2048u / mcu_min_bits + 2u) * nblocks + 4u + 3u) & ~3u;
+}
+
 // What the host makes of one file when the GPU does everything else (jda_pipeline): see jda_front_prepare in jda_frontend.cpp
 struct jda_front {
     jda_image_info info;
@@ -127,6 +137,7 @@ struct jda_front {
     uint8_t fast_provable;       // the 24-bit-multiply bound holds for every legal stream with these quantisers
     uint32_t raw_off, raw_len;   // the entropy-coded segment inside the file (unfiltered)
     uint32_t n_intervals;        // restart intervals (0: no DRI)
+    uint32_t rec_cap;            // jda_record_cap of the image's tables
 };
 
 #endif

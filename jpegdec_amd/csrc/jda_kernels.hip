@@ -444,7 +444,7 @@ void jda_segscan_write(const jda_segscan_params *__restrict__ params)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
     const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
-    if (blockIdx.x * 256u >= P.n_segs) return;                       // (uniform per workgroup: images of a batch differ in size)
+    if (blockIdx.x * 256u >= P.n_segs || P.records) return;          // (uniform per workgroup: images of a batch differ in size; RECORD mode has no WRITE walk)
     uint8_t *tab = lds;
     jda_walk_tables_stage(P.walk_tables, threadIdx.x, 256u, tab);      // the walk's four tables are all that is staged
     const bool in_range = seg < P.n_segs;
@@ -502,10 +502,14 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
     ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
     const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];       // the scan starts at a block start (jpeg.inl:4996-4998)
     const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
-    const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST) : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST);
+    // (streams with restart intervals keep round 2's passes -- counting walk, then WRITE walk -- for now: P.records is NULL for them)
+    const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST)
+                     : ((OP == JDA_SEG_FUSED && P.records) ? jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, segw, tab, S, ST, round)
+                                                           : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST));
     if (OP == JDA_SEG_FUSED) {
-        uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, P.seg_sum) + (size_t)seg * 6;
-        o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
+        uint32_t *o = P.seg_sum + (size_t)seg * JDA_SEG_SUM_WORDS;
+        jda_store_u32x4(o, S.nblk, (uint32_t)S.dcsum[0], (uint32_t)S.dcsum[1], (uint32_t)S.dcsum[2]);
+        jda_store_u32x4(o + 4, S.phase_map, S.bad | (S.max_ac << 4), S.lag_last, round);
     }
     if (round == 0) { if (seg + 1u < P.n_segs) E[seg + 1u] = x; }       // (nobody reads the entry states in round 0)
     else {
@@ -654,18 +658,20 @@ __device__ __forceinline__ jda_sum_el jda_sum_wave_scan(jda_sum_el v, uint32_t l
 }
 // a chunk = the 64 segments of one wavefront step: every lane's element (what is behind the chunk's first bad segment is dead:
 // identity) and the chunk-local verdict
-__device__ __forceinline__ jda_sum_el jda_sum_load_chunk(const jda_segscan_params &P, uint32_t chunk, uint32_t lane, uint32_t &first_bad)
+__device__ __forceinline__ jda_sum_el jda_sum_load_chunk(const jda_segscan_params &P, uint32_t chunk, uint32_t lane, uint32_t &first_bad, uint32_t &max_ac)
 {
     const uint32_t seg = chunk * 64u + lane;
     jda_sum_el e = jda_sum_identity();
     uint32_t bad = 0;
+    max_ac = 0;
     if (seg < P.n_segs) {
-        const uint32_t JDA_GLOBAL *su = JDA_G(const uint32_t, P.seg_sum) + (size_t)seg * 6;
+        const uint32_t JDA_GLOBAL *su = JDA_G(const uint32_t, P.seg_sum) + (size_t)seg * JDA_SEG_SUM_WORDS;
         e.nblk = su[0]; e.d0 = su[1]; e.d1 = su[2]; e.d2 = su[3]; e.map = su[4]; bad = su[5] & 1u; e.flag = (su[5] & JDA_SEG_HAS_RESTART) ? 1u : 0u;
+        max_ac = (su[5] >> 4) & 15u;
     }
     const uint64_t badmask = __builtin_amdgcn_ballot_w64(bad != 0);
     first_bad = badmask ? (uint32_t)__builtin_ctzll(badmask) : 64u;
-    if (lane > first_bad) e = jda_sum_identity();                   // (the bad segment's own block count still counts; nothing behind it does)
+    if (lane > first_bad) { e = jda_sum_identity(); max_ac = 0; }   // (the bad segment's own block count still counts; nothing behind it does)
     return e;
 }
 
@@ -688,8 +694,8 @@ void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
     const uint32_t n_chunks = (P.n_segs + 63u) / 64u;
     if (n_chunks > JDA_SUMS_MAX_CHUNKS) { if (threadIdx.x == 0) P.stats[6] = 0; return; }    // (the front end admits no scan that long)
     for (uint32_t c = wave; c < n_chunks; c += JDA_SUMS_WAVES) {    // ---- chunk aggregates
-        uint32_t first_bad;
-        const jda_sum_el incl = jda_sum_wave_scan(jda_sum_load_chunk(P, c, lane, first_bad), lane);
+        uint32_t first_bad, mac;
+        const jda_sum_el incl = jda_sum_wave_scan(jda_sum_load_chunk(P, c, lane, first_bad, mac), lane);
         if (lane == 63u) { agg[c] = incl; agg[c].flag = (incl.flag & 1u) | (first_bad < 64u ? 2u : 0u); }
     }
     __syncthreads();
@@ -720,11 +726,16 @@ void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
     __syncthreads();
     uint32_t *seg_start = const_cast<uint32_t *>(P.seg_start);
     for (uint32_t c = wave; c < n_chunks; c += JDA_SUMS_WAVES) {    // ---- every segment's entry values
-        uint32_t first_bad;
-        const jda_sum_el incl = jda_sum_wave_scan(jda_sum_load_chunk(P, c, lane, first_bad), lane);
+        uint32_t first_bad, mac;
+        const jda_sum_el incl = jda_sum_wave_scan(jda_sum_load_chunk(P, c, lane, first_bad, mac), lane);
         jda_sum_el excl = jda_sum_shfl_up(incl, 1);
         if (lane == 0) excl = jda_sum_identity();
         const jda_sum_el in = agg[c];
+        if (P.records) {                                            // RECORD mode: the largest AC category of the settled walks (WRITE's result word)
+            if (in.flag & 4u) mac = 0;
+            mac = jda_wave_max_u32(mac);
+            if (lane == 0 && mac) atomicMax(&P.stats[2], mac);
+        }
         const jda_sum_el pre = jda_sum_combine(in, excl);
         const uint32_t seg = c * 64u + lane;
         if (seg < P.n_segs) {
@@ -762,6 +773,70 @@ extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params,
     }
     hipLaunchKernelGGL(jda_segscan_write, dim3((max_segs + 255u) / 256u, n_images), dim3(256), lds_bytes, stream, params);
     return hipGetLastError();
+}
+
+// RECORD mode, after the sums: the records of every segment -> index entries (canonical) and DC predictors, block-parallel -- a
+// wavefront per segment, sixteen segments one after the other, lane = record: coalesced reads and writes, no walk.  Result words as
+// WRITE left them: [0] bad (a predictor out of range, a stream read on into its padding), [1] closing entry written, [3] max |DC|.
+#define JDA_FIN_SEGS_PER_WAVE 16u
+__global__ __launch_bounds__(256)
+void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
+{
+    const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
+    if (!P.records || blockIdx.x * (4u * JDA_FIN_SEGS_PER_WAVE) >= P.n_segs) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t seg0 = (blockIdx.x * 4u + wave) * JDA_FIN_SEGS_PER_WAVE;
+    jda_fin_acc A;
+    A.bad = 0; A.terminal = 0; A.max_abs_dc = 0;
+    for (uint32_t seg = seg0; seg < seg0 + JDA_FIN_SEGS_PER_WAVE && seg < P.n_segs; seg++) {
+        const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)seg * 5;
+        const uint32_t g0 = jda_uni32(st[0]);
+        if (g0 > P.n_blocks_total) break;                            // behind the image, or behind a bad code (0xfffffff0)
+        uint32_t nblk = jda_uni32(JDA_G(const uint32_t, P.seg_sum)[(size_t)seg * JDA_SEG_SUM_WORDS]);
+        if (nblk > P.rec_cap) { nblk = P.rec_cap; A.bad = 1; }
+        const int32_t pr0 = (int32_t)jda_uni32(st[1]), pr1 = (int32_t)jda_uni32(st[2]), pr2 = (int32_t)jda_uni32(st[3]);
+        for (uint32_t i = lane; i < nblk; i += 64u) jda_finalize_item(P, seg, i, g0, pr0, pr1, pr2, A);
+    }
+    const uint32_t m_dc = jda_wave_max_u32(A.max_abs_dc), n_term = jda_wave_sum_u32(A.terminal);
+    const bool any_bad = __builtin_amdgcn_ballot_w64(A.bad != 0) != 0;
+    if (lane == 0) {
+        if (any_bad) atomicOr(&P.stats[0], 1u);
+        if (n_term) atomicAdd(&P.stats[1], n_term);
+        if (m_dc) atomicMax(&P.stats[3], m_dc);
+    }
+}
+// .. and the candidates: the truncated reads of the true lag flag their blocks (behind jda_segscan_finalize: it overwrites entries)
+__global__ __launch_bounds__(256)
+void jda_segscan_resolve_cands(const jda_segscan_params *__restrict__ params)
+{
+    const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
+    if (!P.records) return;
+    const uint32_t n = P.stats[JDA_ST_NCAND];
+    if (blockIdx.x * 256u >= n) return;
+    if (n > P.cand_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&P.stats[0], 1u); return; }     // more than the list holds: the serial pre-scan
+    uint32_t hits = 0;
+    for (uint32_t ci = blockIdx.x * 256u + threadIdx.x; ci < n; ci += gridDim.x * 256u) hits += jda_resolve_item(P, ci);
+    hits = jda_wave_sum_u32(hits);
+    if ((threadIdx.x & 63u) == 0u && hits) atomicAdd(&P.stats[4], hits);
+}
+
+// every pass of the device pre-scan behind the filter, on one stream: round 0 and the counting round over every segment, the
+// work-list rounds, the sums, then WRITE (streams with restart intervals) / finalize + candidates (RECORD mode)
+extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
+                                                int any_write, int any_record, hipStream_t stream)
+{
+    if (n_images == 0 || max_segs == 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    for (uint32_t r = 0; r < list_rounds && e == hipSuccess; r++) e = jda_launch_segscan_fused(params, n_images, max_segs, r, stream);
+    if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, list_rounds, max_round, stream);
+    if (e == hipSuccess) e = jda_launch_segscan_sums(params, n_images, stream);
+    if (e == hipSuccess && any_write) e = jda_launch_segscan_write(params, n_images, max_segs, stream);
+    if (e == hipSuccess && any_record) {
+        hipLaunchKernelGGL(jda_segscan_finalize, dim3((max_segs + 4u * JDA_FIN_SEGS_PER_WAVE - 1u) / (4u * JDA_FIN_SEGS_PER_WAVE), n_images), dim3(256), 0, stream, params);
+        hipLaunchKernelGGL(jda_segscan_resolve_cands, dim3(16, n_images), dim3(256), 0, stream, params);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -118,6 +118,9 @@ struct Img {
     uint32_t n_segs_ub, n_blocks;
     size_t off_raw, off_scan, scan_bytes, off_index, off_dc, off_work, off_zero, off_stats;   // arena offsets
     size_t work_bytes, zero_bytes, off_rpos, off_fwork, off_wt;     // off_rpos / off_fwork: restart positions / the filter's work words inside the work region
+    bool record;                 // the pre-scan runs in RECORD mode (no WRITE walk)
+    size_t off_recs, off_cands;  // block records / truncation candidates inside the work region
+    uint32_t cand_cap;
     size_t ctl_tables;           // offset of its tables inside the control blob
     uint32_t list, n_tiles;      // launch list it is in, tiles (padded)
     size_t strip_off;            // its first strip inside the list
@@ -286,6 +289,8 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     uint32_t list_tiles[JDA_N_LISTS], list_ord[JDA_N_LISTS];
     memset(list_tiles, 0, sizeof(list_tiles)); memset(list_ord, 0, sizeof(list_ord));
     size_t arena = 0;
+    int n_rec = 0;
+    static const bool no_record = getenv("JDA_PIPE_NO_RECORD") != NULL;      // (measuring: round 2's counting walk + WRITE walk for every stream)
     auto take = [&](size_t bytes) { const size_t o = arena; arena += a256(bytes); return o; };
     // regions: [control blob][raw][dc][work][ ZERO: scan | index | zero ][stats]; laid out by region so that one memset and
     // one read-back cover all images
@@ -328,10 +333,20 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         if (!im.device) continue;
         // seg_sum | seg_start | two work lists | where the restart intervals start (+ the sentinel)
         im.n_segs_ub = im.f.raw_len / JDA_SEG_BYTES + 1u;
-        im.off_rpos = a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);
+        im.off_rpos = a16((size_t)im.n_segs_ub * 4 * JDA_SEG_SUM_WORDS) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);
         im.off_fwork = im.off_rpos + (im.f.n_intervals ? a16(((size_t)im.f.n_intervals + 1) * 4) : 0);          // .. | the filter's chunk functions
         im.off_wt = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len));                                       // .. | the walk's tables
         im.work_bytes = im.off_wt + JDA_WT_BYTES;
+        // .. | RECORD mode (streams without restart intervals): the segments' block records, the truncation candidates
+        im.record = im.f.n_intervals == 0 && im.f.rec_cap != 0 && !no_record;
+        im.off_recs = im.off_cands = 0; im.cand_cap = 0;
+        if (im.record) {
+            im.off_recs = a256(im.work_bytes);
+            im.off_cands = im.off_recs + a16((size_t)im.n_segs_ub * im.f.rec_cap * 4);
+            im.cand_cap = std::max<uint32_t>(1024u, im.n_segs_ub * 2u);
+            im.work_bytes = im.off_cands + (size_t)im.cand_cap * 16;
+            n_rec++;
+        }
         im.off_work = take(im.work_bytes);
     }
     const size_t zero_begin = arena;
@@ -406,8 +421,12 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         memset(&P, 0, sizeof(P));
         P.scan = B + im.off_scan; P.tables = B + im.ctl_tables;
         P.entry_cur = (uint32_t *)(B + im.off_zero); P.entry_nxt = P.entry_cur;
-        P.worklist = (uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24) + a16((size_t)im.n_segs_ub * 20)); P.worklist_cap = im.n_segs_ub;
-        P.seg_sum = (uint32_t *)(B + im.off_work); P.seg_start = (const uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 24));
+        P.worklist = (uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 4 * JDA_SEG_SUM_WORDS) + a16((size_t)im.n_segs_ub * 20)); P.worklist_cap = im.n_segs_ub;
+        P.seg_sum = (uint32_t *)(B + im.off_work); P.seg_start = (const uint32_t *)(B + im.off_work + a16((size_t)im.n_segs_ub * 4 * JDA_SEG_SUM_WORDS));
+        if (im.record) {
+            P.records = (uint32_t *)(B + im.off_work + im.off_recs); P.rec_cap = im.f.rec_cap;
+            P.cands = (uint32_t *)(B + im.off_work + im.off_cands); P.cand_cap = im.cand_cap;
+        }
         P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
         P.stats = pstats;
         P.walk_tables = B + im.off_work + im.off_wt;
@@ -451,11 +470,9 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         if (e == hipSuccess) {
             const jda_segscan_params *dp = (const jda_segscan_params *)(B + off_sparams);
             const uint32_t ns = (uint32_t)dev_ix.size();
-            // speculative rounds with the count pass folded in (work lists: a round after the first walks what the one before changed)
-            for (uint32_t r = 0; r < JDA_PIPE_SPEC_ROUNDS && e == hipSuccess; r++) e = jda_launch_segscan_fused(dp, ns, max_segs, r, s_up);
-            if (e == hipSuccess) e = jda_launch_segscan_tail(dp, ns, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, s_up);
-            if (e == hipSuccess) e = jda_launch_segscan_sums(dp, ns, s_up);
-            if (e == hipSuccess) e = jda_launch_segscan_write(dp, ns, max_segs, s_up);
+            // round 0, the counting round (RECORD mode: + a record per block), the work-list rounds, sums, then WRITE (restart
+            // streams) / finalize + candidates (jda_kernels.hip)
+            e = jda_launch_prescan_passes(dp, ns, max_segs, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, n_rec < (int)ns, n_rec > 0, s_up);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.pin_stats, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, s_up);
     }

@@ -24,6 +24,7 @@ extern "C" uint32_t jda_image_general_p1(const jda_image *img);
 extern "C" const uint32_t *jda_image_restart_positions(const jda_image *img, uint32_t *n);
 extern "C" void jda_image_run_host_prescan(jda_image *img);
 extern "C" int jda_image_index_on_device(const jda_image *img);
+extern "C" uint32_t jda_image_record_cap(const jda_image *img);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
 // The plain-case kernel variants (jda_desc_uniform in jda_kernels.hip): full size, every multiply in 24 bits, no stream flags,
 // and one of the (layout, output format) pairs a kernel was built for.  0 = the general kernel.
@@ -214,6 +215,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         size_t alloc, n_blocks; uint32_t tbytes;
         // the index is made on the device (8f N1 / N2): segments of the scan, see jda_seg_walk
         bool seg_mode; uint32_t n_segs; size_t off_ea, off_sum, off_start, off_wl, off_rp, off_wt, off_sstats;
+        bool record; uint32_t rec_cap, cand_cap; size_t off_recs, off_cands, zero_end;      // RECORD mode of the pre-scan (no restart intervals)
         std::vector<uint32_t> rp;            // restart positions + the sentinel, until their copy has been made
         uint32_t sst[68];
     };
@@ -307,12 +309,21 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.n_segs = scan_len / JDA_SEG_BYTES + 1u;
             d->bytes = d->off_scan + align16(std::max((size_t)scan_len + JDA_SCAN_PAD, (size_t)it.n_segs * JDA_SEG_BYTES + 16));
             it.off_ea = d->bytes;
-            it.off_sum = it.off_ea + align16(((size_t)it.n_segs + 1) * 4); it.off_start = it.off_sum + align16((size_t)it.n_segs * 24);
+            it.off_sum = it.off_ea + align16(((size_t)it.n_segs + 1) * 4); it.off_start = it.off_sum + align16((size_t)it.n_segs * 4 * JDA_SEG_SUM_WORDS);
             it.off_wl = it.off_start + align16((size_t)it.n_segs * 20);
             it.off_rp = it.off_wl + align16((size_t)it.n_segs * 8);
             it.off_wt = it.off_rp + (I.restart_interval ? align16(((size_t)it.n_int + 1) * 4) : 0);
             it.off_sstats = it.off_wt + JDA_WT_BYTES;
             it.alloc = it.off_sstats + 512;
+            it.zero_end = it.alloc;                          // (what is memset: everything up to here; records and candidates need none)
+            it.rec_cap = jda_image_record_cap(img);
+            it.record = !I.restart_interval && it.rec_cap != 0 && getenv("JDA_PIPE_NO_RECORD") == NULL;
+            if (it.record) {
+                it.off_recs = (it.alloc + 255) & ~(size_t)255;
+                it.off_cands = it.off_recs + align16((size_t)it.n_segs * it.rec_cap * 4);
+                it.cand_cap = std::max<uint32_t>(1024u, it.n_segs * 2u);
+                it.alloc = it.off_cands + (size_t)it.cand_cap * 16;
+            }
         }
         e = jda_pool_alloc(ctx, (void **)&d->base, it.alloc);
         if (e != hipSuccess) { jda_set_err(ctx, e, "hipMalloc(image)"); rc = JDA_ERROR_MEMORY; break; }
@@ -330,7 +341,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
                 e = hipMemcpyAsync(d->base + d->off_tables, it.stage, it.tbytes, hipMemcpyHostToDevice, ctx->stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(d->base + d->off_scan, it.stage + align16(it.tbytes), scan_len, hipMemcpyHostToDevice, ctx->stream);
             }
-            if (e == hipSuccess) e = hipMemsetAsync(d->base + d->off_scan + scan_len, 0, it.alloc - (d->off_scan + scan_len), ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d->base + d->off_scan + scan_len, 0, it.zero_end - (d->off_scan + scan_len), ctx->stream);
             if (e != hipSuccess) { rc = jda_set_err(ctx, e, "hipMemcpy(image)"); break; }
             jda_segscan_params SP;
             memset(&SP, 0, sizeof(SP));
@@ -349,6 +360,10 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             SP.blk_index = (uint32_t *)(d->base + d->off_index); SP.blk_dc = (int16_t *)(d->base + d->off_dc);
             SP.stats = (uint32_t *)(d->base + it.off_sstats);
             SP.walk_tables = d->base + it.off_wt;
+            if (it.record) {
+                SP.records = (uint32_t *)(d->base + it.off_recs); SP.rec_cap = it.rec_cap;
+                SP.cands = (uint32_t *)(d->base + it.off_cands); SP.cand_cap = it.cand_cap;
+            }
             SP.scan_len = scan_len; SP.n_segs = it.n_segs; SP.n_blocks_total = (uint32_t)it.n_blocks;
             SP.nblocks = (uint8_t)I.blocks_per_mcu; SP.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));
             for (int c = 0; c < 3; c++) { SP.dc_id[c] = d->dc_id[c]; SP.ac_id[c] = d->ac_id[c]; }
@@ -396,18 +411,17 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         e = jda_pool_alloc(ctx, (void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg_params.data(), seg_params.size() * sizeof(jda_segscan_params), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = jda_launch_walk_tables(d_seg, ns, ctx->stream);
-        for (uint32_t r = 0; r < 4 && e == hipSuccess; r++) e = jda_launch_segscan_fused(d_seg, ns, max_segs, r, ctx->stream);
-        if (e == hipSuccess) e = jda_launch_segscan_tail(d_seg, ns, 4, 56, ctx->stream);
-        JDA_UP_MARK("speculative + counting rounds");
-        if (e == hipSuccess) e = jda_launch_segscan_sums(d_seg, ns, ctx->stream);      // first block ordinal, DC predictors, window lag per segment
-        JDA_UP_MARK("sums");
         // the write pass ORs its index entries into place (a block's truncation flag may come from the lane of a later segment
-        // than the one that holds the block's first bit): the index starts as zeros
+        // than the one that holds the block's first bit): the index starts as zeros.  (RECORD mode stores whole entries.)
+        int n_rec = 0;
         for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
             Item &it = items[seg_owner[p]];
+            if (it.record) { n_rec++; continue; }
             e = hipMemsetAsync(it.d->base + it.d->off_index, 0, 4 * (it.n_blocks + 1), ctx->stream);
         }
-        if (e == hipSuccess) e = jda_launch_segscan_write(d_seg, ns, max_segs, ctx->stream);
+        // round 0, the counting round, two work-list rounds, every further round in one launch, the sums (first block ordinal, DC
+        // predictors, window lag per segment), then WRITE (restart streams) / finalize + candidates (RECORD mode)
+        if (e == hipSuccess) e = jda_launch_prescan_passes(d_seg, ns, max_segs, 4, 56, n_rec < (int)ns, n_rec > 0, ctx->stream);
         for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
             Item &it = items[seg_owner[p]];
             e = hipMemcpyAsync(it.sst, it.d->base + it.off_sstats, sizeof(it.sst), hipMemcpyDeviceToHost, ctx->stream);

@@ -63,6 +63,11 @@ extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, ui
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
 static int g_device_prescan = 0;     // != 0: make the block index with the device's segment walk (jda_seg_walk), as jda_upload_batch / jda_pipeline do
 static int g_prescan_used = 0;
+static int g_no_record = 0;              // 1: the counting walk + WRITE walk also for streams without restart intervals (round 2's passes)
+static uint32_t g_prescan_cands = 0;     // truncation candidates the last RECORD-mode pre-scan appended
+extern "C" void hostsim_set_no_record(int on) { g_no_record = on; }
+extern "C" uint32_t hostsim_prescan_candidates(void) { return g_prescan_cands; }
+extern "C" uint32_t jda_image_record_cap(const jda_image *img);
 static uint32_t g_prescan_trunc = 0;
 extern "C" void hostsim_set_device_prescan(int on) { g_device_prescan = on; }
 extern "C" int hostsim_prescan_used(void) { return g_prescan_used; }
@@ -97,7 +102,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         uint8_t *lt = (uint8_t *)lt_store.data();
         for (uint32_t tid = 0; tid < 256; tid++) jda_walk_tables_from(tables, tid, 256, lt);
 
-        std::vector<uint32_t> ea(n_segs + 1, 0), eb(n_segs + 1, 0), seg_sum((size_t)n_segs * 6), seg_start((size_t)n_segs * 5, 0);
+        std::vector<uint32_t> ea(n_segs + 1, 0), eb(n_segs + 1, 0), seg_sum((size_t)n_segs * JDA_SEG_SUM_WORDS), seg_start((size_t)n_segs * 5, 0);
         jda_segscan_params P;
         memset(&P, 0, sizeof(P));
         P.scan = (const uint8_t *)padded.data(); P.tables = tables;
@@ -116,13 +121,48 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             P.round_last = ((uint32_t)(I->mcus_x * I->mcus_y) % (uint32_t)I->restart_interval) == 0 ? 1u : 0u;
         }
         const bool rst = P.restart_pos != nullptr;
+        // RECORD mode (streams without restart intervals), as jda_pipeline / jda_upload_batch run it
+        const bool record = !rst && !g_no_record && jda_image_record_cap(img) != 0;
+        std::vector<uint32_t> records, cands, stats(80, 0);
+        if (record) {
+            P.rec_cap = jda_image_record_cap(img); P.cand_cap = std::max<uint32_t>(1024u, n_segs * 2u);
+            records.assign((size_t)n_segs * P.rec_cap, 0xdeadbeefu); cands.assign((size_t)P.cand_cap * 4, 0);
+            P.records = records.data(); P.cands = cands.data(); P.stats = stats.data();
+        }
         jda_seg_sum S;
         jda_seg_stats ST;
         memset(&ST, 0, sizeof(ST));
         uint32_t rounds = 0;
         bool settled = false;
         uint32_t *cur = ea.data(), *nxt = eb.data();
-        while (rounds < 48 && !settled) {                       // SPEC rounds, exactly as the kernel's lanes do them
+        if (record) {
+            // round 0: every segment from the guess; round 1: every segment from what round 0 handed it, recording; from then on the
+            // segments whose entry state changed (their records, sums and stamps are overwritten; candidates of earlier walks go stale)
+            std::vector<uint32_t> E(n_segs + 1, 0), list, next;
+            for (uint32_t seg = 0; seg < n_segs; seg++) {
+                const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
+                E[seg + 1] = jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, 0u, slot, lt, S, ST);
+            }
+            for (uint32_t seg = 0; seg < n_segs; seg++) list.push_back(seg);
+            rounds = 1;
+            while (!list.empty() && rounds < 57) {
+                const std::vector<uint32_t> snap(E);            // (a round's lanes read what the round before left)
+                next.clear();
+                for (uint32_t seg : list) {
+                    const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
+                    const uint32_t x = jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, seg == 0 ? 0u : snap[seg], slot, lt, S, ST, rounds);
+                    uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
+                    o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map;
+                    o[5] = S.bad | (S.max_ac << 4); o[6] = S.lag_last; o[7] = rounds;
+                    if (seg + 1 < n_segs && x != E[seg + 1]) { E[seg + 1] = x; next.push_back(seg + 1); }
+                }
+                list.swap(next);
+                rounds++;
+            }
+            settled = list.empty();
+            for (uint32_t i = 0; i <= n_segs; i++) ea[i] = E[i];
+        }
+        while (!record && rounds < 48 && !settled) {            // SPEC rounds, exactly as the kernel's lanes do them
             uint32_t changed = 0;
             for (uint32_t seg = 0; seg < n_segs; seg++) {
                 const uint32_t entry = cur[seg];
@@ -160,10 +200,10 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             }
         }
         memset(&ST, 0, sizeof(ST));
-        for (uint32_t seg = 0; seg < n_segs; seg++) {           // COUNT
+        for (uint32_t seg = 0; seg < n_segs && !record; seg++) { // COUNT
             const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
             if (rst) (void)jda_seg_walk<JDA_SEG_COUNT, true>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST); else (void)jda_seg_walk<JDA_SEG_COUNT, false>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST);
-            uint32_t *o = &seg_sum[(size_t)seg * 6];
+            uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
             o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
         }
         bool ok = settled;
@@ -173,7 +213,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             uint32_t j = 0;
             for (uint32_t i = 0; i < n_segs; i++) {
                 uint32_t *st = &seg_start[(size_t)i * 5];
-                const uint32_t *su = &seg_sum[(size_t)i * 6];
+                const uint32_t *su = &seg_sum[(size_t)i * JDA_SEG_SUM_WORDS];
                 st[0] = g > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)g; st[1] = (uint32_t)pred[0]; st[2] = (uint32_t)pred[1]; st[3] = (uint32_t)pred[2]; st[4] = j;
                 g += su[0];
                 if (su[5] & 1u) {
@@ -191,7 +231,24 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         uint32_t terminal = 0;
         std::vector<unsigned> steps_of(n_segs, 0);
         std::vector<std::vector<unsigned> > syms_of(n_segs);
-        for (uint32_t seg = 0; seg < n_segs; seg++) {           // WRITE
+        if (record) {                                           // finalize + candidates (jda_segscan_finalize, jda_segscan_resolve_cands)
+            jda_fin_acc A;
+            A.bad = 0; A.terminal = 0; A.max_abs_dc = 0;
+            for (uint32_t seg = 0; seg < n_segs; seg++) {
+                const uint32_t *st = &seg_start[(size_t)seg * 5];
+                if (st[0] > P.n_blocks_total) break;
+                uint32_t nblk = seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
+                if (nblk > P.rec_cap) { nblk = P.rec_cap; A.bad = 1; }
+                for (uint32_t i = 0; i < nblk; i++) jda_finalize_item(P, seg, i, st[0], (int32_t)st[1], (int32_t)st[2], (int32_t)st[3], A);
+                const uint32_t mac = (seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS + 5] >> 4) & 15u;
+                if (mac > ST.max_ac_bits) ST.max_ac_bits = mac;
+            }
+            g_prescan_cands = stats[JDA_ST_NCAND];
+            if (stats[JDA_ST_NCAND] > P.cand_cap) A.bad = 1;
+            else for (uint32_t ci = 0; ci < stats[JDA_ST_NCAND]; ci++) ST.trunc_events += jda_resolve_item(P, ci);
+            ST.bad |= A.bad; terminal = A.terminal; ST.max_abs_dc = A.max_abs_dc;
+        }
+        for (uint32_t seg = 0; seg < n_segs && !record; seg++) { // WRITE
             g_seg_steps = 0; g_blk_at.clear();
             if (seg_start[(size_t)seg * 5] > P.n_blocks_total) continue;
             const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
@@ -231,7 +288,15 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             jda_image *ref = jda_prepare(jpeg, len, &e2);
             uint32_t nn = 0;
             const uint32_t *hi = ref ? jda_image_block_index(ref, &nn) : NULL;
-            g_index_equal = ref && memcmp(hi, dev_index.data(), (nb + 1) * 4) == 0 && memcmp(jda_image_block_dc(ref), dev_dc.data(), nb * 2) == 0 &&
+            // (the serial pre-scan writes the reference reader's phase into every entry, RECORD mode a canonical one into the entries of
+            // blocks without a truncated read: equal = the same bit position and flag everywhere, the same entry where flagged)
+            bool same_index = ref != NULL;
+            for (size_t i = 0; i <= nb && same_index; i++) {
+                const uint32_t a = hi[i], b = dev_index[i];
+                const uint32_t pa = (a >> JDA_INDEX_OFF_BITS) * 8u + (a & (JDA_INDEX_TRUNC - 1u)), pb = (b >> JDA_INDEX_OFF_BITS) * 8u + (b & (JDA_INDEX_TRUNC - 1u));
+                same_index = pa == pb && (a & JDA_INDEX_TRUNC) == (b & JDA_INDEX_TRUNC) && (!(a & JDA_INDEX_TRUNC) || a == b) && (record || a == b);
+            }
+            g_index_equal = same_index && memcmp(jda_image_block_dc(ref), dev_dc.data(), nb * 2) == 0 &&
                             jda_image_truncation_events(ref) == ST.trunc_events && jda_image_fast_mul(ref) == jda_image_fast_mul(img) ? 1 : 0;
             if (ref && getenv("HOSTSIM_DEBUG")) {
                 for (size_t i = 0; i <= nb; i++) if (hi[i] != dev_index[i] || (i < nb && jda_image_block_dc(ref)[i] != dev_dc[i])) { fprintf(stderr, "first diff at block %zu of %zu: host %u/%u dc %d, dev %u/%u dc %d\n", i, nb, hi[i] >> 7, hi[i] & 127, i < nb ? jda_image_block_dc(ref)[i] : 0, dev_index[i] >> 7, dev_index[i] & 127, i < nb ? dev_dc[i] : 0); break; }

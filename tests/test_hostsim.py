@@ -231,3 +231,56 @@ def test_restart_markers_that_disagree_with_the_mcu_count(name, f, hostsim, orac
             assert hrc == 0 and np.array_equal(got, want)
     finally:
         hostsim.hostsim_set_device_prescan(0)
+
+
+@pytest.mark.parametrize("window", [1 << 20, 64])
+def test_record_mode_flags_the_truncated_reads_of_real_photographs(window, hostsim, oracle):
+    """RECORD mode of the device pre-scan (round 3: no WRITE walk): the counting walk leaves a record per block start and a
+    candidate for every magnitude read that SOME entry lag of its segment truncates; finalize writes canonical entries, the
+    candidates of the true lag become flagged entries with the reference reader's true phase.  The reference's own photographs
+    have such reads: the index must agree with the serial pre-scan's -- bit position and flag of every block, the whole
+    entry of a flagged one, predictors, the count of truncated reads -- and the decode must be the oracle's, through the window
+    reader and (window = 64 bytes) through the general reader, which meets canonical entries there."""
+    from tests.ref_fixtures import GOOD, ref_jpeg
+    hostsim.hostsim_set_device_prescan(2)
+    hostsim.hostsim_set_window(window)
+    seen = 0
+    try:
+        for name in GOOD:
+            jpeg = ref_jpeg(name)
+            if J.parse(jpeg)["restart_interval"] != 0:
+                continue                                   # (restart streams keep the counting walk + WRITE walk for now)
+            for pt, opt in ((J.RGB8888, 0), (J.RGB565_LE, J.SCALE_QUARTER)):
+                rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+                assert rc == 1
+                got = np.full_like(want, 0x33)
+                inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+                assert hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+                assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1, name
+                assert np.array_equal(got, want), (name, pt, opt)
+            p = J.PreparedImage(jpeg)
+            if p.truncation_events() > 0:
+                assert hostsim.hostsim_prescan_candidates() >= p.truncation_events()
+                seen += 1
+            p.close()
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+        hostsim.hostsim_set_window(1 << 20)
+    assert seen >= 2                                           # (the test means something: photographs with truncated reads went through)
+
+
+def test_round_2_passes_still_make_the_same_index(hostsim, oracle):
+    """The counting walk + WRITE walk (what restart streams still take) on a stream without restart intervals: kept honest."""
+    jpeg = jpeg_for("c420_333x217")
+    hostsim.hostsim_set_device_prescan(1)
+    hostsim.hostsim_set_no_record(1)
+    try:
+        rc, want, err = oracle.decode_canvas(jpeg, 2, 0)
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, 2, 0)
+        assert hostsim.hostsim_decode(jpeg, len(jpeg), 2, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1
+        assert np.array_equal(got, want)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+        hostsim.hostsim_set_no_record(0)
