@@ -1318,14 +1318,17 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                 // SURVEY fact 6 without knowing the entry lag: the reference reads the magnitude at ulBitOff = 8 u + (p1 & 7) and loses
                 // bits when that + sz > 64 -- u >= 7 for (p1 & 7) + sz in 9..16, u >= 6 above 16 (u <= 7 here) -- so the six candidate
                 // lags are tested at once; the rare hit is kept with the lag word at the block's start (jda_segscan_resolve)
-                const uint32_t t = (p1 & 7u) + sz;
-                const uint32_t f7 = ((U | kGuard) - 7u * kOnes) & kGuard;
-                const uint32_t hit = t > 16u ? f1 : (t > 8u ? f7 : 0u);
+                // (ulBitOff <= 47 in front of the code for every candidate lag: code + magnitude must be 17 bits and more -- rare symbols)
                 const uint32_t m = acmag ? sz : 0u;
                 max_ac = m > max_ac ? m : max_ac;
-                if (__builtin_expect(acmag && hit != 0u && sbad == 0u, 0)) {
-                    const uint32_t at = jda_atomic_inc_u32(P.stats + JDA_ST_NCAND);
-                    if (at < P.cand_cap) jda_store_u32x4(P.cands + (size_t)at * 4u, seg, nblk | (round << 16), Ublk, hit);
+                if (__builtin_expect(acmag && len + sz > 16u && sbad == 0u, 0)) {
+                    const uint32_t t = (p1 & 7u) + sz;
+                    const uint32_t f7 = ((U | kGuard) - 7u * kOnes) & kGuard;
+                    const uint32_t hit = t > 16u ? f1 : (t > 8u ? f7 : 0u);
+                    if (hit != 0u) {
+                        const uint32_t at = jda_atomic_inc_u32(P.stats + JDA_ST_NCAND);
+                        if (at < P.cand_cap) jda_store_u32x4(P.cands + (size_t)at * 4u, seg, nblk | (round << 16), Ublk, hit);
+                    }
                 }
             }
             U &= dcmag ? ~(f1 - (f1 >> 4)) : 0xffffffffu;           // the refill before an unfolded DC magnitude
@@ -1427,6 +1430,45 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         S.phase_map = map;
     }
     return (p - JDA_SEG_BITS) | (b2 << 5) | (k << 9);
+}
+
+// ---- the marker filter's state machine on sixteen bytes at once (jda_filter_*, jda_kernels.hip) ------------------------------
+// JPEGFilter (jpeg.inl:1431-1540) is a two-state machine: an FF in state 0 waits for its partner (state 1); the partner is dropped
+// with it unless it is 00 (then FF is emitted); state 0 again.  After any byte that is not FF the state is 0, so the state in front
+// of byte i is the parity of its distance from the start of the run of FFs that ends at i - 1: runs that start at an even position
+// put state 1 in front of odd positions and vice versa, and adding the start bits of the even-started runs to the FF mask clears
+// exactly those runs (the carry runs through a run and stops behind it).  cin: the state in front of byte 0 -- then byte 0 is a
+// partner, and a run of FFs from byte 0 on counts as started at -1.
+struct jda_filter_bits { uint32_t S, E, R; };       // state in front of byte i (bits 0..16), byte i is emitted / a restart marker's second byte (bits 0..15)
+JDA_HD uint32_t jda_zero_byte_bits(uint32_t x)      // bit 7 of every byte that is zero
+{
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+}
+JDA_HD uint32_t jda_byte_flags_to_nibble(uint32_t f) { return (((f >> 7) * 0x00204081u) >> 21) & 15u; }     // bits 7, 15, 23, 31 -> 0..3
+struct jda_filter_masks { uint32_t ff, zero, rst; };  // per byte of the sixteen: is FF / is 00 / is D0..D7
+JDA_HD jda_filter_masks jda_filter_classify(const uint32_t b[4])
+{
+    jda_filter_masks M;
+    M.ff = M.zero = M.rst = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        M.ff |= jda_byte_flags_to_nibble(jda_zero_byte_bits(~b[d])) << (4 * d);
+        M.zero |= jda_byte_flags_to_nibble(jda_zero_byte_bits(b[d])) << (4 * d);
+        M.rst |= jda_byte_flags_to_nibble(jda_zero_byte_bits((b[d] & 0xf8f8f8f8u) ^ 0xd0d0d0d0u)) << (4 * d);
+    }
+    return M;
+}
+JDA_HD jda_filter_bits jda_filter_run(const jda_filter_masks &M, uint32_t valid, uint32_t cin)
+{
+    const uint32_t V = (1u << valid) - 1u;                           // valid <= 16
+    const uint32_t starts = M.ff & ~(M.ff << 1);
+    const uint32_t es = starts & 0x5555u & ~cin;                    // (cin: a run from byte 0 on is the tail of one that started at -1)
+    const uint32_t Re = M.ff & ~(M.ff + es), Ro = M.ff & ~Re;
+    jda_filter_bits F;
+    F.S = ((Re << 1) & 0x0aaaau) | ((Ro << 1) & 0x15555u) | cin;
+    F.E = V & ((~F.S & ~M.ff) | (F.S & M.zero));
+    F.R = V & F.S & M.rst;
+    return F;
 }
 
 // ---- RECORD mode: from records to the index (block-parallel) ----------------------------------------

@@ -500,8 +500,8 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
     jda_seg_sum S;
     jda_seg_stats ST;
     ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
-    const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];       // the scan starts at a block start (jpeg.inl:4996-4998)
     const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
+    const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];       // the scan starts at a block start (jpeg.inl:4996-4998)
     // (streams with restart intervals keep round 2's passes -- counting walk, then WRITE walk -- for now: P.records is NULL for them)
     const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST)
                      : ((OP == JDA_SEG_FUSED && P.records) ? jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, segw, tab, S, ST, round)
@@ -778,7 +778,9 @@ extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params,
 // RECORD mode, after the sums: the records of every segment -> index entries (canonical) and DC predictors, block-parallel -- a
 // wavefront per segment, sixteen segments one after the other, lane = record: coalesced reads and writes, no walk.  Result words as
 // WRITE left them: [0] bad (a predictor out of range, a stream read on into its padding), [1] closing entry written, [3] max |DC|.
-#define JDA_FIN_SEGS_PER_WAVE 16u
+#ifndef JDA_FIN_SEGS_PER_WAVE
+#define JDA_FIN_SEGS_PER_WAVE 4u
+#endif
 __global__ __launch_bounds__(256)
 void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
 {
@@ -788,14 +790,21 @@ void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
     const uint32_t seg0 = (blockIdx.x * 4u + wave) * JDA_FIN_SEGS_PER_WAVE;
     jda_fin_acc A;
     A.bad = 0; A.terminal = 0; A.max_abs_dc = 0;
-    for (uint32_t seg = seg0; seg < seg0 + JDA_FIN_SEGS_PER_WAVE && seg < P.n_segs; seg++) {
-        const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)seg * 5;
-        const uint32_t g0 = jda_uni32(st[0]);
-        if (g0 > P.n_blocks_total) break;                            // behind the image, or behind a bad code (0xfffffff0)
-        uint32_t nblk = jda_uni32(JDA_G(const uint32_t, P.seg_sum)[(size_t)seg * JDA_SEG_SUM_WORDS]);
+    // the segments' headers first, one lane each (one round trip for all of them), then segment after segment
+    uint32_t h_g0 = 0xffffffffu, h_n = 0, h_p0 = 0, h_p1 = 0, h_p2 = 0;
+    if (lane < JDA_FIN_SEGS_PER_WAVE && seg0 + lane < P.n_segs) {
+        const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)(seg0 + lane) * 5;
+        h_g0 = st[0]; h_p0 = st[1]; h_p1 = st[2]; h_p2 = st[3];
+        h_n = JDA_G(const uint32_t, P.seg_sum)[(size_t)(seg0 + lane) * JDA_SEG_SUM_WORDS];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_FIN_SEGS_PER_WAVE; k++) {
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)h_g0, (int)k);
+        if (g0 > P.n_blocks_total) break;                            // behind the image, behind a bad code (0xfffffff0), or no such segment
+        uint32_t nblk = (uint32_t)__builtin_amdgcn_readlane((int)h_n, (int)k);
         if (nblk > P.rec_cap) { nblk = P.rec_cap; A.bad = 1; }
-        const int32_t pr0 = (int32_t)jda_uni32(st[1]), pr1 = (int32_t)jda_uni32(st[2]), pr2 = (int32_t)jda_uni32(st[3]);
-        for (uint32_t i = lane; i < nblk; i += 64u) jda_finalize_item(P, seg, i, g0, pr0, pr1, pr2, A);
+        const int32_t pr0 = __builtin_amdgcn_readlane((int)h_p0, (int)k), pr1 = __builtin_amdgcn_readlane((int)h_p1, (int)k), pr2 = __builtin_amdgcn_readlane((int)h_p2, (int)k);
+        for (uint32_t i = lane; i < nblk; i += 64u) jda_finalize_item(P, seg0 + k, i, g0, pr0, pr1, pr2, A);
     }
     const uint32_t m_dc = jda_wave_max_u32(A.max_abs_dc), n_term = jda_wave_sum_u32(A.terminal);
     const bool any_bad = __builtin_amdgcn_ballot_w64(A.bad != 0) != 0;
@@ -870,7 +879,7 @@ __device__ __forceinline__ jda_fsm jda_fsm_compose(jda_fsm A, jda_fsm B)     // 
 }
 #define JDA_FSM_IDENTITY_W0 2u          // state 0 -> 0, 1 -> 1, nothing emitted
 // this thread's 16 bytes of the chunk (valid: how many of them exist) and their function
-__device__ __forceinline__ jda_fsm jda_filter_thread(const jda_filter_params &P, uint32_t chunk, uint32_t tid, uint32_t b[4], uint32_t &valid)
+__device__ __forceinline__ jda_fsm jda_filter_thread(const jda_filter_params &P, uint32_t chunk, uint32_t tid, uint32_t b[4], uint32_t &valid, jda_filter_masks &M)
 {
     const uint32_t off = chunk * JDA_FILTER_CHUNK + tid * 16u;
     valid = off >= P.raw_len ? 0u : (P.raw_len - off < 16u ? P.raw_len - off : 16u);
@@ -879,19 +888,12 @@ __device__ __forceinline__ jda_fsm jda_filter_thread(const jda_filter_params &P,
         const jda_chunk16_alias v = *(const jda_chunk16_alias JDA_GLOBAL *)(JDA_G(const uint8_t, P.raw) + off);
         b[0] = v.w[0]; b[1] = v.w[1]; b[2] = v.w[2]; b[3] = v.w[3];
     }
-    uint32_t s0 = 0, s1 = 1, n0 = 0, n1 = 0, r0 = 0, r1 = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) {
-        const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        const bool live = k < valid, ff = c == 0xffu, zero = c == 0u, rst = (c & 0xf8u) == 0xd0u;
-        if (live) {
-            n0 += s0 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r0 += (s0 && rst) ? 1u : 0u; s0 = s0 ? 0u : (ff ? 1u : 0u);
-            n1 += s1 ? (zero ? 1u : 0u) : (ff ? 0u : 1u); r1 += (s1 && rst) ? 1u : 0u; s1 = s1 ? 0u : (ff ? 1u : 0u);
-        }
-    }
+    // the machine from both incoming states, sixteen bytes at once (jda_filter_run: the byte-by-byte loop was 300 instructions)
+    M = jda_filter_classify(b);
+    const jda_filter_bits F0 = jda_filter_run(M, valid, 0u), F1 = jda_filter_run(M, valid, 1u);
     jda_fsm X;
-    X.w0 = s0 | (s1 << 1) | (n0 << 2) | (n1 << 17);
-    X.w1 = r0 | (r1 << 16);
+    X.w0 = ((F0.S >> valid) & 1u) | (((F1.S >> valid) & 1u) << 1) | ((uint32_t)__builtin_popcount(F0.E) << 2) | ((uint32_t)__builtin_popcount(F1.E) << 17);
+    X.w1 = (uint32_t)__builtin_popcount(F0.R) | ((uint32_t)__builtin_popcount(F1.R) << 16);
     return X;
 }
 // inclusive scan of the functions of a workgroup's 1024 threads (wt: 16 entries of LDS); total: the whole chunk's
@@ -927,7 +929,8 @@ void jda_filter_count(const jda_filter_params *__restrict__ params)
     if (chunk >= n_chunks) return;
     uint32_t b[4], valid;
     jda_fsm total;
-    (void)jda_fsm_block_scan(jda_filter_thread(P, chunk, threadIdx.x, b, valid), threadIdx.x, wt, total);
+    jda_filter_masks M;
+    (void)jda_fsm_block_scan(jda_filter_thread(P, chunk, threadIdx.x, b, valid, M), threadIdx.x, wt, total);
     if (threadIdx.x == 0) { P.work[2u * chunk] = total.w0; P.work[2u * chunk + 1u] = total.w1; }
 }
 
@@ -998,7 +1001,8 @@ void jda_filter_write(const jda_filter_params *__restrict__ params)
     const uint32_t state = carry[0], out_base = carry[1], rst_base = carry[2];
     uint32_t b[4], valid;
     jda_fsm total;
-    const jda_fsm X = jda_filter_thread(P, chunk, tid, b, valid);
+    jda_filter_masks M;
+    const jda_fsm X = jda_filter_thread(P, chunk, tid, b, valid, M);
     const jda_fsm incl = jda_fsm_block_scan(X, tid, wt, total);
     // this thread's entry: the functions of all threads before it, applied to the chunk's entry
     jda_fsm E;
@@ -1007,22 +1011,27 @@ void jda_filter_write(const jda_filter_params *__restrict__ params)
         E.w0 = JDA_FSM_IDENTITY_W0; E.w1 = 0;
         for (uint32_t w = 0; w < (tid >> 6); w++) E = jda_fsm_compose(E, wt[w]);
     }
-    uint32_t st = (E.w0 >> state) & 1u;
+    const uint32_t st = (E.w0 >> state) & 1u;
     const uint32_t mis = out_base & 15u;                          // the staged bytes sit at the alignment they will have in memory
     uint32_t o = mis + ((E.w0 >> (2 + 15 * state)) & 0x7fffu);
     uint32_t rp = rst_base + ((E.w1 >> (16 * state)) & 0xffffu);
     uint32_t JDA_GLOBAL *rpos = JDA_G(uint32_t, P.restart_pos);
+    const jda_filter_bits F = jda_filter_run(M, valid, st);       // which of the sixteen bytes leave, which follow an unpaired FF
+    for (uint32_t R = F.R; R != 0u; R &= R - 1u) {                 // RSTn: the next interval starts here (rare)
+        const uint32_t k = (uint32_t)__builtin_ctz(R);
+        rp++;
+        if (rp < P.restart_cap) rpos[rp] = out_base + (o - mis) + (uint32_t)__builtin_popcount(F.E & ((1u << k) - 1u));
+    }
     // every byte is stored -- to its place, or to a dump byte behind the buffer -- so that the sixteen steps are straight-line code
-    // (a branch per byte was sixteen exec-mask regions per thread); a restart marker is rare and keeps its branch
+    // (a branch per byte was sixteen exec-mask regions per thread).  FF 00 -> FF: the 00 that leaves in state 1 becomes the FF
+    const uint32_t sz = F.S & M.zero;
+#pragma unroll
+    for (uint32_t d = 0; d < 4; d++) b[d] |= ((((sz >> (4u * d)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
-        const uint32_t c = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        const bool live = k < valid, ff = c == 0xffu;
-        const bool emit = live & (st ? c == 0u : !ff);            // FF 00 -> FF; a byte behind an unpaired FF is dropped with it; FF waits for its partner
-        if (live & (st != 0u) & ((c & 0xf8u) == 0xd0u)) { rp++; if (rp < P.restart_cap) rpos[rp] = out_base + (o - mis); }     // RSTn: the next interval starts here
-        stage[emit ? o : (uint32_t)(JDA_FILTER_CHUNK + 31u)] = st ? (uint8_t)0xffu : (uint8_t)c;
+        const bool emit = ((F.E >> k) & 1u) != 0u;
+        stage[emit ? o : (uint32_t)(JDA_FILTER_CHUNK + 31u)] = (uint8_t)(b[k >> 2] >> (8 * (k & 3)));
         o += emit ? 1u : 0u;
-        st = live ? ((st == 0u) & ff ? 1u : 0u) : st;
     }
     __syncthreads();
     const uint32_t n_out = (total.w0 >> (2 + 15 * state)) & 0x7fffu, end = mis + n_out;

@@ -309,7 +309,8 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.n_segs = scan_len / JDA_SEG_BYTES + 1u;
             d->bytes = d->off_scan + align16(std::max((size_t)scan_len + JDA_SCAN_PAD, (size_t)it.n_segs * JDA_SEG_BYTES + 16));
             it.off_ea = d->bytes;
-            it.off_sum = it.off_ea + align16(((size_t)it.n_segs + 1) * 4); it.off_start = it.off_sum + align16((size_t)it.n_segs * 4 * JDA_SEG_SUM_WORDS);
+            it.off_sum = it.off_ea + align16(((size_t)it.n_segs + 1) * 4);
+            it.off_start = it.off_sum + align16((size_t)it.n_segs * 4 * JDA_SEG_SUM_WORDS);
             it.off_wl = it.off_start + align16((size_t)it.n_segs * 20);
             it.off_rp = it.off_wl + align16((size_t)it.n_segs * 8);
             it.off_wt = it.off_rp + (I.restart_interval ? align16(((size_t)it.n_int + 1) * 4) : 0);

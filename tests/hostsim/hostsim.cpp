@@ -63,9 +63,30 @@ extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, ui
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
 static int g_device_prescan = 0;     // != 0: make the block index with the device's segment walk (jda_seg_walk), as jda_upload_batch / jda_pipeline do
 static int g_prescan_used = 0;
+static uint32_t g_round2_list = 0;      // segments the round behind the first recording round had to walk again
+extern "C" uint32_t hostsim_round2_list(void) { return g_round2_list; }
 static int g_no_record = 0;              // 1: the counting walk + WRITE walk also for streams without restart intervals (round 2's passes)
 static uint32_t g_prescan_cands = 0;     // truncation candidates the last RECORD-mode pre-scan appended
 extern "C" void hostsim_set_no_record(int on) { g_no_record = on; }
+// the marker filter's sixteen-byte state machine (jda_filter_classify / jda_filter_run) against the byte-by-byte machine:
+// returns 0 when S, E, R agree for this group, valid count and incoming state
+extern "C" int hostsim_filter_bits_check(const uint8_t *bytes16, uint32_t valid, uint32_t cin)
+{
+    uint32_t b[4];
+    memcpy(b, bytes16, 16);
+    const jda_filter_bits F = jda_filter_run(jda_filter_classify(b), valid, cin);
+    uint32_t st = cin, S = 0, E = 0, R = 0;
+    for (uint32_t k = 0; k < valid; k++) {
+        const uint32_t c = bytes16[k];
+        S |= st << k;
+        if (st ? c == 0u : c != 0xffu) E |= 1u << k;
+        if (st && (c & 0xf8u) == 0xd0u) R |= 1u << k;
+        st = st ? 0u : (c == 0xffu ? 1u : 0u);
+    }
+    S |= st << valid;
+    const uint32_t keep = (2u << valid) - 1u;
+    return ((F.S & keep) == S && F.E == E && F.R == R) ? 0 : 1;
+}
 extern "C" uint32_t hostsim_prescan_candidates(void) { return g_prescan_cands; }
 extern "C" uint32_t jda_image_record_cap(const jda_image *img);
 static uint32_t g_prescan_trunc = 0;
@@ -150,12 +171,14 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 next.clear();
                 for (uint32_t seg : list) {
                     const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-                    const uint32_t x = jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, seg == 0 ? 0u : snap[seg], slot, lt, S, ST, rounds);
+                    const uint32_t entry = seg == 0 ? 0u : snap[seg];
+                    const uint32_t x = jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, slot, lt, S, ST, rounds);
                     uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
                     o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map;
                     o[5] = S.bad | (S.max_ac << 4); o[6] = S.lag_last; o[7] = rounds;
                     if (seg + 1 < n_segs && x != E[seg + 1]) { E[seg + 1] = x; next.push_back(seg + 1); }
                 }
+                if (rounds == 1) g_round2_list = (uint32_t)next.size();
                 list.swap(next);
                 rounds++;
             }

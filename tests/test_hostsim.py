@@ -284,3 +284,21 @@ def test_round_2_passes_still_make_the_same_index(hostsim, oracle):
     finally:
         hostsim.hostsim_set_device_prescan(0)
         hostsim.hostsim_set_no_record(0)
+
+
+def test_filter_state_machine_on_sixteen_bytes_at_once(hostsim):
+    """jda_filter_classify / jda_filter_run (the marker filter's kernels evaluate JPEGFilter's two-state machine, jpeg.inl:1431-1540, on a
+    16-bit "is FF" mask with one add) against the machine run byte by byte: every incoming state and valid count, on random groups
+    that are dense in FF / 00 / RSTn bytes, and on every run length of FFs at every position."""
+    rng = np.random.default_rng(3)
+    alphabet = np.array([0xFF, 0xFF, 0xFF, 0x00, 0x00, 0xD0, 0xD7, 0xD8, 0xCF, 0x12, 0x80, 0xFE, 0x01], np.uint8)
+    groups = [bytes(alphabet[rng.integers(0, len(alphabet), 16)]) for _ in range(4000)]
+    for start in range(16):
+        for run in range(1, 17 - start):
+            g = bytearray(rng.integers(0, 0xFE, 16, dtype=np.uint8).tobytes())
+            g[start:start + run] = b"\xff" * run
+            groups.append(bytes(g))
+    for g in groups:
+        for valid in (16, 15, 9, 1, 0):
+            for cin in (0, 1):
+                assert hostsim.hostsim_filter_bits_check(g, valid, cin) == 0, (g.hex(), valid, cin)
