@@ -95,6 +95,95 @@ def cpu_baseline(jpegs, pixel_type, cores, detail, model, wall_target=5.0):
     return out
 
 
+def check_against_reference(J, ctx, jpeg, pt, options, base, img_bytes, pitch, geo, device_sum=None):
+    """One decoded surface against the checker -- oracle/_ref (the unmodified reference, scalar build) where it travelled, else the
+    oracle restatement: test-infrastructure use of oracle/, outside every timed region."""
+    try:
+        from oracle.loader import OracleDecoder, RefDecoder, ref_available
+        got = ctx.to_host(base, img_bytes).reshape(geo["canvas_h"], pitch)[:, : geo["canvas_w"] * geo["bpp"]]
+        if ref_available(False):
+            want = RefDecoder(False).decode_cb(jpeg, pt, options)["canvas"][: geo["canvas_h"], : geo["canvas_w"] * geo["bpp"]]
+            res = {"checker": "oracle/_ref scalar reference", "bit_exact": bool(np.array_equal(got[: geo["out_h"]], want[: geo["out_h"]]))}
+        else:
+            rc, want, _ = OracleDecoder().decode_canvas(jpeg, pt, options)
+            res = {"checker": "oracle restatement", "bit_exact": bool(rc == 1 and np.array_equal(got, want))}
+        if device_sum is not None:
+            res["device_checksum_equals_host_checksum"] = bool(J.surface_checksum_host(got) == device_sum)
+        return res
+    except Exception as e:  # checker missing: report, do not fail the measurement
+        return {"checker": "unavailable: %s" % e, "bit_exact": None}
+
+
+def config_leg(J, ctx, name, what, jpegs, n_images, pt, options, threads, steps=20, ramp_ms=150.0):
+    """A short kernel-only leg over one of the other BASELINE.json configurations (inputs resident, index made by the device
+    pre-scan at upload): ms per launch from HIP events, fraction of the HBM roofline on the algorithmic bytes, image 0 against
+    the reference.  Reported under `configs` in the line; the headline stays the metric workload."""
+    t0 = time.perf_counter()
+    files = [jpegs[i % len(jpegs)] for i in range(n_images)]
+    prepared = J.prepare_batch(files, device_prescan=True, threads=threads)
+    geo = prepared[0].geometry(pt, options)
+    pitch = (geo["canvas_w"] * geo["bpp"] + 15) & ~15
+    img_bytes = pitch * geo["canvas_h"]
+    base = ctx.malloc(img_bytes * n_images)
+    dev = J.upload_batch(ctx, prepared)
+    outs = [(base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(n_images)]
+    batch = J.Batch(ctx, dev, outs, [pt] * n_images, [options] * n_images)
+    st = batch.stats
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:
+        for _ in range(4):
+            batch.decode()
+        ctx.sync()
+    ctx.timer_start()
+    for _ in range(steps):
+        batch.decode()
+    ctx.timer_stop()
+    ctx.sync()
+    ms = ctx.timer_elapsed_ms() / steps
+    algo = st["output_bytes"] + st["scan_bytes"] + 4 * sum(p.n_mcus for p in prepared)
+    sums = ctx.checksums(outs[:1], [geo["canvas_w"] * geo["bpp"]])
+    res = {"workload": what, "images": n_images, "distinct_images": len(jpegs), "options": options,
+           "bits_per_pixel": round(8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * prepared[0].info.width * prepared[0].info.height), 3),
+           "kernel_ms_per_launch": ms, "mpix_s": st["source_pixels"] / (ms * 1e-3) / 1e6,
+           "algorithmic_bytes_per_launch": algo, "achieved_gb_s": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "index": "device pre-scan at upload" if dev[0].prescan_on_device else "serial host pre-scan",
+           "parity_image_0": check_against_reference(J, ctx, files[0], pt, options, base, img_bytes, pitch, geo, sums[0])}
+    batch.close()
+    for d in dev:
+        d.close()
+    for p_ in prepared:
+        p_.close()
+    ctx.free(base)
+    res["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    return res
+
+
+def run_config_legs(J, ctx, threads, only=None):
+    """BASELINE.json configs 2, 3, 4 (one GPU's shard), 5 (full, 1/2, 1/4, 1/8) and the metric image at q98, one short leg each."""
+    legs = [
+        ("c2", "1024 x 1280x720 4:2:0 -> RGB8888 (BASELINE config 2)", (1280, 720, "4:2:0", 85, 4), 1024, J.RGB8888, 0),
+        ("c3", "256 x 4096x4096 4:4:4 -> RGB8888 (BASELINE config 3)", (4096, 4096, "4:4:4", 85, 2), 256, J.RGB8888, 0),
+        ("c4_shard", "1024 x 1920x1080 4:2:0 -> RGB8888 (one GPU's eighth of BASELINE config 4)", (1920, 1080, "4:2:0", 85, 2), 1024, J.RGB8888, 0),
+        ("c5", "16 x 8192x8192 gray -> GRAY8, full size (BASELINE config 5)", (8192, 8192, "gray", 85, 2), 16, J.GRAY8, 0),
+        ("c5_half", "16 x 8192x8192 gray -> GRAY8 at 1/2", (8192, 8192, "gray", 85, 2), 16, J.GRAY8, J.SCALE_HALF),
+        ("c5_quarter", "16 x 8192x8192 gray -> GRAY8 at 1/4", (8192, 8192, "gray", 85, 2), 16, J.GRAY8, J.SCALE_QUARTER),
+        ("c5_eighth", "16 x 8192x8192 gray -> GRAY8 at 1/8 (DC only)", (8192, 8192, "gray", 85, 2), 16, J.GRAY8, J.SCALE_EIGHTH),
+        ("q98", "64 x 4096x4096 4:2:0 at quality 98 (3.7 bit/px) -> RGB8888", (4096, 4096, "4:2:0", 98, 2), 64, J.RGB8888, 0),
+    ]
+    out, cache = {}, {}
+    for name, what, (w, h, sub, q, nd), n, pt, opt in legs:
+        if only and name not in only:
+            continue
+        try:
+            key = (w, h, sub, q, nd)
+            if key not in cache:
+                cache[key] = [cached_jpeg(w, h, sub, 1234 + i, quality=q) for i in range(nd)]
+            out[name] = config_leg(J, ctx, name, what, cache[key], n, pt, opt, threads)
+        except Exception as e:  # a leg that fails is reported, the headline stands
+            out[name] = {"workload": what, "error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,8 +203,10 @@ def parse_args(argv=None):
     ap.add_argument("--restart-rows", type=int, default=0, help="encode the inputs with a restart marker every N MCU rows (0 = none, the headline config)")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed decode launches before the warm-up steps until the GPU clocks have ramped (0: none)")
     ap.add_argument("--device-prescan", action="store_true", help="resident inputs: the block index is made on the GPU at upload (default: serial host pre-scan; the streamed pipeline always uses the device)")
-    ap.add_argument("--e2e-batches", type=int, default=10, help="batches streamed through jda_pipeline for the end-to-end figure (0: skip)")
+    ap.add_argument("--e2e-batches", type=int, default=24, help="batches streamed through jda_pipeline for the end-to-end figure (0: skip)")
     ap.add_argument("--e2e-depth", type=int, default=4)
+    ap.add_argument("--e2e-distinct", type=int, default=16, help="distinct files a batch of the end-to-end leg cycles through (metric workload; the resident batch keeps --distinct)")
+    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,q98)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs over the other BASELINE.json configurations (`configs` in the line; N = 1, metric workload only)")
@@ -271,20 +362,17 @@ def run(args, J, out=sys.stdout):
                      "images_this_rank": n_mine, "host_placement": placement})
 
     # ---- parity spot check outside the timed region: first image of this rank vs the oracle
+    # (every DISTINCT file of the timed batch is checked, at its first place in this rank's shard)
     parity = None
     if not args.no_parity and rank == 0:
-        try:
-            from oracle.loader import OracleDecoder, RefDecoder, ref_available
-            got = ctx.to_host(out_base, img_bytes).reshape(geo["canvas_h"], pitch)[:, : geo["canvas_w"] * geo["bpp"]]
-            if ref_available(False):
-                want = RefDecoder(False).decode_cb(jpegs[lo % n_distinct], pt, args.options)["canvas"][: geo["canvas_h"], : geo["canvas_w"] * geo["bpp"]]
-                parity = {"checker": "oracle/_ref scalar reference", "bit_exact": bool(np.array_equal(got[: geo["out_h"]], want[: geo["out_h"]]))}
-            else:
-                rc, want, _ = OracleDecoder().decode_canvas(jpegs[lo % n_distinct], pt, args.options)
-                parity = {"checker": "oracle restatement", "bit_exact": bool(rc == 1 and np.array_equal(got, want))}
-            parity["device_checksum_equals_host_checksum"] = bool(J.surface_checksum_host(got) == sums[0])
-        except Exception as e:  # checker missing: report, do not fail the measurement
-            parity = {"checker": "unavailable: %s" % e, "bit_exact": None}
+        first = {}
+        for i in range(lo, hi):
+            first.setdefault(i % n_distinct, i - lo)
+        checks = [check_against_reference(J, ctx, jpegs[d], pt, args.options, out_base + k * img_bytes, img_bytes, pitch, geo, sums[k]) for d, k in sorted(first.items())]
+        parity = dict(checks[0])
+        parity["distinct_files_checked"] = len(checks)
+        parity["bit_exact"] = None if any(c["bit_exact"] is None for c in checks) else all(c["bit_exact"] for c in checks)
+        parity["device_checksum_equals_host_checksum"] = all(c.get("device_checksum_equals_host_checksum", False) for c in checks)
 
     # ---- end to end: the same files streamed from host memory through jda_pipeline (host parse + tables, H2D of the unfiltered
     # scans, device filter + pre-scan + decode; batches overlapped on three streams), host work included, pixels stay in HBM
@@ -293,6 +381,13 @@ def run(args, J, out=sys.stdout):
         eb = min(n_mine, args.batch) if args.workload == "metric" else min(n_mine, 256)
         depth = max(1, min(args.e2e_depth, 4))
         files = my_files[:eb]
+        e2e_distinct = n_distinct
+        if args.workload == "metric" and args.e2e_distinct > n_distinct:
+            # more distinct files per batch than the resident leg keeps: the pre-scan's late rounds are longer (its chains of changed
+            # entry states differ from file to file), which a batch of two files flatters
+            e2e_distinct = min(args.e2e_distinct, eb)
+            pool = [cached_jpeg(width, height, sub, 1234 + i, quality=args.quality, restart_rows=args.restart_rows) for i in range(e2e_distinct)]
+            files = [pool[(lo + i) % e2e_distinct] for i in range(eb)]
         pipe = J.Pipeline(ctx, max_images=eb, depth=depth, host_threads=min(threads, 8))
         surf = [out_base] if eb * depth > n_mine else [out_base + k * eb * img_bytes for k in range(depth)]
         extra = [ctx.malloc(img_bytes * eb) for _ in range(depth - len(surf))]
@@ -333,10 +428,14 @@ def run(args, J, out=sys.stdout):
             ctx.free(p_)
         e2e = {"mpix_s": px_all / dt / 1e6, "ms_per_image": dt / n_img * 1e3, "host_submit_ms_per_image": t_submit / n_img * 1e3,
                "batches": args.e2e_batches, "images_per_batch": eb, "depth": depth, "host_threads": min(threads, 8),
-               "distinct_images": min(n_distinct, eb),      # (more distinct files per batch: a few more latency-bound pre-scan rounds)
+               "distinct_images": min(e2e_distinct, eb),
                "device_path_images": pst["device_images"], "host_path_images": pst["host_path_images"],
                "what": "files in host memory -> pixels resident in HBM through jda_pipeline: host parse + tables, H2D of the unfiltered scans, "
                        "device marker filter + per-block index + decode, batches overlapped; whole job, all ranks; the same files are submitted every batch (host-cache-hot input)"}
+
+    configs = None
+    if not args.no_configs and rank == 0 and world == 1 and args.workload == "metric":
+        configs = run_config_legs(J, ctx, threads, only=[c for c in args.configs.split(",") if c] or None)
 
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
@@ -400,6 +499,7 @@ def run(args, J, out=sys.stdout):
             "cpu_baseline": cpu,
             "parity": parity,
             "sharding": sharding,
+            "configs": configs,
             "end_to_end": e2e,
             "end_to_end_mpix_s": e2e["mpix_s"] if e2e else None,
             "host_prepare_ms_per_image": t_prep1 * 1e3,
