@@ -10,7 +10,7 @@ CSRC  = jpegdec_amd/csrc
 EXTRA ?=
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fwrapv -pthread -Wall -Wno-unused-function -Iinclude $(EXTRA)
 LIB = jpegdec_amd/libjpegdec_amd.so
-LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_pipeline.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
+LIB_SRCS = $(CSRC)/jda_frontend.cpp $(CSRC)/jda_runtime.cpp $(CSRC)/jda_pipeline.cpp $(CSRC)/jda_node.cpp $(CSRC)/jda_kernels.hip $(CSRC)/JPEGDEC.cpp
 LIB_DEPS = $(LIB_SRCS) $(CSRC)/jda_runtime_internal.h $(CSRC)/jda_internal.h $(CSRC)/jda_device_core.h $(CSRC)/jda_plan.h include/jpegdec_amd.h include/JPEGDEC.h
 
 all: lib oracle hostsim classshim
@@ -48,6 +48,11 @@ cuser: tests/capi_c/c_user
 tests/capi_c/c_user: tests/capi_c/c_user.c include/JPEGDEC.h $(LIB)
 	$(CC) -std=c99 -O2 -Wall -Iinclude -o $@ tests/capi_c/c_user.c -Ljpegdec_amd -ljpegdec_amd -Wl,-rpath,'$$ORIGIN/../../jpegdec_amd'
 
+# a plain C program on the node entry points (jda_node_*): one file decoded n times over every GPU of the node
+nodeuser: tests/capi_c/node_user
+tests/capi_c/node_user: tests/capi_c/node_user.c include/jpegdec_amd.h $(LIB)
+	$(CC) -std=c99 -O2 -Wall -Iinclude -o $@ tests/capi_c/node_user.c -Ljpegdec_amd -ljpegdec_amd -Wl,-rpath,'$$ORIGIN/../../jpegdec_amd'
+
 # the reference's own test program (MacOS/JPEGDEC_Test/JPEGDEC_Test/main.cpp) restated against the product's class
 jpegtest: tests/ref_main/jpegtest_amd
 tests/ref_main/jpegtest_amd: tests/ref_main/jpegtest_amd.cpp include/JPEGDEC.h $(LIB)
@@ -59,7 +64,7 @@ tests/fuzz/frontend_fuzz: tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp 
 	$(CXX) -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Wall -Iinclude -pthread -o $@ tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp
 
 clean:
-	rm -f $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user
+	rm -f $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user tests/capi_c/node_user
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim classshim classcpu cuser jpegtest frontfuzz clean
+.PHONY: all lib oracle hostsim classshim classcpu cuser nodeuser jpegtest frontfuzz clean

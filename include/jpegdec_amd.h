@@ -279,6 +279,13 @@ int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_
 int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles);
 
+/* The same with flags.  JDA_TO_HOST_KEEP_UNDECODED (whole image only, mcu_rect == NULL): when the stream has a bad MCU, copy back
+ * only the MCUs in front of it -- whole MCU rows, then the row's MCUs before the bad one -- and leave every other byte of
+ * host_pixels as it was: what the reference's early return does to a caller's framebuffer (jpeg.inl:5354-5356). */
+#define JDA_TO_HOST_KEEP_UNDECODED 1
+int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags);
+
 /* ------------------------------------------------------------------ the streamed pipeline
  * Files in, pixels resident in HBM out, batch after batch: the host parses headers and builds tables (microseconds per file);
  * the unfiltered entropy-coded bytes go to the GPU, which filters them (JPEGFilter, jpeg.inl:1431-1540), makes the per-block
@@ -307,6 +314,34 @@ int jda_pipeline_get_stats(const jda_pipeline *p, jda_pipeline_stats *out);   /*
 /* diagnostics: after jda_pipeline_wait(ticket), before `depth` more batches are submitted -- the per-block index (n_blocks + 1
  * entries) and DC predictors (n_blocks) the device made for image i, and its filtered scan length (any pointer may be NULL) */
 int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t *index, int16_t *dc, uint32_t *filtered_len);
+
+/* ------------------------------------------------------------------ the node: one host process, every GPU
+ * Images are independent (the reference zeroes its whole state per image, src/JPEGDEC.cpp:66): a node shards a LIST of files by
+ * image.  jda_node owns one context + one streamed pipeline per device and deals a submitted list out in contiguous blocks --
+ * device k of K takes images [first, first + count) of jda_node_shard (sizes differ by at most one: the rule the multi-process
+ * bench uses) -- running the devices' host halves on a thread each.  Pixels never cross between GPUs: outputs[i].pixels must be a
+ * DEVICE pointer on the device that owns image i (allocate with jda_malloc(jda_node_context(node, k), ..)).  What comes back
+ * is status[i] per image and, for a proof that every image was decoded once and identically wherever it landed, per-image
+ * checksums made where the pixels are (jda_node_checksums = jda_checksum_surfaces per device).
+ *   jda_node_create   devices == NULL or n_devices <= 0: every visible device (0 .. jda_device_count() - 1); max_images_per_device
+ *                     bounds a device's block; depth / host_threads_per_device as jda_pipeline_create.  Fails with
+ *                     JDA_ERROR_NO_DEVICE when there is no GPU: there is no CPU decode path.
+ *   jda_node_submit   n <= devices * max_images_per_device images; buffers and surfaces stay valid until the list is waited for
+ *   jda_node_wait     blocks until every device has decoded its block; status may be NULL */
+typedef struct jda_node jda_node;
+jda_node *jda_node_create(const int32_t *devices, int32_t n_devices, int32_t max_images_per_device, int32_t depth,
+                          int32_t host_threads_per_device, int32_t *err);
+void jda_node_destroy(jda_node *node);
+int32_t jda_node_device_count(const jda_node *node);
+int32_t jda_node_device(const jda_node *node, int32_t k);          /* HIP device ordinal of the node's k-th device */
+jda_ctx *jda_node_context(jda_node *node, int32_t k);              /* its context (owned by the node) */
+void jda_node_shard(const jda_node *node, int32_t n, int32_t k, int32_t *first, int32_t *count);
+void jda_node_shard_of(int32_t n_devices, int32_t n, int32_t k, int32_t *first, int32_t *count);     /* the same rule without a node */
+int jda_node_submit(jda_node *node, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
+                    const int32_t *pixel_types, const int32_t *options, int32_t *ticket);
+int jda_node_wait(jda_node *node, int32_t ticket, int32_t *status);
+int jda_node_checksums(jda_node *node, int32_t n, const jda_output *surfaces, const int32_t *row_bytes, uint64_t *checksums);
+int jda_node_get_stats(const jda_node *node, jda_pipeline_stats *out);   /* sums over the devices' pipelines */
 
 const char *jda_version(void);
 

@@ -260,7 +260,8 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     // decoded canvas (pitch = width, MCU-padded rows: what the reference writes, jpeg.inl:5114-5124), so the copy back from the
     // GPU lands in it directly -- no intermediate canvas, no second copy
     if (s->framebuffer && !cropped && shift0 == 0 && cw == s->info.width && s->crop_w == s->info.width) {
-        rc = jda_decode_to_host_ex(ctx, s->data, s->size, pt, iOptions, s->framebuffer, cw * bpp, ch, &mcus_decoded);
+        // (a stream with a bad MCU: the MCUs in front of it land in the framebuffer, the rest of it is left alone -- the reference returns there)
+        rc = jda_decode_to_host_flags(ctx, s->data, s->size, pt, iOptions, NULL, s->framebuffer, cw * bpp, ch, &mcus_decoded, NULL, JDA_TO_HOST_KEEP_UNDECODED);
         if (rc != JDA_SUCCESS && rc != JDA_DECODE_ERROR) { s->error = rc; return 0; }
         if (rc == JDA_DECODE_ERROR) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
         return 1;

@@ -18,6 +18,21 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <atomic>
+
+// A kernel's dynamic-LDS limit is a property of the function ON A DEVICE: set once per device and kernel (a process may drive
+// several GPUs -- JPEGDEC::setDevice, jda_node -- from several threads: the flags are atomic, the attribute call is idempotent).
+static hipError_t jda_ensure_lds_limit(const void *fn, int bytes, std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 __device__ unsigned long long *g_jda_trace = nullptr;
 // optional per-wave start/finish stamps of the persistent kernel (profiling aid, tools/wg_balance.py): the constant
 // 100 MHz clock (s_memrealtime) at entry and exit of every wave -> how evenly the static tile split loads the CUs
@@ -149,13 +164,8 @@ template <int MODE, bool FAST>
 static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
     const int lds_bytes = jda_lds_layout<MODE>::TAB_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles<MODE, FAST>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done(0);
+    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_decode_tiles<MODE, FAST>, lds_bytes, attr_done); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((jda_decode_tiles<MODE, FAST>), dim3(n_tiles / jda_lds_layout<MODE>::WAVES), dim3(64 * jda_lds_layout<MODE>::WAVES),
                        lds_bytes, stream, descs, tiles);
     return hipGetLastError();
@@ -397,11 +407,11 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
     const int lds_bytes = L::TAB_BYTES + L::WAVES * L::WAVE_BYTES + 16;   // + the draw counter
     static_assert(L::TAB_BYTES + L::WAVES * L::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
     static_assert(L::WIN_BYTES >= L::COLLIST_ENTRIES * 2 + 16 && L::WIN_BYTES % 16 == 0 && L::WIN_OFF % 16 == 0, "the window covers the column list and its overrun");
-    static int grid_cap = 0;
+    static std::atomic<unsigned long long> attr_done(0);
+    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG>, lds_bytes, attr_done); if (e != hipSuccess) return e; }
+    static std::atomic<int> grid_cap_once(0);                   // (the GPUs of a node are alike: the first device's CU count)
+    int grid_cap = grid_cap_once.load(std::memory_order_relaxed);
     if (!grid_cap) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int per_cu = (160 * 1024) / lds_bytes;
@@ -409,6 +419,7 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
         // work out by who is done first (the static split left the CUs finishing up to 4 % apart: profiles/r01_final_wg_balance.txt)
         static const int mult = []() { const char *e = getenv("JDA_GRID_MULT"); const int m = e ? atoi(e) : JDA_GRID_MULT_DEFAULT; return m < 1 ? 1 : (m > 16 ? 16 : m); }();
         grid_cap = cus * (per_cu > 0 ? per_cu : 1) * mult;
+        grid_cap_once.store(grid_cap, std::memory_order_relaxed);
     }
     const uint32_t n_quads = n_tiles / L::WAVES;
     const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
@@ -597,12 +608,11 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     static const int lds_extra1 = []() { const char *e = getenv("JDA_WALK_LDS_R1"); return e ? atoi(e) : 0; }();
     const int lds_max = JDA_WT_BYTES + (lds_extra0 > lds_extra1 ? lds_extra0 : lds_extra1);
     const int lds_bytes = JDA_WT_BYTES + (round == 0 ? lds_extra0 : lds_extra1);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)jda_segscan_fused<JDA_SEG_FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    static std::atomic<unsigned long long> attr_done0(0), attr_done1(0);
+    {
+        hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_SPEC>, lds_max, attr_done0);
+        if (e == hipSuccess) e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_FUSED>, lds_max, attr_done1);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const uint32_t full = (max_segs + 255u) / 256u;
     // later rounds walk a few percent of the segments: a few workgroups per image, each stepping through the list
@@ -751,12 +761,8 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
 {
     if (n_images == 0) return hipSuccess;
     const int lds_bytes = (int)(JDA_SUMS_MAX_CHUNKS * sizeof(jda_sum_el));
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_sums, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done(0);
+    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_sums, lds_bytes, attr_done); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(jda_segscan_sums, dim3(n_images), dim3(64 * JDA_SUMS_WAVES), lds_bytes, stream, params);
     return hipGetLastError();
 }
@@ -765,12 +771,8 @@ extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params,
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
     const int lds_bytes = JDA_WT_BYTES;               // the tables only: 16 KB per workgroup
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jda_segscan_write, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done(0);
+    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_write, lds_bytes, attr_done); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(jda_segscan_write, dim3((max_segs + 255u) / 256u, n_images), dim3(256), lds_bytes, stream, params);
     return hipGetLastError();
 }
@@ -1104,8 +1106,7 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int
                                         uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
-    static int simple = -1;                           // JDA_KERNEL=simple selects the one-tile-per-wave kernel (A/B, tracing)
-    if (simple < 0) { const char *e = getenv("JDA_KERNEL"); simple = (e && e[0] == 's') ? 1 : 0; }
+    static const int simple = []() { const char *e = getenv("JDA_KERNEL"); return (e && e[0] == 's') ? 1 : 0; }();      // JDA_KERNEL=simple selects the one-tile-per-wave kernel (A/B, tracing)
     if (simple) {
         switch (mode * 2 + (fast_mul ? 1 : 0)) {
         case JDA_MODE_GRAY * 2 + 0: return launch<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);

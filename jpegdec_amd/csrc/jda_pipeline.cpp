@@ -136,6 +136,7 @@ struct Img {
 
 struct jda_pipeline {
     jda_ctx *ctx;
+    jda_ctx *slow_ctx;                   // the redo path's own context (made when the first image needs it)
     int depth, max_images;
     hipStream_t s_up, s_copy;            // pre-scan | memset + H2D + filter (its own stream: a copy must not queue behind the previous batch's pre-scan)
     hipStream_t s_upx[2];                // more pre-scan streams, taken in turn with s_up: a batch's late rounds (a handful of wavefronts, the
@@ -198,7 +199,7 @@ jda_pipeline *jda_pipeline_create(jda_ctx *ctx, int32_t max_images, int32_t dept
     if (max_images <= 0 || depth < 1 || depth > JDA_PIPE_MAX_DEPTH) { *err = JDA_INVALID_PARAMETER; return NULL; }
     jda_pipeline *p = new (std::nothrow) jda_pipeline;
     if (!p) { *err = JDA_ERROR_MEMORY; return NULL; }
-    p->ctx = ctx; p->depth = depth; p->max_images = max_images; p->next_ticket = 0; p->workers = NULL; p->s_up = NULL; p->s_upx[0] = p->s_upx[1] = NULL; p->n_upx = 0; p->s_copy = NULL;
+    p->ctx = ctx; p->slow_ctx = NULL; p->depth = depth; p->max_images = max_images; p->next_ticket = 0; p->workers = NULL; p->s_up = NULL; p->s_upx[0] = p->s_upx[1] = NULL; p->n_upx = 0; p->s_copy = NULL;
     memset(&p->total, 0, sizeof(p->total));
     (void)hipSetDevice(ctx->device);
     bool ok = hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking) == hipSuccess;
@@ -240,6 +241,7 @@ void jda_pipeline_destroy(jda_pipeline *p)
     for (int i = 0; i < 2; i++) if (p->s_upx[i]) (void)hipStreamDestroy(p->s_upx[i]);
     if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
     delete p->workers;
+    if (p->slow_ctx) jda_destroy(p->slow_ctx);
     delete p;
 }
 
@@ -493,9 +495,13 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
 }
 
 // the serial path for one image: host pre-scan, upload, decode into the caller's surface; returns the image's status
+// (On a context -- a stream -- of the pipeline's own: the decodes of the batches submitted after this one are already queued on the
+// caller's stream, and the redo's synchronisations would wait for all of them.  It is ordered behind this batch's optimistic decode
+// of the same surface by jda_pipeline_wait's wait for the batch's event.)
 static int slow_path(jda_pipeline *p, const uint8_t *jpeg, int32_t len, const jda_output &O, int32_t pt, int32_t opt)
 {
-    jda_ctx *ctx = p->ctx;
+    if (!p->slow_ctx) { int32_t e = JDA_SUCCESS; p->slow_ctx = jda_create(p->ctx->device, &e); }
+    jda_ctx *ctx = p->slow_ctx ? p->slow_ctx : p->ctx;
     int32_t err = JDA_SUCCESS;
     jda_image *img = jda_prepare_ex(jpeg, len, 0, &err);
     if (!img) return err;

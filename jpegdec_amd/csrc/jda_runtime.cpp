@@ -44,11 +44,7 @@ int jda_plain_variant(const jda_dev_desc &D)
 // the general variant and the RGB8888 plain case, 24-bit multiplies.  JDA_BIG_WINDOW=0 / 1 forces the choice (A/B runs).
 int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uint32_t tiles_over_small)
 {
-    static int forced = -2;
-    if (forced == -2) {
-        const char *e = getenv("JDA_BIG_WINDOW"), *k = getenv("JDA_KERNEL");
-        forced = (k && k[0] == 's') ? 0 : (e ? atoi(e) : -1);
-    }
+    static const int forced = []() { const char *e = getenv("JDA_BIG_WINDOW"), *k = getenv("JDA_KERNEL"); return (k && k[0] == 's') ? 0 : (e ? atoi(e) : -1); }();
     if (!D.fast_mul || variant > 1) return 0;
     if (variant == 1 && D.mode == JDA_MODE_GRAY) return 0;
     if (forced >= 0) return forced ? 1 : 0;
@@ -781,6 +777,12 @@ int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_
 int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles)
 {
+    return jda_decode_to_host_flags(ctx, jpeg, len, pixel_type, options, mcu_rect, host_pixels, pitch_bytes, rows, mcus_decoded, tiles, 0);
+}
+
+int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags)
+{
     if (mcus_decoded) *mcus_decoded = 0;
     if (tiles) tiles[0] = tiles[1] = 0;
     if (!ctx) return JDA_ERROR_NO_DEVICE;
@@ -829,7 +831,21 @@ int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int3
         }
         if ((!complete || mcu_rect) && r1 > r0) (void)hipMemsetAsync((uint8_t *)dout + (size_t)r0 * dpitch, 0, (size_t)dpitch * (r1 - r0), ctx->stream);
         rc = jda_batch_decode(ctx, b);
-        if (rc == JDA_SUCCESS && r1 > r0) {
+        if (rc == JDA_SUCCESS && !complete && (flags & JDA_TO_HOST_KEEP_UNDECODED) && !mcu_rect) {
+            // the reference returns at the bad MCU and leaves the rest of the caller's buffer alone (jpeg.inl:5354-5356): copy back the
+            // whole MCU rows in front of it and, of its own row, the MCUs in front of it -- nothing else of the host buffer is touched
+            const int mh_out = ch / (I.mcus_y ? I.mcus_y : 1), mw_out = cw / (I.mcus_x ? I.mcus_x : 1);
+            const int full = (int)(nok / (uint32_t)I.mcus_x), part = (int)(nok % (uint32_t)I.mcus_x);
+            const int rf = std::min(drows, full * mh_out), rp = std::min(drows, (full + 1) * mh_out);
+            const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
+            hipError_t e = hipSuccess;
+            if (rf > 0) e = hipMemcpy2DAsync(host_pixels, (size_t)pitch_bytes, dout, (size_t)dpitch, row_bytes, (size_t)rf, hipMemcpyDeviceToHost, ctx->stream);
+            const size_t part_bytes = std::min(row_bytes, (size_t)part * mw_out * bpp);
+            if (e == hipSuccess && part_bytes && rp > rf)
+                e = hipMemcpy2DAsync((uint8_t *)host_pixels + (size_t)rf * pitch_bytes, (size_t)pitch_bytes, (uint8_t *)dout + (size_t)rf * dpitch, (size_t)dpitch, part_bytes, (size_t)(rp - rf), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
+        } else if (rc == JDA_SUCCESS && r1 > r0) {
             const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
             hipError_t e = hipMemcpy2DAsync((uint8_t *)host_pixels + (size_t)r0 * pitch_bytes, (size_t)pitch_bytes, (uint8_t *)dout + (size_t)r0 * dpitch, (size_t)dpitch, row_bytes, (size_t)(r1 - r0), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

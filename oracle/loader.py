@@ -143,8 +143,8 @@ class RefDecoder:
         h = (inf["height"] + adj) >> sh
         return 1, np.ascontiguousarray(r["canvas"][:h, : w * bpp])
 
-    def decode_fb(self, data: bytes, pixel_type=RGB8888, options=0, crop=None):
-        """Framebuffer-mode decode; returns (rc, flat buffer; pitch = W (or the cropped width) * bpp)."""
+    def decode_fb(self, data: bytes, pixel_type=RGB8888, options=0, crop=None, fill=0):
+        """Framebuffer-mode decode; returns (rc, flat buffer; pitch = W (or the cropped width) * bpp).  fill: what the buffer holds before."""
         inf = self.info(data)
         if not inf["ok"]:
             return -1, None
@@ -154,7 +154,7 @@ class RefDecoder:
         bpp = BYTES_PER_PIXEL[pt]
         cy = (inf["height"] + mh - 1) // mh
         rows = cy * mh + mh  # generous: reference overruns rows
-        fb = np.zeros((rows + 8, inf["width"] * bpp + 64), dtype=np.uint8).reshape(-1)
+        fb = np.full((rows + 8, inf["width"] * bpp + 64), fill, dtype=np.uint8).reshape(-1)
         err = C.c_int(0)
         croparr = (C.c_int * 4)(*crop) if crop is not None else None
         rc = self.lib.ref_decode_fb_crop(data, len(data), pixel_type, options, croparr,

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/jpegdec_amd.h"
@@ -25,8 +26,15 @@ extern "C" {
 jda_ctx *jda_create(int32_t device, int32_t *err) { if (err) *err = JDA_SUCCESS; jda_ctx *c = new jda_ctx; c->device = device; return c; }
 void jda_destroy(jda_ctx *ctx) { delete ctx; }
 
+int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags);
 int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles)
+{
+    return jda_decode_to_host_flags(ctx, jpeg, len, pixel_type, options, mcu_rect, host_pixels, pitch_bytes, rows, mcus_decoded, tiles, 0);
+}
+int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags)
 {
     if (mcus_decoded) *mcus_decoded = 0;
     if (tiles) tiles[0] = tiles[1] = 0;
@@ -60,6 +68,14 @@ int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int3
         if (x1 < x0) x1 = x0;
     }
     const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
+    if (!complete && (flags & JDA_TO_HOST_KEEP_UNDECODED) && !mcu_rect) {      // only the MCUs in front of the bad one reach the caller's buffer
+        const int full = (int)(nok / (uint32_t)I.mcus_x), part = (int)(nok % (uint32_t)I.mcus_x);
+        for (int r = 0; r < r1 && r < (full + 1) * mh; r++) {
+            const size_t nbytes = r < full * mh ? row_bytes : std::min(row_bytes, (size_t)part * mw * bpp);
+            memcpy((uint8_t *)host_pixels + (size_t)r * pitch_bytes, canvas.data() + (size_t)r * cw * bpp, nbytes);
+        }
+        return JDA_DECODE_ERROR;
+    }
     for (int r = r0; r < r1; r++) {
         uint8_t *dst = (uint8_t *)host_pixels + (size_t)r * pitch_bytes;
         memset(dst, 0, row_bytes);

@@ -55,3 +55,53 @@ def test_c_program_decodes_the_oracle_frame(c_user, tmp_path, oracle, gpu_ctx):
         rc, want = oracle.decode_frame(jpeg_for(name), 2, 0)
         got = np.fromfile(str(out), dtype=np.uint8).reshape(want.shape)
         assert np.array_equal(got, want), name
+
+
+NODE_EXE = os.path.join(ROOT, "tests", "capi_c", "node_user")
+
+
+@pytest.fixture(scope="module")
+def node_user():
+    subprocess.run(["make", "nodeuser"], cwd=ROOT, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return NODE_EXE
+
+
+def test_node_shard_rule_is_the_ranks_rule(product_lib):
+    """jda_node deals a list out in contiguous blocks whose sizes differ by at most one: the same rule as sharding.shard_range
+    (bench.py's ranks), every image owned exactly once."""
+    import ctypes as C
+    from jpegdec_amd.sharding import shard_range
+    product_lib.jda_node_shard_of.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    product_lib.jda_node_shard_of.restype = None
+    for nd in (1, 2, 3, 8):
+        for n in (0, 1, 7, 8, 9, 64, 8192):
+            seen = 0
+            for k in range(nd):
+                first, count = C.c_int32(-1), C.c_int32(-1)
+                product_lib.jda_node_shard_of(nd, n, k, C.byref(first), C.byref(count))
+                lo, hi = shard_range(n, k, nd)
+                assert (first.value, first.value + count.value) == (lo, hi)
+                seen += count.value
+            assert seen == n
+
+
+def test_node_program_without_gpu_fails_loudly(node_user, tmp_path):
+    import jpegdec_amd as J
+    if J.load_library().jda_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([node_user, _write(tmp_path, "c420_333x217"), "4"], capture_output=True, text=True)
+    assert r.returncode == 6 and "no node" in r.stdout          # JDA_ERROR_NO_DEVICE: there is no CPU decode path
+
+
+@pytest.mark.gpu
+def test_node_program_decodes_a_list_on_every_device(node_user, tmp_path, oracle, gpu_ctx):
+    """A C caller shards a list over the node without Python: every image decoded (status 0), every surface's device-made
+    checksum equal to the checksum of the oracle's canvas."""
+    import jpegdec_amd as J
+    for name, n in (("c420_333x217", 13), ("c444_333x217", 5)):
+        r = subprocess.run([node_user, _write(tmp_path, name), str(n)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        f = r.stdout.split()
+        assert int(f[1]) >= 1 and int(f[3]) == n and int(f[5]) == n and int(f[9]) == 1, r.stdout
+        rc, want, err = oracle.decode_canvas(jpeg_for(name), J.RGB8888, 0)
+        assert rc == 1 and int(f[7], 16) == J.surface_checksum_host(want), r.stdout

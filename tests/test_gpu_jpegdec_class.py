@@ -265,3 +265,43 @@ def test_framebuffer_direct_copy_and_device_selection(product_class, ref_scalar)
             rc_a, fa = product_class.decode_fb(ref_jpeg(name), pt, 0)
             rc_b, fb = ref_scalar.decode_fb(ref_jpeg(name), pt, 0)
             assert rc_a == rc_b == 1 and np.array_equal(fa[: w * h * bpp], fb[: w * h * bpp]), (name, pt)
+
+
+def test_framebuffer_keeps_what_a_bad_stream_does_not_reach(product_class, oracle):
+    """Framebuffer mode on a stream with a bad MCU: the reference returns at that MCU (jpeg.inl:5354-5356) and whatever the caller's
+    buffer held behind it stays -- the direct copy-back path must not lay the canvas's zero fill over it (round 2 did)."""
+    import jpegdec_amd as J
+    from jpegdec_amd.synth import synth_jpeg
+    base = bytearray(synth_jpeg(320, 240, "4:2:0", seed=21, quality=85))
+    sos = bytes(base).index(b"\xff\xda")
+    rng = np.random.default_rng(8)
+    done = 0
+    for _ in range(400):
+        b = bytearray(base)
+        q = int(rng.integers(sos + 14 + (len(b) - sos) // 4, len(b) - 8 - (len(b) - sos) // 4))
+        b[q:q + 6] = b"\xff\x00\xff\x00\xff\x00"       # 24 one bits in the filtered stream: no Annex K code is all ones
+        jb = bytes(b)
+        try:
+            p = J.PreparedImage(jb)
+        except J.JdaError:
+            continue
+        nok, total = p.block_index()[1], p.n_mcus
+        p.close()
+        if not (total // 8 < nok < total - total // 8):
+            continue
+        rc, fb = product_class.decode_fb(jb, RGB8888, 0, fill=0x5A)
+        assert rc == 0 and product_class.last_error == 2                     # JPEG_DECODE_ERROR
+        orc, want, err = oracle.decode_canvas(jb, RGB8888, 0)               # (MCUs before the bad one; zeros behind)
+        got = fb[: 320 * 240 * 4].reshape(240, 320 * 4)
+        mx = 320 // 16
+        for m in range(total):
+            y, x = (m // mx) * 16, (m % mx) * 16
+            blk = got[y:y + 16, x * 4:(x + 16) * 4]
+            if m < nok:
+                assert np.array_equal(blk, want[y:y + 16, x * 4:(x + 16) * 4]), (m, nok)
+            else:
+                assert np.all(blk == 0x5A), (m, nok)
+        done += 1
+        if done == 3:
+            break
+    assert done == 3
