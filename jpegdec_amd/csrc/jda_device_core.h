@@ -957,7 +957,8 @@ enum { JDA_SEG_SPEC = 0, JDA_SEG_COUNT = 1, JDA_SEG_WRITE = 2, JDA_SEG_FUSED = 3
        JDA_SEG_RECORD = 4 /* FUSED + one record per block start + truncation candidates: no WRITE walk follows (jda_segscan_finalize) */ };
 #define JDA_SEG_SUM_WORDS 8u         // per segment: block starts, DC sums [3], phase map, bad | has-restart | max AC category << 4, lag word at the last block start, round
 #define JDA_ST_NCAND 66u             // result word: truncation candidates appended (RECORD)
-#define JDA_REC_POS_BITS 12u         // a record: bit position of the block's first bit in its segment (11 bits) | spare | running DC sum of its component << 12
+#define JDA_REC_POS_BITS 12u         // a record: bit position of the block's first bit in its segment (11 bits) | JDA_REC_AFTER_RST | running DC sum of its component << 12
+#define JDA_REC_AFTER_RST 0x800u     // the sum counts from a restart inside the segment, not from the segment's entry
 
 struct jda_segscan_params {          // one per image
     const uint8_t *scan;             // filtered scan (global), zero padded to n_segs * JDA_SEG_BYTES + 16
@@ -991,6 +992,10 @@ struct jda_segscan_params {          // one per image
     uint32_t rec_cap;
     uint32_t *cands;
     uint32_t cand_cap;
+    // RECORD mode with restart intervals: two words per interval start nr = 1 .. n_intervals - 1, zeroed -- the walk that ends the
+    // interval in front of it leaves (its segment << 11 | blocks it had started by then + 1, its round): jda_segscan_resolve_cands
+    // checks that every marker ended an interval of a settled walk exactly where the MCU count puts it (what WRITE checks as it goes)
+    uint32_t *rst_events;
 };
 #define JDA_RST_SENTINEL 0x1fffffffu      // (a byte position no scan reaches: the index packs positions in 25 bits)
 #define JDA_SEG_HAS_RESTART 2u           // seg_sum word 5, bit 1: an interval ends inside the segment (its DC sums count from there)
@@ -1300,7 +1305,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         if (REC) {                                                  // a counted block starts here: its record (before its own difference joins the sum)
             const bool counted = isdc & (sbad == 0u);
             const int32_t run = c == 0 ? ds0 : (c == 1 ? ds1 : ds2);
-            const uint32_t rec = p | ((uint32_t)run << JDA_REC_POS_BITS);
+            const uint32_t rec = p | (RST && has_rst ? JDA_REC_AFTER_RST : 0u) | ((uint32_t)run << JDA_REC_POS_BITS);
             rb0 = counted ? rb1 : rb0; rb1 = counted ? rb2 : rb1; rb2 = counted ? rb3 : rb2; rb3 = counted ? rec : rb3;
             Ublk = counted ? U : Ublk;
             if (counted && (nblk & 3u) == 3u) {
@@ -1399,6 +1404,10 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                     U &= ~(f - (f >> 4));
                     ds0 = ds1 = ds2 = 0; has_rst = JDA_SEG_HAS_RESTART;
                 }
+                if (REC && sbad == 0u && nr < P.n_intervals) {      // who ended the interval in front of start nr, and after how many of its blocks
+                    uint32_t JDA_GLOBAL *ev = JDA_G(uint32_t, P.rst_events) + 2u * (size_t)nr;
+                    ev[0] = (seg << 11) | (nblk + 1u); ev[1] = round;
+                }
                 p = next_bit;
                 nr++; next_bit = nr <= P.n_intervals ? (rpos[nr] << 3) - seg_bit0 : 0xffffffffu;
             }
@@ -1489,12 +1498,14 @@ JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_
     // (its test is on the reference's pBuf, at most five bytes behind: the margin makes this one the stricter)
     if ((p_abs >> 3) + 8u > P.scan_len + JDA_SCAN_PAD - 8u) A.bad = 1;
     if (g == P.n_blocks_total) {                                    // the reader as the last block left it closes the index
-        JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical(p_abs);
+        // (a whole last interval is rounded up to a byte like the others, jpeg.inl:5339-5346)
+        JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical((P.restart_pos && P.round_last) ? ((p_abs + 7u) & ~7u) : p_abs);
         A.terminal++;
         return;
     }
     const uint32_t b = g % P.nblocks, c = b < P.nluma ? 0u : b - P.nluma + 1u;
-    const int32_t pred = (c == 0u ? pr0 : (c == 1u ? pr1 : pr2)) + ((int32_t)rec >> JDA_REC_POS_BITS);
+    const int32_t base = (rec & JDA_REC_AFTER_RST) ? 0 : (c == 0u ? pr0 : (c == 1u ? pr1 : pr2));      // (predictors restart at zero with an interval)
+    const int32_t pred = base + ((int32_t)rec >> JDA_REC_POS_BITS);
     if (pred < -32768 || pred > 32767) A.bad = 1;
     const uint32_t a = (uint32_t)(pred < 0 ? -pred : pred);
     A.max_abs_dc = a > A.max_abs_dc ? a : A.max_abs_dc;
@@ -1527,6 +1538,22 @@ JDA_HD uint32_t jda_resolve_item(const jda_segscan_params &P, uint32_t ci)
     JDA_G(uint32_t, P.blk_index)[g] = (((p_abs >> 3) - u0) << JDA_INDEX_OFF_BITS) | JDA_INDEX_TRUNC | (8u * u0 + (p_abs & 7u));
     return 1;
 }
+// interval start nr (1 .. n_intervals - 1): did a settled walk end the interval in front of it, after exactly nr x interval_blocks
+// blocks?  (The reference counts MCUs and never looks where the markers were: the two must agree.)  Returns 1 for a mismatch.
+JDA_HD uint32_t jda_rst_event_item(const jda_segscan_params &P, uint32_t nr)
+{
+    const uint32_t JDA_GLOBAL *ev = JDA_G(const uint32_t, P.rst_events) + 2u * (size_t)nr;
+    const uint32_t e = ev[0];
+    if (e == 0u) return 1u;                                         // nobody ended an interval at this marker
+    const uint32_t seg = e >> 11, nb = (e & 2047u) - 1u;
+    if (seg >= P.n_segs || JDA_G(const uint32_t, P.seg_sum)[(size_t)seg * JDA_SEG_SUM_WORDS + 7u] != ev[1]) return 1u;      // .. not in its segment's last walk
+    const uint32_t g0 = JDA_G(const uint32_t, P.seg_start)[(size_t)seg * 5u];
+    if (g0 >= 0xfffffff0u) return 0u;                               // behind a bad code: the image is rejected for that
+    const uint64_t g = (uint64_t)g0 + nb;
+    if (g >= P.n_blocks_total) return 0u;                           // behind the image's last block: nobody counts there
+    return g == (uint64_t)nr * P.interval_blocks ? 0u : 1u;
+}
+
 // ================================================================================================
 // Tile phases.  Every lane of the tile's wavefront runs each phase; a wave-local fence separates
 // consecutive phases (the host emulator runs all 64 lanes of a phase, then the next).

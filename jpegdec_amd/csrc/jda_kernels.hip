@@ -513,10 +513,10 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
     ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
     const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
     const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];       // the scan starts at a block start (jpeg.inl:4996-4998)
-    // (streams with restart intervals keep round 2's passes -- counting walk, then WRITE walk -- for now: P.records is NULL for them)
-    const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST)
-                     : ((OP == JDA_SEG_FUSED && P.records) ? jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, segw, tab, S, ST, round)
-                                                           : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST));
+    // (P.records == NULL: round 2's passes -- the counting walk here, then the WRITE walk)
+    const bool rec = OP == JDA_SEG_FUSED && P.records;
+    const uint32_t x = P.restart_pos ? (rec ? jda_seg_walk<JDA_SEG_RECORD, true>(P, seg, entry, segw, tab, S, ST, round) : jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST))
+                                     : (rec ? jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, segw, tab, S, ST, round) : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST));
     if (OP == JDA_SEG_FUSED) {
         uint32_t *o = P.seg_sum + (size_t)seg * JDA_SEG_SUM_WORDS;
         jda_store_u32x4(o, S.nblk, (uint32_t)S.dcsum[0], (uint32_t)S.dcsum[1], (uint32_t)S.dcsum[2]);
@@ -822,6 +822,11 @@ void jda_segscan_resolve_cands(const jda_segscan_params *__restrict__ params)
 {
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
     if (!P.records) return;
+    if (P.restart_pos) {                                             // every marker where the MCU count puts it?  (result word [5], as WRITE sets it)
+        bool mis = false;
+        for (uint32_t nr = 1u + blockIdx.x * 256u + threadIdx.x; nr < P.n_intervals; nr += gridDim.x * 256u) mis |= jda_rst_event_item(P, nr) != 0u;
+        if (__builtin_amdgcn_ballot_w64(mis) != 0 && (threadIdx.x & 63u) == 0u) atomicOr(&P.stats[5], 1u);
+    }
     const uint32_t n = P.stats[JDA_ST_NCAND];
     if (blockIdx.x * 256u >= n) return;
     if (n > P.cand_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&P.stats[0], 1u); return; }     // more than the list holds: the serial pre-scan

@@ -339,13 +339,16 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         im.off_fwork = im.off_rpos + (im.f.n_intervals ? a16(((size_t)im.f.n_intervals + 1) * 4) : 0);          // .. | the filter's chunk functions
         im.off_wt = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len));                                       // .. | the walk's tables
         im.work_bytes = im.off_wt + JDA_WT_BYTES;
-        // .. | RECORD mode (streams without restart intervals): the segments' block records, the truncation candidates
-        im.record = im.f.n_intervals == 0 && im.f.rec_cap != 0 && !no_record;
+        // .. | RECORD mode: the segments' block records, the truncation candidates
+        im.record = im.f.rec_cap != 0 && !no_record;
         im.off_recs = im.off_cands = 0; im.cand_cap = 0;
         if (im.record) {
-            im.off_recs = a256(im.work_bytes);
+            // (images of one size would put their record regions a constant stride apart: a skew per image keeps the walkers of a
+            // batch of like images -- all at the same place of their scans at the same time -- off each other's memory channels)
+            static const size_t skew = []() { const char *e = getenv("JDA_PIPE_REC_SKEW"); return e ? (size_t)atoi(e) : (size_t)0; }();
+            im.off_recs = a256(im.work_bytes) + a256(skew * (size_t)(i % 16));
             im.off_cands = im.off_recs + a16((size_t)im.n_segs_ub * im.f.rec_cap * 4);
-            im.cand_cap = std::max<uint32_t>(1024u, im.n_segs_ub * 2u);
+            im.cand_cap = std::max<uint32_t>(1024u, im.n_segs_ub * 16u);      // (a high-quality photograph: five candidates per segment, most of them of walks that were redone)
             im.work_bytes = im.off_cands + (size_t)im.cand_cap * 16;
             n_rec++;
         }
@@ -362,7 +365,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     for (int i = 0; i < n; i++) {
         Img &im = S.imgs[(size_t)i];
         if (!im.device) continue;
-        im.zero_bytes = a16(((size_t)im.n_segs_ub + 1) * 4);                                                       // entry states
+        im.zero_bytes = a16(((size_t)im.n_segs_ub + 1) * 4) + (im.record && im.f.n_intervals ? a16((size_t)im.f.n_intervals * 8) : 0);      // entry states | RECORD mode: who ended which restart interval
         im.off_zero = take(im.zero_bytes);
     }
     S.off_stats_dev = arena;
@@ -428,6 +431,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         if (im.record) {
             P.records = (uint32_t *)(B + im.off_work + im.off_recs); P.rec_cap = im.f.rec_cap;
             P.cands = (uint32_t *)(B + im.off_work + im.off_cands); P.cand_cap = im.cand_cap;
+            if (im.f.n_intervals) P.rst_events = (uint32_t *)(B + im.off_zero + a16(((size_t)im.n_segs_ub + 1) * 4));
         }
         P.blk_index = (uint32_t *)(B + im.off_index); P.blk_dc = (int16_t *)(B + im.off_dc);
         P.stats = pstats;
@@ -465,10 +469,22 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         S.st.h2d_bytes += (int64_t)raw_end;
         // the marker filter rides on the copy stream, behind the batch's copy (three short launches over 16 KB chunks: it shares the GPU
         // with whatever the other two streams have running)
-        if (e == hipSuccess) e = jda_launch_walk_tables((const jda_segscan_params *)(B + off_sparams), (uint32_t)dev_ix.size(), p->s_copy);
-        if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), max_raw, p->s_copy);
-        if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s_up, S.ev_copy, 0);
+        // The copy stream carries the memset and the copy ONLY: with the filter behind the copy on the same stream, the next batch's
+        // 110 MB (2 ms at 55 GB/s) could not start before this batch's filter had run -- and the filter's workgroups wait for the decode
+        // kernel of the batch in front to give the CUs' LDS back: the copy stream was the pipeline's period (3.35 ms per batch of 64 x
+        // 4096x4096, profiles/r03_pipeline_timeline_filter_on_copy_stream.txt).  The filter opens the batch's pre-scan stream instead.
+        static const bool filter_on_copy = []() { const char *v = getenv("JDA_PIPE_FILTER_STREAM"); return v && v[0] == 'c'; }();      // (measuring)
+        hipStream_t s_f = filter_on_copy ? p->s_copy : s_up;
+        if (!filter_on_copy) {
+            if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s_up, S.ev_copy, 0);
+        }
+        if (e == hipSuccess) e = jda_launch_walk_tables((const jda_segscan_params *)(B + off_sparams), (uint32_t)dev_ix.size(), s_f);
+        if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), max_raw, s_f);
+        if (filter_on_copy) {
+            if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s_up, S.ev_copy, 0);
+        }
         if (e == hipSuccess) {
             const jda_segscan_params *dp = (const jda_segscan_params *)(B + off_sparams);
             const uint32_t ns = (uint32_t)dev_ix.size();

@@ -210,7 +210,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         jda_dev_image *d; uint8_t *stage; std::vector<uint8_t> heap; bool on_device; uint32_t n_int;
         size_t alloc, n_blocks; uint32_t tbytes;
         // the index is made on the device (8f N1 / N2): segments of the scan, see jda_seg_walk
-        bool seg_mode; uint32_t n_segs; size_t off_ea, off_sum, off_start, off_wl, off_rp, off_wt, off_sstats;
+        bool seg_mode; uint32_t n_segs; size_t off_ea, off_sum, off_start, off_wl, off_rp, off_wt, off_ev, off_sstats;
         bool record; uint32_t rec_cap, cand_cap; size_t off_recs, off_cands, zero_end;      // RECORD mode of the pre-scan (no restart intervals)
         std::vector<uint32_t> rp;            // restart positions + the sentinel, until their copy has been made
         uint32_t sst[68];
@@ -310,15 +310,16 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.off_wl = it.off_start + align16((size_t)it.n_segs * 20);
             it.off_rp = it.off_wl + align16((size_t)it.n_segs * 8);
             it.off_wt = it.off_rp + (I.restart_interval ? align16(((size_t)it.n_int + 1) * 4) : 0);
-            it.off_sstats = it.off_wt + JDA_WT_BYTES;
+            it.off_ev = it.off_wt + JDA_WT_BYTES;                 // RECORD mode: who ended which restart interval (zeroed)
+            it.off_sstats = it.off_ev + (I.restart_interval ? align16((size_t)it.n_int * 8) : 0);
             it.alloc = it.off_sstats + 512;
             it.zero_end = it.alloc;                          // (what is memset: everything up to here; records and candidates need none)
             it.rec_cap = jda_image_record_cap(img);
-            it.record = !I.restart_interval && it.rec_cap != 0 && getenv("JDA_PIPE_NO_RECORD") == NULL;
+            it.record = it.rec_cap != 0 && getenv("JDA_PIPE_NO_RECORD") == NULL;
             if (it.record) {
                 it.off_recs = (it.alloc + 255) & ~(size_t)255;
                 it.off_cands = it.off_recs + align16((size_t)it.n_segs * it.rec_cap * 4);
-                it.cand_cap = std::max<uint32_t>(1024u, it.n_segs * 2u);
+                it.cand_cap = std::max<uint32_t>(1024u, it.n_segs * 16u);
                 it.alloc = it.off_cands + (size_t)it.cand_cap * 16;
             }
         }
@@ -360,6 +361,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             if (it.record) {
                 SP.records = (uint32_t *)(d->base + it.off_recs); SP.rec_cap = it.rec_cap;
                 SP.cands = (uint32_t *)(d->base + it.off_cands); SP.cand_cap = it.cand_cap;
+                if (I.restart_interval) SP.rst_events = (uint32_t *)(d->base + it.off_ev);
             }
             SP.scan_len = scan_len; SP.n_segs = it.n_segs; SP.n_blocks_total = (uint32_t)it.n_blocks;
             SP.nblocks = (uint8_t)I.blocks_per_mcu; SP.nluma = (uint8_t)(I.blocks_per_mcu - (I.ncomp == 3 ? 2 : 0));

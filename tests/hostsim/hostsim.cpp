@@ -143,12 +143,13 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         }
         const bool rst = P.restart_pos != nullptr;
         // RECORD mode (streams without restart intervals), as jda_pipeline / jda_upload_batch run it
-        const bool record = !rst && !g_no_record && jda_image_record_cap(img) != 0;
-        std::vector<uint32_t> records, cands, stats(80, 0);
+        const bool record = !g_no_record && jda_image_record_cap(img) != 0;
+        std::vector<uint32_t> records, cands, stats(80, 0), rst_events;
         if (record) {
-            P.rec_cap = jda_image_record_cap(img); P.cand_cap = std::max<uint32_t>(1024u, n_segs * 2u);
+            P.rec_cap = jda_image_record_cap(img); P.cand_cap = std::max<uint32_t>(1024u, n_segs * 16u);
             records.assign((size_t)n_segs * P.rec_cap, 0xdeadbeefu); cands.assign((size_t)P.cand_cap * 4, 0);
             P.records = records.data(); P.cands = cands.data(); P.stats = stats.data();
+            if (rst) { rst_events.assign((size_t)P.n_intervals * 2 + 2, 0); P.rst_events = rst_events.data(); }
         }
         jda_seg_sum S;
         jda_seg_stats ST;
@@ -162,7 +163,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             std::vector<uint32_t> E(n_segs + 1, 0), list, next;
             for (uint32_t seg = 0; seg < n_segs; seg++) {
                 const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-                E[seg + 1] = jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, 0u, slot, lt, S, ST);
+                E[seg + 1] = rst ? jda_seg_walk<JDA_SEG_SPEC, true>(P, seg, 0u, slot, lt, S, ST) : jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, 0u, slot, lt, S, ST);
             }
             for (uint32_t seg = 0; seg < n_segs; seg++) list.push_back(seg);
             rounds = 1;
@@ -172,7 +173,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 for (uint32_t seg : list) {
                     const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
                     const uint32_t entry = seg == 0 ? 0u : snap[seg];
-                    const uint32_t x = jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, slot, lt, S, ST, rounds);
+                    const uint32_t x = rst ? jda_seg_walk<JDA_SEG_RECORD, true>(P, seg, entry, slot, lt, S, ST, rounds) : jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, slot, lt, S, ST, rounds);
                     uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
                     o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map;
                     o[5] = S.bad | (S.max_ac << 4); o[6] = S.lag_last; o[7] = rounds;
@@ -269,6 +270,13 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             g_prescan_cands = stats[JDA_ST_NCAND];
             if (stats[JDA_ST_NCAND] > P.cand_cap) A.bad = 1;
             else for (uint32_t ci = 0; ci < stats[JDA_ST_NCAND]; ci++) ST.trunc_events += jda_resolve_item(P, ci);
+            if (rst) for (uint32_t nr = 1; nr < P.n_intervals; nr++) {                                          // every marker where the MCU count puts it
+                const uint32_t mis = jda_rst_event_item(P, nr);
+                if (mis && getenv("HOSTSIM_DEBUG")) fprintf(stderr, "restart event %u of %u: ev %u/%u round %u, seg round %u g0 %u want %u\n", nr, P.n_intervals, rst_events[2 * nr] >> 11, rst_events[2 * nr] & 2047u, rst_events[2 * nr + 1],
+                                                            seg_sum[(size_t)(rst_events[2 * nr] >> 11) * JDA_SEG_SUM_WORDS + 7], seg_start[(size_t)(rst_events[2 * nr] >> 11) * 5], nr * P.interval_blocks);
+                ST.bad |= mis;
+            }
+            if (getenv("HOSTSIM_DEBUG")) fprintf(stderr, "finalize: bad %u terminal %u cands %u\n", A.bad, A.terminal, stats[JDA_ST_NCAND]);
             ST.bad |= A.bad; terminal = A.terminal; ST.max_abs_dc = A.max_abs_dc;
         }
         for (uint32_t seg = 0; seg < n_segs && !record; seg++) { // WRITE
