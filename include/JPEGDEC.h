@@ -79,8 +79,12 @@ class JPEGDEC {
   public:
     JPEGDEC();
     ~JPEGDEC();
-    JPEGDEC(const JPEGDEC &) = delete;
-    JPEGDEC &operator=(const JPEGDEC &) = delete;
+    // The reference's class is a plain struct around its JPEGIMAGE (src/JPEGDEC.h:286): objects are copied and assigned freely.
+    // Here a copy clones the open image (file-sourced data included; the close callback stays with the original), a move takes it.
+    JPEGDEC(const JPEGDEC &);
+    JPEGDEC &operator=(const JPEGDEC &);
+    JPEGDEC(JPEGDEC &&) noexcept;
+    JPEGDEC &operator=(JPEGDEC &&) noexcept;
 
     int openRAM(uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw);
     int openFLASH(const uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw);
@@ -121,13 +125,15 @@ class JPEGDEC {
 // ---- the C flavour of the API (reference src/JPEGDEC.h:288-309, bodies src/jpeg.inl:564-739).  The reference
 // offers it to C translation units that include jpeg.inl; here the functions live in libjpegdec_amd.so and are
 // callable from C and C++ alike.  JPEGIMAGE is caller-allocated as in the reference (there: the 18 KB decoder
-// state; here: a small handle -- the state lives behind it and is released by JPEG_close or the next open).
-// Two rules the reference does not have: (1) zero-initialise a JPEGIMAGE before its first JPEG_open* (`JPEGIMAGE j = {0};` --
-// an open tells a live handle from stack garbage by the magic word); (2) ALWAYS call JPEG_close when done, also for RAM /
-// FLASH sources (upstream that is a no-op for them; here it frees the state behind the handle).
+// state; here: a small handle -- the state lives in a slot of a table inside the library).  As in the reference, a JPEGIMAGE needs
+// no initialisation before JPEG_open* (an open tells a live handle from stack garbage by the magic word + slot + generation) and a
+// RAM / FLASH source needs no JPEG_close (src/JPEGDEC.cpp:232-236: a no-op there): a handle that is re-opened reuses its slot, and
+// slots of RAM-sourced images that were never closed are recycled, least recently used first, once 64 are open -- a handle whose
+// slot went that way reports JPEG_INVALID_PARAMETER.  File-sourced images are closed with JPEG_close, as in the reference.
 typedef struct jpeg_image_tag {
     uint32_t magic;          /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
-    void *impl;
+    uint32_t gen;            /* generation of the slot when this handle opened it */
+    void *impl;              /* the slot */
 } JPEGIMAGE;
 
 #ifdef __cplusplus

@@ -9,6 +9,8 @@
 #include "../../include/JPEGDEC.h"
 
 #include <stdio.h>
+#include <atomic>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -109,6 +111,32 @@ int finish_open(jpegdec_amd_state *s, JPEG_DRAW_CALLBACK *draw)
 
 JPEGDEC::JPEGDEC() : _jpeg(new jpegdec_amd_state) { _jpeg->device = -1; reset(_jpeg); }
 JPEGDEC::~JPEGDEC() { delete _jpeg; }
+// a copy: the open image with everything set on it; data read from a file is cloned, RAM / FLASH data stays the caller's; the
+// close callback stays with the original (it closes the caller's file once); the decoded canvas is a cache and starts empty
+static jpegdec_amd_state *clone_state(const jpegdec_amd_state *o)
+{
+    jpegdec_amd_state *s = new jpegdec_amd_state;
+    s->owned = o->owned;
+    s->data = (!o->owned.empty() && o->data == o->owned.data()) ? s->owned.data() : o->data;
+    s->size = o->size; s->info = o->info; s->error = o->error; s->pixel_type = o->pixel_type; s->max_mcus = o->max_mcus;
+    s->options = o->options; s->xoff = o->xoff; s->yoff = o->yoff;
+    s->crop_x = o->crop_x; s->crop_y = o->crop_y; s->crop_w = o->crop_w; s->crop_h = o->crop_h;
+    s->device = o->device; s->user = o->user; s->framebuffer = o->framebuffer; s->draw = o->draw;
+    s->close_cb = NULL; s->close_handle = NULL; s->opened = o->opened;
+    return s;
+}
+JPEGDEC::JPEGDEC(const JPEGDEC &o) : _jpeg(clone_state(o._jpeg)) {}
+JPEGDEC &JPEGDEC::operator=(const JPEGDEC &o)
+{
+    if (this != &o) { jpegdec_amd_state *s = clone_state(o._jpeg); delete _jpeg; _jpeg = s; }
+    return *this;
+}
+JPEGDEC::JPEGDEC(JPEGDEC &&o) noexcept : _jpeg(o._jpeg) { o._jpeg = new jpegdec_amd_state; o._jpeg->device = -1; reset(o._jpeg); }
+JPEGDEC &JPEGDEC::operator=(JPEGDEC &&o) noexcept
+{
+    if (this != &o) { jpegdec_amd_state *t = _jpeg; _jpeg = o._jpeg; o._jpeg = t; reset(o._jpeg); }
+    return *this;
+}
 
 int JPEGDEC::openRAM(uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw)
 {
@@ -413,25 +441,60 @@ int JPEGDEC::decode(int x, int y, int iOptions)
 
 
 // ---- C flavour (reference src/jpeg.inl:564-739): thin wrappers over the class; the caller's JPEGIMAGE holds the object
-#define JPEGIMAGE_MAGIC 0x4a444131u   /* "JDA1" */
-static JPEGDEC *c_obj(JPEGIMAGE *p) { return (p && p->magic == JPEGIMAGE_MAGIC) ? (JPEGDEC *)p->impl : NULL; }
-static JPEGDEC *c_fresh(JPEGIMAGE *p)
+// The objects live in a table of slots inside the library; a handle names its slot and the slot's generation.  A handle that is
+// opened again reuses its slot; when every slot is taken, the least recently used one whose image came from RAM / FLASH -- the
+// reference needs no JPEG_close for those (src/JPEGDEC.cpp:232-236) -- is recycled, and the handle that held it goes stale.
+#define JPEGIMAGE_MAGIC 0x4a444132u   /* "JDA2" */
+#define JPEG_C_SLOTS 64
+namespace {
+struct CSlot { JPEGDEC *obj; uint32_t gen; uint64_t stamp; bool file; };
+CSlot g_cslots[JPEG_C_SLOTS];
+std::mutex g_cslots_mu;
+std::atomic<uint64_t> g_cstamp(1);
+}
+static CSlot *c_slot(JPEGIMAGE *p)
+{
+    if (!p || p->magic != JPEGIMAGE_MAGIC) return NULL;
+    CSlot *s = (CSlot *)p->impl;
+    if (s < g_cslots || s >= g_cslots + JPEG_C_SLOTS || (size_t)((const char *)s - (const char *)g_cslots) % sizeof(CSlot)) return NULL;    // stack garbage
+    return (s->obj && s->gen == p->gen) ? s : NULL;
+}
+static JPEGDEC *c_obj(JPEGIMAGE *p)
+{
+    CSlot *s = c_slot(p);
+    if (!s) return NULL;
+    s->stamp = g_cstamp.fetch_add(1, std::memory_order_relaxed);
+    return s->obj;
+}
+static JPEGDEC *c_fresh(JPEGIMAGE *p, bool file)
 {
     if (!p) return NULL;
-    if (p->magic == JPEGIMAGE_MAGIC && p->impl) delete (JPEGDEC *)p->impl;      // re-open: the reference memsets its state (:569)
-    p->impl = new (std::nothrow) JPEGDEC();
-    p->magic = p->impl ? JPEGIMAGE_MAGIC : 0;
-    return (JPEGDEC *)p->impl;
+    std::lock_guard<std::mutex> lock(g_cslots_mu);
+    CSlot *s = c_slot(p);                                        // re-open: the reference memsets its state (jpeg.inl:569)
+    if (!s) {
+        CSlot *lru = NULL;
+        for (int i = 0; i < JPEG_C_SLOTS && !s; i++) {
+            if (!g_cslots[i].obj) s = &g_cslots[i];
+            else if (!g_cslots[i].file && (!lru || g_cslots[i].stamp < lru->stamp)) lru = &g_cslots[i];
+        }
+        if (!s) s = lru;                                         // every slot taken: the RAM-sourced image nobody has touched the longest
+        if (!s) { p->magic = 0; p->impl = NULL; return NULL; }   // (64 file-sourced images open and never closed)
+    }
+    if (s->obj) { s->obj->close(); delete s->obj; }
+    s->obj = new (std::nothrow) JPEGDEC();
+    s->gen++; s->file = file; s->stamp = g_cstamp.fetch_add(1, std::memory_order_relaxed);
+    p->magic = s->obj ? JPEGIMAGE_MAGIC : 0; p->gen = s->gen; p->impl = s;
+    return s->obj;
 }
 extern "C" {
 int JPEG_openRAM(JPEGIMAGE *pJPEG, uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw)
 {
-    JPEGDEC *j = c_fresh(pJPEG);
+    JPEGDEC *j = c_fresh(pJPEG, false);
     return j ? j->openRAM(pData, iDataSize, pfnDraw) : 0;
 }
 int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *pfnDraw)
 {
-    JPEGDEC *j = c_fresh(pJPEG);
+    JPEGDEC *j = c_fresh(pJPEG, true);
     return j ? j->open(szFilename, pfnDraw) : 0;
 }
 void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer) { if (JPEGDEC *j = c_obj(pJPEG)) j->setFramebuffer(pFramebuffer); }
@@ -444,7 +507,10 @@ int JPEG_decode(JPEGIMAGE *pJPEG, int x, int y, int iOptions) { JPEGDEC *j = c_o
 int JPEG_decodeDither(JPEGIMAGE *pJPEG, uint8_t *pDither, int iOptions) { JPEGDEC *j = c_obj(pJPEG); return j ? j->decodeDither(pDither, iOptions) : 0; }
 void JPEG_close(JPEGIMAGE *pJPEG)
 {
-    if (JPEGDEC *j = c_obj(pJPEG)) { j->close(); delete j; }
+    {
+        std::lock_guard<std::mutex> lock(g_cslots_mu);
+        if (CSlot *s = c_slot(pJPEG)) { s->obj->close(); delete s->obj; s->obj = NULL; s->gen++; }
+    }
     if (pJPEG) { pJPEG->impl = NULL; pJPEG->magic = 0; }
 }
 int JPEG_getLastError(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getLastError() : JPEG_INVALID_PARAMETER; }
