@@ -18,16 +18,20 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
 ctx = J.Context(0)
 oracle = OracleDecoder()
 pipe = J.Pipeline(ctx, max_images=64, depth=3, host_threads=4)
-bases = ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217", "c420_1280x720", "gray_333x217", "c420_256x256_q98", "c440_200x120")
+# (round 3: + the reference's photographs -- they have the magnitude reads the reference truncates, i.e. the RECORD-mode pre-scan's
+# candidates and flagged entries, with and without restart intervals)
+bases = ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217", "c420_1280x720", "gray_333x217", "c420_256x256_q98", "c440_200x120",
+         "ref:zebra", "ref:st_peters", "ref:tulips", "ref:sciopero")
+from tests.ref_fixtures import ref_jpeg  # noqa: E402
 total = on_device = failed = 0
 inflight = []
 for r in range(rounds):
     jp, nm = [], []
     for name in bases:
-        base = bytearray(jpeg_for(name))
+        base = bytearray(ref_jpeg(name[4:]) if name.startswith("ref:") else jpeg_for(name))
         sos = bytes(base).index(b"\xff\xda")
         made = 0
-        while made < 8:
+        while made < (8 if len(bases) == 8 else 5):
             b = bytearray(base)
             for _ in range(int(rng.integers(1, 4))):
                 b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
