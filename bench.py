@@ -455,7 +455,7 @@ def run(args, J, out=sys.stdout):
         # comes from the committed rocprofv3 --pmc passes of the same workload (profiles/), scaled to
         # this batch; null for any other workload
         traffic, traffic_src = None, None
-        for tag in ("r02", "r01_final"):
+        for tag in ("r03", "r02", "r01_final"):
             tp = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
             if (os.path.exists(tp) and args.workload == "metric" and (args.width, args.height, args.subsampling, args.pixel_type, args.options, args.quality)
                     == (4096, 4096, "4:2:0", "rgb8888", 0, 85)):
