@@ -141,13 +141,17 @@ def config_leg(J, ctx, name, what, jpegs, n_images, pt, options, threads, steps=
     ctx.sync()
     ms = ctx.timer_elapsed_ms() / steps
     algo = st["output_bytes"] + st["scan_bytes"] + 4 * sum(p.n_mcus for p in prepared)
-    sums = ctx.checksums(outs[:1], [geo["canvas_w"] * geo["bpp"]])
+    # every surface's checksum, made where the pixels are: all decodes of one file must be one value, image 0's is checked on the host
+    sums = ctx.checksums(outs, [geo["canvas_w"] * geo["bpp"]] * n_images)
+    nd = len(jpegs)
+    all_equal = all(sums[i] == sums[i % nd] for i in range(n_images))
     res = {"workload": what, "images": n_images, "distinct_images": len(jpegs), "options": options,
            "bits_per_pixel": round(8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * prepared[0].info.width * prepared[0].info.height), 3),
            "kernel_ms_per_launch": ms, "mpix_s": st["source_pixels"] / (ms * 1e-3) / 1e6,
            "algorithmic_bytes_per_launch": algo, "achieved_gb_s": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "index": "device pre-scan at upload" if dev[0].prescan_on_device else "serial host pre-scan",
-           "parity_image_0": check_against_reference(J, ctx, files[0], pt, options, base, img_bytes, pitch, geo, sums[0])}
+           "parity_image_0": check_against_reference(J, ctx, files[0], pt, options, base, img_bytes, pitch, geo, sums[0]),
+           "every_surface_equals_the_first_decode_of_its_file": bool(all_equal)}
     batch.close()
     for d in dev:
         d.close()
