@@ -31,7 +31,7 @@
 
 // ---- tile and LDS layout -------------------------------------------------------------------------
 // One wavefront (64 threads) decodes one "tile": up to 64 consecutive 8x8 blocks of one MCU row =
-// 10 MCUs of 4:2:0 (60 blocks), 21 MCUs of 4:4:4 (63 blocks) or 64 MCUs of a gray image.  The four
+// 10 MCUs of 4:2:0 (60 blocks), 20 MCUs of 4:4:4 (60 blocks) or 64 MCUs of a gray image.  The four
 // wavefronts of a workgroup share nothing but the image's tables in LDS, so after the tables are
 // staged there is no workgroup barrier: every phase boundary is a wave-local fence.
 #define JDA_TILE_THREADS 64
@@ -97,7 +97,9 @@ JDA_HD uint32_t jda_ac_entry(uint32_t raw)
 // goes to HBM at every refill: 3-4x slower in P1).
 template <int MODE, int BIG = 0> struct jda_lds_layout {
     enum {
-        MCUS = JDA_TILE_THREADS / jda_mode_traits<MODE>::NBLK,       // MCUs per tile: 10 / 21 / 64
+        // MCUs per tile: 10 (4:2:0) / 20 (4:4:4) / 16 / 64.  4:4:4 takes 20 of the 21 that would fit: 160 pixels = 640-byte rows of
+        // RGB8888 (whole 128-byte lines: 168-pixel tiles wrote 1.9 % more than they stored) and 320 colour-stage items = exactly five passes
+        MCUS = MODE == JDA_MODE_444 ? 20 : JDA_TILE_THREADS / jda_mode_traits<MODE>::NBLK,
         BLOCKS = MCUS * jda_mode_traits<MODE>::NBLK,                 // blocks per tile: 60 / 63 / 64
         // one 136-byte slot per block: int16[64] coefficients, later (first 64 bytes) its 8x8 samples --
         // the row stage stores its bytes over the block it has just read, as the reference does (:2682)
@@ -2137,10 +2139,10 @@ JDA_HD uint32_t jda_565_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t 
 // pixels = exactly five passes of the wavefront): item i = lane + 64 * pass always lands on the same LDS offsets and
 // on the same offset from the tile's first output pixel, so the index arithmetic (a third of the stage's VALU work)
 // is done once per image and kept in registers.  Only the output offset depends on the image (pitch, pixel size).
-// The same for a FULL 4:4:4 tile (21 MCUs = 168 x 8 pixels = 336 items of 4 pixels of one row = five passes and a quarter):
+// The same for a FULL 4:4:4 tile (20 MCUs = 160 x 8 pixels = 320 items of 4 pixels of one row = five passes):
 // yo = the luma bytes (Cb, Cr one and two block slots further), rel as above; co is not used.
 #define JDA_P4_PASSES 5
-#define JDA_P4_PASSES_444 6
+#define JDA_P4_PASSES_444 5
 struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES_444], co[JDA_P4_PASSES], rel[JDA_P4_PASSES_444]; };
 JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, uint32_t pitch, uint32_t bpp)
 {
@@ -2158,7 +2160,7 @@ JDA_HD void jda_p4_precompute_444(jda_p4_pre &P, uint32_t t, uint32_t plane_stri
 {
 #pragma unroll
     for (int it = 0; it < JDA_P4_PASSES_444; it++) {
-        const uint32_t i = t + 64u * (uint32_t)it, r = i / 42u, x4 = (i - r * 42u) * 4u;    // 42 groups of 4 pixels per row
+        const uint32_t i = t + 64u * (uint32_t)it, r = i / 40u, x4 = (i - r * 40u) * 4u;    // 40 groups of 4 pixels per row
         P.yo[it] = (x4 >> 3) * plane_stride + r * 8u + (x4 & 7u);
         P.rel[it] = r * pitch + x4 * bpp;
     }
@@ -2293,7 +2295,7 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
     }
 }
 
-// a full, unclipped 4:4:4 tile: six passes with the precomputed item addresses (the last one a quarter full)
+// a full, unclipped 4:4:4 tile: five passes with the precomputed item addresses
 template <int PT>
 JDA_HD void jda_p4_444_full21(const jda_dev_desc &D, const jda_p4_pre &P, uint32_t t, const uint8_t *plane_base, uint32_t x_base, uint32_t y_base)
 {
@@ -2301,7 +2303,6 @@ JDA_HD void jda_p4_444_full21(const jda_dev_desc &D, const jda_p4_pre &P, uint32
     uint8_t JDA_GLOBAL *tile = JDA_G(uint8_t, D.out) + (y_base * D.out_pitch + x_base * bpp);      // uniform
 #pragma unroll
     for (int it = 0; it < JDA_P4_PASSES_444; it++) {
-        if (it == JDA_P4_PASSES_444 - 1 && t >= 336u - 64u * (JDA_P4_PASSES_444 - 1)) break;
         const uint8_t *Pp = plane_base + P.yo[it];
         const uint32_t y = *(const jda_u32_alias *)Pp, cb = *(const jda_u32_alias *)(Pp + JDA_COEF_STRIDE), cr = *(const jda_u32_alias *)(Pp + 2 * JDA_COEF_STRIDE);
         uint32_t v[4];

@@ -94,7 +94,7 @@ inline uint32_t jda_window_bytes(int mode, int big)
 }
 inline uint32_t jda_mcus_per_tile(int mode)
 {
-    return mode == JDA_MODE_420 ? 10u : mode == JDA_MODE_444 ? 21u : (mode == JDA_MODE_422 || mode == JDA_MODE_440) ? 16u : 64u;
+    return mode == JDA_MODE_420 ? 10u : mode == JDA_MODE_444 ? 20u : (mode == JDA_MODE_422 || mode == JDA_MODE_440) ? 16u : 64u;
 }
 
 // rect = {mx0, my0, mx1, my1} in MCUs (half open) restricts the list to the tiles of that rectangle (crop-aware decode:
