@@ -197,7 +197,7 @@ def parse_args(argv=None):
                     help="metric: batch x N images of --width x --height (weak scaling); c4: BASELINE config 4, 8192 x 1920x1080 4:2:0 split over the ranks (strong scaling)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (metric workload)")
     ap.add_argument("--total-images", type=int, default=8192, help="size of the list of the c4 workload")
-    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images cycled through the list (0: 2 for metric, 8 for c4)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images cycled through the list (0: 16 for metric, 8 for c4)")
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--subsampling", default="4:2:0", choices=["4:2:0", "4:4:4", "4:2:2", "gray"])
@@ -276,7 +276,7 @@ def run(args, J, out=sys.stdout):
     else:
         width, height, sub = args.width, args.height, args.subsampling
         n_total = args.batch * world
-        n_distinct = args.distinct or 2
+        n_distinct = args.distinct or min(16, args.batch)      # (the 4096x4096 q85 set is cached under bench_cache/; other shapes are made on first use)
     jpegs = [cached_jpeg(width, height, sub, 1234 + i, quality=args.quality, restart_rows=args.restart_rows) for i in range(n_distinct)]
     bits_px = 8.0 * sum(len(j) for j in jpegs) / (len(jpegs) * width * height)
     lo, hi = shard_range(n_total, rank, world)
