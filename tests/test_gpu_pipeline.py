@@ -241,3 +241,29 @@ def test_pipeline_corrupted_scans_decode_like_the_oracle(gpu_ctx, oracle):
     for o in outs:
         gpu_ctx.free(o[0])
     pipe.close()
+
+
+def test_pipeline_on_the_densest_streams(gpu_ctx, oracle):
+    """Flat images: some 390 block starts per 256-byte segment (every block its two shortest codes) -- the RECORD-mode pre-scan's record
+    slots hold them, with and without restart intervals, in 4:2:0 and 4:4:4; device index == the serial one, pixels == the oracle's."""
+    from jpegdec_amd.synth import encode_jpeg_custom
+    flat = np.full((256, 640, 3), 117, np.uint8)
+    flat[100:140, 300:360] = 30
+    jp = [encode_jpeg_custom(flat, 90, hv, restart_interval=ri) for hv, ri in (((2, 2), 0), ((1, 1), 0), ((2, 2), 7), ((2, 1), 0))]
+    names = ["flat420", "flat444", "flat420_rst7", "flat422"]
+    pts, opts = [J.RGB8888] * len(jp), [0] * len(jp)
+    pipe = J.Pipeline(gpu_ctx, max_images=8, depth=2, host_threads=2)
+    outs, metas = _surfaces(gpu_ctx, jp, pts, opts)
+    t = pipe.submit(jp, outs, pts, opts)
+    st = pipe.wait(t)
+    _check(gpu_ctx, oracle, jp, pts, opts, outs, metas, st, names)
+    for i, n in enumerate(names):
+        h = J.PreparedImage(jp[i])
+        idx, dc, flen = pipe.read_index(t, i, h.n_blocks)
+        assert J.index_equivalent(idx, h.block_index()[0]) and np.array_equal(dc, h.block_dc()), n
+        assert h.n_blocks * 256 // max(len(h.scan()), 1) > 150, n
+        h.close()
+    assert pipe.stats["device_images"] == len(jp) and pipe.stats["host_path_images"] == 0
+    pipe.close()
+    for o in outs:
+        gpu_ctx.free(o[0])

@@ -302,3 +302,28 @@ def test_filter_state_machine_on_sixteen_bytes_at_once(hostsim):
         for valid in (16, 15, 9, 1, 0):
             for cin in (0, 1):
                 assert hostsim.hostsim_filter_bits_check(g, valid, cin) == 0, (g.hex(), valid, cin)
+
+
+@pytest.mark.parametrize("luma_hv,restart", [((2, 2), 0), ((1, 1), 0), ((2, 2), 7)])
+def test_record_mode_on_the_densest_streams(luma_hv, restart, hostsim, oracle):
+    """A flat image is the densest stream there is -- every block its two shortest codes, 32 bits per 4:2:0 MCU with the Annex K tables:
+    some 390 block starts in a 256-byte segment.  The segments' record slots (jda_record_cap, from the tables' shortest codes) must hold
+    them, the index must be the serial one and the picture the oracle's."""
+    from jpegdec_amd.synth import encode_jpeg_custom
+    flat = np.full((256, 640, 3), 117, np.uint8)
+    flat[100:140, 300:360] = 30                                   # (a little structure, so that not every segment is the same)
+    jpeg = encode_jpeg_custom(flat, 90, luma_hv, restart_interval=restart)
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        rc, want, err = oracle.decode_canvas(jpeg, J.RGB8888, 0)
+        assert rc == 1
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, J.RGB8888, 0)
+        assert hostsim.hostsim_decode(jpeg, len(jpeg), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1
+        assert np.array_equal(got, want)
+        p = J.PreparedImage(jpeg)
+        assert p.n_blocks * 256 // max(len(p.scan()), 1) > 200          # (the test means something: hundreds of blocks per segment)
+        p.close()
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
