@@ -416,6 +416,16 @@ int JPEGDEC::decode(int x, int y, int iOptions)
             }
             uint16_t *buf = strip0 + (dma ? half * half_words : 0);
             const int row_bytes = r[2] > 0 ? r[2] * bpp : 0;
+            // A strip is a few hundred bytes from each of mh canvas rows, a canvas pitch apart: not a pattern the hardware prefetcher
+            // follows.  Ask for the rows of the strip after the next one while this one is copied.
+            if (i + 2 < n && (size_t)cw * ch * bpp > ((size_t)2 << 20)) {      // (a canvas that fits the caches needs no help)
+                const int32_t *q = &rects[(size_t)8 * (i + 2)];
+                const int qb = q[2] > 0 ? q[2] * bpp : 0;
+                for (int rr = 0; rr < mh && q[7] + rr < ch; rr++) {
+                    const uint8_t *src = canvas + ((size_t)(q[7] + rr) * cw + q[6]) * bpp;
+                    for (int o = 0; o < qb; o += 64) __builtin_prefetch(src + o, 0, 0);
+                }
+            }
             for (int rr = 0; rr < mh; rr++) {
                 const int cy_ = r[7] + rr;                       // strip position in the decoded canvas
                 uint8_t *dst = (uint8_t *)buf + (size_t)rr * row_bytes;
