@@ -172,6 +172,10 @@ const char *jda_last_hip_error(const jda_ctx *ctx);
 void *jda_stream(jda_ctx *ctx);        /* the hipStream_t every launch of this ctx goes to */
 
 /* device memory helpers (so callers need no HIP binding of their own) */
+/* Page-locked HOST memory (hipHostMalloc): a destination the copy back of jda_decode_to_host* reaches at link speed and truly
+ * asynchronously -- what lets jda_decode_to_host_bands overlap the copy with the caller's work.  NULL when it cannot be had. */
+void *jda_host_alloc(size_t bytes);
+void jda_host_free(void *p);
 void *jda_malloc(jda_ctx *ctx, size_t bytes);
 void jda_free(jda_ctx *ctx, void *dptr);
 int jda_memset(jda_ctx *ctx, void *dptr, int value, size_t bytes);
@@ -285,6 +289,16 @@ int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int3
 #define JDA_TO_HOST_KEEP_UNDECODED 1
 int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
                              void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags);
+
+/* The same, the copy back cut into n_bands (<= 8) bands of whole MCU rows: band_ready(user, row0, row1) is called, in order, as soon as
+ * rows [row0, row1) of host_pixels have landed -- what the caller does with them (JPEGDEC::decode replays the reference's JPEGDRAW
+ * callbacks, jpeg.inl:5300-5336) overlaps the rest of the copy.  *mcus_decoded is set before the first call.  The copy is NOT cut --
+ * one copy, band_ready never called, the caller looks at all rows after the return -- without a callback, with n_bands <= 1, with a
+ * rectangle, and with JDA_TO_HOST_KEEP_UNDECODED on a stream that has a bad MCU. */
+typedef void(jda_band_callback)(void *user, int32_t row0, int32_t row1);
+int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags,
+                             int32_t n_bands, jda_band_callback *band_ready, void *user);
 
 /* ------------------------------------------------------------------ the streamed pipeline
  * Files in, pixels resident in HBM out, batch after batch: the host parses headers and builds tables (microseconds per file);

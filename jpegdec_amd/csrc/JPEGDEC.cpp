@@ -18,12 +18,20 @@
 
 #include "../../include/jpegdec_amd.h"
 
+#define JDA_MAX_REPLAY_BANDS 8          // bands of the copy back of a large image decoded with draw callbacks
+
 struct jpegdec_amd_state {
     std::vector<uint8_t> owned;       // file-sourced data (open(filename) / callbacks)
     // the decoded canvas the draw callbacks / the framebuffer copy are replayed from, and the replay's strip plan: kept from one
     // decode to the next (they grow to the largest image the object has decoded and go with it) -- a fresh canvas per decode was
     // a memset and a page fault per 4 KB of it: 0.2 ms of a 640x480 decode, 5 ms of a 4096x4096 one
     std::vector<uint8_t> canvas;
+    uint8_t *pinned_canvas;           // large images: page-locked, so that the copy back runs beside the strip replay (jda_decode_to_host_bands)
+    size_t pinned_cap;
+    jpegdec_amd_state() : pinned_canvas(NULL), pinned_cap(0) {}
+    ~jpegdec_amd_state() { if (pinned_canvas) jda_host_free(pinned_canvas); }
+    jpegdec_amd_state(const jpegdec_amd_state &) = delete;
+    jpegdec_amd_state &operator=(const jpegdec_amd_state &) = delete;
     std::vector<int32_t> rects;
     const uint8_t *data;
     int size;
@@ -294,8 +302,16 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         if (rc == JDA_DECODE_ERROR) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
         return 1;
     }
-    if (s->canvas.size() < (size_t)cw * ch * bpp) s->canvas.resize((size_t)cw * ch * bpp);
-    uint8_t *const canvas = s->canvas.data();    // (every row the replay reads is copied back by this decode: the MCU rows it keeps)
+    const size_t canvas_bytes = (size_t)cw * ch * bpp;
+    const bool banded = !s->framebuffer && s->draw && !cropped && canvas_bytes >= ((size_t)2 << 20);      // a large image with draw callbacks
+    if (banded && s->pinned_cap < canvas_bytes) {
+        if (s->pinned_canvas) jda_host_free(s->pinned_canvas);
+        s->pinned_canvas = (uint8_t *)jda_host_alloc(canvas_bytes + canvas_bytes / 8);
+        s->pinned_cap = s->pinned_canvas ? canvas_bytes + canvas_bytes / 8 : 0;
+    }
+    const bool use_pinned = banded && s->pinned_canvas != NULL;
+    if (!use_pinned && s->canvas.size() < canvas_bytes) s->canvas.resize(canvas_bytes);
+    uint8_t *const canvas = use_pinned ? s->pinned_canvas : s->canvas.data();    // (every row the replay reads is copied back by this decode: the MCU rows it keeps)
     static const bool poison = getenv("JPEGDEC_AMD_POISON_CANVAS") != NULL;     // (tests: what the last decode left must never show)
     if (poison) memset(canvas, 0xA5, (size_t)cw * ch * bpp);
     // A cropped decode only launches the tiles of the MCUs the reference keeps (jpeg.inl:5111, :5134-5137: MCU rows from the crop's
@@ -313,15 +329,105 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         if (y1 > s->info.mcus_y) y1 = s->info.mcus_y;
         rect[0] = x0 < x1 ? x0 : 0; rect[1] = y0; rect[2] = x0 < x1 ? x1 : 0; rect[3] = y1 > y0 ? y1 : y0;
     }
-    rc = jda_decode_to_host_rect(ctx, s->data, s->size, pt, iOptions, cropped ? rect : NULL, canvas, cw * bpp, ch, &mcus_decoded, NULL);
-    // the reference walks the MCU rows down to the crop's bottom only (jpeg.inl:5014-5037): a bad MCU below it is never met
-    if (rc == JDA_DECODE_ERROR && cropped && mcus_decoded >= rect[3] * s->info.mcus_x && rect[3] < s->info.mcus_y) rc = JDA_SUCCESS;
-    const bool partial = rc == JDA_DECODE_ERROR;      // the reference still delivers the MCUs before the bad one
-    if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
-
+    // ---- callback mode: the reference's JPEGDRAW sequence (jpeg.inl:5300-5336), planned before the decode so that the strips of a band
+    // of the copy back can go out while the next band is still on the bus (jda_decode_to_host_bands)
+    int n = 0, ri = 0, half = 0;
+    bool stopped = false, partial = false, dma = false;
+    std::vector<int32_t> &rects = s->rects;
+    uint16_t *strip0 = s->strip;
+    size_t half_words = MAX_BUFFERED_PIXELS / 2;
+    std::vector<uint16_t> big;
     const int eff = jda_effective_options(&s->info, iOptions);      // a progressive file is a 1/8 thumbnail (jpeg.inl:4964-4966)
     const int shift = (eff & JPEG_SCALE_HALF) ? 1 : (eff & JPEG_SCALE_QUARTER) ? 2 : (eff & JPEG_SCALE_EIGHTH) ? 3 : 0;
     const int mw = s->info.mcu_w >> shift, mh = s->info.mcu_h >> shift;
+    if (!s->framebuffer && s->draw) {
+        const int32_t crop[4] = { s->crop_x, s->crop_y, s->crop_w, s->crop_h };
+        n = jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0, cropped ? crop : NULL, s->xoff, NULL, 0);   // how many strips
+        if (n > 65536) n = 65536;
+        if (n > 0 && s->rects.size() < (size_t)8 * n) s->rects.resize((size_t)8 * n);
+        if (n > 0) (void)jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0, cropped ? crop : NULL, s->xoff, rects.data(), n);
+        // with JPEG_USES_DMA (and no user cap on the MCU count) the strip ping-pongs between the two halves
+        dma = (iOptions & JPEG_USES_DMA) != 0;
+        {   // the halves only alternate when the user cap did not win (jpeg.inl:5071-5076)
+            int per_call = MAX_BUFFERED_PIXELS / ((s->info.mcu_w >> shift) * mh);
+            if (pt == RGB8888) per_call /= 2;
+            if (pt == EIGHT_BIT_GRAYSCALE) per_call *= 2;
+            if (per_call > s->info.mcus_x) per_call = s->info.mcus_x;
+            if (per_call > s->max_mcus) dma = false;
+        }
+        if (n > 65536) n = 65536;
+        // The reference's strip buffer is usPixels[2048] inside its state; a plan can ask for more (a decode x offset on an image whose
+        // width is not a whole number of MCUs widens the row's last strip, jpeg.inl:5328-5335 -- the reference then writes over the
+        // tables behind usPixels).  Here such a strip gets a buffer of its own size: the callback sees the strip the plan describes.
+        size_t need = 0;
+        for (int i = 0; i < n; i++) {
+            const int32_t *r = &rects[(size_t)8 * i];
+            const size_t bytes = (size_t)(r[2] > 0 ? r[2] : 0) * bpp * (size_t)mh;
+            if (bytes > need) need = bytes;
+        }
+        if (need > (dma ? sizeof(s->strip) / 2 : sizeof(s->strip)) - 16) {
+            half_words = (need + 31) / 2 & ~(size_t)7;
+            big.assign(half_words * 2 + 16, 0);
+            strip0 = big.data();
+        }
+    }
+    auto replay = [&](int row_limit) {
+        for (; ri < n && !stopped; ri++) {
+            const int i = ri;
+            const int32_t *r = &rects[(size_t)8 * i];
+            if (r[7] + mh > row_limit) return;                   // its rows have not landed yet: the next band brings them
+            if (partial) {
+                // the reference returns at the first bad MCU (jpeg.inl:5150-5297 "if (iErr) ... return 0" paths): only the strips it
+                // had completed before that MCU reach the callback
+                int x_last = (r[6] + r[2]) / mw - 1;
+                if (x_last > s->info.mcus_x - 1) x_last = s->info.mcus_x - 1;
+                if ((r[7] / mh) * s->info.mcus_x + x_last >= mcus_decoded) { stopped = true; break; }
+            }
+            uint16_t *buf = strip0 + (dma ? half * half_words : 0);
+            const int row_bytes = r[2] > 0 ? r[2] * bpp : 0;
+            // A strip is a few hundred bytes from each of mh canvas rows, a canvas pitch apart: not a pattern the hardware prefetcher
+            // follows.  Ask for the rows of the strip after the next one while this one is copied.
+            if (i + 2 < n && (size_t)cw * ch * bpp > ((size_t)2 << 20)) {      // (a canvas that fits the caches needs no help)
+                const int32_t *q = &rects[(size_t)8 * (i + 2)];
+                const int qb = q[2] > 0 ? q[2] * bpp : 0;
+                for (int rr = 0; rr < mh && q[7] + rr < ch; rr++) {
+                    const uint8_t *src = canvas + ((size_t)(q[7] + rr) * cw + q[6]) * bpp;
+                    for (int o = 0; o < qb; o += 64) __builtin_prefetch(src + o, 0, 0);
+                }
+            }
+            for (int rr = 0; rr < mh; rr++) {
+                const int cy_ = r[7] + rr;                       // strip position in the decoded canvas
+                uint8_t *dst = (uint8_t *)buf + (size_t)rr * row_bytes;
+                if (cy_ >= ch) { memset(dst, 0, (size_t)row_bytes); continue; }
+                int avail = (cw - r[6]) * bpp;
+                if (avail > row_bytes) avail = row_bytes;
+                if (avail < 0) avail = 0;
+                memcpy(dst, canvas + ((size_t)cy_ * cw + r[6]) * bpp, (size_t)avail);
+                if (avail < row_bytes) memset(dst + avail, 0, (size_t)(row_bytes - avail));
+            }
+            JPEGDRAW jd;
+            jd.x = s->xoff + r[0]; jd.y = s->yoff + r[1];
+            jd.iWidth = r[2]; jd.iHeight = r[3]; jd.iWidthUsed = r[4]; jd.iBpp = r[5];
+            jd.pPixels = buf; jd.pUser = s->user;
+            const int keep_going = (*s->draw)(&jd);    // jpeg.inl:5325
+            half ^= 1;
+            if (!keep_going) { stopped = true; break; }
+        }
+    };
+    const int32_t mcus_total = s->info.mcus_x * s->info.mcus_y;
+    if (use_pinned) {
+        // a large image with draw callbacks: the copy back in bands, each band's strips replayed as it lands
+        struct Trampoline { decltype(replay) *fn; int32_t *decoded; int32_t total; bool *partial; };
+        Trampoline tr = { &replay, &mcus_decoded, mcus_total, &partial };
+        rc = jda_decode_to_host_bands(ctx, s->data, s->size, pt, iOptions, NULL, canvas, cw * bpp, ch, &mcus_decoded, NULL, 0, JDA_MAX_REPLAY_BANDS,
+                                      [](void *u, int32_t, int32_t row1) { Trampoline *t = (Trampoline *)u; *t->partial = *t->decoded < t->total; (*t->fn)(row1); }, &tr);
+    } else
+    rc = jda_decode_to_host_rect(ctx, s->data, s->size, pt, iOptions, cropped ? rect : NULL, canvas, cw * bpp, ch, &mcus_decoded, NULL);
+    // the reference walks the MCU rows down to the crop's bottom only (jpeg.inl:5014-5037): a bad MCU below it is never met
+    if (rc == JDA_DECODE_ERROR && cropped && mcus_decoded >= rect[3] * s->info.mcus_x && rect[3] < s->info.mcus_y) rc = JDA_SUCCESS;
+    partial = rc == JDA_DECODE_ERROR;                 // the reference still delivers the MCUs before the bad one
+    if (rc != JDA_SUCCESS && !partial) { s->error = rc; return 0; }
+
     // MCU rows the reference walks (jpeg.inl:5014-5037); a crop that reaches below the last MCU row makes it
     // decode whatever follows the scan and fail -- here the real rows are delivered and the same error returned
     int rows_mcu = (s->crop_y + s->crop_h + s->info.mcu_h - 1) / s->info.mcu_h;
@@ -371,79 +477,7 @@ int JPEGDEC::decode(int x, int y, int iOptions)
                 }
         }
     } else if (s->draw) {
-        const int32_t crop[4] = { s->crop_x, s->crop_y, s->crop_w, s->crop_h };
-        int n = jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0, cropped ? crop : NULL, s->xoff, NULL, 0);   // how many strips
-        if (n > 65536) n = 65536;
-        if (n > 0 && s->rects.size() < (size_t)8 * n) s->rects.resize((size_t)8 * n);
-        std::vector<int32_t> &rects = s->rects;
-        if (n > 0) (void)jda_draw_plan_at(&s->info, pt, iOptions, s->max_mcus, (iOptions & JPEG_USES_DMA) ? 1 : 0, cropped ? crop : NULL, s->xoff, rects.data(), n);
-        // with JPEG_USES_DMA (and no user cap on the MCU count) the strip ping-pongs between the two halves
-        bool dma = (iOptions & JPEG_USES_DMA) != 0;
-        {   // the halves only alternate when the user cap did not win (jpeg.inl:5071-5076)
-            int per_call = MAX_BUFFERED_PIXELS / ((s->info.mcu_w >> shift) * mh);
-            if (pt == RGB8888) per_call /= 2;
-            if (pt == EIGHT_BIT_GRAYSCALE) per_call *= 2;
-            if (per_call > s->info.mcus_x) per_call = s->info.mcus_x;
-            if (per_call > s->max_mcus) dma = false;
-        }
-        int half = 0;
-        if (n > 65536) n = 65536;
-        // The reference's strip buffer is usPixels[2048] inside its state; a plan can ask for more (a decode x offset on an image whose
-        // width is not a whole number of MCUs widens the row's last strip, jpeg.inl:5328-5335 -- the reference then writes over the
-        // tables behind usPixels).  Here such a strip gets a buffer of its own size: the callback sees the strip the plan describes.
-        size_t need = 0;
-        for (int i = 0; i < n; i++) {
-            const int32_t *r = &rects[(size_t)8 * i];
-            const size_t bytes = (size_t)(r[2] > 0 ? r[2] : 0) * bpp * (size_t)mh;
-            if (bytes > need) need = bytes;
-        }
-        std::vector<uint16_t> big;
-        uint16_t *strip0 = s->strip;
-        size_t half_words = MAX_BUFFERED_PIXELS / 2;
-        if (need > (dma ? sizeof(s->strip) / 2 : sizeof(s->strip)) - 16) {
-            half_words = (need + 31) / 2 & ~(size_t)7;
-            big.assign(half_words * 2 + 16, 0);
-            strip0 = big.data();
-        }
-        for (int i = 0; i < n; i++) {
-            const int32_t *r = &rects[(size_t)8 * i];
-            if (partial) {
-                // the reference returns at the first bad MCU (jpeg.inl:5150-5297 "if (iErr) ... return 0" paths): only the strips it
-                // had completed before that MCU reach the callback
-                int x_last = (r[6] + r[2]) / mw - 1;
-                if (x_last > s->info.mcus_x - 1) x_last = s->info.mcus_x - 1;
-                if ((r[7] / mh) * s->info.mcus_x + x_last >= mcus_decoded) break;
-            }
-            uint16_t *buf = strip0 + (dma ? half * half_words : 0);
-            const int row_bytes = r[2] > 0 ? r[2] * bpp : 0;
-            // A strip is a few hundred bytes from each of mh canvas rows, a canvas pitch apart: not a pattern the hardware prefetcher
-            // follows.  Ask for the rows of the strip after the next one while this one is copied.
-            if (i + 2 < n && (size_t)cw * ch * bpp > ((size_t)2 << 20)) {      // (a canvas that fits the caches needs no help)
-                const int32_t *q = &rects[(size_t)8 * (i + 2)];
-                const int qb = q[2] > 0 ? q[2] * bpp : 0;
-                for (int rr = 0; rr < mh && q[7] + rr < ch; rr++) {
-                    const uint8_t *src = canvas + ((size_t)(q[7] + rr) * cw + q[6]) * bpp;
-                    for (int o = 0; o < qb; o += 64) __builtin_prefetch(src + o, 0, 0);
-                }
-            }
-            for (int rr = 0; rr < mh; rr++) {
-                const int cy_ = r[7] + rr;                       // strip position in the decoded canvas
-                uint8_t *dst = (uint8_t *)buf + (size_t)rr * row_bytes;
-                if (cy_ >= ch) { memset(dst, 0, (size_t)row_bytes); continue; }
-                int avail = (cw - r[6]) * bpp;
-                if (avail > row_bytes) avail = row_bytes;
-                if (avail < 0) avail = 0;
-                memcpy(dst, canvas + ((size_t)cy_ * cw + r[6]) * bpp, (size_t)avail);
-                if (avail < row_bytes) memset(dst + avail, 0, (size_t)(row_bytes - avail));
-            }
-            JPEGDRAW jd;
-            jd.x = s->xoff + r[0]; jd.y = s->yoff + r[1];
-            jd.iWidth = r[2]; jd.iHeight = r[3]; jd.iWidthUsed = r[4]; jd.iBpp = r[5];
-            jd.pPixels = buf; jd.pUser = s->user;
-            const int keep_going = (*s->draw)(&jd);    // jpeg.inl:5325
-            half ^= 1;
-            if (!keep_going) break;
-        }
+        replay(1 << 30);                                      // (what the bands of the copy back have not delivered yet: everything, when it was not banded)
     }
     if (partial || overrun) { s->error = JPEG_DECODE_ERROR; return 0; }   // jpeg.inl:5354-5356
     return 1;

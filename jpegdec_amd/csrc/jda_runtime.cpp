@@ -139,6 +139,7 @@ void jda_destroy(jda_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
+    for (int i = 0; i < JDA_MAX_BANDS; i++) if (ctx->ev_band[i]) (void)hipEventDestroy(ctx->ev_band[i]);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int i = 0; i < JDA_POOL_SLOTS; i++) if (ctx->pool[i].p) (void)hipFree(ctx->pool[i].p);
@@ -147,6 +148,13 @@ void jda_destroy(jda_ctx *ctx)
 
 const char *jda_last_hip_error(const jda_ctx *ctx) { return ctx ? ctx->last_error : "no context"; }
 void *jda_stream(jda_ctx *ctx) { return ctx ? (void *)ctx->stream : NULL; }
+
+void *jda_host_alloc(size_t bytes)
+{
+    void *p = NULL;
+    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : NULL;
+}
+void jda_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 void *jda_malloc(jda_ctx *ctx, size_t bytes)
 {
@@ -785,6 +793,13 @@ int jda_decode_to_host_rect(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int3
 int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
                              void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags)
 {
+    return jda_decode_to_host_bands(ctx, jpeg, len, pixel_type, options, mcu_rect, host_pixels, pitch_bytes, rows, mcus_decoded, tiles, flags, 1, NULL, NULL);
+}
+
+int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags,
+                             int32_t n_bands, jda_band_callback *band_ready, void *user)
+{
     if (mcus_decoded) *mcus_decoded = 0;
     if (tiles) tiles[0] = tiles[1] = 0;
     if (!ctx) return JDA_ERROR_NO_DEVICE;
@@ -800,7 +815,7 @@ int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
     const int32_t prep_flags = len >= dev_from ? JDA_PREPARE_DEVICE_PRESCAN : 0;
     jda_image *img = jda_prepare_ex(jpeg, len, prep_flags, &err);
     if (!img) return err;
-    const jda_image_info &I = *jda_image_get_info(img);
+    const jda_image_info I = *jda_image_get_info(img);       // (by value: the image is freed as soon as it is uploaded)
     int bpp, ow, oh, cw, ch;
     int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
     if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
@@ -845,6 +860,31 @@ int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
             const size_t part_bytes = std::min(row_bytes, (size_t)part * mw_out * bpp);
             if (e == hipSuccess && part_bytes && rp > rf)
                 e = hipMemcpy2DAsync((uint8_t *)host_pixels + (size_t)rf * pitch_bytes, (size_t)pitch_bytes, (uint8_t *)dout + (size_t)rf * dpitch, (size_t)dpitch, part_bytes, (size_t)(rp - rf), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
+        } else if (rc == JDA_SUCCESS && r1 > r0 && band_ready && n_bands > 1) {
+            // the copy back in bands of whole MCU rows, the caller told as each one lands: what it does with band k (the class replays its
+            // draw callbacks) runs while band k + 1 is still on the bus
+            const int mh_out = ch / (I.mcus_y ? I.mcus_y : 1);
+            int nb = n_bands > JDA_MAX_BANDS ? JDA_MAX_BANDS : n_bands;
+            const int mrows = (r1 - r0 + mh_out - 1) / mh_out;
+            if (nb > mrows) nb = mrows;
+            const int per = ((mrows + nb - 1) / nb) * mh_out;
+            const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;
+            hipError_t e = hipSuccess;
+            int made = 0;
+            for (int k = 0; k < nb && e == hipSuccess; k++) {
+                const int b0 = r0 + k * per, b1 = std::min(r1, b0 + per);
+                if (b0 >= b1) break;
+                if (!ctx->ev_band[k]) e = hipEventCreateWithFlags(&ctx->ev_band[k], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipMemcpy2DAsync((uint8_t *)host_pixels + (size_t)b0 * pitch_bytes, (size_t)pitch_bytes, (uint8_t *)dout + (size_t)b0 * dpitch, (size_t)dpitch, row_bytes, (size_t)(b1 - b0), hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipEventRecord(ctx->ev_band[k], ctx->stream);
+                if (e == hipSuccess) made++;
+            }
+            for (int k = 0; k < made && e == hipSuccess; k++) {
+                e = hipEventSynchronize(ctx->ev_band[k]);
+                if (e == hipSuccess) (*band_ready)(user, r0 + k * per, std::min(r1, r0 + (k + 1) * per));
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
         } else if (rc == JDA_SUCCESS && r1 > r0) {

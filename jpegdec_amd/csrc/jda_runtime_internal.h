@@ -12,10 +12,12 @@
 
 #define JDA_POOL_SLOTS 192
 #define JDA_POOL_IDLE_MAX ((size_t)2 << 30)      // idle bytes kept at most
+#define JDA_MAX_BANDS 8
 struct jda_ctx {
     int device;
     hipStream_t stream;
     hipEvent_t ev_start, ev_stop;
+    hipEvent_t ev_band[JDA_MAX_BANDS];   // jda_decode_to_host_bands: one per band of the copy back (made on first use)
     uint8_t *pinned;          // page-locked staging for uploads (grow-only, reused)
     size_t pinned_cap;
     int last_segscan_rounds;  // speculative rounds the last marker-less device pre-scan needed (diagnostics)

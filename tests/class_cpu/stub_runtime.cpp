@@ -23,6 +23,8 @@ struct jda_ctx { int device; };
 
 extern "C" {
 
+void *jda_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
+void jda_host_free(void *p) { free(p); }
 jda_ctx *jda_create(int32_t device, int32_t *err) { if (err) *err = JDA_SUCCESS; jda_ctx *c = new jda_ctx; c->device = device; return c; }
 void jda_destroy(jda_ctx *ctx) { delete ctx; }
 
@@ -83,6 +85,28 @@ int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
         if (b > a) memcpy(dst + a, canvas.data() + (size_t)r * cw * bpp + a, b - a);
     }
     return complete ? JDA_SUCCESS : JDA_DECODE_ERROR;
+}
+
+// (the copy back in bands: the stand-in fills the canvas, then reports the bands one after the other -- the class's resumable replay
+// runs exactly as it does behind the GPU's copies)
+int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,
+                             void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags,
+                             int32_t n_bands, jda_band_callback *band_ready, void *user)
+{
+    const int rc = jda_decode_to_host_flags(ctx, jpeg, len, pixel_type, options, mcu_rect, host_pixels, pitch_bytes, rows, mcus_decoded, tiles, flags);
+    if ((rc == JDA_SUCCESS || rc == JDA_DECODE_ERROR) && band_ready && n_bands > 1 && !mcu_rect && !(flags & JDA_TO_HOST_KEEP_UNDECODED)) {
+        jda_image_info I;
+        int bpp, ow, oh, cw, ch;
+        if (jda_parse(jpeg, len, &I) == JDA_SUCCESS && jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch) == JDA_SUCCESS && I.mcus_y > 0) {
+            const int mh = ch / I.mcus_y, r1 = rows < ch ? rows : ch;
+            int nb = n_bands > 8 ? 8 : n_bands;
+            const int mrows = (r1 + mh - 1) / mh;
+            if (nb > mrows) nb = mrows;
+            const int per = ((mrows + nb - 1) / nb) * mh;
+            for (int k = 0; k < nb && k * per < r1; k++) (*band_ready)(user, k * per, std::min(r1, (k + 1) * per));
+        }
+    }
+    return rc;
 }
 
 int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, void *host_pixels,
