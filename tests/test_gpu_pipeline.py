@@ -267,3 +267,51 @@ def test_pipeline_on_the_densest_streams(gpu_ctx, oracle):
     pipe.close()
     for o in outs:
         gpu_ctx.free(o[0])
+
+
+def test_pipeline_random_shapes_qualities_and_restart_intervals(gpu_ctx, oracle):
+    """A sweep the fixed cases do not cover: 60 files of random size (1-700 pixels a side, ragged edges), layout, quality 20-100 and
+    restart interval through ONE pipeline in two batches, four pixel types and scales mixed: statuses and pixels == the oracle's, and the
+    device-made index == the serial one for every file the device indexed."""
+    from jpegdec_amd.synth import encode_jpeg_custom, value_noise_image
+    rng = np.random.default_rng(20260925)
+    layouts = [(2, 2), (1, 1), (2, 1), (1, 2)]
+    jp, names = [], []
+    for i in range(60):
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        hv = layouts[int(rng.integers(0, 4))]
+        q = int(rng.integers(20, 101))
+        ri = 0 if rng.random() < 0.5 else int(rng.integers(1, 40))
+        jp.append(encode_jpeg_custom(value_noise_image(w, h, 3, 1000 + i), q, hv, restart_interval=ri))
+        names.append("%dx%d_%d%d_q%d_ri%d" % (w, h, hv[0], hv[1], q, ri))
+    modes = [(J.RGB8888, 0), (J.RGB565_LE, J.SCALE_HALF), (J.GRAY8, 0), (J.RGB565_BE, 0), (J.RGB8888, J.SCALE_EIGHTH), (J.RGB565_LE, J.SCALE_QUARTER)]
+    pipe = J.Pipeline(gpu_ctx, max_images=64, depth=2, host_threads=4)
+    inflight = []
+    for b in range(2):
+        pts, opts = [], []
+        for i, n in enumerate(names):
+            pt, opt = modes[(i + b) % len(modes)]
+            if "_12_" in n and pt == J.RGB8888 and (opt & 4):          # (4:4:0 -> RGB8888 at 1/4: the reference writes through a stray pointer, DESIGN 3)
+                opt = 0
+            pts.append(pt); opts.append(opt)
+        outs, metas = _surfaces(gpu_ctx, jp, pts, opts)
+        inflight.append((pipe.submit(jp, outs, pts, opts), pts, opts, outs, metas))
+    indexed = 0
+    for t, pts, opts, outs, metas in inflight:
+        st = pipe.wait(t)
+        _check(gpu_ctx, oracle, jp, pts, opts, outs, metas, st, names)
+        for i, n in enumerate(names):
+            h = J.PreparedImage(jp[i])
+            try:
+                idx, dc, flen = pipe.read_index(t, i, h.n_blocks)
+            except J.JdaError:
+                h.close()
+                continue                                               # (the serial path took it: one restart interval, ...)
+            if flen == len(h.scan()) and idx[-1] != 0:
+                assert J.index_equivalent(idx, h.block_index()[0]) and np.array_equal(dc, h.block_dc()), n
+                indexed += 1
+            h.close()
+        for o in outs:
+            gpu_ctx.free(o[0])
+    assert indexed >= 60
+    pipe.close()
