@@ -254,6 +254,28 @@ JDA_HD uint32_t jda_sat_pk_u8(uint32_t a)
 #endif
 }
 
+// low 32 bits of the product of two values below 2^24 (v_mul_u32_u24, full rate)
+JDA_HD uint32_t jda_umul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xffffffu) * (b & 0xffffffu);
+#endif
+}
+// a byte in all four bytes of a word (one v_perm_b32 where `x * 0x01010101` is a quarter-rate v_mul_lo_u32)
+JDA_HD uint32_t jda_dup8(uint32_t v) { return jda_perm(0, v, 0x00000000u); }
+// sum of the four byte products a.b[i] * b.b[i]  (v_dot4_u32_u8)
+JDA_HD uint32_t jda_udot4(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, 0u, false);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+    return r;
+#endif
+}
 JDA_HD uint32_t jda_dup16(int32_t v) { return jda_perm(0, (uint32_t)v, 0x01000100u); }        // low half in both halves
 JDA_HD uint32_t jda_pack16(int32_t lo, int32_t hi) { return jda_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
@@ -268,7 +290,8 @@ JDA_HD uint32_t jda_range_limit5(int32_t v) { return (uint32_t)jda_clamp255(jda_
 JDA_HD uint64_t jda_be64_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t pos)
 {
     // byte alignment and byte swap in one permute per half: result byte 3 = stream byte sh, .. byte 0 = stream byte sh + 3
-    const uint32_t sel = 0x00010203u + (pos & 3u) * 0x01010101u;
+    // 0x00010203 + (pos & 3) * 0x01010101 without the multiply: four bytes of the descending run 6 5 4 3 2 1 0
+    const uint32_t sel = jda_alignbyte(0x00000102u, 0x03040506u, ~pos);
     return ((uint64_t)jda_perm(w1, w0, sel) << 32) | jda_perm(w2, w1, sel);
 }
 
@@ -291,7 +314,7 @@ JDA_HD uint64_t jda_load_be64(const jda_bitreader &br, uint32_t pos)
     if (rel + 12u <= br.win_len) {                      // (a < win_lo wraps to a huge rel: falls through)
         // the LDS window holds the stream as byte-swapped dwords (jda_window_store): only the byte alignment is left
         const jda_u32_alias *p = (const jda_u32_alias *)(br.win + rel);
-        const uint32_t sel = 0x07060504u - (pos & 3u) * 0x01010101u;
+        const uint32_t sel = jda_alignbyte(0x08070605u, 0x04030201u, ~pos);      // 0x07060504 - (pos & 3) * 0x01010101
         return ((uint64_t)jda_perm(p[0], p[1], sel) << 32) | jda_perm(p[1], p[2], sel);
     }
     const jda_u32_alias JDA_GLOBAL *p = (const jda_u32_alias JDA_GLOBAL *)(br.base + a);
@@ -1165,6 +1188,18 @@ JDA_HD void jda_seg_flush_dc(int16_t *blk_dc, uint32_t g_new, uint32_t n, uint32
     if (n > 6u) o[-6] = (int16_t)(b0 >> 16);
     if (n > 7u) o[-7] = (int16_t)b0;
 }
+// the six 5-bit byte lags of a counting walk + n each (n <= 3): U + n * 0x02108421 on the 24-bit multiplier and a shift-add
+// (the 26-bit constant makes the product a quarter-rate v_mad_u64_u32, twice per symbol)
+JDA_HD uint32_t jda_lag_add(uint32_t U, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;                                                     // (written out: the compiler puts any product + sum it recognises back on v_mad_u64_u32)
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(n), "s"(0x00108421u), "v"(U));
+    return r + (n << 25);
+#else
+    return U + n * 0x02108421u;
+#endif
+}
 template <int OP, bool RST = false>
 JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *wt,
                              jda_seg_sum &S, jda_seg_stats &ST, uint32_t round = 0)
@@ -1319,7 +1354,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         }
         if (CNT) {
             nblk += (isdc & (sbad == 0u)) ? 1u : 0u;
-            U += (((p & 7u) + len) >> 3) * kOnes;                   // whole bytes the code bits advance the stream position by
+            U = jda_lag_add(U, ((p & 7u) + len) >> 3);                   // whole bytes the code bits advance the stream position by
             const uint32_t f1 = ((U | kGuard) - 6u * kOnes) & kGuard;
             if (REC) {
                 // SURVEY fact 6 without knowing the entry lag: the reference reads the magnitude at ulBitOff = 8 u + (p1 & 7) and loses
@@ -1339,7 +1374,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                 }
             }
             U &= dcmag ? ~(f1 - (f1 >> 4)) : 0xffffffffu;           // the refill before an unfolded DC magnitude
-            U += (((p1 & 7u) + sz) >> 3) * kOnes;
+            U = jda_lag_add(U, ((p1 & 7u) + sz) >> 3);
         }
         if (CNT || OP == JDA_SEG_WRITE) {                           // the DC difference (:2155-2165; a folded entry holds the same value)
             const int32_t diff = (isdc & (sz != 0u)) ? jda_extend_top(w << len, sz) : 0;
@@ -1401,7 +1436,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                     pred0 = pred1 = pred2 = 0;
                 }
                 if (CNT) {
-                    U += frac * kOnes;
+                    U = jda_lag_add(U, frac);
                     const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
                     U &= ~(f - (f >> 4));
                     ds0 = ds1 = ds2 = 0; has_rst = JDA_SEG_HAS_RESTART;
@@ -1455,7 +1490,8 @@ JDA_HD uint32_t jda_zero_byte_bits(uint32_t x)      // bit 7 of every byte that 
 {
     return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
 }
-JDA_HD uint32_t jda_byte_flags_to_nibble(uint32_t f) { return (((f >> 7) * 0x00204081u) >> 21) & 15u; }     // bits 7, 15, 23, 31 -> 0..3
+// bits 7, 15, 23, 31 -> 0..3 (one dot product of bytes; the multiply-and-shift of the textbook is a quarter-rate v_mul_lo_u32)
+JDA_HD uint32_t jda_byte_flags_to_nibble(uint32_t f) { return jda_udot4(f >> 7, 0x08040201u); }
 struct jda_filter_masks { uint32_t ff, zero, rst; };  // per byte of the sixteen: is FF / is 00 / is D0..D7
 JDA_HD jda_filter_masks jda_filter_classify(const uint32_t b[4])
 {
@@ -1490,7 +1526,9 @@ JDA_HD jda_filter_bits jda_filter_run(const jda_filter_masks &M, uint32_t valid,
 JDA_HD uint32_t jda_index_canonical(uint32_t p_abs) { return ((p_abs >> 3) << JDA_INDEX_OFF_BITS) | (p_abs & 7u); }
 struct jda_fin_acc { uint32_t bad, terminal, max_abs_dc; };
 // record i of segment seg (first block ordinal g0, predictors pr0..2 at its entry: jda_segscan_sums) -> index entry, predictor
-JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t g0, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
+// b0 = g0 % P.nblocks, inv = jda_fin_recip(P.nblocks): the block's place in the MCU without a division per record
+JDA_HD uint32_t jda_fin_recip(uint32_t nblocks) { return (65536u + nblocks - 1u) / nblocks; }      // x / n = x * inv >> 16 while x * n < 65536
+JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
 {
     const uint32_t g = g0 + i;
     if (g > P.n_blocks_total) return;                               // behind the image: padding decoded as blocks
@@ -1505,7 +1543,7 @@ JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_
         A.terminal++;
         return;
     }
-    const uint32_t b = g % P.nblocks, c = b < P.nluma ? 0u : b - P.nluma + 1u;
+    const uint32_t x = b0 + i, b = x - jda_umul24(jda_umul24(x, inv) >> 16, P.nblocks), c = b < P.nluma ? 0u : b - P.nluma + 1u;      // (x < 6 + rec_cap)
     const int32_t base = (rec & JDA_REC_AFTER_RST) ? 0 : (c == 0u ? pr0 : (c == 1u ? pr1 : pr2));      // (predictors restart at zero with an interval)
     const int32_t pred = base + ((int32_t)rec >> JDA_REC_POS_BITS);
     if (pred < -32768 || pred > 32767) A.bad = 1;
@@ -1797,14 +1835,14 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     const bool win_only = C.win_need <= br.win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
     if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
         if (win_only) jda_decode_block_win<1, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al, trunc); }
-        *(jda_u32_alias *)plane = jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u;
+        *(jda_u32_alias *)plane = jda_dup8(jda_range_limit5(pred * (int32_t)quant[0]));
         return JDA_NO_LIST;
     }
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
         uint32_t flags;
         if (win_only) flags = jda_decode_block_win<5, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc);
         else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred, dc_only, al, trunc); }
-        const uint32_t px = flags == 0 ? jda_range_limit5(pred * (int32_t)quant[0]) * 0x01010101u
+        const uint32_t px = flags == 0 ? jda_dup8(jda_range_limit5(pred * (int32_t)quant[0]))
                                        : jda_idct_2x2(coef, quant);
         *(jda_u32_alias *)plane = px;
         return JDA_NO_LIST;
@@ -1979,7 +2017,7 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, const uint8_t *tab, u
         const uint32_t c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
         const int32_t q0 = *(const int16_t *)(tab + JDA_LT_QUANT_OFF(jda_pick3(D.q_id, c)));
         const int32_t dc = *(const int16_t *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE);
-        const uint32_t v = jda_range_limit5(dc * q0) * 0x01010101u;
+        const uint32_t v = jda_dup8(jda_range_limit5(dc * q0));
         jda_u32_alias *dst = (jda_u32_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE);
 #pragma unroll
         for (int k = 0; k < 16; k++) dst[k] = v;
@@ -1990,15 +2028,6 @@ JDA_HD void jda_p3_rows(const jda_dev_desc &D, uint32_t t, const uint8_t *tab, u
 // i * d < 2^22 (here i < 16 * d and d <= 384, so i * d < 2.4M) and i * ceil(2^22 / d) < 2^32
 JDA_HD uint32_t jda_recip22(uint32_t d) { return ((1u << 22) + d - 1u) / d; }
 
-// low 32 bits of the product of two values below 2^24 (v_mul_u32_u24, full rate)
-JDA_HD uint32_t jda_umul24(uint32_t a, uint32_t b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(a, b);
-#else
-    return (a & 0xffffffu) * (b & 0xffffffu);
-#endif
-}
 
 // ---- P4: colour conversion + coalesced stores ------------------------------------------------------
 // four converted pixels -> memory in the requested format.  CLIP: the group may cross the right edge.

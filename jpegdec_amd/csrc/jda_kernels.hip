@@ -788,16 +788,18 @@ void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
 {
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
     if (!P.records || blockIdx.x * (4u * JDA_FIN_SEGS_PER_WAVE) >= P.n_segs) return;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;      // (uniform: addresses on the scalar unit)
     const uint32_t seg0 = (blockIdx.x * 4u + wave) * JDA_FIN_SEGS_PER_WAVE;
+    const uint32_t inv = jda_fin_recip(P.nblocks);
     jda_fin_acc A;
     A.bad = 0; A.terminal = 0; A.max_abs_dc = 0;
     // the segments' headers first, one lane each (one round trip for all of them), then segment after segment
-    uint32_t h_g0 = 0xffffffffu, h_n = 0, h_p0 = 0, h_p1 = 0, h_p2 = 0;
+    uint32_t h_g0 = 0xffffffffu, h_n = 0, h_p0 = 0, h_p1 = 0, h_p2 = 0, h_b0 = 0;
     if (lane < JDA_FIN_SEGS_PER_WAVE && seg0 + lane < P.n_segs) {
         const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)(seg0 + lane) * 5;
         h_g0 = st[0]; h_p0 = st[1]; h_p1 = st[2]; h_p2 = st[3];
         h_n = JDA_G(const uint32_t, P.seg_sum)[(size_t)(seg0 + lane) * JDA_SEG_SUM_WORDS];
+        h_b0 = h_g0 % P.nblocks;                                     // (the one division: the records take their place in the MCU from it)
     }
 #pragma unroll
     for (uint32_t k = 0; k < JDA_FIN_SEGS_PER_WAVE; k++) {
@@ -806,7 +808,8 @@ void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
         uint32_t nblk = (uint32_t)__builtin_amdgcn_readlane((int)h_n, (int)k);
         if (nblk > P.rec_cap) { nblk = P.rec_cap; A.bad = 1; }
         const int32_t pr0 = __builtin_amdgcn_readlane((int)h_p0, (int)k), pr1 = __builtin_amdgcn_readlane((int)h_p1, (int)k), pr2 = __builtin_amdgcn_readlane((int)h_p2, (int)k);
-        for (uint32_t i = lane; i < nblk; i += 64u) jda_finalize_item(P, seg0 + k, i, g0, pr0, pr1, pr2, A);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h_b0, (int)k);
+        for (uint32_t i = lane; i < nblk; i += 64u) jda_finalize_item(P, seg0 + k, i, g0, b0, inv, pr0, pr1, pr2, A);
     }
     const uint32_t m_dc = jda_wave_max_u32(A.max_abs_dc), n_term = jda_wave_sum_u32(A.terminal);
     const bool any_bad = __builtin_amdgcn_ballot_w64(A.bad != 0) != 0;
@@ -1033,7 +1036,10 @@ void jda_filter_write(const jda_filter_params *__restrict__ params)
     // (a branch per byte was sixteen exec-mask regions per thread).  FF 00 -> FF: the 00 that leaves in state 1 becomes the FF
     const uint32_t sz = F.S & M.zero;
 #pragma unroll
-    for (uint32_t d = 0; d < 4; d++) b[d] |= ((((sz >> (4u * d)) & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+    for (uint32_t d = 0; d < 4; d++) {                               // nibble -> 0xff in the bytes of its set bits (full-rate 24-bit multiply)
+        const uint32_t one = jda_umul24((sz >> (4u * d)) & 15u, 0x00204081u) & 0x01010101u;
+        b[d] |= (one << 8) - one;
+    }
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
         const bool emit = ((F.E >> k) & 1u) != 0u;

@@ -263,7 +263,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 if (st[0] > P.n_blocks_total) break;
                 uint32_t nblk = seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
                 if (nblk > P.rec_cap) { nblk = P.rec_cap; A.bad = 1; }
-                for (uint32_t i = 0; i < nblk; i++) jda_finalize_item(P, seg, i, st[0], (int32_t)st[1], (int32_t)st[2], (int32_t)st[3], A);
+                for (uint32_t i = 0; i < nblk; i++) jda_finalize_item(P, seg, i, st[0], st[0] % P.nblocks, jda_fin_recip(P.nblocks), (int32_t)st[1], (int32_t)st[2], (int32_t)st[3], A);
                 const uint32_t mac = (seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS + 5] >> 4) & 15u;
                 if (mac > ST.max_ac_bits) ST.max_ac_bits = mac;
             }
