@@ -1097,8 +1097,30 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
 //   table number from the block's place in the MCU, key from the stream.  A DC entry under that key is the reference's for every
 //   stream that has those bits, provided no DC code 111110.. is longer than 10 bits (jda_dc_lut_walkable: the front end keeps
 //   such a file -- none seen -- on the serial pre-scan).
-#define JDA_WT_TABLE_BYTES 4096u
+//   An entry is 32 bits: the low half the symbol (the decode kernel's jda_ac_entry layout / jda_dc16_entry), the high half -- AC
+//   tables, short keys -- the symbol BEHIND it where the key's ten bits hold that one's code too: two symbols a step (JDA_WT_PAIR_*;
+//   the second is described by what a walk needs of it: bits it takes, coefficients it moves on by, its magnitude's size).
+#define JDA_WT_TABLE_BYTES 8192u
 #define JDA_WT_BYTES (4u * JDA_WT_TABLE_BYTES)
+#define JDA_WT_PAIR_VALID 0x8000u                     // | size << 10 | (run + 1, 0 = EOB) << 5 | code + magnitude bits (<= 16)
+// the pair half of AC table entry `key` (< 1024): ac = the table's 2048 raw entries (length << 8 | RS, 0 = no code)
+JDA_HD uint32_t jda_wt_pair(const uint16_t JDA_GLOBAL *ac, uint32_t key)
+{
+    const uint32_t ea = jda_ac_entry(ac[key]);
+    if (JDA_AC_STOPS(ea)) return 0u;                                // EOB ends the block, no code ends the walk's luck: no second symbol
+    const uint32_t bits_a = (ea >> 12) + 1u + ((ea >> 8) & 15u);
+    if (bits_a > 9u) return 0u;
+    const uint32_t left = 10u - bits_a, key_b = (key << bits_a) & 1023u;      // the key's bits behind A, zeros behind them
+    if ((key_b >> 4) == 63u) return 0u;                             // six ones: a code of the table's long half
+    const uint32_t eb = jda_ac_entry(ac[key_b]);
+    if ((eb & 0xffu) == JDA_AC_NONE) return 0u;
+    const uint32_t len_b = (eb >> 12) + 1u;
+    if (len_b > left) return 0u;                                    // B's code is not all there (a longer code matched the zeros)
+    const bool eob = (eb & 0xffu) == JDA_AC_EOB;
+    const uint32_t sz_b = eob ? 0u : (eb >> 8) & 15u, run_b = (eb >> 1) & 15u;
+    if (len_b + sz_b > 16u) return 0u;                              // (a magnitude read the reference may truncate is a step of its own)
+    return JDA_WT_PAIR_VALID | (sz_b << 10) | ((eob ? 0u : run_b + 1u) << 5) | (len_b + sz_b);
+}
 JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
 {
     if (e8 == 0u) return JDA_AC_NONE;
@@ -1111,18 +1133,16 @@ JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
 // the segment walk's tables, staged by its workgroup (tid = thread in workgroup): wt holds JDA_WT_BYTES
 JDA_HD void jda_walk_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *wt)
 {
-    const jda_chunk16_alias JDA_GLOBAL *blob = JDA_G(const jda_chunk16_alias, tables);
-    jda_chunk16_alias *out = (jda_chunk16_alias *)wt;
-    for (uint32_t i = tid; i < 2u * JDA_WT_TABLE_BYTES / 16u; i += nthreads) {      // both halves of both AC tables -> the kernels' entries
-        jda_chunk16_alias c = blob[(JDA_TB_AC >> 4) + i];
-#pragma unroll
-        for (int k = 0; k < 4; k++) c.w[k] = jda_ac_entry(c.w[k] & 0xffffu) | (jda_ac_entry(c.w[k] >> 16) << 16);
-        out[i] = c;
+    const uint16_t JDA_GLOBAL *ac = JDA_G(const uint16_t, tables + JDA_TB_AC);
+    uint32_t *out = (uint32_t *)wt;
+    for (uint32_t j = tid; j < 4096u; j += nthreads) {                              // both halves of both AC tables -> the kernels' entries
+        const uint32_t t = j >> 11, key = j & 2047u;
+        out[j] = jda_ac_entry(ac[j]) | (key < 1024u ? jda_wt_pair(ac + t * 2048u, key) << 16 : 0u);
     }
     for (uint32_t j = tid; j < 4096u; j += nthreads) {                              // the DC tables under the same key
         const uint32_t t = j >> 11, idx = jda_dc_lut_index(jda_walk_key_code12(j & 2047u, 0u));
         const uint8_t JDA_GLOBAL *dc = JDA_G(const uint8_t, tables) + JDA_TB_DC + t * 1024u;
-        ((uint16_t *)(wt + 2u * JDA_WT_TABLE_BYTES))[j] = (uint16_t)jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]);
+        out[4096u + j] = jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]);
     }
 }
 // what a walker's workgroup does: a copy of the image's prepared tables (jda_walk_tables_build; 16 KB, one wait)
@@ -1207,6 +1227,10 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     const bool REC = OP == JDA_SEG_RECORD;                            // FUSED + records + truncation candidates
     const bool CNT = OP == JDA_SEG_COUNT || OP == JDA_SEG_FUSED || REC;      // the segment's sums are wanted
     const bool TOL = OP == JDA_SEG_SPEC || OP == JDA_SEG_FUSED || REC;       // a speculative walk steps over an invalid code
+#ifndef JDA_SEG_PAIR_OFF
+#define JDA_SEG_PAIR_OFF() false                                             // (host simulator: a switch, to count what the pairs save)
+#endif
+    const bool PAIR = !RST && OP != JDA_SEG_WRITE && !JDA_SEG_PAIR_OFF();                           // two AC symbols a step where the table holds the second (JDA_WT_PAIR_*)
     S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0; S.lag_last = 0; S.max_ac = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
     uint32_t p = entry & 63u, b2 = ((entry >> 6) & 7u) * 2u, k = (entry >> 9) & 63u;      // b2: twice the block's place in the MCU
@@ -1311,7 +1335,8 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         // stream's top 10 bits, or 1024 + the 10 bits behind six leading ones)
         const uint32_t tsel = jda_bfe(isdc0 ? dcsel : acsel, b2, 2u);
         const uint32_t key = jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
-        const uint32_t e = *(const uint16_t *)(wt + ((tsel << 12) | (key << 1)));
+        const uint32_t e32 = *(const jda_u32_alias *)(wt + ((tsel << 13) | (key << 2)));
+        const uint32_t e = e32 & 0xffffu;
         const uint32_t elow = e & 0xffu;
         // no such code (:2137-2138, :2237-2238).  A speculative walk that is not on the decoder's path yet may meet anything: it steps
         // on one bit and keeps looking (a walk that gave up would hand "dead" down the chain of segments, one per round) -- a
@@ -1410,6 +1435,26 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         }
         k = (ends | inval) ? 0u : kk + 1u;
         b2 = ends ? bn : b2;
+        if (PAIR) {
+            // the symbol behind an AC symbol that leaves its block open, where the table knows it (jda_wt_pair) and the segment goes
+            // on: what a step of its own would do to the walk's state -- an AC symbol moves p, k, the lags and the largest size
+            const uint32_t pd = e32 >> 16;
+            const bool pair = (pd != 0u) & live & !ends & (p < JDA_SEG_BITS);
+            const uint32_t bits_b = pair ? pd & 31u : 0u, dk = (pd >> 5) & 31u, kend = kk + 1u + dk;
+            const bool ends_b = pair & ((dk == 0u) | (kend >= 64u));
+            if (REC) {
+                const uint32_t m = (pair & (dk != 0u) & (kend <= 64u)) ? (pd >> 10) & 15u : 0u;      // (a stored magnitude: the coefficient's place is in the block)
+                max_ac = m > max_ac ? m : max_ac;
+            }
+            if (CNT) {                                              // (no pair: no bytes, and no lag is at 6 behind the refill above)
+                U = jda_lag_add(U, ((p & 7u) + bits_b) >> 3);
+                const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
+                U &= ~(f - (f >> 4));
+            }
+            p += bits_b;
+            k = pair ? (ends_b ? 0u : kend) : k;
+            b2 = ends_b ? bn : b2;
+        }
         if (OP == JDA_SEG_WRITE && ends && pending) {
             ib0 = ib1; ib1 = ib2; ib2 = ib3; ib3 = pend; ib_g = pend_g; ibn++;
             if ((pend_g & 3u) == 3u) {

@@ -604,7 +604,7 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     // Round 0 (exit states only: the lightest walk) runs FASTER with four workgroups per CU than with the eight its 16 KB of tables
     // allow (455 -> 365 us per 64-image batch; five: 407, two: 506): it is launched with 16 KB more than it uses (32 KB per workgroup: four fit).  The
     // counting rounds do not care (540 -> 585 at four).  JDA_WALK_LDS_R0 / JDA_WALK_LDS_R1: extra bytes, for measuring.
-    static const int lds_extra0 = []() { const char *e = getenv("JDA_WALK_LDS_R0"); return e ? atoi(e) : 16384; }();
+    static const int lds_extra0 = []() { const char *e = getenv("JDA_WALK_LDS_R0"); return e ? atoi(e) : 8192; }();
     static const int lds_extra1 = []() { const char *e = getenv("JDA_WALK_LDS_R1"); return e ? atoi(e) : 0; }();
     const int lds_max = JDA_WT_BYTES + (lds_extra0 > lds_extra1 ? lds_extra0 : lds_extra1);
     const int lds_bytes = JDA_WT_BYTES + (round == 0 ? lds_extra0 : lds_extra1);

@@ -14,7 +14,10 @@
 #include <vector>
 static unsigned g_seg_steps = 0;
 static std::vector<unsigned> g_blk_at;
-#define JDA_SEG_STEP_HOOK() (g_seg_steps++)
+static unsigned long long g_all_steps = 0;
+static bool g_pair_off = false;
+#define JDA_SEG_STEP_HOOK() (g_seg_steps++, g_all_steps++)
+#define JDA_SEG_PAIR_OFF() g_pair_off
 #define JDA_SEG_BLOCK_HOOK() (g_blk_at.push_back(g_seg_steps))
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
@@ -379,4 +382,12 @@ extern "C" int hostsim_fast_mul(const uint8_t *jpeg, int len)
     int f = (int)jda_image_fast_mul(img);
     jda_image_free(img);
     return f;
+}
+
+// steps of every walk since the last call (the pairs of the walk's tables: fewer steps for the same symbols); off != 0: walk symbol by symbol
+extern "C" unsigned long long hostsim_walk_steps(int off)
+{
+    const unsigned long long n = g_all_steps;
+    g_all_steps = 0; g_pair_off = off != 0;
+    return n;
 }

@@ -327,3 +327,27 @@ def test_record_mode_on_the_densest_streams(luma_hv, restart, hostsim, oracle):
         p.close()
     finally:
         hostsim.hostsim_set_device_prescan(0)
+
+
+@pytest.mark.parametrize("name", ["c420_1280x720", "c444_333x217", "c420_256x256_q98", "gray_333x217", "c444_256x256_q100_opt"])
+def test_two_symbols_a_step_changes_nothing_but_the_number_of_steps(name, hostsim, oracle):
+    """The walk's tables hold, behind an AC symbol, the symbol that follows it where the ten key bits contain that one's code too
+    (jda_wt_pair): a step then takes both.  Same index, same picture as the walk symbol by symbol -- in a third fewer steps."""
+    jpeg = jpeg_for(name)
+    hostsim.hostsim_walk_steps.restype = C.c_ulonglong
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        rc, want, err = oracle.decode_canvas(jpeg, J.RGB8888, 0)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, J.RGB8888, 0)
+        steps = []
+        for off in (1, 0):
+            hostsim.hostsim_walk_steps(off)
+            got = np.full_like(want, 0x33)
+            assert hostsim.hostsim_decode(jpeg, len(jpeg), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+            assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1
+            assert np.array_equal(got, want)
+            steps.append(hostsim.hostsim_walk_steps(0))
+        assert steps[1] < (0.97 if "q100" in name else 0.8) * steps[0], steps      # (q100: long codes, large magnitudes -- few pairs)
+    finally:
+        hostsim.hostsim_walk_steps(0)
+        hostsim.hostsim_set_device_prescan(0)
