@@ -1103,10 +1103,10 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
 #define JDA_WT_TABLE_BYTES 8192u
 #define JDA_WT_BYTES (4u * JDA_WT_TABLE_BYTES)
 #define JDA_WT_PAIR_VALID 0x8000u                     // | size << 10 | (run + 1, 0 = EOB) << 5 | code + magnitude bits (<= 16)
-// the pair half of AC table entry `key` (< 1024): ac = the table's 2048 raw entries (length << 8 | RS, 0 = no code)
-JDA_HD uint32_t jda_wt_pair(const uint16_t JDA_GLOBAL *ac, uint32_t key)
+// the pair half of the entry ea under `key` (< 1024): ac = the 2048 raw entries (length << 8 | RS, 0 = no code) of the AC table that
+// decodes the symbol behind it -- the table itself for an AC entry, the table of the component for a DC entry (jda_wt_dc_follow)
+JDA_HD uint32_t jda_wt_pair(uint32_t ea, const uint16_t JDA_GLOBAL *ac, uint32_t key)
 {
-    const uint32_t ea = jda_ac_entry(ac[key]);
     if (JDA_AC_STOPS(ea)) return 0u;                                // EOB ends the block, no code ends the walk's luck: no second symbol
     const uint32_t bits_a = (ea >> 12) + 1u + ((ea >> 8) & 15u);
     if (bits_a > 9u) return 0u;
@@ -1130,19 +1130,38 @@ JDA_HD uint32_t jda_dc16_entry(uint32_t e8, int32_t folded)
     return ((len - 1u) << 12) | (s << 8) | (fold ? 1u : 0u);
 }
 
+// which AC table decodes the symbol behind a DC symbol of DC table t (2 bits per t; 2: none -- the components that share the DC
+// table do not share an AC table): the DC entries take their pair halves from it
+JDA_HD uint32_t jda_wt_dc_follow(const jda_segscan_params &P)
+{
+    const uint32_t ncomp = P.nblocks > P.nluma ? 3u : 1u;
+    uint32_t f = 0;
+    for (uint32_t t = 0; t < 2u; t++) {
+        uint32_t seen = 3u;                                         // 3: no component uses DC table t
+        for (uint32_t c = 0; c < ncomp; c++) {
+            if ((P.dc_id[c] & 1u) != t) continue;
+            const uint32_t a = P.ac_id[c] & 1u;
+            seen = seen == 3u ? a : (seen == a ? a : 2u);
+        }
+        f |= (seen == 3u ? 2u : seen) << (2u * t);
+    }
+    return f;
+}
 // the segment walk's tables, staged by its workgroup (tid = thread in workgroup): wt holds JDA_WT_BYTES
-JDA_HD void jda_walk_tables_from(const uint8_t *tables, uint32_t tid, uint32_t nthreads, uint8_t *wt)
+JDA_HD void jda_walk_tables_from(const uint8_t *tables, uint32_t follow, uint32_t tid, uint32_t nthreads, uint8_t *wt)
 {
     const uint16_t JDA_GLOBAL *ac = JDA_G(const uint16_t, tables + JDA_TB_AC);
     uint32_t *out = (uint32_t *)wt;
     for (uint32_t j = tid; j < 4096u; j += nthreads) {                              // both halves of both AC tables -> the kernels' entries
         const uint32_t t = j >> 11, key = j & 2047u;
-        out[j] = jda_ac_entry(ac[j]) | (key < 1024u ? jda_wt_pair(ac + t * 2048u, key) << 16 : 0u);
+        const uint32_t ea = jda_ac_entry(ac[j]);
+        out[j] = ea | (key < 1024u ? jda_wt_pair(ea, ac + t * 2048u, key) << 16 : 0u);
     }
     for (uint32_t j = tid; j < 4096u; j += nthreads) {                              // the DC tables under the same key
         const uint32_t t = j >> 11, idx = jda_dc_lut_index(jda_walk_key_code12(j & 2047u, 0u));
         const uint8_t JDA_GLOBAL *dc = JDA_G(const uint8_t, tables) + JDA_TB_DC + t * 1024u;
-        out[4096u + j] = jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]);
+        const uint32_t ea = jda_dc16_entry(dc[idx], (int8_t)dc[idx + 512u]), key = j & 2047u, fa = (follow >> (2u * t)) & 3u;
+        out[4096u + j] = ea | (key < 1024u && fa < 2u ? jda_wt_pair(ea, ac + fa * 2048u, key) << 16 : 0u);
     }
 }
 // what a walker's workgroup does: a copy of the image's prepared tables (jda_walk_tables_build; 16 KB, one wait)

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(1024)
 void jda_walk_tables_build(const jda_segscan_params *__restrict__ params)
 {
     const jda_segscan_params &P = params[blockIdx.x];
-    jda_walk_tables_from(P.tables, threadIdx.x, 1024u, P.walk_tables);
+    jda_walk_tables_from(P.tables, jda_wt_dc_follow(P), threadIdx.x, 1024u, P.walk_tables);
 }
 extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream)
 {

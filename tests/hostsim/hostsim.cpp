@@ -124,7 +124,6 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         memcpy(padded.data(), scan, sl);
         std::vector<uint64_t> lt_store((JDA_WT_BYTES + 7) / 8);
         uint8_t *lt = (uint8_t *)lt_store.data();
-        for (uint32_t tid = 0; tid < 256; tid++) jda_walk_tables_from(tables, tid, 256, lt);
 
         std::vector<uint32_t> ea(n_segs + 1, 0), eb(n_segs + 1, 0), seg_sum((size_t)n_segs * JDA_SEG_SUM_WORDS), seg_start((size_t)n_segs * 5, 0);
         jda_segscan_params P;
@@ -144,6 +143,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             P.restart_pos = rp.data(); P.n_intervals = n_int; P.interval_blocks = (uint32_t)I->restart_interval * P.nblocks;
             P.round_last = ((uint32_t)(I->mcus_x * I->mcus_y) % (uint32_t)I->restart_interval) == 0 ? 1u : 0u;
         }
+        for (uint32_t tid = 0; tid < 256; tid++) jda_walk_tables_from(tables, jda_wt_dc_follow(P), tid, 256, lt);
         const bool rst = P.restart_pos != nullptr;
         // RECORD mode (streams without restart intervals), as jda_pipeline / jda_upload_batch run it
         const bool record = !g_no_record && jda_image_record_cap(img) != 0;

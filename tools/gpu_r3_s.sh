@@ -8,7 +8,7 @@ for lib in ab/lib_before.so jpegdec_amd/libjpegdec_amd.so; do
   tag=$(basename $lib .so)
   (cd /tmp && JDA_LIBRARY=$R/$lib timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out -o d1_$tag -- python $R/tools/pipeline_bench.py --depth 1 --batches 8 --distinct 16 > /dev/null 2>&1)
 done
-for x in 0 16384; do
+for x in; do
   (cd /tmp && JDA_WALK_LDS_R0=$x timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out -o d1_r0lds$x -- python $R/tools/pipeline_bench.py --depth 1 --batches 8 --distinct 16 > /dev/null 2>&1)
 done
 for rep in 1 2 3; do
