@@ -1270,7 +1270,8 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 8;
     uint32_t U = 0;                                                 // COUNT: the six byte lags
     const uint32_t kOnes = 0x02108421u, kGuard = 0x21084210u;       // 1 / 16 in each 5-bit field
-    uint32_t nblk = 0, sbad = 0;
+    uint32_t nblk = 0;
+    bool sbad = false;                                              // (a flag per lane: the compiler keeps it as a lane mask on the scalar unit)
     int32_t ds0 = 0, ds1 = 0, ds2 = 0;
     uint32_t max_ac = 0, max_dc = 0;
     if (OP == JDA_SEG_WRITE) {
@@ -1354,14 +1355,14 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         // stream's top 10 bits, or 1024 + the 10 bits behind six leading ones)
         const uint32_t tsel = jda_bfe(isdc0 ? dcsel : acsel, b2, 2u);
         const uint32_t key = jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);
-        const uint32_t e32 = *(const jda_u32_alias *)(wt + ((tsel << 13) | (key << 2)));
+        const uint32_t e32 = *(const jda_u32_alias *)(wt + (tsel << 13) + (key << 2));      // (sums: two shift-adds onto the tables' address)
         const uint32_t e = e32 & 0xffffu;
         const uint32_t elow = e & 0xffu;
         // no such code (:2137-2138, :2237-2238).  A speculative walk that is not on the decoder's path yet may meet anything: it steps
         // on one bit and keeps looking (a walk that gave up would hand "dead" down the chain of segments, one per round) -- a
         // one-bit symbol without effects, by selects; the other passes stop.
         const bool inval = elow == JDA_AC_NONE;
-        if (TOL) sbad |= inval ? 1u : 0u; else { bad |= inval; stop |= inval; }
+        if (TOL) sbad |= inval; else { bad |= inval; stop |= inval; }
         const bool live = !inval & !stop;                           // the step's effects count
         const bool isdc = isdc0 & live;
         const bool eob = (elow == JDA_AC_EOB) & !inval;
@@ -1384,20 +1385,20 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             off += sz;
         }
         if (REC) {                                                  // a counted block starts here: its record (before its own difference joins the sum)
-            const bool counted = isdc & (sbad == 0u);
+            const bool counted = isdc & !sbad;
             const int32_t run = c == 0 ? ds0 : (c == 1 ? ds1 : ds2);
             const uint32_t rec = p | (RST && has_rst ? JDA_REC_AFTER_RST : 0u) | ((uint32_t)run << JDA_REC_POS_BITS);
             rb0 = counted ? rb1 : rb0; rb1 = counted ? rb2 : rb1; rb2 = counted ? rb3 : rb2; rb3 = counted ? rec : rb3;
             Ublk = counted ? U : Ublk;
             if (counted && (nblk & 3u) == 3u) {
                 if (nblk < P.rec_cap) jda_store_u32x4(recs + (nblk - 3u), rb0, rb1, rb2, rb3);
-                else sbad |= 1u;                                    // (jda_record_cap leaves no room for this; memory stays ours anyway)
+                else sbad = true;                                   // (jda_record_cap leaves no room for this; memory stays ours anyway)
             }
             // a DC category no 8-bit baseline stream has does not fit the record's 20-bit sum: such a file keeps to the serial pre-scan
-            sbad |= (isdc & (sz > 11u)) ? 1u : 0u;
+            sbad |= isdc & (sz > 11u);
         }
         if (CNT) {
-            nblk += (isdc & (sbad == 0u)) ? 1u : 0u;
+            nblk += (isdc & !sbad) ? 1u : 0u;
             U = jda_lag_add(U, ((p & 7u) + len) >> 3);                   // whole bytes the code bits advance the stream position by
             const uint32_t f1 = ((U | kGuard) - 6u * kOnes) & kGuard;
             if (REC) {
@@ -1407,7 +1408,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                 // (ulBitOff <= 47 in front of the code for every candidate lag: code + magnitude must be 17 bits and more -- rare symbols)
                 const uint32_t m = acmag ? sz : 0u;
                 max_ac = m > max_ac ? m : max_ac;
-                if (__builtin_expect(acmag && len + sz > 16u && sbad == 0u, 0)) {
+                if (__builtin_expect(acmag && len + sz > 16u && !sbad, 0)) {
                     const uint32_t t = (p1 & 7u) + sz;
                     const uint32_t f7 = ((U | kGuard) - 7u * kOnes) & kGuard;
                     const uint32_t hit = t > 16u ? f1 : (t > 8u ? f7 : 0u);
@@ -1505,7 +1506,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                     U &= ~(f - (f >> 4));
                     ds0 = ds1 = ds2 = 0; has_rst = JDA_SEG_HAS_RESTART;
                 }
-                if (REC && sbad == 0u && nr < P.n_intervals) {      // who ended the interval in front of start nr, and after how many of its blocks
+                if (REC && !sbad && nr < P.n_intervals) {      // who ended the interval in front of start nr, and after how many of its blocks
                     uint32_t JDA_GLOBAL *ev = JDA_G(uint32_t, P.rst_events) + 2u * (size_t)nr;
                     ev[0] = (seg << 11) | (nblk + 1u); ev[1] = round;
                 }
@@ -1532,7 +1533,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         }
         S.lag_last = Ublk; S.max_ac = max_ac;
     }
-    S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2; S.bad = sbad | has_rst;
+    S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2; S.bad = (sbad ? 1u : 0u) | has_rst;
     if (bad) { S.bad = 1; ST.bad = 1; return JDA_SEG_DEAD; }
     if (CNT) {
         uint32_t map = 0;
