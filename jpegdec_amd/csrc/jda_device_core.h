@@ -1593,11 +1593,12 @@ struct jda_fin_acc { uint32_t bad, terminal, max_abs_dc; };
 // record i of segment seg (first block ordinal g0, predictors pr0..2 at its entry: jda_segscan_sums) -> index entry, predictor
 // b0 = g0 % P.nblocks, inv = jda_fin_recip(P.nblocks): the block's place in the MCU without a division per record
 JDA_HD uint32_t jda_fin_recip(uint32_t nblocks) { return (65536u + nblocks - 1u) / nblocks; }      // x / n = x * inv >> 16 while x * n < 65536
-JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
+// (the record's load apart from its use: the kernel asks for the records of several segments before it waits for the first)
+JDA_HD uint32_t jda_finalize_load(const jda_segscan_params &P, uint32_t seg, uint32_t i) { return JDA_G(const uint32_t, P.records)[(size_t)seg * P.rec_cap + i]; }
+JDA_HD void jda_finalize_apply(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t rec, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
 {
     const uint32_t g = g0 + i;
     if (g > P.n_blocks_total) return;                               // behind the image: padding decoded as blocks
-    const uint32_t rec = JDA_G(const uint32_t, P.records)[(size_t)seg * P.rec_cap + i];
     const uint32_t p_abs = seg * JDA_SEG_BITS + (rec & (JDA_SEG_BITS - 1u));
     // a stream that ends early has been read on into its zero padding: the serial pre-scan knows what the reference does with it
     // (its test is on the reference's pBuf, at most five bytes behind: the margin makes this one the stricter)
@@ -1616,6 +1617,11 @@ JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_
     A.max_abs_dc = a > A.max_abs_dc ? a : A.max_abs_dc;
     JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical(p_abs);
     JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pred;
+}
+JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
+{
+    if (g0 + i > P.n_blocks_total) return;
+    jda_finalize_apply(P, seg, i, jda_finalize_load(P, seg, i), g0, b0, inv, pr0, pr1, pr2, A);
 }
 // candidate ci: a magnitude read that some entry lag of its segment truncates.  With the segment's true lag known: does it?  Then
 // the block's entry becomes the reference reader's true phase + the flag.  Returns 1 for a truncated read (the serial pre-scan's count).

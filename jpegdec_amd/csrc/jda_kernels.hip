@@ -781,7 +781,7 @@ extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params,
 // wavefront per segment, sixteen segments one after the other, lane = record: coalesced reads and writes, no walk.  Result words as
 // WRITE left them: [0] bad (a predictor out of range, a stream read on into its padding), [1] closing entry written, [3] max |DC|.
 #ifndef JDA_FIN_SEGS_PER_WAVE
-#define JDA_FIN_SEGS_PER_WAVE 4u
+#define JDA_FIN_SEGS_PER_WAVE 8u
 #endif
 __global__ __launch_bounds__(256)
 void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
@@ -801,15 +801,23 @@ void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
         h_n = JDA_G(const uint32_t, P.seg_sum)[(size_t)(seg0 + lane) * JDA_SEG_SUM_WORDS];
         h_b0 = h_g0 % P.nblocks;                                     // (the one division: the records take their place in the MCU from it)
     }
+    // every segment's first 64 records are asked for before the first is used: one trip to memory for the wavefront, not one per segment
+    // (a segment behind the image, behind a bad code (g0 = 0xfffffff0) or that does not exist has no records)
+    if (h_n > P.rec_cap) { h_n = P.rec_cap; A.bad = 1; }
+    if (h_g0 > P.n_blocks_total) h_n = 0;
+    uint32_t rec[JDA_FIN_SEGS_PER_WAVE];
 #pragma unroll
     for (uint32_t k = 0; k < JDA_FIN_SEGS_PER_WAVE; k++) {
-        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)h_g0, (int)k);
-        if (g0 > P.n_blocks_total) break;                            // behind the image, behind a bad code (0xfffffff0), or no such segment
-        uint32_t nblk = (uint32_t)__builtin_amdgcn_readlane((int)h_n, (int)k);
-        if (nblk > P.rec_cap) { nblk = P.rec_cap; A.bad = 1; }
+        const uint32_t nblk = (uint32_t)__builtin_amdgcn_readlane((int)h_n, (int)k);
+        rec[k] = lane < nblk ? jda_finalize_load(P, seg0 + k, lane) : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_FIN_SEGS_PER_WAVE; k++) {
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)h_g0, (int)k), nblk = (uint32_t)__builtin_amdgcn_readlane((int)h_n, (int)k);
         const int32_t pr0 = __builtin_amdgcn_readlane((int)h_p0, (int)k), pr1 = __builtin_amdgcn_readlane((int)h_p1, (int)k), pr2 = __builtin_amdgcn_readlane((int)h_p2, (int)k);
         const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h_b0, (int)k);
-        for (uint32_t i = lane; i < nblk; i += 64u) jda_finalize_item(P, seg0 + k, i, g0, b0, inv, pr0, pr1, pr2, A);
+        if (lane < nblk) jda_finalize_apply(P, seg0 + k, lane, rec[k], g0, b0, inv, pr0, pr1, pr2, A);
+        for (uint32_t i = lane + 64u; i < nblk; i += 64u) jda_finalize_item(P, seg0 + k, i, g0, b0, inv, pr0, pr1, pr2, A);      // (the densest streams)
     }
     const uint32_t m_dc = jda_wave_max_u32(A.max_abs_dc), n_term = jda_wave_sum_u32(A.terminal);
     const bool any_bad = __builtin_amdgcn_ballot_w64(A.bad != 0) != 0;
