@@ -1069,7 +1069,9 @@ struct jda_seg_reader {
     uint32_t hi, lo;                // stream bits, first byte on top
     uint32_t n1, n2, n3;            // the dwords behind lo, as loaded (little endian); valid while idx - base <= 3
 };
+#ifndef JDA_SEG_REFILL_STEPS
 #define JDA_SEG_REFILL_STEPS 8u
+#endif
 JDA_HD void jda_seg_reader_init(jda_seg_reader &R, const uint32_t JDA_GLOBAL *d, uint32_t p)
 {
     R.d = d; R.idx = R.base = p >> 5;
