@@ -1251,7 +1251,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
 #ifndef JDA_SEG_PAIR_OFF
 #define JDA_SEG_PAIR_OFF() false                                             // (host simulator: a switch, to count what the pairs save)
 #endif
-    const bool PAIR = !RST && OP != JDA_SEG_WRITE && !JDA_SEG_PAIR_OFF();                           // two AC symbols a step where the table holds the second (JDA_WT_PAIR_*)
+    const bool PAIR = OP != JDA_SEG_WRITE && !JDA_SEG_PAIR_OFF();                           // two AC symbols a step where the table holds the second (JDA_WT_PAIR_*)
     S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0; S.lag_last = 0; S.max_ac = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
     uint32_t p = entry & 63u, b2 = ((entry >> 6) & 7u) * 2u, k = (entry >> 9) & 63u;      // b2: twice the block's place in the MCU
@@ -1461,17 +1461,20 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             // the symbol behind an AC symbol that leaves its block open, where the table knows it (jda_wt_pair) and the segment goes
             // on: what a step of its own would do to the walk's state -- an AC symbol moves p, k, the lags and the largest size
             const uint32_t pd = e32 >> 16;
-            const bool pair = (pd != 0u) & live & !ends & (p < JDA_SEG_BITS);
-            const uint32_t bits_b = pair ? pd & 31u : 0u, dk = (pd >> 5) & 31u, kend = kk + 1u + dk;
-            const bool ends_b = pair & ((dk == 0u) | (kend >= 64u));
+            const uint32_t dk = (pd >> 5) & 31u, kend = kk + 1u + dk;
+            const bool last_b = (dk == 0u) | (kend >= 64u);         // B would end its block
+            // (RST: a symbol that completes an MCU may complete the interval -- a step of its own, for the test above)
+            const bool pair = (pd != 0u) & live & !ends & (p < JDA_SEG_BITS) & !(RST & last_b & (bn == 0u));
+            const uint32_t bits_b = pair ? pd & 31u : 0u;
+            const bool ends_b = pair & last_b;
             if (REC) {
                 const uint32_t m = (pair & (dk != 0u) & (kend <= 64u)) ? (pd >> 10) & 15u : 0u;      // (a stored magnitude: the coefficient's place is in the block)
                 max_ac = m > max_ac ? m : max_ac;
             }
-            if (CNT) {                                              // (no pair: no bytes, and no lag is at 6 behind the refill above)
+            if (CNT) {                                              // (no pair: no bytes, and no lag is at 6 behind the refill above ..
                 U = jda_lag_add(U, ((p & 7u) + bits_b) >> 3);
                 const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
-                U &= ~(f - (f >> 4));
+                U &= (RST && !pair) ? 0xffffffffu : ~(f - (f >> 4)); // .. but behind an interval's closing EOB, whose refill waits: RST)
             }
             p += bits_b;
             k = pair ? (ends_b ? 0u : kend) : k;

@@ -143,14 +143,16 @@ def _codes(bits, vals):
 
 
 def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), restart_interval: int = 0,
-                       dup_eob: bool = False, long_dc: bool = False) -> bytes:
+                       dup_eob: bool = False, long_dc: bool = False, table_ids=((0, 0), (1, 1), (1, 1))) -> bytes:
     """Baseline JPEG of an HxWx3 RGB image with luma sampling factors luma_hv = (H, V) and 1x1 chroma:
     (1,1) 4:4:4, (2,1) 4:2:2, (1,2) 4:4:0, (2,2) 4:2:0.
     dup_eob: both AC tables code the end-of-block symbol twice (a second, 16-bit code) and every other block ends with
     the second one -- a malformed but decodable DHT (decoders with per-code LUTs do not notice).
     long_dc: both DC tables give categories 0-4 codes of 1-5 bits and categories 5-11 codes of ELEVEN bits, 11111000000 ..
     11111000110 -- legal, and codes that start 111110 and are longer than 10 bits are what the device pre-scan's 11-bit table
-    key cannot tell apart (jda_dc_lut_walkable): such a file must stay on the serial pre-scan."""
+    key cannot tell apart (jda_dc_lut_walkable): such a file must stay on the serial pre-scan.
+    table_ids: (DC table, AC table) of Y, Cb, Cr -- e.g. ((0, 0), (0, 1), (1, 1)): two components share a DC table and not their
+    AC table (the walk's DC entries cannot know which AC symbol follows them: jda_wt_dc_follow)."""
     hs, vs = luma_hv
     h, w = pixels.shape[:2]
     rgb = pixels.astype(np.float64)
@@ -221,10 +223,11 @@ def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), re
         s = a.bit_length()
         return s, (int(v) if v >= 0 else int(v) + (1 << s) - 1)
 
-    def emit_block(blk, t, pred):
+    def emit_block(blk, c, pred):
+        td, t = table_ids[c]
         zz = blk.reshape(64)[_ZIGZAG]
         s, bits = mag(zz[0] - pred)
-        put(*dc_t[t][s])
+        put(*dc_t[td][s])
         if s:
             put(bits, s)
         run = 0
@@ -260,7 +263,7 @@ def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), re
                 for bx in range(hs):
                     pred[0] = emit_block(cb[0][my * vs + by, mx * hs + bx], 0, pred[0])
             pred[1] = emit_block(cb[1][my, mx], 1, pred[1])
-            pred[2] = emit_block(cb[2][my, mx], 1, pred[2])
+            pred[2] = emit_block(cb[2][my, mx], 2, pred[2])
             n_mcu += 1
     if nacc:
         put((1 << (8 - nacc)) - 1, 8 - nacc)
@@ -276,6 +279,7 @@ def encode_jpeg_custom(pixels: np.ndarray, quality: int = 85, luma_hv=(1, 2), re
         hdr += seg(0xC4, bytes([(tc << 4) | th]) + bytes(bits) + bytes(vals))
     if restart_interval:
         hdr += seg(0xDD, restart_interval.to_bytes(2, "big"))
-    hdr += seg(0xDA, bytes([3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0]))
+    hdr += seg(0xDA, bytes([3, 1, (table_ids[0][0] << 4) | table_ids[0][1], 2, (table_ids[1][0] << 4) | table_ids[1][1],
+                            3, (table_ids[2][0] << 4) | table_ids[2][1], 0, 63, 0]))
     # pad small files: the reference rejects anything under 256 bytes (jpeg.inl:1598)
     return bytes(hdr) + bytes(out) + b"\xff\xd9"

@@ -269,6 +269,32 @@ def test_pipeline_on_the_densest_streams(gpu_ctx, oracle):
         gpu_ctx.free(o[0])
 
 
+def test_pipeline_table_assignments_of_the_components(gpu_ctx, oracle):
+    """Components that share a DC table and not their AC table, crossed assignments (DC 0 with AC 1): the walk's DC entries take the
+    first AC symbol along only where one AC table follows them (jda_wt_dc_follow); device index == the serial one, pixels == the oracle's."""
+    from jpegdec_amd.synth import encode_jpeg_custom
+    rng = np.random.default_rng(5)
+    img = np.clip(rng.normal(128, 40, (200, 328, 3)) + np.linspace(0, 60, 328)[None, :, None], 0, 255).astype(np.uint8)
+    ids = [((0, 0), (0, 1), (1, 1)), ((0, 1), (1, 0), (1, 0)), ((1, 1), (0, 0), (0, 1)), ((0, 0), (1, 1), (1, 1))]
+    jp = [encode_jpeg_custom(img, 80, (2, 2) if i % 2 == 0 else (1, 1), table_ids=t) for i, t in enumerate(ids)]
+    names = ["ids_%d" % i for i in range(len(jp))]
+    pts, opts = [J.RGB8888] * len(jp), [0] * len(jp)
+    pipe = J.Pipeline(gpu_ctx, max_images=8, depth=2, host_threads=2)
+    outs, metas = _surfaces(gpu_ctx, jp, pts, opts)
+    t = pipe.submit(jp, outs, pts, opts)
+    st = pipe.wait(t)
+    _check(gpu_ctx, oracle, jp, pts, opts, outs, metas, st, names)
+    for i, n in enumerate(names):
+        h = J.PreparedImage(jp[i])
+        idx, dc, flen = pipe.read_index(t, i, h.n_blocks)
+        assert J.index_equivalent(idx, h.block_index()[0]) and np.array_equal(dc, h.block_dc()), n
+        h.close()
+    assert pipe.stats["device_images"] == len(jp) and pipe.stats["host_path_images"] == 0
+    pipe.close()
+    for o in outs:
+        gpu_ctx.free(o[0])
+
+
 def test_pipeline_random_shapes_qualities_and_restart_intervals(gpu_ctx, oracle):
     """A sweep the fixed cases do not cover: 60 files of random size (1-700 pixels a side, ragged edges), layout, quality 20-100 and
     restart interval through ONE pipeline in two batches, four pixel types and scales mixed: statuses and pixels == the oracle's, and the

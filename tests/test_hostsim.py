@@ -351,3 +351,49 @@ def test_two_symbols_a_step_changes_nothing_but_the_number_of_steps(name, hostsi
     finally:
         hostsim.hostsim_walk_steps(0)
         hostsim.hostsim_set_device_prescan(0)
+
+
+@pytest.mark.parametrize("table_ids", [((0, 0), (0, 1), (1, 1)), ((0, 1), (1, 0), (1, 0)), ((1, 1), (0, 0), (0, 1))])
+def test_components_that_share_a_dc_table_and_not_their_ac_table(table_ids, hostsim, oracle):
+    """A DC entry of the walk's tables takes the first AC symbol of its block along -- from the AC table of the components that use
+    the DC table (jda_wt_dc_follow).  Where two of them use different AC tables there is no such table: those DC entries stay
+    single; crossed assignments (DC 0 with AC 1) follow the cross.  Index and picture as ever."""
+    from jpegdec_amd.synth import encode_jpeg_custom
+    rng = np.random.default_rng(5)
+    img = np.clip(rng.normal(128, 40, (96, 160, 3)) + np.linspace(0, 60, 160)[None, :, None], 0, 255).astype(np.uint8)
+    jpeg = encode_jpeg_custom(img, 80, (2, 2), table_ids=table_ids)
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        rc, want, err = oracle.decode_canvas(jpeg, J.RGB8888, 0)
+        assert rc == 1
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, J.RGB8888, 0)
+        assert hostsim.hostsim_decode(jpeg, len(jpeg), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1
+        assert np.array_equal(got, want)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+
+
+@pytest.mark.parametrize("luma_hv,restart,quality", [((2, 2), 3, 100), ((2, 2), 7, 100), ((1, 1), 5, 100), ((2, 1), 2, 98), ((2, 2), 1, 100)])
+def test_truncated_reads_in_streams_with_restart_intervals(luma_hv, restart, quality, hostsim, oracle):
+    """Noise at quality 98-100: magnitude reads the reference truncates, in intervals of a few MCUs -- the byte lags behind an
+    interval's closing EOB (whose refill waits for the rounding) must come out right for the flags to: whole index entries compared."""
+    from jpegdec_amd.synth import encode_jpeg_custom
+    rng = np.random.default_rng(restart * 10 + quality)
+    img = rng.integers(0, 256, (112, 176, 3)).astype(np.uint8)
+    jpeg = encode_jpeg_custom(img, quality, luma_hv, restart_interval=restart)
+    p = J.PreparedImage(jpeg)
+    assert p.truncation_events() >= 2                             # (the test means something)
+    p.close()
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        rc, want, err = oracle.decode_canvas(jpeg, J.RGB8888, 0)
+        assert rc == 1
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, J.RGB8888, 0)
+        assert hostsim.hostsim_decode(jpeg, len(jpeg), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1
+        assert np.array_equal(got, want)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
