@@ -914,8 +914,10 @@ __device__ __forceinline__ jda_fsm jda_filter_thread(const jda_filter_params &P,
     X.w1 = (uint32_t)__builtin_popcount(F0.R) | ((uint32_t)__builtin_popcount(F1.R) << 16);
     return X;
 }
-// inclusive scan of the functions of a workgroup's 1024 threads (wt: 16 entries of LDS); total: the whole chunk's
-__device__ __forceinline__ jda_fsm jda_fsm_block_scan(jda_fsm v, uint32_t tid, jda_fsm *wt, jda_fsm &total)
+// inclusive scan of the functions of a workgroup's 1024 threads (wt: 32 entries of LDS); total: the whole chunk's, pre: the
+// wavefronts' in front of this thread's.  The sixteen wavefront totals are scanned ONCE, by sixteen lanes of the first wavefront
+// (every thread composing all sixteen for itself was 480 of the kernels' 730 instructions per thread).
+__device__ __forceinline__ jda_fsm jda_fsm_block_scan(jda_fsm v, uint32_t tid, jda_fsm *wt, jda_fsm &total, jda_fsm &pre)
 {
     const uint32_t lane = tid & 63u, wave = tid >> 6;
 #pragma unroll
@@ -926,13 +928,21 @@ __device__ __forceinline__ jda_fsm jda_fsm_block_scan(jda_fsm v, uint32_t tid, j
     }
     if (lane == 63u) wt[wave] = v;
     __syncthreads();
-    jda_fsm pre; pre.w0 = JDA_FSM_IDENTITY_W0; pre.w1 = 0;
-    total = pre;
-    for (uint32_t w = 0; w < 16u; w++) {                          // (uniform: sixteen wavefront totals)
-        const jda_fsm t = wt[w];
-        if (w < wave) pre = jda_fsm_compose(pre, t);
-        total = jda_fsm_compose(total, t);
+    if (wave == 0u) {                                             // (uniform per wavefront)
+        jda_fsm t; t.w0 = JDA_FSM_IDENTITY_W0; t.w1 = 0;
+        if (lane < 16u) t = wt[lane];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            jda_fsm o;
+            o.w0 = (uint32_t)__shfl_up((int)t.w0, d, 64); o.w1 = (uint32_t)__shfl_up((int)t.w1, d, 64);
+            if (lane >= (uint32_t)d) t = jda_fsm_compose(o, t);
+        }
+        if (lane < 16u) wt[16u + lane] = t;                         // [16 + w]: wavefronts 0 .. w
     }
+    __syncthreads();
+    pre.w0 = JDA_FSM_IDENTITY_W0; pre.w1 = 0;
+    if (wave) pre = wt[15u + wave];
+    total = wt[31];
     return jda_fsm_compose(pre, v);
 }
 // work, per image: [chunk] function (2 words) | [chunk] entry state, output offset, marker count (3 words)
@@ -941,14 +951,14 @@ __device__ __forceinline__ uint32_t jda_filter_chunks(uint32_t raw_len) { return
 __global__ __launch_bounds__(1024)
 void jda_filter_count(const jda_filter_params *__restrict__ params)
 {
-    __shared__ jda_fsm wt[16];
+    __shared__ jda_fsm wt[32];
     const jda_filter_params P = params[blockIdx.y];
     const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len);
     if (chunk >= n_chunks) return;
     uint32_t b[4], valid;
-    jda_fsm total;
+    jda_fsm total, pre;
     jda_filter_masks M;
-    (void)jda_fsm_block_scan(jda_filter_thread(P, chunk, threadIdx.x, b, valid, M), threadIdx.x, wt, total);
+    (void)jda_fsm_block_scan(jda_filter_thread(P, chunk, threadIdx.x, b, valid, M), threadIdx.x, wt, total, pre);
     if (threadIdx.x == 0) { P.work[2u * chunk] = total.w0; P.work[2u * chunk + 1u] = total.w1; }
 }
 
@@ -1010,7 +1020,7 @@ void jda_filter_carry(const jda_filter_params *__restrict__ params)
 __global__ __launch_bounds__(1024)
 void jda_filter_write(const jda_filter_params *__restrict__ params)
 {
-    __shared__ jda_fsm wt[16];
+    __shared__ jda_fsm wt[32];
     __shared__ __attribute__((aligned(16))) uint8_t stage[JDA_FILTER_CHUNK + 32];
     const jda_filter_params P = params[blockIdx.y];
     const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len), tid = threadIdx.x;
@@ -1018,17 +1028,14 @@ void jda_filter_write(const jda_filter_params *__restrict__ params)
     const uint32_t *carry = P.work + 2u * n_chunks + 3u * chunk;
     const uint32_t state = carry[0], out_base = carry[1], rst_base = carry[2];
     uint32_t b[4], valid;
-    jda_fsm total;
+    jda_fsm total, pre;
     jda_filter_masks M;
     const jda_fsm X = jda_filter_thread(P, chunk, tid, b, valid, M);
-    const jda_fsm incl = jda_fsm_block_scan(X, tid, wt, total);
+    const jda_fsm incl = jda_fsm_block_scan(X, tid, wt, total, pre);
     // this thread's entry: the functions of all threads before it, applied to the chunk's entry
     jda_fsm E;
     E.w0 = (uint32_t)__shfl_up((int)incl.w0, 1, 64); E.w1 = (uint32_t)__shfl_up((int)incl.w1, 1, 64);
-    if ((tid & 63u) == 0u) {                                      // (lane 0: the wavefronts before this one)
-        E.w0 = JDA_FSM_IDENTITY_W0; E.w1 = 0;
-        for (uint32_t w = 0; w < (tid >> 6); w++) E = jda_fsm_compose(E, wt[w]);
-    }
+    if ((tid & 63u) == 0u) E = pre;                               // (lane 0: the wavefronts before this one)
     const uint32_t st = (E.w0 >> state) & 1u;
     const uint32_t mis = out_base & 15u;                          // the staged bytes sit at the alignment they will have in memory
     uint32_t o = mis + ((E.w0 >> (2 + 15 * state)) & 0x7fffu);
