@@ -1092,7 +1092,7 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
 #define JDA_SEG_READ_DWORDS 68u     // dwords of the scan a walk may touch from its segment's start (64 + the window's reach)
 
 // The walks' DC entries: the reference's DC LUT (jpeg.inl:1098-1152) re-laid out like the AC entries -- (code length - 1) << 12 |
-// SSSS << 8 | folded -- so that one 16-bit lookup serves a DC and an AC symbol alike.  "folded" (bit 0): the reference takes code
+// SSSS << 8 | folded -- so that one lookup serves a DC and an AC symbol alike.  "folded" (bit 0): the reference takes code
 // and magnitude from the LUT in one step (:1132-1152) and does not refill between them.
 //   JDA_WT_* (the segment walk's own LDS layout): FOUR tables of 2048 entries -- AC 0, AC 1, DC 0, DC 1 -- under the AC tables'
 //   11-bit key (the stream's top 10 bits, or 1024 + the 10 bits behind six leading ones), so that a step computes ONE address:
@@ -1166,7 +1166,7 @@ JDA_HD void jda_walk_tables_from(const uint8_t *tables, uint32_t follow, uint32_
         out[4096u + j] = ea | (key < 1024u && fa < 2u ? jda_wt_pair(ea, ac + fa * 2048u, key) << 16 : 0u);
     }
 }
-// what a walker's workgroup does: a copy of the image's prepared tables (jda_walk_tables_build; 16 KB, one wait)
+// what a walker's workgroup does: a copy of the image's prepared tables (jda_walk_tables_build; 32 KB, one wait)
 JDA_HD void jda_walk_tables_stage(const uint8_t *prepared, uint32_t tid, uint32_t nthreads, uint8_t *wt)
 {
     const jda_chunk16_alias JDA_GLOBAL *src = JDA_G(const jda_chunk16_alias, prepared);
@@ -1176,7 +1176,7 @@ JDA_HD void jda_walk_tables_stage(const uint8_t *prepared, uint32_t tid, uint32_
 // One walk of a segment.  wt: the walk's tables (jda_walk_tables_from); segw: the segment's first dword in the (zero-padded)
 // filtered scan.
 //
-// A step decodes ONE symbol, DC or AC alike, without a branch on which it is: the lanes of a wavefront sit at unrelated places
+// A step decodes a symbol (and the one behind it where the table entry describes it: JDA_WT_PAIR_*), DC or AC alike, without a branch on which it is: the lanes of a wavefront sit at unrelated places
 // of their blocks, so "if DC .. else AC .." ran both sides every step -- and every small `if` in the body costs an exec-mask
 // region (s_and_saveexec / s_cbranch / s_or), so the body is written with selects; what stays a branch is what is rare (a
 // truncated magnitude, an invalid code) or has to store (a block's start and end in the WRITE pass).  The reference's refills
@@ -1353,7 +1353,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             g += begin ? 1u : 0u;
         }
         const uint32_t w = jda_seg_reader_peek(R, p);
-        // one 16-bit lookup, one address: the table by the block's place in the MCU and DC / AC, the entry by the 11-bit key (the
+        // one lookup, one address: the table by the block's place in the MCU and DC / AC, the entry by the 11-bit key (the
         // stream's top 10 bits, or 1024 + the 10 bits behind six leading ones)
         const uint32_t tsel = jda_bfe(isdc0 ? dcsel : acsel, b2, 2u);
         const uint32_t key = jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u);

@@ -601,9 +601,10 @@ void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t fi
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    // Round 0 (exit states only: the lightest walk) runs FASTER with four workgroups per CU than with the eight its 16 KB of tables
-    // allow (455 -> 365 us per 64-image batch; five: 407, two: 506): it is launched with 16 KB more than it uses (32 KB per workgroup: four fit).  The
-    // counting rounds do not care (540 -> 585 at four).  JDA_WALK_LDS_R0 / JDA_WALK_LDS_R1: extra bytes, for measuring.
+    // Round 0 (exit states only: the lightest walk) ran FASTER with four workgroups per CU than with the eight that 16 KB of tables
+    // allowed (455 -> 365 us per 64-image batch).  The tables are 32 KB now (pair halves): five fit; round 0 is launched with 8 KB more
+    // than it uses, which makes it four (251 us at five or four, 350 at two; the counting rounds: 331 at five or four, 401 at two --
+    // profiles/r03_walk_sq_counters.txt).  JDA_WALK_LDS_R0 / JDA_WALK_LDS_R1: extra bytes, for measuring.
     static const int lds_extra0 = []() { const char *e = getenv("JDA_WALK_LDS_R0"); return e ? atoi(e) : 8192; }();
     static const int lds_extra1 = []() { const char *e = getenv("JDA_WALK_LDS_R1"); return e ? atoi(e) : 0; }();
     const int lds_max = JDA_WT_BYTES + (lds_extra0 > lds_extra1 ? lds_extra0 : lds_extra1);
@@ -770,7 +771,7 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
 extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_WT_BYTES;               // the tables only: 16 KB per workgroup
+    const int lds_bytes = JDA_WT_BYTES;               // the tables only: 32 KB per workgroup
     static std::atomic<unsigned long long> attr_done(0);
     { const hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_write, lds_bytes, attr_done); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(jda_segscan_write, dim3((max_segs + 255u) / 256u, n_images), dim3(256), lds_bytes, stream, params);

@@ -467,8 +467,6 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         e = hipMemsetAsync(B + zero_begin, 0, zero_end - zero_begin, p->s_copy);
         if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, raw_end, hipMemcpyHostToDevice, p->s_copy);      // control blob + every file's scan
         S.st.h2d_bytes += (int64_t)raw_end;
-        // the marker filter rides on the copy stream, behind the batch's copy (three short launches over 16 KB chunks: it shares the GPU
-        // with whatever the other two streams have running)
         // The copy stream carries the memset and the copy ONLY: with the filter behind the copy on the same stream, the next batch's
         // 110 MB (2 ms at 55 GB/s) could not start before this batch's filter had run -- and the filter's workgroups wait for the decode
         // kernel of the batch in front to give the CUs' LDS back: the copy stream was the pipeline's period (3.35 ms per batch of 64 x
