@@ -391,3 +391,55 @@ extern "C" unsigned long long hostsim_walk_steps(int off)
     g_all_steps = 0; g_pair_off = off != 0;
     return n;
 }
+
+// The pair halves of the walk's tables (jda_wt_pair) against two single look-ups: for every short key of every table and `tries`
+// random continuations of the stream behind the key's ten bits, the symbol a walk would decode behind the first one -- with the key a
+// walk derives from the stream there -- must be what the pair half says (bits, coefficients moved on by, magnitude size), whatever
+// the bits the key does not show.  Returns the number of pairs checked, or -1 - (table << 12 | key) at the first disagreement.
+extern "C" long hostsim_walk_pairs_check(const uint8_t *jpeg, int len, uint32_t tries, uint32_t seed)
+{
+    int32_t err = 0;
+    jda_image *img = jda_prepare(jpeg, len, &err);
+    if (!img) return -1;
+    uint32_t tb = 0;
+    const uint8_t *tables = jda_image_tables(img, &tb);
+    const jda_image_info *I = jda_image_get_info(img);
+    jda_segscan_params P;
+    memset(&P, 0, sizeof(P));
+    P.nblocks = (uint8_t)I->blocks_per_mcu; P.nluma = (uint8_t)(I->blocks_per_mcu - (I->ncomp == 3 ? 2 : 0));
+    uint8_t q_id[3];
+    jda_image_component_ids(img, P.dc_id, P.ac_id, q_id);
+    const uint32_t follow = jda_wt_dc_follow(P);
+    std::vector<uint64_t> store((JDA_WT_BYTES + 7) / 8);
+    uint8_t *wt = (uint8_t *)store.data();
+    for (uint32_t tid = 0; tid < 256; tid++) jda_walk_tables_from(tables, follow, tid, 256, wt);
+    const uint32_t *T = (const uint32_t *)wt;
+    long checked = 0;
+    uint64_t rng = 0x9e3779b97f4a7c15ull ^ seed;
+    for (uint32_t t = 0; t < 4; t++) {
+        const uint32_t fa = t < 2 ? t : (follow >> (2u * (t - 2u))) & 3u;      // the AC table that decodes the second symbol
+        for (uint32_t key = 0; key < 1024; key++) {
+            const uint32_t e32 = T[t * 2048u + key], ea = e32 & 0xffffu, pd = e32 >> 16;
+            if (!pd) continue;
+            if (fa > 1u || JDA_AC_STOPS(ea)) { jda_image_free(img); return -1 - (long)(t << 12 | key); }
+            const uint32_t bits_a = (ea >> 12) + 1u + ((ea >> 8) & 15u);
+            for (uint32_t i = 0; i < tries; i++) {
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                const uint64_t stream = ((uint64_t)key << 54) | (rng >> 10);   // the key's ten bits, then anything
+                const uint32_t w = (uint32_t)((stream << bits_a) >> 32);        // what a walk peeks behind the first symbol
+                const uint32_t kb = w >= 0xfc000000u ? 1024u + ((w >> 16) & 1023u) : w >> 22;
+                const uint32_t eb = T[fa * 2048u + kb] & 0xffffu;
+                if ((eb & 0xffu) == JDA_AC_NONE) { jda_image_free(img); return -1 - (long)(t << 12 | key); }
+                const bool eob = (eb & 0xffu) == JDA_AC_EOB;
+                const uint32_t len_b = (eb >> 12) + 1u, sz_b = eob ? 0u : (eb >> 8) & 15u, dk = eob ? 0u : ((eb >> 1) & 15u) + 1u;
+                if ((pd & 31u) != len_b + sz_b || ((pd >> 5) & 31u) != dk || ((pd >> 10) & 15u) != sz_b || !(pd & JDA_WT_PAIR_VALID)) {
+                    jda_image_free(img);
+                    return -1 - (long)(t << 12 | key);
+                }
+                checked++;
+            }
+        }
+    }
+    jda_image_free(img);
+    return checked;
+}

@@ -397,3 +397,20 @@ def test_truncated_reads_in_streams_with_restart_intervals(luma_hv, restart, qua
         assert np.array_equal(got, want)
     finally:
         hostsim.hostsim_set_device_prescan(0)
+
+
+def test_pair_halves_of_the_walk_tables_against_two_single_lookups(hostsim):
+    """jda_wt_pair: for every short key of the four walk tables that has a pair half, and random continuations of the stream behind the
+    key's ten bits, the symbol a walk decodes behind the first -- by its own key derivation at that place, long codes included -- is the
+    one the pair half describes.  Annex K tables, optimised tables (Pillow's), tables with an 11-bit DC code and crossed assignments."""
+    from jpegdec_amd.synth import encode_jpeg_custom
+    hostsim.hostsim_walk_pairs_check.restype = C.c_long
+    rng = np.random.default_rng(11)
+    img = np.clip(rng.normal(128, 50, (64, 96, 3)), 0, 255).astype(np.uint8)
+    files = [jpeg_for("c420_1280x720"), jpeg_for("c444_256x256_q100_opt"), jpeg_for("gray_333x217"), jpeg_for("c420_250x250_q10"),
+             encode_jpeg_custom(img, 85, (2, 2), table_ids=((0, 1), (1, 0), (1, 0))),
+             encode_jpeg_custom(img, 85, (1, 1), table_ids=((0, 0), (0, 1), (1, 1))),
+             encode_jpeg_custom(img, 90, (2, 2), dup_eob=True)]
+    for i, f in enumerate(files):
+        n = hostsim.hostsim_walk_pairs_check(f, len(f), 48, i)
+        assert n > 20000, (i, n)                                  # (hundreds of paired keys per table, each under 48 continuations)
