@@ -1439,6 +1439,9 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         const uint32_t bn = b2 + 2u == nblocks2 ? 0u : b2 + 2u;
         // RST: this symbol completes an MCU within 7 bits of the next interval's start = it completes the interval
         const bool iend = RST & ends & live & (bn == 0u) & (next_bit - p < 8u);
+#ifdef JDA_SEG_TRACE_HOOK
+        JDA_SEG_TRACE_HOOK(OP, seg, p, k, kk, b2, bn, ends, iend, next_bit, nr, nblk, e, inval);
+#endif
         const bool hold = iend & eob;                               // the refill after an interval's closing EOB waits for the rounding
         // ---- the refill at the end of the step (not after EOB in the reference -- there it is the next block's opening one)
         if (OP == JDA_SEG_WRITE) {
@@ -1660,14 +1663,18 @@ JDA_HD uint32_t jda_rst_event_item(const jda_segscan_params &P, uint32_t nr)
 {
     const uint32_t JDA_GLOBAL *ev = JDA_G(const uint32_t, P.rst_events) + 2u * (size_t)nr;
     const uint32_t e = ev[0];
+    // The reference restarts by MCU count and never looks for the markers.  A marker behind the image's last block by that count
+    // is one it never gets to; every other one must stand exactly where the count puts it -- also when a damaged interval has the
+    // walk reach the marker only behind the image's last block (found by the pipeline's fuzz: the reference had restarted 2,000 bits
+    // earlier, in the middle of what the walk took for one interval).
+    const uint64_t want = (uint64_t)nr * P.interval_blocks;
+    if (want >= P.n_blocks_total) return 0u;
     if (e == 0u) return 1u;                                         // nobody ended an interval at this marker
     const uint32_t seg = e >> 11, nb = (e & 2047u) - 1u;
     if (seg >= P.n_segs || JDA_G(const uint32_t, P.seg_sum)[(size_t)seg * JDA_SEG_SUM_WORDS + 7u] != ev[1]) return 1u;      // .. not in its segment's last walk
     const uint32_t g0 = JDA_G(const uint32_t, P.seg_start)[(size_t)seg * 5u];
     if (g0 >= 0xfffffff0u) return 0u;                               // behind a bad code: the image is rejected for that
-    const uint64_t g = (uint64_t)g0 + nb;
-    if (g >= P.n_blocks_total) return 0u;                           // behind the image's last block: nobody counts there
-    return g == (uint64_t)nr * P.interval_blocks ? 0u : 1u;
+    return (uint64_t)g0 + nb == want ? 0u : 1u;
 }
 
 // ================================================================================================

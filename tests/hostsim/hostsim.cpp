@@ -18,6 +18,8 @@ static unsigned long long g_all_steps = 0;
 static bool g_pair_off = false;
 #define JDA_SEG_STEP_HOOK() (g_seg_steps++, g_all_steps++)
 #define JDA_SEG_PAIR_OFF() g_pair_off
+static int g_trace_seg = -1;
+#define JDA_SEG_TRACE_HOOK(OP, seg, p, k, kk, b2, bn, ends, iend, next_bit, nr, nblk, e, inval) do { if ((int)(seg) == g_trace_seg) fprintf(stderr, "  op %d seg %u: p %u (abs %u) k %u kk %u b2 %u bn %u ends %d iend %d next_bit %d nr %u nblk %u e %04x inval %d\n", (int)(OP), (unsigned)(seg), (unsigned)(p), (unsigned)((seg) * 2048u + (p)), (unsigned)(k), (unsigned)(kk), (unsigned)(b2), (unsigned)(bn), (int)(ends), (int)(iend), (int)(next_bit), (unsigned)(nr), (unsigned)(nblk), (unsigned)(e), (int)(inval)); } while (0)
 #define JDA_SEG_BLOCK_HOOK() (g_blk_at.push_back(g_seg_steps))
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
@@ -71,6 +73,7 @@ extern "C" uint32_t hostsim_round2_list(void) { return g_round2_list; }
 static int g_no_record = 0;              // 1: the counting walk + WRITE walk also for streams without restart intervals (round 2's passes)
 static uint32_t g_prescan_cands = 0;     // truncation candidates the last RECORD-mode pre-scan appended
 extern "C" void hostsim_set_no_record(int on) { g_no_record = on; }
+extern "C" void hostsim_trace_segment(int seg) { g_trace_seg = seg; }
 // the marker filter's sixteen-byte state machine (jda_filter_classify / jda_filter_run) against the byte-by-byte machine:
 // returns 0 when S, E, R agree for this group, valid count and incoming state
 extern "C" int hostsim_filter_bits_check(const uint8_t *bytes16, uint32_t valid, uint32_t cin)
@@ -335,6 +338,12 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             if (ref && getenv("HOSTSIM_DEBUG")) {
                 for (size_t i = 0; i <= nb; i++) if (hi[i] != dev_index[i] || (i < nb && jda_image_block_dc(ref)[i] != dev_dc[i])) { fprintf(stderr, "first diff at block %zu of %zu: host %u/%u dc %d, dev %u/%u dc %d\n", i, nb, hi[i] >> 7, hi[i] & 127, i < nb ? jda_image_block_dc(ref)[i] : 0, dev_index[i] >> 7, dev_index[i] & 127, i < nb ? dev_dc[i] : 0); break; }
                 fprintf(stderr, "rounds %u trunc host %u dev %u\n", rounds, jda_image_truncation_events(ref), ST.trunc_events);
+                for (size_t i = 0; i <= nb; i++) {                  // the first entry that differs in what counts (position, flag, flagged entry, predictor)
+                    const uint32_t a = hi[i], b = dev_index[i];
+                    const uint32_t pa = (a >> JDA_INDEX_OFF_BITS) * 8u + (a & (JDA_INDEX_TRUNC - 1u)), pb = (b >> JDA_INDEX_OFF_BITS) * 8u + (b & (JDA_INDEX_TRUNC - 1u));
+                    const bool eq = pa == pb && (a & JDA_INDEX_TRUNC) == (b & JDA_INDEX_TRUNC) && (!(a & JDA_INDEX_TRUNC) || a == b) && (i == nb || jda_image_block_dc(ref)[i] == dev_dc[i]);
+                    if (!eq) { fprintf(stderr, "first real difference at block %zu of %zu: host bit %u flag %u dc %d, dev bit %u flag %u dc %d (mcus ok host %u)\n", i, nb, pa, (a >> 6) & 1u, i < nb ? jda_image_block_dc(ref)[i] : 0, pb, (b >> 6) & 1u, i < nb ? dev_dc[i] : 0, nn); break; }
+                }
             }
             if (ref) jda_image_free(ref);
         } else {                                                // corrupt / truncated: the serial pre-scan, as jda_upload_batch does

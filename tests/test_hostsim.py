@@ -414,3 +414,66 @@ def test_pair_halves_of_the_walk_tables_against_two_single_lookups(hostsim):
     for i, f in enumerate(files):
         n = hostsim.hostsim_walk_pairs_check(f, len(f), 48, i)
         assert n > 20000, (i, n)                                  # (hundreds of paired keys per table, each under 48 continuations)
+
+
+def test_a_damaged_interval_that_reaches_its_marker_behind_the_images_last_block(hostsim, oracle):
+    """Found by tools/gpu_fuzz_pipeline.py (seed 40404): one changed byte in the interval before the last restart marker; the damaged
+    interval decodes to more blocks than it had, so the reference -- which restarts by MCU count and never looks for markers -- rounds
+    up and resets 2,000 bits before the place the marker stood at, while a walk that follows the markers reaches the marker only
+    with the image's block count used up.  "Behind the image's last block, nobody counts" let that pass: the marker's count (3,444)
+    is inside the image, so it must be met exactly (jda_rst_event_item) -- the image goes to the serial pre-scan."""
+    b = bytearray(jpeg_for("c444_384x192_q100_rst7"))
+    assert b[121832] == 0x65
+    b[121832] = 0x2a
+    jpeg = bytes(b)
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        rc, want, err = oracle.decode_canvas(jpeg, J.RGB8888, 0)
+        assert rc == 1
+        got = np.full_like(want, 0x33)
+        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, J.RGB8888, 0)
+        assert hostsim.hostsim_decode(jpeg, len(jpeg), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+        assert hostsim.hostsim_prescan_used() == 0               # (the walk's index is not the reference's: rejected)
+        assert np.array_equal(got, want)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+
+
+@pytest.mark.parametrize("name", ["c444_384x192_q100_rst7", "c420_640x368_rstrow", "c440_300x64_rst5", "c420_512x256_q98_rstrow"])
+def test_corrupted_restart_streams_through_the_record_mode_walk(name, hostsim, oracle):
+    """More of the corruption test for the streams whose walk follows markers the reference never looks at: every stream through the
+    segment walk in RECORD mode (what the pipeline runs); an index it accepts must be the serial one, the picture the oracle's."""
+    base = bytearray(jpeg_for(name))
+    sos = bytes(base).index(b"\xff\xda")
+    rng = np.random.default_rng(40404)
+    used = agree = 0
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        for it in range(150):
+            b = bytearray(base)
+            for _ in range(int(rng.integers(1, 4))):
+                # (half of the changes in the stream's last tenth: where an interval's damage meets the end of the image)
+                lo = sos + 14 if it % 2 else len(b) - max((len(b) - sos) // 10, 40)
+                b[int(rng.integers(lo, len(b) - 2))] = int(rng.integers(0, 256))
+            jb = bytes(b)
+            try:
+                p = J.PreparedImage(jb)
+            except J.JdaError:
+                continue
+            idx, nok = p.block_index()
+            if (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan()):
+                continue
+            rc, want, err = oracle.decode_canvas(jb, J.RGB8888, 0)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jb, J.RGB8888, 0)
+            hrc = hostsim.hostsim_decode(jb, len(jb), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert (rc == 1) == (hrc == 0), (name, it, rc, err, hrc)
+            if hostsim.hostsim_prescan_used():
+                used += 1
+                assert hostsim.hostsim_index_equal() == 1, (name, it)
+            if rc == 1:
+                assert np.array_equal(got, want), (name, it)
+                agree += 1
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+    assert agree >= 30 and used >= 10, (agree, used)
