@@ -531,11 +531,25 @@ JDA_HD int32_t jda_extend_top(uint32_t t, uint32_t s)
 // (hi:lo, refilled a dword at a time, the next dword prefetched one refill ahead so that no LDS round trip sits between two
 // symbols; the window in LDS holds byte-swapped dwords, so they are taken as they are).  `left` = bits of hi not consumed yet,
 // 0..31 -- hi may be used up completely, never untouched -- so that the next 32 stream bits are one v_alignbit_b32.
+#ifndef JDA_WR_POSITION
+#define JDA_WR_POSITION 1      // 0: the sliding three-dword window of rounds 1-3 (kept for A/B runs)
+#endif
+#if JDA_WR_POSITION
+// The window-only reader keeps ONE number: the position of the last consumed bit (GPU: counted from LDS address 0, so that the
+// dword it sits in is at byte address (m >> 3) & ~3).  A peek reads that dword and the next (one ds_read2_b32) and funnel-shifts;
+// consuming n bits is m += n.  Five instructions a symbol where sliding hi / lo / next by selects took nine; the price is a second
+// LDS read on the symbol's dependent chain.
+struct jda_wreader {
+    uint32_t m;              // bits up to and including the last consumed one (window start = LDS address * 8; host: = 0), minus 1
+    const uint8_t *base;     // host emulator: the window's first byte
+};
+#else
 struct jda_wreader {
     uint32_t hi, lo, nxt;    // 64 stream bits + the dword after them
     uint32_t left;           // bits of hi still to come
     const uint8_t *wp;       // LDS address nxt came from
 };
+#endif
 // a + (b & 0xff) in one instruction (the byte select rides on the add: SDWA)
 JDA_HD uint32_t jda_add_byte0(uint32_t a, uint32_t b)
 {
@@ -563,6 +577,31 @@ JDA_HD uint32_t jda_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)      // low 
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
 #endif
 }
+#if JDA_WR_POSITION
+JDA_HD void jda_wr_init(jda_wreader &R, const uint8_t *wbase, uint32_t pos, uint32_t off)
+{
+    // (for bit 0 of the window the last consumed bit is in the four bytes in front of it -- other LDS data, all "consumed")
+#if defined(__HIP_DEVICE_COMPILE__)
+    R.m = ((uint32_t)(uintptr_t)wbase << 3) + (pos << 3) + off - 1u;       // (the window is 16-byte aligned and not at LDS address 0)
+    R.base = wbase;
+#else
+    R.m = (pos << 3) + off - 1u;
+    R.base = wbase;
+#endif
+}
+JDA_HD uint32_t jda_wr_peek(const jda_wreader &R)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t a = (R.m >> 3) & ~3u;
+    const uint32_t __attribute__((address_space(3))) *p = (const uint32_t __attribute__((address_space(3))) *)a;
+    return jda_alignbit(p[0], p[1], ~R.m);                         // (- (m + 1)) & 31 bits of the first dword are consumed
+#else
+    const uint8_t *p = R.base + (((int32_t)R.m >> 5) * 4);
+    return jda_alignbit(*(const jda_u32_alias *)p, *(const jda_u32_alias *)(p + 4), ~R.m);
+#endif
+}
+JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n) { R.m += n; }
+#else
 JDA_HD void jda_wr_init(jda_wreader &R, const uint8_t *wbase, uint32_t pos, uint32_t off)
 {
     const int32_t bit = (int32_t)((pos << 3) + off);
@@ -582,6 +621,7 @@ JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n)
     R.wp += go ? 4 : 0;
     R.nxt = *(const jda_u32_alias *)R.wp;               // (re)loaded every time: unchanged address, unchanged value
 }
+#endif
 // the reference's refill (jpeg.inl:2110-2114) as far as its ulBitOff is concerned
 JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) : roff; }
 
