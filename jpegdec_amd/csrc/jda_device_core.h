@@ -755,17 +755,22 @@ struct jda_row8 { uint32_t lo, hi; };
 template <int RC>
 JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
 {
-    int32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    // The even part's four terms are only ever needed as the packed pairs (t0, t1) and (t3, t2) of the final butterflies, and only
+    // modulo 2^16 (below): they are made there -- pair + pair and pair - pair -- instead of four 32-bit sums and two packs.
+    int32_t t4, t5, t6, t7;
+    uint32_t p01, p32;
     if (RC == 0) {                                                   // :2688-2697
-        t0 = t1 = t2 = t3 = s[0];
+        p01 = p32 = jda_dup16(s[0]);
         t7 = s[1];
         t6 = (t7 * 217) >> 8;
         t5 = (t7 * 145) >> 8;
         t4 = -((t7 * 51) >> 8);
     } else if (RC == 1) {                                            // :2698-2718
-        const int32_t a = s[0], c = s[2];
+        const int32_t c = s[2];
         const int32_t m = (c * 106) >> 8;
-        t0 = a + c; t3 = a - c; t1 = a + m; t2 = a - m;
+        const uint32_t pa = jda_dup16(s[0]), pc = jda_pack16(c, m);
+        p01 = jda_pk_add16(pa, pc);                                  // t0 = a + c, t1 = a + m
+        p32 = jda_pk_sub16(pa, pc);                                  // t3 = a - c, t2 = a - m
         const int32_t z13 = s[3], z11 = s[1];
         t7 = z11 + z13;
         const int32_t t11 = ((z11 - z13) * 362) >> 8;
@@ -777,7 +782,9 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
         const int32_t t10 = s[0] + s[4], t11 = s[0] - s[4];
         const int32_t t13 = s[2] + s[6];
         const int32_t t12 = (((s[2] - s[6]) * 362) >> 8) - t13;
-        t0 = t10 + t13; t3 = t10 - t13; t1 = t11 + t12; t2 = t11 - t12;
+        const uint32_t pe = jda_pack16(t10, t11), pf = jda_pack16(t13, t12);
+        p01 = jda_pk_add16(pe, pf);                                  // t0 = t10 + t13, t1 = t11 + t12
+        p32 = jda_pk_sub16(pe, pf);                                  // t3 = t10 - t13, t2 = t11 - t12
         const int32_t z13 = s[5] + s[3], z10 = s[5] - s[3];
         const int32_t z11 = s[1] + s[7], z12 = s[1] - s[7];
         t7 = z11 + z13;
@@ -789,19 +796,18 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
     }
     // :2745-2793  the eight outputs t_a +- t_b and ucRangeTable[(v >> 5) & 0x3ff], two per instruction.
     // Only bits 14:5 of an output reach the table index, so the final adds can be done modulo 2^16 on
-    // packed pairs: (o0,o1) = (t0,t1) + (t7,t6), (o7,o6) = (t0,t1) - (t7,t6), (o2,o3) = (t2,t3) + (t5,-t4),
-    // (o5,o4) = (t2,t3) - (t5,-t4).  Then the 10-bit sign-extended field (the table's wrap: << 1, >> 6
+    // packed pairs: (o0,o1) = (t0,t1) + (t7,t6), (o7,o6) = (t0,t1) - (t7,t6), (o3,o2) = (t3,t2) + (-t4,t5),
+    // (o4,o5) = (t3,t2) - (-t4,t5).  Then the 10-bit sign-extended field (the table's wrap: << 1, >> 6
     // arithmetic on 16-bit lanes), + 128, saturate to a byte.
-    const uint32_t p01 = jda_pack16(t0, t1), p23 = jda_pack16(t2, t3);
-    const uint32_t q76 = jda_pack16(t7, t6), q54 = jda_pack16(t5, -t4);
+    const uint32_t q76 = jda_pack16(t7, t6), q45 = jda_pack16(-t4, t5);
     // (the block's samples carry JDA_ROW_BIAS from the column stage: their 10-bit field is in offset-binary form)
     const uint32_t s01 = jda_pk_limit_offset10(jda_pk_add16(p01, q76));      // samples in bytes 1 and 3
     const uint32_t s76 = jda_pk_limit_offset10(jda_pk_sub16(p01, q76));
-    const uint32_t s23 = jda_pk_limit_offset10(jda_pk_add16(p23, q54));
-    const uint32_t s54 = jda_pk_limit_offset10(jda_pk_sub16(p23, q54));
+    const uint32_t s32 = jda_pk_limit_offset10(jda_pk_add16(p32, q45));
+    const uint32_t s45 = jda_pk_limit_offset10(jda_pk_sub16(p32, q45));
     jda_row8 r;
-    r.lo = jda_perm(s23, s01, 0x07050301u);          // bytes o0 o1 o2 o3
-    r.hi = jda_perm(s76, s54, 0x05070103u);          // bytes o4 o5 o6 o7  (s54 = [o5,o4], s76 = [o7,o6])
+    r.lo = jda_perm(s32, s01, 0x05070301u);          // bytes o0 o1 o2 o3  (s32 = [o3,o2])
+    r.hi = jda_perm(s76, s45, 0x05070301u);          // bytes o4 o5 o6 o7  (s45 = [o4,o5], s76 = [o7,o6])
     return r;
 }
 
