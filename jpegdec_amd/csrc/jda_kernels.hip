@@ -782,7 +782,7 @@ extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params,
 // wavefront per segment, sixteen segments one after the other, lane = record: coalesced reads and writes, no walk.  Result words as
 // WRITE left them: [0] bad (a predictor out of range, a stream read on into its padding), [1] closing entry written, [3] max |DC|.
 #ifndef JDA_FIN_SEGS_PER_WAVE
-#define JDA_FIN_SEGS_PER_WAVE 8u
+#define JDA_FIN_SEGS_PER_WAVE 16u
 #endif
 __global__ __launch_bounds__(256)
 void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
