@@ -130,7 +130,9 @@ struct Img {
 } // namespace
 
 #define JDA_PIPE_MAX_DEPTH 4
+#ifndef JDA_PIPE_SPEC_ROUNDS
 #define JDA_PIPE_SPEC_ROUNDS 4       // rounds launched one by one (a round with an empty work list returns at once); the rest in one launch (jda_segscan_tail)
+#endif
 #define JDA_PIPE_MAX_ROUNDS 56       // stats[8 + r] = length of round r's list, r <= 57 < 60
 #define JDA_PIPE_STATS_BYTES 288      // per image: filter result (2 words, 16 bytes) | 64 result words of the pre-scan + 16 bytes
 

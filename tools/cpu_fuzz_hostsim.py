@@ -20,7 +20,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = C.CDLL(os.path.join(ROOT, "tests", "hostsim", "libjda_hostsim.so"))
 lib.hostsim_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
 oracle = OracleDecoder()
-bases = [n for n in sorted(SYNTH_CASES) if SYNTH_CASES[n]["width"] * SYNTH_CASES[n]["height"] <= 640 * 368]
+max_px = int(os.environ.get("FUZZ_MAX_PIXELS", 640 * 368))
+bases = [n for n in sorted(SYNTH_CASES) if SYNTH_CASES[n]["width"] * SYNTH_CASES[n]["height"] <= max_px]
 try:
     from tests.ref_fixtures import GOOD, ref_jpeg
     extra = [("ref:" + n) for n in GOOD]
