@@ -1124,7 +1124,27 @@ JDA_HD void jda_seg_reader_init(jda_seg_reader &R, const uint32_t JDA_GLOBAL *d,
     R.hi = __builtin_bswap32(d[R.idx]); R.lo = __builtin_bswap32(d[R.idx + 1u]);
     R.n1 = d[R.idx + 2u]; R.n2 = d[R.idx + 3u]; R.n3 = d[R.idx + 4u];
 }
+#ifndef JDA_SEG_READER_SELECT
+#define JDA_SEG_READER_SELECT 1      // 0: the reader that reloads on its own inside the step (rounds 2-3; kept for A/B runs)
+#endif
 // the next 32 bits of the stream at bit p of the segment
+#if JDA_SEG_READER_SELECT
+// (the window slides by selects, no branch: the walk's loop sees to it that p stays within the loaded dwords -- jda_seg_reader_holds --
+// and reloads for the whole wavefront otherwise; a peek is at most one dword ahead of the last one)
+JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
+{
+    const uint32_t wi = p >> 5;
+    const bool adv = wi != R.idx;
+    R.hi = adv ? R.lo : R.hi;
+    R.lo = adv ? __builtin_bswap32(R.n1) : R.lo;
+    R.n1 = adv ? R.n2 : R.n1;
+    R.n2 = adv ? R.n3 : R.n2;
+    R.idx = wi;
+    const uint64_t v = ((uint64_t)R.hi << 32) | R.lo;
+    return (uint32_t)((v << (p & 31u)) >> 32);
+}
+JDA_HD bool jda_seg_reader_holds(const jda_seg_reader &R, uint32_t p) { return (p >> 5) - R.base <= 3u; }
+#else
 JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
 {
     const uint32_t wi = p >> 5;
@@ -1135,6 +1155,8 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
     const uint64_t v = ((uint64_t)R.hi << 32) | R.lo;
     return (uint32_t)((v << (p & 31u)) >> 32);
 }
+JDA_HD bool jda_seg_reader_holds(const jda_seg_reader &, uint32_t) { return true; }
+#endif
 #define JDA_SEG_READ_DWORDS 68u     // dwords of the scan a walk may touch from its segment's start (64 + the window's reach)
 
 // The walks' DC entries: the reference's DC LUT (jpeg.inl:1098-1152) re-laid out like the AC entries -- (code length - 1) << 12 |
@@ -1358,6 +1380,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
     while (go) {
     jda_seg_reader_init(R, segw, p);                                // every lane of the wavefront from where it stands: one wait for all of them
     uint32_t since = 0;
+    bool jumped = false;                                            // RST: this step went over an interval's padding
     do {
 #ifdef JDA_SEG_STEP_HOOK
         JDA_SEG_STEP_HOOK();                                        // (host simulator: counts the steps of a walk)
@@ -1565,12 +1588,15 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                     ev[0] = (seg << 11) | (nblk + 1u); ev[1] = round;
                 }
                 p = next_bit;
+                jumped = true;
                 nr++; next_bit = nr <= P.n_intervals ? (rpos[nr] << 3) - seg_bit0 : 0xffffffffu;
             }
         }
         go = (p < JDA_SEG_BITS) & !stop;
         since++;
-    } while (go & (since < JDA_SEG_REFILL_STEPS));
+        // (the next peek must find p within the loaded dwords and at most one dword on: a lane that has used them up, or jumped over an
+        // interval's padding, sits out the rest of the wavefront's steps until the reload)
+    } while (go & (since < JDA_SEG_REFILL_STEPS) & jda_seg_reader_holds(R, p) & !(JDA_SEG_READER_SELECT && RST && jumped));
     }
     if (OP == JDA_SEG_WRITE) {                                      // what is left of the lane's last groups
         if (ibn) jda_seg_flush_index(P.blk_index, ib_g, ibn, ib0, ib1, ib2, ib3);
