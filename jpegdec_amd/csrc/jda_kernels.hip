@@ -1072,14 +1072,180 @@ void jda_filter_write(const jda_filter_params *__restrict__ params)
     }
 }
 
+// ---- the same two kernels without the scan of functions (round 3, late) -------------------------------------------------------
+// After any byte that is not FF the machine is in state 0, so a thread's sixteen bytes either FIX the state behind them (they hold a
+// byte that is not FF: type K, end state known from a run that starts in state 0) or -- all FF, or none at all behind the end of the
+// data -- FLIP it by their parity (type X).  A thread's incoming state is therefore the K-thread nearest in front of it, flipped by the
+// X-threads between: two ballots and some mask arithmetic per wavefront (one shuffle when every lane is a K, which is nearly always),
+// sixteen 2-bit wavefront summaries per workgroup, and then ONE run of the machine per thread with its true incoming state and plain
+// sums of what it emits -- where the scan composed a 2 x 2 table of (end state, bytes, markers) per thread in six shuffle steps and
+// ran the machine three times.  (What a chunk emits for the OTHER incoming state, which the carry kernel wants, differs only in the
+// chunk's first K-thread: every thread behind it starts from the same state either way, and all-FF threads emit nothing.)
+// this thread's 16 bytes of the chunk (valid: how many of them exist)
+__device__ __forceinline__ void jda_filter_load(const jda_filter_params &P, uint32_t chunk, uint32_t tid, uint32_t b[4], uint32_t &valid)
+{
+    const uint32_t off = chunk * JDA_FILTER_CHUNK + tid * 16u;
+    valid = off >= P.raw_len ? 0u : (P.raw_len - off < 16u ? P.raw_len - off : 16u);
+    b[0] = b[1] = b[2] = b[3] = 0;
+    if (valid) {                                                  // (the raw buffer is padded to a multiple of 16 bytes)
+        const jda_chunk16_alias v = *(const jda_chunk16_alias JDA_GLOBAL *)(JDA_G(const uint8_t, P.raw) + off);
+        b[0] = v.w[0]; b[1] = v.w[1]; b[2] = v.w[2]; b[3] = v.w[3];
+    }
+}
+struct jda_fx { uint32_t is_k, bit; };                              // a thread's / wavefront's / chunk's effect on the state: K: -> bit, X: ^= bit
+__device__ __forceinline__ uint32_t jda_fx_apply(uint32_t f, uint32_t st) { return (f & 1u) ? (f >> 1) & 1u : st ^ ((f >> 1) & 1u); }      // f = is_k | bit << 1
+// one thread's part: masks, the run from state 0, its type; the wavefront's ballots; returns the wavefront's summary (uniform)
+struct jda_fthread { jda_filter_masks M; jda_filter_bits F0; uint32_t valid, is_k, bit; unsigned long long C, B; };
+__device__ __forceinline__ uint32_t jda_filter_v2_thread(const jda_filter_params &P, uint32_t chunk, uint32_t tid, uint32_t b[4], jda_fthread &T)
+{
+    jda_filter_load(P, chunk, tid, b, T.valid);
+    T.M = jda_filter_classify(b);
+    T.F0 = jda_filter_run(T.M, T.valid, 0u);
+    const uint32_t V = (1u << T.valid) - 1u;
+    T.is_k = (T.M.ff & V) != V ? 1u : 0u;                          // (valid == 0: X with parity 0, the identity)
+    T.bit = T.is_k ? (T.F0.S >> T.valid) & 1u : T.valid & 1u;
+    T.C = __builtin_amdgcn_ballot_w64(T.is_k != 0u);
+    T.B = __builtin_amdgcn_ballot_w64(T.bit != 0u);
+    const unsigned long long Vm = T.B & T.C, Tm = T.B & ~T.C;
+    if (T.C != 0ull) {
+        const uint32_t j = 63u - (uint32_t)__builtin_clzll(T.C);
+        const unsigned long long above = j == 63u ? 0ull : Tm & ~((2ull << j) - 1ull);
+        return 1u | (((uint32_t)((Vm >> j) & 1ull) ^ ((uint32_t)__builtin_popcountll(above) & 1u)) << 1);
+    }
+    return ((uint32_t)__builtin_popcountll(Tm) & 1u) << 1;
+}
+// the state a lane starts from, given the state its wavefront starts from
+__device__ __forceinline__ uint32_t jda_filter_v2_cin(const jda_fthread &T, uint32_t lane, uint32_t w_in)
+{
+    if (T.C == ~0ull) {                                            // every lane fixes the state: the lane in front's end state (uniform branch)
+        const uint32_t up = (uint32_t)__shfl_up((int)T.bit, 1, 64);
+        return lane ? up : w_in;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull, below = T.C & lt, Vm = T.B & T.C, Tm = T.B & ~T.C;
+    if (below != 0ull) {
+        const uint32_t j = 63u - (uint32_t)__builtin_clzll(below);
+        const unsigned long long between = Tm & lt & ~((2ull << j) - 1ull);
+        return (uint32_t)((Vm >> j) & 1ull) ^ ((uint32_t)__builtin_popcountll(between) & 1u);
+    }
+    return w_in ^ ((uint32_t)__builtin_popcountll(Tm & lt) & 1u);
+}
+
+__global__ __launch_bounds__(1024)
+void jda_filter_count_v2(const jda_filter_params *__restrict__ params)
+{
+    __shared__ uint32_t wf[16], wn[16], alt[2];
+    const jda_filter_params P = params[blockIdx.y];
+    const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len), tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    if (chunk >= n_chunks) return;
+    uint32_t b[4];
+    jda_fthread T;
+    const uint32_t mine = jda_filter_v2_thread(P, chunk, tid, b, T);
+    if (lane == 0u) wf[wave] = mine;
+    if (tid < 2u) alt[tid] = 0u;
+    __syncthreads();
+    uint32_t w_in = 0u, prev_all_x = 1u;                             // the chunk entered in state 0; are all wavefronts in front X?
+    for (uint32_t w = 0; w < wave; w++) { const uint32_t f = wf[w]; w_in = jda_fx_apply(f, w_in); prev_all_x &= (f & 1u) ^ 1u; }
+    const uint32_t cin = jda_filter_v2_cin(T, lane, w_in);
+    jda_filter_bits F = T.F0;
+    if (cin) F = jda_filter_run(T.M, T.valid, 1u);                    // (rare: the thread in front ended on an unpaired FF)
+    uint32_t nr = (uint32_t)__builtin_popcount(F.E) | ((uint32_t)__builtin_popcount(F.R) << 16);
+    // the chunk's first K-thread: what it emits from the other state
+    if (prev_all_x && T.C != 0ull && lane == (uint32_t)__builtin_ctzll(T.C)) {
+        const jda_filter_bits G = cin ? T.F0 : jda_filter_run(T.M, T.valid, 1u);
+        alt[0] = (uint32_t)__builtin_popcount(G.E) - (nr & 0xffffu) + 0x8000u;      // (biased: a difference of -16 .. 16)
+        alt[1] = (uint32_t)__builtin_popcount(G.R) - (nr >> 16) + 0x8000u;
+    }
+    nr = jda_wave_sum_u32(nr);
+    if (lane == 0u) wn[wave] = nr;
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t n0 = 0, r0 = 0, f = 2u * 0u;                         // f: the chunk's effect, composed: starts as X with parity 0
+        uint32_t s0 = 0u, s1 = 1u;
+        for (uint32_t w = 0; w < 16u; w++) { n0 += wn[w] & 0xffffu; r0 += wn[w] >> 16; s0 = jda_fx_apply(wf[w], s0); s1 = jda_fx_apply(wf[w], s1); }
+        (void)f;
+        const uint32_t n1 = alt[0] ? n0 + alt[0] - 0x8000u : n0, r1 = alt[1] ? r0 + alt[1] - 0x8000u : r0;
+        P.work[2u * chunk] = s0 | (s1 << 1) | (n0 << 2) | (n1 << 17);
+        P.work[2u * chunk + 1u] = r0 | (r1 << 16);
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void jda_filter_write_v2(const jda_filter_params *__restrict__ params)
+{
+    __shared__ uint32_t wf[16], wn[16];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[JDA_FILTER_CHUNK + 32];
+    const jda_filter_params P = params[blockIdx.y];
+    const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len), tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    if (chunk >= n_chunks) return;
+    const uint32_t *carry = P.work + 2u * n_chunks + 3u * chunk;
+    const uint32_t state = carry[0], out_base = carry[1], rst_base = carry[2];
+    uint32_t b[4];
+    jda_fthread T;
+    const uint32_t mine = jda_filter_v2_thread(P, chunk, tid, b, T);
+    if (lane == 0u) wf[wave] = mine;
+    __syncthreads();
+    uint32_t w_in = state;
+    for (uint32_t w = 0; w < wave; w++) w_in = jda_fx_apply(wf[w], w_in);
+    const uint32_t st = jda_filter_v2_cin(T, lane, w_in);
+    jda_filter_bits F = T.F0;
+    if (st) F = jda_filter_run(T.M, T.valid, 1u);
+    // bytes and markers in front of this thread: an inclusive sum over the wavefront, the wavefronts in front from LDS
+    const uint32_t nr = (uint32_t)__builtin_popcount(F.E) | ((uint32_t)__builtin_popcount(F.R) << 16);
+    uint32_t inc = nr;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63u) wn[wave] = inc;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+    for (uint32_t w = 0; w < 16u; w++) { const uint32_t t = wn[w]; if (w < wave) pre += t; total += t; }
+    const uint32_t before = pre + inc - nr;
+    const uint32_t mis = out_base & 15u;                          // the staged bytes sit at the alignment they will have in memory
+    uint32_t o = mis + (before & 0xffffu);
+    uint32_t rp = rst_base + (before >> 16);
+    uint32_t JDA_GLOBAL *rpos = JDA_G(uint32_t, P.restart_pos);
+    for (uint32_t R = F.R; R != 0u; R &= R - 1u) {                 // RSTn: the next interval starts here (rare)
+        const uint32_t k = (uint32_t)__builtin_ctz(R);
+        rp++;
+        if (rp < P.restart_cap) rpos[rp] = out_base + (o - mis) + (uint32_t)__builtin_popcount(F.E & ((1u << k) - 1u));
+    }
+    // every byte is stored -- to its place, or to a dump byte behind the buffer -- so that the sixteen steps are straight-line code.
+    // FF 00 -> FF: the 00 that leaves in state 1 becomes the FF
+    const uint32_t sz = F.S & T.M.zero;
+#pragma unroll
+    for (uint32_t d = 0; d < 4; d++) {                               // nibble -> 0xff in the bytes of its set bits
+        const uint32_t one = jda_umul24((sz >> (4u * d)) & 15u, 0x00204081u) & 0x01010101u;
+        b[d] |= (one << 8) - one;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const bool emit = ((F.E >> k) & 1u) != 0u;
+        stage[emit ? o : (uint32_t)(JDA_FILTER_CHUNK + 31u)] = (uint8_t)(b[k >> 2] >> (8 * (k & 3)));
+        o += emit ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t n_out = total & 0xffffu, end = mis + n_out;
+    uint8_t JDA_GLOBAL *gout = JDA_G(uint8_t, P.out) + (out_base - mis);                   // 16-byte aligned (P.out is)
+    for (uint32_t piece = tid; piece * 16u < end; piece += 1024u) {
+        const uint32_t lo = piece * 16u, hi = lo + 16u;
+        if (lo >= mis && hi <= end) *(jda_chunk16_alias JDA_GLOBAL *)(gout + lo) = *(const jda_chunk16_alias *)(stage + lo);
+        else for (uint32_t i = lo < mis ? mis : lo; i < (hi < end ? hi : end); i++) gout[i] = stage[i];        // (the chunk's first and last 16 bytes: a neighbour writes the rest)
+    }
+}
+
 // max_raw_len: the longest raw_len among the images (the grid's width)
 extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, uint32_t max_raw_len, hipStream_t stream)
 {
     if (n_images == 0) return hipSuccess;
     const uint32_t chunks = (max_raw_len + JDA_FILTER_CHUNK - 1u) / JDA_FILTER_CHUNK;
-    if (chunks) hipLaunchKernelGGL(jda_filter_count, dim3(chunks, n_images), dim3(1024), 0, stream, params);
+    static const bool v1 = []() { const char *e = getenv("JDA_FILTER_V1"); return e && e[0] == '1'; }();      // (measuring / differential tests: the scan-of-functions kernels)
+    if (chunks) { if (v1) hipLaunchKernelGGL(jda_filter_count, dim3(chunks, n_images), dim3(1024), 0, stream, params); else hipLaunchKernelGGL(jda_filter_count_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params); }
     hipLaunchKernelGGL(jda_filter_carry, dim3(n_images), dim3(64), 0, stream, params);
-    if (chunks) hipLaunchKernelGGL(jda_filter_write, dim3(chunks, n_images), dim3(1024), 0, stream, params);
+    if (chunks) { if (v1) hipLaunchKernelGGL(jda_filter_write, dim3(chunks, n_images), dim3(1024), 0, stream, params); else hipLaunchKernelGGL(jda_filter_write_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params); }
     return hipGetLastError();
 }
 

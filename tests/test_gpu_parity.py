@@ -321,6 +321,30 @@ def test_marker_filter_on_the_gpu(gpu_ctx, oracle):
         got, rpos, nr = J.filter_on_device(gpu_ctx, rawb)
         assert got == oracle.filter(rawb), (trial, n)
         assert np.array_equal(rpos, _host_restart_positions(rawb)), (trial, n)
+    # runs of FF as long as a thread's sixteen bytes, a wavefront's 1,024, a workgroup's 16 KB and more, at every alignment class, of
+    # either parity, followed by 00 / a marker / a plain byte / the end: a thread (wavefront, chunk) of nothing but FF passes the state
+    # on flipped by its parity -- the kernels take its incoming state from the nearest thread in front that holds another byte
+    for trial, (lead, run, tail) in enumerate([(0, 16, b"\x00"), (5, 16, b"\xd3"), (16, 17, b"\x41"), (3, 32, b"\x00"), (11, 33, b"\xd0\x12"),
+                                               (0, 1024, b"\x00"), (7, 1025, b"\x00"), (1000, 2049, b"\xd7"), (16383, 17, b"\x00"),
+                                               (9, 16384, b"\x00"), (16384, 16385, b"\x41"), (100, 32769, b"\xd1\x00"), (0, 40000, b""),
+                                               (0, 40001, b""), (15, 1, b""), (16, 1, b""), (0, 0, b"\xff"), (16383, 1, b"\x00\xff"), (16384, 15, b"")]):
+        rawb = bytes(rng.integers(0, 255, lead, dtype=np.uint8)) + b"\xff" * run + tail + bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * (1 if tail else 0)
+        got, rpos, nr = J.filter_on_device(gpu_ctx, rawb)
+        assert got == oracle.filter(rawb), ("long run", trial, lead, run)
+        assert np.array_equal(rpos, _host_restart_positions(rawb)), ("long run", trial, lead, run)
+    for trial in range(60):                                       # many runs of sixteen and more in one buffer, runs meeting chunk edges
+        n = int(rng.integers(20000, 90000))
+        raw = rng.integers(0, 256, n, dtype=np.uint8)
+        for _ in range(int(rng.integers(3, 40))):
+            run = int(rng.choice([16, 17, 31, 32, 48, 63, 64, 65, 128, 1023, 1024, 1025, 4096, 16384, 16385]))
+            at = int(rng.choice([rng.integers(0, n), 16384 - run // 2, 16384 - run, 32768 - 1, 16384])) % max(n - 1, 1)
+            raw[at:at + run] = 0xFF
+            end = min(at + run, n - 1)
+            raw[end] = int(rng.choice([0x00, 0xD0 + int(rng.integers(0, 8)), 0x37, 0xFF]))
+        rawb = raw.tobytes()
+        got, rpos, nr = J.filter_on_device(gpu_ctx, rawb)
+        assert got == oracle.filter(rawb), ("many runs", trial, n)
+        assert np.array_equal(rpos, _host_restart_positions(rawb)), ("many runs", trial, n)
 
 
 def _host_restart_positions(raw: bytes):
