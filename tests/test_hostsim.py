@@ -477,3 +477,71 @@ def test_corrupted_restart_streams_through_the_record_mode_walk(name, hostsim, o
     finally:
         hostsim.hostsim_set_device_prescan(0)
     assert agree >= 30 and used >= 10, (agree, used)
+
+
+@pytest.mark.parametrize("name", ["c420_640x368_rstrow", "c444_384x192_q100_rst7", "c440_300x64_rst5", "gray_64x64_rst3"])
+def test_damaged_restart_markers_through_the_record_mode_walk(name, hostsim, oracle):
+    """The reference counts MCUs and never looks for restart markers (jpeg.inl:5337-5348); the segment walk follows them.  Markers
+    deleted, doubled, renumbered, inserted in the middle of an interval, moved by a few bytes, another DRI value: a stream the walk's
+    checks accept must come out with the serial pre-scan's index, every picture and status as the oracle's (tools/cpu_fuzz_markers.py
+    is the long version of this test)."""
+    base = bytearray(jpeg_for(name))
+    sos = bytes(base).index(b"\xff\xda")
+    rng = np.random.default_rng(5)
+
+    def markers(b):
+        out, i = [], sos + 2
+        while i < len(b) - 1:
+            if b[i] == 0xFF and 0xD0 <= b[i + 1] <= 0xD7:
+                out.append(i); i += 2
+            else:
+                i += 1
+        return out
+
+    used = agree = 0
+    hostsim.hostsim_set_device_prescan(2)
+    try:
+        for it in range(90):
+            b = bytearray(base)
+            ms = markers(b)
+            m = ms[int(rng.integers(0, len(ms)))]
+            kind = it % 6
+            if kind == 0:
+                del b[m:m + 2]
+            elif kind == 1:
+                b[m:m] = b[m:m + 2]
+            elif kind == 2:
+                b[m + 1] = 0xD0 + int(rng.integers(0, 8))
+            elif kind == 3:
+                at = int(rng.integers(sos + 14, len(b) - 2))
+                b[at:at] = bytes([0xFF, 0xD0 + int(rng.integers(0, 8))])
+            elif kind == 4:
+                mk = bytes(b[m:m + 2]); del b[m:m + 2]
+                at = max(sos + 14, min(len(b) - 2, m + int(rng.integers(-6, 7))))
+                b[at:at] = mk
+            else:
+                i = bytes(b).find(b"\xff\xdd\x00\x04")
+                v = max(1, ((b[i + 4] << 8) | b[i + 5]) + int(rng.integers(-2, 3)))
+                b[i + 4], b[i + 5] = v >> 8, v & 255
+            jb = bytes(b)
+            try:
+                p = J.PreparedImage(jb)
+            except J.JdaError:
+                continue
+            idx, nok = p.block_index()
+            if (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan()):
+                continue
+            rc, want, err = oracle.decode_canvas(jb, J.RGB8888, 0)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jb, J.RGB8888, 0)
+            hrc = hostsim.hostsim_decode(jb, len(jb), J.RGB8888, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert (rc == 1) == (hrc == 0), (name, it, kind, rc, err, hrc)
+            if hostsim.hostsim_prescan_used():
+                used += 1
+                assert hostsim.hostsim_index_equal() == 1, (name, it, kind)
+            if rc == 1:
+                assert np.array_equal(got, want), (name, it, kind)
+                agree += 1
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+    assert agree >= 20, (agree, used)
