@@ -243,6 +243,61 @@ def test_pipeline_corrupted_scans_decode_like_the_oracle(gpu_ctx, oracle):
     pipe.close()
 
 
+def test_pipeline_damaged_restart_markers(gpu_ctx, oracle):
+    """The reference counts MCUs and never looks for restart markers (jpeg.inl:5337-5348); the device's walk follows them.  Markers
+    deleted, doubled, renumbered, inserted in the middle of an interval, moved by a few bytes, another DRI value, a damaged last
+    interval (tests/test_hostsim.py's regression: one byte in front of the last marker): every surface and status the oracle's --
+    whether the device's index stood or the image went back to the serial pre-scan."""
+    rng = np.random.default_rng(9)
+    jp, nm = [], []
+    fix = bytearray(jpeg_for("c444_384x192_q100_rst7")); fix[121832] = 0x2a
+    jp.append(bytes(fix)); nm.append("one byte in front of the last marker")
+    for name in ("c420_640x368_rstrow", "c444_384x192_q100_rst7", "c440_300x64_rst5", "gray_64x64_rst3"):
+        base = bytearray(jpeg_for(name))
+        sos = bytes(base).index(b"\xff\xda")
+        ms = [i for i in range(sos + 2, len(base) - 1) if base[i] == 0xFF and 0xD0 <= base[i + 1] <= 0xD7]
+        made = it = 0
+        while made < 14 and it < 200:
+            it += 1
+            b = bytearray(base)
+            m = ms[int(rng.integers(0, len(ms)))]
+            kind = it % 7
+            if kind == 0: del b[m:m + 2]
+            elif kind == 1: b[m:m] = b[m:m + 2]
+            elif kind == 2: b[m + 1] = 0xD0 + int(rng.integers(0, 8))
+            elif kind == 3:
+                at = int(rng.integers(sos + 14, len(b) - 2)); b[at:at] = bytes([0xFF, 0xD0 + int(rng.integers(0, 8))])
+            elif kind == 4:
+                mk = bytes(b[m:m + 2]); del b[m:m + 2]
+                at = max(sos + 14, min(len(b) - 2, m + int(rng.integers(-6, 7)))); b[at:at] = mk
+            elif kind == 5:
+                i = bytes(b).find(b"\xff\xdd\x00\x04")
+                v = max(1, ((b[i + 4] << 8) | b[i + 5]) + int(rng.integers(-2, 3))); b[i + 4], b[i + 5] = v >> 8, v & 255
+            else:
+                b[int(rng.integers(ms[max(0, len(ms) - 3)], len(b) - 2))] = int(rng.integers(0, 256))
+            jb = bytes(b)
+            try:
+                p = J.PreparedImage(jb)
+            except J.JdaError:
+                continue
+            idx, nok = p.block_index()
+            ooc = (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan())
+            p.close()
+            if ooc:
+                continue
+            jp.append(jb); nm.append("%s#%d kind %d" % (name, made, kind)); made += 1
+    pts = [J.RGB8888] * len(jp)
+    opts = [0] * len(jp)
+    pipe = J.Pipeline(gpu_ctx, max_images=64, depth=2, host_threads=4)
+    outs, metas = _surfaces(gpu_ctx, jp, pts, opts)
+    st = pipe.wait(pipe.submit(jp, outs, pts, opts))
+    _check(gpu_ctx, oracle, jp, pts, opts, outs, metas, st, nm)
+    assert pipe.stats["host_path_images"] >= 1                    # (the regression case at least went back to the serial pre-scan)
+    for o in outs:
+        gpu_ctx.free(o[0])
+    pipe.close()
+
+
 def test_pipeline_on_the_densest_streams(gpu_ctx, oracle):
     """Flat images: some 390 block starts per 256-byte segment (every block its two shortest codes) -- the RECORD-mode pre-scan's record
     slots hold them, with and without restart intervals, in 4:2:0 and 4:4:4; device index == the serial one, pixels == the oracle's."""
