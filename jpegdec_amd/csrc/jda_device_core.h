@@ -1113,20 +1113,24 @@ struct jda_seg_reader {
     const uint32_t JDA_GLOBAL *d;   // the segment's first dword (readable: JDA_SEG_SLOT bytes)
     uint32_t idx, base;             // dword index of hi now / when the registers were loaded
     uint32_t hi, lo;                // stream bits, first byte on top
-    uint32_t n1, n2, n3;            // the dwords behind lo, as loaded (little endian); valid while idx - base <= 3
+    uint32_t n1, n2, n3;            // the dwords behind lo (first byte on top, like hi and lo); valid while idx - base <= 3
 };
 #ifndef JDA_SEG_REFILL_STEPS
 #define JDA_SEG_REFILL_STEPS 8u
+#endif
+#ifndef JDA_SEG_READER_SELECT
+#define JDA_SEG_READER_SELECT 1      // 0: the reader that reloads on its own inside the step (rounds 2-3; kept for A/B runs)
 #endif
 JDA_HD void jda_seg_reader_init(jda_seg_reader &R, const uint32_t JDA_GLOBAL *d, uint32_t p)
 {
     R.d = d; R.idx = R.base = p >> 5;
     R.hi = __builtin_bswap32(d[R.idx]); R.lo = __builtin_bswap32(d[R.idx + 1u]);
+#if JDA_SEG_READER_SELECT
+    R.n1 = __builtin_bswap32(d[R.idx + 2u]); R.n2 = __builtin_bswap32(d[R.idx + 3u]); R.n3 = __builtin_bswap32(d[R.idx + 4u]);      // (swapped here, once a reload: the slide is in every step)
+#else
     R.n1 = d[R.idx + 2u]; R.n2 = d[R.idx + 3u]; R.n3 = d[R.idx + 4u];
-}
-#ifndef JDA_SEG_READER_SELECT
-#define JDA_SEG_READER_SELECT 1      // 0: the reader that reloads on its own inside the step (rounds 2-3; kept for A/B runs)
 #endif
+}
 // the next 32 bits of the stream at bit p of the segment
 #if JDA_SEG_READER_SELECT
 // (the window slides by selects, no branch: the walk's loop sees to it that p stays within the loaded dwords -- jda_seg_reader_holds --
@@ -1136,7 +1140,7 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
     const uint32_t wi = p >> 5;
     const bool adv = wi != R.idx;
     R.hi = adv ? R.lo : R.hi;
-    R.lo = adv ? __builtin_bswap32(R.n1) : R.lo;
+    R.lo = adv ? R.n1 : R.lo;
     R.n1 = adv ? R.n2 : R.n1;
     R.n2 = adv ? R.n3 : R.n2;
     R.idx = wi;
