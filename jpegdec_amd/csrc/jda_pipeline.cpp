@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -247,10 +248,22 @@ void jda_pipeline_destroy(jda_pipeline *p)
     delete p;
 }
 
+// (measuring: JDA_PIPE_TIME=1 prints where jda_pipeline_submit's time goes, summed over the submits, when the process ends)
+struct jda_submit_clock {
+    bool on; double acc[8]; long n; std::chrono::steady_clock::time_point t;
+    jda_submit_clock() : on(getenv("JDA_PIPE_TIME") != NULL), n(0) { for (double &a : acc) a = 0; }
+    ~jda_submit_clock() { if (on && n) fprintf(stderr, "jda_pipeline_submit x %ld: setup %.1f us, parse + tables %.1f, layout %.1f, grow buffers %.1f, parameters %.1f, strips + copy into the page-locked mirror %.1f, enqueue %.1f (per submit)\n", n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n); }
+    long calls = 0;                                                 // (the first eight submits warm buffers and pages up: not counted)
+    void start() { if (on) { t = std::chrono::steady_clock::now(); calls++; if (calls > 8) n++; } }
+    void lap(int k) { if (on) { const auto u = std::chrono::steady_clock::now(); if (calls > 8) acc[k] += std::chrono::duration<double, std::micro>(u - t).count(); t = u; } }
+};
+static jda_submit_clock g_submit_clock;
+
 int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
                         const int32_t *pixel_types, const int32_t *options, int32_t *ticket)
 {
     if (!p) return JDA_ERROR_NO_DEVICE;
+    g_submit_clock.start();
     if (n <= 0 || n > p->max_images || !jpegs || !lens || !outputs || !ticket) return JDA_INVALID_PARAMETER;
     jda_ctx *ctx = p->ctx;
     (void)hipSetDevice(ctx->device);
@@ -282,12 +295,14 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         S.pin_cap = want;
     }
 
+    g_submit_clock.lap(0);
     // ---- host: parse + tables, in parallel
     p->workers->run(n, [&](int i) {
         Img &im = S.imgs[(size_t)i];
         im.err = (jpegs[i] && lens[i] > 0) ? jda_front_prepare(jpegs[i], lens[i], S.pin + im.ctl_tables, &im.f) : JDA_INVALID_PARAMETER;
     });
 
+    g_submit_clock.lap(1);
     // ---- launch plan and arena layout
     std::vector<jda_dev_desc> descs((size_t)n);
     uint32_t list_tiles[JDA_N_LISTS], list_ord[JDA_N_LISTS];
@@ -377,6 +392,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     const size_t zero_end = arena;
     arena += 8192;                                            // slack: readers run a few hundred bytes past a (corrupt) scan
 
+    g_submit_clock.lap(2);
     S.pin_stats = a256(raw_end);                              // the read-back of the result words sits behind the mirror
     const size_t pin_stats = S.pin_stats;
     if (S.pin_cap < pin_stats + S.stats_bytes + 256) {        // (strips and scans did not fit: grow, keeping the tables)
@@ -396,6 +412,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         S.dev_cap = want;
     }
 
+    g_submit_clock.lap(3);
     // ---- control blob, part 2: parameters, descriptors, strips (in parallel: the strip lists are the bulk)
     jda_filter_params *fp = (jda_filter_params *)(S.pin + off_fparams);
     jda_segscan_params *sp = (jda_segscan_params *)(S.pin + off_sparams);
@@ -450,6 +467,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         sp[k] = P;
         max_segs = std::max(max_segs, im.n_segs_ub);
     }
+    g_submit_clock.lap(4);
     p->workers->run((int)dev_ix.size(), [&](int k) {
         const int i = dev_ix[(size_t)k];
         const Img &im = S.imgs[(size_t)i];
@@ -460,6 +478,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         memcpy(S.pin + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len);
     });
 
+    g_submit_clock.lap(5);
     // ---- enqueue: upload stream
     const int up_ix = t % (p->n_upx + 1);
     hipStream_t s_up = up_ix ? p->s_upx[up_ix - 1] : p->s_up;           // batches take the pre-scan streams in turn
@@ -504,6 +523,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     }
     if (e == hipSuccess) e = hipEventRecord(S.ev_dec, ctx->stream);
     if (e != hipSuccess) { (void)hipStreamSynchronize(p->s_copy); (void)hipStreamSynchronize(s_up); (void)hipStreamSynchronize(ctx->stream); return jda_set_err(ctx, e, "jda_pipeline_submit"); }
+    g_submit_clock.lap(6);
     S.ticket = t; S.in_flight = true;
     p->next_ticket++;
     *ticket = t;
