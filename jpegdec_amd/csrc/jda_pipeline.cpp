@@ -41,7 +41,7 @@ inline size_t a16(size_t v) { return (v + 15) & ~(size_t)15; }
 inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // a few persistent worker threads: run(n, fn) calls fn(0..n-1) across them and the caller.  Items are handed out under the
-// mutex (an item is tens of microseconds of work: no contention to speak of), tagged with the run's generation so that a
+// mutex, a few at a time (an item is a few to tens of microseconds of work), tagged with the run's generation so that a
 // worker that is late leaving one run cannot take an item of the next one twice.
 class Workers {
 public:
@@ -76,16 +76,20 @@ private:
     void work(uint64_t g)
     {
         for (;;) {
-            int i;
+            int i, k;
             const std::function<void(int)> *f;
             {
                 std::lock_guard<std::mutex> lk(m_);
                 if (gen_ != g || next_ >= n_) return;
-                i = next_++; f = fn_;
+                // (a run of hundreds of small files: a few items per visit to the mutex -- a quarter of an even share, so that the
+                // threads still finish together)
+                k = n_ / (4 * ((int)th_.size() + 1));
+                k = k < 1 ? 1 : (k > n_ - next_ ? n_ - next_ : k);
+                i = next_; next_ += k; f = fn_;
             }
-            (*f)(i);
+            for (int j = 0; j < k; j++) (*f)(i + j);
             std::lock_guard<std::mutex> lk(m_);
-            if (gen_ == g && ++done_ >= n_) cv_done_.notify_all();
+            if (gen_ == g && (done_ += k) >= n_) cv_done_.notify_all();
         }
     }
     void loop()
