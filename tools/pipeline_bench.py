@@ -74,11 +74,24 @@ def main():
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--restart-rows", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic files the batch cycles through (more: more segments that need a late round)")
+    ap.add_argument("--no-pin", action="store_true", help="leave the process where the scheduler puts it (default: the CPUs of the GPU's NUMA node)")
     a = ap.parse_args()
     jpegs = [cached_jpeg(a.width, a.height, a.subsampling, 1234 + i, quality=a.quality, restart_rows=a.restart_rows) for i in range(a.distinct)]
     ctx = J.Context(0)
+    pinned = None
+    if not a.no_pin and hasattr(os, "sched_setaffinity"):     # as bench.py's ranks do: the process (and the pipeline's workers) on the GPU's NUMA node
+        from jpegdec_amd.sharding import _parse_cpulist, numa_node_of_pci
+        node = numa_node_of_pci(ctx.pci_bus_id())
+        try:
+            cpus = sorted(set(_parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())) & os.sched_getaffinity(0)) if node is not None else []
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                pinned = {"numa_node": node, "cpus": len(cpus)}
+        except Exception:
+            pinned = None
     r = run(ctx, jpegs, a.batch, a.batches, a.depth, a.threads)
     r["distinct"] = a.distinct
+    r["pinned"] = pinned
     print(json.dumps(r))
     ctx.close()
 
