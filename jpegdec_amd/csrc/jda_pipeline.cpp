@@ -35,7 +35,36 @@
 extern "C" int jda_front_prepare(const uint8_t *jpeg, int32_t len, uint8_t *tables, jda_front *out);
 extern "C" uint32_t jda_front_fast_mul(const uint8_t *tables, const jda_front *f, uint32_t max_ac_bits, int32_t max_abs_dc);
 
+#if defined(__x86_64__) || defined(_M_X64)
+#include <emmintrin.h>
+#endif
+
 namespace {
+
+// A file's entropy-coded bytes into the page-locked mirror: written once, read next by the copy engine, never by this core again --
+// streaming stores (no read for ownership, nothing of the files evicted from the caches for it); the short ends by memcpy.
+inline void copy_to_mirror(uint8_t *dst, const uint8_t *src, size_t n)
+{
+#if defined(__x86_64__) || defined(_M_X64)
+    static const bool plain = getenv("JDA_PIPE_PLAIN_COPY") != NULL;      // (measuring)
+    if (n >= 4096 && !plain) {
+        const size_t head = (size_t)(-(intptr_t)dst) & 15u;
+        memcpy(dst, src, head);
+        dst += head; src += head; n -= head;
+        const size_t body = n & ~(size_t)63;
+        for (size_t i = 0; i < body; i += 64) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16));
+            const __m128i c = _mm_loadu_si128((const __m128i *)(src + i + 32)), d = _mm_loadu_si128((const __m128i *)(src + i + 48));
+            _mm_stream_si128((__m128i *)(dst + i), a); _mm_stream_si128((__m128i *)(dst + i + 16), b);
+            _mm_stream_si128((__m128i *)(dst + i + 32), c); _mm_stream_si128((__m128i *)(dst + i + 48), d);
+        }
+        _mm_sfence();
+        memcpy(dst + body, src + body, n - body);
+        return;
+    }
+#endif
+    memcpy(dst, src, n);
+}
 
 inline size_t a16(size_t v) { return (v + 15) & ~(size_t)15; }
 inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -479,7 +508,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         fill_strips((jda_strip *)(S.pin + S.list_off[im.list]) + im.strip_off, im.n_tiles, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, im.ord);
         // the file's entropy-coded bytes into the page-locked mirror (the workers' memcpy is the only time the host touches them):
         // the whole batch then travels as ONE asynchronous copy instead of a blocking pageable copy per file
-        memcpy(S.pin + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len);
+        copy_to_mirror(S.pin + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len);
     });
 
     g_submit_clock.lap(5);
