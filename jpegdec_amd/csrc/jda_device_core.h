@@ -1465,10 +1465,9 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             const uint32_t rec = p | (RST && has_rst ? JDA_REC_AFTER_RST : 0u) | ((uint32_t)run << JDA_REC_POS_BITS);
             rb0 = counted ? rb1 : rb0; rb1 = counted ? rb2 : rb1; rb2 = counted ? rb3 : rb2; rb3 = counted ? rec : rb3;
             Ublk = counted ? U : Ublk;
-            if (counted && (nblk & 3u) == 3u) {
-                if (nblk < P.rec_cap) jda_store_u32x4(recs + (nblk - 3u), rb0, rb1, rb2, rb3);
-                else sbad = true;                                   // (jda_record_cap leaves no room for this; memory stays ours anyway)
-            }
+            const bool group = counted & ((nblk & 3u) == 3u), fits = nblk < P.rec_cap;      // (one branch region, not two nested ones)
+            if (group & fits) jda_store_u32x4(recs + (nblk - 3u), rb0, rb1, rb2, rb3);
+            sbad |= group & !fits;                                  // (jda_record_cap leaves no room for this; memory stays ours anyway)
             // a DC category no 8-bit baseline stream has does not fit the record's 20-bit sum: such a file keeps to the serial pre-scan
             sbad |= isdc & (sz > 11u);
         }
