@@ -345,18 +345,22 @@ class DeviceImage:
 
 
 def index_equivalent(a, b) -> bool:
-    """Do two per-block indexes name the same decode?  An entry is (byte position << 7) | flag << 6 | bit offset: the bit position
-    pos * 8 + off of the block's first bit is what P1 starts from; the split into (pos, off) -- the reference reader's phase after
-    the block's opening refill -- only matters for a block flagged JDA_INDEX_TRUNC (its truncated magnitude reads are emulated
-    from that phase).  The serial pre-scan writes the true phase everywhere, the device pre-scan's RECORD mode a canonical one
-    ((p >> 3) << 7 | p & 7) into unflagged entries: equivalent = same bit position and flag everywhere, same entry where flagged."""
+    """Do two per-block indexes (format 2) name the same decode?  An entry is (byte position << 7) | flag << 6 | bit offset: the
+    bit position pos * 8 + off of the block's FIRST AC SYMBOL is what P1 starts from; the split into (pos, off) -- the reference
+    reader's phase behind the refill at the top of its AC loop -- only matters for a block flagged JDA_INDEX_TRUNC (its truncated
+    magnitude reads are emulated from that phase).  The serial pre-scan writes the true phase everywhere, the device pre-scan a
+    canonical one ((p >> 3) << 7 | p & 7) into unflagged entries: equivalent = same bit position and flag in every block's entry,
+    same entry where flagged.  The closing entry (the last one) only bounds the scan from above: the device pre-scan's lies up to
+    41 bits behind the serial one's (the DC symbol the stream's padding decodes to, an interval's rounding); either order of
+    the arguments is accepted."""
     a = np.asarray(a, dtype=np.uint32)
     b = np.asarray(b, dtype=np.uint32)
-    if a.shape != b.shape:
+    if a.shape != b.shape or a.size == 0:
         return False
-    pa, pb = (a >> 7) * 8 + (a & 63), (b >> 7) * 8 + (b & 63)
-    fa, fb = a & 64, b & 64
-    return bool(np.array_equal(pa, pb) and np.array_equal(fa, fb) and np.array_equal(a[fa != 0], b[fb != 0]))
+    pa, pb = (a[:-1] >> 7) * 8 + (a[:-1] & 63), (b[:-1] >> 7) * 8 + (b[:-1] & 63)
+    fa, fb = a[:-1] & 64, b[:-1] & 64
+    ea, eb = int(a[-1] >> 7) * 8 + int(a[-1] & 127), int(b[-1] >> 7) * 8 + int(b[-1] & 127)
+    return bool(np.array_equal(pa, pb) and np.array_equal(fa, fb) and np.array_equal(a[:-1][fa != 0], b[:-1][fb != 0]) and abs(ea - eb) <= 41)
 
 
 def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0, strict: bool = True):

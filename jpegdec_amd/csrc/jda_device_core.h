@@ -445,16 +445,16 @@ struct jda_tables {
     uint32_t eob_sh, eob_code;   // the window-only reader finds EOB by comparing stream bits (jda_lane_pre)
 };
 
-// dc_only / al: the scan holds DC symbols only (first scan of a progressive file, JPEGDecodeMCU_P jpeg.inl:1819-2084 with
-// Ss = Se = 0) and their differences are shifted left by Al (:1884); a baseline scan has dc_only = false, al = 0.
+// The index entry of a block is the reader at its FIRST AC SYMBOL (after the refill at the top of the AC loop, jpeg.inl:2225-2230) and
+// its DC value comes with it (index format 2: both pre-scans decode the DC symbol, jpeg.inl:2129-2165, as they pass it), so a block's
+// decode starts with coefficient 1.
 // exact: the block is flagged JDA_INDEX_TRUNC -- its index entry is the reference reader's true phase, and magnitude reads lose the
 // bits the reference's window does not hold.  An unflagged block's entry may be canonical (the device pre-scan's: same bit
 // position, another phase), and the reference truncates nothing in it: the reader refills instead of reading short.
 template <int LIMIT>
-JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t &pred, bool dc_only = false, uint32_t al = 0, bool exact = true)
+JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t *coef, int32_t dc, bool exact = true)
 {
     uint32_t flags = 0;
-    jda_refill(br);
     if (LIMIT == 64) {
         jda_u64_alias *z = (jda_u64_alias *)coef;       // memset(pMCU, 0, 128)  :2121
 #pragma unroll
@@ -462,26 +462,10 @@ JDA_HD uint32_t jda_decode_block(jda_bitreader &br, const jda_tables &T, int16_t
     } else if (LIMIT == 5) {
         coef[1] = 0; coef[8] = 0; coef[9] = 0;          // :2118
     }
-    // DC  (:2129-2165)
-    uint32_t code = (uint32_t)(br.bits >> (52 - br.off)) & 0xfffu;
-    code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
-    uint32_t e = T.dc[code];
-    br.off += e >> 4;
-    const uint32_t s = e & 0xfu;
-    if (s) {
-        const int32_t folded = (int8_t)T.dc[code + 512];
-        if (folded) pred += folded;
-        else {
-            jda_refill(br);
-            pred += (int32_t)((uint32_t)jda_take_extend(br.bits, br.off, s) << al);
-            br.off += s;
-        }
-    }
-    if (LIMIT == 1) return 0;
-    coef[0] = (int16_t)pred;
-    if (dc_only) return 0;
+    coef[0] = (int16_t)dc;
     // AC  (:2223-2265).  The reference refills at the top AND the bottom of every iteration; the top
     // one is a no-op after a bottom one, so one refill before the loop + one per iteration is identical.
+    uint32_t code, e;
     int k = 1;
     jda_refill(br);
     while (k < LIMIT) {
@@ -527,14 +511,7 @@ JDA_HD int32_t jda_extend_top(uint32_t t, uint32_t s)
     return (int32_t)(v + (neg & ((0xffffffffu << s) + 1u)));
 }
 
-// The reader of the window-only path.  It does NOT keep the reference's 64-bit window: it keeps its own 64 bits
-// (hi:lo, refilled a dword at a time, the next dword prefetched one refill ahead so that no LDS round trip sits between two
-// symbols; the window in LDS holds byte-swapped dwords, so they are taken as they are).  `left` = bits of hi not consumed yet,
-// 0..31 -- hi may be used up completely, never untouched -- so that the next 32 stream bits are one v_alignbit_b32.
-#ifndef JDA_WR_POSITION
-#define JDA_WR_POSITION 1      // 0: the sliding three-dword window of rounds 1-3 (kept for A/B runs)
-#endif
-#if JDA_WR_POSITION
+// The reader of the window-only path (the window in LDS holds byte-swapped dwords, so they are taken as they are).
 // The window-only reader keeps ONE number: the position of the last consumed bit (GPU: counted from LDS address 0, so that the
 // dword it sits in is at byte address (m >> 3) & ~3).  A peek reads that dword and the next (one ds_read2_b32) and funnel-shifts;
 // consuming n bits is m += n.  Five instructions a symbol where sliding hi / lo / next by selects took nine; the price is a second
@@ -543,13 +520,6 @@ struct jda_wreader {
     uint32_t m;              // bits up to and including the last consumed one (window start = LDS address * 8; host: = 0), minus 1
     const uint8_t *base;     // host emulator: the window's first byte
 };
-#else
-struct jda_wreader {
-    uint32_t hi, lo, nxt;    // 64 stream bits + the dword after them
-    uint32_t left;           // bits of hi still to come
-    const uint8_t *wp;       // LDS address nxt came from
-};
-#endif
 // a + (b & 0xff) in one instruction (the byte select rides on the add: SDWA)
 JDA_HD uint32_t jda_add_byte0(uint32_t a, uint32_t b)
 {
@@ -577,7 +547,6 @@ JDA_HD uint32_t jda_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)      // low 
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
 #endif
 }
-#if JDA_WR_POSITION
 JDA_HD void jda_wr_init(jda_wreader &R, const uint8_t *wbase, uint32_t pos, uint32_t off)
 {
     // (for bit 0 of the window the last consumed bit is in the four bytes in front of it -- other LDS data, all "consumed")
@@ -601,27 +570,6 @@ JDA_HD uint32_t jda_wr_peek(const jda_wreader &R)
 #endif
 }
 JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n) { R.m += n; }
-#else
-JDA_HD void jda_wr_init(jda_wreader &R, const uint8_t *wbase, uint32_t pos, uint32_t off)
-{
-    const int32_t bit = (int32_t)((pos << 3) + off);
-    // the dword holding the last consumed bit (for bit 0 of the window: the four bytes in front of it -- other LDS data, all "consumed")
-    const uint8_t *p = wbase + (((bit - 1) >> 5) * 4);
-    R.hi = *(const jda_u32_alias *)p; R.lo = *(const jda_u32_alias *)(p + 4); R.nxt = *(const jda_u32_alias *)(p + 8);
-    R.wp = p + 8; R.left = (uint32_t)(-bit) & 31u;
-}
-JDA_HD uint32_t jda_wr_peek(const jda_wreader &R) { return jda_alignbit(R.hi, R.lo, R.left); }
-// n <= 31 bits consumed: slide a dword when hi is used up and more
-JDA_HD void jda_wr_consume(jda_wreader &R, uint32_t n)
-{
-    const bool go = n > R.left;
-    R.left = (R.left - n) & 31u;
-    R.hi = go ? R.lo : R.hi;
-    R.lo = go ? R.nxt : R.lo;
-    R.wp += go ? 4 : 0;
-    R.nxt = *(const jda_u32_alias *)R.wp;               // (re)loaded every time: unchanged address, unchanged value
-}
-#endif
 // the reference's refill (jpeg.inl:2110-2114) as far as its ulBitOff is concerned
 JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) : roff; }
 
@@ -641,44 +589,25 @@ JDA_HD uint32_t jda_ref_refill(uint32_t roff) { return roff > 47u ? (roff & 7u) 
 // zero_fill: clear the block first.
 // trunc: this lane's block is the flagged one (EXACT runs for the whole wavefront when any lane's is).
 template <int LIMIT, bool EXACT, bool LONG_LDS>
-JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t &pred, bool zero_fill,
-                                     bool dc_only, uint32_t al, bool trunc = true)
+JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *wbase, const jda_tables &T, int16_t *coef, int32_t dc, bool zero_fill, bool trunc = true)
 {
     jda_wreader R;
     jda_wr_init(R, wbase, pos, off);
     uint32_t fl = 0;                                     // OR of zz entries of the stored coefficients
-    uint32_t roff = EXACT ? jda_ref_refill(off) : 0u;   // the reference's ulBitOff
-    if (LIMIT == 64) {
-        if (zero_fill) {
-            jda_u64_alias *z = (jda_u64_alias *)coef;
+    uint32_t roff = EXACT ? jda_ref_refill(off) : 0u;   // the reference's ulBitOff at the block's first AC symbol
+    // (the pre-scan decoded the DC symbol, jpeg.inl:2129-2165: the entry points behind it, the value rides on the block's clearing)
+    if (LIMIT == 64 && zero_fill) {
+        jda_u64_alias *z = (jda_u64_alias *)coef;
+        z[0] = (uint64_t)(uint16_t)dc;
 #pragma unroll
-            for (int i = 0; i < 16; i++) z[i] = 0;
-        }
-    } else if (LIMIT == 5) {
-        coef[1] = 0; coef[8] = 0; coef[9] = 0;
+        for (int i = 1; i < 16; i++) z[i] = 0;
+    } else {
+        if (LIMIT == 5) { coef[1] = 0; coef[8] = 0; coef[9] = 0; }
+        coef[0] = (int16_t)dc;
     }
-    // DC  (:2129-2165).  Code (<= 16 bits) and magnitude (<= 15) are both inside the 32 peeked bits; the reference
-    // refills before the magnitude read (:2149), so a DC value is never truncated.
-    uint32_t w = jda_wr_peek(R);
-    uint32_t code = w >> 20;
-    code = code >= 0xf80u ? (code & 0xffu) : (code >> 6);
-    uint32_t e = T.dc[code];
-    const int32_t folded = (int8_t)T.dc[code + 512];
-    const uint32_t dlen = e >> 4, s = e & 0xfu;
-    const bool take = s != 0 && folded == 0;             // magnitude bits follow in the stream
-    const int32_t mag = (int32_t)((uint32_t)jda_extend_top(w << dlen, s) << al);
-    pred += s == 0 ? 0 : (folded ? folded : mag);
-    if (EXACT) {
-        roff += dlen;
-        if (take) roff = jda_ref_refill(roff) + s;
-    }
-    jda_wr_consume(R, dlen + (take ? s : 0u));
-    if (LIMIT == 1) return 0;
-    coef[0] = (int16_t)pred;
-    if (dc_only) return 0;                               // no AC symbol in this scan: a DC-only block (flags 0)
+    uint32_t w, e;
     const uint32_t zzb = JDA_LDS_A32(T.zz);              // (GPU: the zigzag table's LDS address rides in k2, so a lookup's address is one add)
     uint32_t k2 = zzb + 2;                               // twice the zigzag position: the byte offset into the zigzag table
-    if (EXACT) roff = jda_ref_refill(roff);
     // EOB is recognised on the stream bits themselves -- one code per table, checked by the host (JDA_DESC_GENERAL_P1) --
     // before the symbol is looked up: a block costs one trip per coefficient symbol, none for its EOB, and the wavefront
     // runs as many trips as its longest block needs.  (A block of a decoded MCU holds no invalid code: the pre-scan ends
@@ -1024,12 +953,12 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 #define JDA_SEG_SLOT  268u           // bytes a lane reads: its segment + 12 bytes of the next; 67 dwords per lane in LDS (odd: no bank conflicts)
 #define JDA_SEG_DEAD  0x7fffffffu    // state of a walk that met an invalid code (bit 31 is the rounds' "changed" mark)
 #define JDA_SEG_CHANGED 0x80000000u // entry-state word: "differs from the previous round's" (the walker's own bits are 14:0)
-enum { JDA_SEG_SPEC = 0, JDA_SEG_COUNT = 1, JDA_SEG_WRITE = 2, JDA_SEG_FUSED = 3 /* SPEC and COUNT in one walk: jda_segscan_fused */,
-       JDA_SEG_RECORD = 4 /* FUSED + one record per block start + truncation candidates: no WRITE walk follows (jda_segscan_finalize) */ };
+enum { JDA_SEG_SPEC = 0 /* round 0: the exit state only */, JDA_SEG_RECORD = 4 /* + the segment's sums, one record per block start, truncation candidates (jda_segscan_finalize) */ };
 #define JDA_SEG_SUM_WORDS 8u         // per segment: block starts, DC sums [3], phase map, bad | has-restart | max AC category << 4, lag word at the last block start, round
 #define JDA_ST_NCAND 66u             // result word: truncation candidates appended (RECORD)
-#define JDA_REC_POS_BITS 12u         // a record: bit position of the block's first bit in its segment (11 bits) | JDA_REC_AFTER_RST | running DC sum of its component << 12
-#define JDA_REC_AFTER_RST 0x800u     // the sum counts from a restart inside the segment, not from the segment's entry
+#define JDA_REC_POS_BITS 12u         // a record: bit position of the block's first AC symbol, counted from its segment's first bit (the block's DC symbol starts in the
+                                     // segment: <= 2047 + 27) | running DC sum of its component, the block's own difference included, << 12
+#define JDA_SEG_FIRST_RST_SHIFT 8u   // seg_sum word 5, bits 31:8: the ordinal of the segment's first block behind an interval end (its sums count from a restart)
 
 struct jda_segscan_params {          // one per image
     const uint8_t *scan;             // filtered scan (global), zero padded to n_segs * JDA_SEG_BYTES + 16
@@ -1118,21 +1047,13 @@ struct jda_seg_reader {
 #ifndef JDA_SEG_REFILL_STEPS
 #define JDA_SEG_REFILL_STEPS 8u
 #endif
-#ifndef JDA_SEG_READER_SELECT
-#define JDA_SEG_READER_SELECT 1      // 0: the reader that reloads on its own inside the step (rounds 2-3; kept for A/B runs)
-#endif
 JDA_HD void jda_seg_reader_init(jda_seg_reader &R, const uint32_t JDA_GLOBAL *d, uint32_t p)
 {
     R.d = d; R.idx = R.base = p >> 5;
     R.hi = __builtin_bswap32(d[R.idx]); R.lo = __builtin_bswap32(d[R.idx + 1u]);
-#if JDA_SEG_READER_SELECT
     R.n1 = __builtin_bswap32(d[R.idx + 2u]); R.n2 = __builtin_bswap32(d[R.idx + 3u]); R.n3 = __builtin_bswap32(d[R.idx + 4u]);      // (swapped here, once a reload: the slide is in every step)
-#else
-    R.n1 = d[R.idx + 2u]; R.n2 = d[R.idx + 3u]; R.n3 = d[R.idx + 4u];
-#endif
 }
 // the next 32 bits of the stream at bit p of the segment
-#if JDA_SEG_READER_SELECT
 // (the window slides by selects, no branch: the walk's loop sees to it that p stays within the loaded dwords -- jda_seg_reader_holds --
 // and reloads for the whole wavefront otherwise; a peek is at most one dword ahead of the last one)
 JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
@@ -1148,19 +1069,6 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
     return (uint32_t)((v << (p & 31u)) >> 32);
 }
 JDA_HD bool jda_seg_reader_holds(const jda_seg_reader &R, uint32_t p) { return (p >> 5) - R.base <= 3u; }
-#else
-JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
-{
-    const uint32_t wi = p >> 5;
-    if (wi != R.idx) {
-        if ((wi - R.idx != 1u) | (wi - R.base > 3u)) jda_seg_reader_init(R, R.d, p);      // (rare: see above)
-        else { R.hi = R.lo; R.lo = __builtin_bswap32(R.n1); R.n1 = R.n2; R.n2 = R.n3; R.idx = wi; }
-    }
-    const uint64_t v = ((uint64_t)R.hi << 32) | R.lo;
-    return (uint32_t)((v << (p & 31u)) >> 32);
-}
-JDA_HD bool jda_seg_reader_holds(const jda_seg_reader &, uint32_t) { return true; }
-#endif
 #define JDA_SEG_READ_DWORDS 68u     // dwords of the scan a walk may touch from its segment's start (64 + the window's reach)
 
 // The walks' DC entries: the reference's DC LUT (jpeg.inl:1098-1152) re-laid out like the AC entries -- (code length - 1) << 12 |
@@ -1280,27 +1188,6 @@ JDA_HD void jda_store_u32x4(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_
     uint32_t *o = (uint32_t *)p; o[0] = a; o[1] = b; o[2] = c; o[3] = d;
 #endif
 }
-// WRITE's entry-by-entry stores (a lane's first and last group): the n newest of the buffered entries, the newest at ordinal g_new
-JDA_HD void jda_seg_flush_index(uint32_t *blk_index, uint32_t g_new, uint32_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
-{
-    uint32_t JDA_GLOBAL *o = JDA_G(uint32_t, blk_index) + g_new;
-    o[0] = b3;
-    if (n > 1u) o[-1] = b2;
-    if (n > 2u) o[-2] = b1;
-    if (n > 3u) o[-3] = b0;
-}
-JDA_HD void jda_seg_flush_dc(int16_t *blk_dc, uint32_t g_new, uint32_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
-{
-    int16_t JDA_GLOBAL *o = JDA_G(int16_t, blk_dc) + g_new;
-    o[0] = (int16_t)(b3 >> 16);
-    if (n > 1u) o[-1] = (int16_t)b3;
-    if (n > 2u) o[-2] = (int16_t)(b2 >> 16);
-    if (n > 3u) o[-3] = (int16_t)b2;
-    if (n > 4u) o[-4] = (int16_t)(b1 >> 16);
-    if (n > 5u) o[-5] = (int16_t)b1;
-    if (n > 6u) o[-6] = (int16_t)(b0 >> 16);
-    if (n > 7u) o[-7] = (int16_t)b0;
-}
 // the six 5-bit byte lags of a counting walk + n each (n <= 3): U + n * 0x02108421 on the 24-bit multiplier and a shift-add
 // (the 26-bit constant makes the product a quarter-rate v_mad_u64_u32, twice per symbol)
 JDA_HD uint32_t jda_lag_add(uint32_t U, uint32_t n)
@@ -1317,13 +1204,12 @@ template <int OP, bool RST = false>
 JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t entry, const uint32_t JDA_GLOBAL *segw, const uint8_t *wt,
                              jda_seg_sum &S, jda_seg_stats &ST, uint32_t round = 0)
 {
-    const bool REC = OP == JDA_SEG_RECORD;                            // FUSED + records + truncation candidates
-    const bool CNT = OP == JDA_SEG_COUNT || OP == JDA_SEG_FUSED || REC;      // the segment's sums are wanted
-    const bool TOL = OP == JDA_SEG_SPEC || OP == JDA_SEG_FUSED || REC;       // a speculative walk steps over an invalid code
+    const bool REC = OP == JDA_SEG_RECORD;                            // sums + one record per block start + truncation candidates (else: the exit state only)
 #ifndef JDA_SEG_PAIR_OFF
 #define JDA_SEG_PAIR_OFF() false                                             // (host simulator: a switch, to count what the pairs save)
 #endif
-    const bool PAIR = OP != JDA_SEG_WRITE && !JDA_SEG_PAIR_OFF();                           // two AC symbols a step where the table holds the second (JDA_WT_PAIR_*)
+    const bool PAIR = !JDA_SEG_PAIR_OFF();                           // two AC symbols a step where the table holds the second (JDA_WT_PAIR_*)
+    (void)ST;
     S.nblk = 0; S.dcsum[0] = S.dcsum[1] = S.dcsum[2] = 0; S.phase_map = 0; S.bad = 0; S.lag_last = 0; S.max_ac = 0;
     if (entry == JDA_SEG_DEAD) { S.bad = 1; return JDA_SEG_DEAD; }
     uint32_t p = entry & 63u, b2 = ((entry >> 6) & 7u) * 2u, k = (entry >> 9) & 63u;      // b2: twice the block's place in the MCU
@@ -1338,46 +1224,28 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         const uint32_t a = ci == 0u ? aid0 : (ci == 1u ? aid1 : aid2), d = ci == 0u ? did0 : (ci == 1u ? did1 : did2);
         if (i < P.nblocks && ci < 3u) { csel |= ci << (2u * i); acsel |= a << (2u * i); dcsel |= (2u + d) << (2u * i); }
     }
-    // WRITE: the reference reader (pBuf, ulBitOff), the block ordinal and the DC predictors at the entry
-    uint32_t pos = 0, off = 0, g = 0, pos_pre = 0, off_pre = 0;
-    int32_t pred0 = 0, pred1 = 0, pred2 = 0;
-    const uint32_t limit_pos = P.scan_len + JDA_SCAN_PAD - 8;
-    uint32_t U = 0;                                                 // COUNT: the six byte lags
+    uint32_t U = 0;                                                 // the six byte lags
     const uint32_t kOnes = 0x02108421u, kGuard = 0x21084210u;       // 1 / 16 in each 5-bit field
     uint32_t nblk = 0;
     bool sbad = false;                                              // (a flag per lane: the compiler keeps it as a lane mask on the scalar unit)
     int32_t ds0 = 0, ds1 = 0, ds2 = 0;
-    uint32_t max_ac = 0, max_dc = 0;
-    if (OP == JDA_SEG_WRITE) {
-        const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)seg * 5;
-        g = st[0]; pred0 = (int32_t)st[1]; pred1 = (int32_t)st[2]; pred2 = (int32_t)st[3];
-        const uint32_t j = st[4], p_abs = seg * JDA_SEG_BITS + p;
-        pos = (p_abs >> 3) - j; off = (p_abs & 7u) + 8u * j;
-        pos_pre = pos; off_pre = off;
-    }
-    if (CNT) U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);
-    uint32_t pend = 0, pend_g = 0;                                  // WRITE: index entry of the block in progress (if it began here)
-    // WRITE: a lane's entries go to consecutive ordinals, one every few steps, each lane in a cache line of its own: the lane
-    // keeps the last four index entries / eight predictors in registers (shifted in, newest last) and stores an aligned group of
-    // 16 bytes when it completes one; the groups it shares with its neighbours (its first and last) go out entry by entry.
-    uint32_t ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0, ibn = 0, ib_g = 0;  // ibn: entries not stored yet, ib_g: ordinal of the newest
-    uint32_t db0 = 0, db1 = 0, db2 = 0, db3 = 0, dbn = 0;            // (the newest predictor's ordinal is g - 1)
+    uint32_t max_ac = 0;
+    if (REC) U = 0u | (1u << 5) | (2u << 10) | (3u << 15) | (4u << 20) | (5u << 25);
     // RECORD: the last four records (newest last; a group of four is stored when it is complete: the segment's slots are its own),
-    // the lag word at the start of the block in progress
+    // the lag word at the first AC symbol of the block in progress
     uint32_t rb0 = 0, rb1 = 0, rb2 = 0, rb3 = 0, Ublk = 0;
     uint32_t JDA_GLOBAL *recs = REC ? JDA_G(uint32_t, P.records) + (size_t)seg * P.rec_cap : (uint32_t JDA_GLOBAL *)0;
-    bool pending = false, bad = false, stop = false;                // stop: leave the loop after this step (one exit test per step)
-    // RST: the next interval start ahead of the walk (as a bit position relative to the segment), blocks left in the interval
+    // RST: the next interval start ahead of the walk (as a bit position relative to the segment); the ordinal of the segment's first
+    // block behind an interval end (its DC sums count from there)
     const uint32_t JDA_GLOBAL *rpos = JDA_G(const uint32_t, P.restart_pos);
     const uint32_t seg_bit0 = seg * JDA_SEG_BITS;
-    uint32_t nr = 0, next_bit = 0xffffffffu, left_blocks = 0, has_rst = 0;
+    uint32_t nr = 0, next_bit = 0xffffffffu, has_rst = 0, first_rst = 0;
     if (RST) {
         const uint32_t byte0 = (seg_bit0 + p) >> 3;                 // smallest nr >= 1 with restart_pos[nr] * 8 > the entry position
         uint32_t lo = 1, hi = P.n_intervals;                        // (restart_pos[n_intervals] is the sentinel)
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rpos[mid] > byte0) hi = mid; else lo = mid + 1; }
         nr = lo;
         next_bit = (rpos[nr] << 3) - seg_bit0;
-        if (OP == JDA_SEG_WRITE) left_blocks = P.interval_blocks - (g - (k != 0u ? 1u : 0u)) % P.interval_blocks;   // (k != 0: block g - 1 is still open)
     }
     jda_seg_reader R;
     bool go = p < JDA_SEG_BITS;
@@ -1395,36 +1263,6 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         }
         const bool isdc0 = k == 0;
         const uint32_t c = jda_bfe(csel, b2, 2u);
-        if (OP == JDA_SEG_WRITE) {                                  // a block starts here (jpeg.inl:2129-2165): by selects, but for the two stores
-            const bool term = isdc0 & (g >= P.n_blocks_total);      // past the image: the reader as the last block left it closes the index
-            const bool begin = isdc0 & !term;
-            if (term) {
-                if (g == P.n_blocks_total) {
-                    const uint32_t off_end = (RST && P.round_last) ? ((off_pre + 7u) & ~7u) : off_pre;    // (a whole last interval is rounded up like the others)
-                    JDA_G(uint32_t, P.blk_index)[g] = (pos_pre << JDA_INDEX_OFF_BITS) | off_end; ST.terminal = 1;
-                }
-            }
-            const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-            const bool out_of_range = begin & ((pr < -32768) | (pr > 32767));
-            bad |= out_of_range; stop |= out_of_range | term;
-            if (begin) {
-                db0 = jda_alignbit(db1, db0, 16); db1 = jda_alignbit(db2, db1, 16);
-                db2 = jda_alignbit(db3, db2, 16); db3 = jda_alignbit((uint32_t)pr, db3, 16);
-                dbn++;
-                if ((g & 7u) == 7u) {
-                    if (dbn == 8u) jda_store_u32x4(P.blk_dc + (g - 7u), db0, db1, db2, db3);
-                    else jda_seg_flush_dc(P.blk_dc, g, dbn, db0, db1, db2, db3);
-                    dbn = 0;
-                }
-            }
-#ifdef JDA_SEG_BLOCK_HOOK
-            if (begin) JDA_SEG_BLOCK_HOOK();                        // (host simulator: where blocks start among the steps)
-#endif
-            pend = begin ? (pos << JDA_INDEX_OFF_BITS) | off : pend;       // the reader after the block's opening refill
-            pend_g = begin ? g : pend_g;
-            pending = pending | begin;
-            g += begin ? 1u : 0u;
-        }
         const uint32_t w = jda_seg_reader_peek(R, p);
         // one lookup, one address: the table by the block's place in the MCU and DC / AC, the entry by the 11-bit key (the
         // stream's top 10 bits, or 1024 + the 10 bits behind six leading ones)
@@ -1433,12 +1271,12 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         const uint32_t e32 = *(const jda_u32_alias *)(wt + (tsel << 13) + (key << 2));      // (sums: two shift-adds onto the tables' address)
         const uint32_t e = e32 & 0xffffu;
         const uint32_t elow = e & 0xffu;
-        // no such code (:2137-2138, :2237-2238).  A speculative walk that is not on the decoder's path yet may meet anything: it steps
+        // no such code (:2137-2138, :2237-2238).  A walk that is not on the decoder's path yet may meet anything: it steps
         // on one bit and keeps looking (a walk that gave up would hand "dead" down the chain of segments, one per round) -- a
-        // one-bit symbol without effects, by selects; the other passes stop.
+        // one-bit symbol without effects, by selects; its sums are void from there on (sbad).
         const bool inval = elow == JDA_AC_NONE;
-        if (TOL) sbad |= inval; else { bad |= inval; stop |= inval; }
-        const bool live = !inval & !stop;                           // the step's effects count
+        sbad |= inval;
+        const bool live = !inval;                                   // the step's effects count
         const bool isdc = isdc0 & live;
         const bool eob = (elow == JDA_AC_EOB) & !inval;
         const uint32_t len = inval ? 1u : (e >> 12) + 1u, sz = (eob | inval) ? 0u : (e >> 8) & 15u;
@@ -1446,65 +1284,41 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
         const bool dcmag = isdc & (sz != 0u) & ((e & 1u) == 0u);    // a DC magnitude the reference refills for (not folded into the LUT entry)
         const bool acmag = !isdc0 & live & (sz != 0u) & (kk < 64u); // an AC magnitude that is stored
         const uint32_t p1 = p + len;
-        if (OP == JDA_SEG_WRITE) {
-            off += len;
-            const bool r1 = dcmag & (off > 47u);                    // :2149-2154
-            pos += r1 ? off >> 3 : 0u; off = r1 ? off & 7u : off;
-            if (acmag && off + sz > 64u) {                          // the magnitude read runs out of the window (rare)
-                ST.trunc_events++;
-                if (pending) pend |= JDA_INDEX_TRUNC;               // the block began in this segment: its entry is still here
-                else jda_atomic_or_u32(P.blk_index + (g - 1u), JDA_INDEX_TRUNC);
-            }
-            const uint32_t m = acmag ? sz : 0u;
-            max_ac = m > max_ac ? m : max_ac;
-            off += sz;
-        }
-        if (REC) {                                                  // a counted block starts here: its record (before its own difference joins the sum)
-            const bool counted = isdc & !sbad;
+        bool counted = false;
+        if (REC) {
+            // a counted block starts here: its record is its DC VALUE so far as the segment knows it -- the running sum of its
+            // component's differences (:2155-2165; a folded entry holds the same value), its own included -- and the place of its first AC symbol
+            // a DC category no 8-bit baseline stream has does not fit the record's 20-bit sum: such a file keeps to the serial pre-scan
+            sbad |= isdc & (sz > 11u);
+            counted = isdc & !sbad;
+            const int32_t diff = (counted & (sz != 0u)) ? jda_extend_top(w << len, sz) : 0;
+            ds0 += c == 0 ? diff : 0; ds1 += c == 1 ? diff : 0; ds2 += c >= 2 ? diff : 0;
             const int32_t run = c == 0 ? ds0 : (c == 1 ? ds1 : ds2);
-            const uint32_t rec = p | (RST && has_rst ? JDA_REC_AFTER_RST : 0u) | ((uint32_t)run << JDA_REC_POS_BITS);
+            const uint32_t rec = (p1 + sz) | ((uint32_t)run << JDA_REC_POS_BITS);          // (<= 2047 + 27: twelve bits)
             rb0 = counted ? rb1 : rb0; rb1 = counted ? rb2 : rb1; rb2 = counted ? rb3 : rb2; rb3 = counted ? rec : rb3;
-            Ublk = counted ? U : Ublk;
             const bool group = counted & ((nblk & 3u) == 3u), fits = nblk < P.rec_cap;      // (one branch region, not two nested ones)
             if (group & fits) jda_store_u32x4(recs + (nblk - 3u), rb0, rb1, rb2, rb3);
             sbad |= group & !fits;                                  // (jda_record_cap leaves no room for this; memory stays ours anyway)
-            // a DC category no 8-bit baseline stream has does not fit the record's 20-bit sum: such a file keeps to the serial pre-scan
-            sbad |= isdc & (sz > 11u);
-        }
-        if (CNT) {
-            nblk += (isdc & !sbad) ? 1u : 0u;
+            nblk += counted ? 1u : 0u;
             U = jda_lag_add(U, ((p & 7u) + len) >> 3);                   // whole bytes the code bits advance the stream position by
             const uint32_t f1 = ((U | kGuard) - 6u * kOnes) & kGuard;
-            if (REC) {
-                // SURVEY fact 6 without knowing the entry lag: the reference reads the magnitude at ulBitOff = 8 u + (p1 & 7) and loses
-                // bits when that + sz > 64 -- u >= 7 for (p1 & 7) + sz in 9..16, u >= 6 above 16 (u <= 7 here) -- so the six candidate
-                // lags are tested at once; the rare hit is kept with the lag word at the block's start (jda_segscan_resolve)
-                // (ulBitOff <= 47 in front of the code for every candidate lag: code + magnitude must be 17 bits and more -- rare symbols)
-                const uint32_t m = acmag ? sz : 0u;
-                max_ac = m > max_ac ? m : max_ac;
-                if (__builtin_expect(acmag && len + sz > 16u && !sbad, 0)) {
-                    const uint32_t t = (p1 & 7u) + sz;
-                    const uint32_t f7 = ((U | kGuard) - 7u * kOnes) & kGuard;
-                    const uint32_t hit = t > 16u ? f1 : (t > 8u ? f7 : 0u);
-                    if (hit != 0u) {
-                        const uint32_t at = jda_atomic_inc_u32(P.stats + JDA_ST_NCAND);
-                        if (at < P.cand_cap) jda_store_u32x4(P.cands + (size_t)at * 4u, seg, nblk | (round << 16), Ublk, hit);
-                    }
+            // SURVEY fact 6 without knowing the entry lag: the reference reads the magnitude at ulBitOff = 8 u + (p1 & 7) and loses
+            // bits when that + sz > 64 -- u >= 7 for (p1 & 7) + sz in 9..16, u >= 6 above 16 (u <= 7 here) -- so the six candidate
+            // lags are tested at once; the rare hit is kept with the lag word at the block's first AC symbol (jda_segscan_resolve)
+            // (ulBitOff <= 47 in front of the code for every candidate lag: code + magnitude must be 17 bits and more -- rare symbols)
+            const uint32_t m = acmag ? sz : 0u;
+            max_ac = m > max_ac ? m : max_ac;
+            if (__builtin_expect(acmag && len + sz > 16u && !sbad, 0)) {
+                const uint32_t t = (p1 & 7u) + sz;
+                const uint32_t f7 = ((U | kGuard) - 7u * kOnes) & kGuard;
+                const uint32_t hit = t > 16u ? f1 : (t > 8u ? f7 : 0u);
+                if (hit != 0u) {
+                    const uint32_t at = jda_atomic_inc_u32(P.stats + JDA_ST_NCAND);
+                    if (at < P.cand_cap) jda_store_u32x4(P.cands + (size_t)at * 4u, seg, nblk | (round << 16), Ublk, hit);
                 }
             }
             U &= dcmag ? ~(f1 - (f1 >> 4)) : 0xffffffffu;           // the refill before an unfolded DC magnitude
             U = jda_lag_add(U, ((p1 & 7u) + sz) >> 3);
-        }
-        if (CNT || OP == JDA_SEG_WRITE) {                           // the DC difference (:2155-2165; a folded entry holds the same value)
-            const int32_t diff = (isdc & (sz != 0u)) ? jda_extend_top(w << len, sz) : 0;
-            const int32_t d0 = c == 0 ? diff : 0, d1 = c == 1 ? diff : 0, d2 = c >= 2 ? diff : 0;
-            if (CNT) { const int32_t gate = sbad ? 0 : -1; ds0 += d0 & gate; ds1 += d1 & gate; ds2 += d2 & gate; }
-            if (OP == JDA_SEG_WRITE) {
-                pred0 += d0; pred1 += d1; pred2 += d2;
-                const int32_t pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-                const uint32_t a = isdc ? (uint32_t)(pr < 0 ? -pr : pr) : 0u;
-                max_dc = a > max_dc ? a : max_dc;
-            }
         }
         p = p1 + sz;
         const bool ends = (eob | (kk + 1u >= 64u)) & !inval;
@@ -1516,19 +1330,10 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
 #endif
         const bool hold = iend & eob;                               // the refill after an interval's closing EOB waits for the rounding
         // ---- the refill at the end of the step (not after EOB in the reference -- there it is the next block's opening one)
-        if (OP == JDA_SEG_WRITE) {
-            const bool r2 = (off > 47u) & !hold;
-            const uint32_t npos = pos + (r2 ? off >> 3 : 0u), noff = r2 ? off & 7u : off;
-            // what closes the index if this was the image's last symbol: the reader before the refill after an EOB (the reference has
-            // not refilled yet), after it otherwise (a block that ends on its 63rd coefficient has had its bottom refill)
-            pos_pre = eob ? pos : npos; off_pre = eob ? off : noff;
-            pos = npos; off = noff;
-            const bool over = pos > limit_pos;                      // the stream ran out: the serial pre-scan knows what the reference does then
-            bad |= over; stop |= over;
-        }
-        if (CNT) {
+        if (REC) {
             const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
             U &= hold ? 0xffffffffu : ~(f - (f >> 4));
+            Ublk = counted ? U : Ublk;                              // the lags at the block's first AC symbol (behind the refill at the top of the AC loop)
         }
         k = (ends | inval) ? 0u : kk + 1u;
         b2 = ends ? bn : b2;
@@ -1545,9 +1350,7 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             if (REC) {
                 const uint32_t m = (pair & (dk != 0u) & (kend <= 64u)) ? (pd >> 10) & 15u : 0u;      // (a stored magnitude: the coefficient's place is in the block)
                 max_ac = m > max_ac ? m : max_ac;
-            }
-            if (CNT) {                                              // (no pair: no bytes, and no lag is at 6 behind the refill above ..
-                U = jda_lag_add(U, ((p & 7u) + bits_b) >> 3);
+                U = jda_lag_add(U, ((p & 7u) + bits_b) >> 3);       // (no pair: no bytes, and no lag is at 6 behind the refill above ..
                 const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
                 U &= (RST && !pair) ? 0xffffffffu : ~(f - (f >> 4)); // .. but behind an interval's closing EOB, whose refill waits: RST)
             }
@@ -1555,36 +1358,15 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             k = pair ? (ends_b ? 0u : kend) : k;
             b2 = ends_b ? bn : b2;
         }
-        if (OP == JDA_SEG_WRITE && ends && pending) {
-            ib0 = ib1; ib1 = ib2; ib2 = ib3; ib3 = pend; ib_g = pend_g; ibn++;
-            if ((pend_g & 3u) == 3u) {
-                if (ibn == 4u) jda_store_u32x4(P.blk_index + (pend_g - 3u), ib0, ib1, ib2, ib3);
-                else jda_seg_flush_index(P.blk_index, pend_g, ibn, ib0, ib1, ib2, ib3);
-                ibn = 0;
-            }
-            pending = false;
-        }
         if (RST) {
-            if (OP == JDA_SEG_WRITE) {
-                // the reference restarts by MCU count, the filter found the markers: they must agree
-                left_blocks -= ends ? 1u : 0u;
-                const bool expect = ends & live & (left_blocks == 0u);
-                if ((expect != iend) & (g < P.n_blocks_total)) ST.mismatch = 1;
-                left_blocks = left_blocks == 0u ? P.interval_blocks : left_blocks;
-            }
             if (iend) {                                             // over the padding to the next interval's first byte
                 const uint32_t frac = (p & 7u) ? 1u : 0u;           // (interval starts are byte aligned, so are segment starts)
-                if (OP == JDA_SEG_WRITE) {
-                    off = (off + 7u) & ~7u;                         // :5339-5346, no refill ..
-                    pos_pre = pos; off_pre = off;
-                    if (off > 47u) { pos += off >> 3; off &= 7u; }  // .. then the next block's opening one
-                    pred0 = pred1 = pred2 = 0;
-                }
-                if (CNT) {
+                if (REC) {
                     U = jda_lag_add(U, frac);
                     const uint32_t f = ((U | kGuard) - 6u * kOnes) & kGuard;
                     U &= ~(f - (f >> 4));
-                    ds0 = ds1 = ds2 = 0; has_rst = JDA_SEG_HAS_RESTART;
+                    ds0 = ds1 = ds2 = 0;
+                    first_rst = has_rst ? first_rst : nblk; has_rst = JDA_SEG_HAS_RESTART;
                 }
                 if (REC && !sbad && nr < P.n_intervals) {      // who ended the interval in front of start nr, and after how many of its blocks
                     uint32_t JDA_GLOBAL *ev = JDA_G(uint32_t, P.rst_events) + 2u * (size_t)nr;
@@ -1595,18 +1377,12 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
                 nr++; next_bit = nr <= P.n_intervals ? (rpos[nr] << 3) - seg_bit0 : 0xffffffffu;
             }
         }
-        go = (p < JDA_SEG_BITS) & !stop;
+        go = p < JDA_SEG_BITS;
         since++;
         // (the next peek must find p within the loaded dwords and at most one dword on: a lane that has used them up, or jumped over an
         // interval's padding, sits out the rest of the wavefront's steps until the reload)
-    } while (go & (since < JDA_SEG_REFILL_STEPS) & jda_seg_reader_holds(R, p) & !(JDA_SEG_READER_SELECT && RST && jumped));
+    } while (go & (since < JDA_SEG_REFILL_STEPS) & jda_seg_reader_holds(R, p) & !(RST && jumped));
     }
-    if (OP == JDA_SEG_WRITE) {                                      // what is left of the lane's last groups
-        if (ibn) jda_seg_flush_index(P.blk_index, ib_g, ibn, ib0, ib1, ib2, ib3);
-        if (dbn) jda_seg_flush_dc(P.blk_dc, g - 1u, dbn, db0, db1, db2, db3);
-    }
-    if (OP == JDA_SEG_WRITE && pending && !bad) jda_atomic_or_u32(P.blk_index + pend_g, pend);      // the block goes on in the next segment
-    if (OP == JDA_SEG_WRITE) { ST.max_ac_bits = max_ac; ST.max_abs_dc = max_dc; }
     if (REC) {                                                      // what is left of the last group, slot by slot
         const uint32_t r = nblk & 3u, n4 = nblk & ~3u;
         if (nblk <= P.rec_cap) {
@@ -1615,14 +1391,12 @@ JDA_HD uint32_t jda_seg_walk(const jda_segscan_params &P, uint32_t seg, uint32_t
             if (r > 2u) recs[n4 + r - 3u] = rb1;
         }
         S.lag_last = Ublk; S.max_ac = max_ac;
-    }
-    S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2; S.bad = (sbad ? 1u : 0u) | has_rst;
-    if (bad) { S.bad = 1; ST.bad = 1; return JDA_SEG_DEAD; }
-    if (CNT) {
         uint32_t map = 0;
         for (int j = 0; j < 6; j++) map |= ((U >> (5 * j)) & 7u) << (3 * j);
         S.phase_map = map;
     }
+    S.nblk = nblk; S.dcsum[0] = ds0; S.dcsum[1] = ds1; S.dcsum[2] = ds2;
+    S.bad = (sbad ? 1u : 0u) | has_rst | (first_rst << JDA_SEG_FIRST_RST_SHIFT);
     return (p - JDA_SEG_BITS) | (b2 << 5) | (k << 9);
 }
 
@@ -1666,48 +1440,54 @@ JDA_HD jda_filter_bits jda_filter_run(const jda_filter_masks &M, uint32_t valid,
     return F;
 }
 
-// ---- RECORD mode: from records to the index (block-parallel) ----------------------------------------
-// The index entry of a block the reference reads without truncation is CANONICAL here: (p >> 3) << 7 | (p & 7) for the bit
-// position p of the block's first bit -- P1 needs p alone (pos * 8 + off, whatever the split); only a block flagged
-// JDA_INDEX_TRUNC carries the reference reader's true (pBuf, ulBitOff), which its emulation starts from.  The serial pre-scan
-// writes the true phase everywhere: the two indexes agree on p and on the flag of every block and on the whole entry of a flagged one.
+// ---- from records to the index (block-parallel) ----------------------------------------------------------
+// Index format 2: entry = the reader at the block's FIRST AC SYMBOL, blk_dc = the block's own DC value.  The entry of a block the
+// reference reads without truncation is CANONICAL here: (p >> 3) << 7 | (p & 7) for the bit position p -- P1 needs p alone
+// (pos * 8 + off, whatever the split); only a block flagged JDA_INDEX_TRUNC carries the reference reader's true (pBuf, ulBitOff)
+// there, which its emulation starts from.  The serial pre-scan writes the true phase everywhere: the two indexes agree on p and
+// on the flag of every block and on the whole entry of a flagged one.  The closing entry (behind the last block) bounds the scan
+// from above: the serial pre-scan's is the reader as the last block left it, this one's lies behind the DC symbol that the stream's
+// padding decodes to -- at most 34 bits further on (nothing reads it as a position: the last tile's window ends there).
 JDA_HD uint32_t jda_index_canonical(uint32_t p_abs) { return ((p_abs >> 3) << JDA_INDEX_OFF_BITS) | (p_abs & 7u); }
 struct jda_fin_acc { uint32_t bad, terminal, max_abs_dc; };
-// record i of segment seg (first block ordinal g0, predictors pr0..2 at its entry: jda_segscan_sums) -> index entry, predictor
+// record i of segment seg (first block ordinal g0, DC values pr0..2 of the components at its entry: jda_segscan_sums; rst_from: the
+// segment's first record behind an interval end, 0xffffffff without one) -> index entry, DC value
 // b0 = g0 % P.nblocks, inv = jda_fin_recip(P.nblocks): the block's place in the MCU without a division per record
 JDA_HD uint32_t jda_fin_recip(uint32_t nblocks) { return (65536u + nblocks - 1u) / nblocks; }      // x / n = x * inv >> 16 while x * n < 65536
 // (the record's load apart from its use: the kernel asks for the records of several segments before it waits for the first)
 JDA_HD uint32_t jda_finalize_load(const jda_segscan_params &P, uint32_t seg, uint32_t i) { return JDA_G(const uint32_t, P.records)[(size_t)seg * P.rec_cap + i]; }
-JDA_HD void jda_finalize_apply(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t rec, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
+JDA_HD uint32_t jda_fin_rst_from(uint32_t sum5) { return (sum5 & JDA_SEG_HAS_RESTART) ? sum5 >> JDA_SEG_FIRST_RST_SHIFT : 0xffffffffu; }
+JDA_HD void jda_finalize_apply(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t rec, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2,
+                               uint32_t rst_from, jda_fin_acc &A)
 {
     const uint32_t g = g0 + i;
     if (g > P.n_blocks_total) return;                               // behind the image: padding decoded as blocks
-    const uint32_t p_abs = seg * JDA_SEG_BITS + (rec & (JDA_SEG_BITS - 1u));
+    const uint32_t p_abs = seg * JDA_SEG_BITS + (rec & ((1u << JDA_REC_POS_BITS) - 1u));
     // a stream that ends early has been read on into its zero padding: the serial pre-scan knows what the reference does with it
     // (its test is on the reference's pBuf, at most five bytes behind: the margin makes this one the stricter)
     if ((p_abs >> 3) + 8u > P.scan_len + JDA_SCAN_PAD - 8u) A.bad = 1;
-    if (g == P.n_blocks_total) {                                    // the reader as the last block left it closes the index
-        // (a whole last interval is rounded up to a byte like the others, jpeg.inl:5339-5346)
-        JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical((P.restart_pos && P.round_last) ? ((p_abs + 7u) & ~7u) : p_abs);
+    if (g == P.n_blocks_total) {                                    // behind the last block: the closing entry (an upper bound, see above)
+        JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical(P.restart_pos ? ((p_abs + 7u) & ~7u) : p_abs);
         A.terminal++;
         return;
     }
     const uint32_t x = b0 + i, b = x - jda_umul24(jda_umul24(x, inv) >> 16, P.nblocks), c = b < P.nluma ? 0u : b - P.nluma + 1u;      // (x < 6 + rec_cap)
-    const int32_t base = (rec & JDA_REC_AFTER_RST) ? 0 : (c == 0u ? pr0 : (c == 1u ? pr1 : pr2));      // (predictors restart at zero with an interval)
-    const int32_t pred = base + ((int32_t)rec >> JDA_REC_POS_BITS);
-    if (pred < -32768 || pred > 32767) A.bad = 1;
-    const uint32_t a = (uint32_t)(pred < 0 ? -pred : pred);
+    const int32_t base = i >= rst_from ? 0 : (c == 0u ? pr0 : (c == 1u ? pr1 : pr2));      // (DC values restart at zero with an interval)
+    const int32_t dc = base + ((int32_t)rec >> JDA_REC_POS_BITS);
+    if (dc < -32768 || dc > 32767) A.bad = 1;
+    const uint32_t a = (uint32_t)(dc < 0 ? -dc : dc);
     A.max_abs_dc = a > A.max_abs_dc ? a : A.max_abs_dc;
     JDA_G(uint32_t, P.blk_index)[g] = jda_index_canonical(p_abs);
-    JDA_G(int16_t, P.blk_dc)[g] = (int16_t)pred;
+    JDA_G(int16_t, P.blk_dc)[g] = (int16_t)dc;
 }
-JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2, jda_fin_acc &A)
+JDA_HD void jda_finalize_item(const jda_segscan_params &P, uint32_t seg, uint32_t i, uint32_t g0, uint32_t b0, uint32_t inv, int32_t pr0, int32_t pr1, int32_t pr2, uint32_t rst_from, jda_fin_acc &A)
 {
     if (g0 + i > P.n_blocks_total) return;
-    jda_finalize_apply(P, seg, i, jda_finalize_load(P, seg, i), g0, b0, inv, pr0, pr1, pr2, A);
+    jda_finalize_apply(P, seg, i, jda_finalize_load(P, seg, i), g0, b0, inv, pr0, pr1, pr2, rst_from, A);
 }
 // candidate ci: a magnitude read that some entry lag of its segment truncates.  With the segment's true lag known: does it?  Then
-// the block's entry becomes the reference reader's true phase + the flag.  Returns 1 for a truncated read (the serial pre-scan's count).
+// the block's entry becomes the reference reader's true phase (at the block's first AC symbol) + the flag.  Returns 1 for a
+// truncated read (the serial pre-scan's count).
 JDA_HD uint32_t jda_resolve_item(const jda_segscan_params &P, uint32_t ci)
 {
     const uint32_t JDA_GLOBAL *cd = JDA_G(const uint32_t, P.cands) + (size_t)ci * 4u;
@@ -1727,8 +1507,8 @@ JDA_HD uint32_t jda_resolve_item(const jda_segscan_params &P, uint32_t ci)
     }
     if (g >= P.n_blocks_total || i >= P.rec_cap) return 0;
     const uint32_t rec = JDA_G(const uint32_t, P.records)[(size_t)t * P.rec_cap + i];
-    const uint32_t p_abs = t * JDA_SEG_BITS + (rec & (JDA_SEG_BITS - 1u));
-    const uint32_t u0 = (lagw >> (5u * jt)) & 15u;                  // the window's byte lag at the block's opening refill
+    const uint32_t p_abs = t * JDA_SEG_BITS + (rec & ((1u << JDA_REC_POS_BITS) - 1u));
+    const uint32_t u0 = (lagw >> (5u * jt)) & 15u;                  // the window's byte lag at the block's first AC symbol (behind the AC loop's opening refill)
     JDA_G(uint32_t, P.blk_index)[g] = (((p_abs >> 3) - u0) << JDA_INDEX_OFF_BITS) | JDA_INDEX_TRUNC | (8u * u0 + (p_abs & 7u));
     return 1;
 }
@@ -1797,7 +1577,7 @@ JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &
     else if (C.first_mcu + C.count > D.n_mcus_ok) C.count = D.n_mcus_ok - C.first_mcu;
     C.first_block = C.first_mcu * T::NBLK;
     C.win_lo = 0; C.win_len = 0; C.win_need = 0;
-    if (C.count) {
+    if (C.count && D.scale_shift != 3 && !(D.pad_[0] & JDA_DESC_DC_ONLY)) {      // (1/8, a progressive file's DC scan: the DC values are all there is, the scan is not read)
         C.win_lo = (ix_first >> JDA_INDEX_OFF_BITS) & ~15u;
         uint32_t hi = ((ix_end >> JDA_INDEX_OFF_BITS) + 8u + 12u + 15u) & ~15u;
         const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;
@@ -1820,7 +1600,7 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
     else if (C.first_mcu + C.count > D.n_mcus_ok) C.count = D.n_mcus_ok - C.first_mcu;
     C.first_block = C.first_mcu * T::NBLK;
     C.win_lo = 0; C.win_len = 0; C.win_need = 0;
-    if (C.count) {
+    if (C.count && D.scale_shift != 3 && !(D.pad_[0] & JDA_DESC_DC_ONLY)) {
         // the tile's blocks are consecutive in the scan: stage one contiguous run of bytes
         C.win_lo = (JDA_G(const uint32_t, D.blk_index)[C.first_block] >> JDA_INDEX_OFF_BITS) & ~15u;
         // a thread may read 12 bytes past (start of the block after the tile) + 8
@@ -1983,24 +1763,29 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     br.pos = ix >> JDA_INDEX_OFF_BITS;
     br.off = ix & (JDA_INDEX_TRUNC - 1u);
     const uint8_t *wbase = br.win - br.win_lo;
-    int32_t pred = in.pred;
-    const bool dc_only = (D.pad_[0] & JDA_DESC_DC_ONLY) != 0;     // wave-uniform (progressive thumbnail)
-    const uint32_t al = (uint32_t)D.pad_[0] >> 4;
+    const int32_t dc = in.pred;                                  // the block's own DC value (index format 2)
 
     JDA_P1_TRACE(8);
     const int shift = D.scale_shift;
-    // wave-uniform: the whole slice is in LDS (and the tables allow the window-only reader's EOB test)
-    const bool win_only = C.win_need <= br.win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
-    if (shift == 3) {                                            // 1/8: DC only (:5146-5154, bThumbnail)
-        if (win_only) jda_decode_block_win<1, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc); else { br.bits = jda_load_be64(br, br.pos); jda_decode_block<1>(br, TB, coef, pred, dc_only, al, trunc); }
-        *(jda_u32_alias *)plane = jda_dup8(jda_range_limit5(pred * (int32_t)quant[0]));
+    const bool dc_only = (D.pad_[0] & JDA_DESC_DC_ONLY) != 0;     // wave-uniform: the DC scan of a progressive file -- no AC symbol exists (JPEGDecodeMCU_P with Se = 0)
+    if (shift == 3 || (dc_only && shift == 2)) {                 // 1/8: the DC term is the pixel (:5146-5154, bThumbnail) -- the scan is not read at all
+        *(jda_u32_alias *)plane = jda_dup8(jda_range_limit5(dc * (int32_t)quant[0]));
         return JDA_NO_LIST;
     }
+    if (dc_only) {                                               // (a progressive file asked for at full or half size: DC-only blocks through the IDCT's bypass)
+        jda_u64_alias *z = (jda_u64_alias *)coef;
+        z[0] = (uint64_t)(uint16_t)dc;
+#pragma unroll
+        for (int i = 1; i < 16; i++) z[i] = 0;
+        return 0;
+    }
+    // wave-uniform: the whole slice is in LDS (and the tables allow the window-only reader's EOB test)
+    const bool win_only = C.win_need <= br.win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
     if (shift == 2) {                                            // 1/4: 2x2 from coefficients 0,1,8,9
         uint32_t flags;
-        if (win_only) flags = jda_decode_block_win<5, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc);
-        else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, pred, dc_only, al, trunc); }
-        const uint32_t px = flags == 0 ? jda_dup8(jda_range_limit5(pred * (int32_t)quant[0]))
+        if (win_only) flags = jda_decode_block_win<5, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, dc, true, trunc);
+        else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<5>(br, TB, coef, dc, trunc); }
+        const uint32_t px = flags == 0 ? jda_dup8(jda_range_limit5(dc * (int32_t)quant[0]))
                                        : jda_idct_2x2(coef, quant);
         *(jda_u32_alias *)plane = px;
         return JDA_NO_LIST;
@@ -2009,10 +1794,10 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     if (win_only) {
         // the reference's ulBitOff is followed only in a tile that holds a block with a truncated magnitude read (the
         // pre-scan flags those: a fraction of a percent of the blocks of a photograph, none of most synthetic images)
-        if (jda_wave_any(trunc)) flags = jda_decode_block_win<64, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al, trunc);
-        else flags = jda_decode_block_win<64, false, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, pred, true, dc_only, al);
+        if (jda_wave_any(trunc)) flags = jda_decode_block_win<64, true, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, dc, true, trunc);
+        else flags = jda_decode_block_win<64, false, L::LONG_LDS != 0>(br.pos, br.off, wbase, TB, coef, dc, true);
     }
-    else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, pred, dc_only, al, trunc); }
+    else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, dc, trunc); }
     JDA_P1_TRACE(9);
     return flags;
 }

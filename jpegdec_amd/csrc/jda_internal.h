@@ -49,6 +49,15 @@ static inline int jda_dc_lut_walkable(const uint8_t *tables, uint32_t t)
     return 1;
 }
 
+// Measuring switches (environment variables that change what a build does) exist only in laboratory builds: make lib EXTRA=-DJDA_LAB.
+// The product library reads JPEGDEC_AMD_DEVICE (which GPU the drop-in class uses) and nothing else.
+#ifdef JDA_LAB
+#include <stdlib.h>
+#define JDA_LAB_ENV(name) getenv(name)
+#else
+#define JDA_LAB_ENV(name) ((const char *)0)
+#endif
+
 // kinds of MCU the kernels are specialised for
 enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2, JDA_MODE_422 = 3 /* h2v1, MCU 16x8 */, JDA_MODE_440 = 4 /* h1v2, MCU 8x16 */, JDA_N_MODES = 5 };
 

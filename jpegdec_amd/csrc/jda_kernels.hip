@@ -112,66 +112,6 @@ __device__ __forceinline__ jda_strip jda_load_record(const jda_strip *tp)
     return jda_unpack_record(w[0], w[1], w[2], w[3]);
 }
 
-template <int MODE, bool FAST>
-__global__ __launch_bounds__(64 * jda_lds_layout<MODE>::WAVES)
-void jda_decode_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    typedef jda_lds_layout<MODE> L;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    unsigned long long *trace = (blockIdx.x % JDA_TRACE_STRIDE == 0) ? g_jda_trace : nullptr;
-    JDA_TRACE(0);
-
-    // tile record and image descriptor are wave-uniform: keep them in SGPRs
-    const jda_strip S = jda_load_record(tiles + (size_t)blockIdx.x * jda_lds_layout<MODE>::WAVES + wave);
-    const jda_dev_desc D = jda_desc_uniform(descs + S.image);   // the four tiles of a workgroup belong to one image
-    jda_tile_ctx C = jda_tile_setup<MODE>(D, S);
-    C.count = __builtin_amdgcn_readfirstlane(C.count);
-    C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);
-    C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);
-
-    uint8_t *tab = lds;
-    uint8_t *wl = lds + L::TAB_BYTES + wave * L::WAVE_BYTES;
-    const jda_p1_inputs p1in = jda_p1_prefetch<MODE>(D, C, lane);   // in flight while LDS is staged
-    JDA_TRACE(1);
-    jda_p0_tables(D, threadIdx.x, 64 * jda_lds_layout<MODE>::WAVES, tab, jda_lds_layout<MODE>::LONG_LDS != 0);
-    jda_p0_stage<MODE>(D, C, lane, wl, L::WIN_BYTES);
-    JDA_TRACE(2);
-    __syncthreads();                                  // the only workgroup barrier: tables are in LDS
-    JDA_TRACE(3);
-    uint32_t p1flags = JDA_NO_LIST;
-    jda_lane_pre LP;
-    jda_lane_prepare<MODE>(LP, D, lane, tab);
-    p1flags = jda_p1_entropy<MODE>(D, C, p1in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
-    if (D.scale_shift < 2) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
-    JDA_WAVE_SYNC();
-    JDA_TRACE(4);
-    if (D.scale_shift < 2 && !(D.pad_[0] & 2)) {
-        jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
-        JDA_WAVE_SYNC();
-        JDA_TRACE(5);
-        jda_p3_rows<MODE>(D, lane, tab, wl);
-        JDA_WAVE_SYNC();
-        JDA_TRACE(6);
-    }
-    jda_p4_pre P4;
-    jda_p4_prepare<MODE>(P4, D, lane);
-    if (!(D.pad_[0] & 1)) jda_p4_output<MODE>(D, S, C, lane, wl, P4);
-    JDA_TRACE(7);
-}
-
-template <int MODE, bool FAST>
-static hipError_t launch(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
-{
-    const int lds_bytes = jda_lds_layout<MODE>::TAB_BYTES + jda_lds_layout<MODE>::WAVES * jda_lds_layout<MODE>::WAVE_BYTES;
-    static std::atomic<unsigned long long> attr_done(0);
-    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_decode_tiles<MODE, FAST>, lds_bytes, attr_done); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL((jda_decode_tiles<MODE, FAST>), dim3(n_tiles / jda_lds_layout<MODE>::WAVES), dim3(64 * jda_lds_layout<MODE>::WAVES),
-                       lds_bytes, stream, descs, tiles);
-    return hipGetLastError();
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Persistent variant (the default): one workgroup per CU (sized by LDS), each given a contiguous run of the
 // batch's tiles.  The wavefronts of a workgroup DRAW their tiles from that run through a counter in LDS: the
@@ -417,7 +357,7 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
         const int per_cu = (160 * 1024) / lds_bytes;
         // more workgroups than CUs: the ones that do not fit start as others finish, so the hardware deals the second half of the
         // work out by who is done first (the static split left the CUs finishing up to 4 % apart: profiles/r01_final_wg_balance.txt)
-        static const int mult = []() { const char *e = getenv("JDA_GRID_MULT"); const int m = e ? atoi(e) : JDA_GRID_MULT_DEFAULT; return m < 1 ? 1 : (m > 16 ? 16 : m); }();
+        static const int mult = []() { const char *e = JDA_LAB_ENV("JDA_GRID_MULT"); const int m = e ? atoi(e) : JDA_GRID_MULT_DEFAULT; return m < 1 ? 1 : (m > 16 ? 16 : m); }();
         grid_cap = cus * (per_cu > 0 ? per_cu : 1) * mult;
         grid_cap_once.store(grid_cap, std::memory_order_relaxed);
     }
@@ -446,47 +386,7 @@ __device__ __forceinline__ uint32_t jda_wave_sum_u32(uint32_t v)
 }
 // ------------------------------------------------------------------------------------------------
 // The per-block index on the device (the algorithm is described at jda_seg_walk): one lane per 256-byte segment
-// of the filtered scan, read where it lies; a workgroup of four wavefronts around one copy of the walk's tables.  This kernel is the
-// WRITE pass (entry states settled, every segment's first block ordinal / DC predictors / window lag known): it stores the index
-// entries and DC predictors, exactly the serial pre-scan's.
-__global__ __launch_bounds__(256)
-void jda_segscan_write(const jda_segscan_params *__restrict__ params)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
-    const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
-    if (blockIdx.x * 256u >= P.n_segs || P.records) return;          // (uniform per workgroup: images of a batch differ in size; RECORD mode has no WRITE walk)
-    uint8_t *tab = lds;
-    jda_walk_tables_stage(P.walk_tables, threadIdx.x, 256u, tab);      // the walk's four tables are all that is staged
-    const bool in_range = seg < P.n_segs;
-    uint32_t entry = 0;
-    bool need = in_range;                                            // (the wavefronts stay whole for the reduction of their results)
-    if (in_range) entry = P.entry_cur[seg];
-    if (in_range && P.seg_start[(size_t)seg * 5] > P.n_blocks_total) need = false;   // past the image
-    __syncthreads();                                                 // the tables are in LDS
-    const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
-    jda_seg_sum S;
-    jda_seg_stats ST;
-    ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
-    if (need) {
-        if (P.restart_pos) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
-        else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, entry & ~JDA_SEG_CHANGED, segw, tab, S, ST);
-    }
-    // the image's result words, ONE atomic per wavefront and word: every lane has maxima to report, and 6,500 lanes of an image
-    // finishing together on the same two addresses cost a quarter of the pass (1.54 -> 1.13 ms per 64-image batch)
-    const uint32_t m_ac = jda_wave_max_u32(ST.max_ac_bits), m_dc = jda_wave_max_u32(ST.max_abs_dc), n_tr = jda_wave_sum_u32(ST.trunc_events);
-    const bool any_bad = __builtin_amdgcn_ballot_w64(ST.bad != 0) != 0, any_mis = __builtin_amdgcn_ballot_w64(ST.mismatch != 0) != 0;
-    const uint32_t n_term = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ST.terminal != 0));
-    if ((threadIdx.x & 63u) == 0u) {
-        if (any_bad) atomicOr(&P.stats[0], 1u);
-        if (any_mis) atomicOr(&P.stats[5], 1u);
-        if (n_term) atomicAdd(&P.stats[1], n_term);
-        if (m_ac) atomicMax(&P.stats[2], m_ac);
-        if (m_dc) atomicMax(&P.stats[3], m_dc);
-        if (n_tr) atomicAdd(&P.stats[4], n_tr);
-    }
-}
-
+// of the filtered scan, read where it lies; a workgroup of four wavefronts around one copy of the walk's tables.
 // The walk's tables, once per image (every walker's workgroup converted the blob itself before: 16 dependent rounds of byte
 // loads in front of each of them -- a fifth of the latency-bound rounds)
 __global__ __launch_bounds__(1024)
@@ -513,11 +413,8 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
     ST.bad = 0; ST.terminal = 0; ST.max_ac_bits = 0; ST.max_abs_dc = 0; ST.trunc_events = 0; ST.mismatch = 0;
     const uint32_t JDA_GLOBAL *segw = JDA_G(const uint32_t, P.scan) + (size_t)seg * (JDA_SEG_BYTES / 4u);
     const uint32_t entry = (seg == 0 || round == 0) ? 0u : E[seg];       // the scan starts at a block start (jpeg.inl:4996-4998)
-    // (P.records == NULL: round 2's passes -- the counting walk here, then the WRITE walk)
-    const bool rec = OP == JDA_SEG_FUSED && P.records;
-    const uint32_t x = P.restart_pos ? (rec ? jda_seg_walk<JDA_SEG_RECORD, true>(P, seg, entry, segw, tab, S, ST, round) : jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST))
-                                     : (rec ? jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, segw, tab, S, ST, round) : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST));
-    if (OP == JDA_SEG_FUSED) {
+    const uint32_t x = P.restart_pos ? jda_seg_walk<OP, true>(P, seg, entry, segw, tab, S, ST, round) : jda_seg_walk<OP, false>(P, seg, entry, segw, tab, S, ST, round);
+    if (OP == JDA_SEG_RECORD) {
         uint32_t *o = P.seg_sum + (size_t)seg * JDA_SEG_SUM_WORDS;
         jda_store_u32x4(o, S.nblk, (uint32_t)S.dcsum[0], (uint32_t)S.dcsum[1], (uint32_t)S.dcsum[2]);
         jda_store_u32x4(o + 4, S.phase_map, S.bad | (S.max_ac << 4), S.lag_last, round);
@@ -540,7 +437,7 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
     }
 }
 
-template <int OP>       // JDA_SEG_SPEC: round 0 (every segment from the guess "a block starts here": exit states only); JDA_SEG_FUSED: the rest
+template <int OP>       // JDA_SEG_SPEC: round 0 (every segment from the guess "a block starts here": exit states only); JDA_SEG_RECORD: the rest
 __global__ __launch_bounds__(256)
 void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t round)
 {
@@ -588,7 +485,7 @@ void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t fi
         for (uint32_t base = wave * 64u; base < count; base += 1024u) {
             const uint32_t item = base + lane;
             if (item >= count) continue;
-            jda_fused_item<JDA_SEG_FUSED>(P, tab, wl_in[item], round, lane, E, wl_out);
+            jda_fused_item<JDA_SEG_RECORD>(P, tab, wl_in[item], round, lane, E, wl_out);
         }
         __threadfence();                                             // this round's entry states, sums and list, for every wavefront of the next
         __syncthreads();
@@ -605,21 +502,21 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     // allowed (455 -> 365 us per 64-image batch).  The tables are 32 KB now (pair halves): five fit; round 0 is launched with 8 KB more
     // than it uses, which makes it four (251 us at five or four, 350 at two; the counting rounds: 331 at five or four, 401 at two --
     // profiles/r03_walk_sq_counters.txt).  JDA_WALK_LDS_R0 / JDA_WALK_LDS_R1: extra bytes, for measuring.
-    static const int lds_extra0 = []() { const char *e = getenv("JDA_WALK_LDS_R0"); return e ? atoi(e) : 8192; }();
-    static const int lds_extra1 = []() { const char *e = getenv("JDA_WALK_LDS_R1"); return e ? atoi(e) : 0; }();
+    static const int lds_extra0 = []() { const char *e = JDA_LAB_ENV("JDA_WALK_LDS_R0"); return e ? atoi(e) : 8192; }();
+    static const int lds_extra1 = []() { const char *e = JDA_LAB_ENV("JDA_WALK_LDS_R1"); return e ? atoi(e) : 0; }();
     const int lds_max = JDA_WT_BYTES + (lds_extra0 > lds_extra1 ? lds_extra0 : lds_extra1);
     const int lds_bytes = JDA_WT_BYTES + (round == 0 ? lds_extra0 : lds_extra1);
     static std::atomic<unsigned long long> attr_done0(0), attr_done1(0);
     {
         hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_SPEC>, lds_max, attr_done0);
-        if (e == hipSuccess) e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_FUSED>, lds_max, attr_done1);
+        if (e == hipSuccess) e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_RECORD>, lds_max, attr_done1);
         if (e != hipSuccess) return e;
     }
     const uint32_t full = (max_segs + 255u) / 256u;
     // later rounds walk a few percent of the segments: a few workgroups per image, each stepping through the list
     const dim3 grid(round <= 1 ? full : (full < 8u ? full : 8u), n_images), block(256);
     if (round == 0) hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
-    else hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_FUSED>, grid, block, lds_bytes, stream, params, round);
+    else hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_RECORD>, grid, block, lds_bytes, stream, params, round);
     return hipGetLastError();
 }
 
@@ -768,16 +665,6 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
     return hipGetLastError();
 }
 
-extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, hipStream_t stream)
-{
-    if (n_images == 0 || max_segs == 0) return hipSuccess;
-    const int lds_bytes = JDA_WT_BYTES;               // the tables only: 32 KB per workgroup
-    static std::atomic<unsigned long long> attr_done(0);
-    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_write, lds_bytes, attr_done); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(jda_segscan_write, dim3((max_segs + 255u) / 256u, n_images), dim3(256), lds_bytes, stream, params);
-    return hipGetLastError();
-}
-
 // RECORD mode, after the sums: the records of every segment -> index entries (canonical) and DC predictors, block-parallel -- a
 // wavefront per segment, sixteen segments one after the other, lane = record: coalesced reads and writes, no walk.  Result words as
 // WRITE left them: [0] bad (a predictor out of range, a stream read on into its padding), [1] closing entry written, [3] max |DC|.
@@ -795,11 +682,12 @@ void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
     jda_fin_acc A;
     A.bad = 0; A.terminal = 0; A.max_abs_dc = 0;
     // the segments' headers first, one lane each (one round trip for all of them), then segment after segment
-    uint32_t h_g0 = 0xffffffffu, h_n = 0, h_p0 = 0, h_p1 = 0, h_p2 = 0, h_b0 = 0;
+    uint32_t h_g0 = 0xffffffffu, h_n = 0, h_p0 = 0, h_p1 = 0, h_p2 = 0, h_b0 = 0, h_rf = 0xffffffffu;
     if (lane < JDA_FIN_SEGS_PER_WAVE && seg0 + lane < P.n_segs) {
         const uint32_t JDA_GLOBAL *st = JDA_G(const uint32_t, P.seg_start) + (size_t)(seg0 + lane) * 5;
         h_g0 = st[0]; h_p0 = st[1]; h_p1 = st[2]; h_p2 = st[3];
         h_n = JDA_G(const uint32_t, P.seg_sum)[(size_t)(seg0 + lane) * JDA_SEG_SUM_WORDS];
+        h_rf = jda_fin_rst_from(JDA_G(const uint32_t, P.seg_sum)[(size_t)(seg0 + lane) * JDA_SEG_SUM_WORDS + 5u]);
         h_b0 = h_g0 % P.nblocks;                                     // (the one division: the records take their place in the MCU from it)
     }
     // every segment's first 64 records are asked for before the first is used: one trip to memory for the wavefront, not one per segment
@@ -816,9 +704,9 @@ void jda_segscan_finalize(const jda_segscan_params *__restrict__ params)
     for (uint32_t k = 0; k < JDA_FIN_SEGS_PER_WAVE; k++) {
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)h_g0, (int)k), nblk = (uint32_t)__builtin_amdgcn_readlane((int)h_n, (int)k);
         const int32_t pr0 = __builtin_amdgcn_readlane((int)h_p0, (int)k), pr1 = __builtin_amdgcn_readlane((int)h_p1, (int)k), pr2 = __builtin_amdgcn_readlane((int)h_p2, (int)k);
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h_b0, (int)k);
-        if (lane < nblk) jda_finalize_apply(P, seg0 + k, lane, rec[k], g0, b0, inv, pr0, pr1, pr2, A);
-        for (uint32_t i = lane + 64u; i < nblk; i += 64u) jda_finalize_item(P, seg0 + k, i, g0, b0, inv, pr0, pr1, pr2, A);      // (the densest streams)
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h_b0, (int)k), rf = (uint32_t)__builtin_amdgcn_readlane((int)h_rf, (int)k);
+        if (lane < nblk) jda_finalize_apply(P, seg0 + k, lane, rec[k], g0, b0, inv, pr0, pr1, pr2, rf, A);
+        for (uint32_t i = lane + 64u; i < nblk; i += 64u) jda_finalize_item(P, seg0 + k, i, g0, b0, inv, pr0, pr1, pr2, rf, A);      // (the densest streams)
     }
     const uint32_t m_dc = jda_wave_max_u32(A.max_abs_dc), n_term = jda_wave_sum_u32(A.terminal);
     const bool any_bad = __builtin_amdgcn_ballot_w64(A.bad != 0) != 0;
@@ -851,14 +739,13 @@ void jda_segscan_resolve_cands(const jda_segscan_params *__restrict__ params)
 // every pass of the device pre-scan behind the filter, on one stream: round 0 and the counting round over every segment, the
 // work-list rounds, the sums, then WRITE (streams with restart intervals) / finalize + candidates (RECORD mode)
 extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
-                                                int any_write, int any_record, hipStream_t stream)
+                                                int any_record, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
     hipError_t e = hipSuccess;
     for (uint32_t r = 0; r < list_rounds && e == hipSuccess; r++) e = jda_launch_segscan_fused(params, n_images, max_segs, r, stream);
     if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, list_rounds, max_round, stream);
     if (e == hipSuccess) e = jda_launch_segscan_sums(params, n_images, stream);
-    if (e == hipSuccess && any_write) e = jda_launch_segscan_write(params, n_images, max_segs, stream);
     if (e == hipSuccess && any_record) {
         hipLaunchKernelGGL(jda_segscan_finalize, dim3((max_segs + 4u * JDA_FIN_SEGS_PER_WAVE - 1u) / (4u * JDA_FIN_SEGS_PER_WAVE), n_images), dim3(256), 0, stream, params);
         hipLaunchKernelGGL(jda_segscan_resolve_cands, dim3(16, n_images), dim3(256), 0, stream, params);
@@ -882,86 +769,9 @@ extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params
 // of 64 on 64 CUs -- which a decode kernel launched meanwhile could not use: its workgroups need a CU's whole LDS, and the ones
 // that had to wait started a millisecond late with a full share of the tiles.)
 #define JDA_FILTER_CHUNK 16384u
-struct jda_fsm { uint32_t w0, w1; };   // w0: end state for incoming 0 | for incoming 1 << 1 | emitted (in 0) << 2 | emitted (in 1) << 17; w1: markers (in 0) | (in 1) << 16
-__device__ __forceinline__ jda_fsm jda_fsm_compose(jda_fsm A, jda_fsm B)     // A first, then B
-{
-    const uint32_t m0 = A.w0 & 1u, m1 = (A.w0 >> 1) & 1u;
-    const uint32_t e0 = (B.w0 >> m0) & 1u, e1 = (B.w0 >> m1) & 1u;
-    const uint32_t n0 = ((A.w0 >> 2) & 0x7fffu) + ((B.w0 >> (2 + 15 * m0)) & 0x7fffu);
-    const uint32_t n1 = ((A.w0 >> 17) & 0x7fffu) + ((B.w0 >> (2 + 15 * m1)) & 0x7fffu);
-    const uint32_t r0 = (A.w1 & 0xffffu) + ((B.w1 >> (16 * m0)) & 0xffffu);
-    const uint32_t r1 = (A.w1 >> 16) + ((B.w1 >> (16 * m1)) & 0xffffu);
-    jda_fsm R;
-    R.w0 = e0 | (e1 << 1) | (n0 << 2) | (n1 << 17);
-    R.w1 = r0 | (r1 << 16);
-    return R;
-}
-#define JDA_FSM_IDENTITY_W0 2u          // state 0 -> 0, 1 -> 1, nothing emitted
-// this thread's 16 bytes of the chunk (valid: how many of them exist) and their function
-__device__ __forceinline__ jda_fsm jda_filter_thread(const jda_filter_params &P, uint32_t chunk, uint32_t tid, uint32_t b[4], uint32_t &valid, jda_filter_masks &M)
-{
-    const uint32_t off = chunk * JDA_FILTER_CHUNK + tid * 16u;
-    valid = off >= P.raw_len ? 0u : (P.raw_len - off < 16u ? P.raw_len - off : 16u);
-    b[0] = b[1] = b[2] = b[3] = 0;
-    if (valid) {                                                  // (the raw buffer is padded to a multiple of 16 bytes)
-        const jda_chunk16_alias v = *(const jda_chunk16_alias JDA_GLOBAL *)(JDA_G(const uint8_t, P.raw) + off);
-        b[0] = v.w[0]; b[1] = v.w[1]; b[2] = v.w[2]; b[3] = v.w[3];
-    }
-    // the machine from both incoming states, sixteen bytes at once (jda_filter_run: the byte-by-byte loop was 300 instructions)
-    M = jda_filter_classify(b);
-    const jda_filter_bits F0 = jda_filter_run(M, valid, 0u), F1 = jda_filter_run(M, valid, 1u);
-    jda_fsm X;
-    X.w0 = ((F0.S >> valid) & 1u) | (((F1.S >> valid) & 1u) << 1) | ((uint32_t)__builtin_popcount(F0.E) << 2) | ((uint32_t)__builtin_popcount(F1.E) << 17);
-    X.w1 = (uint32_t)__builtin_popcount(F0.R) | ((uint32_t)__builtin_popcount(F1.R) << 16);
-    return X;
-}
-// inclusive scan of the functions of a workgroup's 1024 threads (wt: 32 entries of LDS); total: the whole chunk's, pre: the
-// wavefronts' in front of this thread's.  The sixteen wavefront totals are scanned ONCE, by sixteen lanes of the first wavefront
-// (every thread composing all sixteen for itself was 480 of the kernels' 730 instructions per thread).
-__device__ __forceinline__ jda_fsm jda_fsm_block_scan(jda_fsm v, uint32_t tid, jda_fsm *wt, jda_fsm &total, jda_fsm &pre)
-{
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        jda_fsm o;
-        o.w0 = (uint32_t)__shfl_up((int)v.w0, d, 64); o.w1 = (uint32_t)__shfl_up((int)v.w1, d, 64);
-        if (lane >= (uint32_t)d) v = jda_fsm_compose(o, v);
-    }
-    if (lane == 63u) wt[wave] = v;
-    __syncthreads();
-    if (wave == 0u) {                                             // (uniform per wavefront)
-        jda_fsm t; t.w0 = JDA_FSM_IDENTITY_W0; t.w1 = 0;
-        if (lane < 16u) t = wt[lane];
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            jda_fsm o;
-            o.w0 = (uint32_t)__shfl_up((int)t.w0, d, 64); o.w1 = (uint32_t)__shfl_up((int)t.w1, d, 64);
-            if (lane >= (uint32_t)d) t = jda_fsm_compose(o, t);
-        }
-        if (lane < 16u) wt[16u + lane] = t;                         // [16 + w]: wavefronts 0 .. w
-    }
-    __syncthreads();
-    pre.w0 = JDA_FSM_IDENTITY_W0; pre.w1 = 0;
-    if (wave) pre = wt[15u + wave];
-    total = wt[31];
-    return jda_fsm_compose(pre, v);
-}
+// a chunk's function as jda_filter_count_v2 leaves it (two words): w0 = end state for incoming 0 | for incoming 1 << 1 | emitted (in 0) << 2 | emitted (in 1) << 17; w1 = markers (in 0) | (in 1) << 16
 // work, per image: [chunk] function (2 words) | [chunk] entry state, output offset, marker count (3 words)
 __device__ __forceinline__ uint32_t jda_filter_chunks(uint32_t raw_len) { return (raw_len + JDA_FILTER_CHUNK - 1u) / JDA_FILTER_CHUNK; }
-
-__global__ __launch_bounds__(1024)
-void jda_filter_count(const jda_filter_params *__restrict__ params)
-{
-    __shared__ jda_fsm wt[32];
-    const jda_filter_params P = params[blockIdx.y];
-    const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len);
-    if (chunk >= n_chunks) return;
-    uint32_t b[4], valid;
-    jda_fsm total, pre;
-    jda_filter_masks M;
-    (void)jda_fsm_block_scan(jda_filter_thread(P, chunk, threadIdx.x, b, valid, M), threadIdx.x, wt, total, pre);
-    if (threadIdx.x == 0) { P.work[2u * chunk] = total.w0; P.work[2u * chunk + 1u] = total.w1; }
-}
 
 struct jda_fsm_wide { uint32_t s, n0, n1, r0, r1; };                // s: end state for incoming 0 | for incoming 1 << 1; counts unpacked (sums over chunks)
 __device__ __forceinline__ jda_fsm_wide jda_fsm_wide_compose(const jda_fsm_wide &A, const jda_fsm_wide &B)
@@ -1015,60 +825,6 @@ void jda_filter_carry(const jda_filter_params *__restrict__ params)
             P.restart_pos[0] = 0;
             if (rst_base + 1u < P.restart_cap) P.restart_pos[rst_base + 1u] = JDA_RST_SENTINEL;      // behind the last interval start (the segment walk's search ends there)
         }
-    }
-}
-
-__global__ __launch_bounds__(1024)
-void jda_filter_write(const jda_filter_params *__restrict__ params)
-{
-    __shared__ jda_fsm wt[32];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[JDA_FILTER_CHUNK + 32];
-    const jda_filter_params P = params[blockIdx.y];
-    const uint32_t chunk = blockIdx.x, n_chunks = jda_filter_chunks(P.raw_len), tid = threadIdx.x;
-    if (chunk >= n_chunks) return;
-    const uint32_t *carry = P.work + 2u * n_chunks + 3u * chunk;
-    const uint32_t state = carry[0], out_base = carry[1], rst_base = carry[2];
-    uint32_t b[4], valid;
-    jda_fsm total, pre;
-    jda_filter_masks M;
-    const jda_fsm X = jda_filter_thread(P, chunk, tid, b, valid, M);
-    const jda_fsm incl = jda_fsm_block_scan(X, tid, wt, total, pre);
-    // this thread's entry: the functions of all threads before it, applied to the chunk's entry
-    jda_fsm E;
-    E.w0 = (uint32_t)__shfl_up((int)incl.w0, 1, 64); E.w1 = (uint32_t)__shfl_up((int)incl.w1, 1, 64);
-    if ((tid & 63u) == 0u) E = pre;                               // (lane 0: the wavefronts before this one)
-    const uint32_t st = (E.w0 >> state) & 1u;
-    const uint32_t mis = out_base & 15u;                          // the staged bytes sit at the alignment they will have in memory
-    uint32_t o = mis + ((E.w0 >> (2 + 15 * state)) & 0x7fffu);
-    uint32_t rp = rst_base + ((E.w1 >> (16 * state)) & 0xffffu);
-    uint32_t JDA_GLOBAL *rpos = JDA_G(uint32_t, P.restart_pos);
-    const jda_filter_bits F = jda_filter_run(M, valid, st);       // which of the sixteen bytes leave, which follow an unpaired FF
-    for (uint32_t R = F.R; R != 0u; R &= R - 1u) {                 // RSTn: the next interval starts here (rare)
-        const uint32_t k = (uint32_t)__builtin_ctz(R);
-        rp++;
-        if (rp < P.restart_cap) rpos[rp] = out_base + (o - mis) + (uint32_t)__builtin_popcount(F.E & ((1u << k) - 1u));
-    }
-    // every byte is stored -- to its place, or to a dump byte behind the buffer -- so that the sixteen steps are straight-line code
-    // (a branch per byte was sixteen exec-mask regions per thread).  FF 00 -> FF: the 00 that leaves in state 1 becomes the FF
-    const uint32_t sz = F.S & M.zero;
-#pragma unroll
-    for (uint32_t d = 0; d < 4; d++) {                               // nibble -> 0xff in the bytes of its set bits (full-rate 24-bit multiply)
-        const uint32_t one = jda_umul24((sz >> (4u * d)) & 15u, 0x00204081u) & 0x01010101u;
-        b[d] |= (one << 8) - one;
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) {
-        const bool emit = ((F.E >> k) & 1u) != 0u;
-        stage[emit ? o : (uint32_t)(JDA_FILTER_CHUNK + 31u)] = (uint8_t)(b[k >> 2] >> (8 * (k & 3)));
-        o += emit ? 1u : 0u;
-    }
-    __syncthreads();
-    const uint32_t n_out = (total.w0 >> (2 + 15 * state)) & 0x7fffu, end = mis + n_out;
-    uint8_t JDA_GLOBAL *gout = JDA_G(uint8_t, P.out) + (out_base - mis);                   // 16-byte aligned (P.out is)
-    for (uint32_t piece = tid; piece * 16u < end; piece += 1024u) {
-        const uint32_t lo = piece * 16u, hi = lo + 16u;
-        if (lo >= mis && hi <= end) *(jda_chunk16_alias JDA_GLOBAL *)(gout + lo) = *(const jda_chunk16_alias *)(stage + lo);
-        else for (uint32_t i = lo < mis ? mis : lo; i < (hi < end ? hi : end); i++) gout[i] = stage[i];        // (the chunk's first and last 16 bytes: a neighbour writes the rest)
     }
 }
 
@@ -1242,10 +998,9 @@ extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_
 {
     if (n_images == 0) return hipSuccess;
     const uint32_t chunks = (max_raw_len + JDA_FILTER_CHUNK - 1u) / JDA_FILTER_CHUNK;
-    static const bool v1 = []() { const char *e = getenv("JDA_FILTER_V1"); return e && e[0] == '1'; }();      // (measuring / differential tests: the scan-of-functions kernels)
-    if (chunks) { if (v1) hipLaunchKernelGGL(jda_filter_count, dim3(chunks, n_images), dim3(1024), 0, stream, params); else hipLaunchKernelGGL(jda_filter_count_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params); }
+    if (chunks) hipLaunchKernelGGL(jda_filter_count_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params);
     hipLaunchKernelGGL(jda_filter_carry, dim3(n_images), dim3(64), 0, stream, params);
-    if (chunks) { if (v1) hipLaunchKernelGGL(jda_filter_write, dim3(chunks, n_images), dim3(1024), 0, stream, params); else hipLaunchKernelGGL(jda_filter_write_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params); }
+    if (chunks) hipLaunchKernelGGL(jda_filter_write_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params);
     return hipGetLastError();
 }
 
@@ -1299,22 +1054,6 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int
                                         uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
-    static const int simple = []() { const char *e = getenv("JDA_KERNEL"); return (e && e[0] == 's') ? 1 : 0; }();      // JDA_KERNEL=simple selects the one-tile-per-wave kernel (A/B, tracing)
-    if (simple) {
-        switch (mode * 2 + (fast_mul ? 1 : 0)) {
-        case JDA_MODE_GRAY * 2 + 0: return launch<JDA_MODE_GRAY, false>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_GRAY * 2 + 1: return launch<JDA_MODE_GRAY, true>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_444 * 2 + 0: return launch<JDA_MODE_444, false>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_444 * 2 + 1: return launch<JDA_MODE_444, true>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 2 + 0: return launch<JDA_MODE_420, false>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 2 + 1: return launch<JDA_MODE_420, true>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_422 * 2 + 0: return launch<JDA_MODE_422, false>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_422 * 2 + 1: return launch<JDA_MODE_422, true>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_440 * 2 + 0: return launch<JDA_MODE_440, false>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_440 * 2 + 1: return launch<JDA_MODE_440, true>(descs, tiles, n_tiles, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
     if (big) {                                        // the large-window kernels for high-bitrate images (jda_big_window in jda_runtime.cpp decides who gets here)
         switch (mode * 4 + variant) {
         case JDA_MODE_GRAY * 4 + 0: return launch_persistent<JDA_MODE_GRAY, true, 0, 1>(descs, tiles, n_tiles, stream);

@@ -46,7 +46,7 @@ namespace {
 inline void copy_to_mirror(uint8_t *dst, const uint8_t *src, size_t n)
 {
 #if defined(__x86_64__) || defined(_M_X64)
-    static const bool plain = getenv("JDA_PIPE_PLAIN_COPY") != NULL;      // (measuring)
+    static const bool plain = JDA_LAB_ENV("JDA_PIPE_PLAIN_COPY") != NULL;      // (measuring)
     if (n >= 4096 && !plain) {
         const size_t head = (size_t)(-(intptr_t)dst) & 15u;
         memcpy(dst, src, head);
@@ -240,7 +240,7 @@ jda_pipeline *jda_pipeline_create(jda_ctx *ctx, int32_t max_images, int32_t dept
     (void)hipSetDevice(ctx->device);
     bool ok = hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking) == hipSuccess;
     {
-        const char *e = getenv("JDA_PIPE_UP_STREAMS");
+        const char *e = JDA_LAB_ENV("JDA_PIPE_UP_STREAMS");
         int want = e ? atoi(e) : 2;
         if (want > depth) want = depth;
         for (int i = 1; i < want && i < 3 && ok; i++) { ok = hipStreamCreateWithFlags(&p->s_upx[i - 1], hipStreamNonBlocking) == hipSuccess; if (ok) p->n_upx = i; }
@@ -284,7 +284,7 @@ void jda_pipeline_destroy(jda_pipeline *p)
 // (measuring: JDA_PIPE_TIME=1 prints where jda_pipeline_submit's time goes, summed over the submits, when the process ends)
 struct jda_submit_clock {
     bool on; double acc[8]; long n; std::chrono::steady_clock::time_point t;
-    jda_submit_clock() : on(getenv("JDA_PIPE_TIME") != NULL), n(0) { for (double &a : acc) a = 0; }
+    jda_submit_clock() : on(JDA_LAB_ENV("JDA_PIPE_TIME") != NULL), n(0) { for (double &a : acc) a = 0; }
     ~jda_submit_clock() { if (on && n) fprintf(stderr, "jda_pipeline_submit x %ld: setup %.1f us, parse + tables %.1f, layout %.1f, grow buffers %.1f, parameters %.1f, strips + copy into the page-locked mirror %.1f, enqueue %.1f (per submit)\n", n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n); }
     long calls = 0;                                                 // (the first eight submits warm buffers and pages up: not counted)
     void start() { if (on) { t = std::chrono::steady_clock::now(); calls++; if (calls > 8) n++; } }
@@ -342,7 +342,6 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     memset(list_tiles, 0, sizeof(list_tiles)); memset(list_ord, 0, sizeof(list_ord));
     size_t arena = 0;
     int n_rec = 0;
-    static const bool no_record = getenv("JDA_PIPE_NO_RECORD") != NULL;      // (measuring: round 2's counting walk + WRITE walk for every stream)
     auto take = [&](size_t bytes) { const size_t o = arena; arena += a256(bytes); return o; };
     // regions: [control blob][raw][dc][work][ ZERO: scan | index | zero ][stats]; laid out by region so that one memset and
     // one read-back cover all images
@@ -390,12 +389,12 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         im.off_wt = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len));                                       // .. | the walk's tables
         im.work_bytes = im.off_wt + JDA_WT_BYTES;
         // .. | RECORD mode: the segments' block records, the truncation candidates
-        im.record = im.f.rec_cap != 0 && !no_record;
+        im.record = true;                                    // (device_ok streams have record slots: front_common)
         im.off_recs = im.off_cands = 0; im.cand_cap = 0;
         if (im.record) {
             // (images of one size would put their record regions a constant stride apart: a skew per image keeps the walkers of a
             // batch of like images -- all at the same place of their scans at the same time -- off each other's memory channels)
-            static const size_t skew = []() { const char *e = getenv("JDA_PIPE_REC_SKEW"); return e ? (size_t)atoi(e) : (size_t)0; }();
+            static const size_t skew = []() { const char *e = JDA_LAB_ENV("JDA_PIPE_REC_SKEW"); return e ? (size_t)atoi(e) : (size_t)0; }();
             im.off_recs = a256(im.work_bytes) + a256(skew * (size_t)(i % 16));
             im.off_cands = im.off_recs + a16((size_t)im.n_segs_ub * im.f.rec_cap * 4);
             im.cand_cap = std::max<uint32_t>(1024u, im.n_segs_ub * 16u);      // (a high-quality photograph: five candidates per segment, most of them of walks that were redone)
@@ -525,7 +524,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         // 110 MB (2 ms at 55 GB/s) could not start before this batch's filter had run -- and the filter's workgroups wait for the decode
         // kernel of the batch in front to give the CUs' LDS back: the copy stream was the pipeline's period (3.35 ms per batch of 64 x
         // 4096x4096, profiles/r03_pipeline_timeline_filter_on_copy_stream.txt).  The filter opens the batch's pre-scan stream instead.
-        static const bool filter_on_copy = []() { const char *v = getenv("JDA_PIPE_FILTER_STREAM"); return v && v[0] == 'c'; }();      // (measuring)
+        static const bool filter_on_copy = []() { const char *v = JDA_LAB_ENV("JDA_PIPE_FILTER_STREAM"); return v && v[0] == 'c'; }();      // (measuring)
         hipStream_t s_f = filter_on_copy ? p->s_copy : s_up;
         if (!filter_on_copy) {
             if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
@@ -542,7 +541,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
             const uint32_t ns = (uint32_t)dev_ix.size();
             // round 0, the counting round (RECORD mode: + a record per block), the work-list rounds, sums, then WRITE (restart
             // streams) / finalize + candidates (jda_kernels.hip)
-            e = jda_launch_prescan_passes(dp, ns, max_segs, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, n_rec < (int)ns, n_rec > 0, s_up);
+            e = jda_launch_prescan_passes(dp, ns, max_segs, JDA_PIPE_SPEC_ROUNDS, JDA_PIPE_MAX_ROUNDS, 1, s_up);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(S.pin + S.pin_stats, B + S.off_stats_dev, S.stats_bytes, hipMemcpyDeviceToHost, s_up);
     }
@@ -630,14 +629,14 @@ int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status)
                 max_ac = ps[2]; max_dc = ps[3];
                 S.st.spec_rounds_max = std::max<int32_t>(S.st.spec_rounds_max, [&]() { int r = 2; while (r <= JDA_PIPE_MAX_ROUNDS + 1 && ps[8 + r]) r++; return r; }());   // rounds that had something to walk
                 {
-                    static const bool trace_lists = getenv("JDA_PIPE_TRACE_LISTS") != NULL;      // (what the rounds behind round 1 had to walk)
+                    static const bool trace_lists = JDA_LAB_ENV("JDA_PIPE_TRACE_LISTS") != NULL;      // (what the rounds behind round 1 had to walk)
                     if (trace_lists && i == 0) fprintf(stderr, "jda_pipeline: ticket %d image 0: %u segments, work lists of rounds 2.. : %u %u %u %u %u\n", ticket, rb[0] / JDA_SEG_BYTES + 1u, ps[10], ps[11], ps[12], ps[13], ps[14]);
                 }
                 if (ok && im.fast && !jda_front_fast_mul(S.pin + im.ctl_tables, &im.f, max_ac, (int32_t)max_dc)) ok = false;   // a magnitude no legal stream has
                 redo = !ok;
                 if (ok) S.st.device_images++;
                 else {
-                    static const bool trace = getenv("JDA_PIPE_TRACE") != NULL;
+                    static const bool trace = JDA_LAB_ENV("JDA_PIPE_TRACE") != NULL;
                     if (trace) fprintf(stderr, "jda_pipeline: image %d (%dx%d, %u restart intervals) of ticket %d goes to the host path: filter %u bytes / %u markers, result words %u %u %u %u %u, [5] %u [6] %u, settled %u, fast %d\n",
                                        i, im.f.info.width, im.f.info.height, im.f.n_intervals, ticket, rb[0], rb[1], ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6],
                                        ps[7], (int)im.fast);

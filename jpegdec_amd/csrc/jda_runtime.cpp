@@ -44,7 +44,7 @@ int jda_plain_variant(const jda_dev_desc &D)
 // the general variant and the RGB8888 plain case, 24-bit multiplies.  JDA_BIG_WINDOW=0 / 1 forces the choice (A/B runs).
 int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uint32_t tiles_over_small)
 {
-    static const int forced = []() { const char *e = getenv("JDA_BIG_WINDOW"), *k = getenv("JDA_KERNEL"); return (k && k[0] == 's') ? 0 : (e ? atoi(e) : -1); }();
+    static const int forced = []() { const char *e = JDA_LAB_ENV("JDA_BIG_WINDOW"); return e ? atoi(e) : -1; }();
     if (!D.fast_mul || variant > 1) return 0;
     if (variant == 1 && D.mode == JDA_MODE_GRAY) return 0;
     if (forced >= 0) return forced ? 1 : 0;
@@ -208,7 +208,7 @@ static double now_ms()
 int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;
-    const bool trace = getenv("JDA_UPLOAD_TRACE") != NULL;          // stage timings on stderr (diagnostics)
+    const bool trace = JDA_LAB_ENV("JDA_UPLOAD_TRACE") != NULL;          // stage timings on stderr (diagnostics)
     const double t_begin = now_ms();
     double t_mark = t_begin;
 #define JDA_UP_MARK(what) do { if (trace) { (void)hipStreamSynchronize(ctx->stream); const double t_ = now_ms(); fprintf(stderr, "jda_upload_batch: %-28s %8.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
@@ -323,7 +323,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             it.alloc = it.off_sstats + 512;
             it.zero_end = it.alloc;                          // (what is memset: everything up to here; records and candidates need none)
             it.rec_cap = jda_image_record_cap(img);
-            it.record = it.rec_cap != 0 && getenv("JDA_PIPE_NO_RECORD") == NULL;
+            it.record = true;                                 // (a stream the device walks has record slots: front_common)
             if (it.record) {
                 it.off_recs = (it.alloc + 255) & ~(size_t)255;
                 it.off_cands = it.off_recs + align16((size_t)it.n_segs * it.rec_cap * 4);
@@ -418,17 +418,9 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         e = jda_pool_alloc(ctx, (void **)&d_seg, seg_params.size() * sizeof(jda_segscan_params));
         if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg_params.data(), seg_params.size() * sizeof(jda_segscan_params), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = jda_launch_walk_tables(d_seg, ns, ctx->stream);
-        // the write pass ORs its index entries into place (a block's truncation flag may come from the lane of a later segment
-        // than the one that holds the block's first bit): the index starts as zeros.  (RECORD mode stores whole entries.)
-        int n_rec = 0;
-        for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
-            Item &it = items[seg_owner[p]];
-            if (it.record) { n_rec++; continue; }
-            e = hipMemsetAsync(it.d->base + it.d->off_index, 0, 4 * (it.n_blocks + 1), ctx->stream);
-        }
-        // round 0, the counting round, two work-list rounds, every further round in one launch, the sums (first block ordinal, DC
-        // predictors, window lag per segment), then WRITE (restart streams) / finalize + candidates (RECORD mode)
-        if (e == hipSuccess) e = jda_launch_prescan_passes(d_seg, ns, max_segs, 4, 56, n_rec < (int)ns, n_rec > 0, ctx->stream);
+        // round 0, the recording round, two work-list rounds, every further round in one launch, the sums (first block ordinal, DC
+        // predictors, window lag per segment), then finalize + candidates (records -> index entries and DC values)
+        if (e == hipSuccess) e = jda_launch_prescan_passes(d_seg, ns, max_segs, 4, 56, 1, ctx->stream);
         for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
             Item &it = items[seg_owner[p]];
             e = hipMemcpyAsync(it.sst, it.d->base + it.off_sstats, sizeof(it.sst), hipMemcpyDeviceToHost, ctx->stream);
@@ -580,7 +572,7 @@ int jda_fill_launch_desc(jda_dev_desc &D, const jda_image_info &I, const uint8_t
     D.gray_from_color = (uint8_t)(D.mode != JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE);
     memcpy(D.dc_id, dc_id, 3); memcpy(D.ac_id, ac_id, 3); memcpy(D.q_id, q_id, 3);
     D.fast_mul = (uint8_t)(fast_mul ? 1 : 0);
-    { static const char *dbg = getenv("JDA_DEBUG_SKIP"); D.pad_[0] = (uint8_t)((dbg ? (atoi(dbg) & 3) : 0) | jda_desc_stream_bits(I) | (general_p1 ? JDA_DESC_GENERAL_P1 : 0u)); }   // profiling aid: 1 = no P4, 2 = no IDCT
+    { static const char *dbg = JDA_LAB_ENV("JDA_DEBUG_SKIP"); D.pad_[0] = (uint8_t)((dbg ? (atoi(dbg) & 3) : 0) | jda_desc_stream_bits(I) | (general_p1 ? JDA_DESC_GENERAL_P1 : 0u)); }   // profiling aid: 1 = no P4, 2 = no IDCT
     D.mcus_x = (uint32_t)I.mcus_x; D.mcus_y = (uint32_t)I.mcus_y;
     D.n_mcus_ok = n_mcus_ok; D.scan_len = scan_len;
     D.out = (uint8_t *)O.pixels;
@@ -804,14 +796,14 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
     if (tiles) tiles[0] = tiles[1] = 0;
     if (!ctx) return JDA_ERROR_NO_DEVICE;
     int32_t err = JDA_SUCCESS;
-    static const bool trace = getenv("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
+    static const bool trace = JDA_LAB_ENV("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
     double t_mark = trace ? now_ms() : 0.0;
 #define JDA_OC_MARK(what) do { if (trace) { const double t_ = now_ms(); fprintf(stderr, "jda_decode_to_host: %-24s %7.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
     // One image at a time, the device pre-scan is seven latency-bound launches of ~0.1-0.25 ms each whatever the size (a 640x480 scan
     // is four wavefronts' worth of segments): 0.88 ms all in where the serial host pre-scan of that image makes it 0.37 ms.  The host
     // costs 6.8 us per KB of file, so the device wins from about 120 KB on (1920x1080, 250 KB: 1.24 ms against 1.95; 4096x4096: 4.2 ms
     // against 13 for the host pre-scan alone) -- in batches it always does.
-    static const int32_t dev_from = []() { const char *e = getenv("JDA_ONECALL_DEVICE_PRESCAN_BYTES"); return e ? atoi(e) : (128 << 10); }();   // (for measuring the crossover)
+    static const int32_t dev_from = []() { const char *e = JDA_LAB_ENV("JDA_ONECALL_DEVICE_PRESCAN_BYTES"); return e ? atoi(e) : (128 << 10); }();   // (for measuring the crossover)
     const int32_t prep_flags = len >= dev_from ? JDA_PREPARE_DEVICE_PRESCAN : 0;
     jda_image *img = jda_prepare_ex(jpeg, len, prep_flags, &err);
     if (!img) return err;

@@ -64,7 +64,6 @@ int jda_fill_launch_desc(jda_dev_desc &D, const jda_image_info &I, const uint8_t
                          int fast_mul, int general_p1, uint32_t n_mcus_ok, uint32_t scan_len, const jda_output &O, int pixel_type, int options,
                          int *bpp_out);
 
-extern "C" hipError_t jda_launch_segscan_write(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream);
 extern "C" hipError_t jda_launch_checksum(const void *base, uint32_t pitch, uint32_t row_bytes, uint32_t rows, unsigned long long *out, hipStream_t stream);
 extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t first_round, uint32_t max_round, hipStream_t stream);
@@ -72,7 +71,7 @@ extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_
 extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);   // before the first walk
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
-                                                int any_write, int any_record, hipStream_t stream);
+                                                int any_record, hipStream_t stream);
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
 

@@ -222,6 +222,8 @@ class OracleDecoder:
         L.orc_quant_tables.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
         L.orc_entropy.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_entropy2.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_block_pixels.argtypes = [C.c_void_p, C.c_uint16, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_block_pixels.restype = None
         L.orc_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -286,10 +288,11 @@ class OracleDecoder:
         dcp = np.zeros((cx * cy, 3), dtype=np.int32)
         self.blk_state = np.zeros((nb, 2), dtype=np.uint32)
         self.blk_pred = np.zeros(nb, dtype=np.int32)
-        n = self.lib.orc_entropy(data, len(data), options, nb, coefs.ctypes.data_as(C.c_void_p),
-                                 flags.ctypes.data_as(C.c_void_p), state.ctypes.data_as(C.c_void_p),
-                                 dcp.ctypes.data_as(C.c_void_p), self.blk_state.ctypes.data_as(C.c_void_p),
-                                 self.blk_pred.ctypes.data_as(C.c_void_p))
+        self.blk_ac_state = np.zeros((nb, 2), dtype=np.uint32)      # the reader at every block's first AC symbol (the product's index format 2)
+        n = self.lib.orc_entropy2(data, len(data), options, nb, coefs.ctypes.data_as(C.c_void_p),
+                                  flags.ctypes.data_as(C.c_void_p), state.ctypes.data_as(C.c_void_p),
+                                  dcp.ctypes.data_as(C.c_void_p), self.blk_state.ctypes.data_as(C.c_void_p),
+                                  self.blk_pred.ctypes.data_as(C.c_void_p), self.blk_ac_state.ctypes.data_as(C.c_void_p))
         return n, coefs, flags, state, dcp
 
     def decode_canvas(self, data: bytes, pixel_type=RGB8888, options=0):

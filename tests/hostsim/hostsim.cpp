@@ -13,14 +13,12 @@
 
 #include <vector>
 static unsigned g_seg_steps = 0;
-static std::vector<unsigned> g_blk_at;
 static unsigned long long g_all_steps = 0;
 static bool g_pair_off = false;
 #define JDA_SEG_STEP_HOOK() (g_seg_steps++, g_all_steps++)
 #define JDA_SEG_PAIR_OFF() g_pair_off
 static int g_trace_seg = -1;
 #define JDA_SEG_TRACE_HOOK(OP, seg, p, k, kk, b2, bn, ends, iend, next_bit, nr, nblk, e, inval) do { if ((int)(seg) == g_trace_seg) fprintf(stderr, "  op %d seg %u: p %u (abs %u) k %u kk %u b2 %u bn %u ends %d iend %d next_bit %d nr %u nblk %u e %04x inval %d\n", (int)(OP), (unsigned)(seg), (unsigned)(p), (unsigned)((seg) * 2048u + (p)), (unsigned)(k), (unsigned)(kk), (unsigned)(b2), (unsigned)(bn), (int)(ends), (int)(iend), (int)(next_bit), (unsigned)(nr), (unsigned)(nblk), (unsigned)(e), (int)(inval)); } while (0)
-#define JDA_SEG_BLOCK_HOOK() (g_blk_at.push_back(g_seg_steps))
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
 
@@ -70,9 +68,7 @@ static int g_device_prescan = 0;     // != 0: make the block index with the devi
 static int g_prescan_used = 0;
 static uint32_t g_round2_list = 0;      // segments the round behind the first recording round had to walk again
 extern "C" uint32_t hostsim_round2_list(void) { return g_round2_list; }
-static int g_no_record = 0;              // 1: the counting walk + WRITE walk also for streams without restart intervals (round 2's passes)
 static uint32_t g_prescan_cands = 0;     // truncation candidates the last RECORD-mode pre-scan appended
-extern "C" void hostsim_set_no_record(int on) { g_no_record = on; }
 extern "C" void hostsim_trace_segment(int seg) { g_trace_seg = seg; }
 // the marker filter's sixteen-byte state machine (jda_filter_classify / jda_filter_run) against the byte-by-byte machine:
 // returns 0 when S, E, R agree for this group, valid count and incoming state
@@ -118,7 +114,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         // markers, and (hostsim_set_device_prescan(2), as jda_pipeline does it) streams with them
         const jda_image_info *I = jda_image_get_info(img);
         const size_t nb = (size_t)I->mcus_x * I->mcus_y * I->blocks_per_mcu;
-        dev_index.assign(nb + 1, 0u); dev_dc.assign(nb, 0x7777);      // (the write pass ORs its entries into a zeroed index, as jda_upload_batch has it)
+        dev_index.assign(nb + 1, 0xdeadbeefu); dev_dc.assign(nb, 0x7777);      // (finalize stores whole entries: nothing relies on what was there)
         uint32_t sl = 0, tb = 0;
         const uint8_t *scan = jda_image_scan(img, &sl);
         const uint8_t *tables = jda_image_tables(img, &tb);
@@ -148,22 +144,19 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         }
         for (uint32_t tid = 0; tid < 256; tid++) jda_walk_tables_from(tables, jda_wt_dc_follow(P), tid, 256, lt);
         const bool rst = P.restart_pos != nullptr;
-        // RECORD mode (streams without restart intervals), as jda_pipeline / jda_upload_batch run it
-        const bool record = !g_no_record && jda_image_record_cap(img) != 0;
+        // the passes as jda_pipeline / jda_upload_batch run them
         std::vector<uint32_t> records, cands, stats(80, 0), rst_events;
-        if (record) {
-            P.rec_cap = jda_image_record_cap(img); P.cand_cap = std::max<uint32_t>(1024u, n_segs * 16u);
-            records.assign((size_t)n_segs * P.rec_cap, 0xdeadbeefu); cands.assign((size_t)P.cand_cap * 4, 0);
-            P.records = records.data(); P.cands = cands.data(); P.stats = stats.data();
-            if (rst) { rst_events.assign((size_t)P.n_intervals * 2 + 2, 0); P.rst_events = rst_events.data(); }
-        }
+        P.rec_cap = jda_image_record_cap(img); P.cand_cap = std::max<uint32_t>(1024u, n_segs * 16u);
+        records.assign((size_t)n_segs * P.rec_cap, 0xdeadbeefu); cands.assign((size_t)P.cand_cap * 4, 0);
+        P.records = records.data(); P.cands = cands.data(); P.stats = stats.data();
+        if (rst) { rst_events.assign((size_t)P.n_intervals * 2 + 2, 0); P.rst_events = rst_events.data(); }
         jda_seg_sum S;
         jda_seg_stats ST;
         memset(&ST, 0, sizeof(ST));
         uint32_t rounds = 0;
         bool settled = false;
-        uint32_t *cur = ea.data(), *nxt = eb.data();
-        if (record) {
+        uint32_t *cur = ea.data();
+        {
             // round 0: every segment from the guess; round 1: every segment from what round 0 handed it, recording; from then on the
             // segments whose entry state changed (their records, sums and stamps are overwritten; candidates of earlier walks go stale)
             std::vector<uint32_t> E(n_segs + 1, 0), list, next;
@@ -192,26 +185,6 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             settled = list.empty();
             for (uint32_t i = 0; i <= n_segs; i++) ea[i] = E[i];
         }
-        while (!record && rounds < 48 && !settled) {            // SPEC rounds, exactly as the kernel's lanes do them
-            uint32_t changed = 0;
-            for (uint32_t seg = 0; seg < n_segs; seg++) {
-                const uint32_t entry = cur[seg];
-                const bool need = rounds == 0 || (entry & JDA_SEG_CHANGED) != 0;
-                const uint32_t old = cur[seg + 1] & ~JDA_SEG_CHANGED;
-                uint32_t out = old;
-                if (need) {
-                    const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-                    const uint32_t x = (rst ? jda_seg_walk<JDA_SEG_SPEC, true>(P, seg, entry & ~JDA_SEG_CHANGED, slot, lt, S, ST) : jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, entry & ~JDA_SEG_CHANGED, slot, lt, S, ST)) & ~JDA_SEG_CHANGED;
-                    out = x;
-                    if (x != old) { out |= JDA_SEG_CHANGED; changed++; }
-                }
-                nxt[seg + 1] = out;
-            }
-            nxt[0] = 0;
-            std::swap(cur, nxt);
-            rounds++;
-            if (changed == 0) settled = true;
-        }
         g_segscan_rounds = (int)rounds;
         if (getenv("HOSTSIM_SEGDEBUG")) {       // how fast do the states become the true ones?
             std::vector<uint32_t> truth(cur, cur + n_segs + 1), a(n_segs + 1, 0), b2(n_segs + 1, 0);
@@ -228,13 +201,6 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 for (uint32_t i = 0; i <= n_segs; i++) { good += c2[i] == truth[i]; dead += c2[i] == JDA_SEG_DEAD; }
                 fprintf(stderr, "round %u: %u of %u states true, %u dead\n", r, good, n_segs + 1, dead);
             }
-        }
-        memset(&ST, 0, sizeof(ST));
-        for (uint32_t seg = 0; seg < n_segs && !record; seg++) { // COUNT
-            const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-            if (rst) (void)jda_seg_walk<JDA_SEG_COUNT, true>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST); else (void)jda_seg_walk<JDA_SEG_COUNT, false>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, ST);
-            uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
-            o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map; o[5] = S.bad;
         }
         bool ok = settled;
         {   // the host's sums (jda_upload_batch)
@@ -259,9 +225,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
         }
         memset(&ST, 0, sizeof(ST));
         uint32_t terminal = 0;
-        std::vector<unsigned> steps_of(n_segs, 0);
-        std::vector<std::vector<unsigned> > syms_of(n_segs);
-        if (record) {                                           // finalize + candidates (jda_segscan_finalize, jda_segscan_resolve_cands)
+        {                                                       // finalize + candidates (jda_segscan_finalize, jda_segscan_resolve_cands)
             jda_fin_acc A;
             A.bad = 0; A.terminal = 0; A.max_abs_dc = 0;
             for (uint32_t seg = 0; seg < n_segs; seg++) {
@@ -269,7 +233,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 if (st[0] > P.n_blocks_total) break;
                 uint32_t nblk = seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
                 if (nblk > P.rec_cap) { nblk = P.rec_cap; A.bad = 1; }
-                for (uint32_t i = 0; i < nblk; i++) jda_finalize_item(P, seg, i, st[0], st[0] % P.nblocks, jda_fin_recip(P.nblocks), (int32_t)st[1], (int32_t)st[2], (int32_t)st[3], A);
+                for (uint32_t i = 0; i < nblk; i++) jda_finalize_item(P, seg, i, st[0], st[0] % P.nblocks, jda_fin_recip(P.nblocks), (int32_t)st[1], (int32_t)st[2], (int32_t)st[3], jda_fin_rst_from(seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS + 5]), A);
                 const uint32_t mac = (seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS + 5] >> 4) & 15u;
                 if (mac > ST.max_ac_bits) ST.max_ac_bits = mac;
             }
@@ -285,38 +249,6 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             if (getenv("HOSTSIM_DEBUG")) fprintf(stderr, "finalize: bad %u terminal %u cands %u\n", A.bad, A.terminal, stats[JDA_ST_NCAND]);
             ST.bad |= A.bad; terminal = A.terminal; ST.max_abs_dc = A.max_abs_dc;
         }
-        for (uint32_t seg = 0; seg < n_segs && !record; seg++) { // WRITE
-            g_seg_steps = 0; g_blk_at.clear();
-            if (seg_start[(size_t)seg * 5] > P.n_blocks_total) continue;
-            const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
-            jda_seg_stats T1;
-            memset(&T1, 0, sizeof(T1));
-            if (rst) (void)jda_seg_walk<JDA_SEG_WRITE, true>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1); else (void)jda_seg_walk<JDA_SEG_WRITE, false>(P, seg, cur[seg] & ~JDA_SEG_CHANGED, slot, lt, S, T1);
-            steps_of[seg] = g_seg_steps;
-            {   // symbols per block of this walk: the part of a block that began earlier, then whole blocks, then the part of the last one
-                std::vector<unsigned> &v = syms_of[seg];
-                unsigned prev = 0;
-                for (size_t i = 0; i < g_blk_at.size(); i++) { if (i || g_blk_at[i]) v.push_back(g_blk_at[i] - 1 - prev + (i ? 0 : 1)); prev = g_blk_at[i] - 1; }
-                v.push_back(g_seg_steps - prev);
-            }
-            ST.bad |= T1.bad | T1.mismatch; terminal += T1.terminal; ST.trunc_events += T1.trunc_events;
-            if (T1.max_ac_bits > ST.max_ac_bits) ST.max_ac_bits = T1.max_ac_bits;
-            if (T1.max_abs_dc > ST.max_abs_dc) ST.max_abs_dc = T1.max_abs_dc;
-        }
-        if (getenv("HOSTSIM_SEGDEBUG")) {       // how uneven are the walks of the 64 lanes of a wavefront?
-            double sum = 0, summax = 0; unsigned mx = 0;
-            for (uint32_t b0 = 0; b0 < n_segs; b0 += 64) { unsigned m = 0; for (uint32_t i = b0; i < n_segs && i < b0 + 64; i++) { sum += steps_of[i]; if (steps_of[i] > m) m = steps_of[i]; } summax += 64.0 * m; if (m > mx) mx = m; }
-            fprintf(stderr, "steps per segment: mean %.1f, mean of the wavefronts' maxima %.1f, max %u (lane efficiency %.2f)\n", sum / n_segs, summax / 64.0 / ((n_segs + 63) / 64), mx, sum / summax);
-            // what a block-synchronous walk would cost: per wavefront, sum over block iterations of the longest block of the 64 lanes
-            double outer = 0, inner = 0, waves = 0;
-            for (uint32_t b0 = 0; b0 < n_segs; b0 += 64) {
-                size_t nb_max = 0;
-                for (uint32_t i = b0; i < n_segs && i < b0 + 64; i++) nb_max = std::max(nb_max, syms_of[i].size());
-                for (size_t k = 0; k < nb_max; k++) { unsigned m = 0; for (uint32_t i = b0; i < n_segs && i < b0 + 64; i++) if (k < syms_of[i].size()) m = std::max(m, syms_of[i][k]); inner += m; }
-                outer += nb_max; waves++;
-            }
-            fprintf(stderr, "block-synchronous: %.1f block iterations and %.1f symbol iterations per wavefront (now: %.1f steps)\n", outer / waves, inner / waves, summax / 64.0 / waves);
-        }
         if (ok && !ST.bad && terminal == 1) {
             g_prescan_trunc = ST.trunc_events;
             jda_image_adopt_prescan(img, (uint32_t)(I->mcus_x * I->mcus_y), ST.max_ac_bits, (int32_t)ST.max_abs_dc, ST.trunc_events);
@@ -328,17 +260,22 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
             // (the serial pre-scan writes the reference reader's phase into every entry, RECORD mode a canonical one into the entries of
             // blocks without a truncated read: equal = the same bit position and flag everywhere, the same entry where flagged)
             bool same_index = ref != NULL;
-            for (size_t i = 0; i <= nb && same_index; i++) {
+            for (size_t i = 0; i < nb && same_index; i++) {
                 const uint32_t a = hi[i], b = dev_index[i];
                 const uint32_t pa = (a >> JDA_INDEX_OFF_BITS) * 8u + (a & (JDA_INDEX_TRUNC - 1u)), pb = (b >> JDA_INDEX_OFF_BITS) * 8u + (b & (JDA_INDEX_TRUNC - 1u));
-                same_index = pa == pb && (a & JDA_INDEX_TRUNC) == (b & JDA_INDEX_TRUNC) && (!(a & JDA_INDEX_TRUNC) || a == b) && (record || a == b);
+                same_index = pa == pb && (a & JDA_INDEX_TRUNC) == (b & JDA_INDEX_TRUNC) && (!(a & JDA_INDEX_TRUNC) || a == b);
+            }
+            if (same_index) {                                       // the closing entry: the device's bounds the serial one's from above, by 34 bits at most (+ 7 of an interval's rounding)
+                const uint32_t a = hi[nb], b = dev_index[nb];
+                const uint32_t pa = (a >> JDA_INDEX_OFF_BITS) * 8u + (a & 127u), pb = (b >> JDA_INDEX_OFF_BITS) * 8u + (b & 127u);
+                same_index = pb >= pa && pb <= pa + 41u;
             }
             g_index_equal = same_index && memcmp(jda_image_block_dc(ref), dev_dc.data(), nb * 2) == 0 &&
                             jda_image_truncation_events(ref) == ST.trunc_events && jda_image_fast_mul(ref) == jda_image_fast_mul(img) ? 1 : 0;
             if (ref && getenv("HOSTSIM_DEBUG")) {
                 for (size_t i = 0; i <= nb; i++) if (hi[i] != dev_index[i] || (i < nb && jda_image_block_dc(ref)[i] != dev_dc[i])) { fprintf(stderr, "first diff at block %zu of %zu: host %u/%u dc %d, dev %u/%u dc %d\n", i, nb, hi[i] >> 7, hi[i] & 127, i < nb ? jda_image_block_dc(ref)[i] : 0, dev_index[i] >> 7, dev_index[i] & 127, i < nb ? dev_dc[i] : 0); break; }
                 fprintf(stderr, "rounds %u trunc host %u dev %u\n", rounds, jda_image_truncation_events(ref), ST.trunc_events);
-                for (size_t i = 0; i <= nb; i++) {                  // the first entry that differs in what counts (position, flag, flagged entry, predictor)
+                for (size_t i = 0; i < nb; i++) {                   // the first entry that differs in what counts (position, flag, flagged entry, DC value)
                     const uint32_t a = hi[i], b = dev_index[i];
                     const uint32_t pa = (a >> JDA_INDEX_OFF_BITS) * 8u + (a & (JDA_INDEX_TRUNC - 1u)), pb = (b >> JDA_INDEX_OFF_BITS) * 8u + (b & (JDA_INDEX_TRUNC - 1u));
                     const bool eq = pa == pb && (a & JDA_INDEX_TRUNC) == (b & JDA_INDEX_TRUNC) && (!(a & JDA_INDEX_TRUNC) || a == b) && (i == nb || jda_image_block_dc(ref)[i] == dev_dc[i]);

@@ -31,22 +31,23 @@ def test_prepare_matches_oracle_stage_by_stage(name, oracle, product_lib):
     rc, q = oracle.quant_tables(jpeg)
     assert np.array_equal(t[10240:10752].view(np.int16).reshape(4, 64), q)
     assert list(t[10752:10816]) == [oracle.lib.orc_zigzag_to_natural(k) for k in range(64)]
-    # pre-scan index == the oracle's bit-reader phase and DC predictor on entry to every block
+    # pre-scan index (format 2) == the oracle's bit-reader phase at every block's first AC symbol + the block's own DC value
     n, coefs, flags, state, dcp = oracle.entropy(jpeg, 0)
     idx, nok = p.block_index()
     assert nok == p.n_mcus and n == len(flags) == p.n_blocks
-    # (an entry holds the reader AFTER the block's opening refill, jpeg.inl:2110-2114: offsets above 47 are folded into the
-    # byte position; bit 6 flags a block with a truncated magnitude read)
-    def refilled(st):
-        pos, off = st[:, 0].astype(np.int64), st[:, 1].astype(np.int64)
-        big = off > 47
-        return np.where(big, pos + (off >> 3), pos), np.where(big, off & 7, off)
-    wpos, woff = refilled(oracle.blk_state)
+    # (an entry holds the reader behind the refill at the top of the AC loop, jpeg.inl:2225-2230: offset <= 47; bit 6 flags a block
+    # with a truncated magnitude read)
+    wpos, woff = oracle.blk_ac_state[:, 0].astype(np.int64), oracle.blk_ac_state[:, 1].astype(np.int64)
+    assert woff.max() <= 47
     assert np.array_equal(idx[:-1] >> 7, wpos) and np.array_equal(idx[:-1] & 63, woff)
-    assert np.array_equal(p.block_dc().astype(np.int32), oracle.blk_pred)
-    bpm = p.info.blocks_per_mcu                      # MCU starts are the first block of each MCU
-    mpos, moff = refilled(state)
-    assert np.array_equal(idx[:-1:bpm] >> 7, mpos) and np.array_equal(idx[:-1:bpm] & 63, moff)
+    assert np.array_equal(p.block_dc(), coefs[:, 0])
+    # .. and that DC value is the predictor the next block of its component is entered with (what format 1 stored)
+    bpm = p.info.blocks_per_mcu
+    comp = np.array([0 if b < bpm - (2 if p.info.ncomp == 3 else 0) else b - (bpm - 2) + 1 for b in range(bpm)])
+    if p.info.restart_interval == 0:
+        for c in range(3 if p.info.ncomp == 3 else 1):
+            sel = np.flatnonzero(np.tile(comp, p.n_mcus) == c)
+            assert np.array_equal(oracle.blk_pred[sel][1:], coefs[sel, 0][:-1].astype(np.int32))
     n_flagged = int(np.count_nonzero(idx[:-1] & 64))
     assert n_flagged <= p.truncation_events() and (n_flagged > 0) == (p.truncation_events() > 0)
     p.close()

@@ -269,23 +269,6 @@ def test_record_mode_flags_the_truncated_reads_of_real_photographs(window, hosts
     assert seen >= 2                                           # (the test means something: photographs with truncated reads went through)
 
 
-def test_round_2_passes_still_make_the_same_index(hostsim, oracle):
-    """The counting walk + WRITE walk (what restart streams still take) on a stream without restart intervals: kept honest."""
-    jpeg = jpeg_for("c420_333x217")
-    hostsim.hostsim_set_device_prescan(1)
-    hostsim.hostsim_set_no_record(1)
-    try:
-        rc, want, err = oracle.decode_canvas(jpeg, 2, 0)
-        got = np.full_like(want, 0x33)
-        inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, 2, 0)
-        assert hostsim.hostsim_decode(jpeg, len(jpeg), 2, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
-        assert hostsim.hostsim_prescan_used() == 2 and hostsim.hostsim_index_equal() == 1
-        assert np.array_equal(got, want)
-    finally:
-        hostsim.hostsim_set_device_prescan(0)
-        hostsim.hostsim_set_no_record(0)
-
-
 def test_filter_state_machine_on_sixteen_bytes_at_once(hostsim):
     """jda_filter_classify / jda_filter_run (the marker filter's kernels evaluate JPEGFilter's two-state machine, jpeg.inl:1431-1540, on a
     16-bit "is FF" mask with one add) against the machine run byte by byte: every incoming state and valid count, on random groups
