@@ -140,7 +140,12 @@ def config_leg(J, ctx, name, what, jpegs, n_images, pt, options, threads, steps=
     ctx.timer_stop()
     ctx.sync()
     ms = ctx.timer_elapsed_ms() / steps
-    algo = st["output_bytes"] + st["scan_bytes"] + 4 * sum(p.n_mcus for p in prepared)
+    # algorithmic bytes: output + filtered scan + 4 B/MCU of index; at 1/8 the pixels are the blocks' DC values (index
+    # format 2 carries them): output + 2 B per block, no scan, no index entry
+    if options & J.SCALE_EIGHTH and not options & (J.SCALE_HALF | J.SCALE_QUARTER):
+        algo = st["output_bytes"] + 2 * sum(p.n_blocks for p in prepared)
+    else:
+        algo = st["output_bytes"] + st["scan_bytes"] + 4 * sum(p.n_mcus for p in prepared)
     # every surface's checksum, made where the pixels are: all decodes of one file must be one value, image 0's is checked on the host
     sums = ctx.checksums(outs, [geo["canvas_w"] * geo["bpp"]] * n_images)
     nd = len(jpegs)
@@ -160,6 +165,74 @@ def config_leg(J, ctx, name, what, jpegs, n_images, pt, options, threads, steps=
     ctx.free(base)
     res["leg_wall_s"] = round(time.perf_counter() - t0, 2)
     return res
+
+
+def photos_leg(J, ctx, threads, n_images=2048, steps=20, ramp_ms=150.0):
+    """Real photographs: the reference's own fixtures (tests/golden/ref: tulips 640x480, zebra, st_peters, perf.jpg) tiled to one
+    batch, kernel-only (inputs resident, index by the device pre-scan), RGB8888, every distinct file against the reference.  Their
+    blocks are long and uneven (1.5-4 bit/px): what the synthetic legs do not show."""
+    t0 = time.perf_counter()
+    names = ("tulips", "zebra", "st_peters", "perf")
+    d = os.path.join(ROOT, "tests", "golden", "ref")
+    jpegs = [open(os.path.join(d, n + ".jpg"), "rb").read() for n in names]
+    files = [jpegs[i % len(jpegs)] for i in range(n_images)]
+    prepared = J.prepare_batch(files, device_prescan=True, threads=threads)
+    pt = J.RGB8888
+    geos, pitches, sizes = [], [], []
+    for p in prepared[: len(jpegs)]:
+        g = p.geometry(pt, 0)
+        geos.append(g); pitches.append((g["canvas_w"] * g["bpp"] + 15) & ~15); sizes.append(pitches[-1] * g["canvas_h"])
+    offs, total = [], 0
+    for i in range(n_images):
+        offs.append(total); total += (sizes[i % len(jpegs)] + 255) & ~255
+    base = ctx.malloc(total)
+    dev = J.upload_batch(ctx, prepared)
+    outs = [(base + offs[i], pitches[i % len(jpegs)], geos[i % len(jpegs)]["canvas_w"], geos[i % len(jpegs)]["canvas_h"]) for i in range(n_images)]
+    batch = J.Batch(ctx, dev, outs, [pt] * n_images, [0] * n_images)
+    st = batch.stats
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:
+        for _ in range(4):
+            batch.decode()
+        ctx.sync()
+    ctx.timer_start()
+    for _ in range(steps):
+        batch.decode()
+    ctx.timer_stop()
+    ctx.sync()
+    ms = ctx.timer_elapsed_ms() / steps
+    algo = st["output_bytes"] + st["scan_bytes"] + 4 * sum(p.n_mcus for p in prepared)
+    sums = ctx.checksums(outs, [geos[i % len(jpegs)]["canvas_w"] * geos[i % len(jpegs)]["bpp"] for i in range(n_images)])
+    nd = len(jpegs)
+    checks = {names[k]: check_against_reference(J, ctx, jpegs[k], pt, 0, base + offs[k], sizes[k], pitches[k], geos[k], sums[k]) for k in range(nd)}
+    res = {"workload": "%d photographs -> RGB8888: the reference's fixtures %s tiled, inputs resident" % (n_images, ", ".join(names)),
+           "images": n_images, "distinct_images": nd,
+           "bits_per_pixel": {names[k]: round(8.0 * len(jpegs[k]) / (prepared[k].info.width * prepared[k].info.height), 2) for k in range(nd)},
+           "subsampling": {names[k]: "0x%02x" % prepared[k].info.subsample for k in range(nd)},
+           "launches_per_step": st.get("n_launches"),
+           "kernel_ms_per_step": ms, "mpix_s": st["source_pixels"] / (ms * 1e-3) / 1e6,
+           "algorithmic_bytes_per_step": algo, "achieved_gb_s": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "index": "device pre-scan at upload" if dev[0].prescan_on_device else "serial host pre-scan",
+           "parity": checks, "bit_exact": all(c["bit_exact"] for c in checks.values()),
+           "every_surface_equals_the_first_decode_of_its_file": bool(all(sums[i] == sums[i % nd] for i in range(n_images)))}
+    batch.close()
+    for d_ in dev:
+        d_.close()
+    for p_ in prepared:
+        p_.close()
+    ctx.free(base)
+    res["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    return res
+
+
+def kernel_sources_sha():
+    """What the decode kernel is compiled from: the PMC traffic file under profiles/ names the hash it was measured at."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("jda_kernels.hip", "jda_device_core.h"):
+        h.update(open(os.path.join(ROOT, "jpegdec_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def run_config_legs(J, ctx, threads, only=None):
@@ -185,6 +258,11 @@ def run_config_legs(J, ctx, threads, only=None):
             out[name] = config_leg(J, ctx, name, what, cache[key], n, pt, opt, threads)
         except Exception as e:  # a leg that fails is reported, the headline stands
             out[name] = {"workload": what, "error": "%s: %s" % (type(e).__name__, e)}
+    if not only or "photos" in only:
+        try:
+            out["photos"] = photos_leg(J, ctx, threads)
+        except Exception as e:
+            out["photos"] = {"workload": "photographs", "error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -210,7 +288,7 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-batches", type=int, default=24, help="batches streamed through jda_pipeline for the end-to-end figure (0: skip)")
     ap.add_argument("--e2e-depth", type=int, default=4)
     ap.add_argument("--e2e-distinct", type=int, default=16, help="distinct files a batch of the end-to-end leg cycles through (metric workload; the resident batch keeps --distinct)")
-    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,q98)")
+    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,q98,photos)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs over the other BASELINE.json configurations (`configs` in the line; N = 1, metric workload only)")
@@ -458,14 +536,21 @@ def run(args, J, out=sys.stdout):
         # HBM traffic per launch: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 --pmc passes of the same workload (profiles/), scaled to
         # this batch; null for any other workload
+        # The file names the hash of the kernel sources it was measured at (tools/gpu_profile.sh): with other sources in the tree the
+        # figure is stale and the line says null + why.
         traffic, traffic_src = None, None
-        for tag in ("r03", "r02", "r01_final"):
-            tp = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
-            if (os.path.exists(tp) and args.workload == "metric" and (args.width, args.height, args.subsampling, args.pixel_type, args.options, args.quality)
-                    == (4096, 4096, "4:2:0", "rgb8888", 0, 85)):
-                traffic = json.load(open(tp))["hbm_bytes_per_image"] * n_mine
-                traffic_src = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)" % tag
-                break
+        tp = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        if (os.path.exists(tp) and args.workload == "metric" and (args.width, args.height, args.subsampling, args.pixel_type, args.options, args.quality)
+                == (4096, 4096, "4:2:0", "rgb8888", 0, 85)):
+            tj = json.load(open(tp))
+            if tj.get("kernel_sources_sha16") == kernel_sources_sha():
+                traffic = tj["hbm_bytes_per_image"] * n_mine
+                traffic_src = ("profiles/r04_pmc_traffic.json (tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
+                               "correction; measured at kernel sources %s = this tree's)" % tj["kernel_sources_sha16"])
+            else:
+                traffic_src = ("stale: profiles/r04_pmc_traffic.json was measured at kernel sources %s, this tree has %s -- rerun tools/gpu_profile.sh"
+                               % (tj.get("kernel_sources_sha16"), kernel_sources_sha()))
+                print("bench.py: " + traffic_src, file=sys.stderr)
         line = {
             "metric": "Mpixels/s decoded",
             "value": value,

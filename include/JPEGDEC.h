@@ -83,7 +83,7 @@ class JPEGDEC {
     // Here a copy clones the open image (file-sourced data included; the close callback stays with the original), a move takes it.
     JPEGDEC(const JPEGDEC &);
     JPEGDEC &operator=(const JPEGDEC &);
-    JPEGDEC(JPEGDEC &&) noexcept;
+    JPEGDEC(JPEGDEC &&);
     JPEGDEC &operator=(JPEGDEC &&) noexcept;
 
     int openRAM(uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw);
@@ -118,22 +118,24 @@ class JPEGDEC {
 
   private:
     jpegdec_amd_state *_jpeg;
+    friend struct jpegdec_amd_c_api;      // (the C flavour below is served by objects of this class)
 };
 
 #endif // __cplusplus
 
 // ---- the C flavour of the API (reference src/JPEGDEC.h:288-309, bodies src/jpeg.inl:564-739).  The reference
 // offers it to C translation units that include jpeg.inl; here the functions live in libjpegdec_amd.so and are
-// callable from C and C++ alike.  JPEGIMAGE is caller-allocated as in the reference (there: the 18 KB decoder
-// state; here: a small handle -- the state lives in a slot of a table inside the library).  As in the reference, a JPEGIMAGE needs
-// no initialisation before JPEG_open* (an open tells a live handle from stack garbage by the magic word + slot + generation) and a
-// RAM / FLASH source needs no JPEG_close (src/JPEGDEC.cpp:232-236: a no-op there): a handle that is re-opened reuses its slot, and
-// slots of RAM-sourced images that were never closed are recycled, least recently used first, once 64 are open -- a handle whose
-// slot went that way reports JPEG_INVALID_PARAMETER.  File-sourced images are closed with JPEG_close, as in the reference.
+// callable from C and C++ alike.  JPEGIMAGE is caller-allocated as in the reference and holds the open image as plain
+// data (there: the 18 KB decoder state; here: source pointer, parsed header, settings).  As in the reference, a JPEGIMAGE
+// needs no initialisation before JPEG_open*, any number of them may be open, and a RAM / FLASH source needs no JPEG_close
+// (src/JPEGDEC.cpp:232-236: a no-op there).  A file-sourced image owns the file's bytes until JPEG_close, as the
+// reference's owns its open file.  A handle is used where it was opened: a struct copy of a JPEGIMAGE is not a handle.
 typedef struct jpeg_image_tag {
-    uint32_t magic;          /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
-    uint32_t gen;            /* generation of the slot when this handle opened it */
-    void *impl;              /* the slot */
+    uint32_t magic;                 /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
+    uint32_t reserved;
+    struct jpeg_image_tag *self;    /* an open handle points at itself */
+    void *file_data;                /* JPEG_openFile: the file's bytes, freed by JPEG_close */
+    uint64_t state[40];             /* the open image (opaque) */
 } JPEGIMAGE;
 
 #ifdef __cplusplus

@@ -102,7 +102,7 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
 /* The same with options.  JDA_PREPARE_DEVICE_PRESCAN: skip the serial Huffman pre-scan on the host; the per-block
  * index is then made on the GPU when the image is uploaded (jda_upload / jda_upload_batch) by the segment walk --
  * one lane per 256-byte segment of the filtered scan, with or without restart markers (DRI, jpeg.inl:1715-1718,
- * 5337-5348) -- entry for entry what the serial pre-scan makes.  The upload falls back to the host pre-scan by itself
+ * 5337-5348) -- the same index as the serial pre-scan's in the sense of jda_index_equivalent.  The upload falls back to the host pre-scan by itself
  * when the walk cannot guarantee that (an invalid code, a marker out of place, states that do not settle); files the
  * walk cannot take at all (progressive, one restart interval, table ids 2-3, DC codes its table key cannot tell
  * apart) are pre-scanned here whatever the flag says: jda_image_prescan_pending tells. */
@@ -117,15 +117,27 @@ int jda_image_prescan_pending(const jda_image *img);
 void jda_image_free(jda_image *img);
 
 const jda_image_info *jda_image_get_info(const jda_image *img);
-/* views into the prepared image (owned by img): the filtered scan; the per-BLOCK index
- * (n_blocks+1 entries, n_blocks = mcus_x*mcus_y*blocks_per_mcu, scan order): (byte position << 7) |
- * bit offset = the reference bit reader's state (bb.pBuf, bb.ulBitOff) on entry to JPEGDecodeMCU
- * for that block; and the DC predictor of the block's component on entry (n_blocks int16).
+/* views into the prepared image (owned by img): the filtered scan; the per-BLOCK index, FORMAT 2
+ * (n_blocks+1 entries, n_blocks = mcus_x*mcus_y*blocks_per_mcu, scan order): (byte position << 7) | flag << 6 |
+ * bit offset = the reference bit reader's state (bb.pBuf, bb.ulBitOff) at the block's FIRST AC SYMBOL, behind the
+ * refill at the top of JPEGDecodeMCU's AC loop (jpeg.inl:2225-2230: offset 0..47); and the block's OWN DC value
+ * (n_blocks int16: the pre-scan decoded the DC symbol, :2129-2165).  The decode kernel starts every block at
+ * coefficient 1; a 1/8 or progressive thumbnail (:5146-5154, :4964-4966) reads the DC values and nothing else.
+ * Flag (bit 6): the reference truncates a magnitude read of this block (its window is not refilled between a code and its
+ * magnitude, :2249-2252) -- the kernel emulates that from the entry's exact (pBuf, ulBitOff).  The last entry closes
+ * the index: a bit position at or behind the last block's last bit (see jda_index_equivalent).
  * *n_mcus_ok < mcus_x*mcus_y means the pre-scan hit an invalid code in that MCU (the reference
  * returns JPEG_DECODE_ERROR there, jpeg.inl:2137, 2237, 5354-5356). */
 const uint8_t *jda_image_scan(const jda_image *img, uint32_t *len);
 const uint32_t *jda_image_block_index(const jda_image *img, uint32_t *n_mcus_ok);
 const int16_t *jda_image_block_dc(const jda_image *img);
+/* Do two indexes of n_blocks + 1 entries (one from the serial pre-scan, one read back from the device: jda_dev_image_read_index,
+ * jda_pipeline_read_index) name the same decode?  The contract between the two pre-scans: every block's entry has the same bit
+ * position (byte position * 8 + bit offset) and the same flag; a FLAGGED block's entry is identical (the reference reader's exact
+ * phase); an unflagged block's entry from the device is canonical -- (p >> 3) << 7 | (p & 7) for its bit position p -- where the
+ * serial pre-scan stores the reader's phase; the closing entries lie within 41 bits of each other (the device's is behind the DC
+ * symbol that the stream's padding decodes to, and rounded up to a byte in a stream with restart intervals).  Returns 1 / 0. */
+int jda_index_equivalent(const uint32_t *a, const uint32_t *b, uint32_t n_blocks);
 /* the table blob uploaded to the GPU: DC LUTs 2x1024 B, AC LUTs 2x2048 uint16, quant 4x64 int16, zigzag 64 B,
  * and (ours) the end-of-block code of each AC table, 2 x uint32 = (32 - length) << 16 | code */
 const uint8_t *jda_image_tables(const jda_image *img, uint32_t *bytes);
@@ -183,8 +195,8 @@ int jda_copy_to_host(jda_ctx *ctx, void *host, const void *dptr, size_t bytes); 
 int jda_copy_to_device(jda_ctx *ctx, void *dptr, const void *host, size_t bytes); /* synchronous */
 
 /* H2D: tables + index + filtered scan of one prepared image into one HBM allocation.  For an image prepared
- * with JDA_PREPARE_DEVICE_PRESCAN whose index is still pending, the index is made here on the GPU, equal to
- * the serial pre-scan's entry for entry: one lane per 256 bytes of the scan, whose decoder states settle by
+ * with JDA_PREPARE_DEVICE_PRESCAN whose index is still pending, the index is made here on the GPU, equivalent to
+ * the serial pre-scan's (jda_index_equivalent; the DC values are equal): one lane per 256 bytes of the scan, whose decoder states settle by
  * self-synchronisation in a few speculative rounds (restart intervals end where the filter found the markers).  A marker that is not where the MCU count puts it, a corrupt or truncated stream, or states that do
  * not settle send the image to the serial host pre-scan instead (the image object is completed in place). */
 jda_dev_image *jda_upload(jda_ctx *ctx, jda_image *img, int32_t *err);
@@ -197,7 +209,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
  * index-aligned with the caller's file list; jda_batch_create accepts the holes and launches nothing for them. */
 int jda_upload_batch_ex(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_image **out, int32_t *status);
 int jda_dev_image_prescan_on_device(const jda_dev_image *dimg);   /* 1: a device pre-scan produced the index */
-/* copy the per-block index (n_blocks + 1 entries) and DC predictors (n_blocks) of a resident image back to the host
+/* copy the per-block index (n_blocks + 1 entries) and DC values (n_blocks) of a resident image back to the host
  * (either pointer may be NULL); n_blocks = mcus_x * mcus_y * blocks_per_mcu.  Synchronous. */
 int jda_dev_image_read_index(jda_ctx *ctx, const jda_dev_image *dimg, uint32_t *index, int16_t *dc);
 uint32_t jda_dev_image_mcus_ok(const jda_dev_image *dimg);        /* MCUs the pre-scan validated */
@@ -303,7 +315,7 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
 /* ------------------------------------------------------------------ the streamed pipeline
  * Files in, pixels resident in HBM out, batch after batch: the host parses headers and builds tables (microseconds per file);
  * the unfiltered entropy-coded bytes go to the GPU, which filters them (JPEGFilter, jpeg.inl:1431-1540), makes the per-block
- * index (equal to the serial pre-scan's, entry for entry) and decodes (jpeg.inl:5109-5353).  Upload + filter + pre-scan of
+ * index (equivalent to the serial pre-scan's: jda_index_equivalent) and decodes (jpeg.inl:5109-5353).  Upload + filter + pre-scan of
  * batch n+1 run on streams of their own under the decode of batch n (three batches in flight keep the GPU busy).  Images the device walk cannot take or that fail its checks
  * (progressive, corrupt, truncated, ...) are redone through the serial host pre-scan when the batch is waited for, so every
  * image ends with the status -- and the pixels -- the one-image path (jda_decode_to_host) gives it.
@@ -326,7 +338,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
 int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status);
 int jda_pipeline_get_stats(const jda_pipeline *p, jda_pipeline_stats *out);   /* totals over the batches waited for */
 /* diagnostics: after jda_pipeline_wait(ticket), before `depth` more batches are submitted -- the per-block index (n_blocks + 1
- * entries) and DC predictors (n_blocks) the device made for image i, and its filtered scan length (any pointer may be NULL) */
+ * entries) and DC values (n_blocks) the device made for image i, and its filtered scan length (any pointer may be NULL) */
 int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t *index, int16_t *dc, uint32_t *filtered_len);
 
 /* ------------------------------------------------------------------ the node: one host process, every GPU

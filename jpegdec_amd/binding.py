@@ -72,6 +72,7 @@ _PROTOTYPES = [
     ("jda_image_scan", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_block_index", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_block_dc", _P, [_P]),
+    ("jda_index_equivalent", C.c_int, [_P, _P, C.c_uint32]),
     ("jda_image_tables", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_truncation_events", C.c_uint32, [_P]),
     ("jda_image_general_p1", C.c_uint32, [_P]),
@@ -353,14 +354,11 @@ def index_equivalent(a, b) -> bool:
     same entry where flagged.  The closing entry (the last one) only bounds the scan from above: the device pre-scan's lies up to
     41 bits behind the serial one's (the DC symbol the stream's padding decodes to, an interval's rounding); either order of
     the arguments is accepted."""
-    a = np.asarray(a, dtype=np.uint32)
-    b = np.asarray(b, dtype=np.uint32)
-    if a.shape != b.shape or a.size == 0:
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    if a.shape != b.shape or a.ndim != 1 or a.size == 0:
         return False
-    pa, pb = (a[:-1] >> 7) * 8 + (a[:-1] & 63), (b[:-1] >> 7) * 8 + (b[:-1] & 63)
-    fa, fb = a[:-1] & 64, b[:-1] & 64
-    ea, eb = int(a[-1] >> 7) * 8 + int(a[-1] & 127), int(b[-1] >> 7) * 8 + int(b[-1] & 127)
-    return bool(np.array_equal(pa, pb) and np.array_equal(fa, fb) and np.array_equal(a[:-1][fa != 0], b[:-1][fb != 0]) and abs(ea - eb) <= 41)
+    return bool(load_library().jda_index_equivalent(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), a.size - 1))
 
 
 def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0, strict: bool = True):

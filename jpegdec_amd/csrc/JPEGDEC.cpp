@@ -20,19 +20,9 @@
 
 #define JDA_MAX_REPLAY_BANDS 8          // bands of the copy back of a large image decoded with draw callbacks
 
-struct jpegdec_amd_state {
-    std::vector<uint8_t> owned;       // file-sourced data (open(filename) / callbacks)
-    // the decoded canvas the draw callbacks / the framebuffer copy are replayed from, and the replay's strip plan: kept from one
-    // decode to the next (they grow to the largest image the object has decoded and go with it) -- a fresh canvas per decode was
-    // a memset and a page fault per 4 KB of it: 0.2 ms of a 640x480 decode, 5 ms of a 4096x4096 one
-    std::vector<uint8_t> canvas;
-    uint8_t *pinned_canvas;           // large images: page-locked, so that the copy back runs beside the strip replay (jda_decode_to_host_bands)
-    size_t pinned_cap;
-    jpegdec_amd_state() : pinned_canvas(NULL), pinned_cap(0) {}
-    ~jpegdec_amd_state() { if (pinned_canvas) jda_host_free(pinned_canvas); }
-    jpegdec_amd_state(const jpegdec_amd_state &) = delete;
-    jpegdec_amd_state &operator=(const jpegdec_amd_state &) = delete;
-    std::vector<int32_t> rects;
+// What an open image IS, as plain data: the source, the parsed header, everything the setters set.  A C++ object holds it inside
+// its state; a C JPEGIMAGE holds exactly this (the caller's memory, as the reference's 18 KB struct is the caller's).
+struct jpegdec_amd_settings {
     const uint8_t *data;
     int size;
     jda_image_info info;
@@ -49,6 +39,20 @@ struct jpegdec_amd_state {
     JPEG_CLOSE_CALLBACK *close_cb;
     void *close_handle;
     bool opened;
+};
+struct jpegdec_amd_state : jpegdec_amd_settings {
+    std::vector<uint8_t> owned;       // file-sourced data (open(filename) / callbacks)
+    // the decoded canvas the draw callbacks / the framebuffer copy are replayed from, and the replay's strip plan: kept from one
+    // decode to the next (they grow to the largest image the object has decoded and go with it) -- a fresh canvas per decode was
+    // a memset and a page fault per 4 KB of it: 0.2 ms of a 640x480 decode, 5 ms of a 4096x4096 one
+    std::vector<uint8_t> canvas;
+    uint8_t *pinned_canvas;           // large images: page-locked, so that the copy back runs beside the strip replay (jda_decode_to_host_bands)
+    size_t pinned_cap;
+    jpegdec_amd_state() : pinned_canvas(NULL), pinned_cap(0) {}
+    ~jpegdec_amd_state() { if (pinned_canvas) jda_host_free(pinned_canvas); }
+    jpegdec_amd_state(const jpegdec_amd_state &) = delete;
+    jpegdec_amd_state &operator=(const jpegdec_amd_state &) = delete;
+    std::vector<int32_t> rects;
     // strip handed to the draw callback; two halves alternate with JPEG_USES_DMA (jpeg.inl:5073-5076)
     alignas(16) uint16_t strip[MAX_BUFFERED_PIXELS + 8];
 };
@@ -139,7 +143,11 @@ JPEGDEC &JPEGDEC::operator=(const JPEGDEC &o)
     if (this != &o) { jpegdec_amd_state *s = clone_state(o._jpeg); delete _jpeg; _jpeg = s; }
     return *this;
 }
-JPEGDEC::JPEGDEC(JPEGDEC &&o) noexcept : _jpeg(o._jpeg) { o._jpeg = new jpegdec_amd_state; o._jpeg->device = -1; reset(o._jpeg); }
+JPEGDEC::JPEGDEC(JPEGDEC &&o) : _jpeg(new jpegdec_amd_state)      // (allocates: not noexcept -- the source stays a valid, closed object)
+{
+    _jpeg->device = -1; reset(_jpeg);
+    jpegdec_amd_state *t = _jpeg; _jpeg = o._jpeg; o._jpeg = t;
+}
 JPEGDEC &JPEGDEC::operator=(JPEGDEC &&o) noexcept
 {
     if (this != &o) { jpegdec_amd_state *t = _jpeg; _jpeg = o._jpeg; o._jpeg = t; reset(o._jpeg); }
@@ -484,86 +492,97 @@ int JPEGDEC::decode(int x, int y, int iOptions)
 }
 
 
-// ---- C flavour (reference src/jpeg.inl:564-739): thin wrappers over the class; the caller's JPEGIMAGE holds the object
-// The objects live in a table of slots inside the library; a handle names its slot and the slot's generation.  A handle that is
-// opened again reuses its slot; when every slot is taken, the least recently used one whose image came from RAM / FLASH -- the
-// reference needs no JPEG_close for those (src/JPEGDEC.cpp:232-236) -- is recycled, and the handle that held it goes stale.
-#define JPEGIMAGE_MAGIC 0x4a444132u   /* "JDA2" */
-#define JPEG_C_SLOTS 64
+// ---- C flavour (reference src/jpeg.inl:564-739).  The caller's JPEGIMAGE holds the open image as plain data (jpegdec_amd_settings:
+// source pointer, parsed header, what the setters set) -- the caller's memory, like the reference's struct: any number of handles,
+// no initialisation before JPEG_open*, no JPEG_close for RAM / FLASH sources (src/JPEGDEC.cpp:232-236), nothing shared between
+// handles, no table and no lock inside the library.  A file-sourced handle also owns the file's bytes (read whole at open: the GPU
+// path needs the whole scan) until JPEG_close, as the reference's owns its open file.  The work is done by one JPEGDEC object per
+// THREAD that a call loads the handle's settings into and stores them back from; the decoded canvas and the page-locked copy-back
+// buffer are that object's and serve every handle the thread decodes.
+#define JPEGIMAGE_MAGIC 0x4a444133u   /* "JDA3" */
+struct jpegdec_amd_c_api { static jpegdec_amd_state *state(JPEGDEC &j) { return j._jpeg; } };
 namespace {
-struct CSlot { JPEGDEC *obj; uint32_t gen; uint64_t stamp; bool file; };
-CSlot g_cslots[JPEG_C_SLOTS];
-std::mutex g_cslots_mu;
-std::atomic<uint64_t> g_cstamp(1);
-}
-static CSlot *c_slot(JPEGIMAGE *p)
+static_assert(sizeof(jpegdec_amd_settings) <= sizeof(((JPEGIMAGE *)0)->state), "JPEGIMAGE holds the settings");
+thread_local JPEGDEC t_cworker;
+// a live handle: opened by this library and still at the address it was opened at (stack garbage and struct copies are not)
+bool c_live(const JPEGIMAGE *p) { return p && p->magic == JPEGIMAGE_MAGIC && p->self == p; }
+jpegdec_amd_state *c_load(JPEGIMAGE *p)
 {
-    if (!p || p->magic != JPEGIMAGE_MAGIC) return NULL;
-    CSlot *s = (CSlot *)p->impl;
-    if (s < g_cslots || s >= g_cslots + JPEG_C_SLOTS || (size_t)((const char *)s - (const char *)g_cslots) % sizeof(CSlot)) return NULL;    // stack garbage
-    return (s->obj && s->gen == p->gen) ? s : NULL;
+    if (!c_live(p)) return NULL;
+    jpegdec_amd_state *s = jpegdec_amd_c_api::state(t_cworker);
+    memcpy(static_cast<jpegdec_amd_settings *>(s), p->state, sizeof(jpegdec_amd_settings));
+    return s;
 }
-static JPEGDEC *c_obj(JPEGIMAGE *p)
+void c_store(JPEGIMAGE *p) { memcpy(p->state, static_cast<const jpegdec_amd_settings *>(jpegdec_amd_c_api::state(t_cworker)), sizeof(jpegdec_amd_settings)); }
+// JPEG_open*: the reference memsets its state (jpeg.inl:569); a live file-sourced handle that is opened again gives its bytes back first
+void c_begin_open(JPEGIMAGE *p)
 {
-    CSlot *s = c_slot(p);
-    if (!s) return NULL;
-    s->stamp = g_cstamp.fetch_add(1, std::memory_order_relaxed);
-    return s->obj;
+    if (c_live(p) && p->file_data) free(p->file_data);
+    memset(p, 0, sizeof(*p));
+    p->magic = JPEGIMAGE_MAGIC; p->self = p;
+    jpegdec_amd_c_api::state(t_cworker)->device = -1;
 }
-static JPEGDEC *c_fresh(JPEGIMAGE *p, bool file)
-{
-    if (!p) return NULL;
-    std::lock_guard<std::mutex> lock(g_cslots_mu);
-    CSlot *s = c_slot(p);                                        // re-open: the reference memsets its state (jpeg.inl:569)
-    if (!s) {
-        CSlot *lru = NULL;
-        for (int i = 0; i < JPEG_C_SLOTS && !s; i++) {
-            if (!g_cslots[i].obj) s = &g_cslots[i];
-            else if (!g_cslots[i].file && (!lru || g_cslots[i].stamp < lru->stamp)) lru = &g_cslots[i];
-        }
-        if (!s) s = lru;                                         // every slot taken: the RAM-sourced image nobody has touched the longest
-        if (!s) { p->magic = 0; p->impl = NULL; return NULL; }   // (64 file-sourced images open and never closed)
-    }
-    if (s->obj) { s->obj->close(); delete s->obj; }
-    s->obj = new (std::nothrow) JPEGDEC();
-    s->gen++; s->file = file; s->stamp = g_cstamp.fetch_add(1, std::memory_order_relaxed);
-    p->magic = s->obj ? JPEGIMAGE_MAGIC : 0; p->gen = s->gen; p->impl = s;
-    return s->obj;
 }
 extern "C" {
 int JPEG_openRAM(JPEGIMAGE *pJPEG, uint8_t *pData, int iDataSize, JPEG_DRAW_CALLBACK *pfnDraw)
 {
-    JPEGDEC *j = c_fresh(pJPEG, false);
-    return j ? j->openRAM(pData, iDataSize, pfnDraw) : 0;
+    if (!pJPEG) return 0;
+    c_begin_open(pJPEG);
+    const int rc = t_cworker.openRAM(pData, iDataSize, pfnDraw);
+    c_store(pJPEG);
+    return rc;
 }
 int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *pfnDraw)
 {
-    JPEGDEC *j = c_fresh(pJPEG, true);
-    return j ? j->open(szFilename, pfnDraw) : 0;
+    if (!pJPEG) return 0;
+    c_begin_open(pJPEG);
+    const int rc = t_cworker.open(szFilename, pfnDraw);
+    jpegdec_amd_state *s = jpegdec_amd_c_api::state(t_cworker);
+    if (!s->owned.empty()) {                                    // the file's bytes go with the handle (the worker serves other handles next)
+        pJPEG->file_data = malloc(s->owned.size());
+        if (pJPEG->file_data) { memcpy(pJPEG->file_data, s->owned.data(), s->owned.size()); s->data = (const uint8_t *)pJPEG->file_data; }
+        else { s->data = NULL; s->size = 0; s->opened = false; s->error = JPEG_ERROR_MEMORY; }
+        std::vector<uint8_t>().swap(s->owned);
+    }
+    c_store(pJPEG);
+    return pJPEG->file_data || s->size == 0 ? rc : 0;
 }
-void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer) { if (JPEGDEC *j = c_obj(pJPEG)) j->setFramebuffer(pFramebuffer); }
-void JPEG_setDevice(JPEGIMAGE *pJPEG, int iDevice) { if (JPEGDEC *j = c_obj(pJPEG)) j->setDevice(iDevice); }
-void JPEG_setCropArea(JPEGIMAGE *pJPEG, int x, int y, int w, int h) { if (JPEGDEC *j = c_obj(pJPEG)) j->setCropArea(x, y, w, h); }
-void JPEG_getCropArea(JPEGIMAGE *pJPEG, int *x, int *y, int *w, int *h) { if (JPEGDEC *j = c_obj(pJPEG)) j->getCropArea(x, y, w, h); }
-int JPEG_getWidth(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getWidth() : 0; }
-int JPEG_getHeight(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getHeight() : 0; }
-int JPEG_decode(JPEGIMAGE *pJPEG, int x, int y, int iOptions) { JPEGDEC *j = c_obj(pJPEG); return j ? j->decode(x, y, iOptions) : 0; }
-int JPEG_decodeDither(JPEGIMAGE *pJPEG, uint8_t *pDither, int iOptions) { JPEGDEC *j = c_obj(pJPEG); return j ? j->decodeDither(pDither, iOptions) : 0; }
+#define JDA_C_CALL(p, expr) do { if (jpegdec_amd_state *s_ = c_load(p)) { (void)s_; expr; c_store(p); } } while (0)
+void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer) { JDA_C_CALL(pJPEG, t_cworker.setFramebuffer(pFramebuffer)); }
+void JPEG_setDevice(JPEGIMAGE *pJPEG, int iDevice) { JDA_C_CALL(pJPEG, t_cworker.setDevice(iDevice)); }
+void JPEG_setCropArea(JPEGIMAGE *pJPEG, int x, int y, int w, int h) { JDA_C_CALL(pJPEG, t_cworker.setCropArea(x, y, w, h)); }
+void JPEG_getCropArea(JPEGIMAGE *pJPEG, int *x, int *y, int *w, int *h) { JDA_C_CALL(pJPEG, t_cworker.getCropArea(x, y, w, h)); }
+int JPEG_getWidth(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getWidth() : 0; }
+int JPEG_getHeight(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getHeight() : 0; }
+int JPEG_decode(JPEGIMAGE *pJPEG, int x, int y, int iOptions)
+{
+    int rc = 0;
+    JDA_C_CALL(pJPEG, rc = t_cworker.decode(x, y, iOptions));
+    return rc;
+}
+int JPEG_decodeDither(JPEGIMAGE *pJPEG, uint8_t *pDither, int iOptions)
+{
+    int rc = 0;
+    JDA_C_CALL(pJPEG, rc = t_cworker.decodeDither(pDither, iOptions));
+    return rc;
+}
 void JPEG_close(JPEGIMAGE *pJPEG)
 {
-    {
-        std::lock_guard<std::mutex> lock(g_cslots_mu);
-        if (CSlot *s = c_slot(pJPEG)) { s->obj->close(); delete s->obj; s->obj = NULL; s->gen++; }
+    if (!pJPEG) return;
+    if (c_live(pJPEG)) {
+        JDA_C_CALL(pJPEG, t_cworker.close());
+        if (pJPEG->file_data) free(pJPEG->file_data);
     }
-    if (pJPEG) { pJPEG->impl = NULL; pJPEG->magic = 0; }
+    pJPEG->file_data = NULL; pJPEG->self = NULL; pJPEG->magic = 0;
 }
-int JPEG_getLastError(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getLastError() : JPEG_INVALID_PARAMETER; }
-int JPEG_getOrientation(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getOrientation() : 0; }
-int JPEG_getBpp(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getBpp() : 0; }
-int JPEG_getSubSample(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getSubSample() : 0; }
-int JPEG_hasThumb(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->hasThumb() : 0; }
-int JPEG_getThumbWidth(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getThumbWidth() : 0; }
-int JPEG_getThumbHeight(JPEGIMAGE *pJPEG) { JPEGDEC *j = c_obj(pJPEG); return j ? j->getThumbHeight() : 0; }
-void JPEG_setPixelType(JPEGIMAGE *pJPEG, int iType) { if (JPEGDEC *j = c_obj(pJPEG)) j->setPixelType(iType); }
-void JPEG_setMaxOutputSize(JPEGIMAGE *pJPEG, int iMaxMCUs) { if (JPEGDEC *j = c_obj(pJPEG)) j->setMaxOutputSize(iMaxMCUs); }
+int JPEG_getLastError(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getLastError() : JPEG_INVALID_PARAMETER; }
+int JPEG_getOrientation(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getOrientation() : 0; }
+int JPEG_getBpp(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getBpp() : 0; }
+int JPEG_getSubSample(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getSubSample() : 0; }
+int JPEG_hasThumb(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.hasThumb() : 0; }
+int JPEG_getThumbWidth(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getThumbWidth() : 0; }
+int JPEG_getThumbHeight(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getThumbHeight() : 0; }
+void JPEG_setPixelType(JPEGIMAGE *pJPEG, int iType) { JDA_C_CALL(pJPEG, t_cworker.setPixelType(iType)); }
+void JPEG_setMaxOutputSize(JPEGIMAGE *pJPEG, int iMaxMCUs) { JDA_C_CALL(pJPEG, t_cworker.setMaxOutputSize(iMaxMCUs)); }
+#undef JDA_C_CALL
 }

@@ -19,9 +19,11 @@
 #define JDA_TABLE_BYTES  10832
 
 #define JDA_SCAN_PAD     32       // zero bytes after the filtered scan (window loads overrun)
-#define JDA_INDEX_OFF_BITS 7      // index entry = (byte position << 7) | flags/bit offset: the reference's bit reader AFTER the block's
-                                  // opening refill (jpeg.inl:2110-2114; bit offset 0..47 in bits 5:0), bit 6 = JDA_INDEX_TRUNC.  (The closing
-                                  // entry behind the last block is the reader as the last block left it: offset 0..64, no flag.)
+#define JDA_INDEX_OFF_BITS 7      // index entry (format 2) = (byte position << 7) | flags/bit offset: the reference's bit reader at the block's
+                                  // FIRST AC SYMBOL, behind the refill at the top of its AC loop (jpeg.inl:2225-2230; bit offset 0..47 in bits
+                                  // 5:0), bit 6 = JDA_INDEX_TRUNC; the block's own DC value rides beside it (blk_dc).  (The closing entry behind
+                                  // the last block bounds the scan: the reader as the last block left it, offset 0..64, no flag -- or, from the
+                                  // device pre-scan, up to 41 bits further on.)
 #define JDA_INDEX_TRUNC 0x40u     // the reference truncates a magnitude read of this block: P1 must follow its ulBitOff
 
 // ---- the segment walk's 11-bit table key (jda_device_core.h, JDA_WT_*) and the reference's DC LUT index, shared with the front end
@@ -73,8 +75,8 @@ enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2, JDA_MODE_422 = 3 /
 // ---- device-side descriptors ----
 struct jda_dev_desc {             // one per image of a batch, 96 bytes
     const uint8_t *scan;          // filtered entropy-coded bytes (4-byte aligned, padded)
-    const uint32_t *blk_index;    // n_blocks+1 entries: (byte position << 7) | bit offset at each block start
-    const int16_t *blk_dc;        // n_blocks: the block's DC predictor on entry
+    const uint32_t *blk_index;    // n_blocks+1 entries: (byte position << 7) | bit offset at each block's first AC symbol
+    const int16_t *blk_dc;        // n_blocks: the block's own DC value
     const uint8_t *tables;        // JDA_TABLE_BYTES
     uint8_t *out;                 // output surface
     uint32_t out_pitch;           // bytes

@@ -95,6 +95,36 @@ __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
     return L;
 }
 
+// The same through the CONSTANT address space: the descriptor array is written before the launch and never by a kernel, and the
+// address is uniform, so these are scalar loads (s_load_dwordx8: no vector memory instruction, no v_readfirstlane, a scalar-cache
+// hit for every wavefront but the first).  What the DC thumbnail kernel uses: its wavefronts live for three dependent round trips,
+// and two of them are this.  (The persistent decode kernel re-reading its descriptor per phase instead of holding it in SGPRs
+// was measured: 28 -> 13 SGPR spills, 1.5 % SLOWER -- the scalar loads' waits cost more than the v_readlanes they replace.)
+typedef const jda_dev_desc __attribute__((address_space(4))) *jda_desc_cptr;
+template <int VARIANT = 0, int MODE = JDA_MODE_420>
+__device__ __forceinline__ jda_dev_desc jda_desc_const(jda_desc_cptr c)
+{
+    asm volatile("" : "+s"(c));
+    jda_dev_desc L;
+    L.scan = (const uint8_t *)c->scan; L.blk_index = (const uint32_t *)c->blk_index; L.blk_dc = (const int16_t *)c->blk_dc;
+    L.tables = (const uint8_t *)c->tables; L.out = (uint8_t *)c->out;
+    L.out_pitch = c->out_pitch; L.out_w = c->out_w; L.out_rows = c->out_rows;
+    L.mcus_x = c->mcus_x; L.mcus_y = c->mcus_y; L.n_mcus_ok = c->n_mcus_ok;
+    L.scan_len = c->scan_len;
+#pragma unroll
+    for (int i = 0; i < 4; i++) L.cfg[i] = c->cfg[i];
+    if (VARIANT >= 1) {
+        L.scale_shift = 0; L.pad_[0] = 0;
+        L.pixel_type = VARIANT == 1 ? JDA_RGB8888 : (VARIANT == 2 ? JDA_RGB565_LITTLE_ENDIAN : JDA_EIGHT_BIT_GRAYSCALE);
+        L.gray_from_color = (VARIANT == 3 && MODE != JDA_MODE_GRAY) ? 1 : 0;
+    }
+    return L;
+}
+__device__ __forceinline__ jda_desc_cptr jda_desc_at(const jda_dev_desc *descs, uint32_t image)
+{
+    return (jda_desc_cptr)(uintptr_t)(descs + image);
+}
+
 // a tile record (16 bytes, wave-uniform address) -> SGPRs
 __device__ __forceinline__ jda_strip jda_unpack_record(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
@@ -365,6 +395,128 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
     const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
     hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG>), dim3(grid), dim3(64 * L::WAVES), lds_bytes, stream,
                        descs, tiles, n_quads);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The DC thumbnail: 1/8 scale (every progressive file's DC scan included).  A pixel is its block's DC term -- the range-limited
+// (DC x q0) >> 5 of jpeg.inl:5146-5154 -- so with index format 2 (the pre-scan stored every block's own DC value) nothing but
+// 2 bytes per block is read: no scan, no index entry, no tables in LDS, no IDCT.  A wavefront takes JDA_THUMB_TILES consecutive
+// tiles of the list (a tile = the decode kernel's: <= 64 consecutive blocks of one MCU row; crop-aware lists stay what they are),
+// lane = block for the load, lane = output pixel for the store; the samples of a pixel's MCU come from their lanes by ds_bpermute.
+// Output as JPEGPutMCU* at bThumbnail: (MCU_W / 8) x (MCU_H / 8) pixels per MCU, chroma shared by the MCU.
+#define JDA_THUMB_TILES 8u
+// what a tile's lanes load: the DC value of lane's block (0 behind the tile's decoded blocks); count: the tile's MCUs that are decoded
+template <int MODE>
+__device__ __forceinline__ int32_t jda_thumb_load(const jda_dev_desc &D, const jda_strip &S, uint32_t lane, uint32_t &count)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t first_mcu = S.mcu_y * D.mcus_x + S.mcu_x0;
+    count = S.count;
+    if (first_mcu >= D.n_mcus_ok) count = 0;                             // MCUs behind a bad one are not decoded (jpeg.inl:5354-5356)
+    else if (first_mcu + count > D.n_mcus_ok) count = D.n_mcus_ok - first_mcu;
+    int32_t dc = 0;
+    if (lane < count * (uint32_t)T::NBLK) dc = JDA_G(const int16_t, D.blk_dc)[first_mcu * (uint32_t)T::NBLK + lane];
+    return dc;
+}
+// .. and what they store: lane = pixel p of the tile's (count * mw) x mh pixels, row-major
+template <int MODE>
+__device__ __forceinline__ void jda_thumb_store(const jda_dev_desc &D, const jda_strip &S, uint32_t lane, uint32_t count, int32_t dc, int32_t q0)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t mw = (uint32_t)T::MCU_W >> 3, mh = (uint32_t)T::MCU_H >> 3;      // an MCU's pixels: 1 x 1, 2 x 2, 2 x 1, 1 x 2
+    const uint32_t sample = jda_range_limit5(dc * q0);                   // the block's 64 samples, all this one (:5146-5154)
+    const uint32_t tile_w = count * mw;
+    const uint32_t row = (mh == 2u && lane >= tile_w) ? 1u : 0u, x = lane - row * tile_w;
+    const uint32_t m = mw == 2u ? x >> 1 : x, px = mw == 2u ? x & 1u : 0u;
+    // which luma block of the MCU (jda_fetch at shift 3: 4:2:0 (py, px) -> 2 py + px; 4:2:2 px; 4:4:0 py)
+    const uint32_t q = MODE == JDA_MODE_420 ? 2u * row + px : (MODE == JDA_MODE_422 ? px : (MODE == JDA_MODE_440 ? row : 0u));
+    const uint32_t yl = m * (uint32_t)T::NBLK + q;
+    const uint32_t y = MODE == JDA_MODE_GRAY ? sample : (uint32_t)__builtin_amdgcn_ds_bpermute((int)(yl << 2), (int)sample);
+    uint32_t cb = 128u, cr = 128u;
+    if (MODE != JDA_MODE_GRAY) {
+        cb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((m * (uint32_t)T::NBLK + (uint32_t)T::NLUMA) << 2), (int)sample);
+        cr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((m * (uint32_t)T::NBLK + (uint32_t)T::NLUMA + 1u) << 2), (int)sample);
+    }
+    const uint32_t X = S.mcu_x0 * mw + x, Y = S.mcu_y * mh + row;
+    if (lane >= tile_w * mh || X >= D.out_w || Y >= D.out_rows) return;
+    uint8_t JDA_GLOBAL *rowp = JDA_G(uint8_t, D.out) + (size_t)Y * D.out_pitch;
+    const int pt = D.pixel_type;
+    if (pt == JDA_EIGHT_BIT_GRAYSCALE) rowp[X] = (uint8_t)y;
+    else if (MODE == JDA_MODE_GRAY) ((uint16_t JDA_GLOBAL *)rowp)[X] = (uint16_t)jda_gray_565(y, pt != JDA_RGB565_LITTLE_ENDIAN);      // JPEGPutMCUGray
+    else {
+        jda_ycc p;
+        p.y = (int32_t)(y << 12); p.cb = (int32_t)cb; p.cr = (int32_t)cr;
+        if (pt == JDA_RGB8888) ((jda_u32_alias JDA_GLOBAL *)rowp)[X] = jda_pixel_rgba(p);
+        else ((uint16_t JDA_GLOBAL *)rowp)[X] = (uint16_t)jda_pixel_565(p, pt == JDA_RGB565_BIG_ENDIAN);
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256)
+void jda_dc_thumbnail(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_tiles)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t t0 = jda_uni32((blockIdx.x * 4u + (threadIdx.x >> 6)) * JDA_THUMB_TILES);
+    if (t0 >= n_tiles) return;
+    const uint32_t n_here = n_tiles - t0 < JDA_THUMB_TILES ? n_tiles - t0 : JDA_THUMB_TILES;
+    // the run's records through the scalar cache (uniform addresses): 16 bytes each
+    const uint32_t __attribute__((address_space(4))) *rw = (const uint32_t __attribute__((address_space(4))) *)(uintptr_t)(tiles + t0);
+    jda_strip S[JDA_THUMB_TILES];
+    uint32_t w0[JDA_THUMB_TILES], w1[JDA_THUMB_TILES], w2[JDA_THUMB_TILES];
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_THUMB_TILES; k++) {                      // (behind the list's end: the last record again -- every load asked for before the first wait)
+        const uint32_t kk = k < n_here ? k : n_here - 1u;
+        w0[k] = rw[4u * kk]; w1[k] = rw[4u * kk + 1u]; w2[k] = rw[4u * kk + 2u];
+    }
+    bool one_image = true;
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_THUMB_TILES; k++) {
+        S[k].image = w0[k]; S[k].mcu_y = (uint16_t)(w1[k] & 0xffffu); S[k].mcu_x0 = (uint16_t)(w1[k] >> 16);
+        S[k].count = k < n_here ? (uint8_t)(w2[k] & 0xffu) : (uint8_t)0; S[k].first = 0; S[k].pad_ = 0; S[k].ord = 0;
+        one_image = one_image && w0[k] == w0[0];
+    }
+    const uint32_t b_in_mcu = lane % (uint32_t)T::NBLK, comp = b_in_mcu < (uint32_t)T::NLUMA ? 0u : b_in_mcu - (uint32_t)T::NLUMA + 1u;
+    uint32_t cur_image = S[0].image;
+    jda_dev_desc D = jda_desc_const<0, MODE>(jda_desc_at(descs, cur_image));
+    // the lane's quantiser's first entry: one of three scalar loads
+#define JDA_THUMB_Q0(D_) do {                                                                                                                  \
+        const uint32_t __attribute__((address_space(4))) *qt_ = (const uint32_t __attribute__((address_space(4))) *)(uintptr_t)((D_).tables + JDA_TB_QUANT); \
+        const int32_t qa_ = (int16_t)qt_[(D_).q_id[0] * 32u], qb_ = (int16_t)qt_[(D_).q_id[1] * 32u], qc_ = (int16_t)qt_[(D_).q_id[2] * 32u];            \
+        q0 = comp == 0u ? qa_ : (comp == 1u ? qb_ : qc_);                                                                                      \
+    } while (0)
+    int32_t q0;
+    JDA_THUMB_Q0(D);
+    if (one_image) {
+        // the run is one image's (all but the runs across an image boundary of the list): every tile's load is asked for before the first is used
+        int32_t dcv[JDA_THUMB_TILES];
+        uint32_t cnt[JDA_THUMB_TILES];
+#pragma unroll
+        for (uint32_t k = 0; k < JDA_THUMB_TILES; k++) dcv[k] = jda_thumb_load<MODE>(D, S[k], lane, cnt[k]);
+#pragma unroll
+        for (uint32_t k = 0; k < JDA_THUMB_TILES; k++)
+            if (cnt[k]) jda_thumb_store<MODE>(D, S[k], lane, cnt[k], dcv[k], q0);
+        return;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_THUMB_TILES; k++) {
+        if (S[k].count == 0) continue;                                   // (padding entry, or behind the list's end)
+        if (S[k].image != cur_image) {
+            cur_image = S[k].image;
+            D = jda_desc_const<0, MODE>(jda_desc_at(descs, cur_image));
+            JDA_THUMB_Q0(D);
+        }
+        uint32_t count;
+        const int32_t dc = jda_thumb_load<MODE>(D, S[k], lane, count);
+        if (count) jda_thumb_store<MODE>(D, S[k], lane, count, dc, q0);
+    }
+#undef JDA_THUMB_Q0
+}
+template <int MODE>
+static hipError_t launch_dc_thumbnail(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
+{
+    const uint32_t per_wg = 4u * JDA_THUMB_TILES;
+    hipLaunchKernelGGL((jda_dc_thumbnail<MODE>), dim3((n_tiles + per_wg - 1u) / per_wg), dim3(256), 0, stream, descs, tiles, n_tiles);
     return hipGetLastError();
 }
 
@@ -1054,6 +1206,16 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int
                                         uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
+    if (!fast_mul && variant == 3) {                  // JDA_LIST_THUMB: 1/8 scale, the DC values are the pixels
+        switch (mode) {
+        case JDA_MODE_GRAY: return launch_dc_thumbnail<JDA_MODE_GRAY>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_444: return launch_dc_thumbnail<JDA_MODE_444>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_420: return launch_dc_thumbnail<JDA_MODE_420>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_422: return launch_dc_thumbnail<JDA_MODE_422>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_440: return launch_dc_thumbnail<JDA_MODE_440>(descs, tiles, n_tiles, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (big) {                                        // the large-window kernels for high-bitrate images (jda_big_window in jda_runtime.cpp decides who gets here)
         switch (mode * 4 + variant) {
         case JDA_MODE_GRAY * 4 + 0: return launch_persistent<JDA_MODE_GRAY, true, 0, 1>(descs, tiles, n_tiles, stream);

@@ -341,7 +341,6 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     uint32_t list_tiles[JDA_N_LISTS], list_ord[JDA_N_LISTS];
     memset(list_tiles, 0, sizeof(list_tiles)); memset(list_ord, 0, sizeof(list_ord));
     size_t arena = 0;
-    int n_rec = 0;
     auto take = [&](size_t bytes) { const size_t o = arena; arena += a256(bytes); return o; };
     // regions: [control blob][raw][dc][work][ ZERO: scan | index | zero ][stats]; laid out by region so that one memset and
     // one read-back cover all images
@@ -364,8 +363,8 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         const int variant = jda_plain_variant(D);
         // (window size: the filtered length is not known yet; the unfiltered one is at most a few percent larger)
         D.scan_len = im.f.raw_len;
-        const int big = jda_big_window(D, variant);
-        im.list = (uint32_t)(((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big);
+        const int big = D.scale_shift == 3 ? 0 : jda_big_window(D, variant);
+        im.list = (uint32_t)jda_list_index(D, variant, big);
         im.n_tiles = count_tiles(D.mcus_x, D.mcus_y, D.mode, big);
         im.strip_off = list_tiles[im.list]; list_tiles[im.list] += im.n_tiles;
         im.ord = list_ord[im.list]++;
@@ -399,7 +398,6 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
             im.off_cands = im.off_recs + a16((size_t)im.n_segs_ub * im.f.rec_cap * 4);
             im.cand_cap = std::max<uint32_t>(1024u, im.n_segs_ub * 16u);      // (a high-quality photograph: five candidates per segment, most of them of walks that were redone)
             im.work_bytes = im.off_cands + (size_t)im.cand_cap * 16;
-            n_rec++;
         }
         im.off_work = take(im.work_bytes);
     }

@@ -67,7 +67,7 @@ inline int jda_fill_desc(jda_dev_desc &D, const jda_image *img, int pixel_type, 
     return JDA_SUCCESS;
 }
 
-// Tiles of one image: each MCU row is cut into runs of <= 64 blocks (10 MCUs of 4:2:0, 21 of 4:4:4,
+// Tiles of one image: each MCU row is cut into runs of <= 64 blocks (10 MCUs of 4:2:0, 20 of 4:4:4, 16 of 4:2:2 / 4:4:0,
 // 64 of gray); one wavefront decodes one tile, and a workgroup is as many wavefronts as fit in a CU's LDS
 // next to one copy of the tables (16 for 4:2:0, 15 otherwise).  The list is padded with empty tiles per
 // image so that a workgroup never spans two images (it stages one table set).

@@ -625,9 +625,9 @@ jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *
         // kernel variant 1: the plain case -- full size, RGB8888, every block decoded -- runs a kernel in which these
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
-        const int big = jda_big_window(D, variant, im->tiles_total, im->tiles_over_small);
+        const int big = D.scale_shift == 3 ? 0 : jda_big_window(D, variant, im->tiles_total, im->tiles_over_small);
         {
-            std::vector<jda_strip> &lst = strips[((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big];
+            std::vector<jda_strip> &lst = strips[jda_list_index(D, variant, big)];
             const size_t before = lst.size();
             jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL);
             for (size_t k = before; k < lst.size(); k++) if (lst[k].count) st.tiles++;
@@ -852,7 +852,7 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
             const size_t part_bytes = std::min(row_bytes, (size_t)part * mw_out * bpp);
             if (e == hipSuccess && part_bytes && rp > rf)
                 e = hipMemcpy2DAsync((uint8_t *)host_pixels + (size_t)rf * pitch_bytes, (size_t)pitch_bytes, (uint8_t *)dout + (size_t)rf * dpitch, (size_t)dpitch, part_bytes, (size_t)(rp - rf), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            { const hipError_t es = hipStreamSynchronize(ctx->stream); if (e == hipSuccess) e = es; }
             if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
         } else if (rc == JDA_SUCCESS && r1 > r0 && band_ready && n_bands > 1) {
             // the copy back in bands of whole MCU rows, the caller told as each one lands: what it does with band k (the class replays its
@@ -877,7 +877,8 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
                 e = hipEventSynchronize(ctx->ev_band[k]);
                 if (e == hipSuccess) (*band_ready)(user, r0 + k * per, std::min(r1, r0 + (k + 1) * per));
             }
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            // (also after an error: copies queued before it may still be writing the caller's buffer, and the surface goes back to the pool)
+            { const hipError_t es = hipStreamSynchronize(ctx->stream); if (e == hipSuccess) e = es; }
             if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
         } else if (rc == JDA_SUCCESS && r1 > r0) {
             const size_t row_bytes = (size_t)cw * bpp < (size_t)pitch_bytes ? (size_t)cw * bpp : (size_t)pitch_bytes;

@@ -57,6 +57,15 @@ int jda_set_err(jda_ctx *ctx, hipError_t e, const char *what);
 hipError_t jda_pool_alloc(jda_ctx *ctx, void **out, size_t bytes);
 void jda_pool_free(jda_ctx *ctx, void *p);
 int jda_plain_variant(const jda_dev_desc &D);
+// which launch list an image's tiles go to: ((mode * 2 + fast) * 4 + variant) * 2 + big.  The combination fast = 0, variant = 3 (no
+// plain-case kernel exists without the 24-bit multiplies) names the DC thumbnail kernel: 1/8 scale -- also every progressive
+// file's DC scan at its default scale --, whose pixels are the blocks' DC values (jpeg.inl:5146-5154): no scan, no index, no IDCT
+#define JDA_LIST_THUMB(mode) ((((mode) * 2 + 0) * 4 + 3) * 2 + 0)
+inline int jda_list_index(const jda_dev_desc &D, int variant, int big)
+{
+    if (D.scale_shift == 3) return JDA_LIST_THUMB(D.mode);
+    return ((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big;
+}
 int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total = 0, uint32_t tiles_over_small = 0);
 // Fill the descriptor of one image of a launch plan (everything but the pointers into the image's HBM block, which the
 // caller sets) and validate the output surface.  Returns JDA_SUCCESS or the error jda_batch_create reports.

@@ -44,21 +44,37 @@ int main(int argc, char **argv)
     std::vector<JPEGDEC> pool(3, d);                // containers of decoders, as with the reference's struct
     CHECK(8, pool[2].getHeight() == h);
 
-    // ---- the C flavour: no initialisation, no close for RAM sources, slots recycled
-    enum { N = 200 };
+    // ---- the C flavour: no initialisation, no close for RAM sources, any number of handles (the state is the caller's struct)
+    enum { N = 2000 };
     static JPEGIMAGE imgs[N];
     memset(imgs, 0xA5, sizeof(imgs));               // stack-garbage look-alike: an open must cope
+    CHECK(9, JPEG_getWidth(&imgs[0]) == 0 && JPEG_getLastError(&imgs[0]) == JPEG_INVALID_PARAMETER);       // garbage is not a handle
     for (int i = 0; i < N; i++) {
         CHECK(10, JPEG_openRAM(&imgs[i], jpeg.data(), (int)len, draw) == 1);
         CHECK(11, JPEG_getWidth(&imgs[i]) == w);
     }
-    CHECK(12, JPEG_getWidth(&imgs[N - 1]) == w);                                     // the recent ones are live
-    CHECK(13, JPEG_getWidth(&imgs[0]) == 0 && JPEG_getLastError(&imgs[0]) == JPEG_INVALID_PARAMETER);   // the oldest slot was recycled: stale, not wrong
-    CHECK(14, JPEG_openRAM(&imgs[0], jpeg.data(), (int)len, draw) == 1 && JPEG_getWidth(&imgs[0]) == w);   // and can be opened again
-    for (int k = 0; k < 1000; k++) CHECK(15, JPEG_openRAM(&imgs[5], jpeg.data(), (int)len, draw) == 1);    // re-opening one handle reuses its slot
-    CHECK(16, JPEG_getWidth(&imgs[N - 1]) == w);
+    for (int i = 0; i < N; i++) CHECK(12, JPEG_getWidth(&imgs[i]) == w && JPEG_getHeight(&imgs[i]) == h);    // every one of them stays open (the reference: src/JPEGDEC.h:199-239 is the caller's memory)
+    JPEG_setPixelType(&imgs[7], RGB8888);
+    JPEG_setCropArea(&imgs[7], 16, 16, 64, 32);
+    int cx = 0, cy = 0, cw = 0, ch = 0;
+    JPEG_getCropArea(&imgs[7], &cx, &cy, &cw, &ch);
+    CHECK(13, cx == 16 && cy == 16 && cw > 0 && ch > 0);                              // what is set on a handle stays with it ..
+    JPEG_getCropArea(&imgs[8], &cx, &cy, &cw, &ch);
+    CHECK(14, cx == 0 && cy == 0 && cw == w && ch == h);                              // .. and with no other
+    for (int k = 0; k < 1000; k++) CHECK(15, JPEG_openRAM(&imgs[5], jpeg.data(), (int)len, draw) == 1);    // re-opening a handle
+    JPEGIMAGE copy = imgs[3];                                                         // a struct copy is not a handle
+    CHECK(16, JPEG_getWidth(&copy) == 0 && JPEG_getWidth(&imgs[3]) == w);
     JPEG_close(&imgs[N - 1]);
     CHECK(17, JPEG_getWidth(&imgs[N - 1]) == 0);
+    for (int k = 0; k < 50; k++) {                                                   // file sources: opened, re-opened without a close (the bytes are given back), closed
+        JPEGIMAGE fi;
+        memset(&fi, 0x5A, sizeof(fi));
+        CHECK(18, JPEG_openFile(&fi, argv[1], draw) == 1 && JPEG_getWidth(&fi) == w);
+        CHECK(19, JPEG_openFile(&fi, argv[1], draw) == 1 && JPEG_getHeight(&fi) == h);
+        JPEG_close(&fi);
+        CHECK(20, JPEG_getWidth(&fi) == 0);
+    }
+    CHECK(21, JPEG_openFile(&imgs[0], "/nonexistent/file.jpg", draw) == 0);
     printf("ok\n");
     return 0;
 }

@@ -110,7 +110,8 @@ def test_node_program_decodes_a_list_on_every_device(node_user, tmp_path, oracle
 def test_object_semantics_of_the_reference_boundary(tmp_path):
     """tests/capi_c/semantics_user.cpp: JPEGDEC objects are copied, assigned, moved and kept in containers like the reference's plain
     struct (src/JPEGDEC.h:286); a C JPEGIMAGE needs no initialisation and no JPEG_close for RAM sources (src/JPEGDEC.cpp:232-236) --
-    200 handles opened and never closed, the oldest slot recycled and its handle stale (an error, not a wrong image)."""
+    2,000 handles opened and never closed, every one of them live (the state is the caller's struct, as the reference's is: no table,
+    no limit); what is set on one stays with it; a struct copy is not a handle; file sources own their bytes until JPEG_close."""
     subprocess.run(["make", "semuser"], cwd=ROOT, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     r = subprocess.run([os.path.join(ROOT, "tests", "capi_c", "semantics_user"), _write(tmp_path, "c420_333x217")], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
