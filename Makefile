@@ -72,4 +72,9 @@ clean:
 	rm -f $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user tests/capi_c/node_user tests/capi_c/semantics_user
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim classshim classcpu cuser nodeuser semuser jpegtest frontfuzz clean
+.PHONY: all lib oracle hostsim classshim classcpu cuser nodeuser semuser jpegtest frontfuzz nodestub clean
+
+# jda_node.cpp (host code above the C-ABI) over eight pretend devices -- test infrastructure, no GPU (tests/test_c_api.py)
+nodestub: tests/node_stub/node_stub_user
+tests/node_stub/node_stub_user: tests/node_stub/node_stub_user.cpp tests/node_stub/stub_pipeline.cpp $(CSRC)/jda_node.cpp include/jpegdec_amd.h
+	$(CXX) -std=c++17 -O1 -g -fsanitize=thread -Wall -Iinclude -pthread -o $@ tests/node_stub/node_stub_user.cpp tests/node_stub/stub_pipeline.cpp $(CSRC)/jda_node.cpp

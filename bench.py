@@ -287,6 +287,8 @@ def parse_args(argv=None):
     ap.add_argument("--device-prescan", action="store_true", help="resident inputs: the block index is made on the GPU at upload (default: serial host pre-scan; the streamed pipeline always uses the device)")
     ap.add_argument("--e2e-batches", type=int, default=24, help="batches streamed through jda_pipeline for the end-to-end figure (0: skip)")
     ap.add_argument("--e2e-depth", type=int, default=4)
+    ap.add_argument("--no-e2e-sweep", action="store_true", help="end-to-end leg: skip the host-thread sweep, the pageable-input and the cold-input runs")
+    ap.add_argument("--e2e-cold-gb", type=float, default=2.0, help="end-to-end leg, cold input: GB of distinct page-locked buffers the batches cycle through")
     ap.add_argument("--e2e-distinct", type=int, default=16, help="distinct files a batch of the end-to-end leg cycles through (metric workload; the resident batch keeps --distinct)")
     ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,q98,photos)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -457,63 +459,97 @@ def run(args, J, out=sys.stdout):
         parity["device_checksum_equals_host_checksum"] = all(c.get("device_checksum_equals_host_checksum", False) for c in checks)
 
     # ---- end to end: the same files streamed from host memory through jda_pipeline (host parse + tables, H2D of the unfiltered
-    # scans, device filter + pre-scan + decode; batches overlapped on three streams), host work included, pixels stay in HBM
+    # scans, device filter + pre-scan + decode; batches overlapped on three streams), host work included, pixels stay in HBM.
+    # The input lies in page-locked memory (what a loader that feeds a GPU reads into) and is submitted with JDA_SUBMIT_PINNED_INPUT:
+    # the copy engine takes the files where they are, no host core copies them.  Besides the headline figure (this rank's threads,
+    # at most 8): the same with 1, 2, 4, 8 host threads -- an 8-GPU node leaves a rank a few cores --, with COLD input (>= 2 GB of
+    # distinct buffers: nothing the host or the copy engine reads is in a cache), and with pageable input (the pipeline's own
+    # page-locked mirror, filled by the workers).
     e2e = None
     if args.e2e_batches > 0:
         eb = min(n_mine, args.batch) if args.workload == "metric" else min(n_mine, 256)
         depth = max(1, min(args.e2e_depth, 4))
-        files = my_files[:eb]
         e2e_distinct = n_distinct
+        pool = jpegs
         if args.workload == "metric" and args.e2e_distinct > n_distinct:
             # more distinct files per batch than the resident leg keeps: the pre-scan's late rounds are longer (its chains of changed
             # entry states differ from file to file), which a batch of two files flatters
             e2e_distinct = min(args.e2e_distinct, eb)
             pool = [cached_jpeg(width, height, sub, 1234 + i, quality=args.quality, restart_rows=args.restart_rows) for i in range(e2e_distinct)]
-            files = [pool[(lo + i) % e2e_distinct] for i in range(eb)]
-        pipe = J.Pipeline(ctx, max_images=eb, depth=depth, host_threads=min(threads, 8))
+        picks = [(lo + i) % e2e_distinct for i in range(eb)]
         surf = [out_base] if eb * depth > n_mine else [out_base + k * eb * img_bytes for k in range(depth)]
         extra = [ctx.malloc(img_bytes * eb) for _ in range(depth - len(surf))]
         surf += extra
+        outs_of = [[(base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(eb)] for base in surf]
+        have_pinned = hasattr(J, "PinnedFiles")
+        hot = J.PinnedFiles(pool) if have_pinned else None
 
-        # (the submit's C arrays, one set per surface, built once: a C caller holds them anyway)
-        packed = [pipe.pack(files, [(base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(eb)], [pt] * eb, [args.options] * eb) for base in surf]
+        def e2e_run(host_threads, batches, source):
+            """source: "pinned" (hot: the same page-locked files every batch), "pageable" (Python bytes through the mirror),
+            or a PinnedFiles arena of many copies (cold)."""
+            pipe = J.Pipeline(ctx, max_images=eb, depth=depth, host_threads=host_threads)
+            if source == "pageable" or not have_pinned:
+                packed = [pipe.pack([pool[k] for k in picks], o, [pt] * eb, [args.options] * eb) for o in outs_of]
+                flags, n_sets = 0, len(packed)
+            elif source == "pinned":
+                packed = [pipe.pack_pinned(hot, picks, o, [pt] * eb, [args.options] * eb) for o in outs_of]
+                flags, n_sets = J.SUBMIT_PINNED_INPUT, len(packed)
+            else:                                   # cold: batch k reads copies the copy engine has not seen for len(source.addrs) / eb batches
+                n_sets = max(depth, len(source.addrs) // eb)
+                packed = [pipe.pack_pinned(source, [(k * eb + i) % len(source.addrs) for i in range(eb)], outs_of[k % depth], [pt] * eb, [args.options] * eb) for k in range(n_sets)]
+                flags = J.SUBMIT_PINNED_INPUT
+            submit = (lambda k: pipe.submit_packed(packed[k % n_sets], flags)) if have_pinned else (lambda k: pipe.submit_packed(packed[k % n_sets]))
+            inflight, t_submit, warm = [], 0.0, max(2, depth)
+            tb0, n_failed = 0.0, 0                # (failures are counted, the barriers completed, and the ranks fail together afterwards)
+            for k in range(warm + batches):
+                if k == warm:
+                    while inflight:
+                        pipe.wait(inflight.pop(0))
+                    barrier()
+                    tb0 = time.perf_counter()
+                if len(inflight) == depth:
+                    n_failed += sum(1 for s_ in pipe.wait(inflight.pop(0)) if s_ != 0)
+                ts = time.perf_counter()
+                inflight.append(submit(k))
+                if k >= warm:
+                    t_submit += time.perf_counter() - ts
+            while inflight:
+                n_failed += sum(1 for s_ in pipe.wait(inflight.pop(0)) if s_ != 0)
+            barrier()
+            dt = group.max(time.perf_counter() - tb0)
+            n_failed = int(group.sum(float(n_failed)))
+            if n_failed:
+                raise SystemExit("bench.py: %d image(s) of the end-to-end leg did not decode" % n_failed)
+            n_img = eb * batches
+            px_all = group.sum(float(geo["out_w"] * geo["out_h"] * n_img))
+            pst = pipe.stats
+            pipe.close()
+            return {"mpix_s": px_all / dt / 1e6, "ms_per_image": dt / n_img * 1e3, "host_submit_ms_per_image": t_submit / n_img * 1e3,
+                    "host_threads": host_threads, "batches": batches, "device_path_images": pst["device_images"], "host_path_images": pst["host_path_images"]}
 
-        def submit(k):
-            return pipe.submit_packed(packed[k % depth])
-
-        inflight, t_submit, warm = [], 0.0, max(2, depth)
-        tb0, n_failed = 0.0, 0                # (failures are counted, the barriers completed, and the ranks fail together afterwards)
-        for k in range(warm + args.e2e_batches):
-            if k == warm:
-                while inflight:
-                    pipe.wait(inflight.pop(0))
-                barrier()
-                tb0 = time.perf_counter()
-            if len(inflight) == depth:
-                n_failed += sum(1 for s in pipe.wait(inflight.pop(0)) if s != 0)
-            ts = time.perf_counter()
-            inflight.append(submit(k))
-            if k >= warm:
-                t_submit += time.perf_counter() - ts
-        while inflight:
-            n_failed += sum(1 for s in pipe.wait(inflight.pop(0)) if s != 0)
-        barrier()
-        dt = group.max(time.perf_counter() - tb0)
-        n_failed = int(group.sum(float(n_failed)))
-        if n_failed:
-            raise SystemExit("bench.py: %d image(s) of the end-to-end leg did not decode" % n_failed)
-        n_img = eb * args.e2e_batches
-        px_all = group.sum(float(geo["out_w"] * geo["out_h"] * n_img))
-        pst = pipe.stats
-        pipe.close()
+        main_threads = min(threads, 8)
+        e2e = e2e_run(main_threads, args.e2e_batches, "pinned")
+        e2e.update({"images_per_batch": eb, "depth": depth, "distinct_images": min(e2e_distinct, eb),
+                    "input": "page-locked, JDA_SUBMIT_PINNED_INPUT (files >= 128 KB: DMA from where they lie)" if have_pinned else "pageable",
+                    "what": "files in host memory -> pixels resident in HBM through jda_pipeline: host parse + tables, H2D of the unfiltered scans, "
+                            "device marker filter + per-block index + decode, batches overlapped; whole job, all ranks; the same files are submitted every batch"})
+        if have_pinned and rank == 0 and world == 1 and not args.no_e2e_sweep:
+            short = max(8, args.e2e_batches // 2)
+            e2e["host_thread_sweep"] = {str(t_): round(e2e_run(t_, short, "pinned")["mpix_s"]) for t_ in (1, 2, 4, 8)}
+            e2e["pageable_input"] = {str(t_): round(e2e_run(t_, short, "pageable")["mpix_s"]) for t_ in (2, 8)}
+            # cold input: >= 2 GB of distinct page-locked buffers (copies of the distinct files), each read once per ~2 GB of traffic
+            t_c = time.perf_counter()
+            n_copies = max(eb * depth, int(args.e2e_cold_gb * (1 << 30) / (sum(len(f) for f in pool) / len(pool))) + 1)
+            cold = J.PinnedFiles([pool[k % len(pool)] for k in range(n_copies)])
+            r = e2e_run(main_threads, max(short, 2 * n_copies // eb), cold)
+            e2e["cold_input"] = {"mpix_s": r["mpix_s"], "vs_hot": r["mpix_s"] / e2e["mpix_s"], "distinct_buffers": n_copies, "bytes": cold.bytes,
+                                 "batches": r["batches"], "setup_s": round(time.perf_counter() - t_c, 2),
+                                 "what": "every batch reads page-locked buffers nobody has touched for %d batches (%.1f GB in all)" % (n_copies // eb, cold.bytes / 2 ** 30)}
+            cold.close()
+        if hot:
+            hot.close()
         for p_ in extra:
             ctx.free(p_)
-        e2e = {"mpix_s": px_all / dt / 1e6, "ms_per_image": dt / n_img * 1e3, "host_submit_ms_per_image": t_submit / n_img * 1e3,
-               "batches": args.e2e_batches, "images_per_batch": eb, "depth": depth, "host_threads": min(threads, 8),
-               "distinct_images": min(e2e_distinct, eb),
-               "device_path_images": pst["device_images"], "host_path_images": pst["host_path_images"],
-               "what": "files in host memory -> pixels resident in HBM through jda_pipeline: host parse + tables, H2D of the unfiltered scans, "
-                       "device marker filter + per-block index + decode, batches overlapped; whole job, all ranks; the same files are submitted every batch (host-cache-hot input)"}
 
     configs = None
     if not args.no_configs and rank == 0 and world == 1 and args.workload == "metric":

@@ -188,6 +188,9 @@ void *jda_stream(jda_ctx *ctx);        /* the hipStream_t every launch of this c
  * asynchronously -- what lets jda_decode_to_host_bands overlap the copy with the caller's work.  NULL when it cannot be had. */
 void *jda_host_alloc(size_t bytes);
 void jda_host_free(void *p);
+/* page-lock memory the caller already has (a file cache, a receive buffer) for JDA_SUBMIT_PINNED_INPUT; undo before freeing it */
+int jda_host_register(void *p, size_t bytes);
+int jda_host_unregister(void *p);
 void *jda_malloc(jda_ctx *ctx, size_t bytes);
 void jda_free(jda_ctx *ctx, void *dptr);
 int jda_memset(jda_ctx *ctx, void *dptr, int value, size_t bytes);
@@ -273,6 +276,7 @@ int jda_sync(jda_ctx *ctx);
 int jda_checksum_surfaces(jda_ctx *ctx, int32_t n, const jda_output *surfaces, const int32_t *row_bytes, uint64_t *checksums);
 /* PCI bus id ("0000:8e:00.0") of the context's GPU, for NUMA placement of the host threads that feed it; buf >= 16 bytes */
 int jda_device_pci_bus_id(jda_ctx *ctx, char *buf, int32_t len);
+int jda_device_pci_bus_id_of(int32_t device, char *buf, int32_t len);      /* the same by device ordinal, without a context */
 
 /* HIP-event timing on the ctx stream: start/stop record events on that stream; elapsed blocks
  * until stop has happened and returns milliseconds (<0 on error). */
@@ -335,6 +339,13 @@ jda_pipeline *jda_pipeline_create(jda_ctx *ctx, int32_t max_images, int32_t dept
 void jda_pipeline_destroy(jda_pipeline *p);
 int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
                         const int32_t *pixel_types, const int32_t *options, int32_t *ticket);
+/* The same with flags.  JDA_SUBMIT_PINNED_INPUT: every jpegs[i] lies in page-locked host memory (jda_host_alloc, or any buffer
+ * made known with jda_host_register) -- the copy engine then reads the files' entropy-coded bytes where they are, and no host core
+ * copies them into the pipeline's own page-locked mirror first (the host's largest share of a batch; what lets a rank with two or
+ * three cores feed its GPU).  Files under 128 KB still go through the mirror: a copy command per file costs more than their copy. */
+#define JDA_SUBMIT_PINNED_INPUT 1
+int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
+                           const int32_t *pixel_types, const int32_t *options, int32_t flags, int32_t *ticket);
 int jda_pipeline_wait(jda_pipeline *p, int32_t ticket, int32_t *status);
 int jda_pipeline_get_stats(const jda_pipeline *p, jda_pipeline_stats *out);   /* totals over the batches waited for */
 /* diagnostics: after jda_pipeline_wait(ticket), before `depth` more batches are submitted -- the per-block index (n_blocks + 1
@@ -345,7 +356,10 @@ int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t
  * Images are independent (the reference zeroes its whole state per image, src/JPEGDEC.cpp:66): a node shards a LIST of files by
  * image.  jda_node owns one context + one streamed pipeline per device and deals a submitted list out in contiguous blocks --
  * device k of K takes images [first, first + count) of jda_node_shard (sizes differ by at most one: the rule the multi-process
- * bench uses) -- running the devices' host halves on a thread each.  Pixels never cross between GPUs: outputs[i].pixels must be a
+ * bench uses).  Every device has ONE PERSISTENT host thread, made with the node and pinned to the CPUs of its GPU's NUMA node
+ * (devices on one NUMA node share its CPUs; jda_node_placement tells): it creates the device's context and pipeline -- whose
+ * workers inherit the placement -- and runs the device's half of every submit / wait / checksum call, so the calling thread makes
+ * no HIP call and keeps its current device.  Pixels never cross between GPUs: outputs[i].pixels must be a
  * DEVICE pointer on the device that owns image i (allocate with jda_malloc(jda_node_context(node, k), ..)).  What comes back
  * is status[i] per image and, for a proof that every image was decoded once and identically wherever it landed, per-image
  * checksums made where the pixels are (jda_node_checksums = jda_checksum_surfaces per device).
@@ -365,7 +379,11 @@ void jda_node_shard(const jda_node *node, int32_t n, int32_t k, int32_t *first, 
 void jda_node_shard_of(int32_t n_devices, int32_t n, int32_t k, int32_t *first, int32_t *count);     /* the same rule without a node */
 int jda_node_submit(jda_node *node, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
                     const int32_t *pixel_types, const int32_t *options, int32_t *ticket);
+int jda_node_submit_ex(jda_node *node, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
+                       const int32_t *pixel_types, const int32_t *options, int32_t flags, int32_t *ticket);      /* flags: JDA_SUBMIT_* */
 int jda_node_wait(jda_node *node, int32_t ticket, int32_t *status);
+/* where device k's host thread runs: its GPU's NUMA node (-1: unknown) and how many CPUs it is pinned to (0: not pinned) */
+int jda_node_placement(const jda_node *node, int32_t k, int32_t *numa_node, int32_t *cpus_pinned);
 int jda_node_checksums(jda_node *node, int32_t n, const jda_output *surfaces, const int32_t *row_bytes, uint64_t *checksums);
 int jda_node_get_stats(const jda_node *node, jda_pipeline_stats *out);   /* sums over the devices' pipelines */
 

@@ -20,6 +20,8 @@ from .binding import (  # noqa: F401
     DeviceImage,
     JdaError,
     Pipeline,
+    PinnedFiles,
+    SUBMIT_PINNED_INPUT,
     PreparedImage,
     crop_round,
     decode_to_host,

@@ -107,6 +107,8 @@ _PROTOTYPES = [
     ("jda_decode_to_host_ex", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_pipeline_create", _P, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_pipeline_destroy", None, [_P]),
+    ("jda_pipeline_submit_ex", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(Output), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_pipeline_submit", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(Output), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("jda_pipeline_wait", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
@@ -121,6 +123,8 @@ _PROTOTYPES = [
     ("jda_batch_create_rect", _P, [_P, C.c_int32, C.POINTER(_P), C.POINTER(Output), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("jda_version", C.c_char_p, []),
+    ("jda_host_alloc", _P, [C.c_size_t]),
+    ("jda_host_free", None, [_P]),
 ]
 
 
@@ -453,10 +457,22 @@ class Pipeline:
         opts = (C.c_int32 * n)(*options)
         return (jpegs, arr, lens, outs, pts, opts, n)
 
-    def submit_packed(self, packed) -> int:
-        jpegs, arr, lens, outs, pts, opts, n = packed
+    @staticmethod
+    def pack_pinned(pinned, picks, outputs, pixel_types, options):
+        """The same for files that lie in page-locked memory (PinnedFiles): picks = indices into it.  Submitted with
+        JDA_SUBMIT_PINNED_INPUT, the copy engine reads them where they are."""
+        n = len(picks)
+        arr = (C.c_void_p * n)(*[pinned.addrs[k] for k in picks])
+        lens = (C.c_int32 * n)(*[pinned.lens[k] for k in picks])
+        outs = (Output * n)(*[Output(*o) for o in outputs])
+        pts = (C.c_int32 * n)(*pixel_types)
+        opts = (C.c_int32 * n)(*options)
+        return (pinned, C.cast(arr, C.POINTER(C.c_char_p)), lens, outs, pts, opts, n, arr)
+
+    def submit_packed(self, packed, flags: int = 0) -> int:
+        arr, lens, outs, pts, opts, n = packed[1:7]
         t = C.c_int32(-1)
-        self.ctx.check(self.ctx.lib.jda_pipeline_submit(self.handle, n, arr, lens, outs, pts, opts, C.byref(t)), "jda_pipeline_submit")
+        self.ctx.check(self.ctx.lib.jda_pipeline_submit_ex(self.handle, n, arr, lens, outs, pts, opts, flags, C.byref(t)), "jda_pipeline_submit_ex")
         self._keep[t.value] = packed                                      # the buffers stay alive until the batch is waited for
         return t.value
 
@@ -466,7 +482,7 @@ class Pipeline:
 
     def wait(self, ticket: int):
         """Blocks until the batch is decoded; returns the list of per-image status codes."""
-        n = self._keep[ticket][-1]
+        n = self._keep[ticket][6]
         st = (C.c_int32 * n)()
         self.ctx.check(self.ctx.lib.jda_pipeline_wait(self.handle, ticket, st), "jda_pipeline_wait")
         del self._keep[ticket]
@@ -491,6 +507,34 @@ class Pipeline:
         if self.handle:
             self.ctx.lib.jda_pipeline_destroy(self.handle)
             self.handle = None
+
+
+class PinnedFiles:
+    """Files copied once into ONE page-locked arena (jda_host_alloc), each at a 4 KB boundary: what a loader that reads into
+    page-locked memory hands to jda_pipeline_submit_ex(.., JDA_SUBMIT_PINNED_INPUT, ..)."""
+
+    def __init__(self, files):
+        self.lib = load_library()
+        self.lens = [len(f) for f in files]
+        offs, total = [], 0
+        for ln in self.lens:
+            offs.append(total)
+            total += (ln + 4095) & ~4095
+        self.bytes = total
+        self.base = self.lib.jda_host_alloc(max(total, 4096))
+        if not self.base:
+            raise JdaError(5, "jda_host_alloc(%d)" % total)
+        self.addrs = [self.base + o for o in offs]
+        for a, f in zip(self.addrs, files):
+            C.memmove(a, f, len(f))
+
+    def close(self):
+        if self.base:
+            self.lib.jda_host_free(self.base)
+            self.base = None
+
+
+SUBMIT_PINNED_INPUT = 1
 
 
 def surface_checksum_host(canvas: np.ndarray) -> int:

@@ -152,6 +152,7 @@ struct Img {
     uint32_t n_segs_ub, n_blocks;
     size_t off_raw, off_scan, scan_bytes, off_index, off_dc, off_work, off_zero, off_stats;   // arena offsets
     size_t work_bytes, zero_bytes, off_rpos, off_fwork, off_wt;     // off_rpos / off_fwork: restart positions / the filter's work words inside the work region
+    bool direct;                 // its bytes go to the GPU from where the caller has them (JDA_SUBMIT_PINNED_INPUT): no copy into the mirror
     bool record;                 // the pre-scan runs in RECORD mode (no WRITE walk)
     size_t off_recs, off_cands;  // block records / truncation candidates inside the work region
     uint32_t cand_cap;
@@ -295,6 +296,18 @@ static jda_submit_clock g_submit_clock;
 int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
                         const int32_t *pixel_types, const int32_t *options, int32_t *ticket)
 {
+    return jda_pipeline_submit_ex(p, n, jpegs, lens, outputs, pixel_types, options, 0, ticket);
+}
+
+// Files below this size still go through the page-locked mirror when the input is page-locked already: a copy command per file costs
+// the submitting thread a few microseconds, which for a 100 KB file is more than the workers' copy of it
+#ifndef JDA_PIPE_DIRECT_MIN_BYTES
+#define JDA_PIPE_DIRECT_MIN_BYTES (128u << 10)
+#endif
+
+int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
+                           const int32_t *pixel_types, const int32_t *options, int32_t flags, int32_t *ticket)
+{
     if (!p) return JDA_ERROR_NO_DEVICE;
     g_submit_clock.start();
     if (n <= 0 || n > p->max_images || !jpegs || !lens || !outputs || !ticket) return JDA_INVALID_PARAMETER;
@@ -375,8 +388,14 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     (void)strips_base;
     S.ctl_bytes = a256(ctl);
     arena = S.ctl_bytes;
-    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_raw = take(a16(im.f.raw_len) + 16); }
-    const size_t raw_end = arena;                             // [0, raw_end) = control blob + unfiltered scans: one H2D copy from the page-locked mirror
+    // the unfiltered scans: first the ones that travel through the mirror, then -- input that is page-locked where it lies
+    // (JDA_SUBMIT_PINNED_INPUT) -- the ones the copy engine reads from the caller's buffers: no host core touches those bytes
+    static const uint32_t direct_min = []() { const char *e = JDA_LAB_ENV("JDA_PIPE_DIRECT_MIN"); return e ? (uint32_t)atoi(e) : (uint32_t)JDA_PIPE_DIRECT_MIN_BYTES; }();
+    int n_direct = 0;
+    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; im.direct = im.device && (flags & JDA_SUBMIT_PINNED_INPUT) && im.f.raw_len >= direct_min; n_direct += im.direct ? 1 : 0; }
+    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device && !im.direct) im.off_raw = take(a16(im.f.raw_len) + 16); }
+    const size_t raw_end = arena;                             // [0, raw_end) = control blob + the mirrored scans: one H2D copy from the page-locked mirror
+    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.direct) im.off_raw = take(a16(im.f.raw_len) + 16); }
     for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_dc = take((size_t)im.n_blocks * 2); }
     for (int i = 0; i < n; i++) {
         Img &im = S.imgs[(size_t)i];
@@ -505,7 +524,7 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
         fill_strips((jda_strip *)(S.pin + S.list_off[im.list]) + im.strip_off, im.n_tiles, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, im.ord);
         // the file's entropy-coded bytes into the page-locked mirror (the workers' memcpy is the only time the host touches them):
         // the whole batch then travels as ONE asynchronous copy instead of a blocking pageable copy per file
-        copy_to_mirror(S.pin + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len);
+        if (!im.direct) copy_to_mirror(S.pin + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len);
     });
 
     g_submit_clock.lap(5);
@@ -516,8 +535,14 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
     uint8_t *B = S.dev;
     if (n_dev) {
         e = hipMemsetAsync(B + zero_begin, 0, zero_end - zero_begin, p->s_copy);
-        if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, raw_end, hipMemcpyHostToDevice, p->s_copy);      // control blob + every file's scan
+        if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, raw_end, hipMemcpyHostToDevice, p->s_copy);      // control blob + every mirrored scan
         S.st.h2d_bytes += (int64_t)raw_end;
+        for (int i = 0; i < n && n_direct && e == hipSuccess; i++) {                                      // .. and the others from where they lie
+            const Img &im = S.imgs[(size_t)i];
+            if (!im.direct) continue;
+            e = hipMemcpyAsync(B + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len, hipMemcpyHostToDevice, p->s_copy);
+            S.st.h2d_bytes += (int64_t)im.f.raw_len;
+        }
         // The copy stream carries the memset and the copy ONLY: with the filter behind the copy on the same stream, the next batch's
         // 110 MB (2 ms at 55 GB/s) could not start before this batch's filter had run -- and the filter's workgroups wait for the decode
         // kernel of the batch in front to give the CUs' LDS back: the copy stream was the pipeline's period (3.35 ms per batch of 64 x

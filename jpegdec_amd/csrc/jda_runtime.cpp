@@ -152,9 +152,11 @@ void *jda_stream(jda_ctx *ctx) { return ctx ? (void *)ctx->stream : NULL; }
 void *jda_host_alloc(size_t bytes)
 {
     void *p = NULL;
-    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : NULL;
+    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) == hipSuccess ? p : NULL;      // (every GPU of the node may read it: jda_node)
 }
 void jda_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int jda_host_register(void *p, size_t bytes) { return (p && bytes && hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess) ? JDA_SUCCESS : JDA_ERROR_HIP; }
+int jda_host_unregister(void *p) { return (p && hipHostUnregister(p) == hipSuccess) ? JDA_SUCCESS : JDA_ERROR_HIP; }
 
 void *jda_malloc(jda_ctx *ctx, size_t bytes)
 {
@@ -727,6 +729,11 @@ int jda_checksum_surfaces(jda_ctx *ctx, int32_t n, const jda_output *surfaces, c
 }
 
 // "0000:8e:00.0" of the context's GPU (for NUMA placement of the host threads that feed it); buf >= 16 bytes
+int jda_device_pci_bus_id_of(int32_t device, char *buf, int32_t len)
+{
+    if (!buf || len < 16) return JDA_INVALID_PARAMETER;
+    return hipDeviceGetPCIBusId(buf, len, device) == hipSuccess ? JDA_SUCCESS : JDA_ERROR_HIP;
+}
 int jda_device_pci_bus_id(jda_ctx *ctx, char *buf, int32_t len)
 {
     if (!ctx) return JDA_ERROR_NO_DEVICE;

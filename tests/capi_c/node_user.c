@@ -56,6 +56,21 @@ int main(int argc, char **argv)
     if (rc == JDA_SUCCESS) rc = jda_node_checksums(node, n, outs, rowb, sums);
     int ok = 0, same = 1;
     for (int32_t i = 0; i < n; i++) { ok += status[i] == JDA_SUCCESS; same &= sums[i] == sums[0]; }
+    /* the same list again from PAGE-LOCKED input (jda_host_alloc + JDA_SUBMIT_PINNED_INPUT: the copy engines read the file where it
+     * lies, one file larger than the direct-copy threshold by repetition is not needed -- small files still take the mirror): the
+     * same pixels must come out */
+    if (rc == JDA_SUCCESS) {
+        const uint64_t first_sum = sums[0];
+        uint8_t *pinned = (uint8_t *)jda_host_alloc((size_t)len);
+        if (!pinned) return JDA_ERROR_MEMORY;
+        memcpy(pinned, jpeg, (size_t)len);
+        for (int32_t i = 0; i < n; i++) { jpegs[i] = pinned; status[i] = -1; sums[i] = 0; }
+        rc = jda_node_submit_ex(node, n, jpegs, lens, outs, pts, opts, JDA_SUBMIT_PINNED_INPUT, &ticket);
+        if (rc == JDA_SUCCESS) rc = jda_node_wait(node, ticket, status);
+        if (rc == JDA_SUCCESS) rc = jda_node_checksums(node, n, outs, rowb, sums);
+        for (int32_t i = 0; i < n; i++) { same &= status[i] == JDA_SUCCESS && sums[i] == first_sum; }
+        jda_host_free(pinned);
+    }
     printf("devices %d images %d ok %d checksum %016llx same %d\n", nd, n, ok, (unsigned long long)sums[0], same);
     for (int32_t k = 0; k < nd; k++) if (blocks[k]) jda_free(jda_node_context(node, k), blocks[k]);
     jda_node_destroy(node);

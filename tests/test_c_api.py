@@ -115,3 +115,13 @@ def test_object_semantics_of_the_reference_boundary(tmp_path):
     subprocess.run(["make", "semuser"], cwd=ROOT, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     r = subprocess.run([os.path.join(ROOT, "tests", "capi_c", "semantics_user"), _write(tmp_path, "c420_333x217")], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_node_over_eight_stub_devices():
+    """tests/node_stub: jda_node.cpp (host code above the C-ABI only) linked against a stand-in for the device half with EIGHT pretend
+    devices, built with ThreadSanitizer: the contiguous shard rule, ONE PERSISTENT host thread per device that makes every call of that
+    device (none comes from the caller's thread: its current HIP device is never touched), statuses in list order, the submit flags
+    handed through, depth, a device that refuses its block, a short list, a subset of devices.  No GPU needed."""
+    subprocess.run(["make", "nodestub"], cwd=ROOT, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run([os.path.join(ROOT, "tests", "node_stub", "node_stub_user")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

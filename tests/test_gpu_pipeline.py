@@ -396,3 +396,39 @@ def test_pipeline_random_shapes_qualities_and_restart_intervals(gpu_ctx, oracle)
             gpu_ctx.free(o[0])
     assert indexed >= 60
     pipe.close()
+
+
+def test_pipeline_page_locked_input_is_read_where_it_lies(gpu_ctx, oracle):
+    """JDA_SUBMIT_PINNED_INPUT: the files lie in page-locked memory (J.PinnedFiles = jda_host_alloc) and the copy engine takes the
+    large ones (>= 128 KB of scan) from there, the small ones still go through the mirror -- a batch that mixes both, a damaged large
+    file (its redo through the serial path reads the caller's buffer again) and the reference's fixtures: pixels, statuses and h2d
+    byte counts as with pageable input."""
+    rng = np.random.default_rng(5)
+    from jpegdec_amd.synth import synth_jpeg
+    big = [synth_jpeg(1600, 1200, "4:2:0", seed=70 + k, quality=92) for k in range(3)]      # ~ 400-500 KB each: direct
+    assert all(len(b) > (160 << 10) for b in big)
+    bad = bytearray(big[0])
+    at = len(bad) // 2
+    bad[at:at + 64] = bytes(rng.integers(0, 255, 64, dtype=np.uint8))
+    small = [jpeg_for(n) for n in sorted(SYNTH_CASES)[:8]] + [ref_jpeg(n) for n in ("tulips", "zebra")]
+    files = [big[0], small[0], big[1], bytes(bad)] + small[1:] + [big[2]]
+    names = ["big0", "s0", "big1", "bad"] + ["s%d" % i for i in range(1, len(small))] + ["big2"]
+    pts = [J.RGB8888 if not (J.parse(f)["subsample"] == 0) else J.GRAY8 for f in files]
+    opts = [0] * len(files)
+    pinned = J.PinnedFiles(files)
+    pipe = J.Pipeline(gpu_ctx, max_images=len(files), depth=2, host_threads=2)
+    results = []
+    for mode in ("pageable", "pinned", "pinned"):
+        outs, metas = _surfaces(gpu_ctx, files, pts, opts)
+        if mode == "pageable":
+            t = pipe.submit(files, outs, pts, opts)
+        else:
+            t = pipe.submit_packed(pipe.pack_pinned(pinned, list(range(len(files))), outs, pts, opts), J.SUBMIT_PINNED_INPUT)
+        st = pipe.wait(t)
+        _check(gpu_ctx, oracle, files, pts, opts, outs, metas, st, names)
+        results.append(st)
+        for o in outs:
+            gpu_ctx.free(o[0])
+    assert results[0] == results[1] == results[2]
+    pipe.close()
+    pinned.close()
