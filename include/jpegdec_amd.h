@@ -342,7 +342,9 @@ int jda_pipeline_submit(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs,
 /* The same with flags.  JDA_SUBMIT_PINNED_INPUT: every jpegs[i] lies in page-locked host memory (jda_host_alloc, or any buffer
  * made known with jda_host_register) -- the copy engine then reads the files' entropy-coded bytes where they are, and no host core
  * copies them into the pipeline's own page-locked mirror first (the host's largest share of a batch; what lets a rank with two or
- * three cores feed its GPU).  Files under 128 KB still go through the mirror: a copy command per file costs more than their copy. */
+ * three cores feed its GPU).  Files that lie next to one another in memory (gaps up to 64 KB: a loader's arena, a ring of receive
+ * buffers) travel as one copy command; a command that would carry less than 128 KB is not worth what it costs the submitting
+ * thread, so isolated small files still go through the mirror. */
 #define JDA_SUBMIT_PINNED_INPUT 1
 int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpegs, const int32_t *lens, const jda_output *outputs,
                            const int32_t *pixel_types, const int32_t *options, int32_t flags, int32_t *ticket);

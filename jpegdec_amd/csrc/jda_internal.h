@@ -122,11 +122,22 @@ struct jda_filter_params {
     uint8_t *out;                // filtered scan (zero-initialised by the caller: the padding behind it stays zero)
     uint32_t *restart_pos;       // [0] = 0, then the filtered offset at which each RSTn marker stood (first restart_cap entries)
     uint32_t *result;            // [0] filtered length, [1] number of RSTn markers
-    uint32_t raw_len, restart_cap;
+    uint32_t raw_len, restart_cap;   // raw_len: bytes from `raw` on, the skipped ones included
     uint32_t *work;              // JDA_FILTER_WORK_BYTES(raw_len): the chunks' transition functions and entry values
+    uint32_t raw_skip;           // 0..15 bytes at `raw` that are not the stream's: `raw` is 16-byte aligned, a file that the copy engine took from where the
+    uint32_t pad_;               // caller had it (JDA_SUBMIT_PINNED_INPUT) keeps its alignment -- its first byte is raw[raw_skip]
 };
 #define JDA_FILTER_WORK_BYTES(raw_len) (((size_t)(raw_len) / 16384u + 1u) * 20u)
 
+
+// The tile list of a whole image, made where it is used (jda_pipeline: the lists of a batch of 64 x 4096x4096 are 6.8 MB -- written by
+// the host and carried over the bus they were 6 % of a batch's traffic): one of these per image, the kernel writes the records
+struct jda_strips_params {
+    jda_strip *dst;              // the image's place in its launch list (n_padded records)
+    uint32_t n_padded;           // tiles, padded to whole workgroups with empty records
+    uint32_t image, ord;
+    uint32_t mcus_x, mcus_y, per;   // per: MCUs in a tile (jda_mcus_per_tile)
+};
 
 // Slots a 256-byte segment's block records need (RECORD mode of the device pre-scan, jda_device_core.h): more than its 2,048 bits
 // can start blocks.  mcu_min_bits: the fewest bits an MCU of the image can take -- per block the shortest DC code + the shorter of

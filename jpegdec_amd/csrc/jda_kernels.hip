@@ -399,6 +399,32 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
 }
 
 // ------------------------------------------------------------------------------------------------
+// The tile lists of whole images (jda_append_strips' records, jda_plan.h), written on the device: thread = tile
+__global__ __launch_bounds__(256)
+void jda_fill_strips(const jda_strips_params *__restrict__ params)
+{
+    const jda_strips_params P = params[blockIdx.y];
+    const uint32_t per_row = (P.mcus_x + P.per - 1u) / P.per, n_real = P.mcus_y * per_row;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < P.n_padded; k += gridDim.x * 256u) {
+        uint32_t w1 = 0, w2 = 0;
+        if (k < n_real) {
+            const uint32_t y = k / per_row, x = (k - y * per_row) * P.per;
+            const uint32_t count = P.mcus_x - x < P.per ? P.mcus_x - x : P.per;
+            w1 = y | (x << 16); w2 = count | (k == 0u ? 1u << 8 : 0u);      // mcu_y | mcu_x0 << 16, count | first << 8
+        }
+        jda_store_u32x4(P.dst + k, P.image, w1, w2, P.ord);
+    }
+}
+extern "C" hipError_t jda_launch_fill_strips(const jda_strips_params *params, uint32_t n_images, uint32_t max_tiles, hipStream_t stream)
+{
+    if (n_images == 0 || max_tiles == 0) return hipSuccess;
+    uint32_t gx = (max_tiles + 1023u) / 1024u;                        // four records a thread
+    if (gx > 64u) gx = 64u;
+    hipLaunchKernelGGL(jda_fill_strips, dim3(gx, n_images), dim3(256), 0, stream, params);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // The DC thumbnail: 1/8 scale (every progressive file's DC scan included).  A pixel is its block's DC term -- the range-limited
 // (DC x q0) >> 5 of jpeg.inl:5146-5154 -- so with index format 2 (the pre-scan stored every block's own DC value) nothing but
 // 2 bytes per block is read: no scan, no index entry, no tables in LDS, no IDCT.  A wavefront takes JDA_THUMB_TILES consecutive
@@ -1008,7 +1034,12 @@ __device__ __forceinline__ uint32_t jda_filter_v2_thread(const jda_filter_params
 {
     jda_filter_load(P, chunk, tid, b, T.valid);
     T.M = jda_filter_classify(b);
+    // bytes in front of the stream's first (raw_skip, in the image's first thread): plain bytes that are not emitted -- the machine
+    // starts in state 0 and a byte that is not FF leaves it there
+    const uint32_t sk = (chunk == 0u && tid == 0u) ? (1u << P.raw_skip) - 1u : 0u;
+    T.M.ff &= ~sk; T.M.zero &= ~sk; T.M.rst &= ~sk;
     T.F0 = jda_filter_run(T.M, T.valid, 0u);
+    T.F0.E &= ~sk;
     const uint32_t V = (1u << T.valid) - 1u;
     T.is_k = (T.M.ff & V) != V ? 1u : 0u;                          // (valid == 0: X with parity 0, the identity)
     T.bit = T.is_k ? (T.F0.S >> T.valid) & 1u : T.valid & 1u;

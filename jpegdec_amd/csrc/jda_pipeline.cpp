@@ -153,6 +153,7 @@ struct Img {
     size_t off_raw, off_scan, scan_bytes, off_index, off_dc, off_work, off_zero, off_stats;   // arena offsets
     size_t work_bytes, zero_bytes, off_rpos, off_fwork, off_wt;     // off_rpos / off_fwork: restart positions / the filter's work words inside the work region
     bool direct;                 // its bytes go to the GPU from where the caller has them (JDA_SUBMIT_PINNED_INPUT): no copy into the mirror
+    uint32_t raw_skip;           // .. keeping their alignment: the stream's first byte is raw_skip bytes behind the 16-byte aligned off_raw
     bool record;                 // the pre-scan runs in RECORD mode (no WRITE walk)
     size_t off_recs, off_cands;  // block records / truncation candidates inside the work region
     uint32_t cand_cap;
@@ -210,22 +211,6 @@ static uint32_t count_tiles(uint32_t mcus_x, uint32_t mcus_y, int mode, int big)
     const uint32_t n = mcus_y * ((mcus_x + per - 1) / per);
     return (n + wg - 1) / wg * wg;
 }
-static void fill_strips(jda_strip *dst, uint32_t n_padded, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, uint32_t ord)
-{
-    const uint32_t per = jda_mcus_per_tile(mode);
-    uint32_t k = 0;
-    for (uint32_t y = 0; y < mcus_y; y++)
-        for (uint32_t x = 0; x < mcus_x; x += per, k++) {
-            jda_strip s;
-            memset(&s, 0, sizeof(s));
-            s.image = image; s.mcu_y = (uint16_t)y; s.mcu_x0 = (uint16_t)x;
-            s.count = (uint8_t)(mcus_x - x < per ? mcus_x - x : per);
-            s.first = k == 0 ? 1 : 0; s.ord = ord;
-            dst[k] = s;
-        }
-    for (; k < n_padded; k++) { jda_strip s; memset(&s, 0, sizeof(s)); s.image = image; s.ord = ord; dst[k] = s; }
-}
-
 extern "C" {
 
 jda_pipeline *jda_pipeline_create(jda_ctx *ctx, int32_t max_images, int32_t depth, int32_t host_threads, int32_t *err)
@@ -330,7 +315,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     const size_t off_fparams = a16(ctl); ctl = off_fparams + a16((size_t)n * sizeof(jda_filter_params));
     const size_t off_sparams = ctl; ctl += a16((size_t)n * sizeof(jda_segscan_params));
     S.off_descs = ctl; ctl += a16((size_t)n * sizeof(jda_dev_desc));
-    const size_t strips_base = ctl;
+    const size_t off_tparams = ctl; ctl += a16((size_t)n * sizeof(jda_strips_params));      // the tile lists are written on the device (jda_fill_strips)
     // the page-locked buffer must hold the tables before the strips are counted: size it generously for them now
     size_t pin_need_min = ctl + (size_t)n * JDA_PIPE_STATS_BYTES + 4096;
     if (S.pin_cap < pin_need_min) {
@@ -384,18 +369,50 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         S.st.source_pixels += (int64_t)I.width * I.height;
         S.st.compressed_bytes += lens[i];
     }
-    for (int m = 0; m < JDA_N_LISTS; m++) { S.list_off[m] = ctl; S.list_n[m] = list_tiles[m]; ctl += a16((size_t)list_tiles[m] * sizeof(jda_strip)); }
-    (void)strips_base;
     S.ctl_bytes = a256(ctl);
     arena = S.ctl_bytes;
-    // the unfiltered scans: first the ones that travel through the mirror, then -- input that is page-locked where it lies
-    // (JDA_SUBMIT_PINNED_INPUT) -- the ones the copy engine reads from the caller's buffers: no host core touches those bytes
+    // The unfiltered scans.  Input that is page-locked where it lies (JDA_SUBMIT_PINNED_INPUT) is read there by the copy engine: no
+    // host core touches those bytes.  Files that lie next to one another in the caller's memory (a loader's arena, a ring of receive
+    // buffers) travel as ONE copy command -- a command per file costs the submitting thread 25-30 us, 2 ms for a batch of 64 --: the
+    // covering range goes to the arena as it is (headers and gaps of up to 64 KB included) and a file's scan keeps its place in it
+    // (raw_skip: its alignment).  A command that would carry less than 128 KB is not worth its cost: those files, and all of them when
+    // the input is pageable, go through the pipeline's page-locked mirror (the workers copy them, one command takes them all).
     static const uint32_t direct_min = []() { const char *e = JDA_LAB_ENV("JDA_PIPE_DIRECT_MIN"); return e ? (uint32_t)atoi(e) : (uint32_t)JDA_PIPE_DIRECT_MIN_BYTES; }();
-    int n_direct = 0;
-    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; im.direct = im.device && (flags & JDA_SUBMIT_PINNED_INPUT) && im.f.raw_len >= direct_min; n_direct += im.direct ? 1 : 0; }
+    struct Run { const uint8_t *src; size_t bytes, off; int files; };
+    std::vector<Run> runs;
+    std::vector<size_t> delta((size_t)n, 0);
+    std::vector<int> run_of((size_t)n, -1);
+    for (int i = 0; i < n; i++) { S.imgs[(size_t)i].direct = false; S.imgs[(size_t)i].raw_skip = 0; }
+    if (flags & JDA_SUBMIT_PINNED_INPUT) {
+        std::vector<int> dix;
+        for (int i = 0; i < n; i++) if (S.imgs[(size_t)i].device) dix.push_back(i);
+        std::sort(dix.begin(), dix.end(), [&](int a, int b) { return jpegs[a] + S.imgs[(size_t)a].f.raw_off < jpegs[b] + S.imgs[(size_t)b].f.raw_off; });
+        const uint8_t *last_end = NULL;
+        for (int i : dix) {
+            Img &im = S.imgs[(size_t)i];
+            const uint8_t *b = jpegs[i] + im.f.raw_off, *e = b + im.f.raw_len;
+            if (runs.empty() || b < last_end || (size_t)(b - last_end) > ((size_t)64 << 10) || (size_t)(e - runs.back().src) > ((size_t)1 << 30)) {
+                Run r;
+                r.src = (const uint8_t *)((uintptr_t)b & ~(uintptr_t)15); r.bytes = 0; r.off = 0; r.files = 0;
+                runs.push_back(r);
+            }
+            Run &r = runs.back();
+            r.bytes = a16((size_t)(e - r.src)); r.files++;
+            delta[(size_t)i] = (size_t)(b - r.src); run_of[(size_t)i] = (int)runs.size() - 1;
+            last_end = e;
+        }
+        for (int i : dix) S.imgs[(size_t)i].direct = runs[(size_t)run_of[(size_t)i]].bytes >= direct_min;
+    }
     for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device && !im.direct) im.off_raw = take(a16(im.f.raw_len) + 16); }
     const size_t raw_end = arena;                             // [0, raw_end) = control blob + the mirrored scans: one H2D copy from the page-locked mirror
-    for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.direct) im.off_raw = take(a16(im.f.raw_len) + 16); }
+    for (Run &r : runs) if (r.bytes >= direct_min) r.off = take(r.bytes + 16);
+    for (int i = 0; i < n; i++) {
+        Img &im = S.imgs[(size_t)i];
+        if (!im.direct) continue;
+        im.off_raw = runs[(size_t)run_of[(size_t)i]].off + (delta[(size_t)i] & ~(size_t)15);
+        im.raw_skip = (uint32_t)(delta[(size_t)i] & 15u);
+    }
+    for (int m = 0; m < JDA_N_LISTS; m++) { S.list_n[m] = list_tiles[m]; S.list_off[m] = list_tiles[m] ? take((size_t)list_tiles[m] * sizeof(jda_strip)) : 0; }
     for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device) im.off_dc = take((size_t)im.n_blocks * 2); }
     for (int i = 0; i < n; i++) {
         Img &im = S.imgs[(size_t)i];
@@ -404,7 +421,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         im.n_segs_ub = im.f.raw_len / JDA_SEG_BYTES + 1u;
         im.off_rpos = a16((size_t)im.n_segs_ub * 4 * JDA_SEG_SUM_WORDS) + a16((size_t)im.n_segs_ub * 20) + a16((size_t)im.n_segs_ub * 8);
         im.off_fwork = im.off_rpos + (im.f.n_intervals ? a16(((size_t)im.f.n_intervals + 1) * 4) : 0);          // .. | the filter's chunk functions
-        im.off_wt = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len));                                       // .. | the walk's tables
+        im.off_wt = im.off_fwork + a16(JDA_FILTER_WORK_BYTES(im.f.raw_len + 16u));                                 // .. | the walk's tables
         im.work_bytes = im.off_wt + JDA_WT_BYTES;
         // .. | RECORD mode: the segments' block records, the truncation candidates
         im.record = true;                                    // (device_ok streams have record slots: front_common)
@@ -468,7 +485,8 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     jda_dev_desc *dd = (jda_dev_desc *)(S.pin + S.off_descs);
     std::vector<int> dev_ix;
     for (int i = 0; i < n; i++) if (S.imgs[(size_t)i].device) dev_ix.push_back(i);
-    uint32_t max_segs = 0, max_raw = 0;
+    jda_strips_params *tp = (jda_strips_params *)(S.pin + off_tparams);
+    uint32_t max_segs = 0, max_raw = 0, max_tiles = 0;
     for (size_t k = 0; k < dev_ix.size(); k++) {
         const int i = dev_ix[k];
         Img &im = S.imgs[(size_t)i];
@@ -477,12 +495,13 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         uint32_t *fres = (uint32_t *)(B + im.off_stats);
         uint32_t *pstats = (uint32_t *)(B + im.off_stats + 16);
         jda_filter_params &F = fp[k];
-        F.raw = B + im.off_raw; F.out = B + im.off_scan; F.result = fres; F.raw_len = im.f.raw_len;
+        F.raw = B + im.off_raw; F.out = B + im.off_scan; F.result = fres; F.raw_skip = im.direct ? im.raw_skip : 0u; F.pad_ = 0;
+        F.raw_len = im.f.raw_len + F.raw_skip;
         const uint32_t n_int = im.f.n_intervals;                       // 0: no restart intervals
         F.restart_pos = (uint32_t *)(B + im.off_work + im.off_rpos);
         F.restart_cap = n_int ? n_int + 1u : 0u;
         F.work = (uint32_t *)(B + im.off_work + im.off_fwork);
-        max_raw = std::max(max_raw, im.f.raw_len);
+        max_raw = std::max(max_raw, F.raw_len);
         jda_dev_desc &D = descs[(size_t)i];
         D.tables = B + im.ctl_tables;
         D.blk_index = (const uint32_t *)(B + im.off_index);
@@ -515,13 +534,15 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         }
         sp[k] = P;
         max_segs = std::max(max_segs, im.n_segs_ub);
+        jda_strips_params &TP = tp[k];
+        TP.dst = (jda_strip *)(B + S.list_off[im.list]) + im.strip_off; TP.n_padded = im.n_tiles; TP.image = (uint32_t)i; TP.ord = im.ord;
+        TP.mcus_x = D.mcus_x; TP.mcus_y = D.mcus_y; TP.per = jda_mcus_per_tile(D.mode);
+        max_tiles = std::max(max_tiles, im.n_tiles);
     }
     g_submit_clock.lap(4);
     p->workers->run((int)dev_ix.size(), [&](int k) {
         const int i = dev_ix[(size_t)k];
         const Img &im = S.imgs[(size_t)i];
-        const jda_dev_desc &D = descs[(size_t)i];
-        fill_strips((jda_strip *)(S.pin + S.list_off[im.list]) + im.strip_off, im.n_tiles, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, im.ord);
         // the file's entropy-coded bytes into the page-locked mirror (the workers' memcpy is the only time the host touches them):
         // the whole batch then travels as ONE asynchronous copy instead of a blocking pageable copy per file
         if (!im.direct) copy_to_mirror(S.pin + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len);
@@ -537,11 +558,10 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         e = hipMemsetAsync(B + zero_begin, 0, zero_end - zero_begin, p->s_copy);
         if (e == hipSuccess) e = hipMemcpyAsync(B, S.pin, raw_end, hipMemcpyHostToDevice, p->s_copy);      // control blob + every mirrored scan
         S.st.h2d_bytes += (int64_t)raw_end;
-        for (int i = 0; i < n && n_direct && e == hipSuccess; i++) {                                      // .. and the others from where they lie
-            const Img &im = S.imgs[(size_t)i];
-            if (!im.direct) continue;
-            e = hipMemcpyAsync(B + im.off_raw, jpegs[i] + im.f.raw_off, im.f.raw_len, hipMemcpyHostToDevice, p->s_copy);
-            S.st.h2d_bytes += (int64_t)im.f.raw_len;
+        for (size_t r = 0; r < runs.size() && e == hipSuccess; r++) {                                      // .. and the others from where they lie
+            if (runs[r].bytes < direct_min) continue;
+            e = hipMemcpyAsync(B + runs[r].off, runs[r].src, runs[r].bytes, hipMemcpyHostToDevice, p->s_copy);
+            S.st.h2d_bytes += (int64_t)runs[r].bytes;
         }
         // The copy stream carries the memset and the copy ONLY: with the filter behind the copy on the same stream, the next batch's
         // 110 MB (2 ms at 55 GB/s) could not start before this batch's filter had run -- and the filter's workgroups wait for the decode
@@ -553,6 +573,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
             if (e == hipSuccess) e = hipEventRecord(S.ev_copy, p->s_copy);
             if (e == hipSuccess) e = hipStreamWaitEvent(s_up, S.ev_copy, 0);
         }
+        if (e == hipSuccess) e = jda_launch_fill_strips((const jda_strips_params *)(B + off_tparams), (uint32_t)dev_ix.size(), max_tiles, s_f);
         if (e == hipSuccess) e = jda_launch_walk_tables((const jda_segscan_params *)(B + off_sparams), (uint32_t)dev_ix.size(), s_f);
         if (e == hipSuccess) e = jda_launch_filter((const jda_filter_params *)(B + off_fparams), (uint32_t)dev_ix.size(), max_raw, s_f);
         if (filter_on_copy) {

@@ -515,7 +515,7 @@ int jda_filter_on_device(jda_ctx *ctx, const uint8_t *raw, int32_t len, uint8_t 
     if (e != hipSuccess) return jda_set_err(ctx, e, "hipMalloc(filter)");
     jda_filter_params P;
     P.raw = d; P.out = d + off_out; P.restart_pos = (uint32_t *)(d + off_rpos); P.result = (uint32_t *)(d + off_res);
-    P.raw_len = (uint32_t)len; P.restart_cap = (uint32_t)rcap; P.work = (uint32_t *)(d + off_work);
+    P.raw_len = (uint32_t)len; P.restart_cap = (uint32_t)rcap; P.work = (uint32_t *)(d + off_work); P.raw_skip = 0; P.pad_ = 0;
     e = hipMemsetAsync(d, 0, off_par, ctx->stream);
     if (e == hipSuccess && len) e = hipMemcpyAsync(d, raw, (size_t)len, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + off_par, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
