@@ -8,13 +8,13 @@ tag=${1:-r04_prof}; prefix=${2:-r04}
 out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out -o kt -- python $R/bench.py --no-parity --no-cpu-baseline --e2e-batches 0 --no-configs > /dev/null 2>&1)
+(cd /tmp && timeout -k 5 90 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out -o kt -- python $R/bench.py --no-parity --no-cpu-baseline --e2e-batches 0 --no-configs > /dev/null 2>&1)
 B="--steps 10 --warmup 2 --ramp-ms 0 --no-parity --no-cpu-baseline --e2e-batches 0 --no-configs"
-(cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out -o fetch -- python $R/bench.py $B > /dev/null 2>&1)
-(cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out -o write -- python $R/bench.py $B > /dev/null 2>&1)
+(cd /tmp && timeout -k 5 90 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out -o fetch -- python $R/bench.py $B > /dev/null 2>&1)
+(cd /tmp && timeout -k 5 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out -o write -- python $R/bench.py $B > /dev/null 2>&1)
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"; do
-  i=$((i+1)); (cd /tmp && timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/$out -o sq_$i -- python $R/bench.py --steps 2 --warmup 1 --batch 16 --ramp-ms 0 --no-parity --no-cpu-baseline --e2e-batches 0 --no-configs > /dev/null 2>&1)
+  i=$((i+1)); (cd /tmp && timeout -k 5 90 rocprofv3 --pmc $grp --output-format csv -d $R/$out -o sq_$i -- python $R/bench.py --steps 2 --warmup 1 --batch 16 --ramp-ms 0 --no-parity --no-cpu-baseline --e2e-batches 0 --no-configs > /dev/null 2>&1)
 done
 python - <<PY
 import csv, glob, collections, json, sys
