@@ -131,6 +131,16 @@ const jda_image_info *jda_image_get_info(const jda_image *img);
 const uint8_t *jda_image_scan(const jda_image *img, uint32_t *len);
 const uint32_t *jda_image_block_index(const jda_image *img, uint32_t *n_mcus_ok);
 const int16_t *jda_image_block_dc(const jda_image *img);
+/* The optional part of the index: continuation entries, one every 8 AC symbols of a long block, through which several lanes of
+ * the decode kernel share it (photographs: luma blocks of forty symbols beside chroma blocks of four -- a wavefront runs as long as
+ * its longest CHUNK then, not its longest block).  cont_first[g] .. cont_first[g + 1] (n_blocks + 1 offsets) are block g's entries in
+ * the returned array of *n_cont entries: bits 11:0 the bit position of the entry's first symbol relative to the block's first AC
+ * symbol, bits 17:12 the zigzag index of its first coefficient, bits 24:18 the low bits of g.  The serial pre-scan writes them; the
+ * decode takes them for images between jda_cont_min_bits() and twice that many bits of scan per block (default 56 .. 112: where the
+ * mode was measured to pay; jda_set_cont_min_bits: 0 = every image that has entries, < 0 = none). */
+const uint32_t *jda_image_block_cont(const jda_image *img, const uint32_t **cont_first, uint32_t *n_cont);
+int32_t jda_cont_min_bits(void);
+void jda_set_cont_min_bits(int32_t bits_per_block);
 /* Do two indexes of n_blocks + 1 entries (one from the serial pre-scan, one read back from the device: jda_dev_image_read_index,
  * jda_pipeline_read_index) name the same decode?  The contract between the two pre-scans: every block's entry has the same bit
  * position (byte position * 8 + bit offset) and the same flag; a FLAGGED block's entry is identical (the reference reader's exact

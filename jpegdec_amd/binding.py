@@ -73,6 +73,9 @@ _PROTOTYPES = [
     ("jda_image_block_index", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_block_dc", _P, [_P]),
     ("jda_index_equivalent", C.c_int, [_P, _P, C.c_uint32]),
+    ("jda_image_block_cont", _P, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
+    ("jda_cont_min_bits", C.c_int32, []),
+    ("jda_set_cont_min_bits", None, [C.c_int32]),
     ("jda_image_tables", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_truncation_events", C.c_uint32, [_P]),
     ("jda_image_general_p1", C.c_uint32, [_P]),
@@ -234,6 +237,14 @@ class PreparedImage:
         p = self.lib.jda_image_block_index(self.handle, C.byref(n))
         arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(self.n_blocks + 1,)).copy()
         return arr, n.value
+
+    def block_cont(self):
+        """(cont_first[n_blocks + 1], cont[n]) -- the serial pre-scan's continuation entries (jda_image_block_cont)"""
+        cf, n = _P(), C.c_uint32(0)
+        p = self.lib.jda_image_block_cont(self.handle, C.byref(cf), C.byref(n))
+        first = np.ctypeslib.as_array(C.cast(cf, C.POINTER(C.c_uint32)), shape=(self.n_blocks + 1,)).copy()
+        ent = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+        return first, ent
 
     def block_dc(self) -> np.ndarray:
         p = self.lib.jda_image_block_dc(self.handle)

@@ -67,7 +67,8 @@ template <> struct jda_mode_traits<JDA_MODE_440>  { enum { NLUMA = 2, NBLK = 4, 
 #define JDA_ZZ_ENTRIES 144       //   j < 64: (column bit 1 << (n & 7)) << 8 | 2 n (n = natural index: the byte offset in the
                                  //   block); j >= 64 (past the block, or 64 + j for a symbol that stores nothing): 128 = the
                                  //   block's padding, no flags.  j <= 63 + 15 + 64.
-#define JDA_ZZ_DUMP    128u
+#define JDA_ZZ_DUMP    134u      // (the last two of the slot's eight pad bytes; bytes 128..131 are the block's shared flag word in P1's chunked mode)
+#define JDA_SLOT_FLAGS  128u      // byte offset in a block's slot: OR of the flag words of the chunks other lanes decoded (jda_p1c_*)
 #define JDA_LT_BYTES   10528
 #define JDA_LT_LONG_BYTES 0           // (the long halves are part of JDA_LT_AC now)
 
@@ -649,6 +650,43 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     // A.2: column bits in 7:0, (n << 8) bits above -- only bit 13 (some n >= 32) is ever tested; fl holds 2n in 7:0
     return (fl >> 8) | ((fl & 0x40u) << 7);
 }
+
+// ---- a CHUNK of a block: at most JDA_CONT_SYMS AC symbols from a continuation entry (or from the block's first AC symbol), so that
+// the lanes of a wavefront share its long blocks (jda_p1c_*).  The loop is jda_decode_block_win's; it starts at zigzag position k0 and
+// ends at EOB, behind coefficient 63 or after max_syms symbols.  Returns the OR of the zigzag entries of what it stored (the caller
+// folds the chunks' words into the block's flags: jda_p1c_fold).  Only for blocks the reference reads without truncation.
+JDA_HD uint32_t jda_decode_chunk_win(uint32_t bitpos, const uint8_t *wbase, const jda_tables &T, int16_t *coef, uint32_t k0, uint32_t max_syms)
+{
+    jda_wreader R;
+    jda_wr_init(R, wbase, bitpos >> 3, bitpos & 7u);
+    uint32_t fl = 0;
+    const uint32_t zzb = JDA_LDS_A32(T.zz);
+    uint32_t k2 = zzb + 2u * k0;
+    uint32_t t_prev = JDA_ZZ_DUMP;
+    int32_t v_prev = 0;
+    uint32_t w = jda_wr_peek(R), left = max_syms;
+    if ((w >> T.eob_sh) != T.eob_code) for (;;) {
+        const uint32_t e = T.ac_short[jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u)];
+        fl |= t_prev;
+        JDA_COEF_STORE(coef, t_prev, v_prev);
+        const uint32_t kk2 = jda_add_byte0(k2, e);
+        const uint32_t t = JDA_LDS_LOAD_U16(T.zz, kk2);
+        const uint32_t len = (e >> 12) + 1u, ms = (e >> 8) & 0xfu;
+        const uint32_t m = w << len;
+        v_prev = jda_extend_top(m, ms);
+        t_prev = t;
+        jda_wr_consume(R, len + ms);
+        k2 += (e & 0x1eu) + 2u;
+        w = jda_wr_peek(R);
+        left--;
+        if (left == 0u || k2 >= zzb + 128u || (w >> T.eob_sh) == T.eob_code) break;
+    }
+    fl |= t_prev;
+    JDA_COEF_STORE(coef, t_prev, v_prev);
+    return fl;
+}
+// the block's flags (A.2) from the OR of its chunks' words: column bits in 7:0, bit 13 = some coefficient in rows 4-7
+JDA_HD uint32_t jda_p1c_fold(uint32_t fl) { return ((fl >> 8) & 0xffu) | ((fl & 0x40u) << 7); }
 
 // Does some lane of the wavefront (of those that are here) say yes?  The host emulator steps the lanes one after another:
 // there a lane answers for itself (the exact decoder is right for every block, the short one for every unflagged block).
@@ -1800,6 +1838,121 @@ JDA_HD uint32_t jda_p1_entropy(const jda_dev_desc &D, const jda_tile_ctx &C, con
     else { br.bits = jda_load_be64(br, br.pos); flags = jda_decode_block<64>(br, TB, coef, dc, trunc); }
     JDA_P1_TRACE(9);
     return flags;
+}
+
+// ---- P1 in chunks (images whose index carries continuation entries: photographs, high qualities) -------------------------------
+// A wavefront runs P1's symbol loop as long as its longest block, and the blocks of a photograph differ by a factor of ten -- a luma
+// block of forty symbols beside chroma blocks of four: 23-41 % of the lanes' trips do work (profiles/r04_p1_lane_balance_estimate.txt).
+// With an entry every JDA_CONT_SYMS symbols of a long block (JDA_CONT_*: both pre-scans write them as they pass) the tile's work is
+//   pass A   lane = block: the block's first chunk (<= 8 symbols) -- clears the block, stores its DC value;
+//   passes B lane = continuation entry e of the tile (they are contiguous in memory, blocks in order: entry C0 + 64 p + lane): the
+//            chunk behind it, into ITS block's coefficients; the block's bit position comes from the lane that owns the block
+//            (ds_bpermute), the chunk's flag word is ORed into the block's slot (ds_or_b32 on JDA_SLOT_FLAGS);
+//   finish   lane = block: own flag word | the slot's.
+// A block flagged JDA_INDEX_TRUNC is decoded whole by its own lane in pass A (the reference's ulBitOff has to be followed from the
+// block's first symbol); a tile whose slice of the scan does not fit the LDS window takes the general reader, whole blocks.
+// cross-lane read (GPU: ds_bpermute, every lane of the wavefront active; host emulator: the array of every lane's value)
+JDA_HD uint32_t jda_lane_pull(uint32_t mine, uint32_t src, const uint32_t *all)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)all;
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)mine);
+#else
+    (void)mine;
+    return all[src & 63u];
+#endif
+}
+JDA_HD void jda_lds_or_u32(uint8_t *p, uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)__hip_atomic_fetch_or((uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *(jda_u32_alias *)p |= v;
+#endif
+}
+#define JDA_P1C_SKIP  0x80000000u    // own.bits: the lane has no block to share (no block, chroma of a luma-only decode, a flagged block, a tile on the general reader)
+struct jda_p1c_own { uint32_t bits;  // bit position of the block's first AC symbol | JDA_P1C_SKIP
+                     uint32_t fl;    // pass A's flag word (chunk mode: the OR of zigzag entries; whole mode: the block's folded flags)
+                     uint32_t whole; // the block was decoded whole in pass A
+                     uint32_t listed; };
+template <int MODE>
+JDA_HD void jda_p1c_tables(jda_tables &TB, const jda_dev_desc &D, uint32_t blk_lane, const uint8_t *tab)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t b = blk_lane % (uint32_t)T::NBLK, c = b < (uint32_t)T::NLUMA ? 0u : b - T::NLUMA + 1u;
+    const uint32_t ac_id = jda_pick3(D.ac_id, c);
+    const uint32_t eob = *(const jda_u32_alias *)(tab + JDA_LT_EOB + 4u * ac_id);
+    TB.dc = tab; TB.ac_short = (const uint16_t *)(tab + JDA_LT_AC + ac_id * 4096u); TB.ac_long = nullptr; TB.ac_long_lds = TB.ac_short + 1024;
+    TB.zz = (const uint16_t *)(tab + JDA_LT_ZZ);
+    TB.eob_sh = eob >> 16; TB.eob_code = eob & 0xffffu;
+}
+// pass A.  chunked: the tile takes the chunked path (uniform: its slice is in the window, the tables allow the window reader)
+template <int MODE>
+JDA_HD jda_p1c_own jda_p1c_block(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, const jda_lane_pre &LP, const uint8_t *tab, uint8_t *wl,
+                                 const uint8_t *win, uint32_t win_cap, bool chunked)
+{
+    typedef jda_lds_layout<MODE> L;
+    jda_p1c_own O;
+    O.bits = JDA_P1C_SKIP; O.fl = 0; O.whole = 1; O.listed = 0;
+    if (!in.active) return O;
+    if (MODE != JDA_MODE_GRAY && D.gray_from_color && LP.chroma) return O;
+    O.listed = 1;
+    jda_tables TB;
+    TB.dc = tab + LP.dc_off;
+    TB.ac_short = (const uint16_t *)(tab + LP.ac_off);
+    TB.ac_long = nullptr;
+    TB.ac_long_lds = TB.ac_short + 1024;
+    TB.zz = (const uint16_t *)(tab + JDA_LT_ZZ);
+    TB.eob_sh = LP.eob_sh; TB.eob_code = LP.eob_code;
+    int16_t *coef = (int16_t *)(wl + L::COEF_OFF + in.lb * JDA_COEF_STRIDE);
+    const uint32_t ix = in.ix;
+    const bool trunc = (ix & JDA_INDEX_TRUNC) != 0u;
+    const uint32_t pos = ix >> JDA_INDEX_OFF_BITS, off = ix & (JDA_INDEX_TRUNC - 1u);
+    const uint32_t win_len = C.win_len < win_cap ? C.win_len : win_cap;
+    const uint8_t *wbase = win - C.win_lo;
+    if (!chunked) {                                              // the general reader, whole blocks (as jda_p1_entropy)
+        jda_bitreader br;
+        br.base = JDA_G(const uint8_t, D.scan); br.win = win; br.win_lo = C.win_lo; br.win_len = win_len; br.pos = pos; br.off = off;
+        const bool win_only = C.win_need <= win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
+        if (win_only) O.fl = jda_decode_block_win<64, true, true>(pos, off, wbase, TB, coef, in.pred, true, trunc);
+        else { br.bits = jda_load_be64(br, br.pos); O.fl = jda_decode_block<64>(br, TB, coef, in.pred, trunc); }
+        return O;
+    }
+    *(jda_u64_alias *)((uint8_t *)coef + JDA_SLOT_FLAGS) = 0;    // the chunks' shared flag word (and the dump bytes behind it)
+    if (trunc) {                                                 // (rare) the reference truncates a read of this block: whole, from its exact phase
+        O.fl = jda_decode_block_win<64, true, true>(pos, off, wbase, TB, coef, in.pred, true, true);
+        return O;
+    }
+    jda_u64_alias *z = (jda_u64_alias *)coef;
+    z[0] = (uint64_t)(uint16_t)in.pred;
+#pragma unroll
+    for (int i = 1; i < 16; i++) z[i] = 0;
+    O.whole = 0;
+    O.bits = pos * 8u + off;
+    O.fl = jda_decode_chunk_win(O.bits, wbase, TB, coef, 1u, JDA_CONT_SYMS);
+    return O;
+}
+// a pass B item: entry = the continuation entry (valid: this lane has one), owner_bits = the owning lane's jda_p1c_own::bits
+template <int MODE>
+JDA_HD void jda_p1c_item(const jda_dev_desc &D, const jda_tile_ctx &C, uint32_t entry, uint32_t blk_lane, uint32_t owner_bits, bool valid,
+                         const uint8_t *tab, uint8_t *wl, const uint8_t *win)
+{
+    typedef jda_lds_layout<MODE> L;
+    if (!valid || (owner_bits & JDA_P1C_SKIP)) return;
+    jda_tables TB;
+    jda_p1c_tables<MODE>(TB, D, blk_lane, tab);
+    uint8_t *slot = wl + L::COEF_OFF + blk_lane * JDA_COEF_STRIDE;
+    const uint32_t fl = jda_decode_chunk_win(owner_bits + JDA_CONT_REL(entry), win - C.win_lo, TB, (int16_t *)slot, JDA_CONT_K(entry), JDA_CONT_SYMS);
+    jda_lds_or_u32(slot + JDA_SLOT_FLAGS, fl);
+}
+// finish: the block's flags for the IDCT work lists (what jda_p1_entropy returns)
+template <int MODE>
+JDA_HD uint32_t jda_p1c_finish(const jda_p1c_own &O, uint32_t lb, const uint8_t *wl)
+{
+    typedef jda_lds_layout<MODE> L;
+    if (!O.listed) return JDA_NO_LIST;
+    if (O.whole) return O.fl;
+    return jda_p1c_fold(O.fl | *(const jda_u32_alias *)(wl + L::COEF_OFF + lb * JDA_COEF_STRIDE + JDA_SLOT_FLAGS));
 }
 
 // The work lists of the IDCT stages, built by the whole wavefront at once (every lane calls this, with

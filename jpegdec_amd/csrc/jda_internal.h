@@ -25,6 +25,16 @@
                                   // the last block bounds the scan: the reader as the last block left it, offset 0..64, no flag -- or, from the
                                   // device pre-scan, up to 41 bits further on.)
 #define JDA_INDEX_TRUNC 0x40u     // the reference truncates a magnitude read of this block: P1 must follow its ulBitOff
+// Continuation entries (optional part of the index): a long block can be entered every JDA_CONT_SYMS AC symbols, so that several lanes
+// of P1 share it -- the wavefront runs as long as its longest CHUNK, not its longest block (photographs: luma blocks of 40 symbols beside
+// chroma blocks of 4).  blk_cont_first[g] .. blk_cont_first[g + 1] are block g's entries in blk_cont; an entry: the bit position of
+// its first symbol relative to the block's first AC symbol (bits 11:0), the zigzag index of its first coefficient (bits 17:12), the low
+// seven bits of the block's ordinal (bits 24:18: which lane of a tile owns it).  A block flagged JDA_INDEX_TRUNC is decoded whole.
+#define JDA_CONT_SYMS 8u
+#define JDA_CONT_ENTRY(rel, k, g) ((uint32_t)(rel) | ((uint32_t)(k) << 12) | (((uint32_t)(g) & 127u) << 18))
+#define JDA_CONT_REL(e) ((e) & 0xfffu)
+#define JDA_CONT_K(e) (((e) >> 12) & 63u)
+#define JDA_CONT_G7(e) (((e) >> 18) & 127u)
 
 // ---- the segment walk's 11-bit table key (jda_device_core.h, JDA_WT_*) and the reference's DC LUT index, shared with the front end
 #if defined(__HIPCC__)
@@ -73,12 +83,14 @@ enum { JDA_MODE_GRAY = 0, JDA_MODE_444 = 1, JDA_MODE_420 = 2, JDA_MODE_422 = 3 /
 #define JDA_G(T, p) ((T JDA_GLOBAL *)(p))
 
 // ---- device-side descriptors ----
-struct jda_dev_desc {             // one per image of a batch, 96 bytes
+struct jda_dev_desc {             // one per image of a batch, 104 bytes
     const uint8_t *scan;          // filtered entropy-coded bytes (4-byte aligned, padded)
     const uint32_t *blk_index;    // n_blocks+1 entries: (byte position << 7) | bit offset at each block's first AC symbol
     const int16_t *blk_dc;        // n_blocks: the block's own DC value
     const uint8_t *tables;        // JDA_TABLE_BYTES
     uint8_t *out;                 // output surface
+    const uint32_t *blk_cont_first;   // continuation entries (JDA_CONT_*; NULL: the image has none / is decoded block by block): n_blocks + 1 offsets ..
+    const uint32_t *blk_cont;         // .. into the entries
     uint32_t out_pitch;           // bytes
     uint32_t out_w, out_rows;     // clip in output pixels / rows
     uint32_t mcus_x, mcus_y;

@@ -82,6 +82,7 @@ __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
     jda_dev_desc L;
     L.scan = jda_uni_ptr(g->scan); L.blk_index = jda_uni_ptr(g->blk_index); L.blk_dc = jda_uni_ptr(g->blk_dc);
     L.tables = jda_uni_ptr(g->tables); L.out = jda_uni_ptr(g->out);
+    L.blk_cont_first = jda_uni_ptr(g->blk_cont_first); L.blk_cont = jda_uni_ptr(g->blk_cont);      // (dead in the kernels that do not decode in chunks)
     L.out_pitch = jda_uni32(g->out_pitch); L.out_w = jda_uni32(g->out_w); L.out_rows = jda_uni32(g->out_rows);
     L.mcus_x = jda_uni32(g->mcus_x); L.mcus_y = jda_uni32(g->mcus_y); L.n_mcus_ok = jda_uni32(g->n_mcus_ok);
     L.scan_len = jda_uni32(g->scan_len);
@@ -108,6 +109,7 @@ __device__ __forceinline__ jda_dev_desc jda_desc_const(jda_desc_cptr c)
     jda_dev_desc L;
     L.scan = (const uint8_t *)c->scan; L.blk_index = (const uint32_t *)c->blk_index; L.blk_dc = (const int16_t *)c->blk_dc;
     L.tables = (const uint8_t *)c->tables; L.out = (uint8_t *)c->out;
+    L.blk_cont_first = (const uint32_t *)c->blk_cont_first; L.blk_cont = (const uint32_t *)c->blk_cont;
     L.out_pitch = c->out_pitch; L.out_w = c->out_w; L.out_rows = c->out_rows;
     L.mcus_x = c->mcus_x; L.mcus_y = c->mcus_y; L.n_mcus_ok = c->n_mcus_ok;
     L.scan_len = c->scan_len;
@@ -162,9 +164,10 @@ __device__ __forceinline__ uint32_t jda_draw_tile(uint32_t *ctr, uint32_t lane)
 }
 
 // per-lane index / DC entries of a tile + the entry just past it (for the window bounds)
-template <int MODE>
+// CONT: also the block's place in the continuation entries (cf0 .. cf1: jda_p1c_*)
+template <int MODE, int CONT = 0>
 __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, const jda_strip &S, uint32_t lane,
-                                                      jda_p1_inputs &in, uint32_t &ix_end)
+                                                      jda_p1_inputs &in, uint32_t &ix_end, uint32_t *cf0 = nullptr, uint32_t *cf1 = nullptr)
 {
     typedef jda_mode_traits<MODE> T;
     uint32_t count = S.count;
@@ -177,6 +180,10 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
     if (in.active) {
         in.ix = JDA_G(const uint32_t, D.blk_index)[first_block + lane];
         in.pred = JDA_G(const int16_t, D.blk_dc)[first_block + lane];
+    }
+    if (CONT) {
+        *cf0 = *cf1 = 0;
+        if (in.active) { *cf0 = JDA_G(const uint32_t, D.blk_cont_first)[first_block + lane]; *cf1 = JDA_G(const uint32_t, D.blk_cont_first)[first_block + lane + 1u]; }
     }
     if (nb) ix_end = JDA_G(const uint32_t, D.blk_index)[first_block + nb];     // uniform address
 }
@@ -206,7 +213,39 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
 #ifndef JDA_EXP_SKIP
 #define JDA_EXP_SKIP 0       // profiling builds (tools/phase_count_libs.sh): 1 no P4, 2 no P3, 4 no P2, 8 no lists, 16 no P1
 #endif
-template <int MODE, bool FAST, int VARIANT, int BIG>
+// P1 of a tile in chunks (CONT kernels): pass A, the tile's continuation entries in passes of 64, the finish (jda_p1c_*)
+#define JDA_P1C_PRELOADED 2          // passes whose entries are asked for before pass A runs
+template <int MODE>
+__device__ __forceinline__ uint32_t jda_p1_chunked(const jda_dev_desc &D, const jda_tile_ctx &C, const jda_p1_inputs &in, uint32_t cf0, uint32_t cf1, const jda_lane_pre &LP,
+                                                   const uint8_t *tab, uint8_t *wl, const uint8_t *win, uint32_t win_cap, uint32_t lane)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t win_len = C.win_len < win_cap ? C.win_len : win_cap;
+    const bool chunked = C.win_need <= win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);       // uniform
+    // the tile's entries are contiguous: from the first block's first to the last block's last
+    const uint32_t nb = C.count * (uint32_t)T::NBLK;
+    const uint32_t c0 = jda_uni32(cf0);
+    const uint32_t c1 = nb ? (uint32_t)__builtin_amdgcn_readlane((int)cf1, (int)(nb - 1u)) : c0;
+    const uint32_t n_items = chunked ? c1 - c0 : 0u;
+    const uint32_t JDA_GLOBAL *cont = JDA_G(const uint32_t, D.blk_cont) + c0;
+    uint32_t ent[JDA_P1C_PRELOADED];
+#pragma unroll
+    for (uint32_t p = 0; p < JDA_P1C_PRELOADED; p++) { ent[p] = 0; if (64u * p + lane < n_items) ent[p] = cont[64u * p + lane]; }
+    const jda_p1c_own own = jda_p1c_block<MODE>(D, C, in, LP, tab, wl, win, win_cap, chunked);
+    JDA_WAVE_SYNC();
+    for (uint32_t p = 0; 64u * p < n_items; p++) {               // uniform trip count
+        uint32_t entry = p == 0u ? ent[0] : (p == 1u ? ent[1] : 0u);
+        const bool valid = 64u * p + lane < n_items;
+        if (p >= JDA_P1C_PRELOADED && valid) entry = cont[64u * p + lane];
+        const uint32_t bl = valid ? (JDA_CONT_G7(entry) - C.first_block) & 63u : lane;
+        const uint32_t owner_bits = jda_lane_pull(own.bits, bl, nullptr);                   // (every lane takes part)
+        jda_p1c_item<MODE>(D, C, entry, bl, owner_bits, valid, tab, wl, win);
+    }
+    JDA_WAVE_SYNC();
+    return jda_p1c_finish<MODE>(own, in.lb, wl);
+}
+
+template <int MODE, bool FAST, int VARIANT, int BIG, int CONT = 0>
 __global__ __launch_bounds__((64 * jda_lds_layout<MODE, BIG>::WAVES))
 void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads)
 {
@@ -248,18 +287,19 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     if (S.image != R0.image) Dc = jda_desc_uniform<VARIANT, MODE>(descs + S.image);
     jda_p1_inputs in;
     jda_tile_ctx C;
+    uint32_t cf0 = 0, cf1 = 0;                        // CONT: the lane's block among the continuation entries
     // everything a tile needs before its P1, fetched with nothing to overlap it (first tile of a wavefront, first
     // tile after an image boundary): index entries -> window bounds -> scan slice into the LDS window
 #define JDA_TILE_COLD_START()                                                                                     \
     do {                                                                                                          \
         uint32_t ixe_;                                                                                            \
-        jda_issue_index_loads<MODE>(Dc, S, lane, in, ixe_);                                                       \
+        jda_issue_index_loads<MODE, CONT>(Dc, S, lane, in, ixe_, &cf0, &cf1);                                     \
         C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ixe_), (uint32_t)L::WIN_BYTES); \
         C.count = __builtin_amdgcn_readfirstlane(C.count);                                                        \
         C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);                                                      \
         C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);                                                    \
         jda_window_store<L::WIN_CHUNKS>(wl + L::WIN_OFF, C.win_len, lane, jda_window_load<L::WIN_CHUNKS>(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane)); \
-        asm volatile("" : "+v"(in.ix), "+v"(in.pred));   /* nothing in flight when the loop (re)starts */                                \
+        asm volatile("" : "+v"(in.ix), "+v"(in.pred), "+v"(cf0), "+v"(cf1));   /* nothing in flight when the loop (re)starts */          \
     } while (0)
     JDA_TILE_COLD_START();
     jda_p4_pre P4;                                    // the colour stage's item addresses for this image (pitch, pixel size)
@@ -293,13 +333,15 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         jda_p1_inputs inn;
         uint32_t ixn_end = 0;
         inn.lb = lane; inn.ix = 0; inn.pred = 0; inn.active = false;
-        if (pipelined) jda_issue_index_loads<MODE>(D, Sn, lane, inn, ixn_end);
+        uint32_t cfn0 = 0, cfn1 = 0;
+        if (pipelined) jda_issue_index_loads<MODE, CONT>(D, Sn, lane, inn, ixn_end, &cfn0, &cfn1);
 
         JDA_PTRACE(1);
         // wave priorities: the phase that is a dependent chain (P1) and the one that feeds the memory pipe (P4) go first,
         // the arithmetic-dense IDCT fills the issue slots they leave (measured: 0.6-1 % over "oldest wave first")
         __builtin_amdgcn_s_setprio(JDA_PRIO_P1);
-        const uint32_t p1flags = (JDA_EXP_SKIP & 16) ? 0u : jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES);
+        const uint32_t p1flags = (JDA_EXP_SKIP & 16) ? 0u : (CONT ? jda_p1_chunked<MODE>(D, C, in, cf0, cf1, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES, lane)
+                                                                  : jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES));
         if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 8)) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
         __builtin_amdgcn_s_setprio(JDA_PRIO_IDCT);
         JDA_WAVE_SYNC();
@@ -314,7 +356,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // the index loads and the record have landed: settle their waits HERE.  Left to the compiler, the record's wait
         // lands after P4 (where it is consumed) as s_waitcnt vmcnt(0) -- the counter is shared with stores on gfx9, so the
         // wavefront would sit out the write acknowledgements of its own tile before starting the next one
-        asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+        asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(cfn0), "+v"(cfn1));
         if (pipelined) {
             Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end), (uint32_t)L::WIN_BYTES);
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
@@ -354,7 +396,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         if (!have_next) break;
         S = Sn; i_nxt = i_nn;
         Sn = jda_unpack_record(r0, r1, r2, r3);
-        if (pipelined) { C = Cn; in = inn; }
+        if (pipelined) { C = Cn; in = inn; cf0 = cfn0; cf1 = cfn1; }
         else {                                        // image boundary: every wavefront of the workgroup passes here once
             Dc = jda_desc_uniform<VARIANT, MODE>(descs + S.image);
             JDA_ADVANCE_TABLES(S.ord, true, S, Dc);
@@ -370,7 +412,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u + 1u] = wall_clock64();
 }
 
-template <int MODE, bool FAST, int VARIANT, int BIG = 0>
+template <int MODE, bool FAST, int VARIANT, int BIG = 0, int CONT = 0>
 static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
     typedef jda_lds_layout<MODE, BIG> L;
@@ -378,7 +420,7 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
     static_assert(L::TAB_BYTES + L::WAVES * L::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
     static_assert(L::WIN_BYTES >= L::COLLIST_ENTRIES * 2 + 16 && L::WIN_BYTES % 16 == 0 && L::WIN_OFF % 16 == 0, "the window covers the column list and its overrun");
     static std::atomic<unsigned long long> attr_done(0);
-    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG>, lds_bytes, attr_done); if (e != hipSuccess) return e; }
+    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG, CONT>, lds_bytes, attr_done); if (e != hipSuccess) return e; }
     static std::atomic<int> grid_cap_once(0);                   // (the GPUs of a node are alike: the first device's CU count)
     int grid_cap = grid_cap_once.load(std::memory_order_relaxed);
     if (!grid_cap) {
@@ -393,7 +435,7 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
     }
     const uint32_t n_quads = n_tiles / L::WAVES;
     const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
-    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG>), dim3(grid), dim3(64 * L::WAVES), lds_bytes, stream,
+    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG, CONT>), dim3(grid), dim3(64 * L::WAVES), lds_bytes, stream,
                        descs, tiles, n_quads);
     return hipGetLastError();
 }
@@ -1233,10 +1275,32 @@ extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)
 }
 
 // Launch entry used by jda_runtime.cpp.  n_tiles is a multiple of jda_lds_layout<MODE>::WAVES (padded per image).
-extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, const jda_dev_desc *descs, const jda_strip *tiles,
+extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, int cont, const jda_dev_desc *descs, const jda_strip *tiles,
                                         uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
+    if (cont) {                                       // P1 in chunks (jda_use_cont decides who gets here): general variant and the RGB8888 plain case, 24-bit multiplies
+        if (!fast_mul || variant > 1) return hipErrorInvalidValue;
+        switch ((mode * 2 + variant) * 2 + (big ? 1 : 0)) {
+        case (JDA_MODE_GRAY * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_GRAY, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_GRAY * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_GRAY, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_444 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_444, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_444 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_444, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_444 * 2 + 1) * 2 + 0: return launch_persistent<JDA_MODE_444, true, 1, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_444 * 2 + 1) * 2 + 1: return launch_persistent<JDA_MODE_444, true, 1, 1, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_420 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_420, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_420 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_420, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_420 * 2 + 1) * 2 + 0: return launch_persistent<JDA_MODE_420, true, 1, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_420 * 2 + 1) * 2 + 1: return launch_persistent<JDA_MODE_420, true, 1, 1, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_422 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_422, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_422 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_422, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_422 * 2 + 1) * 2 + 0: return launch_persistent<JDA_MODE_422, true, 1, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_422 * 2 + 1) * 2 + 1: return launch_persistent<JDA_MODE_422, true, 1, 1, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_440 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_440, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
+        case (JDA_MODE_440 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_440, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (!fast_mul && variant == 3) {                  // JDA_LIST_THUMB: 1/8 scale, the DC values are the pixels
         switch (mode) {
         case JDA_MODE_GRAY: return launch_dc_thumbnail<JDA_MODE_GRAY>(descs, tiles, n_tiles, stream);

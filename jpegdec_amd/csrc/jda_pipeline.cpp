@@ -594,7 +594,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, S.ev_up, 0);
     for (int m = 0; m < JDA_N_LISTS && e == hipSuccess && n_dev; m++) {
         if (!S.list_n[m]) continue;
-        e = jda_launch_decode(m >> 4, (m >> 3) & 1, (m >> 1) & 3, m & 1, (const jda_dev_desc *)(B + S.off_descs), (const jda_strip *)(B + S.list_off[m]), S.list_n[m], ctx->stream);
+        e = jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), (const jda_dev_desc *)(B + S.off_descs), (const jda_strip *)(B + S.list_off[m]), S.list_n[m], ctx->stream);
         S.st.launches++;
     }
     if (e == hipSuccess) e = hipEventRecord(S.ev_dec, ctx->stream);

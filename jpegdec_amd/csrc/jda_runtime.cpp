@@ -57,6 +57,21 @@ int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uin
     return avg + avg / 2 + 48 > jda_window_bytes(D.mode, 0) ? 1 : 0;
 }
 
+static std::atomic<int32_t> g_cont_min_bits(56);
+extern "C" int32_t jda_cont_min_bits(void) { return g_cont_min_bits.load(std::memory_order_relaxed); }
+extern "C" void jda_set_cont_min_bits(int32_t bits) { g_cont_min_bits.store(bits, std::memory_order_relaxed); }
+int jda_use_cont(const jda_dev_desc &D, int variant, uint64_t scan_bytes, uint64_t n_blocks, uint32_t n_cont)
+{
+    if (!n_cont || !n_blocks || !D.fast_mul || variant > 1 || D.scale_shift > 1 || (D.pad_[0] & (JDA_DESC_GENERAL_P1 | JDA_DESC_DC_ONLY))) return 0;
+    const int32_t min_bits = jda_cont_min_bits();
+    if (min_bits < 0) return 0;
+    if (min_bits == 0) return 1;                                  // (tests: every image that has entries)
+    // measured (profiles/r04_p1_chunks_ab.txt): + 3 % (tulips, 62 bits a block) to + 15 % (zebra, 77) where long luma blocks stand beside
+    // short ones; - 6 % at quality 98 (158 bits a block: every block is long, a pass of chunks costs what four symbols cost) and - 13 %
+    // where most tiles hold a block the reference truncates (perf.jpg, 140): the window in which it pays
+    return scan_bytes * 8u >= (uint64_t)min_bits * n_blocks && scan_bytes * 8u < (uint64_t)2 * min_bits * n_blocks ? 1 : 0;
+}
+
 int jda_set_err(jda_ctx *ctx, hipError_t e, const char *what)
 {
     if (ctx) snprintf(ctx->last_error, sizeof(ctx->last_error), "%s: %s", what, hipGetErrorString(e));
@@ -306,6 +321,17 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         d->off_dc = d->off_index + align16((it.n_blocks + 1) * sizeof(uint32_t));
         d->off_scan = d->off_dc + align16(it.n_blocks * sizeof(int16_t));
         d->bytes = d->off_scan + align16((size_t)scan_len + JDA_SCAN_PAD);
+        d->off_cont_first = d->off_cont = 0; d->n_cont = 0;
+        if (!it.on_device) {                                      // the serial pre-scan's continuation entries travel with its index
+            const uint32_t *cf = NULL;
+            uint32_t nc = 0;
+            (void)jda_image_block_cont(img, &cf, &nc);
+            if (nc) {
+                d->n_cont = nc;
+                d->off_cont_first = d->bytes; d->off_cont = d->off_cont_first + align16((it.n_blocks + 1) * sizeof(uint32_t));
+                d->bytes = d->off_cont + align16((size_t)nc * sizeof(uint32_t));
+            }
+        }
         it.alloc = d->bytes;
         it.seg_mode = it.on_device;
         it.n_segs = 0;
@@ -389,6 +415,12 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
             const uint32_t *index = jda_image_block_index(img, &nok);
             memcpy(it.stage + d->off_index, index, (it.n_blocks + 1) * sizeof(uint32_t));
             memcpy(it.stage + d->off_dc, jda_image_block_dc(img), it.n_blocks * sizeof(int16_t));
+            if (d->n_cont) {
+                const uint32_t *cf = NULL;
+                const uint32_t *ce = jda_image_block_cont(img, &cf, NULL);
+                memcpy(it.stage + d->off_cont_first, cf, (it.n_blocks + 1) * sizeof(uint32_t));
+                memcpy(it.stage + d->off_cont, ce, (size_t)d->n_cont * sizeof(uint32_t));
+            }
             {   // the scan slice of every tile, as jda_tile_setup_from computes it: how many exceed the 16-wave kernel's window
                 const int mode = jda_mode_of(I);
                 const uint32_t per = jda_mcus_per_tile(mode), win = jda_window_bytes(mode, 0), nb = (uint32_t)I.blocks_per_mcu;
@@ -628,8 +660,10 @@ jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
         const int big = D.scale_shift == 3 ? 0 : jda_big_window(D, variant, im->tiles_total, im->tiles_over_small);
+        const int cont = jda_use_cont(D, variant, im->scan_len, (uint64_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu, im->n_cont);
+        if (cont) { D.blk_cont_first = (const uint32_t *)(im->base + im->off_cont_first); D.blk_cont = (const uint32_t *)(im->base + im->off_cont); }
         {
-            std::vector<jda_strip> &lst = strips[jda_list_index(D, variant, big)];
+            std::vector<jda_strip> &lst = strips[jda_list_index(D, variant, big, cont)];
             const size_t before = lst.size();
             jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL);
             for (size_t k = before; k < lst.size(); k++) if (lst[k].count) st.tiles++;
@@ -657,7 +691,7 @@ jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *
         e = jda_pool_alloc(ctx, (void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(m / 16, m & 1));
+        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(JDA_LIST_MODE(m), JDA_LIST_BIG(m)));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -687,7 +721,7 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
     if (!b) return JDA_INVALID_PARAMETER;
     for (int m = 0; m < JDA_N_LISTS; m++) {
         if (!b->n_strips[m]) continue;
-        JDA_HIP(ctx, jda_launch_decode(m >> 4, (m >> 3) & 1, (m >> 1) & 3, m & 1, b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
+        JDA_HIP(ctx, jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
     }
     return JDA_SUCCESS;
 }

@@ -7,8 +7,14 @@
 #include "jda_internal.h"
 #include "jda_plan.h"
 
-// launch lists of a batch: one per (mode, fast_mul, kernel variant, window size); index = ((mode * 2 + fast) * 4 + variant) * 2 + big
-#define JDA_N_LISTS (16 * JDA_N_MODES)
+// launch lists of a batch: one per (mode, fast_mul, kernel variant, window size, P1 in chunks);
+// index = (((mode * 2 + fast) * 4 + variant) * 2 + big) * 2 + cont
+#define JDA_N_LISTS (32 * JDA_N_MODES)
+#define JDA_LIST_MODE(m) ((m) >> 5)
+#define JDA_LIST_FAST(m) (((m) >> 4) & 1)
+#define JDA_LIST_VARIANT(m) (((m) >> 2) & 3)
+#define JDA_LIST_BIG(m) (((m) >> 1) & 1)
+#define JDA_LIST_CONT(m) ((m) & 1)
 
 #define JDA_POOL_SLOTS 192
 #define JDA_POOL_IDLE_MAX ((size_t)2 << 30)      // idle bytes kept at most
@@ -40,6 +46,8 @@ struct jda_dev_image {
     uint8_t fast_mul;
     uint8_t general_p1;          // JDA_DESC_GENERAL_P1
     uint8_t prescan_on_device;   // the block index was made on the device (jda_segscan_*)
+    size_t off_cont_first, off_cont;   // continuation entries (0 / 0: none uploaded)
+    uint32_t n_cont;
     uint32_t tiles_total, tiles_over_small;   // host index known: tiles, and those whose scan slice exceeds the 16-wave kernel's window (0 / 0: unknown)
 };
 
@@ -60,12 +68,18 @@ int jda_plain_variant(const jda_dev_desc &D);
 // which launch list an image's tiles go to: ((mode * 2 + fast) * 4 + variant) * 2 + big.  The combination fast = 0, variant = 3 (no
 // plain-case kernel exists without the 24-bit multiplies) names the DC thumbnail kernel: 1/8 scale -- also every progressive
 // file's DC scan at its default scale --, whose pixels are the blocks' DC values (jpeg.inl:5146-5154): no scan, no index, no IDCT
-#define JDA_LIST_THUMB(mode) ((((mode) * 2 + 0) * 4 + 3) * 2 + 0)
-inline int jda_list_index(const jda_dev_desc &D, int variant, int big)
+#define JDA_LIST_THUMB(mode) (((((mode) * 2 + 0) * 4 + 3) * 2 + 0) * 2 + 0)
+inline int jda_list_index(const jda_dev_desc &D, int variant, int big, int cont = 0)
 {
     if (D.scale_shift == 3) return JDA_LIST_THUMB(D.mode);
-    return ((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big;
+    return (((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big) * 2 + cont;
 }
+// P1 in chunks (jda_p1c_*: the lanes of a wavefront share a tile's long blocks through the index's continuation entries) pays where the
+// blocks are long AND uneven -- photographs at moderate qualities -- and costs where they are short or all long: taken between
+// jda_cont_min_bits() and twice that many bits of scan per block (default 56 .. 112; the metric's synthetic image has 34, the reference's
+// tulips 62, zebra 77, perf.jpg 140, a quality-98 file 158).  The kernels exist for the general variant and the RGB8888 plain case with
+// 24-bit multiplies, full and half size.
+int jda_use_cont(const jda_dev_desc &D, int variant, uint64_t scan_bytes, uint64_t n_blocks, uint32_t n_cont);
 int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total = 0, uint32_t tiles_over_small = 0);
 // Fill the descriptor of one image of a launch plan (everything but the pointers into the image's HBM block, which the
 // caller sets) and validate the output surface.  Returns JDA_SUCCESS or the error jda_batch_create reports.
@@ -82,7 +96,7 @@ extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, u
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
                                                 int any_record, hipStream_t stream);
-extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, const jda_dev_desc *descs, const jda_strip *strips,
+extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, int cont, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, hipStream_t stream);
 
 #endif

@@ -22,6 +22,11 @@ static int g_trace_seg = -1;
 #include "../../jpegdec_amd/csrc/jda_device_core.h"
 #include "../../jpegdec_amd/csrc/jda_plan.h"
 
+static unsigned long long g_chunk_items = 0;      // continuation entries decoded as chunks since the last call of hostsim_chunk_items
+extern "C" unsigned long long hostsim_chunk_items(void) { const unsigned long long n = g_chunk_items; g_chunk_items = 0; return n; }
+static int g_use_cont = 0;        // 1: decode through P1's chunked mode (the serial pre-scan's continuation entries)
+extern "C" void hostsim_set_chunked(int on) { g_use_cont = on; }
+extern "C" const uint32_t *jda_image_block_cont(const jda_image *img, const uint32_t **cont_first, uint32_t *n_cont);
 static int g_reverse_tiles = 0;   // tests run the tiles in reverse order too: results must not depend on which wave finishes first
 extern "C" void hostsim_set_reverse(int on) { g_reverse_tiles = on; }
 static uint32_t g_window_bytes = 1024;   // tests shrink it to exercise the HBM fall-back of the bit reader (each layout caps it at its WIN_BYTES)
@@ -47,6 +52,23 @@ static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles
         uint32_t flags[JDA_TILE_THREADS];
         jda_lane_pre LP[JDA_TILE_THREADS];
         for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_lane_prepare<MODE>(LP[t], D, t, tab);
+        if (D.blk_cont_first && D.scale_shift < 2) {       // P1 in chunks (jda_p1c_*): pass A for every lane, the tile's continuation entries, the finish
+            typedef jda_mode_traits<MODE> T;
+            const uint32_t win_len = C.win_len < g_window_bytes ? C.win_len : g_window_bytes;
+            const bool chunked = C.win_need <= win_len && !(D.pad_[0] & JDA_DESC_GENERAL_P1);
+            jda_p1c_own own[JDA_TILE_THREADS];
+            for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) own[t] = jda_p1c_block<MODE>(D, C, in[t], LP[t], tab, wl, wl + L::WIN_OFF, g_window_bytes, chunked);
+            if (chunked && C.count) {
+                const uint32_t nb = C.count * (uint32_t)T::NBLK, c0 = D.blk_cont_first[C.first_block], c1 = D.blk_cont_first[C.first_block + nb];
+                for (uint32_t e = c0; e < c1; e++) {
+                    const uint32_t entry = D.blk_cont[e], bl = (JDA_CONT_G7(entry) - C.first_block) & 127u;
+                    if (bl >= nb) { fprintf(stderr, "hostsim: continuation entry %u of tile at block %u names lane %u\n", e, C.first_block, bl); abort(); }
+                    g_chunk_items++;
+                    jda_p1c_item<MODE>(D, C, entry, bl, own[bl].bits, true, tab, wl, wl + L::WIN_OFF);
+                }
+            }
+            for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) flags[t] = jda_p1c_finish<MODE>(own[t], t, wl);
+        } else
         for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) flags[t] = jda_p1_entropy<MODE>(D, C, in[t], LP[t], tab, wl, wl + L::WIN_OFF, g_window_bytes);
         if (D.scale_shift < 2) {
             for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_p1_lists<MODE>(D, LP[t], t, flags[t], flags, tab, wl);
@@ -299,6 +321,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     D.blk_index = jda_image_block_index(img, &n);
     D.blk_dc = jda_image_block_dc(img);
     if (g_prescan_used) { D.blk_index = dev_index.data(); D.blk_dc = dev_dc.data(); }
+    if (g_use_cont && !g_prescan_used) { uint32_t nc = 0; D.blk_cont = jda_image_block_cont(img, &D.blk_cont_first, &nc); }
     D.tables = jda_image_tables(img, &n);
     std::vector<jda_strip> strips;
     jda_append_strips(strips, 0, D.mcus_x, D.mcus_y, D.mode);

@@ -528,3 +528,31 @@ def test_damaged_restart_markers_through_the_record_mode_walk(name, hostsim, ora
     finally:
         hostsim.hostsim_set_device_prescan(0)
     assert agree >= 20, (agree, used)
+
+
+def test_p1_in_chunks_on_the_host_simulator(hostsim, oracle):
+    """P1's chunked mode (jda_p1c_block / _item / _finish, jda_decode_chunk_win) stepped lane by lane over the serial pre-scan's
+    continuation entries (one every 8 AC symbols: jda_image_block_cont): pass A for every block, then every entry of the tile as an item
+    of its own -- blocks flagged for truncated reads decoded whole, restart streams, every layout -- bit-exact with the oracle, and the
+    photographs really do go through chunks (thousands of items)."""
+    from tests.ref_fixtures import ref_jpeg
+    hostsim.hostsim_chunk_items.restype = C.c_ulonglong
+    hostsim.hostsim_set_chunked(1)
+    try:
+        hostsim.hostsim_chunk_items()
+        cases = [(n, jpeg_for(n)) for n in ("c420_333x217", "c444_256x256_q100_opt", "c422_333x217", "c440_200x120", "gray_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7")]
+        cases += [("ref:" + n, ref_jpeg(n)) for n in ("tulips", "zebra", "perf")]
+        items = 0
+        for name, jpeg in cases:
+            gray = oracle.info(jpeg)["ncomp"] == 1
+            for pt, opt in ((2, 0), (1, 2)) if gray else ((3, 0), (1, 0), (3, 2)):
+                rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+                assert rc == 1
+                got = np.full_like(want, 0x33)
+                inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+                assert hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh) == 0
+                assert np.array_equal(got, want), (name, pt, opt, int(np.count_nonzero(got != want)))
+            items += hostsim.hostsim_chunk_items()
+        assert items > 20000
+    finally:
+        hostsim.hostsim_set_chunked(0)
