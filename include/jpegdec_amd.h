@@ -326,6 +326,15 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
                              void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags,
                              int32_t n_bands, jda_band_callback *band_ready, void *user);
 
+/* The whole image STRIP-MAJOR: as the JPEGDRAW strips the reference hands to its draw callback (jpeg.inl:5300-5336) -- strip_mcus MCUs
+ * wide (a row's last strip: what is left), one MCU row high, in raster order, every strip's pixels contiguous with the strip's own
+ * width as pitch; strip (row y, column s) starts (y * ceil(mcus_x / strip_mcus) + s) * strip_mcus * mcu_w' * mcu_h' * bpp bytes into
+ * host_pixels (mcu_w', mcu_h': the MCU in output pixels).  The kernels write the surface in that layout; a consumer hands out
+ * pointers instead of copying strips together.  host_bytes >= mcus_y * ceil(mcus_x / strip_mcus) * that strip size.  The copy back
+ * in n_bands bands of MCU rows as jda_decode_to_host_bands (band_ready may be NULL). */
+int jda_decode_to_host_strips(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, int32_t strip_mcus,
+                              void *host_pixels, size_t host_bytes, int32_t *mcus_decoded, int32_t n_bands, jda_band_callback *band_ready, void *user);
+
 /* ------------------------------------------------------------------ the streamed pipeline
  * Files in, pixels resident in HBM out, batch after batch: the host parses headers and builds tables (microseconds per file);
  * the unfiltered entropy-coded bytes go to the GPU, which filters them (JPEGFilter, jpeg.inl:1431-1540), makes the per-block

@@ -379,11 +379,51 @@ int JPEGDEC::decode(int x, int y, int iOptions)
             strip0 = big.data();
         }
     }
+    // A large image with draw callbacks leaves the GPU STRIP-MAJOR when its plan is the regular one (every strip of a row strip_mcus
+    // MCUs wide, the last one what is left: any whole-image decode): the kernels write every strip's pixels contiguously
+    // (jda_decode_to_host_strips), the callback gets a pointer into the page-locked canvas and no strip is copied together here
+    int strip_mcus = 0, n_sx = 0;
+    size_t strip_bytes = 0;
+    if (use_pinned && n > 0 && mw > 0) {
+        strip_mcus = rects[2] / mw;
+        bool regular = strip_mcus > 0 && rects[2] == strip_mcus * mw;
+        for (int i = 0; i < n && regular; i++) {
+            const int32_t *r = &rects[(size_t)8 * i];
+            const int left = s->info.mcus_x * mw - r[6];
+            regular = r[6] % (strip_mcus * mw) == 0 && r[7] % mh == 0 && r[2] == (left < strip_mcus * mw ? left : strip_mcus * mw);
+        }
+        if (regular) {
+            n_sx = (s->info.mcus_x + strip_mcus - 1) / strip_mcus;
+            strip_bytes = (size_t)strip_mcus * mw * mh * bpp;
+            const size_t total = strip_bytes * n_sx * s->info.mcus_y;
+            if (s->pinned_cap < total) {
+                jda_host_free(s->pinned_canvas);
+                s->pinned_canvas = (uint8_t *)jda_host_alloc(total + total / 8);
+                s->pinned_cap = s->pinned_canvas ? total + total / 8 : 0;
+            }
+            if (!s->pinned_canvas) { s->error = JPEG_ERROR_MEMORY; return 0; }
+        } else strip_mcus = 0;
+    }
+    uint8_t *const strips = strip_mcus ? s->pinned_canvas : NULL;
     auto replay = [&](int row_limit) {
         for (; ri < n && !stopped; ri++) {
             const int i = ri;
             const int32_t *r = &rects[(size_t)8 * i];
             if (r[7] + mh > row_limit) return;                   // its rows have not landed yet: the next band brings them
+            if (strips) {                                        // strip-major: the strip is where the GPU wrote it
+                if (partial) {
+                    int x_last = (r[6] + r[2]) / mw - 1;
+                    if (x_last > s->info.mcus_x - 1) x_last = s->info.mcus_x - 1;
+                    if ((r[7] / mh) * s->info.mcus_x + x_last >= mcus_decoded) { stopped = true; break; }
+                }
+                JPEGDRAW jd;
+                jd.x = s->xoff + r[0]; jd.y = s->yoff + r[1];
+                jd.iWidth = r[2]; jd.iHeight = r[3]; jd.iWidthUsed = r[4]; jd.iBpp = r[5];
+                jd.pPixels = (uint16_t *)(strips + ((size_t)(r[7] / mh) * n_sx + (size_t)(r[6] / (strip_mcus * mw))) * strip_bytes);
+                jd.pUser = s->user;
+                if (!(*s->draw)(&jd)) { stopped = true; break; }     // jpeg.inl:5325
+                continue;
+            }
             if (partial) {
                 // the reference returns at the first bad MCU (jpeg.inl:5150-5297 "if (iErr) ... return 0" paths): only the strips it
                 // had completed before that MCU reach the callback
@@ -427,6 +467,10 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         // a large image with draw callbacks: the copy back in bands, each band's strips replayed as it lands
         struct Trampoline { decltype(replay) *fn; int32_t *decoded; int32_t total; bool *partial; };
         Trampoline tr = { &replay, &mcus_decoded, mcus_total, &partial };
+        if (strips)
+            rc = jda_decode_to_host_strips(ctx, s->data, s->size, pt, iOptions, strip_mcus, strips, s->pinned_cap, &mcus_decoded, JDA_MAX_REPLAY_BANDS,
+                                           [](void *u, int32_t, int32_t row1) { Trampoline *t = (Trampoline *)u; *t->partial = *t->decoded < t->total; (*t->fn)(row1); }, &tr);
+        else
         rc = jda_decode_to_host_bands(ctx, s->data, s->size, pt, iOptions, NULL, canvas, cw * bpp, ch, &mcus_decoded, NULL, 0, JDA_MAX_REPLAY_BANDS,
                                       [](void *u, int32_t, int32_t row1) { Trampoline *t = (Trampoline *)u; *t->partial = *t->decoded < t->total; (*t->fn)(row1); }, &tr);
     } else

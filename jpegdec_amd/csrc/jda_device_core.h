@@ -2807,7 +2807,29 @@ JDA_HD void jda_p4_prepare(jda_p4_pre &P, const jda_dev_desc &D, uint32_t t)
 }
 
 template <int MODE>
+JDA_HD void jda_p4_output_at(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *wl, const jda_p4_pre &P, bool precomputed);
+template <int MODE>
 JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *wl, const jda_p4_pre &P)
+{
+    typedef jda_mode_traits<MODE> T;
+    if (C.count == 0) return;
+    if (D.strip_mcus == 0) { jda_p4_output_at<MODE>(D, S, C, t, wl, P, true); return; }
+    // A strip-major surface: the tile lies inside ONE strip (the tile list is cut at strip edges), and inside it the surface is an
+    // ordinary one -- base and pitch of the strip, shifted so that the tile's absolute pixel coordinates address it
+    const int shift = D.scale_shift;
+    const uint32_t mw = (uint32_t)T::MCU_W >> shift, mh = (uint32_t)T::MCU_H >> shift;
+    const uint32_t bpp = D.pixel_type == JDA_RGB8888 ? 4u : (D.pixel_type == JDA_EIGHT_BIT_GRAYSCALE ? 1u : 2u);
+    const uint32_t n_sx = (D.mcus_x + D.strip_mcus - 1u) / D.strip_mcus, sx = S.mcu_x0 / D.strip_mcus;
+    const uint32_t in_strip = D.mcus_x - sx * D.strip_mcus < D.strip_mcus ? D.mcus_x - sx * D.strip_mcus : D.strip_mcus;      // MCUs of this strip (a row's last one may be narrower)
+    const uint32_t pitch = in_strip * mw * bpp;
+    const size_t strip_bytes = (size_t)D.strip_mcus * mw * mh * bpp;
+    jda_dev_desc V = D;
+    V.out_pitch = pitch;
+    V.out = D.out + ((size_t)S.mcu_y * n_sx + sx) * strip_bytes - ((size_t)S.mcu_y * mh * pitch + (size_t)sx * D.strip_mcus * mw * bpp);
+    jda_p4_output_at<MODE>(V, S, C, t, wl, P, false);
+}
+template <int MODE>
+JDA_HD void jda_p4_output_at(const jda_dev_desc &D, const jda_strip &S, const jda_tile_ctx &C, uint32_t t, const uint8_t *wl, const jda_p4_pre &P, bool precomputed)
 {
     typedef jda_mode_traits<MODE> T;
     typedef jda_lds_layout<MODE> L;
@@ -2820,14 +2842,14 @@ JDA_HD void jda_p4_output(const jda_dev_desc &D, const jda_strip &S, const jda_t
     const bool colour_out = D.pixel_type != JDA_EIGHT_BIT_GRAYSCALE;
     if ((MODE == JDA_MODE_444 || MODE == JDA_MODE_420 || MODE == JDA_MODE_422) && shift == 0 && colour_out) {      // specialised full-size colour paths
         const bool inside = x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows;   // no clipping in this tile
-        if (MODE == JDA_MODE_420 && inside && C.count == (uint32_t)L::MCUS) {          // the common case: a full tile
+        if (MODE == JDA_MODE_420 && inside && precomputed && C.count == (uint32_t)L::MCUS) {          // the common case: a full tile
             const int pt = D.pixel_type;
             if (pt == JDA_RGB8888) jda_p4_420_full10<JDA_RGB8888>(D, P, plane_base, x_base, y_base);
             else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_420_full10<JDA_RGB565_LITTLE_ENDIAN>(D, P, plane_base, x_base, y_base);
             else jda_p4_420_full10<JDA_RGB565_BIG_ENDIAN>(D, P, plane_base, x_base, y_base);
             return;
         }
-        if (MODE == JDA_MODE_444 && inside && C.count == (uint32_t)L::MCUS) {          // a full 4:4:4 tile
+        if (MODE == JDA_MODE_444 && inside && precomputed && C.count == (uint32_t)L::MCUS) {          // a full 4:4:4 tile
             const int pt = D.pixel_type;
             if (pt == JDA_RGB8888) jda_p4_444_full21<JDA_RGB8888>(D, P, t, plane_base, x_base, y_base);
             else if (pt == JDA_RGB565_LITTLE_ENDIAN) jda_p4_444_full21<JDA_RGB565_LITTLE_ENDIAN>(D, P, t, plane_base, x_base, y_base);

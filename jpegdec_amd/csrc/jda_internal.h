@@ -96,6 +96,9 @@ struct jda_dev_desc {             // one per image of a batch, 104 bytes
     uint32_t mcus_x, mcus_y;
     uint32_t n_mcus_ok;           // MCUs the pre-scan validated (others are not decoded)
     uint32_t scan_len;
+    uint32_t strip_mcus;          // != 0: the surface is STRIP-MAJOR -- the JPEGDRAW strips of the reference's callback (jpeg.inl:5300-5336), strip_mcus MCUs
+                                  // wide and one MCU row high, in raster order, each strip's pixels contiguous (pitch = the strip's own width), a strip
+                                  // every strip_mcus x MCU width x MCU height x bytes per pixel; out_pitch then only bounds the surface
     union {                       // 16 bytes of small fields; the kernels carry them as four dwords in SGPRs (cfg)
         struct {
             uint8_t mode;                 // JDA_MODE_*

@@ -85,11 +85,11 @@ __device__ __forceinline__ jda_dev_desc jda_desc_uniform(const jda_dev_desc *p)
     L.blk_cont_first = jda_uni_ptr(g->blk_cont_first); L.blk_cont = jda_uni_ptr(g->blk_cont);      // (dead in the kernels that do not decode in chunks)
     L.out_pitch = jda_uni32(g->out_pitch); L.out_w = jda_uni32(g->out_w); L.out_rows = jda_uni32(g->out_rows);
     L.mcus_x = jda_uni32(g->mcus_x); L.mcus_y = jda_uni32(g->mcus_y); L.n_mcus_ok = jda_uni32(g->n_mcus_ok);
-    L.scan_len = jda_uni32(g->scan_len);
+    L.scan_len = jda_uni32(g->scan_len); L.strip_mcus = jda_uni32(g->strip_mcus);
 #pragma unroll
     for (int i = 0; i < 4; i++) L.cfg[i] = jda_uni32(g->cfg[i]);      // mode .. pad_: sixteen byte fields in four SGPRs
     if (VARIANT >= 1) {
-        L.scale_shift = 0; L.pad_[0] = 0;
+        L.scale_shift = 0; L.pad_[0] = 0; L.strip_mcus = 0;
         L.pixel_type = VARIANT == 1 ? JDA_RGB8888 : (VARIANT == 2 ? JDA_RGB565_LITTLE_ENDIAN : JDA_EIGHT_BIT_GRAYSCALE);
         L.gray_from_color = (VARIANT == 3 && MODE != JDA_MODE_GRAY) ? 1 : 0;
     }
@@ -112,11 +112,11 @@ __device__ __forceinline__ jda_dev_desc jda_desc_const(jda_desc_cptr c)
     L.blk_cont_first = (const uint32_t *)c->blk_cont_first; L.blk_cont = (const uint32_t *)c->blk_cont;
     L.out_pitch = c->out_pitch; L.out_w = c->out_w; L.out_rows = c->out_rows;
     L.mcus_x = c->mcus_x; L.mcus_y = c->mcus_y; L.n_mcus_ok = c->n_mcus_ok;
-    L.scan_len = c->scan_len;
+    L.scan_len = c->scan_len; L.strip_mcus = c->strip_mcus;
 #pragma unroll
     for (int i = 0; i < 4; i++) L.cfg[i] = c->cfg[i];
     if (VARIANT >= 1) {
-        L.scale_shift = 0; L.pad_[0] = 0;
+        L.scale_shift = 0; L.pad_[0] = 0; L.strip_mcus = 0;
         L.pixel_type = VARIANT == 1 ? JDA_RGB8888 : (VARIANT == 2 ? JDA_RGB565_LITTLE_ENDIAN : JDA_EIGHT_BIT_GRAYSCALE);
         L.gray_from_color = (VARIANT == 3 && MODE != JDA_MODE_GRAY) ? 1 : 0;
     }
@@ -299,7 +299,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);                                                      \
         C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);                                                    \
         jda_window_store<L::WIN_CHUNKS>(wl + L::WIN_OFF, C.win_len, lane, jda_window_load<L::WIN_CHUNKS>(JDA_G(const uint8_t, Dc.scan), C.win_lo, C.win_len, lane)); \
-        asm volatile("" : "+v"(in.ix), "+v"(in.pred), "+v"(cf0), "+v"(cf1));   /* nothing in flight when the loop (re)starts */          \
+        asm volatile("" : "+v"(in.ix), "+v"(in.pred));   /* nothing in flight when the loop (re)starts */                                \
+        if (CONT) asm volatile("" : "+v"(cf0), "+v"(cf1));                                                        \
     } while (0)
     JDA_TILE_COLD_START();
     jda_p4_pre P4;                                    // the colour stage's item addresses for this image (pitch, pixel size)
@@ -356,7 +357,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // the index loads and the record have landed: settle their waits HERE.  Left to the compiler, the record's wait
         // lands after P4 (where it is consumed) as s_waitcnt vmcnt(0) -- the counter is shared with stores on gfx9, so the
         // wavefront would sit out the write acknowledgements of its own tile before starting the next one
-        asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(cfn0), "+v"(cfn1));
+        asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+        if (CONT) asm volatile("" : "+v"(cfn0), "+v"(cfn1));
         if (pipelined) {
             Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end), (uint32_t)L::WIN_BYTES);
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
@@ -430,6 +432,9 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
         // more workgroups than CUs: the ones that do not fit start as others finish, so the hardware deals the second half of the
         // work out by who is done first (the static split left the CUs finishing up to 4 % apart: profiles/r01_final_wg_balance.txt)
         static const int mult = []() { const char *e = JDA_LAB_ENV("JDA_GRID_MULT"); const int m = e ? atoi(e) : JDA_GRID_MULT_DEFAULT; return m < 1 ? 1 : (m > 16 ? 16 : m); }();
+        // (measuring: CUs left to the pre-scan's latency-bound rounds while a decode kernel runs)
+        static const int spare = []() { const char *e = JDA_LAB_ENV("JDA_DECODE_SPARE_CUS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+        if (spare < cus) cus -= spare;
         grid_cap = cus * (per_cu > 0 ? per_cu : 1) * mult;
         grid_cap_once.store(grid_cap, std::memory_order_relaxed);
     }

@@ -357,6 +357,10 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
                                             outputs[i], S.pts[(size_t)i], S.opts[(size_t)i], &bpp);
         if (rc != JDA_SUCCESS) { im.err = rc; continue; }
         if (!im.f.device_ok) continue;                       // valid, but the serial host pre-scan has to make its index (jda_pipeline_wait)
+        // the block records of the device pre-scan are rec_cap slots per 256-byte segment: 6 x the scan with the usual tables, up to
+        // 16 x with a DHT whose shortest codes are one or two bits.  Past 8 x (+ 16 MB of grace) the image takes the serial path: a
+        // batch of such files must not ask for an arena several times what the same files needed before the records existed
+        if ((uint64_t)(im.f.raw_len / JDA_SEG_BYTES + 1u) * im.f.rec_cap * 4u > 8ull * im.f.raw_len + (16ull << 20)) continue;
         im.device = true; n_dev++;
         const int variant = jda_plain_variant(D);
         // (window size: the filtered length is not known yet; the unfiltered one is at most a few percent larger)
@@ -474,7 +478,16 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         S.dev = NULL; S.dev_cap = 0;
         const size_t want = a256(arena + arena / 4);
         hipError_t e = hipMalloc((void **)&S.dev, want);
-        if (e != hipSuccess) { S.dev = NULL; return jda_set_err(ctx, e, "hipMalloc(pipeline arena)"), JDA_ERROR_MEMORY; }
+        if (e != hipSuccess) {                               // give back what the slots that are not in flight hold, and what is not strictly needed: once
+            (void)hipGetLastError();
+            for (int k = 0; k < p->depth; k++) {
+                jda_pipeline::Slot &o = p->slots[k];
+                if (&o != &S && !o.in_flight && o.dev) { (void)hipFree(o.dev); o.dev = NULL; o.dev_cap = 0; }
+            }
+            e = hipMalloc((void **)&S.dev, a256(arena));
+            if (e != hipSuccess) { S.dev = NULL; return jda_set_err(ctx, e, "hipMalloc(pipeline arena)"), JDA_ERROR_MEMORY; }
+            S.dev_cap = a256(arena);
+        } else
         S.dev_cap = want;
     }
 

@@ -99,7 +99,8 @@ inline uint32_t jda_mcus_per_tile(int mode)
 
 // rect = {mx0, my0, mx1, my1} in MCUs (half open) restricts the list to the tiles of that rectangle (crop-aware decode:
 // the per-block index lets a tile start at any MCU); NULL = the whole image
-inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, int big = 0, const int32_t *rect = nullptr)
+// edge_mcus != 0: no tile crosses a multiple of edge_mcus MCUs (a strip-major surface: jda_dev_desc::strip_mcus)
+inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, int big = 0, const int32_t *rect = nullptr, uint32_t edge_mcus = 0)
 {
     const uint32_t per = jda_mcus_per_tile(mode);
     const uint32_t ord = v.empty() ? 0u : v.back().ord + 1u;      // images are appended one after the other
@@ -111,11 +112,13 @@ inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_
     }
     bool first = true;
     for (uint32_t y = y0; y < y1; y++)
-        for (uint32_t x = x0; x < x1; x += per) {
+        for (uint32_t x = x0, step = per; x < x1; x += step) {
             jda_strip s;
             memset(&s, 0, sizeof(s));
             s.image = image; s.mcu_y = (uint16_t)y; s.mcu_x0 = (uint16_t)x;
-            s.count = (uint8_t)(x1 - x < per ? x1 - x : per);
+            step = x1 - x < per ? x1 - x : per;
+            if (edge_mcus && (x / edge_mcus + 1u) * edge_mcus - x < step) step = (x / edge_mcus + 1u) * edge_mcus - x;
+            s.count = (uint8_t)step;
             s.first = first ? 1 : 0; s.ord = ord;
             first = false;
             v.push_back(s);

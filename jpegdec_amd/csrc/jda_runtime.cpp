@@ -30,7 +30,7 @@ extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint
 // and one of the (layout, output format) pairs a kernel was built for.  0 = the general kernel.
 int jda_plain_variant(const jda_dev_desc &D)
 {
-    if (D.scale_shift != 0 || D.pad_[0] != 0 || !D.fast_mul) return 0;
+    if (D.scale_shift != 0 || D.pad_[0] != 0 || !D.fast_mul || D.strip_mcus != 0) return 0;
     const bool colour = D.mode != JDA_MODE_GRAY;
     if (D.pixel_type == JDA_RGB8888 && !D.gray_from_color) return (D.mode == JDA_MODE_444 || D.mode == JDA_MODE_420 || D.mode == JDA_MODE_422) ? 1 : 0;
     if (D.pixel_type == JDA_RGB565_LITTLE_ENDIAN && colour && !D.gray_from_color) return (D.mode == JDA_MODE_444 || D.mode == JDA_MODE_420) ? 2 : 0;
@@ -57,9 +57,6 @@ int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uin
     return avg + avg / 2 + 48 > jda_window_bytes(D.mode, 0) ? 1 : 0;
 }
 
-static std::atomic<int32_t> g_cont_min_bits(56);
-extern "C" int32_t jda_cont_min_bits(void) { return g_cont_min_bits.load(std::memory_order_relaxed); }
-extern "C" void jda_set_cont_min_bits(int32_t bits) { g_cont_min_bits.store(bits, std::memory_order_relaxed); }
 int jda_use_cont(const jda_dev_desc &D, int variant, uint64_t scan_bytes, uint64_t n_blocks, uint32_t n_cont)
 {
     if (!n_cont || !n_blocks || !D.fast_mul || variant > 1 || D.scale_shift > 1 || (D.pad_[0] & (JDA_DESC_GENERAL_P1 | JDA_DESC_DC_ONLY))) return 0;
@@ -307,6 +304,11 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         const uint8_t *tables = jda_image_tables(img, &it.tbytes);
         it.n_blocks = (size_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu;
         it.on_device = jda_image_index_on_device(img) != 0;      // index to be made on the device
+        if (it.on_device) {                                      // (the record area's bound: jda_pipeline_submit_ex has the same)
+            uint32_t sl = 0;
+            (void)jda_image_scan(img, &sl);
+            if ((uint64_t)(sl / JDA_SEG_BYTES + 1u) * jda_image_record_cap(img) * 4u > 8ull * sl + (16ull << 20)) { jda_image_run_host_prescan(img); it.on_device = false; }
+        }
         const uint32_t *rpos = jda_image_restart_positions(img, &it.n_int);
         jda_dev_image *d = new (std::nothrow) jda_dev_image;
         if (!d) { rc = JDA_ERROR_MEMORY; break; }
@@ -633,6 +635,14 @@ jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *
                                  const jda_output *outputs, const int32_t *pixel_types,
                                  const int32_t *options, const int32_t *mcu_rects, int32_t *err)
 {
+    return jda_batch_create_strips(ctx, n, images, outputs, pixel_types, options, mcu_rects, NULL, err);
+}
+
+// strip_mcus[i] != 0: image i's surface is strip-major (jda_dev_desc::strip_mcus; outputs[i] then describes the surface's extent only:
+// pitch_bytes x rows >= the strips' bytes)
+jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const *images, const jda_output *outputs, const int32_t *pixel_types,
+                                   const int32_t *options, const int32_t *mcu_rects, const int32_t *strip_mcus, int32_t *err)
+{
     int32_t dummy;
     if (!err) err = &dummy;
     if (!ctx) { *err = JDA_ERROR_NO_DEVICE; return NULL; }
@@ -656,6 +666,7 @@ jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *
         D.blk_index = (const uint32_t *)(im->base + im->off_index);
         D.blk_dc = (const int16_t *)(im->base + im->off_dc);
         D.scan = im->base + im->off_scan;
+        D.strip_mcus = (strip_mcus && strip_mcus[i] > 0) ? (uint32_t)strip_mcus[i] : 0u;
         // kernel variant 1: the plain case -- full size, RGB8888, every block decoded -- runs a kernel in which these
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
@@ -665,7 +676,7 @@ jda_batch *jda_batch_create_rect(jda_ctx *ctx, int32_t n, jda_dev_image *const *
         {
             std::vector<jda_strip> &lst = strips[jda_list_index(D, variant, big, cont)];
             const size_t before = lst.size();
-            jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL);
+            jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL, D.strip_mcus);
             for (size_t k = before; k < lst.size(); k++) if (lst[k].count) st.tiles++;
             const uint32_t per = jda_mcus_per_tile(D.mode);
             st.tiles_whole_images += (int64_t)D.mcus_y * ((D.mcus_x + per - 1) / per);
@@ -827,6 +838,74 @@ int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
                              void *host_pixels, int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded, int32_t *tiles, int32_t flags)
 {
     return jda_decode_to_host_bands(ctx, jpeg, len, pixel_type, options, mcu_rect, host_pixels, pitch_bytes, rows, mcus_decoded, tiles, flags, 1, NULL, NULL);
+}
+
+// The whole image as the reference's JPEGDRAW strips (jpeg.inl:5300-5336): strip_mcus MCUs wide, one MCU row high, in raster order, every
+// strip's pixels contiguous -- what JPEGDEC::decode hands to the draw callback without touching a pixel (a strip of a row-major canvas is
+// a few hundred bytes from each of 16 rows a pitch apart: 8,192 strips of a 4096x4096 image were 1.5 ms of small strided copies).
+int jda_decode_to_host_strips(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, int32_t strip_mcus,
+                              void *host_pixels, size_t host_bytes, int32_t *mcus_decoded, int32_t n_bands, jda_band_callback *band_ready, void *user)
+{
+    if (mcus_decoded) *mcus_decoded = 0;
+    if (!ctx) return JDA_ERROR_NO_DEVICE;
+    if (!jpeg || !host_pixels || strip_mcus <= 0) return JDA_INVALID_PARAMETER;
+    (void)hipSetDevice(ctx->device);
+    int32_t err = JDA_SUCCESS;
+    jda_image *img = jda_prepare_ex(jpeg, len, len >= (128 << 10) ? JDA_PREPARE_DEVICE_PRESCAN : 0, &err);
+    if (!img) return err;
+    const jda_image_info I = *jda_image_get_info(img);
+    int bpp, ow, oh, cw, ch;
+    int rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
+    if (rc != JDA_SUCCESS) { jda_image_free(img); return rc; }
+    const int mw = cw / I.mcus_x, mh = ch / I.mcus_y;
+    const int n_sx = (I.mcus_x + strip_mcus - 1) / strip_mcus;
+    const size_t strip_bytes = (size_t)strip_mcus * mw * mh * bpp, row_bytes = (size_t)n_sx * strip_bytes, total = row_bytes * I.mcus_y;
+    if (host_bytes < total) { jda_image_free(img); return JDA_INVALID_PARAMETER; }
+    jda_dev_image *dimg = jda_upload(ctx, img, &err);
+    uint32_t nok = 0;
+    jda_image_block_index(img, &nok);
+    const bool complete = nok == (uint32_t)(I.mcus_x * I.mcus_y);
+    if (mcus_decoded) *mcus_decoded = (int32_t)nok;
+    jda_image_free(img);
+    if (!dimg) return err;
+    void *dout = NULL;
+    const int dpitch = (int)align16((size_t)cw * bpp);
+    const size_t surf = std::max(total, (size_t)dpitch * ch) + 256;
+    if (jda_pool_alloc(ctx, &dout, surf) != hipSuccess) { jda_dev_image_free(ctx, dimg); return JDA_ERROR_MEMORY; }
+    jda_output O;
+    O.pixels = dout; O.pitch_bytes = dpitch; O.width_px = cw; O.rows = ch;
+    jda_batch *b = jda_batch_create_strips(ctx, 1, &dimg, &O, &pixel_type, &options, NULL, &strip_mcus, &err);
+    rc = err;
+    if (b) {
+        if (!complete) (void)hipMemsetAsync(dout, 0, total, ctx->stream);       // (callback mode: what a bad stream does not reach reads zero)
+        rc = jda_batch_decode(ctx, b);
+        if (rc == JDA_SUCCESS) {
+            int nb = (band_ready && n_bands > 1) ? (n_bands > JDA_MAX_BANDS ? JDA_MAX_BANDS : n_bands) : 1;
+            if (nb > I.mcus_y) nb = I.mcus_y;
+            const int per = (I.mcus_y + nb - 1) / nb;                            // MCU rows a band
+            hipError_t e = hipSuccess;
+            int made = 0;
+            for (int k = 0; k < nb && e == hipSuccess; k++) {
+                const int y0 = k * per, y1 = std::min(I.mcus_y, y0 + per);
+                if (y0 >= y1) break;
+                if (!ctx->ev_band[k]) e = hipEventCreateWithFlags(&ctx->ev_band[k], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipMemcpyAsync((uint8_t *)host_pixels + (size_t)y0 * row_bytes, (uint8_t *)dout + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipEventRecord(ctx->ev_band[k], ctx->stream);
+                if (e == hipSuccess) made++;
+            }
+            for (int k = 0; k < made && e == hipSuccess; k++) {
+                e = hipEventSynchronize(ctx->ev_band[k]);
+                if (e == hipSuccess && band_ready) (*band_ready)(user, k * per * mh, std::min(I.mcus_y, (k + 1) * per) * mh);
+            }
+            { const hipError_t es = hipStreamSynchronize(ctx->stream); if (e == hipSuccess) e = es; }
+            if (e != hipSuccess) rc = jda_set_err(ctx, e, "copy back");
+        }
+        jda_batch_destroy(ctx, b);
+    }
+    jda_pool_free(ctx, dout);
+    jda_dev_image_free(ctx, dimg);
+    if (rc == JDA_SUCCESS && !complete) rc = JDA_DECODE_ERROR;   // jpeg.inl:5354-5356
+    return rc;
 }
 
 int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, const int32_t *mcu_rect,

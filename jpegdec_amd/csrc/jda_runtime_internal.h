@@ -64,6 +64,8 @@ struct jda_batch {
 int jda_set_err(jda_ctx *ctx, hipError_t e, const char *what);
 hipError_t jda_pool_alloc(jda_ctx *ctx, void **out, size_t bytes);
 void jda_pool_free(jda_ctx *ctx, void *p);
+extern "C" jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const *images, const jda_output *outputs, const int32_t *pixel_types,
+                                              const int32_t *options, const int32_t *mcu_rects, const int32_t *strip_mcus, int32_t *err);
 int jda_plain_variant(const jda_dev_desc &D);
 // which launch list an image's tiles go to: ((mode * 2 + fast) * 4 + variant) * 2 + big.  The combination fast = 0, variant = 3 (no
 // plain-case kernel exists without the 24-bit multiplies) names the DC thumbnail kernel: 1/8 scale -- also every progressive

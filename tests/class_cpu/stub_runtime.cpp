@@ -109,6 +109,39 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
     return rc;
 }
 
+// strip-major: the row-major stand-in canvas, rearranged as the kernels would have written it
+int jda_decode_to_host_strips(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, int32_t strip_mcus,
+                              void *host_pixels, size_t host_bytes, int32_t *mcus_decoded, int32_t n_bands, jda_band_callback *band_ready, void *user)
+{
+    jda_image_info I;
+    int bpp, ow, oh, cw, ch;
+    int rc = jda_parse(jpeg, len, &I);
+    if (rc != JDA_SUCCESS) return rc;
+    rc = jda_output_geometry(&I, pixel_type, options, &bpp, &ow, &oh, &cw, &ch);
+    if (rc != JDA_SUCCESS) return rc;
+    if (strip_mcus <= 0 || I.mcus_x <= 0 || I.mcus_y <= 0) return JDA_INVALID_PARAMETER;
+    const int mw = cw / I.mcus_x, mh = ch / I.mcus_y, n_sx = (I.mcus_x + strip_mcus - 1) / strip_mcus;
+    const size_t strip_bytes = (size_t)strip_mcus * mw * mh * bpp;
+    if (host_bytes < strip_bytes * n_sx * I.mcus_y) return JDA_INVALID_PARAMETER;
+    std::vector<uint8_t> canvas((size_t)cw * ch * bpp, 0);
+    rc = jda_decode_to_host_flags(ctx, jpeg, len, pixel_type, options, NULL, canvas.data(), cw * bpp, ch, mcus_decoded, NULL, 0);
+    if (rc != JDA_SUCCESS && rc != JDA_DECODE_ERROR) return rc;
+    for (int y = 0; y < I.mcus_y; y++)
+        for (int sx = 0; sx < n_sx; sx++) {
+            const int m0 = sx * strip_mcus, mc = std::min(strip_mcus, I.mcus_x - m0);
+            uint8_t *dst = (uint8_t *)host_pixels + ((size_t)y * n_sx + sx) * strip_bytes;
+            for (int r = 0; r < mh; r++)
+                memcpy(dst + (size_t)r * mc * mw * bpp, canvas.data() + ((size_t)(y * mh + r) * cw + (size_t)m0 * mw) * bpp, (size_t)mc * mw * bpp);
+        }
+    if (band_ready && n_bands > 1) {
+        int nb = n_bands > 8 ? 8 : n_bands;
+        if (nb > I.mcus_y) nb = I.mcus_y;
+        const int per = (I.mcus_y + nb - 1) / nb;
+        for (int k = 0; k < nb && k * per < I.mcus_y; k++) (*band_ready)(user, k * per * mh, std::min(I.mcus_y, (k + 1) * per) * mh);
+    }
+    return rc;
+}
+
 int jda_decode_to_host_ex(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int32_t pixel_type, int32_t options, void *host_pixels,
                           int32_t pitch_bytes, int32_t rows, int32_t *mcus_decoded)
 {

@@ -54,3 +54,13 @@ def test_walks_under_asan_ubsan(class_cpu):
         r = subprocess.run([os.path.join(ROOT, "tests", "class_cpu", "walks_asan"), td, str(len(names))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
         assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
         assert "walks done" in r.stdout and int(r.stdout.split("walks done")[0].split()[-1]) == len(lines), r.stdout[-300:]
+
+
+def test_large_images_leave_the_device_strip_major(class_cpu):
+    """tests/strip_major_cases.py over the stand-in device: the class's side of the strip-major path (plan regularity, strip addresses,
+    the bands' replay) against the unmodified reference."""
+    from oracle.loader import ref_available
+    from tests.strip_major_cases import check_strip_major_decodes
+    if not ref_available(False):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    check_strip_major_decodes(class_cpu, RefDecoder(False))

@@ -305,3 +305,11 @@ def test_framebuffer_keeps_what_a_bad_stream_does_not_reach(product_class, oracl
         if done == 3:
             break
     assert done == 3
+
+
+def test_large_images_leave_the_device_strip_major(product_class, ref_scalar):
+    """tests/strip_major_cases.py on the GPU: the kernels write a surface of 2 MB and more as the reference's JPEGDRAW strips (tiles cut
+    at strip edges, every strip's pixels contiguous), the class hands out pointers into the page-locked copy of it -- every strip and
+    every pixel the unmodified reference's."""
+    from tests.strip_major_cases import check_strip_major_decodes
+    check_strip_major_decodes(product_class, ref_scalar)

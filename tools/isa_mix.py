@@ -5,9 +5,9 @@ import collections
 import re
 import sys
 
-MANGLED = {"<2,true,1,0>": "_Z27jda_decode_tiles_persistentILi2ELb1ELi1ELi0EEvPK12jda_dev_descPK9jda_stripj",
-           "<1,true,1,0>": "_Z27jda_decode_tiles_persistentILi1ELb1ELi1ELi0EEvPK12jda_dev_descPK9jda_stripj",
-           "<0,true,3,0>": "_Z27jda_decode_tiles_persistentILi0ELb1ELi3ELi0EEvPK12jda_dev_descPK9jda_stripj"}
+MANGLED = {"<2,true,1,0>": "_Z27jda_decode_tiles_persistentILi2ELb1ELi1ELi0ELi0EEvPK12jda_dev_descPK9jda_stripj",
+           "<1,true,1,0>": "_Z27jda_decode_tiles_persistentILi1ELb1ELi1ELi0ELi0EEvPK12jda_dev_descPK9jda_stripj",
+           "<0,true,3,0>": "_Z27jda_decode_tiles_persistentILi0ELb1ELi3ELi0ELi0EEvPK12jda_dev_descPK9jda_stripj"}
 
 
 def kernel_lines(path, name):
