@@ -528,6 +528,10 @@ def run(args, J, out=sys.stdout):
                     "host_threads": host_threads, "batches": batches, "device_path_images": pst["device_images"], "host_path_images": pst["host_path_images"]}
 
         main_threads = min(threads, 8)
+        # (untimed, like the clock ramp: the first few dozen batches that read a fresh page-locked arena run 10-25 % below the rate
+        # every later one has -- profiles/r04_e2e_input_modes.txt, first against second pass over the same six runs)
+        if have_pinned and not args.no_e2e_sweep:
+            e2e_run(main_threads, 2 * args.e2e_batches, "pinned")
         e2e = e2e_run(main_threads, args.e2e_batches, "pinned")
         e2e.update({"images_per_batch": eb, "depth": depth, "distinct_images": min(e2e_distinct, eb),
                     "input": "page-locked, JDA_SUBMIT_PINNED_INPUT (files >= 128 KB: DMA from where they lie)" if have_pinned else "pageable",

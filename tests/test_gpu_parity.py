@@ -158,8 +158,8 @@ def test_clip_to_image_size(gpu_ctx, oracle):
                                   "c422_1100x24_rstrow", "c440_300x64_rst5"])
 def test_restart_marker_fast_path(name, gpu_ctx, oracle):
     """JDA_PREPARE_DEVICE_PRESCAN leaves the Huffman pre-scan of a stream with restart markers to
-    the GPU (jda_upload: phase-map pass + exact pass, one lane per restart interval).  Same pixels as the
-    oracle, and the path really was taken."""
+    the GPU (jda_upload: the segment walk's RST flavour -- interval ends found by position, sums restart behind
+    them, every marker checked against the MCU count).  Same pixels as the oracle, and the path really was taken."""
     import jpegdec_amd as J
     jpeg = jpeg_for(name)
     prep = J.PreparedImage(jpeg, device_prescan=True)
