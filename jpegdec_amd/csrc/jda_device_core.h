@@ -2909,4 +2909,118 @@ JDA_HD void jda_p4_output_at(const jda_dev_desc &D, const jda_strip &S, const jd
         jda_p4_generic<MODE>(D, t, plane_base, L::PLANE_STRIDE, tile_w, x_base, y_base);
 }
 
+// ---- 1/4 scale: a kernel of its own (jda_quarter_tiles in jda_kernels.hip; tests/hostsim steps the same functions) ---------------
+// At 1/4 a block is the 2x2 IDCT of coefficients 0, 1, 8, 9 (jpeg.inl:2305-2326) -- zigzag positions 0, 1, 2, 4: the reference's
+// JPEGDecodeMCU stores nothing behind position 4 (:2117-2119), and with a per-block index nothing behind it has to be read either.
+// So a block is its DC value (index format 2), at most FOUR AC symbols -- they lie in the 104 bits behind its index entry -- and
+// sixteen multiplies: no window in LDS, no coefficient slot, no work lists.  lane = block; the five dwords of the scan that hold those bits
+// come straight from memory (neighbouring lanes read neighbouring bytes) and the reader slides through them in registers.
+struct jda_q4_bits { uint32_t d[5]; };      // scan dwords, big-endian (byte-swapped): d[0] holds the last CONSUMED bit (jda_q4_first_dword)
+struct jda_q4_quant { int32_t q0, q1, q8, q9; };
+// the dword of the scan that holds the bit in front of the block's first AC symbol
+JDA_HD uint32_t jda_q4_first_dword(uint32_t ix)
+{
+    const uint32_t p = (ix >> JDA_INDEX_OFF_BITS) * 8u + (ix & (JDA_INDEX_TRUNC - 1u));      // (>= 2: a DC symbol lies in front of it)
+    return (p - 1u) >> 5;
+}
+JDA_HD uint32_t jda_bswap32(uint32_t v) { return jda_perm(0, v, 0x00010203u); }
+JDA_HD jda_q4_bits jda_q4_load(const uint8_t *scan, uint32_t ix)
+{
+    // (the scan section is 16-byte aligned and JDA_SCAN_PAD zero bytes longer than the scan: 20 bytes from a decoded block's dword stay inside)
+    const jda_u32_alias JDA_GLOBAL *w = JDA_G(const jda_u32_alias, scan) + jda_q4_first_dword(ix);
+    jda_q4_bits B;
+#pragma unroll
+    for (int i = 0; i < 5; i++) B.d[i] = w[i];
+    return B;
+}
+// the block's four samples: row 0 in bytes 0-1, row 1 in bytes 2-3 (jda_idct_2x2's order).  EXACT / trunc: as jda_decode_block_win
+template <bool EXACT>
+JDA_HD uint32_t jda_q4_block(uint32_t ix, int32_t dc, jda_q4_bits B, const uint16_t *ac, const jda_q4_quant &Q, bool dc_only, bool trunc)
+{
+    const uint32_t off = ix & (JDA_INDEX_TRUNC - 1u);
+    const uint32_t p = (ix >> JDA_INDEX_OFF_BITS) * 8u + off;
+    uint32_t cm = (p - 1u) & 31u;                         // bit of d0 consumed last
+    uint32_t d0 = jda_bswap32(B.d[0]), d1 = jda_bswap32(B.d[1]), d2 = jda_bswap32(B.d[2]), d3 = jda_bswap32(B.d[3]), d4 = jda_bswap32(B.d[4]);
+    uint32_t roff = EXACT ? jda_ref_refill(off) : 0u;    // the reference's ulBitOff at the block's first AC symbol
+    int32_t c1 = 0, c8 = 0, c9 = 0;                      // (:2118)
+    // Four trips without a branch: every symbol moves k on by one at least, so four reach the limit of :2117-2119 (k = 5); a lane whose
+    // block ended earlier (EOB, or a symbol that went past the limit) keeps looking symbols up -- in bits that are not its block's any more,
+    // harmless: k >= 5 stores nothing -- instead of leaving the loop, because every way out of it is an exec-mask region on the dependent
+    // chain (peek -> LUT -> position) and the wavefront runs as many trips as its longest block anyway.
+    uint32_t k = dc_only ? 8u : 1u;
+#pragma unroll
+    for (int trip = 0; trip < 4; trip++) {               // (:2223-2265)
+        const uint32_t w = jda_alignbit(d0, d1, 31u - cm);
+        const uint32_t e = ac[jda_bfe(w, w >= 0xfc000000u ? 16u : 22u, 11u)];
+        const uint32_t len = (e >> 12) + 1u, ms = (e >> 8) & 0xfu;
+        k = JDA_AC_STOPS(e) ? 8u : k + ((e >> 1) & 0xfu);    // EOB ends the block; else the run
+        uint32_t m = w << len;
+        const uint32_t n = len + ms;
+        if (EXACT) {
+            roff += n;                                   // the reference's ulBitOff after its magnitude read (:2249-2252)
+            if (roff > 64u && trunc) m &= ~(0xffffffffu >> ((64u + ms - roff) & 31u));      // its window ended inside the magnitude
+            roff = jda_ref_refill(roff);
+        }
+        const int32_t v = (int16_t)jda_extend_top(m, ms);    // (a symbol without a value is ZRL: it goes past the limit, nothing is stored)
+        c1 = k == 1u ? v : c1; c8 = k == 2u ? v : c8; c9 = k == 4u ? v : c9;
+        k++;
+        if (trip < 3) {
+            cm += n;
+            if (cm >= 32u) { d0 = d1; d1 = d2; d2 = d3; d3 = d4; cm -= 32u; }      // (a symbol is 26 bits at most: one step)
+        }
+    }
+    const int32_t a = (int32_t)(int16_t)dc * Q.q0, b = c8 * Q.q8, c = c1 * Q.q1, d = c9 * Q.q9;
+    const int32_t t0 = a + b, t2 = a - b, t1 = c + d, t3 = c - d;
+    return jda_range_limit5(t0 + t1) | (jda_range_limit5(t0 - t1) << 8) | (jda_range_limit5(t2 + t3) << 16) | (jda_range_limit5(t2 - t3) << 24);
+}
+// what a lane does with a tile's samples: output pixel i of the tile's (count * MCU_W / 4) x (MCU_H / 4) pixels, row-major, in passes
+// of 64; a pixel's samples come from the lanes that decoded its blocks (all: every lane's block samples; GPU: ds_bpermute, so every
+// lane runs every pass).  Pixels as JPEGPutMCU* make them at iScaleShift 2 (jda_fetch's shift == 2 cases).
+template <int MODE>
+JDA_HD void jda_q4_store(const jda_dev_desc &D, const jda_strip &S, uint32_t count, uint32_t lane, uint32_t px, const uint32_t *all)
+{
+    typedef jda_mode_traits<MODE> T;
+    const uint32_t mw = (uint32_t)T::MCU_W >> 2, mh = (uint32_t)T::MCU_H >> 2;          // an MCU's pixels: 2 x 2, 4 x 4, 4 x 2, 2 x 4
+    const uint32_t tile_w = count * mw, n_px = tile_w * mh;
+    const uint32_t x_base = S.mcu_x0 * mw, y_base = S.mcu_y * mh;
+    const int pt = D.pixel_type;
+    if (MODE == JDA_MODE_GRAY && pt == JDA_EIGHT_BIT_GRAYSCALE && count == 64u && (x_base & 3u) == 0u && x_base + tile_w <= D.out_w && y_base + mh <= D.out_rows) {
+        // a whole gray tile to 8-bit gray: two lanes share their blocks' rows -- the even one stores row 0 of both, the odd one row 1
+        const uint32_t nb = jda_lane_pull(px, lane ^ 1u, all);
+        const uint32_t v = (lane & 1u) ? jda_perm(px, nb, 0x07060302u) : jda_perm(nb, px, 0x05040100u);
+        uint8_t JDA_GLOBAL *o = JDA_G(uint8_t, D.out) + ((size_t)(y_base + (lane & 1u)) * D.out_pitch + x_base + 2u * (lane & ~1u));
+        *(jda_u32_alias JDA_GLOBAL *)o = v;
+        return;
+    }
+    for (uint32_t i0 = 0; i0 < n_px; i0 += JDA_TILE_THREADS) {
+        const uint32_t i = i0 + lane;
+        uint32_t row = i >= tile_w ? 1u : 0u;
+        if (mh == 4u) row += (i >= 2u * tile_w ? 1u : 0u) + (i >= 3u * tile_w ? 1u : 0u);
+        const uint32_t x = i - jda_umul24(row, tile_w);
+        const uint32_t m = mw == 4u ? x >> 2 : x >> 1, ax = x & (mw - 1u);
+        // the luma block of the MCU and the sample in it; where the chroma sample lies in its block
+        uint32_t q = 0, ys, cs;
+        if (MODE == JDA_MODE_420) { q = (row >> 1) * 2u + (ax >> 1); ys = (row & 1u) * 2u + (ax & 1u); cs = q; }                   // :3664-3748
+        else if (MODE == JDA_MODE_422) { q = ax >> 1; ys = row * 2u + (ax & 1u); cs = row * 2u + q; }                               // :4789-4838
+        else if (MODE == JDA_MODE_440) { q = row >> 1; ys = (row & 1u) * 2u + ax; cs = q * 2u + ax; }                               // :4610-4682
+        else { ys = row * 2u + ax; cs = ys; }
+        const uint32_t yl = (m * (uint32_t)T::NBLK + q) & 63u, cl = (m * (uint32_t)T::NBLK + (uint32_t)T::NLUMA) & 63u;
+        const uint32_t yw = jda_lane_pull(px, yl, all);
+        uint32_t cbw = 0, crw = 0;
+        if (MODE != JDA_MODE_GRAY) { cbw = jda_lane_pull(px, cl, all); crw = jda_lane_pull(px, (cl + 1u) & 63u, all); }
+        const uint32_t X = x_base + x, Y = y_base + row;
+        if (i >= n_px || X >= D.out_w || Y >= D.out_rows) continue;
+        const uint32_t y = (yw >> (8u * ys)) & 0xffu;
+        uint8_t JDA_GLOBAL *rowp = JDA_G(uint8_t, D.out) + (size_t)Y * D.out_pitch;
+        if (pt == JDA_EIGHT_BIT_GRAYSCALE) rowp[X] = (uint8_t)y;
+        else if (MODE == JDA_MODE_GRAY) ((uint16_t JDA_GLOBAL *)rowp)[X] = (uint16_t)jda_gray_565(y, pt != JDA_RGB565_LITTLE_ENDIAN);      // JPEGPutMCUGray
+        else {
+            jda_ycc c;
+            c.y = (int32_t)(y << 12); c.cb = (int32_t)((cbw >> (8u * cs)) & 0xffu); c.cr = (int32_t)((crw >> (8u * cs)) & 0xffu);
+            if (pt == JDA_RGB8888) ((jda_u32_alias JDA_GLOBAL *)rowp)[X] = jda_pixel_rgba(c);
+            else ((uint16_t JDA_GLOBAL *)rowp)[X] = (uint16_t)jda_pixel_565(c, pt == JDA_RGB565_BIG_ENDIAN);
+        }
+    }
+}
+
 #endif // JDA_DEVICE_CORE_H

@@ -593,6 +593,107 @@ static hipError_t launch_dc_thumbnail(const jda_dev_desc *descs, const jda_strip
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1/4 scale (jda_q4_* in jda_device_core.h): a block is its DC value, at most four AC symbols and a 2x2 IDCT -- the persistent decode
+// kernel spent its time on what surrounds that (window staging, slots, lists, one workgroup per CU for its LDS).  Here a workgroup is
+// four wavefronts with the image's tables in LDS and nothing else, so a CU holds as many as its registers allow; it takes a run of the
+// launch list's groups (a group = the tiles the decode kernel's workgroup would take: one image's, so the tables are staged when the
+// image changes and not per group), a wavefront every fourth tile of a group.  Per tile: lane = block -- index entry and DC value, the
+// five dwords of the scan behind the entry, all four tiles' loads asked for before the first is used --, then lane = output pixel.
+#define JDA_Q4_TILES 4u
+template <int MODE>
+__global__ __launch_bounds__(256)
+void jda_quarter_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_groups, uint32_t group_tiles)
+{
+    typedef jda_mode_traits<MODE> T;
+    __shared__ __attribute__((aligned(16))) uint8_t tab[JDA_LT_BYTES];
+    const uint32_t wave = jda_uni32(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t per = n_groups / gridDim.x, rem = n_groups % gridDim.x;
+    const uint32_t g0 = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
+    const uint32_t g_end = g0 + per + (blockIdx.x < rem ? 1u : 0u);
+    uint32_t staged = 0xffffffffu;
+    jda_dev_desc D;
+    jda_lane_pre LP;
+    jda_q4_quant Q;
+    Q.q0 = Q.q1 = Q.q8 = Q.q9 = 0;
+    bool dc_only = false, skip = false;
+    for (uint32_t g = g0; g < g_end; g++) {
+        const uint32_t __attribute__((address_space(4))) *rw = (const uint32_t __attribute__((address_space(4))) *)(uintptr_t)(tiles + (size_t)g * group_tiles);
+        const uint32_t image = rw[0];                                    // (a group is one image's: jda_append_strips pads per image)
+        if (image != staged) {                                           // the same for every wavefront of the workgroup
+            __syncthreads();                                             // nobody reads the old tables any more
+            D = jda_desc_const<0, MODE>(jda_desc_at(descs, image));
+            jda_p0_tables(D, threadIdx.x, 256, tab, true);
+            __syncthreads();
+            jda_lane_prepare<MODE>(LP, D, lane, tab);
+            const int16_t *quant = (const int16_t *)(tab + LP.quant_off);
+            Q.q0 = quant[0]; Q.q1 = quant[1]; Q.q8 = quant[8]; Q.q9 = quant[9];
+            dc_only = (D.pad_[0] & JDA_DESC_DC_ONLY) != 0;               // the DC scan of a progressive file: no AC symbol exists
+            skip = MODE != JDA_MODE_GRAY && D.gray_from_color && LP.chroma;      // :5225-5233 chroma never decoded
+            staged = image;
+        }
+        // this wavefront's tiles of the group: wave, wave + 4, ..
+        jda_strip S[JDA_Q4_TILES];
+        uint32_t cnt[JDA_Q4_TILES], ix[JDA_Q4_TILES];
+        int32_t dc[JDA_Q4_TILES];
+        jda_q4_bits B[JDA_Q4_TILES];
+#pragma unroll
+        for (uint32_t k = 0; k < JDA_Q4_TILES; k++) {
+            const uint32_t t = wave + 4u * k, tt = t < group_tiles ? t : 0u;
+            const uint32_t w1 = rw[4u * tt + 1u], w2 = rw[4u * tt + 2u];
+            S[k].image = image; S[k].mcu_y = (uint16_t)(w1 & 0xffffu); S[k].mcu_x0 = (uint16_t)(w1 >> 16);
+            S[k].count = t < group_tiles ? (uint8_t)(w2 & 0xffu) : (uint8_t)0; S[k].first = 0; S[k].pad_ = 0; S[k].ord = 0;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < JDA_Q4_TILES; k++) {
+            const uint32_t first_mcu = S[k].mcu_y * D.mcus_x + S[k].mcu_x0;
+            cnt[k] = S[k].count;
+            if (first_mcu >= D.n_mcus_ok) cnt[k] = 0;                    // MCUs behind a bad one are not decoded (jpeg.inl:5354-5356)
+            else if (first_mcu + cnt[k] > D.n_mcus_ok) cnt[k] = D.n_mcus_ok - first_mcu;
+            ix[k] = 0; dc[k] = 0;
+            if (lane < cnt[k] * (uint32_t)T::NBLK && !skip) {
+                ix[k] = JDA_G(const uint32_t, D.blk_index)[first_mcu * (uint32_t)T::NBLK + lane];
+                dc[k] = JDA_G(const int16_t, D.blk_dc)[first_mcu * (uint32_t)T::NBLK + lane];
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < JDA_Q4_TILES; k++) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) B[k].d[i] = 0;
+            if (lane < cnt[k] * (uint32_t)T::NBLK && !skip && !dc_only) B[k] = jda_q4_load(D.scan, ix[k]);
+        }
+        const uint16_t *ac = (const uint16_t *)(tab + LP.ac_off);
+#pragma unroll
+        for (uint32_t k = 0; k < JDA_Q4_TILES; k++) {
+            if (cnt[k] == 0) continue;                                   // (uniform: padding, behind the group's end, behind a bad MCU)
+            uint32_t px = 0;
+            const bool active = lane < cnt[k] * (uint32_t)T::NBLK && !skip;
+            const bool trunc = active && (ix[k] & JDA_INDEX_TRUNC) != 0u;
+            // (every lane runs the block code, the idle ones on zeros: it has no branch to skip with)
+            if (__builtin_amdgcn_ballot_w64(trunc) != 0ull) px = jda_q4_block<true>(ix[k], dc[k], B[k], ac, Q, dc_only, trunc);
+            else px = jda_q4_block<false>(ix[k], dc[k], B[k], ac, Q, dc_only, false);
+            jda_q4_store<MODE>(D, S[k], cnt[k], lane, px, nullptr);
+        }
+    }
+}
+template <int MODE>
+static hipError_t launch_quarter(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, uint32_t group_tiles, hipStream_t stream)
+{
+    const uint32_t n_groups = n_tiles / group_tiles;
+    // two rounds of as many workgroups as the GPU holds at once (the registers decide: six or seven of four wavefronts a CU)
+    static const uint32_t resident = []() {
+        int dev = 0, cus = 256, per_cu = 6;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)jda_quarter_tiles<MODE>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 6;
+        return (uint32_t)cus * (uint32_t)per_cu;
+    }();
+    uint32_t grid = resident * 2u;
+    if (grid > n_groups) grid = n_groups;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((jda_quarter_tiles<MODE>), dim3(grid), dim3(256), 0, stream, descs, tiles, n_groups, group_tiles);
+    return hipGetLastError();
+}
+
 // wave-wide maximum / sum of a value of every ACTIVE lane (inactive lanes contribute nothing), the same in every lane
 __device__ __forceinline__ uint32_t jda_wave_max_u32(uint32_t v)
 {
@@ -1303,6 +1404,16 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int
         case (JDA_MODE_422 * 2 + 1) * 2 + 1: return launch_persistent<JDA_MODE_422, true, 1, 1, 1>(descs, tiles, n_tiles, stream);
         case (JDA_MODE_440 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_440, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
         case (JDA_MODE_440 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_440, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (!fast_mul && variant == 3 && big) {           // JDA_LIST_QUARTER: 1/4 scale, a kernel of its own (the list is padded as the large-window kernels')
+        switch (mode) {
+        case JDA_MODE_GRAY: return launch_quarter<JDA_MODE_GRAY>(descs, tiles, n_tiles, jda_lds_layout<JDA_MODE_GRAY, 1>::WAVES, stream);
+        case JDA_MODE_444: return launch_quarter<JDA_MODE_444>(descs, tiles, n_tiles, jda_lds_layout<JDA_MODE_444, 1>::WAVES, stream);
+        case JDA_MODE_420: return launch_quarter<JDA_MODE_420>(descs, tiles, n_tiles, jda_lds_layout<JDA_MODE_420, 1>::WAVES, stream);
+        case JDA_MODE_422: return launch_quarter<JDA_MODE_422>(descs, tiles, n_tiles, jda_lds_layout<JDA_MODE_422, 1>::WAVES, stream);
+        case JDA_MODE_440: return launch_quarter<JDA_MODE_440>(descs, tiles, n_tiles, jda_lds_layout<JDA_MODE_440, 1>::WAVES, stream);
         default: return hipErrorInvalidValue;
         }
     }

@@ -71,9 +71,13 @@ int jda_plain_variant(const jda_dev_desc &D);
 // plain-case kernel exists without the 24-bit multiplies) names the DC thumbnail kernel: 1/8 scale -- also every progressive
 // file's DC scan at its default scale --, whose pixels are the blocks' DC values (jpeg.inl:5146-5154): no scan, no index, no IDCT
 #define JDA_LIST_THUMB(mode) (((((mode) * 2 + 0) * 4 + 3) * 2 + 0) * 2 + 0)
+// .. and the same with big = 1 the 1/4-scale kernel (jda_quarter_tiles): a block is its DC value, <= 4 AC symbols and a 2x2 IDCT
+// (jpeg.inl:2305-2326).  (A strip-major surface at 1/4 stays with the decode kernel, whose colour stage knows the layout.)
+#define JDA_LIST_QUARTER(mode) (((((mode) * 2 + 0) * 4 + 3) * 2 + 1) * 2 + 0)
 inline int jda_list_index(const jda_dev_desc &D, int variant, int big, int cont = 0)
 {
     if (D.scale_shift == 3) return JDA_LIST_THUMB(D.mode);
+    if (D.scale_shift == 2 && D.strip_mcus == 0) return JDA_LIST_QUARTER(D.mode);
     return (((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big) * 2 + cont;
 }
 // P1 in chunks (jda_p1c_*: the lanes of a wavefront share a tile's long blocks through the index's continuation entries) pays where the

@@ -83,6 +83,48 @@ static void run_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles
     }
 }
 
+// the 1/4-scale kernel (jda_quarter_tiles): lane = block for the decode, lane = output pixel for the store
+template <int MODE>
+static void run_quarter_tiles(const jda_dev_desc &D, const std::vector<jda_strip> &tiles)
+{
+    typedef jda_lds_layout<MODE> L;
+    typedef jda_mode_traits<MODE> T;
+    std::vector<uint64_t> tab_store((JDA_LT_BYTES + 7) / 8);
+    uint8_t *tab = (uint8_t *)tab_store.data();
+    for (uint32_t tid = 0; tid < 256; tid++) jda_p0_tables(D, tid, 256, tab, L::LONG_LDS != 0);
+    const bool dc_only = (D.pad_[0] & JDA_DESC_DC_ONLY) != 0;
+    for (size_t ii = 0; ii < tiles.size(); ii++) {
+        const jda_strip &S = tiles[g_reverse_tiles ? tiles.size() - 1 - ii : ii];
+        const uint32_t first_mcu = S.mcu_y * D.mcus_x + S.mcu_x0;
+        uint32_t count = S.count;
+        if (first_mcu >= D.n_mcus_ok) count = 0;
+        else if (first_mcu + count > D.n_mcus_ok) count = D.n_mcus_ok - first_mcu;
+        if (count == 0) continue;
+        uint32_t px[JDA_TILE_THREADS];
+        bool any_trunc = false;
+        for (uint32_t t = 0; t < count * (uint32_t)T::NBLK; t++) any_trunc = any_trunc || (D.blk_index[first_mcu * T::NBLK + t] & JDA_INDEX_TRUNC);
+        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) {
+            px[t] = 0;
+            jda_lane_pre LP;
+            jda_lane_prepare<MODE>(LP, D, t, tab);
+            const bool skip = MODE != JDA_MODE_GRAY && D.gray_from_color && LP.chroma;
+            if (t >= count * (uint32_t)T::NBLK || skip) continue;
+            const int16_t *quant = (const int16_t *)(tab + LP.quant_off);
+            jda_q4_quant Q;
+            Q.q0 = quant[0]; Q.q1 = quant[1]; Q.q8 = quant[8]; Q.q9 = quant[9];
+            const uint32_t ix = D.blk_index[first_mcu * T::NBLK + t];
+            const int32_t dc = D.blk_dc[first_mcu * T::NBLK + t];
+            jda_q4_bits B;
+            memset(&B, 0, sizeof(B));
+            if (!dc_only) B = jda_q4_load(D.scan, ix);
+            const bool trunc = (ix & JDA_INDEX_TRUNC) != 0u;
+            px[t] = any_trunc ? jda_q4_block<true>(ix, dc, B, (const uint16_t *)(tab + LP.ac_off), Q, dc_only, trunc)
+                              : jda_q4_block<false>(ix, dc, B, (const uint16_t *)(tab + LP.ac_off), Q, dc_only, false);
+        }
+        for (uint32_t t = 0; t < JDA_TILE_THREADS; t++) jda_q4_store<MODE>(D, S, count, t, px[t], px);
+    }
+}
+
 extern "C" const uint32_t *jda_image_restart_positions(const jda_image *img, uint32_t *n);
 extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
 extern "C" void jda_image_adopt_prescan(jda_image *img, uint32_t n_mcus_ok, uint32_t max_ac_bits, int32_t max_abs_dc, uint32_t trunc_events);
@@ -325,6 +367,15 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
     D.tables = jda_image_tables(img, &n);
     std::vector<jda_strip> strips;
     jda_append_strips(strips, 0, D.mcus_x, D.mcus_y, D.mode);
+    if (D.scale_shift == 2 && D.strip_mcus == 0) {                    // JDA_LIST_QUARTER (jda_list_index): the 1/4-scale kernel
+        switch (D.mode) {
+        case JDA_MODE_GRAY: run_quarter_tiles<JDA_MODE_GRAY>(D, strips); break;
+        case JDA_MODE_444: run_quarter_tiles<JDA_MODE_444>(D, strips); break;
+        case JDA_MODE_420: run_quarter_tiles<JDA_MODE_420>(D, strips); break;
+        case JDA_MODE_422: run_quarter_tiles<JDA_MODE_422>(D, strips); break;
+        default: run_quarter_tiles<JDA_MODE_440>(D, strips); break;
+        }
+    } else
     switch (D.mode * 2 + (D.fast_mul ? 1 : 0)) {
     case JDA_MODE_GRAY * 2: run_tiles<JDA_MODE_GRAY, false>(D, strips); break;
     case JDA_MODE_GRAY * 2 + 1: run_tiles<JDA_MODE_GRAY, true>(D, strips); break;
