@@ -2924,10 +2924,15 @@ JDA_HD uint32_t jda_q4_first_dword(uint32_t ix)
     return (p - 1u) >> 5;
 }
 JDA_HD uint32_t jda_bswap32(uint32_t v) { return jda_perm(0, v, 0x00010203u); }
-JDA_HD jda_q4_bits jda_q4_load(const uint8_t *scan, uint32_t ix)
+JDA_HD jda_q4_bits jda_q4_load(const uint8_t *scan, uint32_t scan_len, uint32_t ix)
 {
-    // (the scan section is 16-byte aligned and JDA_SCAN_PAD zero bytes longer than the scan: 20 bytes from a decoded block's dword stay inside)
-    const jda_u32_alias JDA_GLOBAL *w = JDA_G(const jda_u32_alias, scan) + jda_q4_first_dword(ix);
+    // (the scan section is 16-byte aligned and JDA_SCAN_PAD zero bytes longer than the scan: 20 bytes from a decoded block's dword stay
+    // inside.  The streamed pipeline launches the decode before the device pre-scan's verdict is read: an image that fails it is decoded
+    // again, but its entries may point anywhere meanwhile -- so the dword is clamped to the section)
+    uint32_t a = jda_q4_first_dword(ix);
+    const uint32_t a_max = (scan_len + JDA_SCAN_PAD - 20u) >> 2;
+    a = a < a_max ? a : a_max;
+    const jda_u32_alias JDA_GLOBAL *w = JDA_G(const jda_u32_alias, scan) + a;
     jda_q4_bits B;
 #pragma unroll
     for (int i = 0; i < 5; i++) B.d[i] = w[i];

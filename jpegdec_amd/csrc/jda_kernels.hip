@@ -660,7 +660,7 @@ void jda_quarter_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *
         for (uint32_t k = 0; k < JDA_Q4_TILES; k++) {
 #pragma unroll
             for (int i = 0; i < 5; i++) B[k].d[i] = 0;
-            if (lane < cnt[k] * (uint32_t)T::NBLK && !skip && !dc_only) B[k] = jda_q4_load(D.scan, ix[k]);
+            if (lane < cnt[k] * (uint32_t)T::NBLK && !skip && !dc_only) B[k] = jda_q4_load(D.scan, D.scan_len, ix[k]);
         }
         const uint16_t *ac = (const uint16_t *)(tab + LP.ac_off);
 #pragma unroll

@@ -116,7 +116,7 @@ static void run_quarter_tiles(const jda_dev_desc &D, const std::vector<jda_strip
             const int32_t dc = D.blk_dc[first_mcu * T::NBLK + t];
             jda_q4_bits B;
             memset(&B, 0, sizeof(B));
-            if (!dc_only) B = jda_q4_load(D.scan, ix);
+            if (!dc_only) B = jda_q4_load(D.scan, D.scan_len, ix);
             const bool trunc = (ix & JDA_INDEX_TRUNC) != 0u;
             px[t] = any_trunc ? jda_q4_block<true>(ix, dc, B, (const uint16_t *)(tab + LP.ac_off), Q, dc_only, trunc)
                               : jda_q4_block<false>(ix, dc, B, (const uint16_t *)(tab + LP.ac_off), Q, dc_only, false);

@@ -205,10 +205,13 @@ def test_pipeline_restart_streams_take_the_segment_walk(gpu_ctx, oracle):
     pipe.close()
 
 
-def test_pipeline_corrupted_scans_decode_like_the_oracle(gpu_ctx, oracle):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_pipeline_corrupted_scans_decode_like_the_oracle(gpu_ctx, oracle, mixed):
     """Random byte corruptions inside the entropy-coded data (the reference's fuzz idea, MacOS/JPEGDEC_Test/main.cpp:262-300), a whole
     batch of them through the device filter, segment walk and decode: the oracle's garbage bit for bit, failure on the same
-    streams -- whether the device's index stood or the image went back to the serial pre-scan."""
+    streams -- whether the device's index stood or the image went back to the serial pre-scan.
+    mixed: pixel type and scale drawn per image.  (The decode is launched before the pre-scan's verdict is read: a kernel must be safe on
+    the index of a stream the walk gave up on -- the 1/4-scale kernel, which reads the scan where the entries point, once was not.)"""
     rng = np.random.default_rng(5)
     jp, nm = [], []
     for name in ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217"):
@@ -232,6 +235,11 @@ def test_pipeline_corrupted_scans_decode_like_the_oracle(gpu_ctx, oracle):
             jp.append(jb); nm.append("%s#%d" % (name, made)); made += 1
     pts = [J.RGB8888] * len(jp)
     opts = [0] * len(jp)
+    if mixed:
+        combos = ((J.RGB565_LE, J.SCALE_QUARTER), (J.GRAY8, J.SCALE_QUARTER), (J.RGB8888, J.SCALE_QUARTER), (J.RGB565_BE, J.SCALE_EIGHTH),
+                  (J.GRAY8, J.SCALE_HALF), (J.RGB8888, J.SCALE_HALF))
+        for i in range(len(jp)):
+            pts[i], opts[i] = combos[int(rng.integers(0, len(combos)))]
     pipe = J.Pipeline(gpu_ctx, max_images=64, depth=2, host_threads=4)
     outs, metas = _surfaces(gpu_ctx, jp, pts, opts)
     st = pipe.wait(pipe.submit(jp, outs, pts, opts))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A longer run of tests/test_gpu_pipeline.py's corruption test (test infrastructure: the oracle is the checker): random byte corruptions
 inside the entropy-coded data of a few files, batches of them through the device filter, segment walk and decode, every surface and status
-against the oracle's.  Usage (GPU box): python tools/gpu_fuzz_pipeline.py [rounds] [seed]"""
+against the oracle's.  Usage (GPU box): python tools/gpu_fuzz_pipeline.py [rounds] [seed] [mixed]
+(mixed: pixel type and scale drawn per image -- the 1/4 and 1/8 kernels and the scaled colour stages see the corrupted streams too)"""
 import os
 import sys
 
@@ -48,6 +49,11 @@ for r in range(rounds):
             jp.append(jb); nm.append("%s#%d.%d" % (name, r, made)); made += 1
     pts = [J.RGB8888] * len(jp)
     opts = [0] * len(jp)
+    if len(sys.argv) > 3 and sys.argv[3] == "mixed":
+        combos = ((J.RGB8888, 0), (J.RGB565_LE, J.SCALE_QUARTER), (J.GRAY8, J.SCALE_QUARTER), (J.RGB8888, J.SCALE_QUARTER), (J.RGB565_BE, J.SCALE_QUARTER),
+                  (J.RGB565_BE, J.SCALE_EIGHTH), (J.GRAY8, J.SCALE_HALF), (J.RGB8888, J.SCALE_HALF))
+        for i in range(len(jp)):
+            pts[i], opts[i] = combos[int(rng.integers(0, len(combos)))]
     outs, metas = _surfaces(ctx, jp, pts, opts)
     inflight.append((pipe.submit(jp, outs, pts, opts), jp, pts, opts, outs, metas, nm))
     if len(inflight) == 3 or r == rounds - 1:                 # three batches in flight: the pre-scan streams really run side by side
