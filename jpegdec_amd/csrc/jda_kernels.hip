@@ -478,7 +478,9 @@ extern "C" hipError_t jda_launch_fill_strips(const jda_strips_params *params, ui
 // tiles of the list (a tile = the decode kernel's: <= 64 consecutive blocks of one MCU row; crop-aware lists stay what they are),
 // lane = block for the load, lane = output pixel for the store; the samples of a pixel's MCU come from their lanes by ds_bpermute.
 // Output as JPEGPutMCU* at bThumbnail: (MCU_W / 8) x (MCU_H / 8) pixels per MCU, chroma shared by the MCU.
+#ifndef JDA_THUMB_TILES
 #define JDA_THUMB_TILES 8u
+#endif
 // what a tile's lanes load: the DC value of lane's block (0 behind the tile's decoded blocks); count: the tile's MCUs that are decoded
 template <int MODE>
 __device__ __forceinline__ int32_t jda_thumb_load(const jda_dev_desc &D, const jda_strip &S, uint32_t lane, uint32_t &count)
@@ -564,6 +566,51 @@ void jda_dc_thumbnail(const jda_dev_desc *__restrict__ descs, const jda_strip *_
         // the run is one image's (all but the runs across an image boundary of the list): every tile's load is asked for before the first is used
         int32_t dcv[JDA_THUMB_TILES];
         uint32_t cnt[JDA_THUMB_TILES];
+        if (MODE == JDA_MODE_GRAY && D.pixel_type == JDA_EIGHT_BIT_GRAYSCALE && JDA_THUMB_TILES % 4u == 0u) {
+            // a gray file to 8-bit gray: four whole tiles side by side are 256 consecutive DC values and 256 consecutive pixels -- a lane
+            // takes four of each (one 8-byte load, one dword store) and makes the samples two at a time in the halves of a word: bits 14:5
+            // of DC x q0 are all ucRangeTable[(DC x q0 >> 5) & 0x3ff] looks at (jpeg.inl:5146-5154), so the 16-bit product is enough
+            typedef unsigned short jda_us2 __attribute__((ext_vector_type(2)));
+            constexpr uint32_t G = JDA_THUMB_TILES / 4u;
+            bool quad[G];
+            uint32_t first[G];
+            uint64_t four[G];
+#pragma unroll
+            for (uint32_t g = 0; g < G; g++) {
+                const jda_strip &A = S[4u * g];
+                first[g] = A.mcu_y * D.mcus_x + A.mcu_x0;
+                bool ok = (first[g] & 3u) == 0u && first[g] + 256u <= D.n_mcus_ok && A.mcu_x0 + 256u <= D.out_w && A.mcu_y < D.out_rows;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) ok = ok && S[4u * g + k].count == 64u && S[4u * g + k].mcu_y == A.mcu_y && S[4u * g + k].mcu_x0 == A.mcu_x0 + 64u * k;
+                quad[g] = ok;
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < G; g++) {
+                four[g] = 0;
+                if (quad[g]) four[g] = JDA_G(const uint64_t, D.blk_dc)[(first[g] >> 2) + lane];
+                else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; k++) dcv[4u * g + k] = jda_thumb_load<MODE>(D, S[4u * g + k], lane, cnt[4u * g + k]);
+                }
+            }
+            const uint32_t qq = ((uint32_t)q0 & 0xffffu) | ((uint32_t)q0 << 16);
+#pragma unroll
+            for (uint32_t g = 0; g < G; g++) {
+                if (quad[g]) {
+                    const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(jda_us2, (uint32_t)four[g]) * __builtin_bit_cast(jda_us2, qq));
+                    const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(jda_us2, (uint32_t)(four[g] >> 32)) * __builtin_bit_cast(jda_us2, qq));
+                    const uint32_t s01 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(p01), 0x00800080u));
+                    const uint32_t s23 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(p23), 0x00800080u));
+                    uint8_t JDA_GLOBAL *o = JDA_G(uint8_t, D.out) + ((size_t)S[4u * g].mcu_y * D.out_pitch + S[4u * g].mcu_x0 + 4u * lane);
+                    *(jda_u32_alias JDA_GLOBAL *)o = s01 | (s23 << 16);
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; k++)
+                        if (cnt[4u * g + k]) jda_thumb_store<MODE>(D, S[4u * g + k], lane, cnt[4u * g + k], dcv[4u * g + k], q0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (uint32_t k = 0; k < JDA_THUMB_TILES; k++) dcv[k] = jda_thumb_load<MODE>(D, S[k], lane, cnt[k]);
 #pragma unroll

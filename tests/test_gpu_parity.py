@@ -44,6 +44,25 @@ def test_progressive_thumbnails(name, gpu_ctx, oracle):
         assert e.value.code == 3
 
 
+@pytest.mark.parametrize("w,h", [(2304, 24), (2048, 8), (4160, 16), (1600, 16)])
+def test_wide_gray_thumbnails(w, h, gpu_ctx, oracle):
+    """1/8 and 1/4 of gray files wide enough for the kernels' whole-tile paths (jda_dc_thumbnail: four whole tiles side by side as packed
+    16-bit products, a dword per lane; jda_quarter_tiles: two lanes share a store), with the ragged tiles at the right edge beside them,
+    and the same files cut short by a damaged byte (the MCUs behind the bad one stay as they were, jpeg.inl:5354-5356)."""
+    from jpegdec_amd.synth import synth_jpeg
+    jpeg = synth_jpeg(w, h, "gray", seed=w)
+    bad = bytearray(jpeg)
+    sos = jpeg.index(b"\xff\xda")
+    bad[sos + 14 + (len(jpeg) - sos) * 2 // 3] ^= 0x5a
+    for jb in (jpeg, bytes(bad)):
+        for pt, opt in ((J.GRAY8, J.SCALE_EIGHTH), (J.GRAY8, J.SCALE_QUARTER), (J.RGB565_LE, J.SCALE_EIGHTH), (J.RGB565_BE, J.SCALE_QUARTER)):
+            orc, want, err = oracle.decode_canvas(jb, pt, opt)
+            rc, got, g = J.decode_to_host(gpu_ctx, jb, pt, opt)
+            assert (rc == 0) == (orc == 1), (w, h, pt, opt, rc, orc, err)
+            if orc == 1:
+                assert np.array_equal(got, want), (w, h, pt, opt, int(np.count_nonzero(got != want)))
+
+
 def test_matches_real_reference_when_present(gpu_ctx, ref_scalar):
     """Same comparison against the unmodified reference (scalar integer build) if oracle/_ref travelled."""
     for name in ("c420_333x217", "c444_256x256_q100_opt", "gray_64x64_rst3", "c420_1280x720"):
