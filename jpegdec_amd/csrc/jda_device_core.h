@@ -343,13 +343,15 @@ JDA_HD jda_chunks<NCH> jda_window_load(const uint8_t JDA_GLOBAL *scan, uint32_t 
 {
     jda_chunks<NCH> r;
     const jda_chunk16_alias JDA_GLOBAL *src = (const jda_chunk16_alias JDA_GLOBAL *)(scan + win_lo);
+    // Every lane loads: one whose chunk lies behind the slice reads the slice's last chunk again (jda_window_store stores what belongs
+    // to the window only).  A load under a lane condition, merged with zeros for the others, came out of the compiler as load -> wait ->
+    // copy: the wavefront sat out the load's latency where the column stage was meant to cover it.
+    const uint32_t n16 = win_len >> 4, last = n16 ? n16 - 1u : 0u;
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
-        r.c[k].w[0] = r.c[k].w[1] = r.c[k].w[2] = r.c[k].w[3] = 0;
-        if (lane + 64u * (uint32_t)k < (win_len >> 4)) {
-            const jda_chunk16_alias v = src[lane + 64u * (uint32_t)k];
-            r.c[k].w[0] = v.w[0]; r.c[k].w[1] = v.w[1]; r.c[k].w[2] = v.w[2]; r.c[k].w[3] = v.w[3];
-        }
+        const uint32_t i = lane + 64u * (uint32_t)k;
+        const jda_chunk16_alias v = src[i < last ? i : last];
+        r.c[k].w[0] = v.w[0]; r.c[k].w[1] = v.w[1]; r.c[k].w[2] = v.w[2]; r.c[k].w[3] = v.w[3];
     }
     return r;
 }

@@ -351,9 +351,6 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // stage C: index entries are here -> window bounds -> the next tile's scan slice (HBM -> registers),
         // in flight during the column stage
         jda_tile_ctx Cn = C;
-        chunks_t chunk;
-#pragma unroll
-        for (int k = 0; k < L::WIN_CHUNKS; k++) chunk.c[k].w[0] = chunk.c[k].w[1] = chunk.c[k].w[2] = chunk.c[k].w[3] = 0;
         // the index loads and the record have landed: settle their waits HERE.  Left to the compiler, the record's wait
         // lands after P4 (where it is consumed) as s_waitcnt vmcnt(0) -- the counter is shared with stores on gfx9, so the
         // wavefront would sit out the write acknowledgements of its own tile before starting the next one
@@ -364,8 +361,10 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
             Cn.win_lo = __builtin_amdgcn_readfirstlane(Cn.win_lo);
             Cn.win_len = __builtin_amdgcn_readfirstlane(Cn.win_len);
-            chunk = jda_window_load<L::WIN_CHUNKS>(JDA_G(const uint8_t, D.scan), Cn.win_lo, Cn.win_len, lane);
         }
+        // (asked for whether or not a next tile of this image exists -- then it is this tile's slice once more, and nothing is stored:
+        // a load under a condition is a load the compiler waits for where it merges the two paths)
+        chunks_t chunk = jda_window_load<L::WIN_CHUNKS>(JDA_G(const uint8_t, D.scan), Cn.win_lo, Cn.win_len, lane);
 
         JDA_PTRACE(3);
         if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 4)) {
