@@ -197,6 +197,19 @@ JDA_HD uint32_t jda_pk_sub16(uint32_t a, uint32_t b)
     return ((a - b) & 0xffffu) | (((a & 0xffff0000u) - (b & 0xffff0000u)) & 0xffff0000u);
 #endif
 }
+// a.lo + b.hi and a.hi + b.hi (v_pk_add_u16 with op_sel: the second operand's UPPER half feeds both lanes -- a value that sits in
+// bits 31:16 of a word is added to a pixel pair without being copied into the lower half first)
+JDA_HD uint32_t jda_pk_add16_bhi(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    const uint32_t h = b >> 16;
+    return ((a + h) & 0xffffu) | ((a + (h << 16)) & 0xffff0000u);
+#endif
+}
 // per 16-bit lane: the sign-extended 10-bit field at bits 14:5  (v_pk_lshlrev_b16 1, v_pk_ashrrev_i16 6)
 JDA_HD uint32_t jda_pk_sext10_at5(uint32_t a)
 {
@@ -600,7 +613,15 @@ JDA_HD uint32_t jda_decode_block_win(uint32_t pos, uint32_t off, const uint8_t *
     uint32_t roff = EXACT ? jda_ref_refill(off) : 0u;   // the reference's ulBitOff at the block's first AC symbol
     // (the pre-scan decoded the DC symbol, jpeg.inl:2129-2165: the entry points behind it, the value rides on the block's clearing)
     if (LIMIT == 64 && zero_fill) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (the block's address in ONE register the compiler cannot see through: sixteen stores at offsets 0 .. 120 from it -- left to
+        // itself it folds the wavefront's constant part of the address into every store and adds it back seven times)
+        uint32_t za = JDA_LDS_A32(coef);
+        asm volatile("" : "+v"(za));
+        jda_u64_alias __attribute__((address_space(3))) *z = (jda_u64_alias __attribute__((address_space(3))) *)za;
+#else
         jda_u64_alias *z = (jda_u64_alias *)coef;
+#endif
         z[0] = (uint64_t)(uint16_t)dc;
 #pragma unroll
         for (int i = 1; i < 16; i++) z[i] = 0;
@@ -2194,18 +2215,6 @@ JDA_HD jda_chroma2 jda_chroma_terms16(uint32_t cb8, uint32_t cr8)
     return t;
 }
 JDA_HD uint32_t jda_pack_hi16(uint32_t lo, uint32_t hi) { return jda_perm(hi, lo, 0x07060302u); }   // {hi[31:16], lo[31:16]}
-JDA_HD jda_chroma2 jda_chroma_terms_dup(uint32_t cb8, uint32_t cr8)
-{
-    const int32_t cb = (int32_t)cb8, cr = (int32_t)cr8;
-    const uint32_t r16 = (uint32_t)(16 * 5742 * cr - 16 * 5742 * 128);
-    const uint32_t g16 = (uint32_t)(-16 * 1409 * cb - 16 * 2925 * cr + 16 * (1409 + 2925) * 128);
-    const uint32_t b16 = (uint32_t)(16 * 7258 * cb - 16 * 7258 * 128);
-    jda_chroma2 t;                                        // (dup of bits 31:16)
-    t.r = jda_perm(0, r16, 0x03020302u);
-    t.g = jda_perm(0, g16, 0x03020302u);
-    t.b = jda_perm(0, b16, 0x03020302u);
-    return t;
-}
 template <int PT>
 JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t)
 {
@@ -2239,6 +2248,16 @@ JDA_HD void jda_rgba_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t tb,
     px1 = jda_perm(b2, rg, 0x0d050302u);                          // [R1, G1, B1, 0xff]
 }
 
+// the same with the chroma terms where jda_chroma_terms16 leaves them: in bits 31:16 of their words, for both pixels of the pair
+JDA_HD void jda_rgba_pair_t16(uint32_t ypair, const jda_chroma2 &t, uint32_t &px0, uint32_t &px1)
+{
+    const uint32_t r2 = jda_sat_pk_u8(jda_pk_add16_bhi(ypair, t.r));
+    const uint32_t g2 = jda_sat_pk_u8(jda_pk_add16_bhi(ypair, t.g));
+    const uint32_t b2 = jda_sat_pk_u8(jda_pk_add16_bhi(ypair, t.b));
+    const uint32_t rg = jda_perm(g2, r2, 0x05010400u);
+    px0 = jda_perm(b2, rg, 0x0d040100u);
+    px1 = jda_perm(b2, rg, 0x0d050302u);
+}
 // per 16-bit lane: clamp a signed value to 0..255 (v_pk_max_i16, v_pk_min_i16)
 JDA_HD uint32_t jda_pk_clamp255(uint32_t a)
 {
@@ -2266,6 +2285,17 @@ JDA_HD uint32_t jda_565_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t 
     const uint32_t b2 = jda_pk_clamp255(jda_pk_add16(ypair, tb));
     uint32_t v = ((r2 & 0x00f800f8u) << 8) | ((g2 & 0x00fc00fcu) << 3) | ((b2 >> 3) & 0x001f001fu);
     if (PT == JDA_RGB565_BIG_ENDIAN) v = jda_perm(0, v, 0x02030001u);      // swap the bytes of each pixel (:3149)
+    return v;
+}
+
+template <int PT>
+JDA_HD uint32_t jda_565_pair_t16(uint32_t ypair, const jda_chroma2 &t)
+{
+    const uint32_t r2 = jda_pk_clamp255(jda_pk_add16_bhi(ypair, t.r));
+    const uint32_t g2 = jda_pk_clamp255(jda_pk_add16_bhi(ypair, t.g));
+    const uint32_t b2 = jda_pk_clamp255(jda_pk_add16_bhi(ypair, t.b));
+    uint32_t v = ((r2 & 0x00f800f8u) << 8) | ((g2 & 0x00fc00fcu) << 3) | ((b2 >> 3) & 0x001f001fu);
+    if (PT == JDA_RGB565_BIG_ENDIAN) v = jda_perm(0, v, 0x02030001u);
     return v;
 }
 
@@ -2309,18 +2339,20 @@ JDA_HD void jda_p4_precompute_444(jda_p4_pre &P, uint32_t t, uint32_t plane_stri
 template <int PT>
 JDA_HD void jda_p4_420_item(uint32_t ya, uint32_t yb, uint32_t cb2, uint32_t cr2, uint32_t v0[4], uint32_t v1[4])
 {
-    const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
-    const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
+    // (a chroma sample's three terms serve the two pixels of a pair in both rows: they stay in the upper halves of their words, the
+    // packed adds pick them up there -- six byte permutes an item less than copying each into both halves first)
+    const jda_chroma2 d0 = jda_chroma_terms16(cb2 & 255u, cr2 & 255u);
+    const jda_chroma2 d1 = jda_chroma_terms16(cb2 >> 8, cr2 >> 8);
     if (PT == JDA_RGB8888) {
-        jda_rgba_pair(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b, v0[0], v0[1]);
-        jda_rgba_pair(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b, v0[2], v0[3]);
-        jda_rgba_pair(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b, v1[0], v1[1]);
-        jda_rgba_pair(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b, v1[2], v1[3]);
+        jda_rgba_pair_t16(jda_perm(0, ya, 0x0c010c00u), d0, v0[0], v0[1]);
+        jda_rgba_pair_t16(jda_perm(0, ya, 0x0c030c02u), d1, v0[2], v0[3]);
+        jda_rgba_pair_t16(jda_perm(0, yb, 0x0c010c00u), d0, v1[0], v1[1]);
+        jda_rgba_pair_t16(jda_perm(0, yb, 0x0c030c02u), d1, v1[2], v1[3]);
     } else {                                                  // RGB565: v[0], v[1] hold pixel pairs
-        v0[0] = jda_565_pair<PT>(jda_perm(0, ya, 0x0c010c00u), d0.r, d0.g, d0.b);
-        v0[1] = jda_565_pair<PT>(jda_perm(0, ya, 0x0c030c02u), d1.r, d1.g, d1.b);
-        v1[0] = jda_565_pair<PT>(jda_perm(0, yb, 0x0c010c00u), d0.r, d0.g, d0.b);
-        v1[1] = jda_565_pair<PT>(jda_perm(0, yb, 0x0c030c02u), d1.r, d1.g, d1.b);
+        v0[0] = jda_565_pair_t16<PT>(jda_perm(0, ya, 0x0c010c00u), d0);
+        v0[1] = jda_565_pair_t16<PT>(jda_perm(0, ya, 0x0c030c02u), d1);
+        v1[0] = jda_565_pair_t16<PT>(jda_perm(0, yb, 0x0c010c00u), d0);
+        v1[1] = jda_565_pair_t16<PT>(jda_perm(0, yb, 0x0c030c02u), d1);
         v0[2] = v0[3] = v1[2] = v1[3] = 0;
     }
 }
@@ -2480,15 +2512,15 @@ JDA_HD void jda_p4_422_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint32_t cb2 = *(const uint16_t *)(plane_base + co), cr2 = *(const uint16_t *)(plane_base + co + JDA_COEF_STRIDE);
         uint32_t v[4];
         if (PT == JDA_RGB8888) {
-            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
-            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
-            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), d0.r, d0.g, d0.b, v[0], v[1]);
-            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), d1.r, d1.g, d1.b, v[2], v[3]);
+            const jda_chroma2 d0 = jda_chroma_terms16(cb2 & 255u, cr2 & 255u);
+            const jda_chroma2 d1 = jda_chroma_terms16(cb2 >> 8, cr2 >> 8);
+            jda_rgba_pair_t16(jda_perm(0, y, 0x0c010c00u), d0, v[0], v[1]);
+            jda_rgba_pair_t16(jda_perm(0, y, 0x0c030c02u), d1, v[2], v[3]);
         } else {
-            const jda_chroma2 d0 = jda_chroma_terms_dup(cb2 & 255u, cr2 & 255u);
-            const jda_chroma2 d1 = jda_chroma_terms_dup(cb2 >> 8, cr2 >> 8);
-            const uint32_t a01 = jda_565_pair<PT>(jda_perm(0, y, 0x0c010c00u), d0.r, d0.g, d0.b);
-            const uint32_t a23 = jda_565_pair<PT>(jda_perm(0, y, 0x0c030c02u), d1.r, d1.g, d1.b);
+            const jda_chroma2 d0 = jda_chroma_terms16(cb2 & 255u, cr2 & 255u);
+            const jda_chroma2 d1 = jda_chroma_terms16(cb2 >> 8, cr2 >> 8);
+            const uint32_t a01 = jda_565_pair_t16<PT>(jda_perm(0, y, 0x0c010c00u), d0);
+            const uint32_t a23 = jda_565_pair_t16<PT>(jda_perm(0, y, 0x0c030c02u), d1);
             v[0] = a01 & 0xffffu; v[1] = a01 >> 16; v[2] = a23 & 0xffffu; v[3] = a23 >> 16;
         }
         jda_store4<PT, CLIP>(out + (size_t)Y * D.out_pitch, X, D.out_w, v);
