@@ -702,12 +702,22 @@ void jda_quarter_tiles(const jda_dev_desc *__restrict__ descs, const jda_strip *
                 dc[k] = JDA_G(const int16_t, D.blk_dc)[first_mcu * (uint32_t)T::NBLK + lane];
             }
         }
+        // (every lane loads, the idle ones wherever the clamp sends them: a load under a lane condition is merged with the other lanes'
+        // zeros by a copy, and the copy waits.  All twenty dwords are settled in one place, before the first tile is worked on:
+        // loads and stores share a counter, and a wait the compiler places later would sit behind the stores of the tiles before)
+        if (!dc_only) {
 #pragma unroll
-        for (uint32_t k = 0; k < JDA_Q4_TILES; k++) {
+            for (uint32_t k = 0; k < JDA_Q4_TILES; k++) B[k] = jda_q4_load(D.scan, D.scan_len, ix[k]);
+        } else {
 #pragma unroll
-            for (int i = 0; i < 5; i++) B[k].d[i] = 0;
-            if (lane < cnt[k] * (uint32_t)T::NBLK && !skip && !dc_only) B[k] = jda_q4_load(D.scan, D.scan_len, ix[k]);
+            for (uint32_t k = 0; k < JDA_Q4_TILES; k++)
+#pragma unroll
+                for (int i = 0; i < 5; i++) B[k].d[i] = 0;
         }
+        asm volatile("" : "+v"(B[0].d[0]), "+v"(B[0].d[1]), "+v"(B[0].d[2]), "+v"(B[0].d[3]), "+v"(B[0].d[4]),
+                          "+v"(B[1].d[0]), "+v"(B[1].d[1]), "+v"(B[1].d[2]), "+v"(B[1].d[3]), "+v"(B[1].d[4]));
+        asm volatile("" : "+v"(B[2].d[0]), "+v"(B[2].d[1]), "+v"(B[2].d[2]), "+v"(B[2].d[3]), "+v"(B[2].d[4]),
+                          "+v"(B[3].d[0]), "+v"(B[3].d[1]), "+v"(B[3].d[2]), "+v"(B[3].d[3]), "+v"(B[3].d[4]));
         const uint16_t *ac = (const uint16_t *)(tab + LP.ac_off);
 #pragma unroll
         for (uint32_t k = 0; k < JDA_Q4_TILES; k++) {
