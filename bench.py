@@ -482,7 +482,9 @@ def run(args, J, out=sys.stdout):
         surf += extra
         outs_of = [[(base + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(eb)] for base in surf]
         have_pinned = hasattr(J, "PinnedFiles")
-        hot = J.PinnedFiles(pool) if have_pinned else None
+        # every image of a batch has a page-locked buffer of its own, as a loader's arena has (copies of the distinct files, side by side:
+        # one copy command a batch; 64 images pointing into 16 buffers would be 64 runs that cannot be joined)
+        hot = J.PinnedFiles([pool[k] for k in picks]) if have_pinned else None
 
         def e2e_run(host_threads, batches, source):
             """source: "pinned" (hot: the same page-locked files every batch), "pageable" (Python bytes through the mirror),
@@ -492,7 +494,7 @@ def run(args, J, out=sys.stdout):
                 packed = [pipe.pack([pool[k] for k in picks], o, [pt] * eb, [args.options] * eb) for o in outs_of]
                 flags, n_sets = 0, len(packed)
             elif source == "pinned":
-                packed = [pipe.pack_pinned(hot, picks, o, [pt] * eb, [args.options] * eb) for o in outs_of]
+                packed = [pipe.pack_pinned(hot, list(range(eb)), o, [pt] * eb, [args.options] * eb) for o in outs_of]
                 flags, n_sets = J.SUBMIT_PINNED_INPUT, len(packed)
             else:                                   # cold: batch k reads copies the copy engine has not seen for len(source.addrs) / eb batches
                 n_sets = max(depth, len(source.addrs) // eb)
@@ -534,7 +536,7 @@ def run(args, J, out=sys.stdout):
             e2e_run(main_threads, 2 * args.e2e_batches, "pinned")
         e2e = e2e_run(main_threads, args.e2e_batches, "pinned")
         e2e.update({"images_per_batch": eb, "depth": depth, "distinct_images": min(e2e_distinct, eb),
-                    "input": "page-locked, JDA_SUBMIT_PINNED_INPUT (files >= 128 KB: DMA from where they lie)" if have_pinned else "pageable",
+                    "input": "page-locked, JDA_SUBMIT_PINNED_INPUT: a buffer per image of the batch, side by side (DMA from where they lie, one copy command a batch)" if have_pinned else "pageable",
                     "what": "files in host memory -> pixels resident in HBM through jda_pipeline: host parse + tables, H2D of the unfiltered scans, "
                             "device marker filter + per-block index + decode, batches overlapped; whole job, all ranks; the same files are submitted every batch"})
         if have_pinned and rank == 0 and world == 1 and not args.no_e2e_sweep:
