@@ -230,13 +230,30 @@ def test_crop_aware_decode_launches_only_the_crop(gpu_ctx):
     xs = [x for x in range(p.info.mcus_x) if not (x * mw < cx or x * mw > cx + cw)]
     rect = (xs[0], (cy + mh - 1) // mh, xs[-1] + 1, min(p.info.mcus_y, (cy + ch + mh - 1) // mh))
     for pt in (RGB8888, RGB565_LE, GRAY8):
-        rc0, full, g = J.decode_to_host(gpu_ctx, jpeg, pt, 0)
-        rc1, part, g1, tiles = J.binding.decode_to_host_rect(gpu_ctx, jpeg, pt, 0, rect)
-        assert rc0 == rc1 == 0 and tiles[1] == 30 and tiles[0] <= 0.4 * tiles[1], tiles
-        bpp = g["bpp"]
-        ys, xb = slice(rect[1] * mh, rect[3] * mh), slice(rect[0] * mw * bpp, rect[2] * mw * bpp)
-        assert np.array_equal(part[ys, xb], full[ys, xb])
-        outside = part.copy()
-        outside[ys, xb] = 0
-        assert not outside.any()
+        for opt, sh in ((0, 0), (J.SCALE_HALF, 1), (J.SCALE_QUARTER, 2), (J.SCALE_EIGHTH, 3)):      # (the 1/4 and 1/8 kernels take the same tile lists)
+            rc0, full, g = J.decode_to_host(gpu_ctx, jpeg, pt, opt)
+            rc1, part, g1, tiles = J.binding.decode_to_host_rect(gpu_ctx, jpeg, pt, opt, rect)
+            assert rc0 == rc1 == 0 and tiles[1] == 30 and tiles[0] <= 0.4 * tiles[1], tiles
+            bpp = g["bpp"]
+            ys, xb = slice(rect[1] * (mh >> sh), rect[3] * (mh >> sh)), slice(rect[0] * (mw >> sh) * bpp, rect[2] * (mw >> sh) * bpp)
+            assert np.array_equal(part[ys, xb], full[ys, xb]), (pt, opt)
+            outside = part.copy()
+            outside[ys, xb] = 0
+            assert not outside.any(), (pt, opt)
     p.close()
+    # a gray file wide enough for whole tiles that start off a tile boundary (and off a 4-pixel one): the 1/4-scale kernel's shared store
+    # and the DC thumbnail kernel's packed path must hand over to their general paths
+    from jpegdec_amd.synth import synth_jpeg
+    wide = synth_jpeg(2304, 40, "gray", seed=77)
+    for x0 in (1, 2, 64, 67):
+        rect = (x0, 1, x0 + 200, 4)
+        for pt, opt, sh in ((GRAY8, J.SCALE_QUARTER, 2), (GRAY8, J.SCALE_EIGHTH, 3), (RGB565_LE, J.SCALE_QUARTER, 2), (GRAY8, 0, 0)):
+            rc0, full, g = J.decode_to_host(gpu_ctx, wide, pt, opt)
+            rc1, part, g1, tiles = J.binding.decode_to_host_rect(gpu_ctx, wide, pt, opt, rect)
+            assert rc0 == rc1 == 0
+            bpp = g["bpp"]
+            ys, xb = slice(rect[1] * (8 >> sh), rect[3] * (8 >> sh)), slice(rect[0] * (8 >> sh) * bpp, rect[2] * (8 >> sh) * bpp)
+            assert np.array_equal(part[ys, xb], full[ys, xb]), (x0, pt, opt)
+            outside = part.copy()
+            outside[ys, xb] = 0
+            assert not outside.any(), (x0, pt, opt)
