@@ -1007,11 +1007,8 @@ JDA_HD uint32_t jda_output_pixel(const uint8_t *planes, uint32_t px, uint32_t py
 // State at a symbol boundary (after the reference's bottom-of-loop refill, before its next top-of-loop refill):
 //   bits 5:0 bit offset from the segment's first bit (entry: how far the previous segment's last symbol reached in),
 //   bits 8:6 block within the MCU, bits 14:9 zigzag position k (0 = the next symbol is a DC code).
-#ifndef JDA_SEG_BYTES
-#define JDA_SEG_BYTES 256u
-#endif
 #define JDA_SEG_BITS  (JDA_SEG_BYTES * 8u)
-#define JDA_SEG_SLOT  268u           // bytes a lane reads: its segment + 12 bytes of the next; 67 dwords per lane in LDS (odd: no bank conflicts)
+#define JDA_SEG_SLOT  (JDA_SEG_BYTES + 12u)           // bytes a lane reads: its segment + 12 bytes of the next; 67 dwords per lane in LDS (odd: no bank conflicts)
 #define JDA_SEG_DEAD  0x7fffffffu    // state of a walk that met an invalid code (bit 31 is the rounds' "changed" mark)
 #define JDA_SEG_CHANGED 0x80000000u // entry-state word: "differs from the previous round's" (the walker's own bits are 14:0)
 enum { JDA_SEG_SPEC = 0 /* round 0: the exit state only */, JDA_SEG_RECORD = 4 /* + the segment's sums, one record per block start, truncation candidates (jda_segscan_finalize) */ };
@@ -1130,7 +1127,7 @@ JDA_HD uint32_t jda_seg_reader_peek(jda_seg_reader &R, uint32_t p)
     return (uint32_t)((v << (p & 31u)) >> 32);
 }
 JDA_HD bool jda_seg_reader_holds(const jda_seg_reader &R, uint32_t p) { return (p >> 5) - R.base <= 3u; }
-#define JDA_SEG_READ_DWORDS 68u     // dwords of the scan a walk may touch from its segment's start (64 + the window's reach)
+#define JDA_SEG_READ_DWORDS (JDA_SEG_BYTES / 4u + 4u)     // dwords of the scan a walk may touch from its segment's start (64 + the window's reach)
 
 // The walks' DC entries: the reference's DC LUT (jpeg.inl:1098-1152) re-laid out like the AC entries -- (code length - 1) << 12 |
 // SSSS << 8 | folded -- so that one lookup serves a DC and an AC symbol alike.  "folded" (bit 0): the reference takes code

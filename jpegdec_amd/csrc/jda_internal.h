@@ -158,10 +158,13 @@ struct jda_strips_params {
 // can start blocks.  mcu_min_bits: the fewest bits an MCU of the image can take -- per block the shortest DC code + the shorter of
 // the EOB code and four of the shortest AC codes (63 coefficients take at least four symbols) -- from the DHT segments
 // (jda_frontend.cpp).  A multiple of four (records are stored in 16-byte groups).
+#ifndef JDA_SEG_BYTES
+#define JDA_SEG_BYTES 256u           // the device pre-scan's segment: one lane walks one (jda_device_core.h)
+#endif
 static inline uint32_t jda_record_cap(uint32_t mcu_min_bits, uint32_t nblocks)
 {
     if (mcu_min_bits < 2u * nblocks) mcu_min_bits = 2u * nblocks;
-    return ((2048u / mcu_min_bits + 2u) * nblocks + 4u + 3u) & ~3u;
+    return (((JDA_SEG_BYTES * 8u) / mcu_min_bits + 2u) * nblocks + 4u + 3u) & ~3u;
 }
 
 // What the host makes of one file when the GPU does everything else (jda_pipeline): see jda_front_prepare in jda_frontend.cpp

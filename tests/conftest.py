@@ -71,6 +71,7 @@ def hostsim(built_checkers):
     """tests/hostsim: the kernels' per-lane logic compiled for the CPU (a wave emulator; test infrastructure only)."""
     import ctypes as C
 
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "hostsim", "libjda_hostsim.so"))
+    # (JDA_HOSTSIM_LIBRARY: another build of the emulator, e.g. one with -DJDA_SEG_BYTES=64u)
+    lib = C.CDLL(os.environ.get("JDA_HOSTSIM_LIBRARY") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "hostsim", "libjda_hostsim.so"))
     lib.hostsim_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     return lib
