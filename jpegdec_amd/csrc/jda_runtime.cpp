@@ -45,7 +45,7 @@ int jda_plain_variant(const jda_dev_desc &D)
 int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uint32_t tiles_over_small)
 {
     static const int forced = []() { const char *e = JDA_LAB_ENV("JDA_BIG_WINDOW"); return e ? atoi(e) : -1; }();
-    if (D.scale_shift == 3) return 0;                             // JDA_LIST_THUMB
+    if (D.scale_shift == 3) return 0;                             // JDA_LIST_THUMB (or, strip-major, the decode kernel without a window)
     if (D.scale_shift == 2 && D.strip_mcus == 0) return 1;        // JDA_LIST_QUARTER: its lists are padded as the large-window kernels' (no window is staged)
     if (!D.fast_mul || variant > 1) return 0;
     if (variant == 1 && D.mode == JDA_MODE_GRAY) return 0;

@@ -76,8 +76,10 @@ int jda_plain_variant(const jda_dev_desc &D);
 #define JDA_LIST_QUARTER(mode) (((((mode) * 2 + 0) * 4 + 3) * 2 + 1) * 2 + 0)
 inline int jda_list_index(const jda_dev_desc &D, int variant, int big, int cont = 0)
 {
-    if (D.scale_shift == 3) return JDA_LIST_THUMB(D.mode);
-    if (D.scale_shift == 2 && D.strip_mcus == 0) return JDA_LIST_QUARTER(D.mode);
+    if (D.strip_mcus == 0) {                                      // (a strip-major surface stays with the decode kernel, whose colour stage knows the layout)
+        if (D.scale_shift == 3) return JDA_LIST_THUMB(D.mode);
+        if (D.scale_shift == 2) return JDA_LIST_QUARTER(D.mode);
+    }
     return (((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big) * 2 + cont;
 }
 // P1 in chunks (jda_p1c_*: the lanes of a wavefront share a tile's long blocks through the index's continuation entries) pays where the

@@ -5,7 +5,7 @@ import numpy as np
 from tests.cases import jpeg_for
 
 RGB565_LE, RGB565_BE, RGB8888, GRAY8 = 0, 1, 2, 3
-SCALE_HALF, USES_DMA = 2, 128
+SCALE_HALF, SCALE_QUARTER, SCALE_EIGHTH, USES_DMA = 2, 4, 8, 128
 
 
 def check_strip_major_decodes(product, ref):
@@ -21,7 +21,12 @@ def check_strip_major_decodes(product, ref):
     bad[at:at + 48] = bytes((i * 37 + 11) & 0xFF for i in range(48))
     runs = [("c420", RGB8888, 0, {}), ("c420", RGB565_LE, 0, {}), ("c420", RGB565_BE, USES_DMA, {}), ("c420", GRAY8, 0, {}),
             ("c420", RGB8888, 0, {"max_mcus": 3}), ("c420", RGB8888, 0, {"xoff": 5, "yoff": 3}), ("c420", RGB8888, SCALE_HALF, {}),
-            ("c444", RGB8888, 0, {}), ("c444", RGB565_LE, 0, {}), ("c422", RGB8888, 0, {}), ("gray", GRAY8, 0, {}), ("gray", RGB565_LE, 0, {})]
+            ("c444", RGB8888, 0, {}), ("c444", RGB565_LE, 0, {}), ("c422", RGB8888, 0, {}), ("gray", GRAY8, 0, {}), ("gray", RGB565_LE, 0, {}),
+            # scaled outputs that are still 2 MB and more: 1/4 and 1/8 have kernels of their own for row-major surfaces, a strip-major one
+            # stays with the decode kernel
+            ("wide", RGB8888, SCALE_QUARTER, {}), ("wide", RGB565_LE, SCALE_QUARTER, {}), ("huge", RGB8888, SCALE_EIGHTH, {})]
+    big["wide"] = synth_jpeg(4096, 2048, "4:2:0", seed=9, quality=80)
+    big["huge"] = synth_jpeg(8192, 4096, "4:2:0", seed=10, quality=60)
     n = 0
     for name, pt, opt, kw in runs:
         a = product.decode_cb(big[name], pt, opt, want_log=True, **kw)
