@@ -1641,6 +1641,9 @@ JDA_HD jda_tile_ctx jda_tile_setup_from(const jda_dev_desc &D, const jda_strip &
         const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
+        // (the slice is asked for by every lane, whatever its length -- jda_window_load --, so an empty one must still start inside the
+        // scan: the streamed pipeline launches a decode before the pre-scan's verdict, the entries of a damaged stream may point anywhere)
+        if (C.win_len == 0) C.win_lo = 0;
         C.win_need = C.win_len;
         if (C.win_len > win_cap) C.win_len = win_cap;
     }
@@ -1666,6 +1669,7 @@ JDA_HD jda_tile_ctx jda_tile_setup(const jda_dev_desc &D, const jda_strip &S)
         const uint32_t cap = (D.scan_len + JDA_SCAN_PAD) & ~15u;      // never past the padded allocation
         if (hi > cap) hi = cap;
         C.win_len = hi > C.win_lo ? hi - C.win_lo : 0;
+        if (C.win_len == 0) C.win_lo = 0;
         C.win_need = C.win_len;
         if (C.win_len > (uint32_t)jda_lds_layout<MODE>::WIN_BYTES) C.win_len = (uint32_t)jda_lds_layout<MODE>::WIN_BYTES;
     }
