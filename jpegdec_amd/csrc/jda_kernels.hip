@@ -973,7 +973,9 @@ __device__ __forceinline__ jda_sum_el jda_sum_load_chunk(const jda_segscan_param
 // A segment that met an invalid code ends the sums: harmless only behind the image's last block.
 // Result word: stats[6] = 1 when the index can be written (enough blocks, no bad code before the end).
 #define JDA_SUMS_WAVES 16u
-#define JDA_SUMS_MAX_CHUNKS ((1u << 25) / (64u * JDA_SEG_BYTES))      // 32 MB of scan (the index packs byte positions in 25 bits)
+// (32 MB of scan -- the index packs byte positions in 25 bits --, or what fits the CU's LDS with smaller segments: a longer scan goes
+// to the serial pre-scan, stats[6] = 0)
+#define JDA_SUMS_MAX_CHUNKS (((1u << 25) / (64u * JDA_SEG_BYTES)) < 6144u ? ((1u << 25) / (64u * JDA_SEG_BYTES)) : 6144u)
 __global__ __launch_bounds__(64 * JDA_SUMS_WAVES)
 void jda_segscan_sums(const jda_segscan_params *__restrict__ params)
 {
