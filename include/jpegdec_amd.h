@@ -107,6 +107,10 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
  * walk cannot take at all (progressive, one restart interval, table ids 2-3, DC codes its table key cannot tell
  * apart) are pre-scanned here whatever the flag says: jda_image_prescan_pending tells. */
 #define JDA_PREPARE_DEVICE_PRESCAN 1
+/* Continuation entries (jda_image_block_cont) for every image the serial pre-scan indexes / for none; default: for the images in the
+ * window of bits per block in which the decode kernel's chunked entropy phase was measured to pay (56 .. 112). */
+#define JDA_PREPARE_CONT_ALWAYS 2
+#define JDA_PREPARE_CONT_NEVER 4
 jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
 /* jda_prepare_ex for n images on `threads` host threads (<= 0: all hardware threads); out[i] / errs[i] per image
  * (errs may be NULL).  Returns JDA_SUCCESS or the first error met. */
@@ -135,12 +139,9 @@ const int16_t *jda_image_block_dc(const jda_image *img);
  * the decode kernel share it (photographs: luma blocks of forty symbols beside chroma blocks of four -- a wavefront runs as long as
  * its longest CHUNK then, not its longest block).  cont_first[g] .. cont_first[g + 1] (n_blocks + 1 offsets) are block g's entries in
  * the returned array of *n_cont entries: bits 11:0 the bit position of the entry's first symbol relative to the block's first AC
- * symbol, bits 17:12 the zigzag index of its first coefficient, bits 24:18 the low bits of g.  The serial pre-scan writes them; the
- * decode takes them for images between jda_cont_min_bits() and twice that many bits of scan per block (default 56 .. 112: where the
- * mode was measured to pay; jda_set_cont_min_bits: 0 = every image that has entries, < 0 = none). */
+ * symbol, bits 17:12 the zigzag index of its first coefficient, bits 24:18 the low bits of g.  The serial pre-scan writes them for
+ * the images JDA_PREPARE_CONT_* names; a decode to RGB8888 of a 4:2:0 or 4:4:4 image that has entries takes them. */
 const uint32_t *jda_image_block_cont(const jda_image *img, const uint32_t **cont_first, uint32_t *n_cont);
-int32_t jda_cont_min_bits(void);
-void jda_set_cont_min_bits(int32_t bits_per_block);
 /* Do two indexes of n_blocks + 1 entries (one from the serial pre-scan, one read back from the device: jda_dev_image_read_index,
  * jda_pipeline_read_index) name the same decode?  The contract between the two pre-scans: every block's entry has the same bit
  * position (byte position * 8 + bit offset) and the same flag; a FLAGGED block's entry is identical (the reference reader's exact
@@ -148,6 +149,10 @@ void jda_set_cont_min_bits(int32_t bits_per_block);
  * serial pre-scan stores the reader's phase; the closing entries lie within 41 bits of each other (the device's is behind the DC
  * symbol that the stream's padding decodes to, and rounded up to a byte in a stream with restart intervals).  Returns 1 / 0. */
 int jda_index_equivalent(const uint32_t *a, const uint32_t *b, uint32_t n_blocks);
+/* Which kernels of the library's code object this process has launched, and how often: "<kernel symbol> <launches>\n" per kernel
+ * into buf (NUL-terminated, truncated at cap); returns the bytes the whole report needs.  (Diagnostics: the GPU test-suite
+ * holds itself to every kernel the library ships.) */
+int jda_kernel_launch_counts(char *buf, int cap);
 /* the table blob uploaded to the GPU: DC LUTs 2x1024 B, AC LUTs 2x2048 uint16, quant 4x64 int16, zigzag 64 B,
  * and (ours) the end-of-block code of each AC table, 2 x uint32 = (32 - length) << 16 | code */
 const uint8_t *jda_image_tables(const jda_image *img, uint32_t *bytes);

@@ -8,6 +8,8 @@ every decode call fails loudly when the HIP library or a GPU is missing.
 from .binding import (  # noqa: F401
     GRAY8,
     LUMA_ONLY,
+    PREPARE_CONT_ALWAYS,
+    PREPARE_CONT_NEVER,
     PREPARE_DEVICE_PRESCAN,
     RGB565_BE,
     RGB565_LE,
@@ -24,7 +26,9 @@ from .binding import (  # noqa: F401
     SUBMIT_PINNED_INPUT,
     PreparedImage,
     crop_round,
+    decode_resident,
     decode_to_host,
+    kernel_launch_counts,
     draw_plan,
     draw_plan_ex,
     filter_on_device,

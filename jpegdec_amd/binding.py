@@ -74,8 +74,7 @@ _PROTOTYPES = [
     ("jda_image_block_dc", _P, [_P]),
     ("jda_index_equivalent", C.c_int, [_P, _P, C.c_uint32]),
     ("jda_image_block_cont", _P, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
-    ("jda_cont_min_bits", C.c_int32, []),
-    ("jda_set_cont_min_bits", None, [C.c_int32]),
+    ("jda_kernel_launch_counts", C.c_int, [C.c_char_p, C.c_int]),
     ("jda_image_tables", _P, [_P, C.POINTER(C.c_uint32)]),
     ("jda_image_truncation_events", C.c_uint32, [_P]),
     ("jda_image_general_p1", C.c_uint32, [_P]),
@@ -187,6 +186,8 @@ def draw_plan_ex(info: ImageInfo, pixel_type=RGB8888, options=0, max_mcus=0, use
 
 
 PREPARE_DEVICE_PRESCAN = 1
+PREPARE_CONT_ALWAYS = 2
+PREPARE_CONT_NEVER = 4
 
 
 class PreparedImage:
@@ -195,10 +196,11 @@ class PreparedImage:
     device_prescan=True (jda_prepare_ex, JDA_PREPARE_DEVICE_PRESCAN): for a stream with restart markers the
     serial pre-scan is left to the GPU (done by DeviceImage / jda_upload); `prescan_pending` tells."""
 
-    def __init__(self, jpeg: bytes, device_prescan: bool = False, _handle=None):
+    def __init__(self, jpeg: bytes, device_prescan: bool = False, _handle=None, flags: int = 0):
+        """flags: further JDA_PREPARE_* bits (PREPARE_CONT_ALWAYS / PREPARE_CONT_NEVER)"""
         self.lib = load_library()
         err = C.c_int32(0)
-        self.handle = _handle if _handle else self.lib.jda_prepare_ex(jpeg, len(jpeg), PREPARE_DEVICE_PRESCAN if device_prescan else 0, C.byref(err))
+        self.handle = _handle if _handle else self.lib.jda_prepare_ex(jpeg, len(jpeg), (PREPARE_DEVICE_PRESCAN if device_prescan else 0) | flags, C.byref(err))
         if not self.handle:
             raise JdaError(err.value, "jda_prepare")
         self.info = self.lib.jda_image_get_info(self.handle).contents
@@ -376,7 +378,7 @@ def index_equivalent(a, b) -> bool:
     return bool(load_library().jda_index_equivalent(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), a.size - 1))
 
 
-def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0, strict: bool = True):
+def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0, strict: bool = True, flags: int = 0):
     """jda_prepare_batch: the images are prepared on `threads` host threads (0 = all).  strict=False: a rejected file leaves a
     None in the list (and its error code in the second return value) instead of failing the whole batch."""
     lib = load_library()
@@ -385,7 +387,7 @@ def prepare_batch(jpegs, device_prescan: bool = False, threads: int = 0, strict:
     lens = (C.c_int32 * n)(*[len(j) for j in jpegs])
     outs = (_P * n)()
     errs = (C.c_int32 * n)()
-    rc = lib.jda_prepare_batch(n, arr, lens, PREPARE_DEVICE_PRESCAN if device_prescan else 0, threads, outs, errs)
+    rc = lib.jda_prepare_batch(n, arr, lens, (PREPARE_DEVICE_PRESCAN if device_prescan else 0) | flags, threads, outs, errs)
     res = [PreparedImage(jpegs[i], _handle=outs[i]) if outs[i] else None for i in range(n)]
     if not strict:
         return res, list(errs)
@@ -574,6 +576,42 @@ def decode_to_host(ctx: Context, jpeg: bytes, pixel_type=RGB8888, options=0, out
     rc = ctx.lib.jda_decode_to_host(ctx.handle, jpeg, len(jpeg), pixel_type, options,
                                     canvas.ctypes.data_as(_P), canvas.shape[1], canvas.shape[0])
     return rc, canvas, g
+
+
+def decode_resident(ctx: Context, prepared: PreparedImage, pixel_type=RGB8888, options=0):
+    """One prepared image through jda_upload + jda_batch_create + jda_batch_decode into an MCU-padded host canvas:
+    (status of the image, canvas, geometry) -- the path on which an image keeps what its jda_prepare_ex flags asked for."""
+    g = prepared.geometry(pixel_type, options)
+    pitch = (g["canvas_w"] * g["bpp"] + 15) & ~15
+    dimg = DeviceImage(ctx, prepared)
+    surf = ctx.malloc(pitch * g["canvas_h"])
+    try:
+        ctx.memset(surf, 0, pitch * g["canvas_h"])
+        batch = Batch(ctx, [dimg], [(surf, pitch, g["canvas_w"], g["canvas_h"])], [pixel_type], [options])
+        try:
+            batch.decode()
+            ctx.sync()
+            st = batch.status()[0]
+        finally:
+            batch.close()
+        canvas = ctx.to_host(surf, pitch * g["canvas_h"]).reshape(g["canvas_h"], pitch)[:, : g["canvas_w"] * g["bpp"]].copy()
+    finally:
+        ctx.free(surf)
+        dimg.close()
+    return st, canvas, g
+
+
+def kernel_launch_counts() -> dict:
+    """jda_kernel_launch_counts: {kernel symbol: launches} for every kernel this process has launched so far."""
+    lib = load_library()
+    need = lib.jda_kernel_launch_counts(None, 0)
+    buf = C.create_string_buffer(need + 4096)
+    lib.jda_kernel_launch_counts(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, _, n = line.rpartition(" ")
+        out[name] = int(n)
+    return out
 
 
 def decode_to_host_rect(ctx: Context, jpeg: bytes, pixel_type, options, mcu_rect):

@@ -1,6 +1,6 @@
 // jda_kernels.hip -- gfx950 (CDNA4) kernels of the decode path.  Written for wave64 only.
 //
-// jda_decode_tiles_persistent<MODE, FAST> (and the one-tile-per-wave jda_decode_tiles kept for profiling):
+// jda_decode_tiles_persistent<MODE, FAST, VARIANT, CONT>:
 // a workgroup is as many independent wavefronts as fit in a CU's LDS next to one copy of the image's
 // tables (16 x 9.8 KB + 6.8 KB for 4:2:0 = one 1024-thread workgroup per CU); each wavefront decodes one
 // tile = up to 64 consecutive 8x8 blocks of one MCU row (10 MCUs of 4:2:0).  After the tables are staged
@@ -17,6 +17,8 @@
 // No MFMA: the IDCT is shift/add integer work; the decode kernel is bound by VALU issue.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
 
 #include <atomic>
 
@@ -31,6 +33,39 @@ static hipError_t jda_ensure_lds_limit(const void *fn, int bytes, std::atomic<un
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
     return e;
+}
+
+// Launches per kernel function of this library, counted where they are made (an atomic add per launch): jda_kernel_launch_counts
+// reports which kernels of the code object a process has used -- tests/test_gpu_zz_kernel_coverage.py holds the suite to all of them.
+struct jda_launch_slot { std::atomic<const void *> fn; std::atomic<unsigned long long> n; };
+#define JDA_LAUNCH_SLOTS 128
+static jda_launch_slot g_launch_slots[JDA_LAUNCH_SLOTS];
+static void jda_count_launch(const void *fn)
+{
+    const uint32_t h = (uint32_t)((((uintptr_t)fn >> 3) * 0x9E3779B97F4A7C15ull) >> 57);
+    for (uint32_t i = 0; i < JDA_LAUNCH_SLOTS; i++) {
+        jda_launch_slot &S = g_launch_slots[(h + i) % JDA_LAUNCH_SLOTS];
+        const void *cur = S.fn.load(std::memory_order_acquire);
+        if (cur == nullptr && S.fn.compare_exchange_strong(cur, fn, std::memory_order_acq_rel)) cur = fn;
+        if (cur == fn) { S.n.fetch_add(1, std::memory_order_relaxed); return; }
+    }
+}
+#define JDA_LAUNCH(kernel, grid, block, lds, stream, ...) do { jda_count_launch((const void *)(kernel)); hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); } while (0)
+// "<kernel symbol> <launches>\n" for every kernel launched so far; returns the bytes the whole report needs (cap too small: truncated)
+extern "C" int jda_kernel_launch_counts(char *buf, int cap)
+{
+    int need = 0;
+    for (uint32_t i = 0; i < JDA_LAUNCH_SLOTS; i++) {
+        const void *fn = g_launch_slots[i].fn.load(std::memory_order_acquire);
+        if (!fn) continue;
+        const char *name = hipKernelNameRefByPtr(fn, nullptr);
+        char line[512];
+        const int n = snprintf(line, sizeof(line), "%s %llu\n", name ? name : "?", g_launch_slots[i].n.load(std::memory_order_relaxed));
+        if (buf && need + n < cap) memcpy(buf + need, line, (size_t)n);
+        need += n;
+    }
+    if (buf && cap > 0) buf[need < cap ? need : cap - 1] = 0;
+    return need + 1;
 }
 
 __device__ unsigned long long *g_jda_trace = nullptr;
@@ -197,7 +232,7 @@ __device__ __forceinline__ void jda_issue_index_loads(const jda_dev_desc &D, con
         __syncthreads();                              /* nobody reads the old tables any more */          \
         if ((have) && (P).first && (P).ord == staged + 1u && lane == 0) *tab_src = (unsigned long long)(DP).tables;  \
         __syncthreads();                                                                                  \
-        jda_p0_tables_from((const uint8_t *)*(volatile unsigned long long *)tab_src, threadIdx.x, 64 * L::WAVES, tab, L::LONG_LDS != 0); \
+        jda_p0_tables_from((const uint8_t *)*(volatile unsigned long long *)tab_src, threadIdx.x, 64u * n_waves, tab, L::LONG_LDS != 0); \
         __syncthreads();                                                                                  \
         staged++;                                                                                         \
     }
@@ -245,12 +280,22 @@ __device__ __forceinline__ uint32_t jda_p1_chunked(const jda_dev_desc &D, const 
     return jda_p1c_finish<MODE>(own, in.lb, wl);
 }
 
-template <int MODE, bool FAST, int VARIANT, int BIG, int CONT = 0>
-__global__ __launch_bounds__((64 * jda_lds_layout<MODE, BIG>::WAVES))
-void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads)
+// big: the workgroup's wavefronts, a wavefront's share of the LDS and its scan window are jda_lds_layout<MODE, 0>'s (as many
+// wavefronts as fit) or <MODE, 1>'s (one less, its LDS shared out as window: high-bitrate images), chosen per launch list.
+// FAST: 1 = every multiply in 24 bits (the plain-case kernels' lists hold only such images), -1 = as the image's descriptor says
+// (the general kernels: a uniform branch around the column stage).
+template <int MODE, int FAST, int VARIANT, int CONT = 0>
+__global__ __launch_bounds__((64 * jda_lds_layout<MODE, 0>::WAVES))
+void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_quads, uint32_t big)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    typedef jda_lds_layout<MODE, BIG> L;
+    typedef jda_lds_layout<MODE, 0> L;
+    typedef jda_lds_layout<MODE, 1> LB;
+    // (one live SGPR: the three numbers are selects between constants wherever they are used)
+#define n_waves (big ? (uint32_t)LB::WAVES : (uint32_t)L::WAVES)
+#define wave_bytes (big ? (uint32_t)LB::WAVE_BYTES : (uint32_t)L::WAVE_BYTES)
+#define win_bytes (big ? (uint32_t)LB::WIN_BYTES : (uint32_t)L::WIN_BYTES)
+    static_assert(jda_lds_layout<MODE, 0>::WIN_CHUNKS == jda_lds_layout<MODE, 1>::WIN_CHUNKS, "both window sizes are staged by the same copy loop");
     typedef jda_chunks<L::WIN_CHUNKS> chunks_t;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // runs of n_quads / grid groups of tiles, the remainder one more each for the first workgroups (rounding the run length up
@@ -259,12 +304,12 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     const uint32_t q0 = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
     const uint32_t q_end = q0 + per + (blockIdx.x < rem ? 1u : 0u);
     if (q0 >= q_end) return;
-    const uint32_t t_begin = q0 * (uint32_t)L::WAVES, t_end = q_end * (uint32_t)L::WAVES;   // this workgroup's run of tiles
+    const uint32_t t_begin = q0 * n_waves, t_end = q_end * n_waves;                       // this workgroup's run of tiles
     unsigned long long *wgtrace = g_jda_wgtrace;
     if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u] = wall_clock64();
     uint8_t *tab = lds;
-    uint8_t *wl = lds + L::TAB_BYTES + wave * L::WAVE_BYTES;
-    uint32_t *ctr = (uint32_t *)(lds + L::TAB_BYTES + L::WAVES * L::WAVE_BYTES);            // the run's draw counter
+    uint8_t *wl = lds + L::TAB_BYTES + wave * wave_bytes;
+    uint32_t *ctr = (uint32_t *)(lds + L::TAB_BYTES + n_waves * wave_bytes);                // the run's draw counter
     unsigned long long *tab_src = (unsigned long long *)(ctr + 2);                          // where the next image's tables are (JDA_ADVANCE_TABLES)
 
     // ---- prologue: the tables of the run's first image, the counter
@@ -273,7 +318,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     uint32_t staged = R0.ord;                                                            // image (ordinal) whose tables are in LDS
     const uint32_t last_ord = jda_load_record(tiles + (t_end - 1u)).ord;
     jda_dev_desc Dc = jda_desc_uniform<VARIANT, MODE>(descs + R0.image);
-    jda_p0_tables(Dc, threadIdx.x, 64 * L::WAVES, tab, L::LONG_LDS != 0);
+    jda_p0_tables(Dc, threadIdx.x, 64u * n_waves, tab, L::LONG_LDS != 0);
     __syncthreads();                                  // tables staged, counter set
 
     uint32_t i_cur = jda_draw_tile<MODE>(ctr, lane);
@@ -294,7 +339,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
     do {                                                                                                          \
         uint32_t ixe_;                                                                                            \
         jda_issue_index_loads<MODE, CONT>(Dc, S, lane, in, ixe_, &cf0, &cf1);                                     \
-        C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ixe_), (uint32_t)L::WIN_BYTES); \
+        C = jda_tile_setup_from<MODE>(Dc, S, __builtin_amdgcn_readfirstlane(in.ix), __builtin_amdgcn_readfirstlane(ixe_), win_bytes); \
         C.count = __builtin_amdgcn_readfirstlane(C.count);                                                        \
         C.win_lo = __builtin_amdgcn_readfirstlane(C.win_lo);                                                      \
         C.win_len = __builtin_amdgcn_readfirstlane(C.win_len);                                                    \
@@ -341,8 +386,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         // wave priorities: the phase that is a dependent chain (P1) and the one that feeds the memory pipe (P4) go first,
         // the arithmetic-dense IDCT fills the issue slots they leave (measured: 0.6-1 % over "oldest wave first")
         __builtin_amdgcn_s_setprio(JDA_PRIO_P1);
-        const uint32_t p1flags = (JDA_EXP_SKIP & 16) ? 0u : (CONT ? jda_p1_chunked<MODE>(D, C, in, cf0, cf1, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES, lane)
-                                                                  : jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, L::WIN_BYTES));
+        const uint32_t p1flags = (JDA_EXP_SKIP & 16) ? 0u : (CONT ? jda_p1_chunked<MODE>(D, C, in, cf0, cf1, LP, tab, wl, wl + L::WIN_OFF, win_bytes, lane)
+                                                                  : jda_p1_entropy<MODE>(D, C, in, LP, tab, wl, wl + L::WIN_OFF, win_bytes));
         if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 8)) jda_p1_lists<MODE>(D, LP, lane, p1flags, nullptr, tab, wl);
         __builtin_amdgcn_s_setprio(JDA_PRIO_IDCT);
         JDA_WAVE_SYNC();
@@ -357,7 +402,7 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
         asm volatile("" : "+v"(inn.ix), "+v"(inn.pred), "+v"(ixn_end), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
         if (CONT) asm volatile("" : "+v"(cfn0), "+v"(cfn1));
         if (pipelined) {
-            Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end), (uint32_t)L::WIN_BYTES);
+            Cn = jda_tile_setup_from<MODE>(D, Sn, __builtin_amdgcn_readfirstlane(inn.ix), __builtin_amdgcn_readfirstlane(ixn_end), win_bytes);
             Cn.count = __builtin_amdgcn_readfirstlane(Cn.count);
             Cn.win_lo = __builtin_amdgcn_readfirstlane(Cn.win_lo);
             Cn.win_len = __builtin_amdgcn_readfirstlane(Cn.win_len);
@@ -368,7 +413,8 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 
         JDA_PTRACE(3);
         if (D.scale_shift < 2 && !(JDA_EXP_SKIP & 4)) {
-            jda_p2_columns<MODE, FAST>(D, lane, tab, wl);
+            if (FAST > 0 || (FAST < 0 && D.fast_mul)) jda_p2_columns<MODE, true>(D, lane, tab, wl);
+            else jda_p2_columns<MODE, false>(D, lane, tab, wl);
             JDA_WAVE_SYNC();
         }
         JDA_PTRACE(4);
@@ -411,23 +457,29 @@ void jda_decode_tiles_persistent(const jda_dev_desc *__restrict__ descs, const j
 #undef JDA_TILE_COLD_START
     JDA_ADVANCE_TABLES(last_ord, false, S, Dc);        // boundaries after this wavefront's last tile
     if (wgtrace && lane == 0) wgtrace[(blockIdx.x * 16u + wave) * 2u + 1u] = wall_clock64();
+#undef n_waves
+#undef wave_bytes
+#undef win_bytes
 }
 
-template <int MODE, bool FAST, int VARIANT, int BIG = 0, int CONT = 0>
-static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
+template <int MODE, int FAST, int VARIANT, int CONT = 0>
+static hipError_t launch_persistent(int big, const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    typedef jda_lds_layout<MODE, BIG> L;
-    const int lds_bytes = L::TAB_BYTES + L::WAVES * L::WAVE_BYTES + 16;   // + the draw counter
-    static_assert(L::TAB_BYTES + L::WAVES * L::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
-    static_assert(L::WIN_BYTES >= L::COLLIST_ENTRIES * 2 + 16 && L::WIN_BYTES % 16 == 0 && L::WIN_OFF % 16 == 0, "the window covers the column list and its overrun");
+    typedef jda_lds_layout<MODE, 0> L0;
+    typedef jda_lds_layout<MODE, 1> L1;
+    static_assert(L0::TAB_BYTES + L0::WAVES * L0::WAVE_BYTES + 16 <= 160 * 1024 && L1::TAB_BYTES + L1::WAVES * L1::WAVE_BYTES + 16 <= 160 * 1024, "one workgroup must fit the CU's LDS");
+    static_assert(L0::WIN_BYTES >= L0::COLLIST_ENTRIES * 2 + 16 && L0::WIN_BYTES % 16 == 0 && L1::WIN_BYTES % 16 == 0 && L0::WIN_OFF % 16 == 0, "the window covers the column list and its overrun");
+    const uint32_t n_waves = big ? L1::WAVES : L0::WAVES, wave_bytes = big ? L1::WAVE_BYTES : L0::WAVE_BYTES, win_bytes = big ? L1::WIN_BYTES : L0::WIN_BYTES;
+    const int lds_max = (L0::WAVES * L0::WAVE_BYTES > L1::WAVES * L1::WAVE_BYTES ? L0::WAVES * L0::WAVE_BYTES : L1::WAVES * L1::WAVE_BYTES) + L0::TAB_BYTES + 16;
+    const int lds_bytes = L0::TAB_BYTES + (int)(n_waves * wave_bytes) + 16;      // + the draw counter
     static std::atomic<unsigned long long> attr_done(0);
-    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG, CONT>, lds_bytes, attr_done); if (e != hipSuccess) return e; }
+    { const hipError_t e = jda_ensure_lds_limit((const void *)jda_decode_tiles_persistent<MODE, FAST, VARIANT, CONT>, lds_max, attr_done); if (e != hipSuccess) return e; }
     static std::atomic<int> grid_cap_once(0);                   // (the GPUs of a node are alike: the first device's CU count)
     int grid_cap = grid_cap_once.load(std::memory_order_relaxed);
     if (!grid_cap) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int per_cu = (160 * 1024) / lds_bytes;
+        const int per_cu = (160 * 1024) / lds_max;
         // more workgroups than CUs: the ones that do not fit start as others finish, so the hardware deals the second half of the
         // work out by who is done first (the static split left the CUs finishing up to 4 % apart: profiles/r01_final_wg_balance.txt)
         static const int mult = []() { const char *e = JDA_LAB_ENV("JDA_GRID_MULT"); const int m = e ? atoi(e) : JDA_GRID_MULT_DEFAULT; return m < 1 ? 1 : (m > 16 ? 16 : m); }();
@@ -437,10 +489,11 @@ static hipError_t launch_persistent(const jda_dev_desc *descs, const jda_strip *
         grid_cap = cus * (per_cu > 0 ? per_cu : 1) * mult;
         grid_cap_once.store(grid_cap, std::memory_order_relaxed);
     }
-    const uint32_t n_quads = n_tiles / L::WAVES;
+    const uint32_t n_quads = n_tiles / n_waves;
     const uint32_t grid = n_quads < (uint32_t)grid_cap ? n_quads : (uint32_t)grid_cap;
-    hipLaunchKernelGGL((jda_decode_tiles_persistent<MODE, FAST, VARIANT, BIG, CONT>), dim3(grid), dim3(64 * L::WAVES), lds_bytes, stream,
-                       descs, tiles, n_quads);
+    JDA_LAUNCH((jda_decode_tiles_persistent<MODE, FAST, VARIANT, CONT>), dim3(grid), dim3(64 * n_waves), lds_bytes, stream,
+               descs, tiles, n_quads, (uint32_t)(big ? 1 : 0));
+    (void)win_bytes;
     return hipGetLastError();
 }
 
@@ -466,7 +519,7 @@ extern "C" hipError_t jda_launch_fill_strips(const jda_strips_params *params, ui
     if (n_images == 0 || max_tiles == 0) return hipSuccess;
     uint32_t gx = (max_tiles + 1023u) / 1024u;                        // four records a thread
     if (gx > 64u) gx = 64u;
-    hipLaunchKernelGGL(jda_fill_strips, dim3(gx, n_images), dim3(256), 0, stream, params);
+    JDA_LAUNCH(jda_fill_strips, dim3(gx, n_images), dim3(256), 0, stream, params);
     return hipGetLastError();
 }
 
@@ -635,7 +688,7 @@ template <int MODE>
 static hipError_t launch_dc_thumbnail(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
     const uint32_t per_wg = 4u * JDA_THUMB_TILES;
-    hipLaunchKernelGGL((jda_dc_thumbnail<MODE>), dim3((n_tiles + per_wg - 1u) / per_wg), dim3(256), 0, stream, descs, tiles, n_tiles);
+    JDA_LAUNCH((jda_dc_thumbnail<MODE>), dim3((n_tiles + per_wg - 1u) / per_wg), dim3(256), 0, stream, descs, tiles, n_tiles);
     return hipGetLastError();
 }
 
@@ -746,7 +799,7 @@ static hipError_t launch_quarter(const jda_dev_desc *descs, const jda_strip *til
     uint32_t grid = resident * 2u;
     if (grid > n_groups) grid = n_groups;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL((jda_quarter_tiles<MODE>), dim3(grid), dim3(256), 0, stream, descs, tiles, n_groups, group_tiles);
+    JDA_LAUNCH((jda_quarter_tiles<MODE>), dim3(grid), dim3(256), 0, stream, descs, tiles, n_groups, group_tiles);
     return hipGetLastError();
 }
 
@@ -780,7 +833,7 @@ void jda_walk_tables_build(const jda_segscan_params *__restrict__ params)
 extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream)
 {
     if (n_images == 0) return hipSuccess;
-    hipLaunchKernelGGL(jda_walk_tables_build, dim3(n_images), dim3(1024), 0, stream, params);
+    JDA_LAUNCH(jda_walk_tables_build, dim3(n_images), dim3(1024), 0, stream, params);
     return hipGetLastError();
 }
 
@@ -897,15 +950,15 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     const uint32_t full = (max_segs + 255u) / 256u;
     // later rounds walk a few percent of the segments: a few workgroups per image, each stepping through the list
     const dim3 grid(round <= 1 ? full : (full < 8u ? full : 8u), n_images), block(256);
-    if (round == 0) hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
-    else hipLaunchKernelGGL(jda_segscan_fused<JDA_SEG_RECORD>, grid, block, lds_bytes, stream, params, round);
+    if (round == 0) JDA_LAUNCH(jda_segscan_fused<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
+    else JDA_LAUNCH(jda_segscan_fused<JDA_SEG_RECORD>, grid, block, lds_bytes, stream, params, round);
     return hipGetLastError();
 }
 
 extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t first_round, uint32_t max_round, hipStream_t stream)
 {
     if (n_images == 0) return hipSuccess;
-    hipLaunchKernelGGL(jda_segscan_tail, dim3(n_images), dim3(1024), JDA_WT_BYTES, stream, params, first_round, max_round);
+    JDA_LAUNCH(jda_segscan_tail, dim3(n_images), dim3(1024), JDA_WT_BYTES, stream, params, first_round, max_round);
     return hipGetLastError();
 }
 
@@ -1045,7 +1098,7 @@ extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, 
     const int lds_bytes = (int)(JDA_SUMS_MAX_CHUNKS * sizeof(jda_sum_el));
     static std::atomic<unsigned long long> attr_done(0);
     { const hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_sums, lds_bytes, attr_done); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(jda_segscan_sums, dim3(n_images), dim3(64 * JDA_SUMS_WAVES), lds_bytes, stream, params);
+    JDA_LAUNCH(jda_segscan_sums, dim3(n_images), dim3(64 * JDA_SUMS_WAVES), lds_bytes, stream, params);
     return hipGetLastError();
 }
 
@@ -1131,8 +1184,8 @@ extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params
     if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, list_rounds, max_round, stream);
     if (e == hipSuccess) e = jda_launch_segscan_sums(params, n_images, stream);
     if (e == hipSuccess && any_record) {
-        hipLaunchKernelGGL(jda_segscan_finalize, dim3((max_segs + 4u * JDA_FIN_SEGS_PER_WAVE - 1u) / (4u * JDA_FIN_SEGS_PER_WAVE), n_images), dim3(256), 0, stream, params);
-        hipLaunchKernelGGL(jda_segscan_resolve_cands, dim3(16, n_images), dim3(256), 0, stream, params);
+        JDA_LAUNCH(jda_segscan_finalize, dim3((max_segs + 4u * JDA_FIN_SEGS_PER_WAVE - 1u) / (4u * JDA_FIN_SEGS_PER_WAVE), n_images), dim3(256), 0, stream, params);
+        JDA_LAUNCH(jda_segscan_resolve_cands, dim3(16, n_images), dim3(256), 0, stream, params);
         e = hipGetLastError();
     }
     return e;
@@ -1387,9 +1440,9 @@ extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_
 {
     if (n_images == 0) return hipSuccess;
     const uint32_t chunks = (max_raw_len + JDA_FILTER_CHUNK - 1u) / JDA_FILTER_CHUNK;
-    if (chunks) hipLaunchKernelGGL(jda_filter_count_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params);
-    hipLaunchKernelGGL(jda_filter_carry, dim3(n_images), dim3(64), 0, stream, params);
-    if (chunks) hipLaunchKernelGGL(jda_filter_write_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params);
+    if (chunks) JDA_LAUNCH(jda_filter_count_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params);
+    JDA_LAUNCH(jda_filter_carry, dim3(n_images), dim3(64), 0, stream, params);
+    if (chunks) JDA_LAUNCH(jda_filter_write_v2, dim3(chunks, n_images), dim3(1024), 0, stream, params);
     return hipGetLastError();
 }
 
@@ -1424,7 +1477,7 @@ extern "C" hipError_t jda_launch_checksum(const void *base, uint32_t pitch, uint
     uint64_t g = (total + 256u * 8u - 1u) / (256u * 8u);
     if (g > 4096) g = 4096;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(jda_surface_checksum, dim3((uint32_t)g), dim3(256), 0, stream, (const uint8_t *)base, pitch, row_bytes, rows, out);
+    JDA_LAUNCH(jda_surface_checksum, dim3((uint32_t)g), dim3(256), 0, stream, (const uint8_t *)base, pitch, row_bytes, rows, out);
     return hipGetLastError();
 }
 
@@ -1443,25 +1496,11 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int
                                         uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
-    if (cont) {                                       // P1 in chunks (jda_use_cont decides who gets here): general variant and the RGB8888 plain case, 24-bit multiplies
-        if (!fast_mul || variant > 1) return hipErrorInvalidValue;
-        switch ((mode * 2 + variant) * 2 + (big ? 1 : 0)) {
-        case (JDA_MODE_GRAY * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_GRAY, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_GRAY * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_GRAY, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_444 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_444, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_444 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_444, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_444 * 2 + 1) * 2 + 0: return launch_persistent<JDA_MODE_444, true, 1, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_444 * 2 + 1) * 2 + 1: return launch_persistent<JDA_MODE_444, true, 1, 1, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_420 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_420, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_420 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_420, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_420 * 2 + 1) * 2 + 0: return launch_persistent<JDA_MODE_420, true, 1, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_420 * 2 + 1) * 2 + 1: return launch_persistent<JDA_MODE_420, true, 1, 1, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_422 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_422, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_422 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_422, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_422 * 2 + 1) * 2 + 0: return launch_persistent<JDA_MODE_422, true, 1, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_422 * 2 + 1) * 2 + 1: return launch_persistent<JDA_MODE_422, true, 1, 1, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_440 * 2 + 0) * 2 + 0: return launch_persistent<JDA_MODE_440, true, 0, 0, 1>(descs, tiles, n_tiles, stream);
-        case (JDA_MODE_440 * 2 + 0) * 2 + 1: return launch_persistent<JDA_MODE_440, true, 0, 1, 1>(descs, tiles, n_tiles, stream);
+    if (cont) {                                       // P1 in chunks (jda_use_cont decides who gets here): the RGB8888 plain case of 4:2:0 and 4:4:4
+        if (!fast_mul || variant != 1) return hipErrorInvalidValue;
+        switch (mode) {
+        case JDA_MODE_444: return launch_persistent<JDA_MODE_444, 1, 1, 1>(big, descs, tiles, n_tiles, stream);
+        case JDA_MODE_420: return launch_persistent<JDA_MODE_420, 1, 1, 1>(big, descs, tiles, n_tiles, stream);
         default: return hipErrorInvalidValue;
         }
     }
@@ -1485,42 +1524,26 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int
         default: return hipErrorInvalidValue;
         }
     }
-    if (big) {                                        // the large-window kernels for high-bitrate images (jda_big_window in jda_runtime.cpp decides who gets here)
-        switch (mode * 4 + variant) {
-        case JDA_MODE_GRAY * 4 + 0: return launch_persistent<JDA_MODE_GRAY, true, 0, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_444 * 4 + 0: return launch_persistent<JDA_MODE_444, true, 0, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 4 + 0: return launch_persistent<JDA_MODE_420, true, 0, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_422 * 4 + 0: return launch_persistent<JDA_MODE_422, true, 0, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_440 * 4 + 0: return launch_persistent<JDA_MODE_440, true, 0, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_444 * 4 + 1: return launch_persistent<JDA_MODE_444, true, 1, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 4 + 1: return launch_persistent<JDA_MODE_420, true, 1, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_422 * 4 + 1: return launch_persistent<JDA_MODE_422, true, 1, 1>(descs, tiles, n_tiles, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
+    // big: the larger scan window for high-bitrate images, one wavefront less per workgroup (jda_big_window in jda_runtime.cpp decides)
     if (variant >= 1 && fast_mul) {                   // the plain-case kernels (jda_plain_variant decides who gets here)
         switch (mode * 4 + variant) {
-        case JDA_MODE_444 * 4 + 1: return launch_persistent<JDA_MODE_444, true, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 4 + 1: return launch_persistent<JDA_MODE_420, true, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_422 * 4 + 1: return launch_persistent<JDA_MODE_422, true, 1>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_444 * 4 + 2: return launch_persistent<JDA_MODE_444, true, 2>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 4 + 2: return launch_persistent<JDA_MODE_420, true, 2>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_420 * 4 + 3: return launch_persistent<JDA_MODE_420, true, 3>(descs, tiles, n_tiles, stream);
-        case JDA_MODE_GRAY * 4 + 3: return launch_persistent<JDA_MODE_GRAY, true, 3>(descs, tiles, n_tiles, stream);
+        case JDA_MODE_444 * 4 + 1: return launch_persistent<JDA_MODE_444, 1, 1>(big, descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 1: return launch_persistent<JDA_MODE_420, 1, 1>(big, descs, tiles, n_tiles, stream);
+        case JDA_MODE_422 * 4 + 1: return launch_persistent<JDA_MODE_422, 1, 1>(big, descs, tiles, n_tiles, stream);
+        case JDA_MODE_444 * 4 + 2: return launch_persistent<JDA_MODE_444, 1, 2>(big, descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 2: return launch_persistent<JDA_MODE_420, 1, 2>(big, descs, tiles, n_tiles, stream);
+        case JDA_MODE_420 * 4 + 3: return launch_persistent<JDA_MODE_420, 1, 3>(big, descs, tiles, n_tiles, stream);
+        case JDA_MODE_GRAY * 4 + 3: return launch_persistent<JDA_MODE_GRAY, 1, 3>(big, descs, tiles, n_tiles, stream);
         default: return hipErrorInvalidValue;
         }
     }
-    switch (mode * 2 + (fast_mul ? 1 : 0)) {
-    case JDA_MODE_GRAY * 2 + 0: return launch_persistent<JDA_MODE_GRAY, false, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_GRAY * 2 + 1: return launch_persistent<JDA_MODE_GRAY, true, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_444 * 2 + 0: return launch_persistent<JDA_MODE_444, false, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_444 * 2 + 1: return launch_persistent<JDA_MODE_444, true, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_420 * 2 + 0: return launch_persistent<JDA_MODE_420, false, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_420 * 2 + 1: return launch_persistent<JDA_MODE_420, true, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_422 * 2 + 0: return launch_persistent<JDA_MODE_422, false, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_422 * 2 + 1: return launch_persistent<JDA_MODE_422, true, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_440 * 2 + 0: return launch_persistent<JDA_MODE_440, false, 0>(descs, tiles, n_tiles, stream);
-    case JDA_MODE_440 * 2 + 1: return launch_persistent<JDA_MODE_440, true, 0>(descs, tiles, n_tiles, stream);
+    if (variant != 0) return hipErrorInvalidValue;
+    switch (mode) {                                   // the general kernels: 24- or 32-bit multiplies as the image's descriptor says
+    case JDA_MODE_GRAY: return launch_persistent<JDA_MODE_GRAY, -1, 0>(big, descs, tiles, n_tiles, stream);
+    case JDA_MODE_444: return launch_persistent<JDA_MODE_444, -1, 0>(big, descs, tiles, n_tiles, stream);
+    case JDA_MODE_420: return launch_persistent<JDA_MODE_420, -1, 0>(big, descs, tiles, n_tiles, stream);
+    case JDA_MODE_422: return launch_persistent<JDA_MODE_422, -1, 0>(big, descs, tiles, n_tiles, stream);
+    case JDA_MODE_440: return launch_persistent<JDA_MODE_440, -1, 0>(big, descs, tiles, n_tiles, stream);
     default: return hipErrorInvalidValue;
     }
 }

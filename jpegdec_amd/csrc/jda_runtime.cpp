@@ -40,15 +40,13 @@ int jda_plain_variant(const jda_dev_desc &D)
 
 // High-bitrate images go to the kernel variant with one wavefront less per CU and a larger scan window (jda_lds_layout<MODE, 1>):
 // a tile whose slice of the scan does not fit the window takes the general bit reader, which goes to HBM at every refill.
-// Decided per image from its average bytes of scan per full tile (+ 50 % for the spread between tiles); the kernels exist for
-// the general variant and the RGB8888 plain case, 24-bit multiplies.  JDA_BIG_WINDOW=0 / 1 forces the choice (A/B runs).
+// Decided per image from its average bytes of scan per full tile (+ 50 % for the spread between tiles), or from the tiles' slices
+// themselves where the host made the index; every decode kernel takes either layout (a launch argument).
 int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uint32_t tiles_over_small)
 {
     static const int forced = []() { const char *e = JDA_LAB_ENV("JDA_BIG_WINDOW"); return e ? atoi(e) : -1; }();
     if (D.scale_shift == 3) return 0;                             // JDA_LIST_THUMB (or, strip-major, the decode kernel without a window)
     if (D.scale_shift == 2 && D.strip_mcus == 0) return 1;        // JDA_LIST_QUARTER: its lists are padded as the large-window kernels' (no window is staged)
-    if (!D.fast_mul || variant > 1) return 0;
-    if (variant == 1 && D.mode == JDA_MODE_GRAY) return 0;
     if (forced >= 0) return forced ? 1 : 0;
     // the index was made on the host: the tiles' slices are known exactly -- the larger window (and the wavefront it costs) only
     // when more than one tile in a hundred does not fit the smaller one
@@ -59,16 +57,13 @@ int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total, uin
     return avg + avg / 2 + 48 > jda_window_bytes(D.mode, 0) ? 1 : 0;
 }
 
-int jda_use_cont(const jda_dev_desc &D, int variant, uint64_t scan_bytes, uint64_t n_blocks, uint32_t n_cont)
+// P1 in chunks: for an image that HAS continuation entries (the serial pre-scan wrote them: the image lies in the window in which
+// the mode was measured to pay, or its caller asked for them: JDA_PREPARE_CONT_*) and whose decode has such a kernel -- the RGB8888
+// plain case of 4:2:0 and 4:4:4
+int jda_use_cont(const jda_dev_desc &D, int variant, uint32_t n_cont)
 {
-    if (!n_cont || !n_blocks || !D.fast_mul || variant > 1 || D.scale_shift > 1 || (D.pad_[0] & (JDA_DESC_GENERAL_P1 | JDA_DESC_DC_ONLY))) return 0;
-    const int32_t min_bits = jda_cont_min_bits();
-    if (min_bits < 0) return 0;
-    if (min_bits == 0) return 1;                                  // (tests: every image that has entries)
-    // measured (profiles/r04_p1_chunks_ab.txt): + 3 % (tulips, 62 bits a block) to + 15 % (zebra, 77) where long luma blocks stand beside
-    // short ones; - 6 % at quality 98 (158 bits a block: every block is long, a pass of chunks costs what four symbols cost) and - 13 %
-    // where most tiles hold a block the reference truncates (perf.jpg, 140): the window in which it pays
-    return scan_bytes * 8u >= (uint64_t)min_bits * n_blocks && scan_bytes * 8u < (uint64_t)2 * min_bits * n_blocks ? 1 : 0;
+    if (!n_cont || variant != 1 || (D.mode != JDA_MODE_420 && D.mode != JDA_MODE_444)) return 0;
+    return 1;
 }
 
 int jda_set_err(jda_ctx *ctx, hipError_t e, const char *what)
@@ -673,7 +668,7 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
         // descriptor fields are compile-time constants (jda_desc_uniform<1>)
         const int variant = jda_plain_variant(D);
         const int big = D.scale_shift == 3 ? 0 : jda_big_window(D, variant, im->tiles_total, im->tiles_over_small);
-        const int cont = jda_use_cont(D, variant, im->scan_len, (uint64_t)I.mcus_x * I.mcus_y * I.blocks_per_mcu, im->n_cont);
+        const int cont = jda_use_cont(D, variant, im->n_cont);
         if (cont) { D.blk_cont_first = (const uint32_t *)(im->base + im->off_cont_first); D.blk_cont = (const uint32_t *)(im->base + im->off_cont); }
         {
             std::vector<jda_strip> &lst = strips[jda_list_index(D, variant, big, cont)];

@@ -82,12 +82,7 @@ inline int jda_list_index(const jda_dev_desc &D, int variant, int big, int cont 
     }
     return (((D.mode * 2 + (D.fast_mul ? 1 : 0)) * 4 + variant) * 2 + big) * 2 + cont;
 }
-// P1 in chunks (jda_p1c_*: the lanes of a wavefront share a tile's long blocks through the index's continuation entries) pays where the
-// blocks are long AND uneven -- photographs at moderate qualities -- and costs where they are short or all long: taken between
-// jda_cont_min_bits() and twice that many bits of scan per block (default 56 .. 112; the metric's synthetic image has 34, the reference's
-// tulips 62, zebra 77, perf.jpg 140, a quality-98 file 158).  The kernels exist for the general variant and the RGB8888 plain case with
-// 24-bit multiplies, full and half size.
-int jda_use_cont(const jda_dev_desc &D, int variant, uint64_t scan_bytes, uint64_t n_blocks, uint32_t n_cont);
+int jda_use_cont(const jda_dev_desc &D, int variant, uint32_t n_cont);
 int jda_big_window(const jda_dev_desc &D, int variant, uint32_t tiles_total = 0, uint32_t tiles_over_small = 0);
 // Fill the descriptor of one image of a launch plan (everything but the pointers into the image's HBM block, which the
 // caller sets) and validate the output surface.  Returns JDA_SUCCESS or the error jda_batch_create reports.

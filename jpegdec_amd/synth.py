@@ -72,16 +72,54 @@ def encode_jpeg(pixels: np.ndarray, quality: int = 85, subsampling="4:2:0", opti
     return buf.getvalue()
 
 
+def widen_dqt(jpeg: bytes, factor: int) -> bytes:
+    """Every DQT table of the file rewritten at word precision (Pq = 1, jpeg.inl:1742-1750) with its entries x factor
+    (clipped to 65535): the reference takes such tables as they come, and with them max |coef| x max |q'| leaves the range the
+    kernels' 24-bit multiplier covers -- the inputs that reach the 32-bit-multiply kernels."""
+    out, i = bytearray(jpeg[:2]), 2
+    while i < len(jpeg):
+        assert jpeg[i] == 0xFF
+        m = jpeg[i + 1]
+        if m == 0xDA:
+            out += jpeg[i:]
+            break
+        ln = (jpeg[i + 2] << 8) | jpeg[i + 3]
+        seg = jpeg[i + 4:i + 2 + ln]
+        if m == 0xDB:
+            body, j = bytearray(), 0
+            while j < len(seg):
+                pq, tq = seg[j] >> 4, seg[j] & 15
+                n = 128 if pq else 64
+                vals = [(seg[j + 1 + 2 * k] << 8) | seg[j + 2 + 2 * k] for k in range(64)] if pq else list(seg[j + 1:j + 65])
+                body.append(0x10 | tq)
+                for v in vals:
+                    body += min(65535, v * factor).to_bytes(2, "big")
+                j += 1 + n
+            out += bytes([0xFF, 0xDB]) + (len(body) + 2).to_bytes(2, "big") + body
+        else:
+            out += jpeg[i:i + 2 + ln]
+        i += 2 + ln
+    return bytes(out)
+
+
 def synth_jpeg(width: int, height: int, subsampling="4:2:0", seed: int = 1234, quality: int = 85,
-               optimize: bool = False, restart_rows: int = 0, restart_blocks: int = 0, progressive: bool = False) -> bytes:
+               optimize: bool = False, restart_rows: int = 0, restart_blocks: int = 0, progressive: bool = False,
+               dqt16: int = 0, noise: bool = False) -> bytes:
     """subsampling: '4:2:0' | '4:4:4' | '4:2:2' | '4:4:0' | 'gray'.  4:4:0 (luma sampled 1x2) goes through
-    encode_jpeg_custom (restart_blocks = its restart interval in MCUs)."""
+    encode_jpeg_custom (restart_blocks = its restart interval in MCUs).
+    noise: uniform pixel noise instead of the value-noise image (high contrast: long blocks, large coefficients).
+    dqt16: the finished file's quantisers rewritten at word precision, x dqt16 (widen_dqt)."""
     ch = 1 if subsampling == "gray" else 3
-    px = value_noise_image(width, height, ch, seed)
+    if noise:
+        px = np.random.default_rng(seed).integers(0, 256, size=(height, width, ch) if ch == 3 else (height, width), dtype=np.uint8)
+    else:
+        px = value_noise_image(width, height, ch, seed)
     if subsampling == "4:4:0":
-        return encode_jpeg_custom(px, quality, (1, 2), restart_interval=restart_blocks)
-    return encode_jpeg(px, quality, subsampling if ch == 3 else None, optimize, restart_rows,
-                       restart_blocks, progressive)
+        jpeg = encode_jpeg_custom(px, quality, (1, 2), restart_interval=restart_blocks)
+    else:
+        jpeg = encode_jpeg(px, quality, subsampling if ch == 3 else None, optimize, restart_rows,
+                           restart_blocks, progressive)
+    return widen_dqt(jpeg, dqt16) if dqt16 else jpeg
 
 
 def bits_per_pixel(jpeg: bytes, width: int, height: int) -> float:

@@ -30,7 +30,15 @@ SYNTH_CASES = {
     "c440_200x120": dict(width=200, height=120, subsampling="4:4:0", seed=43, quality=90),
     "c440_300x64_rst5": dict(width=300, height=64, subsampling="4:4:0", seed=44, restart_blocks=5),
     "c420_250x250_q10": dict(width=250, height=250, subsampling="4:2:0", seed=22, quality=10),  # many DC-only blocks
+    # word-precision DQT (jpeg.inl:1742-1750): quantisers x 400 / x 3000 over uniform noise -> max |coef| x max |q'| >= 2^21, the
+    # 32-bit-multiply kernels (jda_image_fast_mul == 0: asserted by tests/test_frontend.py::test_word_precision_dqt_cases)
+    "w16_gray_200x120_x400": dict(width=200, height=120, subsampling="gray", seed=61, quality=90, noise=True, dqt16=400),
+    "w16_c444_136x88_x3000": dict(width=136, height=88, subsampling="4:4:4", seed=62, quality=90, noise=True, dqt16=3000),
+    "w16_c420_333x217_x400": dict(width=333, height=217, subsampling="4:2:0", seed=63, quality=90, noise=True, dqt16=400),
+    "w16_c422_200x72_x3000": dict(width=200, height=72, subsampling="4:2:2", seed=64, quality=90, noise=True, dqt16=3000),
+    "w16_c440_120x96_x400": dict(width=120, height=96, subsampling="4:4:0", seed=65, quality=90, noise=True, dqt16=400),
 }
+WORD_DQT_CASES = sorted(k for k in SYNTH_CASES if k.startswith("w16_"))
 
 # progressive files (decoded from their first, DC-only scan as a 1/8 thumbnail, jpeg.inl:4964-4966)
 PROGRESSIVE_CASES = {
@@ -57,7 +65,7 @@ def jpeg_for(name: str) -> bytes:
 def all_modes(name):
     for pt in PIXEL_TYPES:
         for opt in OPTIONS:
-            if name.startswith("c440") and pt == 2 and (opt & 4):
+            if "c440" in name and pt == 2 and (opt & 4):
                 continue       # JPEGPutMCU12, 1/4 scale, RGB8888 writes through the address of a local (jpeg.inl:4620): UB in the reference
             yield pt, opt
 

@@ -25,7 +25,7 @@ static int g_trace_seg = -1;
 static unsigned long long g_chunk_items = 0;      // continuation entries decoded as chunks since the last call of hostsim_chunk_items
 extern "C" unsigned long long hostsim_chunk_items(void) { const unsigned long long n = g_chunk_items; g_chunk_items = 0; return n; }
 static int g_use_cont = 0;        // 1: decode through P1's chunked mode (the serial pre-scan's continuation entries)
-extern "C" void hostsim_set_chunked(int on) { g_use_cont = on; jda_set_cont_min_bits(on ? 0 : 56); }      // (0: the serial pre-scan writes entries for every image)
+extern "C" void hostsim_set_chunked(int on) { g_use_cont = on; }      // (the serial pre-scan then writes entries for every image: JDA_PREPARE_CONT_ALWAYS)
 extern "C" const uint32_t *jda_image_block_cont(const jda_image *img, const uint32_t **cont_first, uint32_t *n_cont);
 static int g_reverse_tiles = 0;   // tests run the tiles in reverse order too: results must not depend on which wave finishes first
 extern "C" void hostsim_set_reverse(int on) { g_reverse_tiles = on; }
@@ -168,7 +168,7 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                               uint8_t *out, int pitch_bytes, int width_px, int rows)
 {
     int32_t err = 0;
-    jda_image *img = jda_prepare_ex(jpeg, len, g_device_prescan ? JDA_PREPARE_DEVICE_PRESCAN : 0, &err);
+    jda_image *img = jda_prepare_ex(jpeg, len, (g_device_prescan ? JDA_PREPARE_DEVICE_PRESCAN : 0) | (g_use_cont ? JDA_PREPARE_CONT_ALWAYS : 0), &err);
     if (!img) return err ? err : -1;
     std::vector<uint32_t> dev_index;
     std::vector<int16_t> dev_dc;

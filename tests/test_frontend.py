@@ -245,3 +245,20 @@ def test_cropped_draw_plan_depends_on_the_x_offset(ref_scalar):
                     checked += 1
         p.close()
     assert checked > 100
+
+
+def test_word_precision_dqt_cases(hostsim, oracle):
+    """jpeg.inl:1742-1750: the reference takes 16-bit quantisers as they come.  The w16_* cases (uniform noise, quantisers x 400 / x 3000
+    at word precision) leave the range the kernels' 24-bit multiplier covers -- jda_image_fast_mul == 0 for each of them, i.e. they
+    are the inputs of the 32-bit-multiply column stage --, every other synthetic case stays inside it; the oracle decodes them."""
+    from tests.cases import SYNTH_CASES, WORD_DQT_CASES, jpeg_for
+    assert len(WORD_DQT_CASES) == 5
+    for name in sorted(SYNTH_CASES):
+        jpeg = jpeg_for(name)
+        assert hostsim.hostsim_fast_mul(jpeg, len(jpeg)) == (0 if name in WORD_DQT_CASES else 1), name
+    for name in WORD_DQT_CASES:
+        jpeg = jpeg_for(name)
+        dqt = jpeg.index(b"\xff\xdb")
+        assert jpeg[dqt + 4] >> 4 == 1                      # Pq = 1
+        rc, want, err = oracle.decode_canvas(jpeg, 2 if "gray" not in name else 0, 0)
+        assert rc == 1 and len(set(want.ravel().tolist())) > 8   # (not one flat colour: the IDCT's every path sees values)

@@ -448,32 +448,30 @@ def test_one_bad_file_does_not_poison_a_resident_batch(gpu_ctx, oracle):
 
 def test_p1_in_chunks_is_bit_exact(gpu_ctx, oracle):
     """P1's chunked mode (jda_p1c_*: the lanes of a wavefront share a tile's long blocks through the index's continuation entries,
-    one every 8 AC symbols) forced on for every image that has entries (jda_set_cont_min_bits(0); by default it is taken from 48 bits
-    of scan per block on): every synthetic case and the reference's photographs, the output formats whose kernels exist in that
-    mode (general + RGB8888 plain case, full and half size) and the others (which keep their kernels) -- bit-exact with the oracle.
-    The entries themselves: every one names its block and a place inside it."""
+    one every 8 AC symbols) asked for on every image (JDA_PREPARE_CONT_ALWAYS; by default the serial pre-scan writes entries between
+    56 and 112 bits of scan per block): every synthetic case and the reference's photographs, to RGB8888 (4:2:0 and 4:4:4 have a
+    chunked kernel) and to the formats that keep their kernels -- bit-exact with the oracle.  The entries themselves: every one
+    names its block and a place inside it."""
     from tests.ref_fixtures import GOOD, ref_jpeg
-    lib = J.load_library()
-    before = lib.jda_cont_min_bits()
-    lib.jda_set_cont_min_bits(0)
-    try:
-        cases = [(n, jpeg_for(n)) for n in sorted(SYNTH_CASES)] + [("ref:" + n, ref_jpeg(n)) for n in GOOD]
-        n_entries = 0
-        for name, jpeg in cases:
-            p = J.PreparedImage(jpeg)
-            first, ent = p.block_cont()
-            assert first[0] == 0 and first[-1] == len(ent) and np.all(np.diff(first.astype(np.int64)) >= 0)
-            owner = np.repeat(np.arange(p.n_blocks), np.diff(first.astype(np.int64)))
-            assert np.array_equal((ent >> 18) & 127, owner & 127) and np.all(((ent >> 12) & 63) >= 9), name   # (eight symbols in: coefficient 9 at the least)
-            n_entries += len(ent)
-            gray = p.info.ncomp == 1
-            p.close()
-            for pt, opt in ((J.RGB565_BE, 0), (J.GRAY8, 0), (J.RGB565_BE, J.SCALE_HALF)) if gray else ((J.RGB8888, 0), (J.RGB565_BE, 0), (J.RGB8888, J.SCALE_HALF), (J.RGB565_LE, 0), (J.GRAY8, 0)):
-                rc, got, g = J.decode_to_host(gpu_ctx, jpeg, pt, opt)
-                orc, want, err = oracle.decode_canvas(jpeg, pt, opt)
-                assert (rc == 0) == (orc == 1), (name, pt, opt, rc, orc)
-                if orc == 1:
-                    assert np.array_equal(got, want), (name, pt, opt, int(np.count_nonzero(got != want)))
-        assert n_entries > 50000
-    finally:
-        lib.jda_set_cont_min_bits(before)
+    cases = [(n, jpeg_for(n)) for n in sorted(SYNTH_CASES)] + [("ref:" + n, ref_jpeg(n)) for n in GOOD]
+    n_entries = 0
+    before = J.kernel_launch_counts()
+    for name, jpeg in cases:
+        p = J.PreparedImage(jpeg, flags=J.PREPARE_CONT_ALWAYS)
+        first, ent = p.block_cont()
+        assert first[0] == 0 and first[-1] == len(ent) and np.all(np.diff(first.astype(np.int64)) >= 0)
+        owner = np.repeat(np.arange(p.n_blocks), np.diff(first.astype(np.int64)))
+        assert np.array_equal((ent >> 18) & 127, owner & 127) and np.all(((ent >> 12) & 63) >= 9), name   # (eight symbols in: coefficient 9 at the least)
+        n_entries += len(ent)
+        gray = p.info.ncomp == 1
+        for pt, opt in ((J.RGB565_BE, 0), (J.GRAY8, 0)) if gray else ((J.RGB8888, 0), (J.RGB565_BE, 0), (J.RGB8888, J.SCALE_HALF)):
+            st, got, g = J.decode_resident(gpu_ctx, p, pt, opt)
+            orc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+            assert (st == 0) == (orc == 1), (name, pt, opt, st, orc)
+            if orc == 1:
+                assert np.array_equal(got, want), (name, pt, opt, int(np.count_nonzero(got != want)))
+        p.close()
+    assert n_entries > 50000
+    after = J.kernel_launch_counts()
+    chunked = [k for k in after if "persistent" in k and k.endswith("Li1EEvPK12jda_dev_descPK9jda_stripjj") and after[k] > before.get(k, 0)]
+    assert len(chunked) == 2, (chunked, sorted(after))           # the 4:2:0 and the 4:4:4 kernel both ran

@@ -22,7 +22,9 @@ work = [("photos x2048", [photo[n] for n in ("tulips", "zebra", "st_peters", "pe
         ("metric x32", [cached_jpeg(4096, 4096, "4:2:0", 1234 + i) for i in range(2)], 32)]
 for name, jpegs, n in work:
     files = [jpegs[i % len(jpegs)] for i in range(n)]
-    prepared = J.prepare_batch(files, device_prescan=dev_prescan, threads=8)
+    prep = {"blocks": J.prepare_batch(files, device_prescan=dev_prescan, threads=8, flags=J.PREPARE_CONT_NEVER),
+            "chunks": J.prepare_batch(files, device_prescan=dev_prescan, threads=8, flags=J.PREPARE_CONT_ALWAYS)}
+    prepared = prep["blocks"]
     geos = [p.geometry(J.RGB8888, 0) for p in prepared[: len(jpegs)]]
     pit = [(g["canvas_w"] * 4 + 15) & ~15 for g in geos]
     size = [pit[k] * geos[k]["canvas_h"] for k in range(len(jpegs))]
@@ -30,13 +32,12 @@ for name, jpegs, n in work:
     for i in range(n):
         offs.append(total); total += (size[i % len(jpegs)] + 255) & ~255
     base = ctx.malloc(total)
-    devimgs = J.upload_batch(ctx, prepared)
+    dev = {m: J.upload_batch(ctx, prep[m]) for m in prep}
+    devimgs = dev["blocks"]
     outs = [(base + offs[i], pit[i % len(jpegs)], geos[i % len(jpegs)]["canvas_w"], geos[i % len(jpegs)]["canvas_h"]) for i in range(n)]
     batches = {}
-    for mode, bits in (("blocks", -1), ("chunks", 0)):
-        lib.jda_set_cont_min_bits(bits)
-        batches[mode] = J.Batch(ctx, devimgs, outs, [J.RGB8888] * n, [0] * n)
-    lib.jda_set_cont_min_bits(56)
+    for mode in ("blocks", "chunks"):
+        batches[mode] = J.Batch(ctx, dev[mode], outs, [J.RGB8888] * n, [0] * n)
     res = {"blocks": [], "chunks": []}
     for rep in range(3):
         for mode in ("blocks", "chunks"):
@@ -56,8 +57,9 @@ for name, jpegs, n in work:
         name, "device" if devimgs[0].prescan_on_device else "host", mb, mc, mb / mc, batches["blocks"].stats["n_launches"], batches["chunks"].stats["n_launches"], ok), flush=True)
     for b in batches.values():
         b.close()
-    for x in devimgs:
-        x.close()
-    for p in prepared:
-        p.close()
+    for m in dev:
+        for x in dev[m]:
+            x.close()
+        for p in prep[m]:
+            p.close()
     ctx.free(base)
