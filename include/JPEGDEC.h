@@ -128,14 +128,16 @@ class JPEGDEC {
 // callable from C and C++ alike.  JPEGIMAGE is caller-allocated as in the reference and holds the open image as plain
 // data (there: the 18 KB decoder state; here: source pointer, parsed header, settings).  As in the reference, a JPEGIMAGE
 // needs no initialisation before JPEG_open*, any number of them may be open, and a RAM / FLASH source needs no JPEG_close
-// (src/JPEGDEC.cpp:232-236: a no-op there).  A file-sourced image owns the file's bytes until JPEG_close, as the
-// reference's owns its open file.  A handle is used where it was opened: a struct copy of a JPEGIMAGE is not a handle.
+// (src/JPEGDEC.cpp:232-236: a no-op there).  As with the reference's struct (src/JPEGDEC.h:199-239: plain state), a struct copy
+// (assignment, memcpy, a growing array that moves its elements) of an open JPEGIMAGE is an open JPEGIMAGE of the same image with
+// the same settings, independent of the original from then on.  A file-sourced image owns the file's bytes until JPEG_close, as
+// the reference's owns its open file; copies of it share them as the reference's copies share the FILE: close ONE of them.
 typedef struct jpeg_image_tag {
-    uint32_t magic;                 /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
-    uint32_t reserved;
-    struct jpeg_image_tag *self;    /* an open handle points at itself */
+    uint32_t magic[2];              /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
+    struct jpeg_image_tag *file_owner;  /* JPEG_openFile: the handle that read the file (re-opening THAT handle gives the bytes back) */
     void *file_data;                /* JPEG_openFile: the file's bytes, freed by JPEG_close */
-    uint64_t state[40];             /* the open image (opaque) */
+    uint64_t file_check;            /* file_data under a cookie: the bytes are only ever freed through a handle whose words agree */
+    uint64_t state[40];             /* the open image (opaque plain data) */
 } JPEGIMAGE;
 
 #ifdef __cplusplus

@@ -127,6 +127,8 @@ _PROTOTYPES = [
     ("jda_version", C.c_char_p, []),
     ("jda_host_alloc", _P, [C.c_size_t]),
     ("jda_host_free", None, [_P]),
+    ("jda_host_register", C.c_int, [_P, C.c_size_t]),
+    ("jda_host_unregister", C.c_int, [_P]),
 ]
 
 
@@ -523,12 +525,33 @@ class Pipeline:
 
 
 class PinnedFiles:
-    """Files copied once into ONE page-locked arena (jda_host_alloc), each at a 4 KB boundary: what a loader that reads into
-    page-locked memory hands to jda_pipeline_submit_ex(.., JDA_SUBMIT_PINNED_INPUT, ..)."""
+    """Files copied once into page-locked host memory: what a loader that reads into page-locked memory hands to
+    jda_pipeline_submit_ex(.., JDA_SUBMIT_PINNED_INPUT, ..).  Default: ONE arena (jda_host_alloc), each file at a 4 KB boundary.
+    separate=True: one allocation of exactly the file's size per file, alternately jda_host_alloc and a malloc'ed buffer made
+    known with jda_host_register (separate page-locked objects: no copy may run over the end of one or across two)."""
 
-    def __init__(self, files):
+    def __init__(self, files, separate: bool = False):
         self.lib = load_library()
         self.lens = [len(f) for f in files]
+        self.base, self._allocs, self._registered = None, [], []
+        if separate:
+            self.addrs = []
+            for k, f in enumerate(files):
+                if k & 1:
+                    buf = C.create_string_buffer(len(f))
+                    if self.lib.jda_host_register(C.addressof(buf), len(f)) != 0:
+                        raise JdaError(5, "jda_host_register(%d)" % len(f))
+                    self._registered.append(buf)
+                    a = C.addressof(buf)
+                else:
+                    a = self.lib.jda_host_alloc(len(f))
+                    if not a:
+                        raise JdaError(5, "jda_host_alloc(%d)" % len(f))
+                    self._allocs.append(a)
+                C.memmove(a, f, len(f))
+                self.addrs.append(a)
+            self.bytes = sum(self.lens)
+            return
         offs, total = [], 0
         for ln in self.lens:
             offs.append(total)
@@ -545,6 +568,11 @@ class PinnedFiles:
         if self.base:
             self.lib.jda_host_free(self.base)
             self.base = None
+        for a in self._allocs:
+            self.lib.jda_host_free(a)
+        for buf in self._registered:
+            self.lib.jda_host_unregister(C.addressof(buf))
+        self._allocs, self._registered = [], []
 
 
 SUBMIT_PINNED_INPUT = 1

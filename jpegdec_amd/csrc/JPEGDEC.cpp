@@ -320,8 +320,6 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     const bool use_pinned = banded && s->pinned_canvas != NULL;
     if (!use_pinned && s->canvas.size() < canvas_bytes) s->canvas.resize(canvas_bytes);
     uint8_t *const canvas = use_pinned ? s->pinned_canvas : s->canvas.data();    // (every row the replay reads is copied back by this decode: the MCU rows it keeps)
-    static const bool poison = getenv("JPEGDEC_AMD_POISON_CANVAS") != NULL;     // (tests: what the last decode left must never show)
-    if (poison) memset(canvas, 0xA5, (size_t)cw * ch * bpp);
     // A cropped decode only launches the tiles of the MCUs the reference keeps (jpeg.inl:5111, :5134-5137: MCU rows from the crop's
     // first row on, MCU columns from iCropX up to and including the one AT iCropX + iCropCX -- the '>' there).  The reference
     // still entropy-decodes what it skips (it has to, to find the next MCU); the per-block index makes that unnecessary here.
@@ -543,13 +541,18 @@ int JPEGDEC::decode(int x, int y, int iOptions)
 // path needs the whole scan) until JPEG_close, as the reference's owns its open file.  The work is done by one JPEGDEC object per
 // THREAD that a call loads the handle's settings into and stores them back from; the decoded canvas and the page-locked copy-back
 // buffer are that object's and serve every handle the thread decodes.
-#define JPEGIMAGE_MAGIC 0x4a444133u   /* "JDA3" */
+#define JPEGIMAGE_MAGIC0 0x4a444133u   /* "JDA3" */
+#define JPEGIMAGE_MAGIC1 0x9b1e5a7du
+#define JPEGIMAGE_FILE_COOKIE 0x6a64615f66696c65ull
 struct jpegdec_amd_c_api { static jpegdec_amd_state *state(JPEGDEC &j) { return j._jpeg; } };
 namespace {
 static_assert(sizeof(jpegdec_amd_settings) <= sizeof(((JPEGIMAGE *)0)->state), "JPEGIMAGE holds the settings");
 thread_local JPEGDEC t_cworker;
-// a live handle: opened by this library and still at the address it was opened at (stack garbage and struct copies are not)
-bool c_live(const JPEGIMAGE *p) { return p && p->magic == JPEGIMAGE_MAGIC && p->self == p; }
+// a live handle: opened by this library (64 bits that stack garbage does not hold), wherever it lies now -- a struct copy of an open
+// JPEGIMAGE is an open JPEGIMAGE, as with the reference's plain struct (src/JPEGDEC.h:199-239)
+bool c_live(const JPEGIMAGE *p) { return p && p->magic[0] == JPEGIMAGE_MAGIC0 && p->magic[1] == JPEGIMAGE_MAGIC1; }
+// .. that holds a file's bytes: the pointer and its check word agree (nothing is freed through a handle whose words do not)
+bool c_has_file(const JPEGIMAGE *p) { return c_live(p) && p->file_data && p->file_check == ((uint64_t)(uintptr_t)p->file_data ^ JPEGIMAGE_FILE_COOKIE); }
 jpegdec_amd_state *c_load(JPEGIMAGE *p)
 {
     if (!c_live(p)) return NULL;
@@ -558,12 +561,13 @@ jpegdec_amd_state *c_load(JPEGIMAGE *p)
     return s;
 }
 void c_store(JPEGIMAGE *p) { memcpy(p->state, static_cast<const jpegdec_amd_settings *>(jpegdec_amd_c_api::state(t_cworker)), sizeof(jpegdec_amd_settings)); }
-// JPEG_open*: the reference memsets its state (jpeg.inl:569); a live file-sourced handle that is opened again gives its bytes back first
+// JPEG_open*: the reference memsets its state (jpeg.inl:569).  The handle that READ a file gives its bytes back when it is opened
+// again without a close (the reference leaks its FILE there); a copy of it that is opened again leaves them to the original.
 void c_begin_open(JPEGIMAGE *p)
 {
-    if (c_live(p) && p->file_data) free(p->file_data);
+    if (c_has_file(p) && p->file_owner == p) free(p->file_data);
     memset(p, 0, sizeof(*p));
-    p->magic = JPEGIMAGE_MAGIC; p->self = p;
+    p->magic[0] = JPEGIMAGE_MAGIC0; p->magic[1] = JPEGIMAGE_MAGIC1;
     jpegdec_amd_c_api::state(t_cworker)->device = -1;
 }
 }
@@ -583,13 +587,15 @@ int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *
     const int rc = t_cworker.open(szFilename, pfnDraw);
     jpegdec_amd_state *s = jpegdec_amd_c_api::state(t_cworker);
     if (!s->owned.empty()) {                                    // the file's bytes go with the handle (the worker serves other handles next)
-        pJPEG->file_data = malloc(s->owned.size());
-        if (pJPEG->file_data) { memcpy(pJPEG->file_data, s->owned.data(), s->owned.size()); s->data = (const uint8_t *)pJPEG->file_data; }
-        else { s->data = NULL; s->size = 0; s->opened = false; s->error = JPEG_ERROR_MEMORY; }
+        if (rc) pJPEG->file_data = malloc(s->owned.size());     // (a file that was read and did not parse: nothing to keep -- the reference has nothing to free after a failed open either)
+        if (pJPEG->file_data) {
+            memcpy(pJPEG->file_data, s->owned.data(), s->owned.size()); s->data = (const uint8_t *)pJPEG->file_data;
+            pJPEG->file_owner = pJPEG; pJPEG->file_check = (uint64_t)(uintptr_t)pJPEG->file_data ^ JPEGIMAGE_FILE_COOKIE;
+        } else { s->data = NULL; s->size = 0; s->opened = false; if (rc) s->error = JPEG_ERROR_MEMORY; }
         std::vector<uint8_t>().swap(s->owned);
     }
     c_store(pJPEG);
-    return pJPEG->file_data || s->size == 0 ? rc : 0;
+    return pJPEG->file_data ? rc : 0;
 }
 #define JDA_C_CALL(p, expr) do { if (jpegdec_amd_state *s_ = c_load(p)) { (void)s_; expr; c_store(p); } } while (0)
 void JPEG_setFramebuffer(JPEGIMAGE *pJPEG, void *pFramebuffer) { JDA_C_CALL(pJPEG, t_cworker.setFramebuffer(pFramebuffer)); }
@@ -614,10 +620,11 @@ void JPEG_close(JPEGIMAGE *pJPEG)
 {
     if (!pJPEG) return;
     if (c_live(pJPEG)) {
+        const bool file = c_has_file(pJPEG);
         JDA_C_CALL(pJPEG, t_cworker.close());
-        if (pJPEG->file_data) free(pJPEG->file_data);
+        if (file) free(pJPEG->file_data);
     }
-    pJPEG->file_data = NULL; pJPEG->self = NULL; pJPEG->magic = 0;
+    pJPEG->file_data = NULL; pJPEG->file_owner = NULL; pJPEG->file_check = 0; pJPEG->magic[0] = pJPEG->magic[1] = 0;
 }
 int JPEG_getLastError(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getLastError() : JPEG_INVALID_PARAMETER; }
 int JPEG_getOrientation(JPEGIMAGE *pJPEG) { return c_load(pJPEG) ? t_cworker.getOrientation() : 0; }

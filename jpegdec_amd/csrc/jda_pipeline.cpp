@@ -382,26 +382,34 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     // (raw_skip: its alignment).  A command that would carry less than 128 KB is not worth its cost: those files, and all of them when
     // the input is pageable, go through the pipeline's page-locked mirror (the workers copy them, one command takes them all).
     static const uint32_t direct_min = []() { const char *e = JDA_LAB_ENV("JDA_PIPE_DIRECT_MIN"); return e ? (uint32_t)atoi(e) : (uint32_t)JDA_PIPE_DIRECT_MIN_BYTES; }();
-    struct Run { const uint8_t *src; size_t bytes, off; int files; };
+    struct Run { const uint8_t *src; size_t bytes, off; int files; uintptr_t range; };
     std::vector<Run> runs;
     std::vector<size_t> delta((size_t)n, 0);
     std::vector<int> run_of((size_t)n, -1);
     for (int i = 0; i < n; i++) { S.imgs[(size_t)i].direct = false; S.imgs[(size_t)i].raw_skip = 0; }
     if (flags & JDA_SUBMIT_PINNED_INPUT) {
+        // a file is read where it lies when its entropy-coded bytes lie inside ONE page-locked range the library knows (jda_host_alloc /
+        // jda_host_register); the others take the mirror.  A command copies [start rounded down to 16 bytes -- still the file's own
+        // header --, the last file's last byte): nothing in front of, behind or between page-locked objects is read
         std::vector<int> dix;
-        for (int i = 0; i < n; i++) if (S.imgs[(size_t)i].device) dix.push_back(i);
+        std::vector<uintptr_t> range_of((size_t)n, 0);
+        for (int i = 0; i < n; i++) {
+            Img &im = S.imgs[(size_t)i];
+            uintptr_t rb = 0; size_t rl = 0;
+            if (im.device && im.f.raw_off >= 16u && jda_host_range_of(jpegs[i] + im.f.raw_off - 15u, (size_t)im.f.raw_len + 15u, &rb, &rl)) { range_of[(size_t)i] = rb; dix.push_back(i); }
+        }
         std::sort(dix.begin(), dix.end(), [&](int a, int b) { return jpegs[a] + S.imgs[(size_t)a].f.raw_off < jpegs[b] + S.imgs[(size_t)b].f.raw_off; });
         const uint8_t *last_end = NULL;
         for (int i : dix) {
             Img &im = S.imgs[(size_t)i];
             const uint8_t *b = jpegs[i] + im.f.raw_off, *e = b + im.f.raw_len;
-            if (runs.empty() || b < last_end || (size_t)(b - last_end) > ((size_t)64 << 10) || (size_t)(e - runs.back().src) > ((size_t)1 << 30)) {
+            if (runs.empty() || runs.back().range != range_of[(size_t)i] || b < last_end || (size_t)(b - last_end) > ((size_t)64 << 10) || (size_t)(e - runs.back().src) > ((size_t)1 << 30)) {
                 Run r;
-                r.src = (const uint8_t *)((uintptr_t)b & ~(uintptr_t)15); r.bytes = 0; r.off = 0; r.files = 0;
+                r.src = (const uint8_t *)((uintptr_t)b & ~(uintptr_t)15); r.bytes = 0; r.off = 0; r.files = 0; r.range = range_of[(size_t)i];
                 runs.push_back(r);
             }
             Run &r = runs.back();
-            r.bytes = a16((size_t)(e - r.src)); r.files++;
+            r.bytes = (size_t)(e - r.src); r.files++;
             delta[(size_t)i] = (size_t)(b - r.src); run_of[(size_t)i] = (int)runs.size() - 1;
             last_end = e;
         }
@@ -409,7 +417,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     }
     for (int i = 0; i < n; i++) { Img &im = S.imgs[(size_t)i]; if (im.device && !im.direct) im.off_raw = take(a16(im.f.raw_len) + 16); }
     const size_t raw_end = arena;                             // [0, raw_end) = control blob + the mirrored scans: one H2D copy from the page-locked mirror
-    for (Run &r : runs) if (r.bytes >= direct_min) r.off = take(r.bytes + 16);
+    for (Run &r : runs) if (r.bytes >= direct_min) r.off = take(a16(r.bytes) + 16);
     for (int i = 0; i < n; i++) {
         Img &im = S.imgs[(size_t)i];
         if (!im.direct) continue;
@@ -722,6 +730,7 @@ int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t
     if (ticket < 0 || ticket >= p->next_ticket) return JDA_INVALID_PARAMETER;
     jda_pipeline::Slot &S = p->slots[ticket % p->depth];
     if (S.in_flight || S.ticket != ticket || i < 0 || i >= (int)S.imgs.size() || !S.imgs[(size_t)i].device) return JDA_INVALID_PARAMETER;
+    if (!S.dev) return JDA_INVALID_PARAMETER;               // (the slot's arena was given back when another slot ran out of memory)
     const Img &im = S.imgs[(size_t)i];
     (void)hipSetDevice(p->ctx->device);
     hipError_t e = hipSuccess;

@@ -17,6 +17,9 @@
 #include <thread>
 #include <vector>
 
+#include <map>
+#include <mutex>
+
 #include "jda_runtime_internal.h"
 
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
@@ -158,14 +161,47 @@ void jda_destroy(jda_ctx *ctx)
 const char *jda_last_hip_error(const jda_ctx *ctx) { return ctx ? ctx->last_error : "no context"; }
 void *jda_stream(jda_ctx *ctx) { return ctx ? (void *)ctx->stream : NULL; }
 
+// The page-locked host ranges the library has made or been told of (jda_host_alloc / jda_host_register), by base address:
+// jda_pipeline_submit_ex(.., JDA_SUBMIT_PINNED_INPUT) lets the copy engine read a file where it lies only when the file lies
+// inside ONE of them, and joins two files into one copy command only inside the same one (a copy that runs over the end of a
+// page-locked object, or across the gap between two, is not the caller's memory to read).
+namespace {
+std::mutex g_host_ranges_mu;
+std::map<uintptr_t, size_t> g_host_ranges;
+void host_range_add(void *p, size_t bytes) { std::lock_guard<std::mutex> g(g_host_ranges_mu); g_host_ranges[(uintptr_t)p] = bytes; }
+void host_range_del(void *p) { std::lock_guard<std::mutex> g(g_host_ranges_mu); g_host_ranges.erase((uintptr_t)p); }
+}
+// the range [*base, *base + *bytes) that holds [p, p + len); 0 when no single known range does
+int jda_host_range_of(const void *p, size_t len, uintptr_t *base, size_t *bytes)
+{
+    std::lock_guard<std::mutex> g(g_host_ranges_mu);
+    auto it = g_host_ranges.upper_bound((uintptr_t)p);
+    if (it == g_host_ranges.begin()) return 0;
+    --it;
+    if ((uintptr_t)p + len > it->first + it->second) return 0;
+    *base = it->first; *bytes = it->second;
+    return 1;
+}
 void *jda_host_alloc(size_t bytes)
 {
     void *p = NULL;
-    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) == hipSuccess ? p : NULL;      // (every GPU of the node may read it: jda_node)
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) return NULL;      // (every GPU of the node may read it: jda_node)
+    host_range_add(p, bytes ? bytes : 16);
+    return p;
 }
-void jda_host_free(void *p) { if (p) (void)hipHostFree(p); }
-int jda_host_register(void *p, size_t bytes) { return (p && bytes && hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess) ? JDA_SUCCESS : JDA_ERROR_HIP; }
-int jda_host_unregister(void *p) { return (p && hipHostUnregister(p) == hipSuccess) ? JDA_SUCCESS : JDA_ERROR_HIP; }
+void jda_host_free(void *p) { if (p) { host_range_del(p); (void)hipHostFree(p); } }
+int jda_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes || hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) return JDA_ERROR_HIP;
+    host_range_add(p, bytes);
+    return JDA_SUCCESS;
+}
+int jda_host_unregister(void *p)
+{
+    if (!p) return JDA_ERROR_HIP;
+    host_range_del(p);
+    return hipHostUnregister(p) == hipSuccess ? JDA_SUCCESS : JDA_ERROR_HIP;
+}
 
 void *jda_malloc(jda_ctx *ctx, size_t bytes)
 {

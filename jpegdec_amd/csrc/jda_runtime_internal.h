@@ -67,6 +67,7 @@ void jda_pool_free(jda_ctx *ctx, void *p);
 extern "C" jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const *images, const jda_output *outputs, const int32_t *pixel_types,
                                               const int32_t *options, const int32_t *mcu_rects, const int32_t *strip_mcus, int32_t *err);
 int jda_plain_variant(const jda_dev_desc &D);
+extern "C" int jda_host_range_of(const void *p, size_t len, uintptr_t *base, size_t *bytes);   // the page-locked range (jda_host_alloc / jda_host_register) that holds [p, p + len)
 // which launch list an image's tiles go to: ((mode * 2 + fast) * 4 + variant) * 2 + big.  The combination fast = 0, variant = 3 (no
 // plain-case kernel exists without the 24-bit multiplies) names the DC thumbnail kernel: 1/8 scale -- also every progressive
 // file's DC scan at its default scale --, whose pixels are the blocks' DC values (jpeg.inl:5146-5154): no scan, no index, no IDCT

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <utility>
 #include <vector>
@@ -62,8 +63,24 @@ int main(int argc, char **argv)
     JPEG_getCropArea(&imgs[8], &cx, &cy, &cw, &ch);
     CHECK(14, cx == 0 && cy == 0 && cw == w && ch == h);                              // .. and with no other
     for (int k = 0; k < 1000; k++) CHECK(15, JPEG_openRAM(&imgs[5], jpeg.data(), (int)len, draw) == 1);    // re-opening a handle
-    JPEGIMAGE copy = imgs[3];                                                         // a struct copy is not a handle
-    CHECK(16, JPEG_getWidth(&copy) == 0 && JPEG_getWidth(&imgs[3]) == w);
+    JPEG_setPixelType(&imgs[3], RGB565_BIG_ENDIAN);
+    JPEGIMAGE copy = imgs[3];                                                         // a struct copy is an open handle of the same image (src/JPEGDEC.h:199-239: plain state) ..
+    CHECK(16, JPEG_getWidth(&copy) == w && JPEG_getWidth(&imgs[3]) == w);
+    JPEG_setCropArea(&copy, 32, 32, 64, 64);                                          // .. independent of the original from then on
+    JPEG_getCropArea(&imgs[3], &cx, &cy, &cw, &ch);
+    CHECK(22, cx == 0 && cy == 0 && cw == w && ch == h);
+    JPEG_getCropArea(&copy, &cx, &cy, &cw, &ch);
+    CHECK(23, cx == 32 && cy == 32);
+    {                                                                                 // a growing array moves its elements: they stay open
+        std::vector<JPEGIMAGE> grow;
+        for (int i = 0; i < 300; i++) {
+            JPEGIMAGE one;
+            memset(&one, 0x77, sizeof(one));
+            CHECK(24, JPEG_openRAM(&one, jpeg.data(), (int)len, draw) == 1);
+            grow.push_back(one);
+        }
+        for (size_t i = 0; i < grow.size(); i++) CHECK(25, JPEG_getWidth(&grow[i]) == w && JPEG_getHeight(&grow[i]) == h);
+    }
     JPEG_close(&imgs[N - 1]);
     CHECK(17, JPEG_getWidth(&imgs[N - 1]) == 0);
     for (int k = 0; k < 50; k++) {                                                   // file sources: opened, re-opened without a close (the bytes are given back), closed
@@ -71,10 +88,28 @@ int main(int argc, char **argv)
         memset(&fi, 0x5A, sizeof(fi));
         CHECK(18, JPEG_openFile(&fi, argv[1], draw) == 1 && JPEG_getWidth(&fi) == w);
         CHECK(19, JPEG_openFile(&fi, argv[1], draw) == 1 && JPEG_getHeight(&fi) == h);
-        JPEG_close(&fi);
-        CHECK(20, JPEG_getWidth(&fi) == 0);
+        JPEGIMAGE moved = fi;                                                         // the struct moved elsewhere: closed where it is now
+        memset(&fi, 0, sizeof(fi));
+        CHECK(26, JPEG_getWidth(&moved) == w);
+        JPEG_close(&moved);
+        CHECK(20, JPEG_getWidth(&moved) == 0);
     }
     CHECK(21, JPEG_openFile(&imgs[0], "/nonexistent/file.jpg", draw) == 0);
+    {                                                                                 // a file that is read and is not a JPEG: the failed open keeps nothing (no close follows it)
+        char bad[] = "/tmp/jda_semantics_bad_XXXXXX";
+        const int fd = mkstemp(bad);
+        CHECK(27, fd >= 0);
+        std::vector<uint8_t> junk(4096, 0x11);
+        FILE *bf = fdopen(fd, "wb");
+        fwrite(junk.data(), 1, junk.size(), bf);
+        fclose(bf);
+        for (int k = 0; k < 200; k++) {
+            JPEGIMAGE fi;
+            memset(&fi, 0x3C, sizeof(fi));
+            CHECK(28, JPEG_openFile(&fi, bad, draw) == 0 && fi.file_data == NULL && JPEG_getLastError(&fi) != JPEG_SUCCESS);
+        }
+        remove(bad);
+    }
     printf("ok\n");
     return 0;
 }

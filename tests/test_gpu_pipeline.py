@@ -424,19 +424,29 @@ def test_pipeline_page_locked_input_is_read_where_it_lies(gpu_ctx, oracle):
     pts = [J.RGB8888 if not (J.parse(f)["subsample"] == 0) else J.GRAY8 for f in files]
     opts = [0] * len(files)
     pinned = J.PinnedFiles(files)
+    # one page-locked object of exactly the file's size per file (jda_host_alloc and jda_host_register in turn): a copy command
+    # covers bytes of ONE of them, from inside the file to its last byte
+    separate = J.PinnedFiles(files, separate=True)
+    assert any(ln % 16 for ln in separate.lens)
     pipe = J.Pipeline(gpu_ctx, max_images=len(files), depth=2, host_threads=2)
-    results = []
-    for mode in ("pageable", "pinned", "pinned"):
+    results, h2d = [], []
+    for mode in ("pageable", "pinned", "pinned", "separate", "separate", "unknown"):
         outs, metas = _surfaces(gpu_ctx, files, pts, opts)
+        before = pipe.stats["h2d_bytes"]
         if mode == "pageable":
             t = pipe.submit(files, outs, pts, opts)
+        elif mode == "unknown":      # the flag over memory the library was never told of: such files take the mirror
+            t = pipe.submit_packed(pipe.pack(files, outs, pts, opts), J.SUBMIT_PINNED_INPUT)
         else:
-            t = pipe.submit_packed(pipe.pack_pinned(pinned, list(range(len(files))), outs, pts, opts), J.SUBMIT_PINNED_INPUT)
+            t = pipe.submit_packed(pipe.pack_pinned(pinned if mode == "pinned" else separate, list(range(len(files))), outs, pts, opts), J.SUBMIT_PINNED_INPUT)
         st = pipe.wait(t)
         _check(gpu_ctx, oracle, files, pts, opts, outs, metas, st, names)
         results.append(st)
+        h2d.append(pipe.stats["h2d_bytes"] - before)
         for o in outs:
             gpu_ctx.free(o[0])
-    assert results[0] == results[1] == results[2]
+    assert all(r == results[0] for r in results)
+    assert h2d[5] == h2d[0] and abs(h2d[3] - h2d[0]) < 4096 * len(files), h2d
     pipe.close()
     pinned.close()
+    separate.close()
