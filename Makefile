@@ -53,6 +53,11 @@ nodeuser: tests/capi_c/node_user
 tests/capi_c/node_user: tests/capi_c/node_user.c include/jpegdec_amd.h $(LIB)
 	$(CC) -std=c99 -O2 -Wall -Iinclude -o $@ tests/capi_c/node_user.c -Ljpegdec_amd -ljpegdec_amd -Wl,-rpath,'$$ORIGIN/../../jpegdec_amd'
 
+# the reference's jpeg_perf_test (examples/jpeg_perf_test/jpeg_perf_test.ino) as a C program on the product library: bench.py's c1 leg
+perfuser: tests/capi_c/perf_user
+tests/capi_c/perf_user: tests/capi_c/perf_user.c include/JPEGDEC.h $(LIB)
+	$(CC) -std=c99 -O2 -Wall -Iinclude -o $@ tests/capi_c/perf_user.c -Ljpegdec_amd -ljpegdec_amd -Wl,-rpath,'$$ORIGIN/../../jpegdec_amd'
+
 # the boundary's object semantics (class copies / moves, JPEGIMAGE without initialisation or close) -- opens only, no GPU needed
 semuser: tests/capi_c/semantics_user
 tests/capi_c/semantics_user: tests/capi_c/semantics_user.cpp include/JPEGDEC.h $(LIB)
@@ -69,10 +74,10 @@ tests/fuzz/frontend_fuzz: tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp 
 	$(CXX) -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Wall -Iinclude -pthread -o $@ tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp
 
 clean:
-	rm -f $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user tests/capi_c/node_user tests/capi_c/semantics_user
+	rm -f $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user tests/capi_c/node_user tests/capi_c/semantics_user tests/capi_c/perf_user
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim classshim classcpu cuser nodeuser semuser jpegtest frontfuzz nodestub clean
+.PHONY: all lib oracle hostsim classshim classcpu cuser nodeuser semuser perfuser jpegtest frontfuzz nodestub clean
 
 # jda_node.cpp (host code above the C-ABI) over eight pretend devices -- test infrastructure, no GPU (tests/test_c_api.py)
 nodestub: tests/node_stub/node_stub_user

@@ -225,6 +225,105 @@ def photos_leg(J, ctx, threads, n_images=2048, steps=20, ramp_ms=150.0):
     return res
 
 
+def e2e_config_leg(J, ctx, what, jpegs, n_images, pt, threads, depth=3, batches=10):
+    """One of the other BASELINE.json configurations END TO END: the batch's files in page-locked host memory (a buffer per image,
+    side by side: a loader's arena) -> pixels resident in HBM through jda_pipeline (host parse + tables, H2D of the unfiltered scans,
+    device filter + pre-scan + decode; `depth` batches overlapped), host work included.  Image 0 of the last batch against the
+    reference, every surface of the last batch against the first decode of its file."""
+    t0 = time.perf_counter()
+    nd = len(jpegs)
+    files = [jpegs[i % nd] for i in range(n_images)]
+    one = J.PreparedImage(jpegs[0])
+    geo = one.geometry(pt, 0)
+    w, h = one.info.width, one.info.height
+    one.close()
+    pitch = (geo["canvas_w"] * geo["bpp"] + 15) & ~15
+    img_bytes = pitch * geo["canvas_h"]
+    surf = [ctx.malloc(img_bytes * n_images) for _ in range(depth)]
+    outs_of = [[(b + i * img_bytes, pitch, geo["canvas_w"], geo["canvas_h"]) for i in range(n_images)] for b in surf]
+    arena = J.PinnedFiles(files)
+    pipe = J.Pipeline(ctx, max_images=n_images, depth=depth, host_threads=min(threads, 8))
+    packed = [pipe.pack_pinned(arena, list(range(n_images)), o, [pt] * n_images, [0] * n_images) for o in outs_of]
+    inflight, failed, warm, tb0, t_submit = [], 0, depth + 3, 0.0, 0.0
+    for k in range(warm + batches):
+        if k == warm:
+            while inflight:
+                pipe.wait(inflight.pop(0))
+            ctx.sync()
+            tb0 = time.perf_counter()
+        if len(inflight) == depth:
+            failed += sum(1 for s_ in pipe.wait(inflight.pop(0)) if s_ != 0)
+        ts = time.perf_counter()
+        inflight.append(pipe.submit_packed(packed[k % depth], J.SUBMIT_PINNED_INPUT))
+        if k >= warm:
+            t_submit += time.perf_counter() - ts
+    while inflight:
+        failed += sum(1 for s_ in pipe.wait(inflight.pop(0)) if s_ != 0)
+    ctx.sync()
+    dt = time.perf_counter() - tb0
+    last = outs_of[(warm + batches - 1) % depth]
+    sums = ctx.checksums(last, [geo["canvas_w"] * geo["bpp"]] * n_images)
+    pst = pipe.stats
+    res = {"workload": what, "images_per_batch": n_images, "distinct_images": nd, "depth": depth, "batches": batches,
+           "bits_per_pixel": round(8.0 * sum(len(j) for j in jpegs) / (nd * w * h), 3),
+           "mpix_s": float(w) * h * n_images * batches / dt / 1e6, "images_per_s": n_images * batches / dt, "ms_per_batch": dt / batches * 1e3,
+           "host_submit_ms_per_batch": t_submit / batches * 1e3, "failed_images": failed,
+           "device_path_images": pst["device_images"], "host_path_images": pst["host_path_images"],
+           "parity_image_0": check_against_reference(J, ctx, files[0], pt, 0, last[0][0], img_bytes, pitch, geo, sums[0]),
+           "every_surface_equals_the_first_decode_of_its_file": bool(all(sums[i] == sums[i % nd] for i in range(n_images)))}
+    pipe.close()
+    arena.close()
+    for b in surf:
+        ctx.free(b)
+    res["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    return res
+
+
+def c1_leg(J):
+    """BASELINE config 1, the reference's one published benchmark (README.md:32-38, examples/jpeg_perf_test/jpeg_perf_test.ino:8-53):
+    test_images/tulips (640x480 4:2:0, restart interval per MCU row) -> RGB565 through the drop-in API with a draw callback that does
+    nothing -- here JPEG_openRAM + JPEG_decode + JPEG_close of libjpegdec_amd.so from a C program (tests/capi_c/perf_user.c), full size
+    and the three scaled decodes of the sketch; beside it the reference's own builds (oracle/_ref: SSE2 and scalar) on ONE thread of
+    this host, the same convention.  A latency figure: one image at a time, files and pixels in host memory."""
+    import subprocess
+
+    t0 = time.perf_counter()
+    path = os.path.join(ROOT, "tests", "golden", "ref", "tulips.jpg")
+    exe = os.path.join(ROOT, "tests", "capi_c", "perf_user")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "perfuser"], cwd=ROOT, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    res = {"workload": "tulips 640x480 4:2:0 (test_images/tulips.h) -> RGB565, one image at a time, open + decode(0, 0, options) + close with a no-op draw "
+                       "callback (jpeg_perf_test.ino); the GPU path through the C flavour of the drop-in API (host memory -> JPEGDRAW strips in host memory)",
+           "gpu_us_per_decode": {}, "reference_sse2_1_thread_us": {}, "reference_scalar_1_thread_us": {}}
+    for tag, opt in (("full", 0), ("half", 2), ("quarter", 4), ("eighth", 8)):
+        r = subprocess.run([exe, path, "0", str(opt), "1500" if opt == 0 else "500"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        try:
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            j = {"error": r.stdout[-300:]}
+        res["gpu_us_per_decode"][tag] = j.get("us_per_decode", j)
+        if tag == "full":
+            res["gpu_best_us"], res["draw_calls_per_decode"] = j.get("best_us"), j.get("draw_calls_per_decode")
+    try:
+        from oracle.loader import RefDecoder, ref_available
+        jpeg = open(path, "rb").read()
+        for key, simd in (("reference_sse2_1_thread_us", True), ("reference_scalar_1_thread_us", False)):
+            if not ref_available(simd):
+                continue
+            dec = RefDecoder(simd)
+            for tag, opt in (("full", 0), ("half", 2), ("quarter", 4), ("eighth", 8)):
+                dec.bench([jpeg], 0, opt, 20, 1)
+                r = dec.bench([jpeg], 0, opt, 400, 1)
+                res[key][tag] = round(r["seconds"] / 400 * 1e6, 1)
+    except Exception as e:
+        res["reference_error"] = "%s: %s" % (type(e).__name__, e)
+    g, c = res["gpu_us_per_decode"].get("full"), res["reference_sse2_1_thread_us"].get("full")
+    if isinstance(g, float) and c:
+        res["gpu_over_sse2_1_thread"] = round(c / g, 2)
+    res["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    return res
+
+
 def kernel_sources_sha():
     """What the decode kernel is compiled from: the PMC traffic file under profiles/ names the hash it was measured at."""
     import hashlib
@@ -245,7 +344,14 @@ def run_config_legs(J, ctx, threads, only=None):
         ("c5_half", "16 x 8192x8192 gray -> GRAY8 at 1/2", (8192, 8192, "gray", 85, 2), 16, J.GRAY8, J.SCALE_HALF),
         ("c5_quarter", "16 x 8192x8192 gray -> GRAY8 at 1/4", (8192, 8192, "gray", 85, 2), 16, J.GRAY8, J.SCALE_QUARTER),
         ("c5_eighth", "16 x 8192x8192 gray -> GRAY8 at 1/8 (DC only)", (8192, 8192, "gray", 85, 2), 16, J.GRAY8, J.SCALE_EIGHTH),
+        # the two scaled kernels as THROUGHPUT: a launch of 16 images is 23-97 us, launch-scale latency; 256 images make it 0.4-1.5 ms
+        ("c5_quarter_256", "256 x 8192x8192 gray -> GRAY8 at 1/4 (a launch long enough to be a throughput figure)", (8192, 8192, "gray", 85, 2), 256, J.GRAY8, J.SCALE_QUARTER),
+        ("c5_eighth_256", "256 x 8192x8192 gray -> GRAY8 at 1/8 (DC only; a launch long enough to be a throughput figure)", (8192, 8192, "gray", 85, 2), 256, J.GRAY8, J.SCALE_EIGHTH),
         ("q98", "64 x 4096x4096 4:2:0 at quality 98 (3.7 bit/px) -> RGB8888", (4096, 4096, "4:2:0", 98, 2), 64, J.RGB8888, 0),
+    ]
+    e2e_legs = [
+        ("c2_e2e", "1024 x 1280x720 4:2:0 -> RGB8888 END TO END through jda_pipeline (BASELINE config 2)", (1280, 720, "4:2:0", 85, 8), 1024, J.RGB8888),
+        ("c4_e2e", "1024 x 1920x1080 4:2:0 -> RGB8888 END TO END through jda_pipeline (one GPU's eighth of BASELINE config 4)", (1920, 1080, "4:2:0", 85, 8), 1024, J.RGB8888),
     ]
     out, cache = {}, {}
     for name, what, (w, h, sub, q, nd), n, pt, opt in legs:
@@ -263,6 +369,21 @@ def run_config_legs(J, ctx, threads, only=None):
             out["photos"] = photos_leg(J, ctx, threads)
         except Exception as e:
             out["photos"] = {"workload": "photographs", "error": "%s: %s" % (type(e).__name__, e)}
+    for name, what, (w, h, sub, q, nd), n, pt in e2e_legs:
+        if only and name not in only:
+            continue
+        try:
+            key = (w, h, sub, q, nd)
+            if key not in cache:
+                cache[key] = [cached_jpeg(w, h, sub, 1234 + i, quality=q) for i in range(nd)]
+            out[name] = e2e_config_leg(J, ctx, what, cache[key], n, pt, threads)
+        except Exception as e:
+            out[name] = {"workload": what, "error": "%s: %s" % (type(e).__name__, e)}
+    if not only or "c1" in only:
+        try:
+            out["c1"] = c1_leg(J)
+        except Exception as e:
+            out["c1"] = {"workload": "BASELINE config 1", "error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -290,7 +411,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e-sweep", action="store_true", help="end-to-end leg: skip the host-thread sweep, the pageable-input and the cold-input runs")
     ap.add_argument("--e2e-cold-gb", type=float, default=2.0, help="end-to-end leg, cold input: GB of distinct page-locked buffers the batches cycle through")
     ap.add_argument("--e2e-distinct", type=int, default=16, help="distinct files a batch of the end-to-end leg cycles through (metric workload; the resident batch keeps --distinct)")
-    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,q98,photos)")
+    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,c5_quarter_256,c5_eighth_256,q98,photos,c2_e2e,c4_e2e,c1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs over the other BASELINE.json configurations (`configs` in the line; N = 1, metric workload only)")
@@ -581,16 +702,16 @@ def run(args, J, out=sys.stdout):
         # The file names the hash of the kernel sources it was measured at (tools/gpu_profile.sh): with other sources in the tree the
         # figure is stale and the line says null + why.
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
         if (os.path.exists(tp) and args.workload == "metric" and (args.width, args.height, args.subsampling, args.pixel_type, args.options, args.quality)
                 == (4096, 4096, "4:2:0", "rgb8888", 0, 85)):
             tj = json.load(open(tp))
             if tj.get("kernel_sources_sha16") == kernel_sources_sha():
                 traffic = tj["hbm_bytes_per_image"] * n_mine
-                traffic_src = ("profiles/r04_pmc_traffic.json (tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
+                traffic_src = ("profiles/r05_pmc_traffic.json (tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                "correction; measured at kernel sources %s = this tree's)" % tj["kernel_sources_sha16"])
             else:
-                traffic_src = ("stale: profiles/r04_pmc_traffic.json was measured at kernel sources %s, this tree has %s -- rerun tools/gpu_profile.sh"
+                traffic_src = ("stale: profiles/r05_pmc_traffic.json was measured at kernel sources %s, this tree has %s -- rerun tools/gpu_profile.sh"
                                % (tj.get("kernel_sources_sha16"), kernel_sources_sha()))
                 print("bench.py: " + traffic_src, file=sys.stderr)
         line = {
@@ -623,7 +744,7 @@ def run(args, J, out=sys.stdout):
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "jda_decode_tiles_persistent<MODE,FAST,VARIANT,BIG>",
+                "kernel": "jda_decode_tiles_persistent<2, 1, 1, 0> (4:2:0, 24-bit multiplies, RGB8888 plain case)",
                 "kernel_ms_per_launch": kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
