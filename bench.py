@@ -225,7 +225,7 @@ def photos_leg(J, ctx, threads, n_images=2048, steps=20, ramp_ms=150.0):
     return res
 
 
-def e2e_config_leg(J, ctx, what, jpegs, n_images, pt, threads, depth=3, batches=10):
+def e2e_config_leg(J, ctx, what, jpegs, n_images, pt, threads, depth=4, batches=12):
     """One of the other BASELINE.json configurations END TO END: the batch's files in page-locked host memory (a buffer per image,
     side by side: a loader's arena) -> pixels resident in HBM through jda_pipeline (host parse + tables, H2D of the unfiltered scans,
     device filter + pre-scan + decode; `depth` batches overlapped), host work included.  Image 0 of the last batch against the

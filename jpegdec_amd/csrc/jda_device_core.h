@@ -1041,6 +1041,7 @@ struct jda_segscan_params {          // one per image
     // the walk's four tables (JDA_WT_BYTES) as jda_walk_tables_build makes them from the blob, once per image: a walker's workgroup
     // copies them (one wait) instead of converting the blob itself
     uint8_t *walk_tables;
+    uint32_t walk_tables_shared;      // 1: another image of the batch (same tables, same table ids) builds them
     // RECORD mode (NULL / 0: the counting walk + WRITE walk of round 2): the counting walk leaves one record per block start --
     // rec_cap slots per segment (more than its 2,048 bits can start blocks: jda_record_cap), 16-byte groups -- and the rare
     // magnitude read that SOME entry lag would truncate as a candidate (16 bytes: segment, ordinal + 1 | round << 16, lag word at

@@ -828,6 +828,7 @@ __global__ __launch_bounds__(1024)
 void jda_walk_tables_build(const jda_segscan_params *__restrict__ params)
 {
     const jda_segscan_params &P = params[blockIdx.x];
+    if (P.walk_tables_shared) return;
     jda_walk_tables_from(P.tables, jda_wt_dc_follow(P), threadIdx.x, 1024u, P.walk_tables);
 }
 extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream)
@@ -872,7 +873,13 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
     }
 }
 
-template <int OP>       // JDA_SEG_SPEC: round 0 (every segment from the guess "a block starts here": exit states only); JDA_SEG_RECORD: the rest
+// JDA_SEG_SPEC: round 0 (every segment from the guess "a block starts here": exit states only); JDA_SEG_RECORD: the rest.
+// LDS_TABLES: the walk's tables staged in LDS (rounds 0 and 1: every segment walks, the lookups are what the round's time is made of)
+// or read where jda_walk_tables_build left them, through the L2 (the rounds behind: a few percent of the segments, each a chain of
+// dependent steps whose length nothing shortens -- what matters there is what the round keeps OTHERS from doing: a workgroup that holds
+// 32 KB of LDS keeps a decode workgroup, which needs the CU's whole LDS, off its CU for the length of a walk; a wavefront of <= 64
+// registers and no LDS runs beside one).
+template <int OP, bool LDS_TABLES>
 __global__ __launch_bounds__(256)
 void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t round)
 {
@@ -886,9 +893,11 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
     const uint32_t JDA_GLOBAL *wl_in = JDA_G(const uint32_t, P.worklist) + ((round & 1u) ? P.worklist_cap : 0u);
     uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
-    uint8_t *tab = lds;
-    jda_walk_tables_stage(P.walk_tables, threadIdx.x, 256u, tab);
-    __syncthreads();                                                 // the tables: all that is staged (a walk reads its segment from memory)
+    const uint8_t *tab = LDS_TABLES ? (const uint8_t *)lds : (const uint8_t *)JDA_G(const uint8_t, P.walk_tables);
+    if (LDS_TABLES) {
+        jda_walk_tables_stage(P.walk_tables, threadIdx.x, 256u, lds);
+        __syncthreads();                                             // the tables: all that is staged (a walk reads its segment from memory)
+    }
     for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < count; base += gridDim.x * 256u) {
         const uint32_t item = base + lane;
         if (item >= count) continue;
@@ -896,13 +905,17 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
     }
 }
 
-// The rounds behind the first few, in ONE launch: one workgroup of 16 wavefronts per image goes round after round (a barrier and a
-// fence between two) until a round leaves its list empty -- lists of a handful of segments by then; a launch per round cost more
-// than its walk, and a fixed number of launches was a limit on the rounds.  stats[7] = 1: settled (0: max_round reached).
-__global__ __launch_bounds__(1024)
+// The rounds behind the first few, in ONE launch: one workgroup per image goes round after round (a barrier and a fence between two)
+// until a round leaves its list empty -- lists of a handful of segments by then; a launch per round cost more than its walk, and a
+// fixed number of launches was a limit on the rounds.  stats[7] = 1: settled (0: max_round reached).
+// LDS_TABLES: sixteen wavefronts around the tables in LDS (large images: dozens of segments a round) / four wavefronts, tables through
+// the L2 (batches of small images: see jda_segscan_fused).
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(LDS_TABLES ? 1024 : 256)
 void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t first_round, uint32_t max_round)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t nthreads = LDS_TABLES ? 1024u : 256u;
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.x]);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t *stats = P.stats;
@@ -910,14 +923,16 @@ void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t fi
     uint32_t count = __hip_atomic_load(&stats[8u + round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (count == 0) { if (threadIdx.x == 0) stats[7] = 1; return; }       // (the usual case: nothing is staged)
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
-    uint8_t *tab = lds;
-    jda_walk_tables_stage(P.walk_tables, threadIdx.x, 1024u, tab);
-    __syncthreads();
+    const uint8_t *tab = LDS_TABLES ? (const uint8_t *)lds : (const uint8_t *)JDA_G(const uint8_t, P.walk_tables);
+    if (LDS_TABLES) {
+        jda_walk_tables_stage(P.walk_tables, threadIdx.x, nthreads, lds);
+        __syncthreads();
+    }
     while (count != 0 && round < max_round) {
         const uint32_t JDA_GLOBAL *wl_in = JDA_G(const uint32_t, P.worklist) + ((round & 1u) ? P.worklist_cap : 0u);
         uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
         if (count > P.worklist_cap) count = P.worklist_cap;
-        for (uint32_t base = wave * 64u; base < count; base += 1024u) {
+        for (uint32_t base = wave * 64u; base < count; base += nthreads) {
             const uint32_t item = base + lane;
             if (item >= count) continue;
             jda_fused_item<JDA_SEG_RECORD>(P, tab, wl_in[item], round, lane, E, wl_out);
@@ -930,6 +945,8 @@ void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t fi
     if (threadIdx.x == 0) stats[7] = count == 0 ? 1u : 0u;
 }
 
+// batches whose longest scan has at most this many segments (512 KB) take the late rounds without LDS
+#define JDA_SMALL_SCAN_SEGS 2048u
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
@@ -943,22 +960,25 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     const int lds_bytes = JDA_WT_BYTES + (round == 0 ? lds_extra0 : lds_extra1);
     static std::atomic<unsigned long long> attr_done0(0), attr_done1(0);
     {
-        hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_SPEC>, lds_max, attr_done0);
-        if (e == hipSuccess) e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_RECORD>, lds_max, attr_done1);
+        hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_SPEC, true>, lds_max, attr_done0);
+        if (e == hipSuccess) e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_RECORD, true>, lds_max, attr_done1);
         if (e != hipSuccess) return e;
     }
     const uint32_t full = (max_segs + 255u) / 256u;
     // later rounds walk a few percent of the segments: a few workgroups per image, each stepping through the list
     const dim3 grid(round <= 1 ? full : (full < 8u ? full : 8u), n_images), block(256);
-    if (round == 0) JDA_LAUNCH(jda_segscan_fused<JDA_SEG_SPEC>, grid, block, lds_bytes, stream, params, round);
-    else JDA_LAUNCH(jda_segscan_fused<JDA_SEG_RECORD>, grid, block, lds_bytes, stream, params, round);
+    if (round == 0) JDA_LAUNCH((jda_segscan_fused<JDA_SEG_SPEC, true>), grid, block, lds_bytes, stream, params, round);
+    else if (round == 1) JDA_LAUNCH((jda_segscan_fused<JDA_SEG_RECORD, true>), grid, block, lds_bytes, stream, params, round);
+    else if (max_segs > JDA_SMALL_SCAN_SEGS) JDA_LAUNCH((jda_segscan_fused<JDA_SEG_RECORD, true>), grid, block, lds_bytes, stream, params, round);
+    else JDA_LAUNCH((jda_segscan_fused<JDA_SEG_RECORD, false>), grid, block, 0, stream, params, round);
     return hipGetLastError();
 }
 
-extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t first_round, uint32_t max_round, hipStream_t stream)
+extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t first_round, uint32_t max_round, hipStream_t stream)
 {
     if (n_images == 0) return hipSuccess;
-    JDA_LAUNCH(jda_segscan_tail, dim3(n_images), dim3(1024), JDA_WT_BYTES, stream, params, first_round, max_round);
+    if (max_segs > JDA_SMALL_SCAN_SEGS) JDA_LAUNCH(jda_segscan_tail<true>, dim3(n_images), dim3(1024), JDA_WT_BYTES, stream, params, first_round, max_round);
+    else JDA_LAUNCH(jda_segscan_tail<false>, dim3(n_images), dim3(256), 0, stream, params, first_round, max_round);
     return hipGetLastError();
 }
 
@@ -1181,7 +1201,7 @@ extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params
     if (n_images == 0 || max_segs == 0) return hipSuccess;
     hipError_t e = hipSuccess;
     for (uint32_t r = 0; r < list_rounds && e == hipSuccess; r++) e = jda_launch_segscan_fused(params, n_images, max_segs, r, stream);
-    if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, list_rounds, max_round, stream);
+    if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, max_segs, list_rounds, max_round, stream);
     if (e == hipSuccess) e = jda_launch_segscan_sums(params, n_images, stream);
     if (e == hipSuccess && any_record) {
         JDA_LAUNCH(jda_segscan_finalize, dim3((max_segs + 4u * JDA_FIN_SEGS_PER_WAVE - 1u) / (4u * JDA_FIN_SEGS_PER_WAVE), n_images), dim3(256), 0, stream, params);

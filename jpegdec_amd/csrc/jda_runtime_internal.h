@@ -93,7 +93,7 @@ int jda_fill_launch_desc(jda_dev_desc &D, const jda_image_info &I, const uint8_t
 
 extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, hipStream_t stream);
 extern "C" hipError_t jda_launch_checksum(const void *base, uint32_t pitch, uint32_t row_bytes, uint32_t rows, unsigned long long *out, hipStream_t stream);
-extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t first_round, uint32_t max_round, hipStream_t stream);
+extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t first_round, uint32_t max_round, hipStream_t stream);
 extern "C" hipError_t jda_launch_filter(const jda_filter_params *params, uint32_t n_images, uint32_t max_raw_len, hipStream_t stream);
 extern "C" hipError_t jda_launch_fill_strips(const jda_strips_params *params, uint32_t n_images, uint32_t max_tiles, hipStream_t stream);
 extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);   // before the first walk
