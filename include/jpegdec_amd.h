@@ -389,7 +389,8 @@ int jda_pipeline_read_index(jda_pipeline *p, int32_t ticket, int32_t i, uint32_t
  * DEVICE pointer on the device that owns image i (allocate with jda_malloc(jda_node_context(node, k), ..)).  What comes back
  * is status[i] per image and, for a proof that every image was decoded once and identically wherever it landed, per-image
  * checksums made where the pixels are (jda_node_checksums = jda_checksum_surfaces per device).
- *   jda_node_create   devices == NULL or n_devices <= 0: every visible device (0 .. jda_device_count() - 1); max_images_per_device
+ *   jda_node_create   devices == NULL or n_devices <= 0: every visible device (0 .. jda_device_count() - 1); an ordinal may be named more
+ *                     than once (each entry is a pipeline, a context and a host thread of its own on that device); max_images_per_device
  *                     bounds a device's block; depth / host_threads_per_device as jda_pipeline_create.  Fails with
  *                     JDA_ERROR_NO_DEVICE when there is no GPU: there is no CPU decode path.
  *   jda_node_submit   n <= devices * max_images_per_device images; buffers and surfaces stay valid until the list is waited for

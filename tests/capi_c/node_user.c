@@ -1,5 +1,5 @@
 /* A plain C program on the node entry points of libjpegdec_amd.so (include/jpegdec_amd.h, jda_node_*): one host process, every GPU.
- * Usage: node_user file.jpg n_images [n_devices]
+ * Usage: node_user file.jpg n_images [n_devices | list of device ordinals "0,0"]
  * Decodes n_images copies of the file to RGB8888 -- sharded over the node's devices in contiguous blocks, pixels resident on the
  * device that decoded them -- and prints "devices D images N ok K checksum %016llx same S": K images with status 0, the checksum of
  * image 0's surface and whether all N checksums are equal.  Exit code 0, or the library's error (6 = no GPU: there is no CPU path). */
@@ -20,14 +20,21 @@ int main(int argc, char **argv)
     uint8_t *jpeg = (uint8_t *)malloc((size_t)len);
     if (fread(jpeg, 1, (size_t)len, f) != (size_t)len) return 102;
     fclose(f);
-    const int32_t n = atoi(argv[2]), want_dev = argc > 3 ? atoi(argv[3]) : 0;
+    const int32_t n = atoi(argv[2]);
+    int32_t want_dev = argc > 3 ? atoi(argv[3]) : 0, dev_list[16];
+    const int32_t *devs = NULL;
+    if (argc > 3 && strchr(argv[3], ',')) {                  /* a list of ordinals (one may come twice: two pipelines on one GPU) */
+        want_dev = 0;
+        for (char *t = strtok(argv[3], ","); t && want_dev < 16; t = strtok(NULL, ",")) dev_list[want_dev++] = atoi(t);
+        devs = dev_list;
+    }
     jda_image_info info;
     int rc = jda_parse(jpeg, (int32_t)len, &info);
     if (rc != JDA_SUCCESS) return rc;
     int32_t bpp, ow, oh, cw, ch, err = 0;
     rc = jda_output_geometry(&info, JDA_RGB8888, 0, &bpp, &ow, &oh, &cw, &ch);
     if (rc != JDA_SUCCESS) return rc;
-    jda_node *node = jda_node_create(NULL, want_dev, n, 2, 4, &err);
+    jda_node *node = jda_node_create(devs, want_dev, n, 2, 4, &err);
     if (!node) { printf("no node: error %d\n", err); return err ? err : 103; }
     const int32_t nd = jda_node_device_count(node);
     const int32_t pitch = (cw * bpp + 15) & ~15;

@@ -85,8 +85,12 @@ int main()
     nd = jda_node_create(devs, 3, 4, 1, 3, &err);
     CHECK(51, nd && jda_node_device_count(nd) == 3 && jda_node_device(nd, 1) == 2 && stub_pipeline_threads(2) == 3);
     jda_node_destroy(nd);
-    const int32_t twice[2] = { 1, 1 };
-    CHECK(52, jda_node_create(twice, 2, 4, 1, 0, &err) == NULL && err == JDA_INVALID_PARAMETER);
+    const int32_t twice[2] = { 1, 1 };                 // a device named twice: two entries, each with its own pipeline on that device
+    nd = jda_node_create(twice, 2, 4, 1, 0, &err);
+    CHECK(52, nd && jda_node_device_count(nd) == 2 && jda_node_device(nd, 0) == 1 && jda_node_device(nd, 1) == 1);
+    jda_node_destroy(nd);
+    const int32_t beyond[1] = { 99 };
+    CHECK(53, jda_node_create(beyond, 1, 4, 1, 0, &err) == NULL && err == JDA_INVALID_PARAMETER);
     printf("ok\n");
     return 0;
 }

@@ -22,7 +22,7 @@ static int g_wrong_thread = 0;              // calls that did not come from the 
 static int g_calls_on_main = 0;
 static std::thread::id g_main = std::this_thread::get_id();
 static std::thread::id g_dev_thread[16];
-static int32_t g_pipeline_threads[16];
+static std::atomic<int32_t> g_pipeline_threads[16];      // (two entries of a node may sit on one device)
 
 extern "C" {
 int stub_wrong_thread_calls(void) { return g_wrong_thread; }
