@@ -111,6 +111,11 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
  * window of bits per block in which the decode kernel's chunked entropy phase was measured to pay (56 .. 112). */
 #define JDA_PREPARE_CONT_ALWAYS 2
 #define JDA_PREPARE_CONT_NEVER 4
+/* The host pre-scan of a stream with restart intervals (>= 4 of them, >= 12 KB of scan) decodes its intervals side by side on a few
+ * helper threads the library keeps (an interval starts at a marker with predictors zero; the reader's phase across intervals -- the
+ * one thing that carries over, SURVEY fact 6 -- is settled afterwards): the same index as the serial pre-scan's in the sense of
+ * jda_index_equivalent.  This flag keeps the pre-scan on the calling thread. */
+#define JDA_PREPARE_SERIAL_PRESCAN 8
 jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
 /* jda_prepare_ex for n images on `threads` host threads (<= 0: all hardware threads); out[i] / errs[i] per image
  * (errs may be NULL).  Returns JDA_SUCCESS or the first error met. */

@@ -190,6 +190,7 @@ def draw_plan_ex(info: ImageInfo, pixel_type=RGB8888, options=0, max_mcus=0, use
 PREPARE_DEVICE_PRESCAN = 1
 PREPARE_CONT_ALWAYS = 2
 PREPARE_CONT_NEVER = 4
+PREPARE_SERIAL_PRESCAN = 8
 
 
 class PreparedImage:

@@ -16,7 +16,7 @@ from tests.cases import SYNTH_CASES, jpeg_for
 @pytest.mark.parametrize("name", sorted(SYNTH_CASES))
 def test_prepare_matches_oracle_stage_by_stage(name, oracle, product_lib):
     jpeg = jpeg_for(name)
-    p = J.PreparedImage(jpeg)
+    p = J.PreparedImage(jpeg, flags=J.PREPARE_SERIAL_PRESCAN)      # (the serial pre-scan: the reference reader's phase in EVERY entry; the interval-parallel one: below)
     oi = oracle.info(jpeg)
     assert (p.info.width, p.info.height, p.info.ncomp, p.info.subsample, p.info.restart_interval, p.info.scan_offset) == (
         oi["width"], oi["height"], oi["ncomp"], oi["subsample"], oi["restart_interval"], oi["scan_offset"])
@@ -214,7 +214,8 @@ def test_frontend_fuzz_under_asan_ubsan():
     subprocess.run(["make", "frontfuzz"], cwd=root, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     exe = os.path.join(root, "tests", "fuzz", "frontend_fuzz")
     for seed, rel in enumerate(("golden/ref/tulips.jpg", "golden/ref/thumb_test.jpg", "golden/c444_8x8_q30.jpg", "golden/c420_16x16.jpg",
-                                "golden/gray_64x64_rst3.jpg", "golden/c440_300x64_rst5.jpg", "golden/p420_200x120.jpg", "golden/ref/corrupt5.jpg")):
+                                "golden/gray_64x64_rst3.jpg", "golden/c440_300x64_rst5.jpg", "golden/p420_200x120.jpg", "golden/ref/corrupt5.jpg",
+                                "golden/c420_640x368_rstrow.jpg", "golden/c444_384x192_q100_rst7.jpg")):      # (the last two: the interval-parallel pre-scan under the sanitizers)
         p = subprocess.run([exe, os.path.join(root, "tests", rel), "2500", str(seed + 1)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert p.returncode == 0, (rel, p.stdout[-3000:])
 
@@ -262,3 +263,63 @@ def test_word_precision_dqt_cases(hostsim, oracle):
         assert jpeg[dqt + 4] >> 4 == 1                      # Pq = 1
         rc, want, err = oracle.decode_canvas(jpeg, 2 if "gray" not in name else 0, 0)
         assert rc == 1 and len(set(want.ravel().tolist())) > 8   # (not one flat colour: the IDCT's every path sees values)
+
+
+def test_interval_parallel_prescan_equals_the_serial_one():
+    """SURVEY 8f N1 on the host: a stream with restart intervals is pre-scanned interval by interval on helper threads
+    (host_prescan_intervals; the reference reader's phase across intervals settled afterwards through the chain of its refill points).
+    Against the serial pre-scan (JDA_PREPARE_SERIAL_PRESCAN) on every restart stream of the suite, the reference's fixtures with DRI
+    (tulips 7 truncated reads, croptest 39, demo 75, perf.jpg 1,793) and dense high-quality streams: the same index in the sense of
+    jda_index_equivalent (positions and flags of every block, flagged entries identical), DC values, truncation count, continuation
+    entries; and on 300 corrupted copies the same verdict (where the interval walk gives up, the serial pre-scan decides)."""
+    import jpegdec_amd as J
+    from jpegdec_amd.synth import synth_jpeg
+    from tests.cases import SYNTH_CASES, jpeg_for
+    from tests.ref_fixtures import GOOD, ref_jpeg
+    cases = [(n, jpeg_for(n)) for n in sorted(SYNTH_CASES) if "rst" in n] + [("ref:" + n, ref_jpeg(n)) for n in GOOD]
+    cases += [("1080p_rstrow", synth_jpeg(1920, 1080, "4:2:0", seed=3, restart_rows=1)), ("c444_q100_rst9", synth_jpeg(640, 480, "4:4:4", seed=4, quality=100, restart_blocks=9)),
+              ("c420_q98_rst5", synth_jpeg(800, 608, "4:2:0", seed=5, quality=98, restart_blocks=5)), ("gray_q95_rst2", synth_jpeg(512, 512, "gray", seed=6, quality=95, restart_blocks=2))]
+
+    def same(jpeg, flags, what):
+        try:
+            a = J.PreparedImage(jpeg, flags=flags | J.PREPARE_SERIAL_PRESCAN)
+        except J.JdaError as ea:
+            with pytest.raises(J.JdaError) as eb:
+                J.PreparedImage(jpeg, flags=flags)
+            assert eb.value.code == ea.code, what
+            return 0
+        b = J.PreparedImage(jpeg, flags=flags)
+        (ia, na), (ib, nb) = a.block_index(), b.block_index()
+        assert na == nb, what
+        if na == a.n_mcus:
+            assert J.index_equivalent(ia, ib), what
+            assert np.array_equal(a.block_dc(), b.block_dc()) and a.truncation_events() == b.truncation_events(), what
+            (fa, ea_), (fb, eb_) = a.block_cont(), b.block_cont()
+            assert np.array_equal(fa, fb) and np.array_equal(ea_, eb_), what
+        else:                                   # the serial pre-scan made both: identical
+            assert np.array_equal(ia, ib) and np.array_equal(a.block_dc(), b.block_dc()), what
+        n = a.truncation_events()
+        a.close(); b.close()
+        return n
+
+    trunc = 0
+    for name, jpeg in cases:
+        for flags in (0, J.PREPARE_CONT_ALWAYS):
+            trunc += same(jpeg, flags, name)
+    assert trunc > 3000                       # (the phase chain really decided: perf.jpg alone has 1,793 truncated reads)
+    rng = np.random.default_rng(77)
+    for name in ("c420_640x368_rstrow", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow"):
+        jpeg = jpeg_for(name)
+        sos = jpeg.index(b"\xff\xda") + 14
+        for it in range(100):
+            bad = bytearray(jpeg)
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(sos, len(bad) - 2))
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    bad[at] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1:
+                    bad[at] = int(rng.integers(0, 256))
+                else:
+                    del bad[at:at + int(rng.integers(1, 40))]
+            same(bytes(bad), 0, (name, it))
