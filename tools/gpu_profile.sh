@@ -4,7 +4,7 @@
 #   domains: MI355X_MICROARCH.md), SQ counters -> gpurun_out/<tag>/, and the summaries the judge reads -> profiles/<prefix>_*:
 #   <prefix>_bench_default.json, <prefix>_kernel_stats.csv, <prefix>_pmc_traffic.json (names the hash of the kernel sources it was
 #   measured at: bench.py reports roofline.traffic from it only while the tree still has those sources), <prefix>_sq_counters.txt
-tag=${1:-r04_prof}; prefix=${2:-r04}
+tag=${1:-r05_prof}; prefix=${2:-r05}
 out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
@@ -27,7 +27,7 @@ for f in glob.glob("$out/sq_*counter_collection.csv"):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 tiles = 16 * 256 * 26          # 16 x 4096x4096 4:2:0: 256 MCU rows x 26 tiles (25 of 10 MCUs + one of 6)
 with open("$out/sq_counters.txt", "w") as o:
-    o.write("rocprofv3 --pmc (two passes) -- python bench.py --steps 2 --warmup 1 --batch 16 --ramp-ms 0: jda_decode_tiles_persistent<2,true,1,0>, mean per launch of 16 x 4096x4096 (%d tiles)\n" % tiles)
+    o.write("rocprofv3 --pmc (two passes) -- python bench.py --steps 2 --warmup 1 --batch 16 --ramp-ms 0: jda_decode_tiles_persistent<2, 1, 1, 0>, mean per launch of 16 x 4096x4096 (%d tiles)\n" % tiles)
     for k, v in sorted(acc.items()):
         o.write("%-26s %.6g\n" % (k, sum(v) / len(v)))
     if "SQ_INSTS_VALU" in acc:
@@ -44,7 +44,7 @@ fk, n = per_launch("$out/fetch_counter_collection.csv", "FETCH_SIZE")
 wk, _ = per_launch("$out/write_counter_collection.csv", "WRITE_SIZE")
 batch = b["config"]["images_per_gpu_per_step"]
 o = {"command": "tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes, no trace domains) --output-format csv -- python bench.py --steps 10 --warmup 2 --ramp-ms 0 --no-parity --no-cpu-baseline --e2e-batches 0 --no-configs",
-     "kernel": "jda_decode_tiles_persistent<2,true,1,0>", "kernel_sources_sha16": bench.kernel_sources_sha(),
+     "kernel": "jda_decode_tiles_persistent<2, 1, 1, 0>", "kernel_sources_sha16": bench.kernel_sources_sha(),
      "launches_sampled": n, "images_per_launch": batch, "workload": b["config"]["workload"],
      "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk, "write_bytes_per_image": wk * 1024 / batch,
      "fetch_bytes_per_image_raw": fk * 1024 / batch, "fetch_bytes_per_image_corrected_x2": 2 * fk * 1024 / batch,

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Static instruction mix of one kernel of the gfx950 assembly (hipcc --cuda-device-only -S of jda_kernels.hip):
-python tools/isa_mix.py k.s '<2,true,1,0>' [--spills]   -> counts per class, SGPR-spill traffic (v_readlane / v_writelane) per basic block."""
+python tools/isa_mix.py k.s '<2,1,1,0>' [--spills]   -> counts per class, SGPR-spill traffic (v_readlane / v_writelane) per basic block."""
 import collections
 import re
 import sys
 
-MANGLED = {"<2,true,1,0>": "_Z27jda_decode_tiles_persistentILi2ELb1ELi1ELi0ELi0EEvPK12jda_dev_descPK9jda_stripj",
-           "<1,true,1,0>": "_Z27jda_decode_tiles_persistentILi1ELb1ELi1ELi0ELi0EEvPK12jda_dev_descPK9jda_stripj",
-           "<0,true,3,0>": "_Z27jda_decode_tiles_persistentILi0ELb1ELi3ELi0ELi0EEvPK12jda_dev_descPK9jda_stripj"}
+MANGLED = {"<2,1,1,0>": "_Z27jda_decode_tiles_persistentILi2ELi1ELi1ELi0EEvPK12jda_dev_descPK9jda_stripjj",
+           "<1,1,1,0>": "_Z27jda_decode_tiles_persistentILi1ELi1ELi1ELi0EEvPK12jda_dev_descPK9jda_stripjj",
+           "<0,1,3,0>": "_Z27jda_decode_tiles_persistentILi0ELi1ELi3ELi0EEvPK12jda_dev_descPK9jda_stripjj"}
 
 
 def kernel_lines(path, name):
