@@ -352,6 +352,7 @@ def run_config_legs(J, ctx, threads, only=None):
     e2e_legs = [
         ("c2_e2e", "1024 x 1280x720 4:2:0 -> RGB8888 END TO END through jda_pipeline (BASELINE config 2)", (1280, 720, "4:2:0", 85, 8), 1024, J.RGB8888),
         ("c4_e2e", "1024 x 1920x1080 4:2:0 -> RGB8888 END TO END through jda_pipeline (one GPU's eighth of BASELINE config 4)", (1920, 1080, "4:2:0", 85, 8), 1024, J.RGB8888),
+        ("vga_e2e", "2048 x 640x480 4:2:0 -> RGB8888 END TO END through jda_pipeline (the size of BASELINE config 1's image, in batches)", (640, 480, "4:2:0", 85, 8), 2048, J.RGB8888),
     ]
     out, cache = {}, {}
     for name, what, (w, h, sub, q, nd), n, pt, opt in legs:
@@ -411,7 +412,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e-sweep", action="store_true", help="end-to-end leg: skip the host-thread sweep, the pageable-input and the cold-input runs")
     ap.add_argument("--e2e-cold-gb", type=float, default=2.0, help="end-to-end leg, cold input: GB of distinct page-locked buffers the batches cycle through")
     ap.add_argument("--e2e-distinct", type=int, default=16, help="distinct files a batch of the end-to-end leg cycles through (metric workload; the resident batch keeps --distinct)")
-    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,c5_quarter_256,c5_eighth_256,q98,photos,c2_e2e,c4_e2e,c1)")
+    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,c5_quarter_256,c5_eighth_256,q98,photos,c2_e2e,c4_e2e,vga_e2e,c1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs over the other BASELINE.json configurations (`configs` in the line; N = 1, metric workload only)")

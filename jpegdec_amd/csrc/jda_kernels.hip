@@ -578,13 +578,16 @@ __device__ __forceinline__ void jda_thumb_store(const jda_dev_desc &D, const jda
         else ((uint16_t JDA_GLOBAL *)rowp)[X] = (uint16_t)jda_pixel_565(p, pt == JDA_RGB565_BIG_ENDIAN);
     }
 }
+#ifndef JDA_THUMB_WAVES
+#define JDA_THUMB_WAVES 4u
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64 * JDA_THUMB_WAVES)
 void jda_dc_thumbnail(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ tiles, uint32_t n_tiles)
 {
     typedef jda_mode_traits<MODE> T;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t0 = jda_uni32((blockIdx.x * 4u + (threadIdx.x >> 6)) * JDA_THUMB_TILES);
+    const uint32_t t0 = jda_uni32((blockIdx.x * JDA_THUMB_WAVES + (threadIdx.x >> 6)) * JDA_THUMB_TILES);
     if (t0 >= n_tiles) return;
     const uint32_t n_here = n_tiles - t0 < JDA_THUMB_TILES ? n_tiles - t0 : JDA_THUMB_TILES;
     // the run's records through the scalar cache (uniform addresses): 16 bytes each
@@ -687,8 +690,79 @@ void jda_dc_thumbnail(const jda_dev_desc *__restrict__ descs, const jda_strip *_
 template <int MODE>
 static hipError_t launch_dc_thumbnail(const jda_dev_desc *descs, const jda_strip *tiles, uint32_t n_tiles, hipStream_t stream)
 {
-    const uint32_t per_wg = 4u * JDA_THUMB_TILES;
-    JDA_LAUNCH((jda_dc_thumbnail<MODE>), dim3((n_tiles + per_wg - 1u) / per_wg), dim3(256), 0, stream, descs, tiles, n_tiles);
+    const uint32_t per_wg = JDA_THUMB_WAVES * JDA_THUMB_TILES;
+    JDA_LAUNCH((jda_dc_thumbnail<MODE>), dim3((n_tiles + per_wg - 1u) / per_wg), dim3(64 * JDA_THUMB_WAVES), 0, stream, descs, tiles, n_tiles);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same for a WHOLE gray image on a row-major surface (no crop, no strips): the image's 1/8 thumbnail is a pointwise map of its DC
+// array -- pixel (X, Y) = f(DC[Y mcus_x + X]) -- so there is nothing to look up per tile: the launch list holds ONE record per image,
+// a thread takes four neighbouring blocks of a row (8 bytes in, 4 or 8 bytes out) and several such quads, all loads asked for before
+// the first is used.  The tile kernel above spent its time on the records (twelve scalar loads and a chain of compares per four
+// tiles: 0.32 ms per 256 x 8192x8192, 2.5 TB/s of the 2 + 1 bytes a block); this one is a copy kernel with a multiply in it.
+#define JDA_FLAT_QUADS 8u          // quads a thread takes, a workgroup's width apart
+__global__ __launch_bounds__(256)
+void jda_dc_thumbnail_flat(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ recs)
+{
+    typedef unsigned short jda_us2 __attribute__((ext_vector_type(2)));
+    const uint32_t __attribute__((address_space(4))) *rw = (const uint32_t __attribute__((address_space(4))) *)(uintptr_t)(recs + blockIdx.y);
+    const jda_dev_desc D = jda_desc_const<0, JDA_MODE_GRAY>(jda_desc_at(descs, rw[0]));
+    const uint32_t __attribute__((address_space(4))) *qt = (const uint32_t __attribute__((address_space(4))) *)(uintptr_t)(D.tables + JDA_TB_QUANT);
+    const int32_t q0 = (int16_t)qt[D.q_id[0] * 32u];
+    const uint32_t Q = (D.mcus_x + 3u) >> 2, n_items = Q * D.mcus_y;          // quads per row, in the image
+    const uint32_t base = blockIdx.x * (256u * JDA_FLAT_QUADS) + threadIdx.x;
+    if (base >= n_items) return;
+    const bool aligned = (D.mcus_x & 3u) == 0u;                          // a quad's four DC values are one aligned 8-byte word
+    const float rq = 1.0f / (float)Q;
+    const int pt = D.pixel_type;
+    uint64_t four[JDA_FLAT_QUADS];
+    uint32_t X0[JDA_FLAT_QUADS], Y0[JDA_FLAT_QUADS], nv[JDA_FLAT_QUADS];
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_FLAT_QUADS; k++) {
+        const uint32_t item = base + k * 256u;
+        uint32_t y = (uint32_t)((float)item * rq);                       // item / Q (item < 2^24 for every image the index admits; corrected below)
+        if (y * Q > item) y--;
+        if ((y + 1u) * Q <= item) y++;
+        const uint32_t x = (item - y * Q) * 4u;
+        X0[k] = x; Y0[k] = y; four[k] = 0; nv[k] = 0;
+        if (item >= n_items) continue;
+        const uint32_t g = y * D.mcus_x + x;                             // the quad's first block
+        uint32_t n = D.mcus_x - x < 4u ? D.mcus_x - x : 4u;              // blocks of the row it holds ..
+        n = g >= D.n_mcus_ok ? 0u : (D.n_mcus_ok - g < n ? D.n_mcus_ok - g : n);      // .. that were decoded (jpeg.inl:5354-5356)
+        nv[k] = n;
+        if (n == 4u && aligned) four[k] = JDA_G(const uint64_t, D.blk_dc)[g >> 2];
+        else for (uint32_t e = 0; e < n; e++) four[k] |= (uint64_t)(uint16_t)JDA_G(const int16_t, D.blk_dc)[g + e] << (16u * e);
+    }
+    const uint32_t qq = ((uint32_t)q0 & 0xffffu) | ((uint32_t)q0 << 16);
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_FLAT_QUADS; k++) {
+        uint32_t n = nv[k];
+        if (n == 0u || Y0[k] >= D.out_rows || X0[k] >= D.out_w) continue;
+        if (D.out_w - X0[k] < n) n = D.out_w - X0[k];
+        // bits 14:5 of DC x q0 are all ucRangeTable[(DC x q0 >> 5) & 0x3ff] looks at (jpeg.inl:5146-5154): the 16-bit product is enough
+        const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(jda_us2, (uint32_t)four[k]) * __builtin_bit_cast(jda_us2, qq));
+        const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(jda_us2, (uint32_t)(four[k] >> 32)) * __builtin_bit_cast(jda_us2, qq));
+        const uint32_t s01 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(p01), 0x00800080u));      // samples 0, 1 in bytes 0, 1
+        const uint32_t s23 = jda_sat_pk_u8(jda_pk_add16(jda_pk_sext10_at5(p23), 0x00800080u));
+        const uint32_t s = s01 | (s23 << 16);
+        uint8_t JDA_GLOBAL *rowp = JDA_G(uint8_t, D.out) + (size_t)Y0[k] * D.out_pitch;
+        if (pt == JDA_EIGHT_BIT_GRAYSCALE) {
+            if (n == 4u) *(jda_u32_alias JDA_GLOBAL *)(rowp + X0[k]) = s;
+            else for (uint32_t e = 0; e < n; e++) rowp[X0[k] + e] = (uint8_t)(s >> (8u * e));
+        } else {                                                         // JPEGPutMCUGray: usGrayTo565
+            const bool be = pt != JDA_RGB565_LITTLE_ENDIAN;
+            uint16_t JDA_GLOBAL *o = (uint16_t JDA_GLOBAL *)rowp + X0[k];
+            const uint32_t a = jda_gray_565(s & 0xffu, be) | (jda_gray_565((s >> 8) & 0xffu, be) << 16), b = jda_gray_565((s >> 16) & 0xffu, be) | (jda_gray_565(s >> 24, be) << 16);
+            if (n == 4u) *(jda_u64_alias JDA_GLOBAL *)o = (uint64_t)a | ((uint64_t)b << 32);
+            else for (uint32_t e = 0; e < n; e++) o[e] = (uint16_t)((e < 2u ? a : b) >> (16u * (e & 1u)));
+        }
+    }
+}
+static hipError_t launch_dc_thumbnail_flat(const jda_dev_desc *descs, const jda_strip *recs, uint32_t n_images, uint32_t max_items, hipStream_t stream)
+{
+    const uint32_t per_wg = 256u * JDA_FLAT_QUADS;
+    JDA_LAUNCH(jda_dc_thumbnail_flat, dim3((max_items + per_wg - 1u) / per_wg, n_images), dim3(256), 0, stream, descs, recs);
     return hipGetLastError();
 }
 
@@ -1513,9 +1587,13 @@ extern "C" hipError_t jda_internal_set_trace(unsigned long long *dev_buf)
 
 // Launch entry used by jda_runtime.cpp.  n_tiles is a multiple of jda_lds_layout<MODE>::WAVES (padded per image).
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, int cont, const jda_dev_desc *descs, const jda_strip *tiles,
-                                        uint32_t n_tiles, hipStream_t stream)
+                                        uint32_t n_tiles, uint32_t aux, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
+    if (cont && !fast_mul && variant == 3) {          // JDA_LIST_THUMB_FLAT: whole gray images at 1/8, a record per image
+        if (mode != JDA_MODE_GRAY || big) return hipErrorInvalidValue;
+        return aux ? launch_dc_thumbnail_flat(descs, tiles, n_tiles, aux, stream) : hipSuccess;
+    }
     if (cont) {                                       // P1 in chunks (jda_use_cont decides who gets here): the RGB8888 plain case of 4:2:0 and 4:4:4
         if (!fast_mul || variant != 1) return hipErrorInvalidValue;
         switch (mode) {

@@ -194,6 +194,7 @@ struct jda_pipeline {
         size_t ctl_bytes, off_stats_dev, stats_bytes, pin_stats;
         size_t list_off[JDA_N_LISTS]; uint32_t list_n[JDA_N_LISTS];
         size_t off_descs;
+        uint32_t flat_max_items;             // JDA_LIST_THUMB_FLAT: the launch's width
         jda_pipeline_stats st;
     } slots[JDA_PIPE_MAX_DEPTH];
     int next_ticket;
@@ -310,6 +311,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     for (int i = 0; i < n; i++) { S.pts[(size_t)i] = pixel_types ? pixel_types[i] : JDA_RGB8888; S.opts[(size_t)i] = options ? options[i] : 0; }
     memset(&S.st, 0, sizeof(S.st));
     S.st.images = n;
+    S.flat_max_items = 0;
 
     // ---- control blob layout, part 1: the tables (the workers write them straight into the page-locked buffer)
     const size_t tab_stride = a16(JDA_TABLE_BYTES);
@@ -346,19 +348,34 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     static_assert(JDA_TABLE_BYTES % 8 == 0, "hashed 8 bytes a step");
     size_t n_tab = 0;
     {
-        std::unordered_map<uint64_t, std::vector<int>> seen;
+        auto same_tables = [&](const Img &om, const Img &im) {
+            return !memcmp(S.pin + om.ctl_tables, S.pin + im.ctl_tables, JDA_TABLE_BYTES) && !memcmp(om.f.dc_id, im.f.dc_id, 3) && !memcmp(om.f.ac_id, im.f.ac_id, 3) &&
+                   !memcmp(om.f.q_id, im.f.q_id, 3) && om.f.info.ncomp == im.f.info.ncomp;
+        };
+        // the first image with a hash value is the candidate owner of everybody with that value; the byte compares (10.8 KB each) run on
+        // the workers; an image whose compare fails (two table sets under one 64-bit hash value: never seen) becomes an owner itself
+        std::unordered_map<uint64_t, int> first;
+        first.reserve((size_t)n);
         for (int i = 0; i < n; i++) {
             Img &im = S.imgs[(size_t)i];
             if (im.err != JDA_SUCCESS) continue;
-            std::vector<int> &cands = seen[im.tab_hash];
-            int owner = -1;
-            for (int o : cands) {
-                const Img &om = S.imgs[(size_t)o];
-                if (!memcmp(S.pin + om.ctl_tables, S.pin + im.ctl_tables, JDA_TABLE_BYTES) && !memcmp(om.f.dc_id, im.f.dc_id, 3) && !memcmp(om.f.ac_id, im.f.ac_id, 3) &&
-                    !memcmp(om.f.q_id, im.f.q_id, 3) && om.f.info.ncomp == im.f.info.ncomp) { owner = o; break; }
+            auto it = first.find(im.tab_hash);
+            if (it == first.end()) first.emplace(im.tab_hash, i); else im.tab_owner = it->second;
+        }
+        p->workers->run(n, [&](int i) {
+            Img &im = S.imgs[(size_t)i];
+            if (im.err == JDA_SUCCESS && im.tab_owner != i && !same_tables(S.imgs[(size_t)im.tab_owner], im)) im.tab_owner = -1 - im.tab_owner;
+        });
+        std::vector<int> odd;                                  // (owners made by a failed compare, in order)
+        for (int i = 0; i < n; i++) {
+            Img &im = S.imgs[(size_t)i];
+            if (im.err != JDA_SUCCESS) continue;
+            if (im.tab_owner < 0) {                             // a collision: among the images that collided before, or an owner of its own
+                im.tab_owner = i;
+                for (int o : odd) if (S.imgs[(size_t)o].tab_hash == im.tab_hash && same_tables(S.imgs[(size_t)o], im)) { im.tab_owner = o; break; }
+                if (im.tab_owner == i) odd.push_back(i);
             }
-            if (owner >= 0) { im.tab_owner = owner; im.ctl_tables = S.imgs[(size_t)owner].ctl_tables; continue; }
-            cands.push_back(i);
+            if (im.tab_owner != i) { im.ctl_tables = S.imgs[(size_t)im.tab_owner].ctl_tables; continue; }
             const size_t to = n_tab * tab_stride;              // (owners in increasing order: a copy only ever moves towards the front)
             if (to != im.ctl_tables) memmove(S.pin + to, S.pin + im.ctl_tables, JDA_TABLE_BYTES);
             im.ctl_tables = to; n_tab++;
@@ -403,8 +420,9 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         // (window size: the filtered length is not known yet; the unfiltered one is at most a few percent larger)
         D.scan_len = im.f.raw_len;
         const int big = D.scale_shift == 3 ? 0 : jda_big_window(D, variant);
-        im.list = (uint32_t)jda_list_index(D, variant, big);
-        im.n_tiles = count_tiles(D.mcus_x, D.mcus_y, D.mode, big);
+        im.list = (uint32_t)jda_list_index(D, variant, big, 0, true);
+        im.n_tiles = im.list == (uint32_t)JDA_LIST_THUMB_FLAT ? 1u : count_tiles(D.mcus_x, D.mcus_y, D.mode, big);      // (a whole gray image at 1/8: one record)
+        if (im.list == (uint32_t)JDA_LIST_THUMB_FLAT) S.flat_max_items = std::max(S.flat_max_items, jda_flat_items(D));
         im.strip_off = list_tiles[im.list]; list_tiles[im.list] += im.n_tiles;
         im.ord = list_ord[im.list]++;
         S.st.source_pixels += (int64_t)I.width * I.height;
@@ -599,6 +617,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         jda_strips_params &TP = tp[k];
         TP.dst = (jda_strip *)(B + S.list_off[im.list]) + im.strip_off; TP.n_padded = im.n_tiles; TP.image = (uint32_t)i; TP.ord = im.ord;
         TP.mcus_x = D.mcus_x; TP.mcus_y = D.mcus_y; TP.per = jda_mcus_per_tile(D.mode);
+        if (im.list == (uint32_t)JDA_LIST_THUMB_FLAT) { TP.mcus_x = 1; TP.mcus_y = 1; TP.per = 1; }      // (jda_fill_strips writes the one record: the image, first = 1)
         max_tiles = std::max(max_tiles, im.n_tiles);
     }
     g_submit_clock.lap(4);
@@ -656,7 +675,8 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, S.ev_up, 0);
     for (int m = 0; m < JDA_N_LISTS && e == hipSuccess && n_dev; m++) {
         if (!S.list_n[m]) continue;
-        e = jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), (const jda_dev_desc *)(B + S.off_descs), (const jda_strip *)(B + S.list_off[m]), S.list_n[m], ctx->stream);
+        e = jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), (const jda_dev_desc *)(B + S.off_descs), (const jda_strip *)(B + S.list_off[m]), S.list_n[m],
+                              m == JDA_LIST_THUMB_FLAT ? S.flat_max_items : 0u, ctx->stream);
         S.st.launches++;
     }
     if (e == hipSuccess) e = hipEventRecord(S.ev_dec, ctx->stream);

@@ -685,6 +685,7 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
     std::vector<int32_t> image_status;
     jda_batch_stats st;
     memset(&st, 0, sizeof(st));
+    uint32_t flat_max_items = 0;
     for (int i = 0; i < n; i++) {
         const jda_dev_image *im = images[i];
         jda_dev_desc &D = descs[(size_t)i];
@@ -707,11 +708,21 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
         const int cont = jda_use_cont(D, variant, im->n_cont);
         if (cont) { D.blk_cont_first = (const uint32_t *)(im->base + im->off_cont_first); D.blk_cont = (const uint32_t *)(im->base + im->off_cont); }
         {
-            std::vector<jda_strip> &lst = strips[jda_list_index(D, variant, big, cont)];
-            const size_t before = lst.size();
-            jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL, D.strip_mcus);
-            for (size_t k = before; k < lst.size(); k++) if (lst[k].count) st.tiles++;
+            const int li = jda_list_index(D, variant, big, cont, mcu_rects == NULL);
+            std::vector<jda_strip> &lst = strips[li];
             const uint32_t per = jda_mcus_per_tile(D.mode);
+            if (li == JDA_LIST_THUMB_FLAT) {                     // a whole gray image at 1/8: one record (jda_dc_thumbnail_flat)
+                jda_strip r;
+                memset(&r, 0, sizeof(r));
+                r.image = (uint32_t)i; r.count = 1; r.first = 1; r.ord = lst.empty() ? 0u : lst.back().ord + 1u;
+                lst.push_back(r);
+                flat_max_items = std::max(flat_max_items, jda_flat_items(D));
+                st.tiles += (int64_t)D.mcus_y * ((D.mcus_x + per - 1) / per);
+            } else {
+                const size_t before = lst.size();
+                jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL, D.strip_mcus);
+                for (size_t k = before; k < lst.size(); k++) if (lst[k].count) st.tiles++;
+            }
             st.tiles_whole_images += (int64_t)D.mcus_y * ((D.mcus_x + per - 1) / per);
         }
         st.source_pixels += (int64_t)I.width * I.height;
@@ -724,6 +735,7 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
     if (!b) { *err = JDA_ERROR_MEMORY; return NULL; }
     memset(b, 0, sizeof(*b));
     b->n_images = n;
+    b->flat_max_items = flat_max_items;
     b->status = new (std::nothrow) int32_t[(size_t)n];
     if (b->status) memcpy(b->status, image_status.data(), (size_t)n * sizeof(int32_t));
     (void)hipSetDevice(ctx->device);
@@ -735,7 +747,7 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
         e = jda_pool_alloc(ctx, (void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += (int32_t)(strips[m].size() / jda_tiles_per_wg(JDA_LIST_MODE(m), JDA_LIST_BIG(m)));
+        st.n_workgroups += m == JDA_LIST_THUMB_FLAT ? (int32_t)strips[m].size() : (int32_t)(strips[m].size() / jda_tiles_per_wg(JDA_LIST_MODE(m), JDA_LIST_BIG(m)));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -765,7 +777,8 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
     if (!b) return JDA_INVALID_PARAMETER;
     for (int m = 0; m < JDA_N_LISTS; m++) {
         if (!b->n_strips[m]) continue;
-        JDA_HIP(ctx, jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), b->d_descs, b->d_strips[m], b->n_strips[m], ctx->stream));
+        JDA_HIP(ctx, jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), b->d_descs, b->d_strips[m], b->n_strips[m],
+                                       m == JDA_LIST_THUMB_FLAT ? b->flat_max_items : 0u, ctx->stream));
     }
     return JDA_SUCCESS;
 }
