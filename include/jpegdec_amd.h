@@ -352,7 +352,7 @@ int jda_decode_to_host_strips(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, in
  * batch n+1 run on streams of their own under the decode of batch n (three batches in flight keep the GPU busy).  Images the device walk cannot take or that fail its checks
  * (progressive, corrupt, truncated, ...) are redone through the serial host pre-scan when the batch is waited for, so every
  * image ends with the status -- and the pixels -- the one-image path (jda_decode_to_host) gives it.
- *   jda_pipeline_create   max_images per batch; depth = batches in flight (1..4); host_threads <= 0: up to 8
+ *   jda_pipeline_create   max_images per batch; depth = batches in flight (1..8); host_threads <= 0: up to 8
  *   jda_pipeline_submit   enqueue one batch; the JPEG buffers and the output surfaces (DEVICE pointers, as jda_output) must
  *                         stay valid until the batch has been waited for.  *ticket identifies the batch.
  *   jda_pipeline_wait     block until the batch is decoded; status[i] = JDA_SUCCESS or the image's error (may be NULL).

@@ -953,8 +953,11 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
 // dependent steps whose length nothing shortens -- what matters there is what the round keeps OTHERS from doing: a workgroup that holds
 // 32 KB of LDS keeps a decode workgroup, which needs the CU's whole LDS, off its CU for the length of a walk; a wavefront of <= 64
 // registers and no LDS runs beside one).
+#ifndef JDA_WALK_THREADS
+#define JDA_WALK_THREADS 256u      // a walker workgroup: the wavefronts that share one copy of the tables in LDS
+#endif
 template <int OP, bool LDS_TABLES>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(JDA_WALK_THREADS)
 void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t round)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -963,16 +966,16 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
     uint32_t JDA_GLOBAL *stats = JDA_G(uint32_t, P.stats);
     const bool all = round <= 1u;                                    // rounds 0 and 1 walk every segment (round 1 to make everybody's sums)
     const uint32_t count = all ? P.n_segs : stats[8u + round];
-    if (blockIdx.x * 256u >= count) return;                          // (uniform per workgroup)
+    if (blockIdx.x * JDA_WALK_THREADS >= count) return;                          // (uniform per workgroup)
     const uint32_t JDA_GLOBAL *wl_in = JDA_G(const uint32_t, P.worklist) + ((round & 1u) ? P.worklist_cap : 0u);
     uint32_t JDA_GLOBAL *wl_out = JDA_G(uint32_t, P.worklist) + ((round & 1u) ? 0u : P.worklist_cap);
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
     const uint8_t *tab = LDS_TABLES ? (const uint8_t *)lds : (const uint8_t *)JDA_G(const uint8_t, P.walk_tables);
     if (LDS_TABLES) {
-        jda_walk_tables_stage(P.walk_tables, threadIdx.x, 256u, lds);
+        jda_walk_tables_stage(P.walk_tables, threadIdx.x, JDA_WALK_THREADS, lds);
         __syncthreads();                                             // the tables: all that is staged (a walk reads its segment from memory)
     }
-    for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < count; base += gridDim.x * 256u) {
+    for (uint32_t base = blockIdx.x * JDA_WALK_THREADS + wave * 64u; base < count; base += gridDim.x * JDA_WALK_THREADS) {
         const uint32_t item = base + lane;
         if (item >= count) continue;
         jda_fused_item<OP>(P, tab, all ? item : wl_in[item], round, lane, E, wl_out);
@@ -1038,9 +1041,9 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
         if (e == hipSuccess) e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_RECORD, true>, lds_max, attr_done1);
         if (e != hipSuccess) return e;
     }
-    const uint32_t full = (max_segs + 255u) / 256u;
+    const uint32_t full = (max_segs + JDA_WALK_THREADS - 1u) / JDA_WALK_THREADS;
     // later rounds walk a few percent of the segments: a few workgroups per image, each stepping through the list
-    const dim3 grid(round <= 1 ? full : (full < 8u ? full : 8u), n_images), block(256);
+    const dim3 grid(round <= 1 ? full : (full < 8u ? full : 8u), n_images), block(JDA_WALK_THREADS);
     if (round == 0) JDA_LAUNCH((jda_segscan_fused<JDA_SEG_SPEC, true>), grid, block, lds_bytes, stream, params, round);
     else if (round == 1) JDA_LAUNCH((jda_segscan_fused<JDA_SEG_RECORD, true>), grid, block, lds_bytes, stream, params, round);
     else if (max_segs > JDA_SMALL_SCAN_SEGS) JDA_LAUNCH((jda_segscan_fused<JDA_SEG_RECORD, true>), grid, block, lds_bytes, stream, params, round);

@@ -140,7 +140,7 @@ jda_node *jda_node_create(const int32_t *devices, int32_t n_devices, int32_t max
     const int visible = jda_device_count();
     if (visible <= 0) { *err = JDA_ERROR_NO_DEVICE; return NULL; }            // there is no CPU decode path
     if (n_devices <= 0) { n_devices = visible; devices = NULL; }
-    if (max_images_per_device <= 0 || depth < 1 || depth > 4) { *err = JDA_INVALID_PARAMETER; return NULL; }
+    if (max_images_per_device <= 0 || depth < 1 || depth > 8) { *err = JDA_INVALID_PARAMETER; return NULL; }
     // (a device may be named more than once: every entry gets a context, a pipeline and a host thread of its own -- several feeders of
     // one GPU, or a node's control flow rehearsed on the one GPU a box has)
     for (int32_t k = 0; k < n_devices; k++) { const int32_t o = devices ? devices[k] : k; if (o < 0 || o >= visible) { *err = JDA_INVALID_PARAMETER; return NULL; } }

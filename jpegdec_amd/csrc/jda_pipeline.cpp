@@ -168,7 +168,7 @@ struct Img {
 
 } // namespace
 
-#define JDA_PIPE_MAX_DEPTH 4
+#define JDA_PIPE_MAX_DEPTH 8
 #ifndef JDA_PIPE_SPEC_ROUNDS
 #define JDA_PIPE_SPEC_ROUNDS 4       // rounds launched one by one (a round with an empty work list returns at once); the rest in one launch (jda_segscan_tail)
 #endif

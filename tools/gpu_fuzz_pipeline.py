@@ -22,7 +22,7 @@ pipe = J.Pipeline(ctx, max_images=64, depth=3, host_threads=4)
 # (round 3: + the reference's photographs -- they have the magnitude reads the reference truncates, i.e. the RECORD-mode pre-scan's
 # candidates and flagged entries, with and without restart intervals)
 bases = ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217", "c420_1280x720", "gray_333x217", "c420_256x256_q98", "c440_200x120",
-         "ref:zebra", "ref:st_peters", "ref:tulips", "ref:sciopero")
+         "ref:zebra", "ref:st_peters", "ref:tulips", "ref:sciopero", "w16_c420_333x217_x400", "w16_gray_200x120_x400")
 from tests.ref_fixtures import ref_jpeg  # noqa: E402
 total = on_device = failed = 0
 inflight = []
