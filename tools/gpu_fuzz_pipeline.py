@@ -18,7 +18,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
 ctx = J.Context(0)
 oracle = OracleDecoder()
-pipe = J.Pipeline(ctx, max_images=64, depth=3, host_threads=4)
+pipe = J.Pipeline(ctx, max_images=128, depth=3, host_threads=4)
 # (round 3: + the reference's photographs -- they have the magnitude reads the reference truncates, i.e. the RECORD-mode pre-scan's
 # candidates and flagged entries, with and without restart intervals)
 bases = ("c420_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c422_333x217", "c420_1280x720", "gray_333x217", "c420_256x256_q98", "c440_200x120",
