@@ -220,6 +220,18 @@ def test_frontend_fuzz_under_asan_ubsan():
         assert p.returncode == 0, (rel, p.stdout[-3000:])
 
 
+def test_interval_parallel_prescan_under_thread_sanitizer():
+    """The helper threads of the interval-parallel host pre-scan (jda_frontend.cpp: RstPool, rst_worker) under ThreadSanitizer: restart
+    streams and corrupted copies of them (an interval that runs past its bytes must not touch what another thread writes)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "fronttsan"], cwd=root, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    exe = os.path.join(root, "tests", "fuzz", "frontend_tsan")
+    for seed, rel in enumerate(("golden/ref/tulips.jpg", "golden/c444_384x192_q100_rst7.jpg", "golden/c420_640x368_rstrow.jpg")):
+        p = subprocess.run([exe, os.path.join(root, "tests", rel), "300", str(seed + 3)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0 and "ThreadSanitizer" not in p.stdout, (rel, p.stdout[-3000:])
+
+
 def test_cropped_draw_plan_depends_on_the_x_offset(ref_scalar):
     """jpeg.inl:5328 compares jd.x (iXOffset included) with iCropX + iCropCX: the strip widths of a cropped decode change with the
     x passed to decode().  jda_draw_plan_at == the real reference's JPEGDRAW sequence for a grid of crops x offsets x pixel types."""
