@@ -348,6 +348,8 @@ def run_config_legs(J, ctx, threads, only=None):
         ("c5_quarter_256", "256 x 8192x8192 gray -> GRAY8 at 1/4 (a launch long enough to be a throughput figure)", (8192, 8192, "gray", 85, 2), 256, J.GRAY8, J.SCALE_QUARTER),
         ("c5_eighth_256", "256 x 8192x8192 gray -> GRAY8 at 1/8 (DC only; a launch long enough to be a throughput figure)", (8192, 8192, "gray", 85, 2), 256, J.GRAY8, J.SCALE_EIGHTH),
         ("q98", "64 x 4096x4096 4:2:0 at quality 98 (3.7 bit/px) -> RGB8888", (4096, 4096, "4:2:0", 98, 2), 64, J.RGB8888, 0),
+        # colour thumbnails: the metric's images at 1/8 (what every progressive file's default decode is, too: DC values only)
+        ("metric_eighth", "64 x 4096x4096 4:2:0 -> RGB8888 at 1/8 (DC only)", (4096, 4096, "4:2:0", 85, 16), 64, J.RGB8888, J.SCALE_EIGHTH),
     ]
     e2e_legs = [
         ("c2_e2e", "1024 x 1280x720 4:2:0 -> RGB8888 END TO END through jda_pipeline (BASELINE config 2)", (1280, 720, "4:2:0", 85, 8), 1024, J.RGB8888),
@@ -412,7 +414,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e-sweep", action="store_true", help="end-to-end leg: skip the host-thread sweep, the pageable-input and the cold-input runs")
     ap.add_argument("--e2e-cold-gb", type=float, default=2.0, help="end-to-end leg, cold input: GB of distinct page-locked buffers the batches cycle through")
     ap.add_argument("--e2e-distinct", type=int, default=16, help="distinct files a batch of the end-to-end leg cycles through (metric workload; the resident batch keeps --distinct)")
-    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,c5_quarter_256,c5_eighth_256,q98,photos,c2_e2e,c4_e2e,vga_e2e,c1)")
+    ap.add_argument("--configs", default="", help="comma-separated subset of the config legs (default: all of c2,c3,c4_shard,c5,c5_half,c5_quarter,c5_eighth,c5_quarter_256,c5_eighth_256,q98,metric_eighth,photos,c2_e2e,c4_e2e,vga_e2e,c1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs over the other BASELINE.json configurations (`configs` in the line; N = 1, metric workload only)")

@@ -766,6 +766,72 @@ static hipError_t launch_dc_thumbnail_flat(const jda_dev_desc *descs, const jda_
     return hipGetLastError();
 }
 
+// .. and a whole 4:2:0 image (every progressive photograph's default decode among them): a thread takes an MCU -- its six DC values are
+// twelve consecutive bytes -- and makes the MCU's 2 x 2 pixels as JPEGPutMCU22 does at bThumbnail (jpeg.inl:3627-3663: luma block q = 2 y + x
+// of the MCU, chroma shared), two 8-byte stores for RGB8888; consecutive threads take consecutive MCUs of a row.
+__global__ __launch_bounds__(256)
+void jda_dc_thumbnail_flat420(const jda_dev_desc *__restrict__ descs, const jda_strip *__restrict__ recs)
+{
+    const uint32_t __attribute__((address_space(4))) *rw = (const uint32_t __attribute__((address_space(4))) *)(uintptr_t)(recs + blockIdx.y);
+    const jda_dev_desc D = jda_desc_const<0, JDA_MODE_420>(jda_desc_at(descs, rw[0]));
+    const uint32_t __attribute__((address_space(4))) *qt = (const uint32_t __attribute__((address_space(4))) *)(uintptr_t)(D.tables + JDA_TB_QUANT);
+    const int32_t qy = (int16_t)qt[D.q_id[0] * 32u], qb = (int16_t)qt[D.q_id[1] * 32u], qr = (int16_t)qt[D.q_id[2] * 32u];
+    const uint32_t n_items = D.mcus_x * D.mcus_y;
+    const uint32_t n_ok = D.n_mcus_ok < n_items ? D.n_mcus_ok : n_items;       // MCUs behind a bad one are not decoded (jpeg.inl:5354-5356)
+    const uint32_t base = blockIdx.x * (256u * JDA_FLAT_QUADS) + threadIdx.x;
+    if (base >= n_ok) return;
+    const float rq = 1.0f / (float)D.mcus_x;
+    const int pt = D.pixel_type;
+    uint32_t w0[JDA_FLAT_QUADS], w1[JDA_FLAT_QUADS], w2[JDA_FLAT_QUADS];
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_FLAT_QUADS; k++) {                      // (all loads asked for before the first is used)
+        const uint32_t item = base + k * 256u;
+        w0[k] = w1[k] = w2[k] = 0;
+        if (item < n_ok) { const uint32_t JDA_GLOBAL *d = JDA_G(const uint32_t, D.blk_dc) + item * 3u; w0[k] = d[0]; w1[k] = d[1]; w2[k] = d[2]; }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < JDA_FLAT_QUADS; k++) {
+        const uint32_t item = base + k * 256u;
+        if (item >= n_ok) continue;
+        uint32_t my = (uint32_t)((float)item * rq);
+        if (my * D.mcus_x > item) my--;
+        if ((my + 1u) * D.mcus_x <= item) my++;
+        const uint32_t mx = item - my * D.mcus_x;
+        const uint32_t y00 = jda_range_limit5((int32_t)(int16_t)w0[k] * qy), y01 = jda_range_limit5((int32_t)(int16_t)(w0[k] >> 16) * qy);
+        const uint32_t y10 = jda_range_limit5((int32_t)(int16_t)w1[k] * qy), y11 = jda_range_limit5((int32_t)(int16_t)(w1[k] >> 16) * qy);
+        const uint32_t cb = jda_range_limit5((int32_t)(int16_t)w2[k] * qb), cr = jda_range_limit5((int32_t)(int16_t)(w2[k] >> 16) * qr);
+        const uint32_t X = 2u * mx, Y = 2u * my;
+#pragma unroll
+        for (uint32_t r = 0; r < 2u; r++) {
+            if (Y + r >= D.out_rows || X >= D.out_w) continue;
+            const uint32_t ya = r ? y10 : y00, yb = r ? y11 : y01;
+            const bool two = X + 1u < D.out_w;
+            uint8_t JDA_GLOBAL *rowp = JDA_G(uint8_t, D.out) + (size_t)(Y + r) * D.out_pitch;
+            if (pt == JDA_EIGHT_BIT_GRAYSCALE) {                         // (luma only: JPEGPutMCU8BitGray)
+                if (two) *(uint16_t JDA_GLOBAL *)(rowp + X) = (uint16_t)(ya | (yb << 8)); else rowp[X] = (uint8_t)ya;
+            } else {
+                jda_ycc a, b;
+                a.y = (int32_t)(ya << 12); a.cb = (int32_t)cb; a.cr = (int32_t)cr;
+                b.y = (int32_t)(yb << 12); b.cb = (int32_t)cb; b.cr = (int32_t)cr;
+                if (pt == JDA_RGB8888) {
+                    const uint32_t pa = jda_pixel_rgba(a), pb = jda_pixel_rgba(b);
+                    if (two) *(jda_u64_alias JDA_GLOBAL *)(rowp + 4u * X) = (uint64_t)pa | ((uint64_t)pb << 32); else *(jda_u32_alias JDA_GLOBAL *)(rowp + 4u * X) = pa;
+                } else {
+                    const bool be = pt == JDA_RGB565_BIG_ENDIAN;
+                    const uint32_t pa = jda_pixel_565(a, be) & 0xffffu, pb = jda_pixel_565(b, be) & 0xffffu;
+                    if (two) *(jda_u32_alias JDA_GLOBAL *)(rowp + 2u * X) = pa | (pb << 16); else *(uint16_t JDA_GLOBAL *)(rowp + 2u * X) = (uint16_t)pa;
+                }
+            }
+        }
+    }
+}
+static hipError_t launch_dc_thumbnail_flat420(const jda_dev_desc *descs, const jda_strip *recs, uint32_t n_images, uint32_t max_items, hipStream_t stream)
+{
+    const uint32_t per_wg = 256u * JDA_FLAT_QUADS;
+    JDA_LAUNCH(jda_dc_thumbnail_flat420, dim3((max_items + per_wg - 1u) / per_wg, n_images), dim3(256), 0, stream, descs, recs);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // 1/4 scale (jda_q4_* in jda_device_core.h): a block is its DC value, at most four AC symbols and a 2x2 IDCT -- the persistent decode
 // kernel spent its time on what surrounds that (window staging, slots, lists, one workgroup per CU for its LDS).  Here a workgroup is
@@ -1593,9 +1659,10 @@ extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int
                                         uint32_t n_tiles, uint32_t aux, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
-    if (cont && !fast_mul && variant == 3) {          // JDA_LIST_THUMB_FLAT: whole gray images at 1/8, a record per image
-        if (mode != JDA_MODE_GRAY || big) return hipErrorInvalidValue;
-        return aux ? launch_dc_thumbnail_flat(descs, tiles, n_tiles, aux, stream) : hipSuccess;
+    if (cont && !fast_mul && variant == 3) {          // JDA_LIST_THUMB_FLAT: whole gray / 4:2:0 images at 1/8, a record per image
+        if ((mode != JDA_MODE_GRAY && mode != JDA_MODE_420) || big) return hipErrorInvalidValue;
+        if (!aux) return hipSuccess;
+        return mode == JDA_MODE_GRAY ? launch_dc_thumbnail_flat(descs, tiles, n_tiles, aux, stream) : launch_dc_thumbnail_flat420(descs, tiles, n_tiles, aux, stream);
     }
     if (cont) {                                       // P1 in chunks (jda_use_cont decides who gets here): the RGB8888 plain case of 4:2:0 and 4:4:4
         if (!fast_mul || variant != 1) return hipErrorInvalidValue;

@@ -421,8 +421,8 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         D.scan_len = im.f.raw_len;
         const int big = D.scale_shift == 3 ? 0 : jda_big_window(D, variant);
         im.list = (uint32_t)jda_list_index(D, variant, big, 0, true);
-        im.n_tiles = im.list == (uint32_t)JDA_LIST_THUMB_FLAT ? 1u : count_tiles(D.mcus_x, D.mcus_y, D.mode, big);      // (a whole gray image at 1/8: one record)
-        if (im.list == (uint32_t)JDA_LIST_THUMB_FLAT) S.flat_max_items = std::max(S.flat_max_items, jda_flat_items(D));
+        im.n_tiles = JDA_LIST_IS_THUMB_FLAT((int)im.list) ? 1u : count_tiles(D.mcus_x, D.mcus_y, D.mode, big);      // (a whole gray image at 1/8: one record)
+        if (JDA_LIST_IS_THUMB_FLAT((int)im.list)) S.flat_max_items = std::max(S.flat_max_items, jda_flat_items(D));
         im.strip_off = list_tiles[im.list]; list_tiles[im.list] += im.n_tiles;
         im.ord = list_ord[im.list]++;
         S.st.source_pixels += (int64_t)I.width * I.height;
@@ -617,7 +617,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         jda_strips_params &TP = tp[k];
         TP.dst = (jda_strip *)(B + S.list_off[im.list]) + im.strip_off; TP.n_padded = im.n_tiles; TP.image = (uint32_t)i; TP.ord = im.ord;
         TP.mcus_x = D.mcus_x; TP.mcus_y = D.mcus_y; TP.per = jda_mcus_per_tile(D.mode);
-        if (im.list == (uint32_t)JDA_LIST_THUMB_FLAT) { TP.mcus_x = 1; TP.mcus_y = 1; TP.per = 1; }      // (jda_fill_strips writes the one record: the image, first = 1)
+        if (JDA_LIST_IS_THUMB_FLAT((int)im.list)) { TP.mcus_x = 1; TP.mcus_y = 1; TP.per = 1; }      // (jda_fill_strips writes the one record: the image, first = 1)
         max_tiles = std::max(max_tiles, im.n_tiles);
     }
     g_submit_clock.lap(4);
@@ -676,7 +676,7 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     for (int m = 0; m < JDA_N_LISTS && e == hipSuccess && n_dev; m++) {
         if (!S.list_n[m]) continue;
         e = jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), (const jda_dev_desc *)(B + S.off_descs), (const jda_strip *)(B + S.list_off[m]), S.list_n[m],
-                              m == JDA_LIST_THUMB_FLAT ? S.flat_max_items : 0u, ctx->stream);
+                              JDA_LIST_IS_THUMB_FLAT(m) ? S.flat_max_items : 0u, ctx->stream);
         S.st.launches++;
     }
     if (e == hipSuccess) e = hipEventRecord(S.ev_dec, ctx->stream);

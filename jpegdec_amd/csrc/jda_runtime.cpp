@@ -711,7 +711,7 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
             const int li = jda_list_index(D, variant, big, cont, mcu_rects == NULL);
             std::vector<jda_strip> &lst = strips[li];
             const uint32_t per = jda_mcus_per_tile(D.mode);
-            if (li == JDA_LIST_THUMB_FLAT) {                     // a whole gray image at 1/8: one record (jda_dc_thumbnail_flat)
+            if (JDA_LIST_IS_THUMB_FLAT(li)) {                     // a whole gray image at 1/8: one record (jda_dc_thumbnail_flat)
                 jda_strip r;
                 memset(&r, 0, sizeof(r));
                 r.image = (uint32_t)i; r.count = 1; r.first = 1; r.ord = lst.empty() ? 0u : lst.back().ord + 1u;
@@ -747,7 +747,7 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
         e = jda_pool_alloc(ctx, (void **)&b->d_strips[m], strips[m].size() * sizeof(jda_strip));
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_strips[m], strips[m].data(), strips[m].size() * sizeof(jda_strip), hipMemcpyHostToDevice, ctx->stream);
         st.n_launches++;
-        st.n_workgroups += m == JDA_LIST_THUMB_FLAT ? (int32_t)strips[m].size() : (int32_t)(strips[m].size() / jda_tiles_per_wg(JDA_LIST_MODE(m), JDA_LIST_BIG(m)));
+        st.n_workgroups += JDA_LIST_IS_THUMB_FLAT(m) ? (int32_t)strips[m].size() : (int32_t)(strips[m].size() / jda_tiles_per_wg(JDA_LIST_MODE(m), JDA_LIST_BIG(m)));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -778,7 +778,7 @@ int jda_batch_decode(jda_ctx *ctx, jda_batch *b)
     for (int m = 0; m < JDA_N_LISTS; m++) {
         if (!b->n_strips[m]) continue;
         JDA_HIP(ctx, jda_launch_decode(JDA_LIST_MODE(m), JDA_LIST_FAST(m), JDA_LIST_VARIANT(m), JDA_LIST_BIG(m), JDA_LIST_CONT(m), b->d_descs, b->d_strips[m], b->n_strips[m],
-                                       m == JDA_LIST_THUMB_FLAT ? b->flat_max_items : 0u, ctx->stream));
+                                       JDA_LIST_IS_THUMB_FLAT(m) ? b->flat_max_items : 0u, ctx->stream));
     }
     return JDA_SUCCESS;
 }

@@ -76,14 +76,15 @@ extern "C" int jda_host_range_of(const void *p, size_t len, uintptr_t *base, siz
 // .. and the same with big = 1 the 1/4-scale kernel (jda_quarter_tiles): a block is its DC value, <= 4 AC symbols and a 2x2 IDCT
 // (jpeg.inl:2305-2326).  (A strip-major surface at 1/4 stays with the decode kernel, whose colour stage knows the layout.)
 #define JDA_LIST_QUARTER(mode) (((((mode) * 2 + 0) * 4 + 3) * 2 + 1) * 2 + 0)
-// .. and (fast = 0, variant = 3, cont = 1) the flat thumbnail kernel: a WHOLE gray image at 1/8 on a row-major surface is a pointwise
-// map of its DC array -- the list holds one record per image (jda_dc_thumbnail_flat)
-#define JDA_LIST_THUMB_FLAT (((((JDA_MODE_GRAY) * 2 + 0) * 4 + 3) * 2 + 0) * 2 + 1)
+// .. and (fast = 0, variant = 3, cont = 1) the flat thumbnail kernels: a WHOLE gray or 4:2:0 image at 1/8 on a row-major surface is a
+// pointwise map of its DC array -- the list holds one record per image (jda_dc_thumbnail_flat)
+#define JDA_LIST_THUMB_FLAT(mode) (((((mode) * 2 + 0) * 4 + 3) * 2 + 0) * 2 + 1)
+#define JDA_LIST_IS_THUMB_FLAT(m) ((m) == JDA_LIST_THUMB_FLAT(JDA_MODE_GRAY) || (m) == JDA_LIST_THUMB_FLAT(JDA_MODE_420))
 // whole: every MCU of the image is launched (no crop rectangle)
 inline int jda_list_index(const jda_dev_desc &D, int variant, int big, int cont = 0, bool whole = false)
 {
     if (D.strip_mcus == 0) {                                      // (a strip-major surface stays with the decode kernel, whose colour stage knows the layout)
-        if (D.scale_shift == 3 && whole && D.mode == JDA_MODE_GRAY) return JDA_LIST_THUMB_FLAT;
+        if (D.scale_shift == 3 && whole && (D.mode == JDA_MODE_GRAY || D.mode == JDA_MODE_420)) return JDA_LIST_THUMB_FLAT(D.mode);
         if (D.scale_shift == 3) return JDA_LIST_THUMB(D.mode);
         if (D.scale_shift == 2) return JDA_LIST_QUARTER(D.mode);
     }
@@ -106,9 +107,9 @@ extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, u
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
                                                 int any_record, hipStream_t stream);
-// aux: JDA_LIST_THUMB_FLAT: the most quads of blocks an image of the list has (jda_flat_items); 0 otherwise
+// aux: JDA_LIST_THUMB_FLAT: the most items an image of the batch's flat lists has (jda_flat_items); 0 otherwise
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, int cont, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, uint32_t aux, hipStream_t stream);
-inline uint32_t jda_flat_items(const jda_dev_desc &D) { return ((D.mcus_x + 3u) >> 2) * D.mcus_y; }
+inline uint32_t jda_flat_items(const jda_dev_desc &D) { return (D.mode == JDA_MODE_GRAY ? (D.mcus_x + 3u) >> 2 : D.mcus_x) * D.mcus_y; }      // quads of blocks (gray) / MCUs
 
 #endif

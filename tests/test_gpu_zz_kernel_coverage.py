@@ -61,13 +61,17 @@ def test_every_kernel_of_the_code_object_is_launched(gpu_ctx, oracle, tmp_path):
         jw = jpeg_for(w16[lay])
         for pt, opt in ((J.RGB565_LE if gray else J.RGB8888, 0), (J.GRAY8, 0), (J.RGB565_BE, J.SCALE_HALF), (J.RGB565_LE, J.SCALE_QUARTER), (J.GRAY8, J.SCALE_EIGHTH)):
             _same(gpu_ctx, oracle, jw, pt, opt, what=w16[lay])
-    # a whole gray image at 1/8 is the flat kernel's (above); a cropped one keeps the tile kernel: the rectangle's pixels are the oracle's
+    # a whole gray or 4:2:0 image at 1/8 is the flat kernels' (above); a cropped one keeps the tile kernel: the rectangle's pixels are the oracle's
     jg = jpeg_for("gray_333x217")
     for pt, bpp in ((J.GRAY8, 1), (J.RGB565_BE, 2)):
         orc, want, err = oracle.decode_canvas(jg, pt, J.SCALE_EIGHTH)
         rc, part, g, tiles = J.binding.decode_to_host_rect(gpu_ctx, jg, pt, J.SCALE_EIGHTH, (3, 2, 30, 20))
         assert orc == 1 and rc == 0
         assert np.array_equal(part[2:20, 3 * bpp:30 * bpp], want[2:20, 3 * bpp:30 * bpp]), pt
+    jc = jpeg_for("c420_333x217")                                # (.. and of a 4:2:0 image: 2 x 2 pixels an MCU)
+    orc, want, err = oracle.decode_canvas(jc, J.RGB8888, J.SCALE_EIGHTH)
+    rc, part, g, tiles = J.binding.decode_to_host_rect(gpu_ctx, jc, J.RGB8888, J.SCALE_EIGHTH, (2, 1, 15, 9))
+    assert orc == 1 and rc == 0 and np.array_equal(part[2:18, 4 * 4:30 * 4], want[2:18, 4 * 4:30 * 4])
     # the large window (one wavefront less per workgroup): uniform noise at a quality whose tiles' scan slices pass the small window and
     # fit the large one (5.0 / 10.3 / 3.5 bits per pixel), and at quality 95, where they pass both (the bit reader's fall-back to HBM)
     for lay, sub, q in (("420", "4:2:0", 75), ("444", "4:4:4", 75), ("gray", "gray", 50)):
