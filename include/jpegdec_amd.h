@@ -113,9 +113,13 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
 #define JDA_PREPARE_CONT_NEVER 4
 /* The host pre-scan of a stream with restart intervals (>= 4 of them, >= 12 KB of scan) decodes its intervals side by side on a few
  * helper threads the library keeps (an interval starts at a marker with predictors zero; the reader's phase across intervals -- the
- * one thing that carries over, SURVEY fact 6 -- is settled afterwards): the same index as the serial pre-scan's in the sense of
- * jda_index_equivalent.  This flag keeps the pre-scan on the calling thread. */
+ * one thing that carries over, SURVEY fact 6 -- is settled afterwards); a stream without them (>= 64 KB of scan) is walked in chunks
+ * from a guess, the true path spliced in front of where each walker fell into step.  Either way the same index as the serial
+ * pre-scan's in the sense of jda_index_equivalent.  This flag keeps the pre-scan on the calling thread. */
 #define JDA_PREPARE_SERIAL_PRESCAN 8
+/* .. and this one takes the helper threads for every stream that admits it, whatever its size (the library's own size limits are where
+ * the threads were measured to pay; tests use it on small files). */
+#define JDA_PREPARE_PARALLEL_PRESCAN 16
 jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
 /* jda_prepare_ex for n images on `threads` host threads (<= 0: all hardware threads); out[i] / errs[i] per image
  * (errs may be NULL).  Returns JDA_SUCCESS or the first error met. */

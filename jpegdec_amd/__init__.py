@@ -11,6 +11,7 @@ from .binding import (  # noqa: F401
     PREPARE_CONT_ALWAYS,
     PREPARE_CONT_NEVER,
     PREPARE_DEVICE_PRESCAN,
+    PREPARE_PARALLEL_PRESCAN,
     PREPARE_SERIAL_PRESCAN,
     RGB565_BE,
     RGB565_LE,

@@ -191,6 +191,7 @@ PREPARE_DEVICE_PRESCAN = 1
 PREPARE_CONT_ALWAYS = 2
 PREPARE_CONT_NEVER = 4
 PREPARE_SERIAL_PRESCAN = 8
+PREPARE_PARALLEL_PRESCAN = 16
 
 
 class PreparedImage:

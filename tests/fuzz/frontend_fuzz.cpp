@@ -20,7 +20,7 @@ static void run(const std::vector<uint8_t> &b, long *ok, long *rejected)
     jda_image_info info;
     (void)jda_parse(b.data(), (int32_t)b.size(), &info);
     int32_t err = 0;
-    jda_image *img = jda_prepare_ex(b.data(), (int32_t)b.size(), (rnd() & 1) ? JDA_PREPARE_DEVICE_PRESCAN : 0, &err);
+    jda_image *img = jda_prepare_ex(b.data(), (int32_t)b.size(), ((rnd() & 1) ? JDA_PREPARE_DEVICE_PRESCAN : 0) | ((rnd() & 1) ? JDA_PREPARE_PARALLEL_PRESCAN : 0), &err);
     if (!img) { (*rejected)++; return; }
     (*ok)++;
     int32_t rects[8 * 64];

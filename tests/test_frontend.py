@@ -227,7 +227,7 @@ def test_interval_parallel_prescan_under_thread_sanitizer():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["make", "fronttsan"], cwd=root, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     exe = os.path.join(root, "tests", "fuzz", "frontend_tsan")
-    for seed, rel in enumerate(("golden/ref/tulips.jpg", "golden/c444_384x192_q100_rst7.jpg", "golden/c420_640x368_rstrow.jpg")):
+    for seed, rel in enumerate(("golden/ref/tulips.jpg", "golden/c444_384x192_q100_rst7.jpg", "golden/c420_640x368_rstrow.jpg", "golden/c420_1280x720.jpg", "golden/ref/zebra.jpg")):
         p = subprocess.run([exe, os.path.join(root, "tests", rel), "300", str(seed + 3)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert p.returncode == 0 and "ThreadSanitizer" not in p.stdout, (rel, p.stdout[-3000:])
 
@@ -278,29 +278,34 @@ def test_word_precision_dqt_cases(hostsim, oracle):
 
 
 def test_interval_parallel_prescan_equals_the_serial_one():
-    """SURVEY 8f N1 on the host: a stream with restart intervals is pre-scanned interval by interval on helper threads
-    (host_prescan_intervals; the reference reader's phase across intervals settled afterwards through the chain of its refill points).
+    """SURVEY 8f N1 / N2 on the host: a stream with restart intervals is pre-scanned interval by interval on helper threads
+    (host_prescan_intervals), one without in chunks walked from a guess (host_prescan_chunks); the reference reader's phase settled
+    afterwards through the chain of its refill points.
     Against the serial pre-scan (JDA_PREPARE_SERIAL_PRESCAN) on every restart stream of the suite, the reference's fixtures with DRI
     (tulips 7 truncated reads, croptest 39, demo 75, perf.jpg 1,793) and dense high-quality streams: the same index in the sense of
     jda_index_equivalent (positions and flags of every block, flagged entries identical), DC values, truncation count, continuation
-    entries; and on 300 corrupted copies the same verdict (where the interval walk gives up, the serial pre-scan decides)."""
+    entries; and on 700 corrupted copies the same verdict (where the parallel walk gives up, the serial pre-scan decides)."""
     import jpegdec_amd as J
     from jpegdec_amd.synth import synth_jpeg
     from tests.cases import SYNTH_CASES, jpeg_for
     from tests.ref_fixtures import GOOD, ref_jpeg
-    cases = [(n, jpeg_for(n)) for n in sorted(SYNTH_CASES) if "rst" in n] + [("ref:" + n, ref_jpeg(n)) for n in GOOD]
+    cases = [(n, jpeg_for(n)) for n in sorted(SYNTH_CASES)] + [("ref:" + n, ref_jpeg(n)) for n in GOOD]
     cases += [("1080p_rstrow", synth_jpeg(1920, 1080, "4:2:0", seed=3, restart_rows=1)), ("c444_q100_rst9", synth_jpeg(640, 480, "4:4:4", seed=4, quality=100, restart_blocks=9)),
               ("c420_q98_rst5", synth_jpeg(800, 608, "4:2:0", seed=5, quality=98, restart_blocks=5)), ("gray_q95_rst2", synth_jpeg(512, 512, "gray", seed=6, quality=95, restart_blocks=2))]
+    # .. and WITHOUT restart markers: chunks of the scan walked from a guess, the true path spliced in front of where each walker fell
+    # into step (host_prescan_chunks)
+    cases += [("1080p", synth_jpeg(1920, 1080, "4:2:0", seed=3)), ("c444_q100", synth_jpeg(640, 480, "4:4:4", seed=4, quality=100)), ("c420_q98", synth_jpeg(800, 608, "4:2:0", seed=5, quality=98)),
+              ("gray_q95", synth_jpeg(512, 512, "gray", seed=6, quality=95)), ("c422", synth_jpeg(1024, 768, "4:2:2", seed=7)), ("noise_q90", synth_jpeg(640, 480, "4:2:0", seed=8, quality=90, noise=True))]
 
     def same(jpeg, flags, what):
         try:
             a = J.PreparedImage(jpeg, flags=flags | J.PREPARE_SERIAL_PRESCAN)
         except J.JdaError as ea:
             with pytest.raises(J.JdaError) as eb:
-                J.PreparedImage(jpeg, flags=flags)
+                J.PreparedImage(jpeg, flags=flags | J.PREPARE_PARALLEL_PRESCAN)
             assert eb.value.code == ea.code, what
             return 0
-        b = J.PreparedImage(jpeg, flags=flags)
+        b = J.PreparedImage(jpeg, flags=flags | J.PREPARE_PARALLEL_PRESCAN)     # (the helper threads whatever the file's size)
         (ia, na), (ib, nb) = a.block_index(), b.block_index()
         assert na == nb, what
         if na == a.n_mcus:
@@ -320,8 +325,8 @@ def test_interval_parallel_prescan_equals_the_serial_one():
             trunc += same(jpeg, flags, name)
     assert trunc > 3000                       # (the phase chain really decided: perf.jpg alone has 1,793 truncated reads)
     rng = np.random.default_rng(77)
-    for name in ("c420_640x368_rstrow", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow"):
-        jpeg = jpeg_for(name)
+    for name in ("c420_640x368_rstrow", "c444_384x192_q100_rst7", "c420_512x256_q98_rstrow", "c420_1280x720", "c444_256x256_q100_opt", "w16_c420_333x217_x400", "ref:zebra"):
+        jpeg = ref_jpeg(name[4:]) if name.startswith("ref:") else jpeg_for(name)
         sos = jpeg.index(b"\xff\xda") + 14
         for it in range(100):
             bad = bytearray(jpeg)

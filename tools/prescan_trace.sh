@@ -1,0 +1,17 @@
+#!/bin/bash
+# phase times of the chunk-parallel host pre-scan (jda_frontend.cpp built with -DJDA_PRESCAN_TRACE), CPU only: tools/prescan_trace.sh
+g++ -O2 -std=c++17 -fPIC -shared -fwrapv -DJDA_PRESCAN_TRACE -Iinclude -pthread -o /tmp/libfront_trace.so jpegdec_amd/csrc/jda_frontend.cpp || exit 1
+python - <<'PY'
+import ctypes as C, sys, time
+sys.path.insert(0, '.')
+from bench import cached_jpeg
+lib = C.CDLL("/tmp/libfront_trace.so")
+lib.jda_prepare_ex.restype = C.c_void_p; lib.jda_prepare_ex.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+lib.jda_image_free.argtypes = [C.c_void_p]
+for (w, h) in ((640, 480), (1280, 720)):
+    j = cached_jpeg(w, h, "4:2:0", 1234)
+    for k in range(4):
+        e = C.c_int32(0)
+        t0 = time.perf_counter(); p = lib.jda_prepare_ex(j, len(j), 0, C.byref(e)); t1 = time.perf_counter(); lib.jda_image_free(p)
+        sys.stderr.write("  %dx%d prepare %.1f us\n" % (w, h, (t1 - t0) * 1e6))
+PY
