@@ -10,7 +10,7 @@ from oracle.loader import RefDecoder  # noqa: E402  (the shim's loader: the same
 from jpegdec_amd.synth import synth_jpeg  # noqa: E402
 
 cls = RefDecoder(False, path=os.path.join(ROOT, "tests", "libjpegdec_class_shim.so"))
-for w, h in ((640, 480), (1920, 1080), (4096, 4096)):
+for w, h in ((640, 480), (1280, 720), (1920, 1080), (4096, 4096)):
     jpeg = synth_jpeg(w, h, "4:2:0", seed=5)
     # a C loop on a thread of its own: openRAM + decode (no-op draw callback) + close on one object.  The thread's device context is
     # created on its first decode (milliseconds, once per thread): runs long enough to make that a per cent

@@ -10,7 +10,7 @@ import jpegdec_amd as J  # noqa: E402
 from jpegdec_amd.synth import synth_jpeg  # noqa: E402
 
 ctx = J.Context(0)
-for w, h in ((640, 480), (1920, 1080), (4096, 4096)):
+for w, h in ((640, 480), (1280, 720), (1920, 1080), (4096, 4096)):
     jpeg = synth_jpeg(w, h, "4:2:0", seed=5)
     for _ in range(3):
         J.decode_to_host(ctx, jpeg, J.RGB565_LE, 0)
