@@ -340,3 +340,28 @@ def test_interval_parallel_prescan_equals_the_serial_one():
                 else:
                     del bad[at:at + int(rng.integers(1, 40))]
             same(bytes(bad), 0, (name, it))
+
+
+def test_prepare_in_a_forked_child_after_the_helper_threads_exist():
+    """The helper threads of the parallel host pre-scans do not exist in a fork()ed child: the child pre-scans on its own thread (same index)
+    and exits normally (the pool is never destroyed: a destructor joining threads the child does not have would hang it)."""
+    import subprocess
+    import sys
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+import jpegdec_amd as J
+from tests.ref_fixtures import ref_jpeg
+j = ref_jpeg('tulips')
+a = J.PreparedImage(j, flags=J.PREPARE_PARALLEL_PRESCAN)
+ia = a.block_index()[0]
+pid = os.fork()
+if pid == 0:
+    b = J.PreparedImage(j, flags=J.PREPARE_PARALLEL_PRESCAN)
+    ok = J.index_equivalent(ia, b.block_index()[0])
+    sys.exit(0 if ok else 3)             # (a normal exit: static destructors run)
+_, st = os.waitpid(pid, 0)
+print('child', st)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and "child 0" in r.stdout, r.stdout[-2000:]
