@@ -128,7 +128,8 @@ struct jda_strip {                // one wavefront's tile: <= 64 consecutive blo
     uint8_t count;                // MCUs in the tile (0 = padding entry)
     uint8_t first;                // 1: the first tile of its image (the wavefront that draws it restages the tables)
     uint16_t pad_;
-    uint32_t ord;                 // position of the image among the images of this launch's tile list (0, 1, 2, ..)
+    uint32_t ord;                 // which set of tables, counted along this launch's tile list (0, 1, 2, ..): the image's own position in the list unless
+                                  // consecutive images share their tables (jda_pipeline: the workgroups then pass from one to the next without restaging)
 };
 
 // device marker / stuffing filter (jda_filter_scan), one per image

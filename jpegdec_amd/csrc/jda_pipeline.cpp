@@ -391,7 +391,9 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
     // ---- launch plan and arena layout
     std::vector<jda_dev_desc> descs((size_t)n);
     uint32_t list_tiles[JDA_N_LISTS], list_ord[JDA_N_LISTS];
+    int list_tab[JDA_N_LISTS];                                // whose tables the list's last image has
     memset(list_tiles, 0, sizeof(list_tiles)); memset(list_ord, 0, sizeof(list_ord));
+    for (int m = 0; m < JDA_N_LISTS; m++) list_tab[m] = -1;
     size_t arena = 0;
     auto take = [&](size_t bytes) { const size_t o = arena; arena += a256(bytes); return o; };
     // regions: [control blob][raw][dc][work][ ZERO: scan | index | zero ][stats]; laid out by region so that one memset and
@@ -424,7 +426,11 @@ int jda_pipeline_submit_ex(jda_pipeline *p, int32_t n, const uint8_t *const *jpe
         im.n_tiles = JDA_LIST_IS_THUMB_FLAT((int)im.list) ? 1u : count_tiles(D.mcus_x, D.mcus_y, D.mode, big);      // (a whole gray image at 1/8: one record)
         if (JDA_LIST_IS_THUMB_FLAT((int)im.list)) S.flat_max_items = std::max(S.flat_max_items, jda_flat_items(D));
         im.strip_off = list_tiles[im.list]; list_tiles[im.list] += im.n_tiles;
-        im.ord = list_ord[im.list]++;
+        // a tile record's `ord` counts the TABLE SETS of its list, not its images: the decode kernel's workgroups restage the tables in LDS
+        // (three barriers) when it moves on -- images that share their tables (above) pass from one to the next without a barrier
+        if (list_tab[im.list] >= 0 && list_tab[im.list] != im.tab_owner) list_ord[im.list]++;
+        list_tab[im.list] = im.tab_owner;
+        im.ord = list_ord[im.list];
         S.st.source_pixels += (int64_t)I.width * I.height;
         S.st.compressed_bytes += lens[i];
     }
