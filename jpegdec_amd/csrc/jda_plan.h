@@ -100,10 +100,12 @@ inline uint32_t jda_mcus_per_tile(int mode)
 // rect = {mx0, my0, mx1, my1} in MCUs (half open) restricts the list to the tiles of that rectangle (crop-aware decode:
 // the per-block index lets a tile start at any MCU); NULL = the whole image
 // edge_mcus != 0: no tile crosses a multiple of edge_mcus MCUs (a strip-major surface: jda_dev_desc::strip_mcus)
-inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, int big = 0, const int32_t *rect = nullptr, uint32_t edge_mcus = 0)
+// same_tables: the image shares its tables with the one appended before it (one table generation: jda_strip::ord)
+inline void jda_append_strips(std::vector<jda_strip> &v, uint32_t image, uint32_t mcus_x, uint32_t mcus_y, int mode, int big = 0, const int32_t *rect = nullptr, uint32_t edge_mcus = 0,
+                              bool same_tables = false)
 {
     const uint32_t per = jda_mcus_per_tile(mode);
-    const uint32_t ord = v.empty() ? 0u : v.back().ord + 1u;      // images are appended one after the other
+    const uint32_t ord = v.empty() ? 0u : v.back().ord + (same_tables ? 0u : 1u);      // images are appended one after the other
     uint32_t x0 = 0, y0 = 0, x1 = mcus_x, y1 = mcus_y;
     if (rect) {
         x0 = rect[0] < 0 ? 0u : (uint32_t)rect[0]; y0 = rect[1] < 0 ? 0u : (uint32_t)rect[1];

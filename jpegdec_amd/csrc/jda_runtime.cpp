@@ -351,6 +351,8 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         d->scan_len = scan_len;
         jda_image_component_ids(img, d->dc_id, d->ac_id, d->q_id);
         d->general_p1 = (uint8_t)jda_image_general_p1(img);
+        d->tables_host = (uint8_t *)malloc(JDA_TABLE_BYTES);
+        if (d->tables_host) { uint32_t tb_ = 0; memcpy(d->tables_host, jda_image_tables(img, &tb_), JDA_TABLE_BYTES); }
         d->off_tables = 0;
         d->off_index = align16(it.tbytes);
         d->off_dc = d->off_index + align16((it.n_blocks + 1) * sizeof(uint32_t));
@@ -616,6 +618,7 @@ void jda_dev_image_free(jda_ctx *ctx, jda_dev_image *dimg)
     if (!dimg) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (dimg->base) { if (ctx) jda_pool_free(ctx, dimg->base); else (void)hipFree(dimg->base); }
+    free(dimg->tables_host);
     delete dimg;
 }
 
@@ -686,6 +689,10 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
     jda_batch_stats st;
     memset(&st, 0, sizeof(st));
     uint32_t flat_max_items = 0;
+    // consecutive images of a list with equal tables and table ids use ONE copy of them (the first one's: it is part of this plan) and are
+    // one table generation to the decode kernel -- its workgroups pass from one to the next without restaging (jda_strip::ord)
+    int list_owner[JDA_N_LISTS];
+    for (int m = 0; m < JDA_N_LISTS; m++) list_owner[m] = -1;
     for (int i = 0; i < n; i++) {
         const jda_dev_image *im = images[i];
         jda_dev_desc &D = descs[(size_t)i];
@@ -710,17 +717,24 @@ jda_batch *jda_batch_create_strips(jda_ctx *ctx, int32_t n, jda_dev_image *const
         {
             const int li = jda_list_index(D, variant, big, cont, mcu_rects == NULL);
             std::vector<jda_strip> &lst = strips[li];
+            bool same_tables = false;
+            if (list_owner[li] >= 0) {
+                const jda_dev_image *om = images[list_owner[li]];
+                same_tables = om->tables_host && im->tables_host && !memcmp(om->dc_id, im->dc_id, 3) && !memcmp(om->ac_id, im->ac_id, 3) && !memcmp(om->q_id, im->q_id, 3) &&
+                              om->info.ncomp == im->info.ncomp && !memcmp(om->tables_host, im->tables_host, JDA_TABLE_BYTES);
+            }
+            if (same_tables) D.tables = descs[(size_t)list_owner[li]].tables; else list_owner[li] = i;
             const uint32_t per = jda_mcus_per_tile(D.mode);
             if (JDA_LIST_IS_THUMB_FLAT(li)) {                     // a whole gray image at 1/8: one record (jda_dc_thumbnail_flat)
                 jda_strip r;
                 memset(&r, 0, sizeof(r));
-                r.image = (uint32_t)i; r.count = 1; r.first = 1; r.ord = lst.empty() ? 0u : lst.back().ord + 1u;
+                r.image = (uint32_t)i; r.count = 1; r.first = 1; r.ord = lst.empty() ? 0u : lst.back().ord + (same_tables ? 0u : 1u);
                 lst.push_back(r);
                 flat_max_items = std::max(flat_max_items, jda_flat_items(D));
                 st.tiles += (int64_t)D.mcus_y * ((D.mcus_x + per - 1) / per);
             } else {
                 const size_t before = lst.size();
-                jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL, D.strip_mcus);
+                jda_append_strips(lst, (uint32_t)i, D.mcus_x, D.mcus_y, D.mode, big, mcu_rects ? mcu_rects + 4 * i : NULL, D.strip_mcus, same_tables);
                 for (size_t k = before; k < lst.size(); k++) if (lst[k].count) st.tiles++;
             }
             st.tiles_whole_images += (int64_t)D.mcus_y * ((D.mcus_x + per - 1) / per);

@@ -49,6 +49,7 @@ struct jda_dev_image {
     size_t off_cont_first, off_cont;   // continuation entries (0 / 0: none uploaded)
     uint32_t n_cont;
     uint32_t tiles_total, tiles_over_small;   // host index known: tiles, and those whose scan slice exceeds the 16-wave kernel's window (0 / 0: unknown)
+    uint8_t *tables_host;     // a host copy of the tables (JDA_TABLE_BYTES): a launch plan lets consecutive images with equal tables share the first one's copy
 };
 
 struct jda_batch {

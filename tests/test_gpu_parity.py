@@ -122,11 +122,18 @@ def test_many_small_images_in_one_launch(gpu_ctx, oracle):
     exactly, in the general kernel (mixed formats) and in the plain-case variant (RGB8888 full size)."""
     names420 = ["c420_16x16", "c420_250x250_q10", "c420_333x217", "c420_256x256_q98", "c420_1100x48"]
     names444 = ["c444_8x8_q30", "c444_600x16", "c444_256x256_q100_opt", "c444_333x217"]
-    for names, variants in ((names420, "plain"), (names420, "mixed"), (names444, "plain")):
+    for names, variants in ((names420, "plain"), (names420, "mixed"), (names444, "plain"), (names420, "runs")):
         n = 240
         seq = [names[(i * 7 + i // 5) % len(names)] for i in range(n)]
-        pts = [J.RGB8888 if variants == "plain" else (J.RGB8888, J.RGB565_LE, J.RGB565_BE)[i % 3] for i in range(n)]
-        opts = [0 if variants == "plain" else (0, J.SCALE_HALF, 0, J.SCALE_EIGHTH)[i % 4] for i in range(n)]
+        if variants == "runs":
+            # runs of images with EQUAL tables (the same file, and different files of one quality): one table generation to the kernel
+            # (jda_batch_create_strips), between runs a new one
+            seq, k = [], 0
+            while len(seq) < n:
+                seq += [names[(k * 3) % len(names)]] * (1 + (k * 5) % 7); k += 1
+            seq = seq[:n]
+        pts = [J.RGB8888 if variants in ("plain", "runs") else (J.RGB8888, J.RGB565_LE, J.RGB565_BE)[i % 3] for i in range(n)]
+        opts = [0 if variants in ("plain", "runs") else (0, J.SCALE_HALF, 0, J.SCALE_EIGHTH)[i % 4] for i in range(n)]
         prep = {nm: J.PreparedImage(jpeg_for(nm)) for nm in names}
         devs = {nm: J.DeviceImage(gpu_ctx, prep[nm]) for nm in names}
         outs, ptrs, geos = [], [], []

@@ -7,6 +7,6 @@ for rep in 1 2 3; do
     JDA_LIBRARY=$GRAFT_REPO_ROOT/$lib timeout 200 python bench.py --no-cpu-baseline --e2e-batches 0 --steps 30 --configs $cfg 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$lib', ' '.join('%s %.4f ms %s' % (k, v['kernel_ms_per_launch'], v['parity_image_0']['bit_exact']) for k, v in d['configs'].items()))" | tee -a $out/ab.txt
+print('$lib', ' '.join('%s %.4f ms frac %.3f' % (k, v.get('kernel_ms_per_launch', v.get('kernel_ms_per_step', 0)), v.get('frac', 0)) for k, v in d['configs'].items()))" | tee -a $out/ab.txt
   done
 done
