@@ -74,15 +74,19 @@ tests/fuzz/frontend_fuzz: tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp 
 	$(CXX) -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Wall -Iinclude -pthread -o $@ tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp
 
 # the same driver under ThreadSanitizer: the interval-parallel host pre-scan (helper threads, jda_frontend.cpp) over restart streams
+chunkequiv: tests/fuzz/chunk_equiv
+tests/fuzz/chunk_equiv: tests/fuzz/chunk_equiv.cpp $(CSRC)/jda_frontend.cpp $(CSRC)/jda_internal.h include/jpegdec_amd.h
+	$(CXX) -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -DJDA_TEST_CHUNK_BYTES_HOOK -Wall -Iinclude -pthread -o $@ tests/fuzz/chunk_equiv.cpp $(CSRC)/jda_frontend.cpp
+
 fronttsan: tests/fuzz/frontend_tsan
 tests/fuzz/frontend_tsan: tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp $(CSRC)/jda_internal.h include/jpegdec_amd.h
 	$(CXX) -std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer -Wall -Iinclude -pthread -o $@ tests/fuzz/frontend_fuzz.cpp $(CSRC)/jda_frontend.cpp
 
 clean:
-	rm -f tests/fuzz/frontend_tsan $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user tests/capi_c/node_user tests/capi_c/semantics_user tests/capi_c/perf_user
+	rm -f tests/fuzz/frontend_tsan $(LIB) tests/class_cpu/*.so tests/class_cpu/*.o tests/class_cpu/walks_asan tests/fuzz/frontend_fuzz tests/fuzz/chunk_equiv tests/ref_main/jpegtest_amd tests/hostsim/libjda_hostsim.so tests/capi_c/c_user tests/capi_c/node_user tests/capi_c/semantics_user tests/capi_c/perf_user
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle hostsim classshim classcpu cuser nodeuser semuser perfuser fronttsan jpegtest frontfuzz nodestub clean
+.PHONY: all lib oracle hostsim classshim classcpu cuser nodeuser semuser perfuser fronttsan chunkequiv jpegtest frontfuzz nodestub clean
 
 # jda_node.cpp (host code above the C-ABI) over eight pretend devices -- test infrastructure, no GPU (tests/test_c_api.py)
 nodestub: tests/node_stub/node_stub_user

@@ -113,7 +113,7 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
 #define JDA_PREPARE_CONT_NEVER 4
 /* The host pre-scan of a stream with restart intervals (>= 4 of them, >= 12 KB of scan) decodes its intervals side by side on a few
  * helper threads the library keeps (an interval starts at a marker with predictors zero; the reader's phase across intervals -- the
- * one thing that carries over, SURVEY fact 6 -- is settled afterwards); a stream without them (>= 64 KB of scan) is walked in chunks
+ * one thing that carries over, SURVEY fact 6 -- is settled afterwards); a stream without them (>= 16 KB of scan) is walked in chunks
  * from a guess, the true path spliced in front of where each walker fell into step.  Either way the same index as the serial
  * pre-scan's in the sense of jda_index_equivalent.  This flag keeps the pre-scan on the calling thread. */
 #define JDA_PREPARE_SERIAL_PRESCAN 8

@@ -220,6 +220,24 @@ def test_frontend_fuzz_under_asan_ubsan():
         assert p.returncode == 0, (rel, p.stdout[-3000:])
 
 
+def test_chunk_parallel_prescan_at_chunk_sizes_no_thread_count_produces():
+    """host_prescan_chunks cuts the scan by the number of threads: a test machine sees one or two chunk sizes.  tests/fuzz/chunk_equiv.cpp
+    (jda_frontend.cpp with the chunk size exposed, ASan + UBSan) runs chunks of 512 bytes .. 16 KB over streams without restart markers and
+    corrupted copies of them against the serial pre-scan: same verdict, same index (jda_index_equivalent), DC values, truncation count,
+    continuation entries.  (Small chunks are where a walker from the guess meets codes that do not exist -- it steps on a bit and keeps
+    looking -- and where the splice has the least room.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "chunkequiv"], cwd=root, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    files = ["c420_1280x720.jpg", "c420_256x256_q98.jpg", "c420_333x217.jpg", "c422_333x217.jpg", "c440_200x120.jpg", "c444_256x256_q100_opt.jpg", "c444_333x217.jpg",
+             "gray_333x217.jpg", "w16_c420_333x217_x400.jpg", "ref/zebra.jpg", "ref/st_peters.jpg", "ref/sciopero.jpg"]
+    p = subprocess.run([os.path.join(root, "tests", "fuzz", "chunk_equiv"), "40", "7"] + files, cwd=os.path.join(root, "tests", "golden"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    taken = int(p.stdout.strip().split()[-9])
+    assert taken > 1500, p.stdout                 # (the chunk-parallel pre-scan really made most of them)
+
+
 def test_interval_parallel_prescan_under_thread_sanitizer():
     """The helper threads of the interval-parallel host pre-scan (jda_frontend.cpp: RstPool, rst_worker) under ThreadSanitizer: restart
     streams and corrupted copies of them (an interval that runs past its bytes must not touch what another thread writes)."""
