@@ -29,6 +29,6 @@ for w, h in ((640, 480), (1280, 720), (1920, 1080), (4096, 4096)):
         q = J.PreparedImage(jpeg); q.close()
     tp = (time.perf_counter() - t1) / 5
     p.close()
-    print("%dx%d: decode_to_host %.2f ms per image into the same canvas (%.2f into a fresh one; a host prepare with the serial pre-scan alone: %.2f ms) = %.0f Mpix/s"
+    print("%dx%d: decode_to_host %.2f ms per image into the same canvas (%.2f into a fresh one; the host prepare alone, default flags: %.2f ms) = %.0f Mpix/s"
           % (w, h, dt * 1e3, dt_fresh * 1e3, tp * 1e3, w * h / dt / 1e6))
 ctx.close()
