@@ -13,6 +13,7 @@
 extern "C" void jda_image_component_ids(const jda_image *img, uint8_t *dc_id, uint8_t *ac_id, uint8_t *q_id);
 extern "C" uint32_t jda_image_fast_mul(const jda_image *img);
 extern "C" uint32_t jda_image_general_p1(const jda_image *img);
+extern "C" int jda_host_prescan_threads(void);      // the threads a host pre-scan runs on (the caller + the helpers: jda_frontend.cpp, RstPool)
 
 
 // descriptor byte pad_[0]: bits 1:0 profiling switches (JDA_DEBUG_SKIP), bit 2 = JDA_DESC_GENERAL_P1, bit 3 = the scan holds DC symbols only (first scan

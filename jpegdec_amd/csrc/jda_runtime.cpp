@@ -979,11 +979,16 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
     static const bool trace = JDA_LAB_ENV("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
     double t_mark = trace ? now_ms() : 0.0;
 #define JDA_OC_MARK(what) do { if (trace) { const double t_ = now_ms(); fprintf(stderr, "jda_decode_to_host: %-24s %7.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
-    // One image at a time, the device pre-scan is seven latency-bound launches of ~0.1-0.25 ms each whatever the size (a 640x480 scan
-    // is four wavefronts' worth of segments): 0.88 ms all in where the serial host pre-scan of that image makes it 0.37 ms.  The host
-    // costs 6.8 us per KB of file, so the device wins from about 120 KB on (1920x1080, 250 KB: 1.24 ms against 1.95; 4096x4096: 4.2 ms
-    // against 13 for the host pre-scan alone) -- in batches it always does.
-    static const int32_t dev_from = []() { const char *e = JDA_LAB_ENV("JDA_ONECALL_DEVICE_PRESCAN_BYTES"); return e ? atoi(e) : (128 << 10); }();   // (for measuring the crossover)
+    // One image at a time, the device pre-scan is seven latency-bound launches of ~0.1-0.15 ms each whatever the size (a 640x480 scan
+    // is four wavefronts' worth of segments).  The host pre-scan costs 8 us per KB of file on one thread and 2.3 on six around one L3
+    // (jda_frontend.cpp, host_prescan_chunks / _intervals): measured end to end on the GPU box (six threads), 1920x1080 (214 KB) 0.65 ms
+    // with the host's index against 0.80 with the device's, 2560x1440 (377 KB) 1.08 against 0.90, 4096x4096 4.5 against 1.44 -- the
+    // device from 256 KB on; from 128 KB where the host has fewer threads (one: 6.8 us per KB, 1920x1080 1.95 ms).  In batches the
+    // device always does it.
+    static const int32_t dev_from = []() {
+        const char *e = JDA_LAB_ENV("JDA_ONECALL_DEVICE_PRESCAN_BYTES");   // (for measuring the crossover)
+        return e ? atoi(e) : ((jda_host_prescan_threads() >= 6 ? 256 : 128) << 10);
+    }();
     const int32_t prep_flags = len >= dev_from ? JDA_PREPARE_DEVICE_PRESCAN : 0;
     jda_image *img = jda_prepare_ex(jpeg, len, prep_flags, &err);
     if (!img) return err;

@@ -11,7 +11,7 @@ def t(f, n):
     t0 = time.perf_counter()
     for _ in range(n): f()
     return (time.perf_counter() - t0) / n * 1e3
-for (w, h, n) in ((640, 480, 300), (1280, 720, 200), (1920, 1080, 100), (4096, 4096, 20)):
+for (w, h, n) in ((1280, 720, 200), (1920, 1080, 100), (2560, 1440, 60), (3072, 2048, 40), (4096, 4096, 20)):
     jp = cached_jpeg(w, h, "4:2:0", 1234)
     ser = t(lambda: J.PreparedImage(jp, flags=J.PREPARE_SERIAL_PRESCAN).close(), n)
     par = t(lambda: J.PreparedImage(jp).close(), n)
