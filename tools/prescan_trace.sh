@@ -8,7 +8,7 @@ from bench import cached_jpeg
 lib = C.CDLL("/tmp/libfront_trace.so")
 lib.jda_prepare_ex.restype = C.c_void_p; lib.jda_prepare_ex.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
 lib.jda_image_free.argtypes = [C.c_void_p]
-for (w, h) in ((1280, 720),):
+for (w, h) in ((640, 480), (1280, 720)):
     j = cached_jpeg(w, h, "4:2:0", 1234)
     for flags in (8, 16):                 # JDA_PREPARE_SERIAL_PRESCAN, JDA_PREPARE_PARALLEL_PRESCAN
         for k in range(6):
