@@ -900,6 +900,22 @@ int jda_decode_to_host_flags(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
     return jda_decode_to_host_bands(ctx, jpeg, len, pixel_type, options, mcu_rect, host_pixels, pitch_bytes, rows, mcus_decoded, tiles, flags, 1, NULL, NULL);
 }
 
+// Who makes the index of ONE image (jda_decode_to_host*, the class).
+static int32_t jda_onecall_prepare_flags(int32_t len)
+{
+    // One image at a time, the device pre-scan is seven latency-bound launches of ~0.1-0.15 ms each whatever the size (a 640x480 scan
+    // is four wavefronts' worth of segments).  The host pre-scan costs 8 us per KB of file on one thread and 2.3 on six around one L3
+    // (jda_frontend.cpp, host_prescan_chunks / _intervals): measured end to end on the GPU box (six threads), 1920x1080 (214 KB) 0.65 ms
+    // with the host's index against 0.80 with the device's, 2560x1440 (377 KB) 1.08 against 0.90, 4096x4096 4.5 against 1.44 -- the
+    // device from 256 KB on; from 128 KB where the host has fewer threads (one: 6.8 us per KB, 1920x1080 1.95 ms).  In batches the
+    // device always does it.
+    static const int32_t dev_from = []() {
+        const char *e = JDA_LAB_ENV("JDA_ONECALL_DEVICE_PRESCAN_BYTES");   // (for measuring the crossover)
+        return e ? atoi(e) : ((jda_host_prescan_threads() >= 6 ? 256 : 128) << 10);
+    }();
+    return len >= dev_from ? JDA_PREPARE_DEVICE_PRESCAN : 0;
+}
+
 // The whole image as the reference's JPEGDRAW strips (jpeg.inl:5300-5336): strip_mcus MCUs wide, one MCU row high, in raster order, every
 // strip's pixels contiguous -- what JPEGDEC::decode hands to the draw callback without touching a pixel (a strip of a row-major canvas is
 // a few hundred bytes from each of 16 rows a pitch apart: 8,192 strips of a 4096x4096 image were 1.5 ms of small strided copies).
@@ -911,7 +927,7 @@ int jda_decode_to_host_strips(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, in
     if (!jpeg || !host_pixels || strip_mcus <= 0) return JDA_INVALID_PARAMETER;
     (void)hipSetDevice(ctx->device);
     int32_t err = JDA_SUCCESS;
-    jda_image *img = jda_prepare_ex(jpeg, len, len >= (128 << 10) ? JDA_PREPARE_DEVICE_PRESCAN : 0, &err);
+    jda_image *img = jda_prepare_ex(jpeg, len, jda_onecall_prepare_flags(len), &err);
     if (!img) return err;
     const jda_image_info I = *jda_image_get_info(img);
     int bpp, ow, oh, cw, ch;
@@ -979,17 +995,7 @@ int jda_decode_to_host_bands(jda_ctx *ctx, const uint8_t *jpeg, int32_t len, int
     static const bool trace = JDA_LAB_ENV("JDA_ONECALL_TRACE") != NULL;       // stage timings on stderr (diagnostics)
     double t_mark = trace ? now_ms() : 0.0;
 #define JDA_OC_MARK(what) do { if (trace) { const double t_ = now_ms(); fprintf(stderr, "jda_decode_to_host: %-24s %7.3f ms\n", what, t_ - t_mark); t_mark = t_; } } while (0)
-    // One image at a time, the device pre-scan is seven latency-bound launches of ~0.1-0.15 ms each whatever the size (a 640x480 scan
-    // is four wavefronts' worth of segments).  The host pre-scan costs 8 us per KB of file on one thread and 2.3 on six around one L3
-    // (jda_frontend.cpp, host_prescan_chunks / _intervals): measured end to end on the GPU box (six threads), 1920x1080 (214 KB) 0.65 ms
-    // with the host's index against 0.80 with the device's, 2560x1440 (377 KB) 1.08 against 0.90, 4096x4096 4.5 against 1.44 -- the
-    // device from 256 KB on; from 128 KB where the host has fewer threads (one: 6.8 us per KB, 1920x1080 1.95 ms).  In batches the
-    // device always does it.
-    static const int32_t dev_from = []() {
-        const char *e = JDA_LAB_ENV("JDA_ONECALL_DEVICE_PRESCAN_BYTES");   // (for measuring the crossover)
-        return e ? atoi(e) : ((jda_host_prescan_threads() >= 6 ? 256 : 128) << 10);
-    }();
-    const int32_t prep_flags = len >= dev_from ? JDA_PREPARE_DEVICE_PRESCAN : 0;
+    const int32_t prep_flags = jda_onecall_prepare_flags(len);
     jda_image *img = jda_prepare_ex(jpeg, len, prep_flags, &err);
     if (!img) return err;
     const jda_image_info I = *jda_image_get_info(img);       // (by value: the image is freed as soon as it is uploaded)

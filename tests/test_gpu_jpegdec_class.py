@@ -230,7 +230,7 @@ def test_objects_on_four_threads_decode_concurrently(product_class):
 
     jpeg = ref_jpeg("tulips")
     want = ref_golden()["tulips"]["frames"]["0:0"]["sha"]
-    n_each = 60
+    n_each = 30
 
     def work(out):
         ok = 0
@@ -239,20 +239,26 @@ def test_objects_on_four_threads_decode_concurrently(product_class):
             ok += int(r["rc"] == 1 and digest(r["canvas"][:480, : 640 * 2]) == want)
         out.append(ok)
 
-    warm = []
-    work(warm)                                            # (first use: context creation, code objects)
-    t0 = time.perf_counter(); one = []; work(one); t1 = time.perf_counter() - t0
+    one = []
+    work(one)                                             # (first use: context creation, code objects)
     res = []
     th = [threading.Thread(target=work, args=(res,)) for _ in range(4)]
-    t0 = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
         t.join()
-    t4 = time.perf_counter() - t0
     assert one == [n_each] and res == [n_each] * 4        # every decode right, on every thread
-    speedup = (4 * n_each / t4) / (n_each / t1)
-    print("class decode: 1 thread %.2f ms / image, 4 threads %.2fx the throughput" % (t1 / n_each * 1e3, speedup))
+    # the rate: C loops of open + decode (no-op draw callback) + close, one object per thread (the shim's bench entry: hashing canvases
+    # in Python holds the interpreter's lock for longer than a decode takes, and threads that queue for it measure the interpreter)
+    reps = 300
+    product_class.bench([jpeg], RGB565_LE, 0, reps=50, threads=4)
+    r1 = product_class.bench([jpeg], RGB565_LE, 0, reps=reps, threads=1)
+    r4 = product_class.bench([jpeg], RGB565_LE, 0, reps=reps, threads=4)
+    assert r1["failures"] == 0 and r4["failures"] == 0
+    speedup = (4 * reps / r4["seconds"]) / (reps / r1["seconds"])
+    print("class decode: 1 thread %.3f ms / image, 4 threads %.2fx the throughput" % (r1["seconds"] / reps * 1e3, speedup))
+    # (one thread's decode has the pre-scan's helper threads to itself; of four at once one has them and three pre-scan on their own
+    # thread: 2x is about what there is to get, and a loaded box takes its share)
     assert speedup > 1.15, speedup
 
 
