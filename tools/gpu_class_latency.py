@@ -14,7 +14,7 @@ for w, h in ((640, 480), (1280, 720), (1920, 1080), (4096, 4096)):
     jpeg = synth_jpeg(w, h, "4:2:0", seed=5)
     # a C loop on a thread of its own: openRAM + decode (no-op draw callback) + close on one object.  The thread's device context is
     # created on its first decode (milliseconds, once per thread): runs long enough to make that a per cent
-    n = 2000 if w * h < 1000000 else (500 if w * h < 4000000 else 100)
+    n = 2000 if w * h < 1000000 else (1000 if w * h < 4000000 else 500)
     r = cls.bench([jpeg], 0, 0, reps=n, threads=1)
     dt = r["seconds"] / n
     assert r["failures"] == 0
