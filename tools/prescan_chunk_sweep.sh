@@ -1,6 +1,6 @@
 #!/bin/bash
 # the chunk-parallel host pre-scan over chunk sizes (trace build of jda_frontend.cpp, CPU only): tools/prescan_chunk_sweep.sh
-g++ -O2 -std=c++17 -fPIC -shared -fwrapv -DJDA_PRESCAN_TRACE -Iinclude -pthread -o /tmp/libfront_trace.so jpegdec_amd/csrc/jda_frontend.cpp || exit 1
+g++ -O2 -std=c++17 -fPIC -shared -fwrapv -DJDA_PRESCAN_TRACE -DJDA_LAB -Iinclude -pthread -o /tmp/libfront_trace.so jpegdec_amd/csrc/jda_frontend.cpp || exit 1
 for cb in 0 2048 3072 4096 6144 9024; do
 JDA_TRACE_CHUNK_BYTES=$cb python - <<'PY'
 import ctypes as C, sys, time, os

@@ -1,6 +1,6 @@
 #!/bin/bash
 # phase times of the chunk-parallel host pre-scan (jda_frontend.cpp built with -DJDA_PRESCAN_TRACE), CPU only: tools/prescan_trace.sh
-g++ -O2 -std=c++17 -fPIC -shared -fwrapv -DJDA_PRESCAN_TRACE -Iinclude -pthread -o /tmp/libfront_trace.so jpegdec_amd/csrc/jda_frontend.cpp || exit 1
+g++ -O2 -std=c++17 -fPIC -shared -fwrapv -DJDA_PRESCAN_TRACE -DJDA_LAB -Iinclude -pthread -o /tmp/libfront_trace.so jpegdec_amd/csrc/jda_frontend.cpp || exit 1
 python - <<'PY'
 import ctypes as C, sys, time
 sys.path.insert(0, '.')
