@@ -121,7 +121,7 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
  * the threads were measured to pay; tests use it on small files). */
 #define JDA_PREPARE_PARALLEL_PRESCAN 16
 jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
-/* jda_prepare_ex for n images on `threads` host threads (<= 0: all hardware threads); out[i] / errs[i] per image
+/* jda_prepare_ex for n images on `threads` host threads (<= 0: as many as the process may keep busy -- hardware threads, its affinity mask, a cgroup quota); out[i] / errs[i] per image
  * (errs may be NULL).  Returns JDA_SUCCESS or the first error met. */
 int jda_prepare_batch(int32_t n, const uint8_t *const *jpegs, const int32_t *lens, int32_t flags, int32_t threads,
                       jda_image **out, int32_t *errs);
