@@ -1022,15 +1022,17 @@ __device__ __forceinline__ void jda_fused_item(const jda_segscan_params &P, cons
 #ifndef JDA_WALK_THREADS
 #define JDA_WALK_THREADS 256u      // a walker workgroup: the wavefronts that share one copy of the tables in LDS
 #endif
+#define JDA_ROUND_ALL 0x80000000u     // jda_segscan_fused's round argument: every segment, whatever the round; jda_segscan_tail's first round: exit states only (SPEC)
 template <int OP, bool LDS_TABLES>
 __global__ __launch_bounds__(JDA_WALK_THREADS)
-void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t round)
+void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t round_and_flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.y]);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t JDA_GLOBAL *stats = JDA_G(uint32_t, P.stats);
-    const bool all = round <= 1u;                                    // rounds 0 and 1 walk every segment (round 1 to make everybody's sums)
+    const uint32_t round = round_and_flag & ~JDA_ROUND_ALL;
+    const bool all = round <= 1u || (round_and_flag & JDA_ROUND_ALL) != 0u;      // rounds 0 and 1 walk every segment (round 1 to make everybody's sums); the closing RECORD round of the states-first order (jda_launch_prescan_passes_ex) too
     const uint32_t count = all ? P.n_segs : stats[8u + round];
     if (blockIdx.x * JDA_WALK_THREADS >= count) return;                          // (uniform per workgroup)
     const uint32_t JDA_GLOBAL *wl_in = JDA_G(const uint32_t, P.worklist) + ((round & 1u) ? P.worklist_cap : 0u);
@@ -1055,14 +1057,15 @@ void jda_segscan_fused(const jda_segscan_params *__restrict__ params, uint32_t r
 // the L2 (batches of small images: see jda_segscan_fused).
 template <bool LDS_TABLES>
 __global__ __launch_bounds__(LDS_TABLES ? 1024 : 256)
-void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t first_round, uint32_t max_round)
+void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t first_round_and_flag, uint32_t max_round)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t nthreads = LDS_TABLES ? 1024u : 256u;
     const jda_segscan_params P = jda_segscan_resolve(params[blockIdx.x]);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t *stats = P.stats;
-    uint32_t round = first_round;
+    const bool states_only = (first_round_and_flag & JDA_ROUND_ALL) != 0u;      // (uniform) the states-first order: these rounds settle the entry states, one RECORD round over every segment follows
+    uint32_t round = first_round_and_flag & ~JDA_ROUND_ALL;
     uint32_t count = __hip_atomic_load(&stats[8u + round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (count == 0) { if (threadIdx.x == 0) stats[7] = 1; return; }       // (the usual case: nothing is staged)
     uint32_t JDA_GLOBAL *E = JDA_G(uint32_t, P.entry_cur);
@@ -1078,7 +1081,8 @@ void jda_segscan_tail(const jda_segscan_params *__restrict__ params, uint32_t fi
         for (uint32_t base = wave * 64u; base < count; base += nthreads) {
             const uint32_t item = base + lane;
             if (item >= count) continue;
-            jda_fused_item<JDA_SEG_RECORD>(P, tab, wl_in[item], round, lane, E, wl_out);
+            if (states_only) jda_fused_item<JDA_SEG_SPEC>(P, tab, wl_in[item], round, lane, E, wl_out);
+            else jda_fused_item<JDA_SEG_RECORD>(P, tab, wl_in[item], round, lane, E, wl_out);
         }
         __threadfence();                                             // this round's entry states, sums and list, for every wavefront of the next
         __syncthreads();
@@ -1116,10 +1120,26 @@ extern "C" hipError_t jda_launch_segscan_fused(const jda_segscan_params *params,
     else JDA_LAUNCH((jda_segscan_fused<JDA_SEG_RECORD, false>), grid, block, 0, stream, params, round);
     return hipGetLastError();
 }
+// The states-first order's rounds (a batch too small to fill the GPU: one image at a time): every round in front of the last walks for
+// exit states only (the SPEC walk: half a RECORD walk's instructions, and a lone wavefront's round is as long as its chain of them), the
+// last one -- all_record -- records every segment from its settled entry state.
+static hipError_t jda_launch_segscan_states_first(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t round, bool all_record, hipStream_t stream)
+{
+    const int lds_bytes = JDA_WT_BYTES;
+    static std::atomic<unsigned long long> attr_s(0), attr_r(0);
+    hipError_t e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_SPEC, true>, JDA_WT_BYTES + 8192, attr_s);
+    if (e == hipSuccess) e = jda_ensure_lds_limit((const void *)jda_segscan_fused<JDA_SEG_RECORD, true>, JDA_WT_BYTES + 8192, attr_r);
+    if (e != hipSuccess) return e;
+    const uint32_t full = (max_segs + JDA_WALK_THREADS - 1u) / JDA_WALK_THREADS;
+    const dim3 grid((round <= 1 || all_record) ? full : (full < 8u ? full : 8u), n_images), block(JDA_WALK_THREADS);
+    if (all_record) JDA_LAUNCH((jda_segscan_fused<JDA_SEG_RECORD, true>), grid, block, lds_bytes, stream, params, round | JDA_ROUND_ALL);
+    else JDA_LAUNCH((jda_segscan_fused<JDA_SEG_SPEC, true>), grid, block, lds_bytes, stream, params, round);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t jda_launch_segscan_tail(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t first_round, uint32_t max_round, hipStream_t stream)
 {
-    if (n_images == 0) return hipSuccess;
+    if (n_images == 0) return hipSuccess;                              // (first_round | JDA_ROUND_ALL: exit states only)
     if (max_segs > JDA_SMALL_SCAN_SEGS) JDA_LAUNCH(jda_segscan_tail<true>, dim3(n_images), dim3(1024), JDA_WT_BYTES, stream, params, first_round, max_round);
     else JDA_LAUNCH(jda_segscan_tail<false>, dim3(n_images), dim3(256), 0, stream, params, first_round, max_round);
     return hipGetLastError();
@@ -1338,13 +1358,21 @@ void jda_segscan_resolve_cands(const jda_segscan_params *__restrict__ params)
 
 // every pass of the device pre-scan behind the filter, on one stream: round 0 and the counting round over every segment, the
 // work-list rounds, the sums, then WRITE (streams with restart intervals) / finalize + candidates (RECORD mode)
-extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
-                                                int any_record, hipStream_t stream)
+// states_first: the order for a batch that cannot fill the GPU (see jda_launch_segscan_states_first): rounds 0 .. list_rounds - 1 and the
+// tail's settle the entry states with the SPEC walk, round max_round (no list round uses that number) records every segment once.
+extern "C" hipError_t jda_launch_prescan_passes_ex(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
+                                                   int any_record, int states_first, hipStream_t stream)
 {
     if (n_images == 0 || max_segs == 0) return hipSuccess;
     hipError_t e = hipSuccess;
-    for (uint32_t r = 0; r < list_rounds && e == hipSuccess; r++) e = jda_launch_segscan_fused(params, n_images, max_segs, r, stream);
-    if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, max_segs, list_rounds, max_round, stream);
+    if (states_first && any_record) {
+        for (uint32_t r = 0; r < list_rounds && e == hipSuccess; r++) e = jda_launch_segscan_states_first(params, n_images, max_segs, r, false, stream);
+        if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, max_segs, list_rounds | JDA_ROUND_ALL, max_round, stream);
+        if (e == hipSuccess) e = jda_launch_segscan_states_first(params, n_images, max_segs, max_round, true, stream);
+    } else {
+        for (uint32_t r = 0; r < list_rounds && e == hipSuccess; r++) e = jda_launch_segscan_fused(params, n_images, max_segs, r, stream);
+        if (e == hipSuccess) e = jda_launch_segscan_tail(params, n_images, max_segs, list_rounds, max_round, stream);
+    }
     if (e == hipSuccess) e = jda_launch_segscan_sums(params, n_images, stream);
     if (e == hipSuccess && any_record) {
         JDA_LAUNCH(jda_segscan_finalize, dim3((max_segs + 4u * JDA_FIN_SEGS_PER_WAVE - 1u) / (4u * JDA_FIN_SEGS_PER_WAVE), n_images), dim3(256), 0, stream, params);
@@ -1352,6 +1380,11 @@ extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params
         e = hipGetLastError();
     }
     return e;
+}
+extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
+                                                int any_record, hipStream_t stream)
+{
+    return jda_launch_prescan_passes_ex(params, n_images, max_segs, list_rounds, max_round, any_record, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

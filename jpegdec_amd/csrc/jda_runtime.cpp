@@ -491,7 +491,14 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         if (e == hipSuccess) e = jda_launch_walk_tables(d_seg, ns, ctx->stream);
         // round 0, the recording round, two work-list rounds, every further round in one launch, the sums (first block ordinal, DC
         // predictors, window lag per segment), then finalize + candidates (records -> index entries and DC values)
-        if (e == hipSuccess) e = jda_launch_prescan_passes(d_seg, ns, max_segs, 4, 56, 1, ctx->stream);
+        // A batch that cannot fill the GPU -- one image at a time is the case -- is as slow as its rounds are long, and a round is one
+        // wavefront's chain of walk steps: the entry states are settled with the SPEC walk (half a RECORD walk's instructions) and every
+        // segment is recorded once, from its settled state (one 4096x4096 image: 0.07 + 3 x 0.15 ms of rounds -> 4 x 0.07 + 0.15).  A batch
+        // that does fill it pays per walk, not per round: there the RECORD round right behind round 0 is the cheaper order.
+        uint64_t total_segs = 0;
+        for (const jda_segscan_params &sp : seg_params) total_segs += sp.n_segs;
+        const int states_first = total_segs <= 131072u ? 1 : 0;                 // (two lanes for every SIMD lane of the GPU)
+        if (e == hipSuccess) e = jda_launch_prescan_passes_ex(d_seg, ns, max_segs, 4, 56, 1, states_first, ctx->stream);
         for (uint32_t p = 0; p < ns && e == hipSuccess; p++) {
             Item &it = items[seg_owner[p]];
             e = hipMemcpyAsync(it.sst, it.d->base + it.off_sstats, sizeof(it.sst), hipMemcpyDeviceToHost, ctx->stream);
@@ -511,7 +518,7 @@ int jda_upload_batch(jda_ctx *ctx, int32_t n, jda_image *const *imgs, jda_dev_im
         Item &it = items[i];
         const jda_image_info &I = *jda_image_get_info(imgs[i]);
         { int r = 2; while (r <= 57 && it.sst[8 + r]) r++; if (r > rounds_max) rounds_max = r; }
-        if (it.sst[7] == 1 && it.sst[6] == 1 && it.sst[0] == 0 && it.sst[1] == 1 && it.sst[5] == 0) {   // states settled, enough blocks, no bad code before the end, the closing index entry written once, every marker where the MCU count puts it
+        if (it.sst[7] == 1 && it.sst[6] == 1 && it.sst[0] == 0 && it.sst[1] == 1 && it.sst[5] == 0 && it.sst[8 + 57] == 0) {   // (.. and the states-first order's recording round found every exit state as the SPEC rounds had left it)   // states settled, enough blocks, no bad code before the end, the closing index entry written once, every marker where the MCU count puts it
             jda_image_adopt_prescan(imgs[i], (uint32_t)(I.mcus_x * I.mcus_y), it.sst[2], (int32_t)it.sst[3], it.sst[4]);
             it.d->prescan_on_device = 1;
         } else {                                                         // corrupt or truncated stream: the serial pre-scan knows what the reference does

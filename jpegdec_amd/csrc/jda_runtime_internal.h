@@ -108,6 +108,9 @@ extern "C" hipError_t jda_launch_walk_tables(const jda_segscan_params *params, u
 extern "C" hipError_t jda_launch_segscan_sums(const jda_segscan_params *params, uint32_t n_images, hipStream_t stream);
 extern "C" hipError_t jda_launch_prescan_passes(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
                                                 int any_record, hipStream_t stream);
+// the same, or -- states_first -- the order for a batch too small to fill the GPU: exit states first (SPEC walks), then ONE recording round
+extern "C" hipError_t jda_launch_prescan_passes_ex(const jda_segscan_params *params, uint32_t n_images, uint32_t max_segs, uint32_t list_rounds, uint32_t max_round,
+                                                   int any_record, int states_first, hipStream_t stream);
 // aux: JDA_LIST_THUMB_FLAT: the most items an image of the batch's flat lists has (jda_flat_items); 0 otherwise
 extern "C" hipError_t jda_launch_decode(int mode, int fast_mul, int variant, int big, int cont, const jda_dev_desc *descs, const jda_strip *strips,
                                         uint32_t n_strips, uint32_t aux, hipStream_t stream);

@@ -160,6 +160,8 @@ extern "C" void hostsim_set_device_prescan(int on) { g_device_prescan = on; }
 extern "C" int hostsim_prescan_used(void) { return g_prescan_used; }
 extern "C" void jda_image_run_host_prescan(jda_image *img);
 static int g_segscan_rounds = 0;     // speculative rounds of the last marker-less device pre-scan
+static int g_states_first = 0;       // the order jda_upload_batch takes for a batch too small to fill the GPU (jda_launch_prescan_passes_ex)
+extern "C" void hostsim_set_states_first(int on) { g_states_first = on; }
 extern "C" int hostsim_segscan_rounds(void) { return g_segscan_rounds; }
 static int g_index_equal = -1;       // after a device-pre-scanned decode: 1 if its index == the serial host pre-scan's
 extern "C" int hostsim_index_equal(void) { return g_index_equal; }
@@ -236,10 +238,14 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 for (uint32_t seg : list) {
                     const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
                     const uint32_t entry = seg == 0 ? 0u : snap[seg];
-                    const uint32_t x = rst ? jda_seg_walk<JDA_SEG_RECORD, true>(P, seg, entry, slot, lt, S, ST, rounds) : jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, slot, lt, S, ST, rounds);
-                    uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
-                    o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map;
-                    o[5] = S.bad | (S.max_ac << 4); o[6] = S.lag_last; o[7] = rounds;
+                    uint32_t x;
+                    if (g_states_first) x = rst ? jda_seg_walk<JDA_SEG_SPEC, true>(P, seg, entry, slot, lt, S, ST, rounds) : jda_seg_walk<JDA_SEG_SPEC, false>(P, seg, entry, slot, lt, S, ST, rounds);
+                    else {
+                        x = rst ? jda_seg_walk<JDA_SEG_RECORD, true>(P, seg, entry, slot, lt, S, ST, rounds) : jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, slot, lt, S, ST, rounds);
+                        uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
+                        o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map;
+                        o[5] = S.bad | (S.max_ac << 4); o[6] = S.lag_last; o[7] = rounds;
+                    }
                     if (seg + 1 < n_segs && x != E[seg + 1]) { E[seg + 1] = x; next.push_back(seg + 1); }
                 }
                 if (rounds == 1) g_round2_list = (uint32_t)next.size();
@@ -247,6 +253,17 @@ extern "C" int hostsim_decode(const uint8_t *jpeg, int len, int pixel_type, int 
                 rounds++;
             }
             settled = list.empty();
+            if (g_states_first) {                               // .. and ONE recording round over every segment, from its settled entry state (round number 56)
+                for (uint32_t seg = 0; seg < n_segs; seg++) {
+                    const uint32_t *slot = padded.data() + (size_t)seg * (JDA_SEG_BYTES / 4);
+                    const uint32_t entry = seg == 0 ? 0u : E[seg];
+                    const uint32_t x = rst ? jda_seg_walk<JDA_SEG_RECORD, true>(P, seg, entry, slot, lt, S, ST, 56u) : jda_seg_walk<JDA_SEG_RECORD, false>(P, seg, entry, slot, lt, S, ST, 56u);
+                    uint32_t *o = &seg_sum[(size_t)seg * JDA_SEG_SUM_WORDS];
+                    o[0] = S.nblk; o[1] = (uint32_t)S.dcsum[0]; o[2] = (uint32_t)S.dcsum[1]; o[3] = (uint32_t)S.dcsum[2]; o[4] = S.phase_map;
+                    o[5] = S.bad | (S.max_ac << 4); o[6] = S.lag_last; o[7] = 56u;
+                    if (seg + 1 < n_segs && x != E[seg + 1]) settled = false;      // (a recording walk leaves the state a SPEC walk leaves)
+                }
+            }
             for (uint32_t i = 0; i <= n_segs; i++) ea[i] = E[i];
         }
         g_segscan_rounds = (int)rounds;

@@ -93,6 +93,54 @@ def test_markerless_prescan_equals_serial(name, hostsim, oracle):
         hostsim.hostsim_set_device_prescan(0)
 
 
+@pytest.mark.parametrize("name", ["c420_333x217", "c444_256x256_q100_opt", "gray_333x217", "c420_1280x720", "c422_333x217", "c420_256x256_q98",
+                                  "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c440_300x64_rst5", "gray_64x64_rst3", "w16_c420_333x217_x400"])
+def test_states_first_prescan_order_equals_serial(name, hostsim, oracle):
+    """The order jda_upload_batch takes for a batch too small to fill the GPU (one image at a time; jda_launch_prescan_passes_ex): the
+    entry states are settled by SPEC walks alone (round 0, round 1 over every segment, the work-list rounds), then ONE recording round
+    walks every segment from its settled state.  The same index as the serial pre-scan's (and so as the other order's), the oracle's
+    pixels; and on corrupted copies the same verdict -- an index that is made must be the serial one."""
+    jpeg = jpeg_for(name)
+    hostsim.hostsim_set_states_first(1)
+    try:
+        hostsim.hostsim_set_device_prescan(2)
+        for pt, opt in ((2, 0), (0, 2), (3, 8)):
+            rc, want, err = oracle.decode_canvas(jpeg, pt, opt)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jpeg, pt, opt)
+            hrc = hostsim.hostsim_decode(jpeg, len(jpeg), pt, opt, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert hrc == 0 and hostsim.hostsim_prescan_used() == 2
+            assert hostsim.hostsim_index_equal() == 1
+            assert np.array_equal(got, want), (name, pt, opt)
+        base = bytearray(jpeg)
+        sos = bytes(base).index(b"\xff\xda")
+        rng = np.random.default_rng(23)
+        for it in range(40):
+            b = bytearray(base)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+            jb = bytes(b)
+            try:
+                p = J.PreparedImage(jb)
+            except J.JdaError:
+                continue
+            idx, nok = p.block_index()
+            if (int(idx[-1]) >> 7) + ((int(idx[-1]) & 127) + 7) // 8 > len(p.scan()):
+                continue                                   # consumed more bits than the scan holds: out of contract
+            rc, want, err = oracle.decode_canvas(jb, 2, 0)
+            got = np.full_like(want, 0x33)
+            inf, cx, cy, mw, mh, bpp, sh = oracle.canvas_geometry(jb, 2, 0)
+            hrc = hostsim.hostsim_decode(jb, len(jb), 2, 0, got.ctypes.data_as(C.c_void_p), got.shape[1], cx * mw, cy * mh)
+            assert (rc == 1) == (hrc == 0), (name, it, rc, err, hrc)
+            if hostsim.hostsim_prescan_used():
+                assert hostsim.hostsim_index_equal() == 1, (name, it)
+            if rc == 1:
+                assert np.array_equal(got, want), (name, it)
+    finally:
+        hostsim.hostsim_set_device_prescan(0)
+        hostsim.hostsim_set_states_first(0)
+
+
 @pytest.mark.parametrize("name", ["c420_333x217", "c444_333x217", "c422_333x217", "c420_640x368_rstrow", "c444_384x192_q100_rst7", "c440_300x64_rst5"])
 def test_corrupted_scans_decode_like_the_oracle(name, hostsim, oracle):
     """The reference's fuzz idea (MacOS/JPEGDEC_Test/main.cpp:262-300) turned into a parity test: random byte
