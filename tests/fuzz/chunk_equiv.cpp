@@ -15,6 +15,7 @@
 
 extern uint32_t jda_test_chunk_bytes;            // jda_frontend.cpp under JDA_TEST_CHUNK_BYTES_HOOK (0: the product's rule)
 extern uint32_t jda_test_chunk_taken;            // counts the images host_prescan_chunks indexed
+extern "C" int jda_host_prescan_threads(void);   // the caller + the helper threads (1: a machine with fewer than four CPUs -- nothing runs in chunks there)
 
 static uint32_t rng_state = 1;
 static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
@@ -79,6 +80,6 @@ int main(int argc, char **argv)
             }
         }
     }
-    printf("chunk_equiv: %ld comparisons, %u images indexed by the chunk-parallel pre-scan\n", checked, jda_test_chunk_taken);
+    printf("chunk_equiv: %ld comparisons, %u images indexed by the chunk-parallel pre-scan on %d threads\n", checked, jda_test_chunk_taken, jda_host_prescan_threads());
     return 0;
 }

@@ -234,8 +234,9 @@ def test_chunk_parallel_prescan_at_chunk_sizes_no_thread_count_produces():
     p = subprocess.run([os.path.join(root, "tests", "fuzz", "chunk_equiv"), "40", "7"] + files, cwd=os.path.join(root, "tests", "golden"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
-    taken = int(p.stdout.strip().split()[-9])
-    assert taken > 1500, p.stdout                 # (the chunk-parallel pre-scan really made most of them)
+    words = p.stdout.strip().split()
+    taken, threads = int(words[-12]), int(words[-2])
+    assert taken > 1500 or threads == 1, p.stdout  # (the chunk-parallel pre-scan really made most of them -- where the machine has CPUs for helper threads)
 
 
 def test_interval_parallel_prescan_under_thread_sanitizer():
