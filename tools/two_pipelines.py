@@ -40,8 +40,34 @@ def run(pipes, nb):
     dt = time.perf_counter() - t0
     return W * H * BATCH * nb / dt / 1e9
 
+import threading
+
+
+def run_threads(pipes, nb):
+    """every pipeline fed by a thread of its own (ctypes calls release the interpreter's lock)"""
+    res = [0.0] * len(pipes)
+    bar = threading.Barrier(len(pipes))
+
+    def feed(i):
+        bar.wait()
+        t0 = time.perf_counter()
+        run([pipes[i]], nb)
+        res[i] = time.perf_counter() - t0
+    th = [threading.Thread(target=feed, args=(i,)) for i in range(len(pipes))]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    return None
+
+
 one = [make(4)]
 two = [make(2), make(2)]
 two4 = [make(4), make(4)]
 for rep in range(3):
     print("one pipeline depth 4: %.1f Gpix/s   two pipelines depth 2+2: %.1f   two pipelines depth 4+4: %.1f" % (run(one, NB), run(two, NB), run(two4, NB)), flush=True)
+# two feeder threads, a pipeline each: the whole job's rate (both run NB timed batches behind 8 warm-up ones; the clock runs from the barrier to the last join, warm-up included)
+for rep in range(3):
+    t0 = time.perf_counter()
+    run_threads(two4, NB)
+    dt = time.perf_counter() - t0
+    print("two pipelines depth 4 + 4, a feeder thread each: %.1f Gpix/s (warm-up batches counted)" % (W * H * BATCH * (NB + 8) * 2 / dt / 1e9), flush=True)
