@@ -131,12 +131,14 @@ class JPEGDEC {
 // (src/JPEGDEC.cpp:232-236: a no-op there).  As with the reference's struct (src/JPEGDEC.h:199-239: plain state), a struct copy
 // (assignment, memcpy, a growing array that moves its elements) of an open JPEGIMAGE is an open JPEGIMAGE of the same image with
 // the same settings, independent of the original from then on.  A file-sourced image owns the file's bytes until JPEG_close, as
-// the reference's owns its open file; copies of it share them as the reference's copies share the FILE: close ONE of them.
+// the reference's owns its open file; copies of it share them as the reference's copies share the FILE: closing one of them (or
+// re-opening the handle that read the file) closes them all -- the others answer like closed handles, and closing them again is harmless.
 typedef struct jpeg_image_tag {
     uint32_t magic[2];              /* set by JPEG_open*: lets an uninitialised (stack) JPEGIMAGE be told from an open one */
     struct jpeg_image_tag *file_owner;  /* JPEG_openFile: the handle that read the file (re-opening THAT handle gives the bytes back) */
     void *file_data;                /* JPEG_openFile: the file's bytes, freed by JPEG_close */
-    uint64_t file_check;            /* file_data under a cookie: the bytes are only ever freed through a handle whose words agree */
+    uint64_t file_check;            /* the serial number the library's list of live file buffers holds for file_data: bytes are freed only while
+                                       (file_data, file_check) is on that list, so closing one copy closes every copy of the handle */
     uint64_t state[40];             /* the open image (opaque plain data) */
 } JPEGIMAGE;
 

@@ -121,6 +121,11 @@ jda_image *jda_prepare(const uint8_t *jpeg, int32_t len, int32_t *err);
  * the threads were measured to pay; tests use it on small files). */
 #define JDA_PREPARE_PARALLEL_PRESCAN 16
 jda_image *jda_prepare_ex(const uint8_t *jpeg, int32_t len, int32_t flags, int32_t *err);
+/* The helper threads (process-wide): n < 0 as many as the library chooses (the default: up to five, none on fewer than four usable CPUs;
+ * made at the first image that takes them, asleep unless one caller decodes image after image within 2 ms of each other), n == 0 none --
+ * no thread is made, every pre-scan runs on its caller's thread --, n > 0 at most n in a job.  Returns the setting it replaces.
+ * jda_prepare_batch's workers (threads > 1) and the pipeline's workers never use them. */
+int jda_set_host_prescan_helpers(int32_t n);
 /* jda_prepare_ex for n images on `threads` host threads (<= 0: as many as the process may keep busy -- hardware threads, its affinity mask, a cgroup quota); out[i] / errs[i] per image
  * (errs may be NULL).  Returns JDA_SUCCESS or the first error met. */
 int jda_prepare_batch(int32_t n, const uint8_t *const *jpegs, const int32_t *lens, int32_t flags, int32_t threads,

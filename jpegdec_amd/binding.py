@@ -58,6 +58,7 @@ _PROTOTYPES = [
     ("jda_parse", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(ImageInfo)]),
     ("jda_prepare", _P, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("jda_prepare_ex", _P, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    ("jda_set_host_prescan_helpers", C.c_int, [C.c_int32]),
     ("jda_image_prescan_pending", C.c_int, [_P]),
     ("jda_prepare_batch", C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("jda_dev_image_prescan_on_device", C.c_int, [_P]),

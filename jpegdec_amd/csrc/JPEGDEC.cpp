@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/jpegdec_amd.h"
@@ -543,7 +544,6 @@ int JPEGDEC::decode(int x, int y, int iOptions)
 // buffer are that object's and serve every handle the thread decodes.
 #define JPEGIMAGE_MAGIC0 0x4a444133u   /* "JDA3" */
 #define JPEGIMAGE_MAGIC1 0x9b1e5a7du
-#define JPEGIMAGE_FILE_COOKIE 0x6a64615f66696c65ull
 struct jpegdec_amd_c_api { static jpegdec_amd_state *state(JPEGDEC &j) { return j._jpeg; } };
 namespace {
 static_assert(sizeof(jpegdec_amd_settings) <= sizeof(((JPEGIMAGE *)0)->state), "JPEGIMAGE holds the settings");
@@ -551,11 +551,51 @@ thread_local JPEGDEC t_cworker;
 // a live handle: opened by this library (64 bits that stack garbage does not hold), wherever it lies now -- a struct copy of an open
 // JPEGIMAGE is an open JPEGIMAGE, as with the reference's plain struct (src/JPEGDEC.h:199-239)
 bool c_live(const JPEGIMAGE *p) { return p && p->magic[0] == JPEGIMAGE_MAGIC0 && p->magic[1] == JPEGIMAGE_MAGIC1; }
-// .. that holds a file's bytes: the pointer and its check word agree (nothing is freed through a handle whose words do not)
-bool c_has_file(const JPEGIMAGE *p) { return c_live(p) && p->file_data && p->file_check == ((uint64_t)(uintptr_t)p->file_data ^ JPEGIMAGE_FILE_COOKIE); }
+// The bytes of the files JPEG_openFile read, by address, each under a serial number no other buffer ever had.  Whether a buffer
+// is freed is decided HERE, never from the words inside a caller's struct: any number of struct copies name the same buffer, and
+// closing (or re-opening) one of them must leave the others knowing that the bytes are gone -- a handle whose (address, serial)
+// pair is not in the table is a closed handle.  (Never destroyed: handles on other threads may outlive main()'s statics.)
+struct c_file_table {
+    std::mutex mu;
+    std::unordered_map<const void *, uint64_t> live;
+    uint64_t next = 0x6a64615f66696c65ull;
+};
+c_file_table &c_files() { static c_file_table *t = new c_file_table; return *t; }
+uint64_t c_file_adopt(void *bytes)
+{
+    c_file_table &t = c_files();
+    std::lock_guard<std::mutex> g(t.mu);
+    const uint64_t serial = ++t.next;
+    t.live[bytes] = serial;
+    return serial;
+}
+bool c_file_alive(const JPEGIMAGE *p)
+{
+    if (!c_live(p) || !p->file_data) return false;
+    c_file_table &t = c_files();
+    std::lock_guard<std::mutex> g(t.mu);
+    auto it = t.live.find(p->file_data);
+    return it != t.live.end() && it->second == p->file_check;
+}
+// gives the bytes back if this handle still names a live buffer; true when it did
+bool c_file_release(JPEGIMAGE *p)
+{
+    if (!c_live(p) || !p->file_data) return false;
+    c_file_table &t = c_files();
+    {
+        std::lock_guard<std::mutex> g(t.mu);
+        auto it = t.live.find(p->file_data);
+        if (it == t.live.end() || it->second != p->file_check) return false;
+        t.live.erase(it);
+    }
+    free(p->file_data);
+    return true;
+}
+// a file-sourced handle whose bytes another copy of it has given back is a closed handle
+bool c_stale_file(const JPEGIMAGE *p) { return c_live(p) && p->file_data && !c_file_alive(p); }
 jpegdec_amd_state *c_load(JPEGIMAGE *p)
 {
-    if (!c_live(p)) return NULL;
+    if (!c_live(p) || c_stale_file(p)) return NULL;
     jpegdec_amd_state *s = jpegdec_amd_c_api::state(t_cworker);
     memcpy(static_cast<jpegdec_amd_settings *>(s), p->state, sizeof(jpegdec_amd_settings));
     return s;
@@ -565,7 +605,7 @@ void c_store(JPEGIMAGE *p) { memcpy(p->state, static_cast<const jpegdec_amd_sett
 // again without a close (the reference leaks its FILE there); a copy of it that is opened again leaves them to the original.
 void c_begin_open(JPEGIMAGE *p)
 {
-    if (c_has_file(p) && p->file_owner == p) free(p->file_data);
+    if (c_live(p) && p->file_owner == p) c_file_release(p);
     memset(p, 0, sizeof(*p));
     p->magic[0] = JPEGIMAGE_MAGIC0; p->magic[1] = JPEGIMAGE_MAGIC1;
     jpegdec_amd_c_api::state(t_cworker)->device = -1;
@@ -590,7 +630,7 @@ int JPEG_openFile(JPEGIMAGE *pJPEG, const char *szFilename, JPEG_DRAW_CALLBACK *
         if (rc) pJPEG->file_data = malloc(s->owned.size());     // (a file that was read and did not parse: nothing to keep -- the reference has nothing to free after a failed open either)
         if (pJPEG->file_data) {
             memcpy(pJPEG->file_data, s->owned.data(), s->owned.size()); s->data = (const uint8_t *)pJPEG->file_data;
-            pJPEG->file_owner = pJPEG; pJPEG->file_check = (uint64_t)(uintptr_t)pJPEG->file_data ^ JPEGIMAGE_FILE_COOKIE;
+            pJPEG->file_owner = pJPEG; pJPEG->file_check = c_file_adopt(pJPEG->file_data);
         } else { s->data = NULL; s->size = 0; s->opened = false; if (rc) s->error = JPEG_ERROR_MEMORY; }
         std::vector<uint8_t>().swap(s->owned);
     }
@@ -620,9 +660,8 @@ void JPEG_close(JPEGIMAGE *pJPEG)
 {
     if (!pJPEG) return;
     if (c_live(pJPEG)) {
-        const bool file = c_has_file(pJPEG);
-        JDA_C_CALL(pJPEG, t_cworker.close());
-        if (file) free(pJPEG->file_data);
+        JDA_C_CALL(pJPEG, t_cworker.close());               // (not for a copy whose file another copy has closed: nothing is open there)
+        c_file_release(pJPEG);                              // frees only bytes that are still on the library's list
     }
     pJPEG->file_data = NULL; pJPEG->file_owner = NULL; pJPEG->file_check = 0; pJPEG->magic[0] = pJPEG->magic[1] = 0;
 }

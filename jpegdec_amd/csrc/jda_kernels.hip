@@ -54,17 +54,19 @@ static void jda_count_launch(const void *fn)
 // "<kernel symbol> <launches>\n" for every kernel launched so far; returns the bytes the whole report needs (cap too small: truncated)
 extern "C" int jda_kernel_launch_counts(char *buf, int cap)
 {
-    int need = 0;
+    int need = 0, written = 0;
+    bool full = false;                                          // (whole lines only, none behind the first that did not fit)
     for (uint32_t i = 0; i < JDA_LAUNCH_SLOTS; i++) {
         const void *fn = g_launch_slots[i].fn.load(std::memory_order_acquire);
         if (!fn) continue;
         const char *name = hipKernelNameRefByPtr(fn, nullptr);
         char line[512];
-        const int n = snprintf(line, sizeof(line), "%s %llu\n", name ? name : "?", g_launch_slots[i].n.load(std::memory_order_relaxed));
-        if (buf && need + n < cap) memcpy(buf + need, line, (size_t)n);
+        int n = snprintf(line, sizeof(line), "%s %llu\n", name ? name : "?", g_launch_slots[i].n.load(std::memory_order_relaxed));
+        if (n >= (int)sizeof(line)) { n = (int)sizeof(line) - 1; line[n - 1] = '\n'; }
+        if (buf && !full && written + n < cap) { memcpy(buf + written, line, (size_t)n); written += n; } else full = true;
         need += n;
     }
-    if (buf && cap > 0) buf[need < cap ? need : cap - 1] = 0;
+    if (buf && cap > 0) buf[written] = 0;                       // the string ends where its content does
     return need + 1;
 }
 

@@ -94,6 +94,30 @@ int main(int argc, char **argv)
         JPEG_close(&moved);
         CHECK(20, JPEG_getWidth(&moved) == 0);
     }
+    for (int k = 0; k < 200; k++) {                                                  // copy, close the COPY, then use / reopen / close the original -- no memset in between:
+        JPEGIMAGE a;                                                                  // (the same stack slot every turn, never initialised: what it holds is the last turn's closed handle)
+        if (k == 0) memset(&a, 0x21, sizeof(a));
+        CHECK(30, JPEG_openFile(&a, argv[1], draw) == 1);
+        JPEGIMAGE b = a;
+        JPEG_close(&b);                                                               // gives the bytes back, once
+        CHECK(31, JPEG_getWidth(&a) == 0 && JPEG_decode(&a, 0, 0, 0) == 0);           // the original knows: a closed handle, not a pointer into freed memory
+        if (k & 1) JPEG_close(&a);                                                    // closing it again frees nothing ..
+        if (k & 2) JPEG_close(&b);
+        if (k & 4) { CHECK(32, JPEG_openFile(&a, argv[1], draw) == 1 && JPEG_getWidth(&a) == w); JPEG_close(&a); }   // .. and so does opening it again
+    }
+    {                                                                                 // the original closed first, the copy afterwards
+        JPEGIMAGE a, b;
+        CHECK(33, JPEG_openFile(&a, argv[1], draw) == 1);
+        b = a;
+        JPEG_close(&a);
+        CHECK(34, JPEG_getWidth(&b) == 0);
+        JPEG_close(&b);
+        CHECK(35, JPEG_openFile(&b, argv[1], draw) == 1 && JPEG_getWidth(&b) == w);   // a copy that is opened again reads its own bytes
+        a = b;
+        CHECK(36, JPEG_openRAM(&a, jpeg.data(), (int)len, draw) == 1);                 // a COPY opened again leaves the file's bytes to the handle that read them
+        CHECK(37, JPEG_getWidth(&b) == w);
+        JPEG_close(&b);
+    }
     CHECK(21, JPEG_openFile(&imgs[0], "/nonexistent/file.jpg", draw) == 0);
     {                                                                                 // a file that is read and is not a JPEG: the failed open keeps nothing (no close follows it)
         char bad[] = "/tmp/jda_semantics_bad_XXXXXX";

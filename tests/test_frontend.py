@@ -384,3 +384,28 @@ print('child', st)
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "child 0" in r.stdout, r.stdout[-2000:]
+
+
+def test_host_prescan_helpers_can_be_switched_off():
+    """jda_set_host_prescan_helpers(0): every pre-scan on its caller's thread, whatever the flags ask for -- and the same index (the
+    serial pre-scan's own).  Restoring the default brings the helpers back (where the machine has the CPUs for them)."""
+    import jpegdec_amd as J
+    from jpegdec_amd.synth import synth_jpeg
+    lib = J.load_library()
+    jpeg = synth_jpeg(1920, 1080, "4:2:0", seed=3)
+    ref = J.PreparedImage(jpeg, flags=J.PREPARE_SERIAL_PRESCAN)
+    was = lib.jda_set_host_prescan_helpers(0)
+    try:
+        assert was == -1
+        a = J.PreparedImage(jpeg, flags=J.PREPARE_PARALLEL_PRESCAN)
+        assert np.array_equal(a.block_index()[0], ref.block_index()[0]) and np.array_equal(a.block_dc(), ref.block_dc())      # identical, not merely equivalent: the serial pre-scan made it
+        a.close()
+        assert lib.jda_set_host_prescan_helpers(1) == 0
+        b = J.PreparedImage(jpeg, flags=J.PREPARE_PARALLEL_PRESCAN)
+        assert J.index_equivalent(b.block_index()[0], ref.block_index()[0]) and np.array_equal(b.block_dc(), ref.block_dc())
+        b.close()
+    finally:
+        lib.jda_set_host_prescan_helpers(-1)
+    c = J.PreparedImage(jpeg, flags=J.PREPARE_PARALLEL_PRESCAN)
+    assert J.index_equivalent(c.block_index()[0], ref.block_index()[0]) and np.array_equal(c.block_dc(), ref.block_dc())
+    c.close(); ref.close()
