@@ -210,6 +210,53 @@ JDA_HD uint32_t jda_pk_add16_bhi(uint32_t a, uint32_t b)
     return ((a + h) & 0xffffu) | ((a + (h << 16)) & 0xffff0000u);
 #endif
 }
+// a.lo + b.lo, a.lo + b.hi  /  a.hi + b.lo, a.hi + b.hi (v_pk_add_u16 with op_sel on the FIRST operand: one half of it feeds both lanes --
+// one pixel's luma sample is added to its red and green terms in one instruction)
+JDA_HD uint32_t jda_pk_add16_alo(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    const uint32_t l = a & 0xffffu;
+    return ((l + b) & 0xffffu) | (((l << 16) + (b & 0xffff0000u)) & 0xffff0000u);
+#endif
+}
+JDA_HD uint32_t jda_pk_add16_ahi(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    const uint32_t h = a >> 16;
+    return ((h + b) & 0xffffu) | (((h << 16) + (b & 0xffff0000u)) & 0xffff0000u);
+#endif
+}
+// Two bytes of LDS `delta` apart read through an address of their own (ds_read_u8 x 2): the compiler joins neighbouring byte loads
+// into wider loads and spends a VALU instruction per byte on taking them apart again -- the colour stage is bound by its VALU
+// instructions, not by its LDS accesses.  The address is hidden from it (and is loop-invariant where the caller's is).
+JDA_HD void jda_lds_bytes_apart(const uint8_t *p, uint32_t delta, uint32_t &b0, uint32_t &b1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t a = (uint32_t)(uintptr_t)p;
+    asm("" : "+v"(a));
+    const uint8_t __attribute__((address_space(3))) *q = (const uint8_t __attribute__((address_space(3))) *)a;
+    b0 = q[0]; b1 = q[delta];
+#else
+    b0 = p[0]; b1 = p[delta];
+#endif
+}
+// a * b + c on operands that fit in 24 signed bits (v_mad_i32_i24, full rate)
+JDA_HD int32_t jda_mad24(int32_t a, int32_t b, int32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b) + c;
+#else
+    return (int32_t)((uint32_t)a * (uint32_t)b + (uint32_t)c);
+#endif
+}
 // per 16-bit lane: the sign-extended 10-bit field at bits 14:5  (v_pk_lshlrev_b16 1, v_pk_ashrrev_i16 6)
 JDA_HD uint32_t jda_pk_sext10_at5(uint32_t a)
 {
@@ -224,28 +271,29 @@ JDA_HD uint32_t jda_pk_sext10_at5(uint32_t a)
     return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
 #endif
 }
-// per 16-bit lane: the range limit of a sample whose 10-bit field (bits 14:5) is in OFFSET-BINARY form (signed value + 512):
-// shift the field to the top, subtract 384 << 6 with unsigned saturation (v_pk_sub_u16 clamp), shift down by 6 -> max(value +
-// 128, 0) in 0..639, which v_sat_pk_u8_i16 then caps at 255: ucRangeTable's clamp(sext10 + 128) (jpeg.inl:159-222) in three
-// packed instructions + the pack.  The offset (512 << 5 = 16384) is added once per block, to the DC term of the column stage.
-#define JDA_ROW_BIAS 16384
-// -> the limited sample in the HIGH byte of each 16-bit lane (the low byte is junk; the byte permute that assembles a row
-// picks bytes 1 and 3)
-JDA_HD uint32_t jda_pk_limit_offset10(uint32_t a)
+// per 16-bit lane: the range limit of a sample, ucRangeTable[(v >> 5) & 0x3ff] = clamp(sext10(v >> 5) + 128) (jpeg.inl:159-222), in
+// three packed instructions: v * 2 + 0x8000 modulo 2^16 (v_pk_mad_u16) puts the 10-bit field at bits 15:6 in OFFSET-BINARY form
+// (signed value + 512; bit 15 of v, which the table's index drops, falls out), subtracting 384 << 6 with unsigned saturation
+// (v_pk_sub_u16 clamp) leaves max(value + 128, 0) << 6 in 0..639 << 6, and x 4 with unsigned saturation (v_pk_mad_u16 clamp) caps
+// it at 255 in the lane's HIGH byte (the low byte is junk; the byte permute that assembles a row picks bytes 1 and 3).
+// (Rounds 3-5 added the offset -- 512 << 5 -- to the DC term of the column stage instead: a compare and a select per column item
+// that the multiply-add's third operand does for nothing.)
+JDA_HD uint32_t jda_pk_limit10(uint32_t a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef unsigned short jda_us2 __attribute__((ext_vector_type(2)));
-    jda_us2 v = __builtin_bit_cast(jda_us2, a);
-    v = v << 1;                                              // the field to bits 15:6
+    uint32_t r, flip = 0x80008000u, four = 4u;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(flip));      // the field to bits 15:6, its sign bit flipped
+    jda_us2 v = __builtin_bit_cast(jda_us2, r);
     const jda_us2 k = { 24576, 24576 };
     v = __builtin_elementwise_sub_sat(v, k);                // max(value + 128, 0) << 6          (v_pk_sub_u16 clamp)
-    uint32_t r = __builtin_bit_cast(uint32_t, v), four = 4u;
+    r = __builtin_bit_cast(uint32_t, v);
     asm("v_pk_mad_u16 %0, %1, %2, 0 op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(r), "v"(four));   // x 4, saturating: high byte = min(.., 255)
     return r;
 #else
     uint32_t r = 0;
     for (int h = 0; h < 2; h++) {
-        uint32_t x = ((a >> (16 * h)) << 1) & 0xffffu;
+        uint32_t x = (((a >> (16 * h)) << 1) + 0x8000u) & 0xffffu;
         x = x > 24576u ? x - 24576u : 0u;
         x *= 4u;
         if (x > 0xffffu) x = 0xffffu;
@@ -790,11 +838,10 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
     // (o4,o5) = (t3,t2) - (-t4,t5).  Then the 10-bit sign-extended field (the table's wrap: << 1, >> 6
     // arithmetic on 16-bit lanes), + 128, saturate to a byte.
     const uint32_t q76 = jda_pack16(t7, t6), q45 = jda_pack16(-t4, t5);
-    // (the block's samples carry JDA_ROW_BIAS from the column stage: their 10-bit field is in offset-binary form)
-    const uint32_t s01 = jda_pk_limit_offset10(jda_pk_add16(p01, q76));      // samples in bytes 1 and 3
-    const uint32_t s76 = jda_pk_limit_offset10(jda_pk_sub16(p01, q76));
-    const uint32_t s32 = jda_pk_limit_offset10(jda_pk_add16(p32, q45));
-    const uint32_t s45 = jda_pk_limit_offset10(jda_pk_sub16(p32, q45));
+    const uint32_t s01 = jda_pk_limit10(jda_pk_add16(p01, q76));      // samples in bytes 1 and 3
+    const uint32_t s76 = jda_pk_limit10(jda_pk_sub16(p01, q76));
+    const uint32_t s32 = jda_pk_limit10(jda_pk_add16(p32, q45));
+    const uint32_t s45 = jda_pk_limit10(jda_pk_sub16(p32, q45));
     jda_row8 r;
     r.lo = jda_perm(s32, s01, 0x05070301u);          // bytes o0 o1 o2 o3  (s32 = [o3,o2])
     r.hi = jda_perm(s76, s45, 0x05070301u);          // bytes o4 o5 o6 o7  (s45 = [o4,o5], s76 = [o7,o6])
@@ -803,14 +850,12 @@ JDA_HD jda_row8 jda_idct_row(const int32_t s[8])
 
 // Column stage for one column (jpeg.inl:2561-2676): c[r] = raw coefficient of row r, q[r] its
 // prescaled quantiser; results truncated to int16 as the reference stores them back.
-// bias: JDA_ROW_BIAS for column 0, else 0 -- it rides on the DC term through the (linear) even part into every sample of the
-// block's row 0 .. 7 / column 0 input of the row stage, where only bits 14:5 of a result matter (jda_pk_limit_offset10)
 template <bool FAST, bool HALF>
-JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], int32_t out[8], int32_t bias)
+JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], int32_t out[8])
 {
     int32_t t0, t1, t2, t3, t4, t5, t6, t7;
     if (HALF) {                                              // :2561-2601
-        const int32_t a = c[0] * q[0] + bias;
+        const int32_t a = c[0] * q[0];
         const int32_t b = c[2] * q[2];
         const int32_t m = jda_mulc<FAST>(b, 106) >> 8;
         t0 = a + b; t3 = a - b; t1 = a + m; t2 = a - m;
@@ -833,7 +878,7 @@ JDA_HD void jda_idct_col(const int32_t c[8], const int32_t q[8], int32_t out[8],
         }
     } else {                                                         // :2602-2676
         // the reference's zero tests on rows 4..7 only skip work; the arithmetic is identical
-        const int32_t e0 = c[0] * q[0] + bias, e4 = c[4] * q[4];
+        const int32_t e0 = c[0] * q[0], e4 = c[4] * q[4];
         const int32_t t10 = e0 + e4, t11 = e0 - e4;
         const int32_t e2 = c[2] * q[2], e6 = c[6] * q[6];
         const int32_t t13 = e2 + e6;
@@ -1746,10 +1791,10 @@ struct jda_lane_pre {          // (offsets, not pointers: a pointer carried arou
     uint32_t ac_off;          // its AC LUT (short half)
     uint32_t ac_long_off;     // byte offset of the AC LUT's long half in the table blob (global)
     uint32_t quant_off;       // byte offset of its quantiser table in the LDS table copy
-    uint32_t qsel;            // (offset of the quantiser table / 128) << 9: the column work items carry it
+    uint32_t qsel;            // (offset of the quantiser table / 128) << 10: the column work items carry it
     uint32_t chroma;          // the lane's block is a chroma block
     uint32_t eob_sh, eob_code;   // the next symbol is EOB when (next 32 stream bits >> eob_sh) == eob_code (JDA_TB_EOB)
-    uint32_t item_pre;        // qsel | lane << 3: a column work item of the lane's block, less its column
+    uint32_t item_pre;        // qsel | lane << 4: a column work item of the lane's block, less its column (which rides in bits 3:1: a byte offset)
 };
 template <int MODE>
 JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t lane, const uint8_t *tab)
@@ -1766,8 +1811,8 @@ JDA_HD void jda_lane_prepare(jda_lane_pre &LP, const jda_dev_desc &D, uint32_t l
     LP.ac_off = JDA_LT_AC + ac_id * 4096;
     LP.ac_long_off = JDA_TB_AC + (ac_id * 2048 + 1024) * 2;
     LP.quant_off = JDA_LT_QUANT_OFF(q_id);
-    LP.qsel = (JDA_LT_QUANT_OFF(q_id) >> 7) << 9;                 // (the table's offset in units of 128 bytes)
-    LP.item_pre = LP.qsel | (lane << 3);
+    LP.qsel = (JDA_LT_QUANT_OFF(q_id) >> 7) << 10;                // (the table's offset in units of 128 bytes)
+    LP.item_pre = LP.qsel | (lane << 4);
     LP.chroma = b >= (uint32_t)T::NLUMA ? 1u : 0u;
 }
 
@@ -2026,14 +2071,14 @@ JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t
     if (ncols == 0) base = n_all;
     const uint16_t *nib = (const uint16_t *)(tab + JDA_LT_NIB);
     const uint32_t lo = colmask & 15u, hi = colmask >> 4;
-    const uint32_t plist = (uint32_t)nib[lo] | (((uint32_t)nib[hi] + 0x924u) << (3u * jda_popcount8(lo)));
+    const uint32_t plist = ((uint32_t)nib[lo] | (((uint32_t)nib[hi] + 0x924u) << (3u * jda_popcount8(lo)))) << 1;      // (<< 1: a column rides in an item as its byte offset)
     uint16_t *dst = collist + base;
 #pragma unroll
     for (int k = 7; k >= 0; k--) {
 #if !defined(__HIP_DEVICE_COMPILE__)
         if ((uint32_t)k >= ncols) continue;          // (the emulator steps the lanes one after another: no overrun there)
 #endif
-        dst[k] = (uint16_t)(LP.item_pre | ((plist >> (3 * k)) & 7u));
+        dst[k] = (uint16_t)(LP.item_pre | ((plist >> (3 * k)) & 0xeu));
         JDA_STORE_ORDER();                           // the ORDER of the eight stores is what makes the overruns harmless
     }
     const uint32_t cls = !listed ? 4u : (flags == 0 ? 3u : ((flags & 0xf0u) ? 2u : ((flags & 0xfcu) ? 1u : 0u)));
@@ -2062,21 +2107,22 @@ JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t
 
 // ---- P2 ---------------------------------------------------------------------------------------
 template <int MODE, bool FAST, bool HALF>
-JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, const uint8_t *tab, uint8_t *wl)
+JDA_HD void jda_p2_column_item(const jda_dev_desc &D, uint32_t item, const uint8_t *tab, uint8_t *cbase)
 {
     typedef jda_mode_traits<MODE> T;
-    typedef jda_lds_layout<MODE> L;
-    const uint32_t blk = (item >> 3) & 63u, col = item & 7u;      // item = quantiser table << 9 | block << 3 | column
+    // item = (quantiser table's offset / 128) << 10 | block << 4 | column << 1: the column as the byte offset it is in both arrays
+    // (six instructions from the item to the two addresses; eight with the column as a number)
+    const uint32_t blk = (item >> 4) & 63u, col2 = item & 0xeu;
     (void)D; (void)sizeof(T);
-    const int16_t *quant = (const int16_t *)(tab + (item >> 9) * 128u) + col;    // item = (quantiser table offset / 128) << 9 | block << 3 | column
-    int16_t *coef = (int16_t *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE) + col;
+    const int16_t *quant = (const int16_t *)(tab + (((item >> 3) & 0x3f80u) | col2));
+    int16_t *coef = (int16_t *)(cbase + col2 + blk * JDA_COEF_STRIDE);
     int32_t cv[8], qv[8], r[8];
 #pragma unroll
     for (int row = 0; row < 8; row++) {
         if (HALF && row >= 4) { cv[row] = 0; qv[row] = 0; }
         else { cv[row] = coef[row * 8]; qv[row] = quant[row * 8]; }
     }
-    jda_idct_col<FAST, HALF>(cv, qv, r, col == 0 ? JDA_ROW_BIAS : 0);
+    jda_idct_col<FAST, HALF>(cv, qv, r);
 #pragma unroll
     for (int row = 0; row < 8; row++) coef[row * 8] = (int16_t)r[row];
 }
@@ -2088,9 +2134,12 @@ JDA_HD void jda_p2_columns(const jda_dev_desc &D, uint32_t t, const uint8_t *tab
     const uint32_t *cnt = (const uint32_t *)(wl + L::CNT_OFF);
     const uint16_t *collist = (const uint16_t *)(wl + L::COLLIST_OFF);
     const uint32_t n_half = cnt[0], n_full = cnt[1];
-    for (uint32_t i = t; i < n_half; i += JDA_TILE_THREADS) jda_p2_column_item<MODE, FAST, true>(D, collist[i], tab, wl);
-    for (uint32_t i = t; i < n_full; i += JDA_TILE_THREADS)
-        jda_p2_column_item<MODE, FAST, false>(D, collist[n_half + i], tab, wl);
+    uint8_t *const cbase = wl + L::COEF_OFF;
+    // (one number walks the list and ends the loop)
+    const uint16_t *lp = collist + t;
+    for (const uint16_t *const lend = collist + n_half; lp < lend; lp += JDA_TILE_THREADS) jda_p2_column_item<MODE, FAST, true>(D, *lp, tab, cbase);
+    lp = collist + n_half + t;
+    for (const uint16_t *const lend = collist + n_half + n_full; lp < lend; lp += JDA_TILE_THREADS) jda_p2_column_item<MODE, FAST, false>(D, *lp, tab, cbase);
 }
 
 // ---- P3 ---------------------------------------------------------------------------------------
@@ -2098,10 +2147,25 @@ template <int MODE, int RC>
 JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *wl, uint32_t first, uint32_t n_blocks)
 {
     typedef jda_lds_layout<MODE> L;
-    const uint8_t *list = wl + L::ROWLIST_OFF + first;
-    for (uint32_t i = t; i < n_blocks * 8; i += JDA_TILE_THREADS) {
-        const uint32_t blk = list[i >> 3], row = i & 7u;
-        const jda_u64_alias *src = (const jda_u64_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 16);
+    // item i = t + 64 pass is row i & 7 = t & 7 of block list[i >> 3] = list[(t >> 3) + 8 pass]: the row and everything that
+    // depends on it alone are the lane's for the whole tile loop, and ONE number walks the list and ends the loop (the loop used to
+    // carry i, shift it for the list and add the row's offset to the block's address: seven instructions a pass, four now)
+    const uint32_t row = t & 7u;
+    const uint8_t *lp = wl + L::ROWLIST_OFF + first + (t >> 3);
+    const uint8_t *const lend = wl + L::ROWLIST_OFF + first + n_blocks;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (one register the compiler cannot see through: it would keep the constant part of the address apart for the store's offset
+    // field and add it back in front of every two-dword read, whose offset fields are too narrow for it)
+    uint32_t rb32 = JDA_LDS_A32(wl + L::COEF_OFF + row * 16);
+    JDA_OPAQUE(rb32);
+    uint8_t *const rowbase = (uint8_t *)(uint8_t __attribute__((address_space(3))) *)rb32;
+#else
+    uint8_t *const rowbase = wl + L::COEF_OFF + row * 16;
+#endif
+    for (; lp < lend; lp += JDA_TILE_THREADS / 8) {
+        const uint32_t blk = *lp;
+        uint8_t *const rp = rowbase + blk * JDA_COEF_STRIDE;
+        const jda_u64_alias *src = (const jda_u64_alias *)rp;
         int32_t sv[8];
         const uint64_t a = src[0];
         sv[0] = (int16_t)a; sv[1] = (int16_t)(a >> 16); sv[2] = (int16_t)(a >> 32); sv[3] = (int16_t)(a >> 48);
@@ -2114,7 +2178,7 @@ JDA_HD void jda_p3_row_class(uint32_t t, uint8_t *wl, uint32_t first, uint32_t n
         // r/2's int16 data -- safe because the 8 rows of a block are handled by 8 adjacent lanes of one
         // wavefront in the same instruction (all reads precede all writes), and on the sequential host
         // emulator rows are visited in ascending order
-        jda_u32_alias *dst = (jda_u32_alias *)(wl + L::COEF_OFF + blk * JDA_COEF_STRIDE + row * 8);
+        jda_u32_alias *dst = (jda_u32_alias *)(rp - row * 8);
         dst[0] = p.lo; dst[1] = p.hi;
     }
 }
@@ -2210,13 +2274,29 @@ struct jda_chroma2 { uint32_t r, g, b; };
 JDA_HD jda_chroma2 jda_chroma_terms16(uint32_t cb8, uint32_t cr8)
 {
     const int32_t cb = (int32_t)cb8, cr = (int32_t)cr8;
-    jda_chroma2 t;
-    t.r = (uint32_t)(16 * 5742 * cr - 16 * 5742 * 128);
-    t.g = (uint32_t)(-16 * 1409 * cb - 16 * 2925 * cr + 16 * (1409 + 2925) * 128);
-    t.b = (uint32_t)(16 * 7258 * cb - 16 * 7258 * 128);
+    jda_chroma2 t;                                                // (four multiply-adds: left to itself the compiler makes the green term two multiplies and a three-operand add)
+    t.r = (uint32_t)jda_mad24(cr, 16 * 5742, -16 * 5742 * 128);
+    int32_t g = jda_mad24(cr, -16 * 2925, 16 * (1409 + 2925) * 128);
+    JDA_OPAQUE(g);                                                // (.. as it does when it sees both products at once)
+    t.g = (uint32_t)jda_mad24(cb, -16 * 1409, g);
+    t.b = (uint32_t)jda_mad24(cb, 16 * 7258, -16 * 7258 * 128);
     return t;
 }
 JDA_HD uint32_t jda_pack_hi16(uint32_t lo, uint32_t hi) { return jda_perm(hi, lo, 0x07060302u); }   // {hi[31:16], lo[31:16]}
+// Two horizontally adjacent RGB8888 pixels, red and green of a pixel side by side in a word.  ypair = Y0 | Y1 << 16; trg0 / trg1 = pixel
+// 0's / 1's red term in bits 15:0 and green term in bits 31:16 (the same word for both when the pixels share their chroma sample);
+// tb: the blue terms where the caller has them -- BHI: one term in bits 31:16 for both pixels, else pixel 0's in 15:0, pixel 1's in 31:16.
+// A pixel costs four instructions (add + saturate for R|G, half an add + saturate for B, one permute that also sets alpha) where
+// three channel pairs cost four and a half.
+template <bool BHI>
+JDA_HD void jda_rgba_pair_rg(uint32_t ypair, uint32_t trg0, uint32_t trg1, uint32_t tb, uint32_t &px0, uint32_t &px1)
+{
+    const uint32_t rg0 = jda_sat_pk_u8(jda_pk_add16_alo(ypair, trg0));                          // [R0, G0, 0, 0]
+    const uint32_t rg1 = jda_sat_pk_u8(jda_pk_add16_ahi(ypair, trg1));                          // [R1, G1, 0, 0]
+    const uint32_t b2 = jda_sat_pk_u8(BHI ? jda_pk_add16_bhi(ypair, tb) : jda_pk_add16(ypair, tb));   // [B0, B1, 0, 0]
+    px0 = jda_perm(b2, rg0, 0x0d040100u);                                                      // [R0, G0, B0, 0xff]
+    px1 = jda_perm(b2, rg1, 0x0d050100u);                                                      // [R1, G1, B1, 0xff]
+}
 template <int PT>
 JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t)
 {
@@ -2237,29 +2317,6 @@ JDA_HD uint32_t jda_rgb_pixel(uint32_t y8, const jda_chroma &t)
     return v;
 }
 
-// Two horizontally adjacent RGB8888 pixels at once.  ypair = Y0 | Y1 << 16; tr/tg/tb = the (already
-// >> 12) chroma terms of pixel 0 in bits 15:0 and of pixel 1 in bits 31:16.  R,G,B = clamp(Y + term),
-// exactly jpeg.inl:3162-3174 (true 0..255 clamp), two pixels per instruction.
-JDA_HD void jda_rgba_pair(uint32_t ypair, uint32_t tr, uint32_t tg, uint32_t tb, uint32_t &px0, uint32_t &px1)
-{
-    const uint32_t r2 = jda_sat_pk_u8(jda_pk_add16(ypair, tr));   // [R0, R1, 0, 0]
-    const uint32_t g2 = jda_sat_pk_u8(jda_pk_add16(ypair, tg));
-    const uint32_t b2 = jda_sat_pk_u8(jda_pk_add16(ypair, tb));
-    const uint32_t rg = jda_perm(g2, r2, 0x05010400u);            // [R0, G0, R1, G1]
-    px0 = jda_perm(b2, rg, 0x0d040100u);                          // [R0, G0, B0, 0xff]
-    px1 = jda_perm(b2, rg, 0x0d050302u);                          // [R1, G1, B1, 0xff]
-}
-
-// the same with the chroma terms where jda_chroma_terms16 leaves them: in bits 31:16 of their words, for both pixels of the pair
-JDA_HD void jda_rgba_pair_t16(uint32_t ypair, const jda_chroma2 &t, uint32_t &px0, uint32_t &px1)
-{
-    const uint32_t r2 = jda_sat_pk_u8(jda_pk_add16_bhi(ypair, t.r));
-    const uint32_t g2 = jda_sat_pk_u8(jda_pk_add16_bhi(ypair, t.g));
-    const uint32_t b2 = jda_sat_pk_u8(jda_pk_add16_bhi(ypair, t.b));
-    const uint32_t rg = jda_perm(g2, r2, 0x05010400u);
-    px0 = jda_perm(b2, rg, 0x0d040100u);
-    px1 = jda_perm(b2, rg, 0x0d050302u);
-}
 // per 16-bit lane: clamp a signed value to 0..255 (v_pk_max_i16, v_pk_min_i16)
 JDA_HD uint32_t jda_pk_clamp255(uint32_t a)
 {
@@ -2309,7 +2366,7 @@ JDA_HD uint32_t jda_565_pair_t16(uint32_t ypair, const jda_chroma2 &t)
 // yo = the luma bytes (Cb, Cr one and two block slots further), rel as above; co is not used.
 #define JDA_P4_PASSES 5
 #define JDA_P4_PASSES_444 5
-struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES_444], co[JDA_P4_PASSES], rel[JDA_P4_PASSES_444]; };
+struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES_444], co[JDA_P4_PASSES], co1[JDA_P4_PASSES], rel[JDA_P4_PASSES_444]; };   // co1 = co + 1 behind JDA_OPAQUE: the item's second chroma sample through an address of its own (jda_lds_bytes_apart)
 JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, uint32_t pitch, uint32_t bpp)
 {
 #pragma unroll
@@ -2318,6 +2375,8 @@ JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, 
         const uint32_t po = (g >> 2) * plane_stride;
         P.yo[it] = po + (rp >> 2) * (2 * JDA_COEF_STRIDE) + (rp & 3u) * 16 + ((g >> 1) & 1u) * JDA_COEF_STRIDE + (g & 1u) * 4;
         P.co[it] = po + 4 * JDA_COEF_STRIDE + rp * 8 + (g & 3u) * 2;
+        P.co1[it] = P.co[it] + 1u;
+        JDA_OPAQUE(P.co1[it]);
         P.rel[it] = rp * 2u * pitch + g * 4u * bpp;
     }
 }
@@ -2331,7 +2390,7 @@ JDA_HD void jda_p4_precompute_444(jda_p4_pre &P, uint32_t t, uint32_t plane_stri
         P.rel[it] = r * pitch + x4 * bpp;
     }
 #pragma unroll
-    for (int it = 0; it < JDA_P4_PASSES; it++) P.co[it] = 0;
+    for (int it = 0; it < JDA_P4_PASSES; it++) P.co[it] = P.co1[it] = 0;
 }
 
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
@@ -2339,17 +2398,19 @@ JDA_HD void jda_p4_precompute_444(jda_p4_pre &P, uint32_t t, uint32_t plane_stri
 // order so that consecutive threads store consecutive 16-byte groups.
 // the eight pixels of one item: ya / yb = four luma samples of the upper / lower row, cb2 / cr2 = two chroma samples each
 template <int PT>
-JDA_HD void jda_p4_420_item(uint32_t ya, uint32_t yb, uint32_t cb2, uint32_t cr2, uint32_t v0[4], uint32_t v1[4])
+JDA_HD void jda_p4_420_item(uint32_t ya, uint32_t yb, uint32_t cb0, uint32_t cb1, uint32_t cr0, uint32_t cr1, uint32_t v0[4], uint32_t v1[4])
 {
     // (a chroma sample's three terms serve the two pixels of a pair in both rows: they stay in the upper halves of their words, the
-    // packed adds pick them up there -- six byte permutes an item less than copying each into both halves first)
-    const jda_chroma2 d0 = jda_chroma_terms16(cb2 & 255u, cr2 & 255u);
-    const jda_chroma2 d1 = jda_chroma_terms16(cb2 >> 8, cr2 >> 8);
+    // packed adds pick them up there; the four chroma samples come as bytes of their own -- ds_read_u8 -- so nothing is spent on
+    // taking a 16-bit load apart)
+    const jda_chroma2 d0 = jda_chroma_terms16(cb0, cr0);
+    const jda_chroma2 d1 = jda_chroma_terms16(cb1, cr1);
     if (PT == JDA_RGB8888) {
-        jda_rgba_pair_t16(jda_perm(0, ya, 0x0c010c00u), d0, v0[0], v0[1]);
-        jda_rgba_pair_t16(jda_perm(0, ya, 0x0c030c02u), d1, v0[2], v0[3]);
-        jda_rgba_pair_t16(jda_perm(0, yb, 0x0c010c00u), d0, v1[0], v1[1]);
-        jda_rgba_pair_t16(jda_perm(0, yb, 0x0c030c02u), d1, v1[2], v1[3]);
+        const uint32_t rg0 = jda_pack_hi16(d0.r, d0.g), rg1 = jda_pack_hi16(d1.r, d1.g);
+        jda_rgba_pair_rg<true>(jda_perm(0, ya, 0x0c010c00u), rg0, rg0, d0.b, v0[0], v0[1]);
+        jda_rgba_pair_rg<true>(jda_perm(0, ya, 0x0c030c02u), rg1, rg1, d1.b, v0[2], v0[3]);
+        jda_rgba_pair_rg<true>(jda_perm(0, yb, 0x0c010c00u), rg0, rg0, d0.b, v1[0], v1[1]);
+        jda_rgba_pair_rg<true>(jda_perm(0, yb, 0x0c030c02u), rg1, rg1, d1.b, v1[2], v1[3]);
     } else {                                                  // RGB565: v[0], v[1] hold pixel pairs
         v0[0] = jda_565_pair_t16<PT>(jda_perm(0, ya, 0x0c010c00u), d0);
         v0[1] = jda_565_pair_t16<PT>(jda_perm(0, ya, 0x0c030c02u), d1);
@@ -2384,9 +2445,9 @@ JDA_HD void jda_p4_420_full10(const jda_dev_desc &D, const jda_p4_pre &P, const 
 #pragma unroll
     for (int it = 0; it < JDA_P4_PASSES; it++) {
         const uint32_t ya = *(const jda_u32_alias *)(plane_base + P.yo[it]), yb = *(const jda_u32_alias *)(plane_base + P.yo[it] + 8);
-        const uint32_t cb2 = *(const uint16_t *)(plane_base + P.co[it]), cr2 = *(const uint16_t *)(plane_base + P.co[it] + JDA_COEF_STRIDE);
+        const uint8_t *cp = plane_base + P.co[it], *cp1 = plane_base + P.co1[it];      // (two addresses the compiler cannot join: four byte loads, nothing to take apart)
         uint32_t v0[4], v1[4];
-        jda_p4_420_item<PT>(ya, yb, cb2, cr2, v0, v1);
+        jda_p4_420_item<PT>(ya, yb, cp[0], cp1[0], cp[JDA_COEF_STRIDE], cp1[JDA_COEF_STRIDE], v0, v1);
         jda_p4_420_store<PT>(tile, P.rel[it], P.rel[it] + pitch, v0, v1);
     }
 }
@@ -2414,9 +2475,12 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint32_t yo = po + (rp >> 2) * (2 * JDA_COEF_STRIDE) + (rp & 3u) * 16 + ((g >> 1) & 1u) * JDA_COEF_STRIDE + (g & 1u) * 4;
         const uint32_t co = po + 4 * JDA_COEF_STRIDE + rp * 8 + (g & 3u) * 2;
         const uint32_t ya = *(const jda_u32_alias *)(plane_base + yo), yb = *(const jda_u32_alias *)(plane_base + yo + 8);
-        const uint32_t cb2 = *(const uint16_t *)(plane_base + co), cr2 = *(const uint16_t *)(plane_base + co + JDA_COEF_STRIDE);
+        const uint8_t *cp = plane_base + co;
         uint32_t v0[4], v1[4];
-        jda_p4_420_item<PT>(ya, yb, cb2, cr2, v0, v1);
+        uint32_t cb0, cr0, cb1, cr1;
+        jda_lds_bytes_apart(cp, JDA_COEF_STRIDE, cb0, cr0);
+        jda_lds_bytes_apart(cp + 1, JDA_COEF_STRIDE, cb1, cr1);
+        jda_p4_420_item<PT>(ya, yb, cb0, cb1, cr0, cr1, v0, v1);
         if (!CLIP) {                                              // whole groups, 16 / 8 bytes per row
             const uint32_t off = tile_off + jda_umul24(rp, 2 * pitch) + x4 * bpp;
             jda_p4_420_store<PT>(out, off, off + pitch, v0, v1);
@@ -2452,8 +2516,8 @@ JDA_HD void jda_p4_444_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
             jda_chroma2 c[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms16((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
-            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
-            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
+            jda_rgba_pair_rg<false>(jda_perm(0, y, 0x0c010c00u), jda_pack_hi16(c[0].r, c[0].g), jda_pack_hi16(c[1].r, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
+            jda_rgba_pair_rg<false>(jda_perm(0, y, 0x0c030c02u), jda_pack_hi16(c[2].r, c[2].g), jda_pack_hi16(c[3].r, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -2478,8 +2542,8 @@ JDA_HD void jda_p4_444_full21(const jda_dev_desc &D, const jda_p4_pre &P, uint32
             jda_chroma2 c[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) c[j] = jda_chroma_terms16((cb >> (8 * j)) & 255u, (cr >> (8 * j)) & 255u);
-            jda_rgba_pair(jda_perm(0, y, 0x0c010c00u), jda_pack_hi16(c[0].r, c[1].r), jda_pack_hi16(c[0].g, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
-            jda_rgba_pair(jda_perm(0, y, 0x0c030c02u), jda_pack_hi16(c[2].r, c[3].r), jda_pack_hi16(c[2].g, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
+            jda_rgba_pair_rg<false>(jda_perm(0, y, 0x0c010c00u), jda_pack_hi16(c[0].r, c[0].g), jda_pack_hi16(c[1].r, c[1].g), jda_pack_hi16(c[0].b, c[1].b), v[0], v[1]);
+            jda_rgba_pair_rg<false>(jda_perm(0, y, 0x0c030c02u), jda_pack_hi16(c[2].r, c[2].g), jda_pack_hi16(c[3].r, c[3].g), jda_pack_hi16(c[2].b, c[3].b), v[2], v[3]);
             jda_chunk16_alias q;
             q.w[0] = v[0]; q.w[1] = v[1]; q.w[2] = v[2]; q.w[3] = v[3];
             *(jda_chunk16_alias JDA_GLOBAL *)(tile + P.rel[it]) = q;
@@ -2514,10 +2578,15 @@ JDA_HD void jda_p4_422_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint32_t cb2 = *(const uint16_t *)(plane_base + co), cr2 = *(const uint16_t *)(plane_base + co + JDA_COEF_STRIDE);
         uint32_t v[4];
         if (PT == JDA_RGB8888) {
-            const jda_chroma2 d0 = jda_chroma_terms16(cb2 & 255u, cr2 & 255u);
-            const jda_chroma2 d1 = jda_chroma_terms16(cb2 >> 8, cr2 >> 8);
-            jda_rgba_pair_t16(jda_perm(0, y, 0x0c010c00u), d0, v[0], v[1]);
-            jda_rgba_pair_t16(jda_perm(0, y, 0x0c030c02u), d1, v[2], v[3]);
+            const uint8_t *cp = plane_base + co;
+            uint32_t cb0, cr0, cb1, cr1;
+            jda_lds_bytes_apart(cp, JDA_COEF_STRIDE, cb0, cr0);
+            jda_lds_bytes_apart(cp + 1, JDA_COEF_STRIDE, cb1, cr1);
+            const jda_chroma2 d0 = jda_chroma_terms16(cb0, cr0);
+            const jda_chroma2 d1 = jda_chroma_terms16(cb1, cr1);
+            const uint32_t rg0 = jda_pack_hi16(d0.r, d0.g), rg1 = jda_pack_hi16(d1.r, d1.g);
+            jda_rgba_pair_rg<true>(jda_perm(0, y, 0x0c010c00u), rg0, rg0, d0.b, v[0], v[1]);
+            jda_rgba_pair_rg<true>(jda_perm(0, y, 0x0c030c02u), rg1, rg1, d1.b, v[2], v[3]);
         } else {
             const jda_chroma2 d0 = jda_chroma_terms16(cb2 & 255u, cr2 & 255u);
             const jda_chroma2 d1 = jda_chroma_terms16(cb2 >> 8, cr2 >> 8);
@@ -2838,7 +2907,7 @@ JDA_HD void jda_p4_prepare(jda_p4_pre &P, const jda_dev_desc &D, uint32_t t)
     else if (MODE == JDA_MODE_444) jda_p4_precompute_444(P, t, L::PLANE_STRIDE, D.out_pitch, D.pixel_type == JDA_RGB8888 ? 4u : 2u);
     else {
 #pragma unroll
-        for (int it = 0; it < JDA_P4_PASSES; it++) P.yo[it] = P.co[it] = P.rel[it] = 0;
+        for (int it = 0; it < JDA_P4_PASSES; it++) P.yo[it] = P.co[it] = P.co1[it] = P.rel[it] = 0;
     }
 }
 
