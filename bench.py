@@ -705,16 +705,16 @@ def run(args, J, out=sys.stdout):
         # The file names the hash of the kernel sources it was measured at (tools/gpu_profile.sh): with other sources in the tree the
         # figure is stale and the line says null + why.
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
         if (os.path.exists(tp) and args.workload == "metric" and (args.width, args.height, args.subsampling, args.pixel_type, args.options, args.quality)
                 == (4096, 4096, "4:2:0", "rgb8888", 0, 85)):
             tj = json.load(open(tp))
             if tj.get("kernel_sources_sha16") == kernel_sources_sha():
                 traffic = tj["hbm_bytes_per_image"] * n_mine
-                traffic_src = ("profiles/r05_pmc_traffic.json (tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
+                traffic_src = ("profiles/r06_pmc_traffic.json (tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                "correction; measured at kernel sources %s = this tree's)" % tj["kernel_sources_sha16"])
             else:
-                traffic_src = ("stale: profiles/r05_pmc_traffic.json was measured at kernel sources %s, this tree has %s -- rerun tools/gpu_profile.sh"
+                traffic_src = ("stale: profiles/r06_pmc_traffic.json was measured at kernel sources %s, this tree has %s -- rerun tools/gpu_profile.sh"
                                % (tj.get("kernel_sources_sha16"), kernel_sources_sha()))
                 print("bench.py: " + traffic_src, file=sys.stderr)
         line = {

@@ -2,7 +2,7 @@
 # kernel time per batch of the streamed pipeline, nothing overlapped (depth 1): tools/gpu_pipeline_stats.sh [prefix]
 #   rocprofv3 --kernel-trace --stats of tools/pipeline_bench.py --depth 1 for the metric batch (64 x 4096x4096) and for batches of small
 #   images (1024 x 1280x720, 1024 x 1920x1080, 2048 x 640x480) -> gpurun_out/pipe_stats/<prefix>_pipeline_<shape>_kernel_stats_depth1.csv
-prefix=${1:-r05}
+prefix=${1:-r06}
 out=gpurun_out/pipe_stats; mkdir -p $out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for cfg in "4096 4096 64 16" "1280 720 1024 8" "1920 1080 1024 8" "640 480 2048 8"; do

@@ -4,7 +4,7 @@
 #   domains: MI355X_MICROARCH.md), SQ counters -> gpurun_out/<tag>/, and the summaries the judge reads -> profiles/<prefix>_*:
 #   <prefix>_bench_default.json, <prefix>_kernel_stats.csv, <prefix>_pmc_traffic.json (names the hash of the kernel sources it was
 #   measured at: bench.py reports roofline.traffic from it only while the tree still has those sources), <prefix>_sq_counters.txt
-tag=${1:-r05_prof}; prefix=${2:-r05}
+tag=${1:-r06_prof}; prefix=${2:-r06}
 out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python bench.py > $out/bench_default.json 2> $out/bench_default.err

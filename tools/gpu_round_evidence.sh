@@ -1,7 +1,7 @@
 #!/bin/bash
 # the round's pipeline evidence in one call: per-kernel times at depth 1 for four batch shapes, one steady-state period (timeline) of the
 # metric batch and of 1,024 x 1280x720 at depth 4, corrupted streams through the pipeline against the oracle -> gpurun_out/evidence/
-prefix=${1:-r05}
+prefix=${1:-r06}
 out=gpurun_out/evidence; mkdir -p $out
 bash tools/gpu_pipeline_stats.sh $prefix > $out/${prefix}_pipeline_kernel_stats_depth1.txt 2>&1
 cp gpurun_out/pipe_stats/${prefix}_pipeline_*_kernel_stats_depth1.csv $out/ 2>/dev/null
