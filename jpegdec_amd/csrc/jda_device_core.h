@@ -234,18 +234,19 @@ JDA_HD uint32_t jda_pk_add16_ahi(uint32_t a, uint32_t b)
     return ((h + b) & 0xffffu) | (((h << 16) + (b & 0xffff0000u)) & 0xffff0000u);
 #endif
 }
-// Two bytes of LDS `delta` apart read through an address of their own (ds_read_u8 x 2): the compiler joins neighbouring byte loads
-// into wider loads and spends a VALU instruction per byte on taking them apart again -- the colour stage is bound by its VALU
-// instructions, not by its LDS accesses.  The address is hidden from it (and is loop-invariant where the caller's is).
-JDA_HD void jda_lds_bytes_apart(const uint8_t *p, uint32_t delta, uint32_t &b0, uint32_t &b1)
+// Two bytes of LDS `delta` apart, at p + step, read through an address of their own (ds_read_u8 x 2): the compiler joins neighbouring
+// byte loads into wider loads and spends a VALU instruction per byte on taking them apart again -- the colour stage is bound by
+// its VALU instructions more than by its LDS accesses.  The address is made where it is used (one add; asm volatile: a copy kept in
+// a register across the tile loop per pass of the colour stage sent the general kernels' registers to scratch memory).
+JDA_HD void jda_lds_bytes_apart(const uint8_t *p, uint32_t step, uint32_t delta, uint32_t &b0, uint32_t &b1)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t a = (uint32_t)(uintptr_t)p;
-    asm("" : "+v"(a));
+    uint32_t a;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(a) : "v"((uint32_t)(uintptr_t)p), "v"(step));
     const uint8_t __attribute__((address_space(3))) *q = (const uint8_t __attribute__((address_space(3))) *)a;
     b0 = q[0]; b1 = q[delta];
 #else
-    b0 = p[0]; b1 = p[delta];
+    b0 = p[step]; b1 = p[step + delta];
 #endif
 }
 // a * b + c on operands that fit in 24 signed bits (v_mad_i32_i24, full rate)
@@ -2366,7 +2367,7 @@ JDA_HD uint32_t jda_565_pair_t16(uint32_t ypair, const jda_chroma2 &t)
 // yo = the luma bytes (Cb, Cr one and two block slots further), rel as above; co is not used.
 #define JDA_P4_PASSES 5
 #define JDA_P4_PASSES_444 5
-struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES_444], co[JDA_P4_PASSES], co1[JDA_P4_PASSES], rel[JDA_P4_PASSES_444]; };   // co1 = co + 1 behind JDA_OPAQUE: the item's second chroma sample through an address of its own (jda_lds_bytes_apart)
+struct jda_p4_pre { uint32_t yo[JDA_P4_PASSES_444], co[JDA_P4_PASSES], rel[JDA_P4_PASSES_444]; };
 JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, uint32_t pitch, uint32_t bpp)
 {
 #pragma unroll
@@ -2375,8 +2376,6 @@ JDA_HD void jda_p4_precompute(jda_p4_pre &P, uint32_t t, uint32_t plane_stride, 
         const uint32_t po = (g >> 2) * plane_stride;
         P.yo[it] = po + (rp >> 2) * (2 * JDA_COEF_STRIDE) + (rp & 3u) * 16 + ((g >> 1) & 1u) * JDA_COEF_STRIDE + (g & 1u) * 4;
         P.co[it] = po + 4 * JDA_COEF_STRIDE + rp * 8 + (g & 3u) * 2;
-        P.co1[it] = P.co[it] + 1u;
-        JDA_OPAQUE(P.co1[it]);
         P.rel[it] = rp * 2u * pitch + g * 4u * bpp;
     }
 }
@@ -2390,7 +2389,7 @@ JDA_HD void jda_p4_precompute_444(jda_p4_pre &P, uint32_t t, uint32_t plane_stri
         P.rel[it] = r * pitch + x4 * bpp;
     }
 #pragma unroll
-    for (int it = 0; it < JDA_P4_PASSES; it++) P.co[it] = P.co1[it] = 0;
+    for (int it = 0; it < JDA_P4_PASSES; it++) P.co[it] = 0;
 }
 
 // full-size 4:2:0 colour output (JPEGPutMCU22 scalar body, jpeg.inl:4333-4543): a work item is a 4x2
@@ -2445,9 +2444,12 @@ JDA_HD void jda_p4_420_full10(const jda_dev_desc &D, const jda_p4_pre &P, const 
 #pragma unroll
     for (int it = 0; it < JDA_P4_PASSES; it++) {
         const uint32_t ya = *(const jda_u32_alias *)(plane_base + P.yo[it]), yb = *(const jda_u32_alias *)(plane_base + P.yo[it] + 8);
-        const uint8_t *cp = plane_base + P.co[it], *cp1 = plane_base + P.co1[it];      // (two addresses the compiler cannot join: four byte loads, nothing to take apart)
+        const uint8_t *cp = plane_base + P.co[it];
         uint32_t v0[4], v1[4];
-        jda_p4_420_item<PT>(ya, yb, cp[0], cp1[0], cp[JDA_COEF_STRIDE], cp1[JDA_COEF_STRIDE], v0, v1);
+        uint32_t cb0, cr0, cb1, cr1;
+        jda_lds_bytes_apart(cp, 0, JDA_COEF_STRIDE, cb0, cr0);
+        jda_lds_bytes_apart(cp, 1, JDA_COEF_STRIDE, cb1, cr1);
+        jda_p4_420_item<PT>(ya, yb, cb0, cb1, cr0, cr1, v0, v1);
         jda_p4_420_store<PT>(tile, P.rel[it], P.rel[it] + pitch, v0, v1);
     }
 }
@@ -2478,8 +2480,8 @@ JDA_HD void jda_p4_420_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         const uint8_t *cp = plane_base + co;
         uint32_t v0[4], v1[4];
         uint32_t cb0, cr0, cb1, cr1;
-        jda_lds_bytes_apart(cp, JDA_COEF_STRIDE, cb0, cr0);
-        jda_lds_bytes_apart(cp + 1, JDA_COEF_STRIDE, cb1, cr1);
+        jda_lds_bytes_apart(cp, 0, JDA_COEF_STRIDE, cb0, cr0);
+        jda_lds_bytes_apart(cp, 1, JDA_COEF_STRIDE, cb1, cr1);
         jda_p4_420_item<PT>(ya, yb, cb0, cb1, cr0, cr1, v0, v1);
         if (!CLIP) {                                              // whole groups, 16 / 8 bytes per row
             const uint32_t off = tile_off + jda_umul24(rp, 2 * pitch) + x4 * bpp;
@@ -2580,8 +2582,8 @@ JDA_HD void jda_p4_422_full(const jda_dev_desc &D, uint32_t t, const uint8_t *pl
         if (PT == JDA_RGB8888) {
             const uint8_t *cp = plane_base + co;
             uint32_t cb0, cr0, cb1, cr1;
-            jda_lds_bytes_apart(cp, JDA_COEF_STRIDE, cb0, cr0);
-            jda_lds_bytes_apart(cp + 1, JDA_COEF_STRIDE, cb1, cr1);
+            jda_lds_bytes_apart(cp, 0, JDA_COEF_STRIDE, cb0, cr0);
+            jda_lds_bytes_apart(cp, 1, JDA_COEF_STRIDE, cb1, cr1);
             const jda_chroma2 d0 = jda_chroma_terms16(cb0, cr0);
             const jda_chroma2 d1 = jda_chroma_terms16(cb1, cr1);
             const uint32_t rg0 = jda_pack_hi16(d0.r, d0.g), rg1 = jda_pack_hi16(d1.r, d1.g);
@@ -2907,7 +2909,7 @@ JDA_HD void jda_p4_prepare(jda_p4_pre &P, const jda_dev_desc &D, uint32_t t)
     else if (MODE == JDA_MODE_444) jda_p4_precompute_444(P, t, L::PLANE_STRIDE, D.out_pitch, D.pixel_type == JDA_RGB8888 ? 4u : 2u);
     else {
 #pragma unroll
-        for (int it = 0; it < JDA_P4_PASSES; it++) P.yo[it] = P.co[it] = P.co1[it] = P.rel[it] = 0;
+        for (int it = 0; it < JDA_P4_PASSES; it++) P.yo[it] = P.co[it] = P.rel[it] = 0;
     }
 }
 
