@@ -328,8 +328,8 @@ int JPEGDEC::decode(int x, int y, int iOptions)
     if (cropped) {
         const int mw0 = s->info.mcu_w >> shift0, mh0 = s->info.mcu_h >> shift0;
         int x0 = s->info.mcus_x, x1 = 0;
-        for (int x = 0; x < s->info.mcus_x; x++)
-            if (!(x * mw0 < s->crop_x || x * mw0 > s->crop_x + s->crop_w)) { if (x < x0) x0 = x; x1 = x + 1; }
+        for (int mx = 0; mx < s->info.mcus_x; mx++)
+            if (!(mx * mw0 < s->crop_x || mx * mw0 > s->crop_x + s->crop_w)) { if (mx < x0) x0 = mx; x1 = mx + 1; }
         int y0 = 0;
         while (y0 < s->info.mcus_y && y0 * mh0 < s->crop_y) y0++;
         int y1 = (s->crop_y + s->crop_h + s->info.mcu_h - 1) / s->info.mcu_h;
@@ -501,27 +501,27 @@ int JPEGDEC::decode(int x, int y, int iOptions)
         const bool wrap = shift != 0 || (pt == EIGHT_BIT_GRAYSCALE && s->info.mcu_w == 8) || s->info.subsample == 0x21 || s->info.subsample == 0x12;
         const int pitch_px = s->crop_w;
         int x0 = 0, x1 = -1;
-        for (int x = 0; x < s->info.mcus_x; x++) {
-            if (x * mw < s->crop_x || x * mw > s->crop_x + s->crop_w) continue;
-            if (x1 < 0) x0 = x;
-            x1 = x;
+        for (int mx = 0; mx < s->info.mcus_x; mx++) {
+            if (mx * mw < s->crop_x || mx * mw > s->crop_x + s->crop_w) continue;
+            if (x1 < 0) x0 = mx;
+            x1 = mx;
         }
         const int strip_px = x1 < 0 ? 0 : (x1 - x0 + 1) * mw;
         const int main_px = strip_px < pitch_px ? strip_px : pitch_px;
         int over_px = wrap ? strip_px - main_px : 0;
         if (over_px > pitch_px) over_px = pitch_px;
         long last_row = -1;
-        for (int y = 0; y < rows_mcu; y++) if (y * mh >= s->crop_y) last_row = (long)y * mh - s->crop_y + mh - 1;
+        for (int my = 0; my < rows_mcu; my++) if (my * mh >= s->crop_y) last_row = (long)my * mh - s->crop_y + mh - 1;
         uint8_t *fb0 = (uint8_t *)s->framebuffer;
-        for (int y = 0; y < rows_mcu; y++) {
-            if (y * mh < s->crop_y) continue;                    // bSkipRow, :5111
-            const long ty = (long)y * mh - s->crop_y;
+        for (int my = 0; my < rows_mcu; my++) {
+            if (my * mh < s->crop_y) continue;                   // bSkipRow, :5111
+            const long ty = (long)my * mh - s->crop_y;
             // 1-byte pixels: the row start is computed in 16-bit units, usPixels += ty*iPitch/2 (:5118-5119),
             // so an odd ty*iPitch starts one byte early
             uint8_t *fb = fb0 - ((bpp == 1) ? ((ty * pitch_px) & 1) : 0);
             for (int pass = 0; pass < 2; pass++)
                 for (int rr = 0; rr < mh; rr++) {
-                    const uint8_t *src = canvas + ((size_t)(y * mh + rr) * cw + (size_t)x0 * mw) * bpp;
+                    const uint8_t *src = canvas + ((size_t)(my * mh + rr) * cw + (size_t)x0 * mw) * bpp;
                     if (pass == 0) memcpy(fb + (size_t)(ty + rr) * pitch_px * bpp, src, (size_t)main_px * bpp);
                     else if (over_px > 0 && ty + rr + 1 <= last_row)
                         memcpy(fb + (size_t)(ty + rr + 1) * pitch_px * bpp, src + (size_t)main_px * bpp, (size_t)over_px * bpp);
