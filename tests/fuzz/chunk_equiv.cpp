@@ -9,12 +9,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "jpegdec_amd.h"
 
 extern uint32_t jda_test_chunk_bytes;            // jda_frontend.cpp under JDA_TEST_CHUNK_BYTES_HOOK (0: the product's rule)
 extern uint32_t jda_test_chunk_taken;            // counts the images host_prescan_chunks indexed
+extern std::atomic<int> jda_test_throw_countdown;   // the n-th allocation point a pre-scan worker passes throws std::bad_alloc (0: never)
 extern "C" int jda_host_prescan_threads(void);   // the caller + the helper threads (1: a machine with fewer than four CPUs -- nothing runs in chunks there)
 
 static uint32_t rng_state = 1;
@@ -80,6 +82,31 @@ int main(int argc, char **argv)
             }
         }
     }
+    // an allocation that fails inside a job of the helper pool -- on the caller's thread or on a helper's, early or late in the walk:
+    // the job is closed, nobody is left inside it, and the image comes out as the serial pre-scan makes it (RstPool::run's try / catch)
+    long thrown = 0;
+    for (int fi = 3; fi < argc && fi < 9; fi++) {
+        FILE *f = fopen(argv[fi], "rb");
+        if (!f) return 2;
+        std::vector<uint8_t> base;
+        fseek(f, 0, SEEK_END); base.resize((size_t)ftell(f)); fseek(f, 0, SEEK_SET);
+        if (fread(base.data(), 1, base.size(), f) != base.size()) return 2;
+        fclose(f);
+        for (uint32_t cs : { 1024u, 4096u }) {
+            jda_test_chunk_bytes = cs;
+            for (int at : { 1, 2, 7, 40, 300, 2000, 9000 }) {
+                jda_test_throw_countdown.store(at);
+                const bool ok = same(base, 0, argv[fi]);
+                if (jda_test_throw_countdown.load() <= 0) thrown++;      // (the point was reached: somebody threw)
+                jda_test_throw_countdown.store(0);
+                if (!ok) { fprintf(stderr, "chunk_equiv: after a thrown allocation (point %d)\n", at); return 1; }
+                if (!same(base, 0, argv[fi])) return 1;                  // .. and the pool works again afterwards
+                checked += 2;
+            }
+        }
+    }
+    if (jda_host_prescan_threads() > 1 && thrown == 0) { fprintf(stderr, "chunk_equiv: no allocation point was ever reached\n"); return 1; }
+    printf("chunk_equiv: %ld allocation failures injected and survived\n", thrown);
     printf("chunk_equiv: %ld comparisons, %u images indexed by the chunk-parallel pre-scan on %d threads\n", checked, jda_test_chunk_taken, jda_host_prescan_threads());
     return 0;
 }

@@ -237,6 +237,13 @@ def test_chunk_parallel_prescan_at_chunk_sizes_no_thread_count_produces():
     words = p.stdout.strip().split()
     taken, threads = int(words[-12]), int(words[-2])
     assert taken > 1500 or threads == 1, p.stdout  # (the chunk-parallel pre-scan really made most of them -- where the machine has CPUs for helper threads)
+    # an allocation that fails inside a job of the helper pool (std::bad_alloc thrown at the n-th allocation point, on whatever thread gets
+    # there): the job ends like one that gave up -- same index as the serial pre-scan's, the pool usable afterwards.  Streams without
+    # restart markers above (the chunk walkers), with them here (the interval walkers)
+    assert "allocation failures injected and survived" in p.stdout and (threads == 1 or int(p.stdout.split("chunk_equiv: ")[-2].split()[0]) > 20), p.stdout
+    q = subprocess.run([os.path.join(root, "tests", "fuzz", "chunk_equiv"), "0", "9", "c420_640x368_rstrow.jpg", "c444_384x192_q100_rst7.jpg", "ref/tulips.jpg"],
+                       cwd=os.path.join(root, "tests", "golden"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert q.returncode == 0 and "allocation failures injected and survived" in q.stdout, q.stdout[-3000:]
 
 
 def test_interval_parallel_prescan_under_thread_sanitizer():
