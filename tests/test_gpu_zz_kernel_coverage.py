@@ -123,3 +123,26 @@ def test_every_kernel_of_the_code_object_is_launched(gpu_ctx, oracle, tmp_path):
         f.write("%d of %d kernels launched\n" % (len(kernels) - len(missing), len(kernels)))
     assert not unknown, unknown
     assert not missing, "kernels no test reaches: %s" % missing
+
+
+def test_launch_count_report_truncates_at_whole_lines(gpu_ctx):
+    """jda_kernel_launch_counts into a buffer that is too small: whole lines only, none behind the first that did not fit, and the string
+    ends where its content ends (the bytes behind it are the caller's, untouched); the return value is what the whole report needs."""
+    import ctypes as C
+    import jpegdec_amd as J
+    from jpegdec_amd.synth import synth_jpeg
+    rc, _, _ = J.decode_to_host(gpu_ctx, synth_jpeg(64, 64, "4:2:0", seed=1), J.RGB8888, 0)      # (at least one kernel has been launched)
+    assert rc == 0
+    lib = J.load_library()
+    need = lib.jda_kernel_launch_counts(None, 0)
+    full = C.create_string_buffer(need)
+    assert lib.jda_kernel_launch_counts(full, need) == need
+    lines = full.value.decode().splitlines(keepends=True)
+    assert lines and len(full.value) == need - 1 and all(ln.endswith("\n") and ln.rpartition(" ")[2].strip().isdigit() for ln in lines)
+    for cap in (1, 2, len(lines[0]), len(lines[0]) + 1, need // 2, need - 1):
+        buf = C.create_string_buffer(b"\x55" * (cap + 8), cap + 8)
+        assert lib.jda_kernel_launch_counts(buf, cap) == need
+        got = buf.raw[:cap].split(b"\0", 1)[0].decode()
+        assert b"\0" in buf.raw[:cap] and buf.raw[cap:] == b"\x55" * 8, cap
+        assert full.value.decode().startswith(got) and (got == "" or got.endswith("\n")), (cap, got[-80:])
+        assert buf.raw[len(got) + 1:cap] == b"\x55" * (cap - len(got) - 1), cap      # nothing written behind the terminator
