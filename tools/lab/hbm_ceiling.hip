@@ -49,6 +49,34 @@ __global__ void tiles(uint8_t *out, int W, int H, int n_img, int tiles_total)
         }
     }
 }
+// the same stores with arithmetic between them: every wavefront does `work` dependent multiply-adds per tile (its four wavefronts a SIMD keep
+// the VALU port busy as the decode kernel's do) and either waits for a tile's write acknowledgements before it goes on (WAIT: what
+// sharing vmcnt with its prefetch loads forces on the decode kernel once a tile) or never waits for them
+template <bool WAIT>
+__global__ void tiles_busy(uint8_t *out, int W, int H, int n_img, int tiles_total, int work, uint32_t *sink)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const int tpr = W / 160, tpi = tpr * (H / 16);
+    const int per_wg = (tiles_total + gridDim.x - 1) / gridDim.x;
+    const int t0 = blockIdx.x * per_wg, t1 = min(t0 + per_wg, tiles_total);
+    const size_t pitch = (size_t)W * 4;
+    uint32_t acc = lane;
+    for (int t = t0 + wave; t < t1; t += waves) {
+        for (int k = 0; k < work; k++) acc = acc * 1664525u + 1013904223u;          // (a quarter-rate multiply and an add a step)
+        const uint4 v = make_uint4(acc, wave, 3, 4);
+        const int img = t / tpi, r = t - img * tpi, ty = r / tpr, tx = r - ty * tpr;
+        uint8_t *tile = out + (size_t)img * pitch * H + (size_t)ty * 16 * pitch + (size_t)tx * 640;
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int i = lane + 64 * it, rp = i / 40, g = i - rp * 40;
+            uint8_t *d = tile + (size_t)rp * 2 * pitch + g * 16;
+            *(uint4 *)d = v;
+            *(uint4 *)(d + pitch) = v;
+        }
+        if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
 int main()
 {
     const int W = 4096, H = 4096, N = 64;
@@ -77,6 +105,13 @@ int main()
     const int tiles_total = N * (W / 160) * (H / 16);      // (25 whole tiles a row: the last 96 columns are left out)
     run("decode-kernel store pattern 256 x 1024", [&]() { hipLaunchKernelGGL(tiles, dim3(256), dim3(1024), 0, 0, a, W, H, N, tiles_total); }, (double)tiles_total * 160 * 16 * 4);
     run("decode-kernel store pattern 512 x 512", [&]() { hipLaunchKernelGGL(tiles, dim3(512), dim3(512), 0, 0, a, W, H, N, tiles_total); }, (double)tiles_total * 160 * 16 * 4);
+    for (int work : {0, 300, 500, 600, 700}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "stores + %d steps a tile, acks waited for", work);
+        run(nm, [&]() { hipLaunchKernelGGL(tiles_busy<true>, dim3(256), dim3(1024), 0, 0, a, W, H, N, tiles_total, work, sink); }, (double)tiles_total * 160 * 16 * 4);
+        snprintf(nm, sizeof nm, "stores + %d steps a tile, never waited for", work);
+        run(nm, [&]() { hipLaunchKernelGGL(tiles_busy<false>, dim3(256), dim3(1024), 0, 0, a, W, H, N, tiles_total, work, sink); }, (double)tiles_total * 160 * 16 * 4);
+    }
     CK(hipMemsetAsync(a, 0, bytes, 0));
     hipEventRecord(e0, 0); for (int i = 0; i < 5; i++) hipMemsetAsync(a, 0, bytes, 0); hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
