@@ -2100,8 +2100,8 @@ JDA_HD void jda_p1_lists(const jda_dev_desc &D, const jda_lane_pre &LP, uint32_t
         // not fill a pass (eight rows each, eight blocks a pass) fit into the idle lanes of class 2's last pass, they move over: the
         // list is class 0 | 1 | 2 | DC-only, the border between 1 and 2 shifts, and class 1 runs one pass less.  (The other
         // variants round differently: nothing else may move.)
-        const uint32_t r1 = n1 & 7u, slack2 = (8u - (n2 & 7u)) & 7u;
-        const uint32_t k = (r1 != 0u && r1 <= slack2) ? r1 : 0u;
+        const uint32_t rem1 = n1 & 7u, slack2 = (8u - (n2 & 7u)) & 7u;
+        const uint32_t k = (rem1 != 0u && rem1 <= slack2) ? rem1 : 0u;
         cnt[2] = n0; cnt[3] = n1 - k; cnt[4] = n2 + k; cnt[5] = n3;
     }
 }

@@ -88,8 +88,11 @@ __device__ unsigned long long *g_jda_wgtrace = nullptr;
 #define JDA_TRACE(slot) do { if (trace && lane == 0 && wave < 4) trace[(blockIdx.x / JDA_TRACE_STRIDE * 4 + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 
 // the same inside the persistent kernel: the second tile a traced workgroup decodes (steady state)
+#ifndef JDA_TRACE_ITER
+#define JDA_TRACE_ITER 1        // which tile of a traced wavefront is stamped (1: its second; 60: steady state, the memory system saturated)
+#endif
 #ifdef JDA_PHASE_TRACE      // (make lib EXTRA=-DJDA_PHASE_TRACE; the stamps cost SGPRs, so they are not in the product build)
-#define JDA_PTRACE(slot) do { if (trace && iter == 1 && lane == 0 && wave < 4) trace[(blockIdx.x / JDA_TRACE_STRIDE * 4 + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define JDA_PTRACE(slot) do { if (trace && iter == JDA_TRACE_ITER && lane == 0 && wave < 4) trace[(blockIdx.x / JDA_TRACE_STRIDE * 4 + wave) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define JDA_PTRACE(slot) ((void)0)
 #endif
