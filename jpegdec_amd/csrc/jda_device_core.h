@@ -339,6 +339,14 @@ JDA_HD uint32_t jda_udot4(uint32_t a, uint32_t b)
     return r;
 #endif
 }
+JDA_HD uint32_t jda_udot4_acc(uint32_t a, uint32_t b, uint32_t c)      // a . b + c (bytes, unsigned)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    return jda_udot4(a, b) + c;
+#endif
+}
 JDA_HD uint32_t jda_dup16(int32_t v) { return jda_perm(0, (uint32_t)v, 0x01000100u); }        // low half in both halves
 JDA_HD uint32_t jda_pack16(int32_t lo, int32_t hi) { return jda_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
@@ -2647,6 +2655,16 @@ JDA_HD void jda_p4_gray8_full(const jda_dev_desc &D, uint32_t t, const uint8_t *
 // two source rows (16 bytes) -> 4 pixels, the sums two at a time in the halves of a word; items are dealt row-major so
 // that consecutive lanes store consecutive dwords.
 JDA_HD uint32_t jda_pair_sums(uint32_t v) { return (v & 0x00ff00ffu) + ((v >> 8) & 0x00ff00ffu); }       // [b0 + b1, b2 + b3] as 16-bit halves
+// four output pixels of the half-size gray image from two source rows of eight samples (a0 a1 / b0 b1): (2x2 sum + 2) >> 2 each.
+// A 2x2 sum is two byte dot products with ones in two places (the second accumulates onto the first, which starts at 2); the four
+// sums are shifted two at a time and their bytes picked by one permute (13 instructions where masks and adds take 21).
+JDA_HD uint32_t jda_half_gray4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1)
+{
+    const uint32_t lo = 0x00000101u, hi = 0x01010000u;
+    const uint32_t s0 = jda_udot4_acc(b0, lo, jda_udot4_acc(a0, lo, 2u)), s1 = jda_udot4_acc(b0, hi, jda_udot4_acc(a0, hi, 2u));
+    const uint32_t s2 = jda_udot4_acc(b1, lo, jda_udot4_acc(a1, lo, 2u)), s3 = jda_udot4_acc(b1, hi, jda_udot4_acc(a1, hi, 2u));
+    return jda_perm(((s3 << 16) | s2) >> 2, ((s1 << 16) | s0) >> 2, 0x06040200u);      // (sums <= 1022: the shifted halves are the bytes)
+}
 template <int MODE, bool CLIP>
 JDA_HD void jda_p4_gray8_half(const jda_dev_desc &D, uint32_t t, const uint8_t *plane_base,
                               uint32_t plane_stride, uint32_t tile_w, uint32_t x_base, uint32_t y_base)
@@ -2663,9 +2681,7 @@ JDA_HD void jda_p4_gray8_half(const jda_dev_desc &D, uint32_t t, const uint8_t *
         uint8_t JDA_GLOBAL *dst = out + tile_off + t * 4u;
 #pragma unroll
         for (uint32_t r = 0; r < 4; r++) {
-            const uint32_t s01 = jda_pair_sums(src[4 * r]) + jda_pair_sums(src[4 * r + 2]) + 0x00020002u;
-            const uint32_t s23 = jda_pair_sums(src[4 * r + 1]) + jda_pair_sums(src[4 * r + 3]) + 0x00020002u;
-            *(jda_u32_alias JDA_GLOBAL *)(dst + jda_umul24(r, pitch)) = jda_perm(s23 >> 2, s01 >> 2, 0x06040200u);
+            *(jda_u32_alias JDA_GLOBAL *)(dst + jda_umul24(r, pitch)) = jda_half_gray4(src[4 * r], src[4 * r + 1], src[4 * r + 2], src[4 * r + 3]);
         }
         return;
     }
@@ -2674,9 +2690,7 @@ JDA_HD void jda_p4_gray8_half(const jda_dev_desc &D, uint32_t t, const uint8_t *
         const uint32_t m = nbx == 2 ? (c >> 1) : c, bxq = nbx == 2 ? (c & 1u) : 0u;
         const uint32_t q = (r >> 2) * nbx + bxq;                  // luma block inside the MCU
         const jda_u32_alias *src = (const jda_u32_alias *)(plane_base + jda_umul24(m, plane_stride) + q * JDA_COEF_STRIDE + (r & 3u) * 16);
-        const uint32_t s01 = jda_pair_sums(src[0]) + jda_pair_sums(src[2]) + 0x00020002u;       // pixels 0, 1: two rows' pair sums + 2
-        const uint32_t s23 = jda_pair_sums(src[1]) + jda_pair_sums(src[3]) + 0x00020002u;       // pixels 2, 3
-        const uint32_t v = jda_perm(s23 >> 2, s01 >> 2, 0x06040200u);                          // (sums <= 1022: the shifted halves are the bytes)
+        const uint32_t v = jda_half_gray4(src[0], src[1], src[2], src[3]);
         const uint32_t X = x_base + c * 4, Y = y_base + r;
         if (!CLIP) *(jda_u32_alias JDA_GLOBAL *)(out + tile_off + jda_umul24(r, pitch) + c * 4) = v;
         else {
